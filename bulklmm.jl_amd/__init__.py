@@ -1,0 +1,13 @@
+"""bulklmm.jl_amd -- MI355X-native drop-in for the bulkscan hot path of senresearch/BulkLMM.jl.
+
+Import name: `bulklmm_jl_amd` (via the shim at the repo root; the directory name contains a dot).
+Everything is computed by libbulklmm_hip.so (HIP, gfx950); importing fails loudly if it is missing."""
+from . import _lib
+from ._lib import build, load, LIB_PATH, EXPORTS
+from .api import (BulkLMMError, Context, default_context, calcKinship, bulkscan, bulkscan_null, bulkscan_null_grid,
+                  bulkscan_alt_grid, scan, transform_rotation, fitlmm_bulk, null_loglik_grid, weighted_liteqtl,
+                  liteqtl_given_h2, bulkscan_dev, lod2log10p)
+
+__all__ = ["BulkLMMError", "Context", "default_context", "calcKinship", "bulkscan", "bulkscan_null", "bulkscan_null_grid",
+           "bulkscan_alt_grid", "scan", "transform_rotation", "fitlmm_bulk", "null_loglik_grid", "weighted_liteqtl",
+           "liteqtl_given_h2", "bulkscan_dev", "lod2log10p", "build", "load", "LIB_PATH", "EXPORTS"]

@@ -1,0 +1,103 @@
+"""ctypes binding of libbulklmm_hip.so (include/bulklmm_hip.h).
+
+There is no CPU fallback: if the HIP library is missing or cannot be loaded, importing this module
+raises.  `build()` compiles it in-tree with hipcc for gfx950 (works without a GPU)."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(_HERE, "csrc")
+LIB_PATH = os.path.join(CSRC, "libbulklmm_hip.so")
+
+# every symbol include/bulklmm_hip.h declares
+EXPORTS = [
+    "blmm_version", "blmm_device_count", "blmm_create", "blmm_destroy", "blmm_last_error", "blmm_err_string",
+    "blmm_set_stream", "blmm_set_timing", "blmm_read_timings", "blmm_synchronize", "blmm_default_opts",
+    "blmm_kinship", "blmm_kinship_dev", "blmm_bulkscan", "blmm_bulkscan_dev", "blmm_scan_perms",
+    "blmm_scan_perms_dev", "blmm_rotate", "blmm_null_h2_brent", "blmm_null_loglik_grid",
+    "blmm_weighted_liteqtl", "blmm_liteqtl_given_h2",
+]
+
+BLMM_NULL_EXACT, BLMM_NULL_GRID, BLMM_ALT_GRID = 0, 1, 2
+BLMM_EIGEN, BLMM_SVD = 0, 1
+BLMM_COMPAT_ALT_COUNTER = 1
+
+ERR_ZERO_NORM_MSG = "Dividing by zeros: the input vector can not contain any zeros!"
+
+
+class blmm_opts(C.Structure):
+    _fields_ = [("method", C.c_int32), ("reml", C.c_int32), ("add_intercept", C.c_int32), ("decomp_scheme", C.c_int32),
+                ("optim_interval", C.c_int32), ("compat_flags", C.c_int32), ("prior_variance", C.c_double),
+                ("prior_sample_size", C.c_double)]
+
+
+class blmm_status(C.Structure):
+    _fields_ = [("n_neg_eig", C.c_int64), ("n_nonpos_weight", C.c_int64), ("n_zero_norm", C.c_int64),
+                ("n_nan_lod", C.c_int64), ("n_brent_maxiter", C.c_int64), ("jacobi_sweeps", C.c_int64),
+                ("t_eigen_ms", C.c_double), ("t_rotate_ms", C.c_double), ("t_h2_ms", C.c_double),
+                ("t_prep_ms", C.c_double), ("t_scan_ms", C.c_double), ("t_total_ms", C.c_double)]
+
+
+def build(force: bool = False) -> str:
+    """Compile libbulklmm_hip.so in-tree (hipcc --offload-arch=gfx950).  Returns the library path."""
+    srcs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".h"))]
+    srcs.append(os.path.join(_HERE, "..", "include", "bulklmm_hip.h"))
+    if not force and os.path.exists(LIB_PATH):
+        lib_m = os.path.getmtime(LIB_PATH)
+        if all(os.path.getmtime(s) <= lib_m for s in srcs if os.path.exists(s)):
+            return LIB_PATH
+    r = subprocess.run(["make", "-C", CSRC, "-j4"], capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("building libbulklmm_hip.so failed:\n" + r.stdout[-4000:] + r.stderr[-4000:])
+    return LIB_PATH
+
+
+_lib = None
+
+
+def load():
+    """dlopen the library and declare prototypes.  Raises OSError if it is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise OSError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                      "(there is no CPU fallback for the bulkscan path)")
+    lib = C.CDLL(LIB_PATH)
+    dp, ip = C.POINTER(C.c_double), C.POINTER(C.c_int32)
+    i64, vp = C.c_int64, C.c_void_p
+    op, sp = C.POINTER(blmm_opts), C.POINTER(blmm_status)
+    lib.blmm_version.restype = C.c_int
+    lib.blmm_device_count.restype = C.c_int
+    lib.blmm_create.argtypes = [C.c_int, vp, C.POINTER(vp)]
+    lib.blmm_destroy.argtypes = [vp]
+    lib.blmm_destroy.restype = None
+    lib.blmm_last_error.argtypes = [vp]
+    lib.blmm_last_error.restype = C.c_char_p
+    lib.blmm_err_string.argtypes = [C.c_int]
+    lib.blmm_err_string.restype = C.c_char_p
+    lib.blmm_set_stream.argtypes = [vp, vp]
+    lib.blmm_set_timing.argtypes = [vp, C.c_int]
+    lib.blmm_synchronize.argtypes = [vp]
+    lib.blmm_read_timings.argtypes = [vp, dp, C.POINTER(C.c_int64)]
+    lib.blmm_default_opts.argtypes = [op]
+    lib.blmm_default_opts.restype = None
+    # data pointers are passed as void* so that both host (numpy) and device (torch data_ptr) addresses fit
+    lib.blmm_kinship.argtypes = [vp, vp, i64, i64, vp]
+    lib.blmm_kinship_dev.argtypes = [vp, vp, i64, i64, vp]
+    lib.blmm_bulkscan.argtypes = [vp, op, vp, i64, i64, vp, i64, vp, i64, vp, vp, vp, i64, vp, vp, sp]
+    lib.blmm_bulkscan_dev.argtypes = [vp, op, vp, i64, i64, vp, i64, vp, i64, vp, vp, vp, i64, vp, i64, vp, sp]
+    lib.blmm_scan_perms.argtypes = [vp, op, vp, i64, vp, i64, vp, i64, vp, vp, i64, C.c_uint64, vp, vp, vp, vp, sp]
+    lib.blmm_scan_perms_dev.argtypes = [vp, op, vp, i64, vp, i64, vp, i64, vp, vp, i64, C.c_uint64, vp, vp, vp, vp, sp]
+    lib.blmm_rotate.argtypes = [vp, op, vp, i64, i64, vp, i64, vp, i64, vp, vp, vp, vp, sp]
+    lib.blmm_null_h2_brent.argtypes = [vp, op, vp, i64, i64, vp, i64, vp, vp, vp, vp, sp]
+    lib.blmm_null_loglik_grid.argtypes = [vp, op, vp, i64, i64, vp, i64, vp, vp, i64, vp, sp]
+    lib.blmm_weighted_liteqtl.argtypes = [vp, vp, i64, i64, vp, i64, i64, vp, C.c_double, vp, sp]
+    lib.blmm_liteqtl_given_h2.argtypes = [vp, vp, i64, i64, vp, i64, i64, vp, vp, vp, sp]
+    for name in EXPORTS:
+        getattr(lib, name)  # AttributeError if a declared symbol is not exported
+    _lib = lib
+    return lib

@@ -1,0 +1,417 @@
+"""Host-side mirror of BulkLMM.jl's API for the bulkscan hot path, over the C ABI of libbulklmm_hip.so.
+
+Same names, argument meaning, defaults, return field names and error strings as the reference
+(src/bulkscan.jl:81-162,188-314,321-397,428-526; src/scan.jl:94-271,485-557; src/kinship.jl:4-14;
+src/transform_helpers.jl:1-54; src/bulkscan_helpers.jl:175-201), so the parity tests read like the
+reference's own tests.  All arithmetic happens on the GPU; there is no CPU fallback."""
+from __future__ import annotations
+
+import ctypes as C
+import warnings
+from typing import NamedTuple, Optional
+
+import numpy as np
+
+from . import _lib as L
+
+
+class BulkLMMError(Exception):
+    """Julia ErrorException stand-in; `.msg` is the reference's message, `.code` the blmm_err."""
+
+    def __init__(self, msg: str, code: int = -1):
+        super().__init__(msg)
+        self.msg = msg
+        self.code = code
+
+
+class Context:
+    """One GPU.  Not thread-safe (include/bulklmm_hip.h)."""
+
+    def __init__(self, device: int = 0, stream: Optional[int] = None):
+        self.lib = L.load()
+        h = C.c_void_p()
+        rc = self.lib.blmm_create(int(device), C.c_void_p(stream) if stream else None, C.byref(h))
+        if rc != 0:
+            raise BulkLMMError(self.lib.blmm_err_string(rc).decode(), rc)
+        self.h = h
+        self.device = device
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.blmm_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def check(self, rc: int):
+        if rc != 0:
+            msg = self.lib.blmm_last_error(self.h).decode() or self.lib.blmm_err_string(rc).decode()
+            raise BulkLMMError(msg, rc)
+
+    def set_timing(self, on: bool):
+        self.check(self.lib.blmm_set_timing(self.h, 1 if on else 0))
+
+    def read_timings(self):
+        """Sum of per-phase device times (ms) over the calls since the last read, and their count."""
+        sums = (C.c_double * 6)()
+        cnt = C.c_int64(0)
+        self.check(self.lib.blmm_read_timings(self.h, sums, C.byref(cnt)))
+        names = ("eigen", "rotate", "h2", "prep", "scan", "total")
+        return {k: float(v) for k, v in zip(names, sums)}, int(cnt.value)
+
+    def set_stream(self, stream: Optional[int]):
+        self.check(self.lib.blmm_set_stream(self.h, C.c_void_p(stream) if stream else None))
+
+    def synchronize(self):
+        self.check(self.lib.blmm_synchronize(self.h))
+
+
+_default_ctx: Optional[Context] = None
+
+
+def default_context() -> Context:
+    global _default_ctx
+    if _default_ctx is None:
+        _default_ctx = Context(0)
+    return _default_ctx
+
+
+def _F(a, ndim=2) -> np.ndarray:
+    a = np.asarray(a, dtype=np.float64)
+    if ndim == 2 and a.ndim == 1:
+        a = a.reshape(-1, 1)
+    return np.asfortranarray(a)
+
+
+def _p(a: Optional[np.ndarray]):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def _opts(method=L.BLMM_NULL_GRID, reml=False, addIntercept=True, decomp_scheme="eigen", optim_interval=1,
+          prior_variance=1.0, prior_sample_size=0.0, compat_flags=0) -> L.blmm_opts:
+    if decomp_scheme == "eigen":
+        d = L.BLMM_EIGEN
+    elif decomp_scheme == "svd":
+        d = L.BLMM_SVD
+    else:
+        d = 99  # the library raises the reference's message (src/transform_helpers.jl:51)
+    return L.blmm_opts(int(method), int(bool(reml)), int(bool(addIntercept)), d, int(optim_interval), int(compat_flags),
+                       float(prior_variance), float(prior_sample_size))
+
+
+def _raise_status(st: L.blmm_status):
+    """Re-issue the reference's warnings / errors from the device counters."""
+    if st.n_neg_eig:
+        warnings.warn("Negative eigenvalues exist. The kinship matrix supplied may not be SPD.")  # src/transform_helpers.jl:29
+    if st.n_nonpos_weight:
+        warnings.warn("Some weights are not positive.")  # src/wls.jl:36
+    if st.n_zero_norm:
+        raise BulkLMMError(L.ERR_ZERO_NORM_MSG, -8)  # src/util.jl:70
+
+
+class BulkscanNullResult(NamedTuple):
+    L: np.ndarray
+    h2_null_list: np.ndarray
+
+
+class BulkscanAltResult(NamedTuple):
+    L: np.ndarray
+    h2_panel: np.ndarray
+
+
+_METHODS = {"null-exact": L.BLMM_NULL_EXACT, "null-grid": L.BLMM_NULL_GRID, "alt-grid": L.BLMM_ALT_GRID}
+
+
+def calcKinship(geno, ctx: Optional[Context] = None) -> np.ndarray:
+    """src/kinship.jl:4-14."""
+    ctx = ctx or default_context()
+    G = _F(geno)
+    n, p = G.shape
+    K = np.empty((n, n), dtype=np.float64, order="F")
+    ctx.check(ctx.lib.blmm_kinship(ctx.h, _p(G), n, p, _p(K)))
+    return K
+
+
+def _bulkscan_call(method, Y, G, K, Covar, h2_grid, addIntercept, weights, prior_variance, prior_sample_size, reml,
+                   optim_interval, decomp_scheme, compat_flags, ctx, return_status=False):
+    ctx = ctx or default_context()
+    Y = _F(Y)
+    G = _F(G)
+    K = _F(K)
+    n, m = Y.shape
+    p = G.shape[1]
+    if G.shape[0] != n or K.shape[0] != n or K.shape[1] != n:
+        raise BulkLMMError("Dimension mismatch.", -2)  # src/transform_helpers.jl:9-11
+    cov = None
+    ncov = 0
+    if Covar is not None:
+        cov = _F(Covar)
+        if cov.shape[0] != n:
+            raise BulkLMMError("Dimension mismatch.", -2)
+        ncov = cov.shape[1]
+    else:
+        addIntercept = True  # bulkscan(Y, G, K): ones(n,1) as the only covariate (src/bulkscan.jl:97-104)
+    w = None if weights is None else np.ascontiguousarray(np.asarray(weights, dtype=np.float64).ravel())
+    if w is not None and w.shape[0] != n:
+        raise BulkLMMError("Dimension mismatch.", -2)
+    grid = None
+    ngrid = 0
+    if method != L.BLMM_NULL_EXACT:
+        grid = np.ascontiguousarray(np.asarray(h2_grid, dtype=np.float64).ravel())
+        ngrid = grid.shape[0]
+    o = _opts(method, reml, addIntercept, decomp_scheme, optim_interval, prior_variance, prior_sample_size, compat_flags)
+    Lout = np.empty((p, m), dtype=np.float64, order="F")
+    h2 = np.empty((p, m) if method == L.BLMM_ALT_GRID else (m,), dtype=np.float64, order="F")
+    st = L.blmm_status()
+    ctx.check(ctx.lib.blmm_bulkscan(ctx.h, C.byref(o), _p(Y), n, m, _p(G), p, _p(cov), ncov, _p(K), _p(w), _p(grid), ngrid,
+                                    _p(Lout), _p(h2), C.byref(st)))
+    _raise_status(st)
+    if return_status:
+        return Lout, h2, st
+    return Lout, h2
+
+
+def bulkscan_null(Y, G, K, Covar=None, *, nb: int = 1, nt_blas: int = 1, addIntercept: bool = True, weights=None,
+                  prior_variance: float = 1.0, prior_sample_size: float = 0.0, reml: bool = False, optim_interval: int = 1,
+                  decomp_scheme: str = "eigen", ctx: Optional[Context] = None) -> BulkscanNullResult:
+    """src/bulkscan.jl:188-314.  `nb` / `nt_blas` are accepted and ignored (CPU thread blocking)."""
+    Lo, h2 = _bulkscan_call(L.BLMM_NULL_EXACT, Y, G, K, Covar, None, addIntercept, weights, prior_variance, prior_sample_size,
+                            reml, optim_interval, decomp_scheme, 0, ctx)
+    return BulkscanNullResult(Lo, h2)
+
+
+def bulkscan_null_grid(Y, G, K, grid_list, Covar=None, *, weights=None, addIntercept: bool = True, prior_variance: float = 1.0,
+                       prior_sample_size: float = 0.0, reml: bool = False, decomp_scheme: str = "eigen",
+                       ctx: Optional[Context] = None) -> BulkscanNullResult:
+    """src/bulkscan.jl:321-385."""
+    Lo, h2 = _bulkscan_call(L.BLMM_NULL_GRID, Y, G, K, Covar, grid_list, addIntercept, weights, prior_variance,
+                            prior_sample_size, reml, 1, decomp_scheme, 0, ctx)
+    return BulkscanNullResult(Lo, h2)
+
+
+def bulkscan_alt_grid(Y, G, K, hsq_list, Covar=None, *, reml: bool = False, prior_variance: float = 1.0,
+                      prior_sample_size: float = 0.0, weights=None, addIntercept: bool = True, decomp_scheme: str = "eigen",
+                      compat_counter_quirk: bool = False, ctx: Optional[Context] = None) -> BulkscanAltResult:
+    """src/bulkscan.jl:428-526 (h2_panel = grid value at the arg-max)."""
+    Lo, h2 = _bulkscan_call(L.BLMM_ALT_GRID, Y, G, K, Covar, hsq_list, addIntercept, weights, prior_variance,
+                            prior_sample_size, reml, 1, decomp_scheme,
+                            L.BLMM_COMPAT_ALT_COUNTER if compat_counter_quirk else 0, ctx)
+    return BulkscanAltResult(Lo, h2)
+
+
+def lod2log10p(lod, df: int = 1):
+    """src/util.jl:199-206 (host post-map; not on the GPU path)."""
+    from scipy.stats import chi2
+    return -chi2.logsf(np.asarray(lod) * 2.0 * np.log(10.0), df) / np.log(10.0)
+
+
+def bulkscan(Y, G, K, Covar=None, *, method: str = "null-grid", h2_grid=None, nb: int = 1, nt_blas: int = 1,
+             addIntercept: bool = True, weights=None, prior_variance: float = 1.0, prior_sample_size: float = 0.0,
+             reml: bool = False, optim_interval: int = 1, decomp_scheme: str = "eigen", output_pvals: bool = False,
+             chisq_df: int = 1, ctx: Optional[Context] = None) -> dict:
+    """src/bulkscan.jl:81-162.  Returns a dict with the reference NamedTuple's field names."""
+    if h2_grid is None:
+        h2_grid = [i / 10.0 for i in range(10)]  # collect(0.0:0.1:0.9)
+    if method not in _METHODS:
+        raise BulkLMMError("Unknown method `%s`; choose null-exact, null-grid or alt-grid." % method, -5)
+    if method == "null-exact":
+        r = bulkscan_null(Y, G, K, Covar, addIntercept=addIntercept, weights=weights, prior_variance=prior_variance,
+                          prior_sample_size=prior_sample_size, reml=reml, optim_interval=optim_interval,
+                          decomp_scheme=decomp_scheme, ctx=ctx)
+        out = {"L": r.L, "h2_null_list": r.h2_null_list}
+    elif method == "null-grid":
+        r = bulkscan_null_grid(Y, G, K, h2_grid, Covar, weights=weights, addIntercept=addIntercept,
+                               prior_variance=prior_variance, prior_sample_size=prior_sample_size, reml=reml,
+                               decomp_scheme=decomp_scheme, ctx=ctx)
+        out = {"L": r.L, "h2_null_list": r.h2_null_list}
+    else:
+        r = bulkscan_alt_grid(Y, G, K, h2_grid, Covar, reml=reml, prior_variance=prior_variance,
+                              prior_sample_size=prior_sample_size, weights=weights, addIntercept=addIntercept,
+                              decomp_scheme=decomp_scheme, ctx=ctx)
+        out = {"L": r.L, "h2_panel": r.h2_panel}
+    if output_pvals:
+        out["log10Pvals_mat"] = lod2log10p(out["L"], chisq_df)
+        out["Chisq_df"] = chisq_df
+    return out
+
+
+def scan(y, g, K, covar=None, *, weights=None, prior_variance: float = 0.0, prior_sample_size: float = 0.0,
+         addIntercept: bool = True, reml: bool = False, assumption: str = "null", method: str = "qr", optim_interval: int = 1,
+         permutation_test: bool = False, nperms: int = 1024, rndseed: int = 0, decomp_scheme: str = "eigen",
+         output_pvals: bool = False, chisq_df: int = 1, perm_idx=None, ctx: Optional[Context] = None) -> dict:
+    """src/scan.jl:94-271 for assumption == "null": the single-trait scan routed through the same GPU
+    kernels (Brent + exact-weights LOD kernel with m = 1), and the permutation test (src/scan.jl:485-557).
+    `perm_idx` (n x nperms, 0-based) supplies the permutations; otherwise the library draws them from
+    `rndseed` with its own generator (Julia's MersenneTwister stream is not reproducible)."""
+    ctx = ctx or default_context()
+    y = _F(y)
+    if covar is None and not addIntercept:
+        raise BulkLMMError("Intercept has to be added when no other covariate is given.", -7)  # src/scan.jl:167-169
+    if assumption == "alt":
+        if permutation_test:
+            raise BulkLMMError("Permutation test option currently is not supported for the alternative assumption.")
+        raise NotImplementedError("scan_alt (per-marker Brent) is outside the GPU hot path (SURVEY.md §8(a) A19)")
+    if assumption != "null":
+        raise BulkLMMError("Assumption keyword is not supported. Please enter null or alt.")
+    if y.shape[1] != 1:
+        raise BulkLMMError("Can only handle one trait.", -6)  # src/scan.jl:496-498
+    G = _F(g)
+    K = _F(K)
+    n = y.shape[0]
+    p = G.shape[1]
+    if G.shape[0] != n or K.shape[0] != n or K.shape[1] != n:
+        raise BulkLMMError("Dimension mismatch.", -2)
+    cov = None
+    ncov = 0
+    if covar is not None:
+        cov = _F(covar)
+        ncov = cov.shape[1]
+    else:
+        addIntercept = True
+    w = None if weights is None else np.ascontiguousarray(np.asarray(weights, dtype=np.float64).ravel())
+    o = _opts(L.BLMM_NULL_EXACT, reml, addIntercept, decomp_scheme, optim_interval, prior_variance, prior_sample_size)
+    st = L.blmm_status()
+    if not permutation_test:
+        nperms = 0
+    if nperms < 0:
+        raise BulkLMMError("The required number of permutations must be a positive integer.", -9)
+    pidx = None
+    if perm_idx is not None and nperms > 0:
+        pidx = np.asfortranarray(np.asarray(perm_idx, dtype=np.int32))
+        if pidx.shape != (n, nperms):
+            raise BulkLMMError("Dimension mismatch.", -2)
+    scal = np.zeros(2)
+    lod = np.empty(p)
+    Lp = np.empty((p, max(nperms, 1)), order="F")
+    ctx.check(ctx.lib.blmm_scan_perms(ctx.h, C.byref(o), _p(y), n, _p(G), p, _p(cov), ncov, _p(K), _p(w), nperms,
+                                      C.c_uint64(int(rndseed)), _p(pidx), _p(scal), _p(lod), _p(Lp), C.byref(st)))
+    _raise_status(st)
+    out = {"sigma2_e": float(scal[0]), "h2_null": float(scal[1]), "lod": lod}
+    if permutation_test:
+        out["L_perms"] = Lp[:, :nperms]
+    if output_pvals:
+        out["log10pvals"] = lod2log10p(lod, chisq_df)
+        if permutation_test:
+            out["log10Pvals_perms"] = lod2log10p(out["L_perms"], chisq_df)  # the reference's UndefVarError fixed (B3)
+    return out
+
+
+# ---- lower-level seams ------------------------------------------------------------------------------
+
+def transform_rotation(y, g, K, *, addIntercept: bool = True, decomp_scheme: str = "eigen", ctx: Optional[Context] = None):
+    """src/transform_helpers.jl:1-54: (Ut*y, Ut*[1 g], lambda).  Eigenvector signs/order within equal
+    eigenvalues are arbitrary, exactly as with LAPACK."""
+    ctx = ctx or default_context()
+    y = _F(y)
+    g = _F(g)
+    K = _F(K)
+    n, m = y.shape
+    if g.shape[0] != n or K.shape[0] != n:
+        raise BulkLMMError("Dimension mismatch.", -2)
+    o = _opts(decomp_scheme=decomp_scheme, addIntercept=addIntercept)
+    if addIntercept:
+        cov, ncov, G, c = None, 0, g, 1
+    else:
+        # the first column of g plays the covariate role only for the layout of X0; rotation is column-wise
+        cov, ncov, G, c = np.asfortranarray(g[:, :1]), 1, np.asfortranarray(g[:, 1:]), 1
+        if G.shape[1] == 0:
+            raise BulkLMMError("Dimension mismatch.", -2)
+    p = G.shape[1]
+    Y0 = np.empty((n, m), order="F")
+    X0 = np.empty((n, c + p), order="F")
+    lam = np.empty(n)
+    st = L.blmm_status()
+    ctx.check(ctx.lib.blmm_rotate(ctx.h, C.byref(o), _p(y), n, m, _p(G), p, _p(cov), ncov, _p(K), _p(Y0), _p(X0), _p(lam), C.byref(st)))
+    _raise_status(st)
+    return Y0, X0, lam
+
+
+def fitlmm_bulk(Y0, Z0, lambda0, prior=(0.0, 0.0), *, reml: bool = False, optim_interval: int = 1, ctx: Optional[Context] = None):
+    """fitlmm (src/lmm.jl:56-86) for every column of Y0: returns (h2, sigma2, ell), m each."""
+    ctx = ctx or default_context()
+    Y0 = _F(Y0)
+    Z0 = _F(Z0)
+    lam = np.ascontiguousarray(np.asarray(lambda0, dtype=np.float64))
+    n, m = Y0.shape
+    o = _opts(reml=reml, optim_interval=optim_interval, prior_variance=prior[0], prior_sample_size=prior[1])
+    h2, s2, ell = np.empty(m), np.empty(m), np.empty(m)
+    st = L.blmm_status()
+    ctx.check(ctx.lib.blmm_null_h2_brent(ctx.h, C.byref(o), _p(Y0), n, m, _p(Z0), Z0.shape[1], _p(lam), _p(h2), _p(s2), _p(ell), C.byref(st)))
+    return h2, s2, ell
+
+
+def null_loglik_grid(Y0, Z0, lambda0, h2_grid, prior=(1.0, 0.0), *, reml: bool = False, ctx: Optional[Context] = None):
+    """wls_multivar(...).Ell over a grid (src/bulkscan_helpers.jl:267-269): ngrid x m."""
+    ctx = ctx or default_context()
+    Y0 = _F(Y0)
+    Z0 = _F(Z0)
+    lam = np.ascontiguousarray(np.asarray(lambda0, dtype=np.float64))
+    grid = np.ascontiguousarray(np.asarray(h2_grid, dtype=np.float64))
+    n, m = Y0.shape
+    o = _opts(reml=reml, prior_variance=prior[0], prior_sample_size=prior[1])
+    Ell = np.empty((grid.shape[0], m), order="F")
+    st = L.blmm_status()
+    ctx.check(ctx.lib.blmm_null_loglik_grid(ctx.h, C.byref(o), _p(Y0), n, m, _p(Z0), Z0.shape[1], _p(lam), _p(grid), grid.shape[0], _p(Ell), C.byref(st)))
+    return Ell
+
+
+def weighted_liteqtl(Y0, X0, lambda0, hsq: float, *, num_of_covar: int = 1, ctx: Optional[Context] = None):
+    """src/bulkscan_helpers.jl:175-201."""
+    ctx = ctx or default_context()
+    Y0 = _F(Y0)
+    X0 = _F(X0)
+    lam = np.ascontiguousarray(np.asarray(lambda0, dtype=np.float64))
+    n, m = Y0.shape
+    p = X0.shape[1] - num_of_covar
+    out = np.empty((p, m), order="F")
+    st = L.blmm_status()
+    ctx.check(ctx.lib.blmm_weighted_liteqtl(ctx.h, _p(Y0), n, m, _p(X0), num_of_covar, p, _p(lam), float(hsq), _p(out), C.byref(st)))
+    _raise_status(st)
+    return out
+
+
+def liteqtl_given_h2(Y0, X0, lambda0, h2, *, num_of_covar: int = 1, ctx: Optional[Context] = None):
+    """univar_liteqtl's scan part (src/bulkscan_helpers.jl:138-146) for every column of Y0 with per-trait h2."""
+    ctx = ctx or default_context()
+    Y0 = _F(Y0)
+    X0 = _F(X0)
+    lam = np.ascontiguousarray(np.asarray(lambda0, dtype=np.float64))
+    h2 = np.ascontiguousarray(np.asarray(h2, dtype=np.float64))
+    n, m = Y0.shape
+    p = X0.shape[1] - num_of_covar
+    out = np.empty((p, m), order="F")
+    st = L.blmm_status()
+    ctx.check(ctx.lib.blmm_liteqtl_given_h2(ctx.h, _p(Y0), n, m, _p(X0), num_of_covar, p, _p(lam), _p(h2), _p(out), C.byref(st)))
+    _raise_status(st)
+    return out
+
+
+# ---- device-resident entry points (torch tensors; used by bench.py and the multi-GPU path) -------------
+
+def bulkscan_dev(ctx: Context, Y, G, K, L_out, h2_out, *, method: str = "null-exact", h2_grid=None, Covar=None, weights=None,
+                 addIntercept: bool = True, prior_variance: float = 1.0, prior_sample_size: float = 0.0, reml: bool = False,
+                 optim_interval: int = 1, decomp_scheme: str = "eigen", status: bool = False):
+    """blmm_bulkscan_dev on torch CUDA tensors laid out column-major: pass Y as a (m, n) contiguous tensor
+    (= n x m column-major), G as (p, n), K as (n, n), L_out as (m, p) (= p x m column-major).
+    Enqueues on the context's stream and does not synchronise unless `status` is requested."""
+    m, n = Y.shape
+    p = G.shape[0]
+    grid = None
+    ngrid = 0
+    if method != "null-exact":
+        grid = np.ascontiguousarray(np.asarray(h2_grid if h2_grid is not None else [i / 10.0 for i in range(10)], dtype=np.float64))
+        ngrid = grid.shape[0]
+    ncov = 0 if Covar is None else Covar.shape[0]
+    if Covar is None:
+        addIntercept = True
+    o = _opts(_METHODS[method], reml, addIntercept, decomp_scheme, optim_interval, prior_variance, prior_sample_size)
+    st = L.blmm_status() if status else None
+    ctx.check(ctx.lib.blmm_bulkscan_dev(ctx.h, C.byref(o), Y.data_ptr(), n, m, G.data_ptr(), p,
+                                        None if Covar is None else Covar.data_ptr(), ncov, K.data_ptr(),
+                                        None if weights is None else weights.data_ptr(), _p(grid), ngrid,
+                                        L_out.data_ptr(), p, h2_out.data_ptr(), C.byref(st) if status else None))
+    return st

@@ -1,0 +1,706 @@
+// blmm_api.hip -- C ABI (include/bulklmm_hip.h) and the host orchestration of the bulkscan pipeline:
+//   design -> eigen (device Jacobi) -> rotation GEMM -> null-model h2 (Brent / grid) -> panels -> LOD kernels.
+// Mirrors bulkscan / bulkscan_null / bulkscan_null_grid / bulkscan_alt_grid (src/bulkscan.jl) and
+// scan_perms_lite (src/scan.jl:485-557) of BulkLMM.jl; nothing here falls back to a CPU path.
+#include "blmm_internal.h"
+#include <cmath>
+#include <cstring>
+#include <limits>
+
+using namespace blmm;
+
+namespace blmm {
+
+int fail(blmm_ctx* ctx, int code, const std::string& msg) {
+  if (ctx) ctx->err = msg;
+  return code;
+}
+
+int ensure(blmm_ctx* ctx, DevBuf& b, size_t bytes) {
+  if (bytes == 0) bytes = 8;
+  if (b.cap >= bytes) return BLMM_OK;
+  if (b.p) {
+    // outstanding work may still use the old buffer
+    hipStreamSynchronize(ctx->stream);
+    hipFree(b.p);
+    b.p = nullptr; b.cap = 0;
+  }
+  size_t want = bytes + bytes / 8 + 256;
+  hipError_t e = hipMalloc(&b.p, want);
+  if (e != hipSuccess) {
+    b.p = nullptr;
+    return fail(ctx, BLMM_ERR_ALLOC, std::string("hipMalloc(") + std::to_string(want) + "): " + hipGetErrorString(e));
+  }
+  b.cap = want;
+  return BLMM_OK;
+}
+
+__global__ void k_fill(double* p, int64_t n, double v) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = v;
+}
+// column-major n x ncols  ->  row-major npad x ld (zero padded)
+__global__ void k_to_rowmajor(const double* __restrict__ In, int n, int64_t ncols, double* __restrict__ Out, int npad, int64_t ld) {
+  __shared__ double tile[32][33];
+  const int64_t c0 = (int64_t)blockIdx.x * 32;
+  const int r0 = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  for (int cc = ty; cc < 32; cc += 8) {
+    const int64_t col = c0 + cc; const int row = r0 + tx;
+    tile[cc][tx] = (row < n && col < ncols) ? In[col * n + row] : 0.0;
+  }
+  __syncthreads();
+  for (int rr = ty; rr < 32; rr += 8) {
+    const int row = r0 + rr; const int64_t col = c0 + tx;
+    if (row < npad && col < ld) Out[(int64_t)row * ld + col] = tile[tx][rr];
+  }
+}
+
+}  // namespace blmm
+
+namespace {
+
+struct Pipe {
+  int n = 0, c = 0, npad = 0, ldr = 0;
+  int64_t m = 0, p = 0, ldy = 0, ldx = 0;
+  double *Yt = nullptr, *Xt = nullptr, *Z0 = nullptr, *lam = nullptr;
+  int64_t* stat = nullptr;
+};
+
+struct Timer {
+  blmm_ctx* ctx; blmm_ctx::EvSet* set = nullptr;
+  explicit Timer(blmm_ctx* c) : ctx(c) {
+    if (!ctx->timing) return;
+    if (ctx->ev_used >= 4096) ctx->ev_used = 0;  // nobody is reading: recycle
+    if (ctx->ev_used == ctx->evsets.size()) {
+      blmm_ctx::EvSet s; s.n = 0;
+      for (auto& e : s.e) (void)hipEventCreate(&e);
+      ctx->evsets.push_back(s);
+    }
+    set = &ctx->evsets[ctx->ev_used++];
+    set->n = 0;
+  }
+  void mark() { if (set && set->n < 8) (void)hipEventRecord(set->e[set->n++], ctx->stream); }
+};
+
+// phase times of one event set; marks: 0 start, 1 eigen done, 2 rotate done, 3 h2 done, 4 prep done, 5 scan done
+void phase_times(const blmm_ctx::EvSet& s, double out[6]) {
+  for (int i = 0; i < 6; ++i) out[i] = 0.0;
+  for (int i = 0; i + 1 < s.n && i < 5; ++i) { float ms = 0; (void)hipEventElapsedTime(&ms, s.e[i], s.e[i + 1]); out[i] = ms; }
+  if (s.n >= 2) { float tot = 0; (void)hipEventElapsedTime(&tot, s.e[0], s.e[s.n - 1]); out[5] = tot; }
+}
+
+int to_rowmajor(blmm_ctx* ctx, const double* In, int n, int64_t ncols, double* Out, int npad, int64_t ld) {
+  dim3 grid((unsigned)((ld + 31) / 32), (unsigned)((npad + 31) / 32));
+  hipLaunchKernelGGL(k_to_rowmajor, grid, dim3(256), 0, ctx->stream, In, n, ncols, Out, npad, ld);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(ctx, BLMM_ERR_HIP, std::string("k_to_rowmajor: ") + hipGetErrorString(e));
+  return BLMM_OK;
+}
+
+int fill(blmm_ctx* ctx, double* p, int64_t n, double v) {
+  if (n <= 0) return BLMM_OK;
+  hipLaunchKernelGGL(k_fill, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, p, n, v);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(ctx, BLMM_ERR_HIP, std::string("k_fill: ") + hipGetErrorString(e));
+  return BLMM_OK;
+}
+
+int check_opts(blmm_ctx* ctx, const blmm_opts* o) {
+  if (!o) return fail(ctx, BLMM_ERR_INVALID, "opts is NULL");
+  if (o->decomp_scheme != BLMM_EIGEN && o->decomp_scheme != BLMM_SVD)
+    return fail(ctx, BLMM_ERR_DECOMP, "Please choose either `eigen` or `svd` for decomposition of the kinship matrix.");
+  return BLMM_OK;
+}
+
+int reset_stat(blmm_ctx* ctx, int64_t** stat) {
+  int rc = ensure(ctx, ctx->stat, sizeof(int64_t) * NSTAT);
+  if (rc) return rc;
+  *stat = ptr<int64_t>(ctx->stat);
+  BLMM_HIP(hipMemsetAsync(*stat, 0, sizeof(int64_t) * NSTAT, ctx->stream));
+  return BLMM_OK;
+}
+
+// Synchronises and fills *status (only when the caller asked for it).
+int finish_status(blmm_ctx* ctx, blmm_status* st, Timer* tm) {
+  if (!st) return BLMM_OK;
+  std::memset(st, 0, sizeof(*st));
+  int64_t h[NSTAT];
+  BLMM_HIP(hipMemcpyAsync(h, ctx->stat.p, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
+  BLMM_HIP(hipStreamSynchronize(ctx->stream));
+  st->n_neg_eig = h[ST_NEG_EIG];
+  st->n_nonpos_weight = h[ST_NONPOS_W];
+  st->n_zero_norm = h[ST_ZERO_NORM];
+  st->n_nan_lod = h[ST_NAN_LOD];
+  st->n_brent_maxiter = h[ST_BRENT_MAXIT];
+  st->jacobi_sweeps = h[ST_JACOBI_SWEEPS];
+  if (tm && tm->set && tm->set->n >= 2) {
+    double t[6];
+    phase_times(*tm->set, t);
+    st->t_eigen_ms = t[0]; st->t_rotate_ms = t[1]; st->t_h2_ms = t[2]; st->t_prep_ms = t[3]; st->t_scan_ms = t[4];
+    st->t_total_ms = t[5];
+  }
+  return BLMM_OK;
+}
+
+// design -> eigen -> rotation of Y and G.  centered = 1: the rotation also removes the unweighted projection
+// on the null covariates (kernels_prep.hip:k_post_eigen).
+int prepare(blmm_ctx* ctx, const blmm_opts* o, const double* dY, int64_t n, int64_t m, const double* dG, int64_t p,
+            const double* dCovar, int64_t ncov, const double* dK, const double* dweights, int centered, Pipe& P, Timer& tm) {
+  if (n < 1 || m < 0 || p < 0 || ncov < 0) return fail(ctx, BLMM_ERR_DIM, "Dimension mismatch.");
+  if (n > 46000) return fail(ctx, BLMM_ERR_UNSUPPORTED, "n too large");
+  int add_int = o->add_intercept ? 1 : 0;
+  if (ncov == 0 || !dCovar) { add_int = 1; ncov = 0; dCovar = nullptr; }  // bulkscan(Y,G,K): intercept-only null model
+  const int c = (int)ncov + add_int;
+  if (c < 1 || c > CMAX) return fail(ctx, BLMM_ERR_UNSUPPORTED, "number of null covariates (incl. intercept) must be 1..4");
+  if (c >= n) return fail(ctx, BLMM_ERR_DIM, "Dimension mismatch.");
+  P.n = (int)n; P.c = c; P.npad = (int)round_up(n, 4); P.ldr = (int)round_up(P.npad, 16);
+  P.m = m; P.p = p; P.ldy = round_up(m > 0 ? m : 1, 128); P.ldx = round_up(p > 0 ? p : 1, 128);
+  int rc;
+  if ((rc = ensure(ctx, ctx->Ks, sizeof(double) * n * n))) return rc;
+  if ((rc = ensure(ctx, ctx->V, sizeof(double) * n * n))) return rc;
+  if ((rc = ensure(ctx, ctx->U, sizeof(double) * n * n))) return rc;
+  if ((rc = ensure(ctx, ctx->lam, sizeof(double) * n))) return rc;
+  if ((rc = ensure(ctx, ctx->Zs, sizeof(double) * n * c))) return rc;
+  if ((rc = ensure(ctx, ctx->Z0, sizeof(double) * n * c))) return rc;
+  if ((rc = ensure(ctx, ctx->Rp, sizeof(double) * (size_t)P.npad * P.ldr))) return rc;
+  if ((rc = ensure(ctx, ctx->Yt, sizeof(double) * (size_t)P.npad * P.ldy))) return rc;
+  if ((rc = ensure(ctx, ctx->Xt, sizeof(double) * (size_t)P.npad * P.ldx))) return rc;
+  if ((rc = reset_stat(ctx, &P.stat))) return rc;
+  P.Yt = ptr<double>(ctx->Yt); P.Xt = ptr<double>(ctx->Xt); P.Z0 = ptr<double>(ctx->Z0); P.lam = ptr<double>(ctx->lam);
+  tm.mark();
+  if ((rc = launch_design(ctx, dK, dCovar, (int)ncov, add_int, dweights, (int)n, ptr<double>(ctx->Ks), ptr<double>(ctx->Zs)))) return rc;
+  if ((rc = launch_jacobi(ctx, ptr<double>(ctx->Ks), ptr<double>(ctx->V), (int)n, P.stat))) return rc;
+  if ((rc = launch_post_eigen(ctx, ptr<double>(ctx->Ks), ptr<double>(ctx->V), ptr<double>(ctx->Zs), dweights, (int)n, c,
+                              P.npad, P.ldr, o->decomp_scheme, centered, P.lam, ptr<double>(ctx->U), P.Z0,
+                              ptr<double>(ctx->Rp), P.stat))) return rc;
+  tm.mark();
+  if ((rc = launch_rotate(ctx, ptr<double>(ctx->Rp), P.ldr, (int)n, P.npad, dY, m, P.Yt, P.ldy, P.ldy))) return rc;
+  if ((rc = launch_rotate(ctx, ptr<double>(ctx->Rp), P.ldr, (int)n, P.npad, dG, p, P.Xt, P.ldx, P.ldx))) return rc;
+  tm.mark();
+  return BLMM_OK;
+}
+
+NullModel null_model(const Pipe& P, const blmm_opts* o) {
+  NullModel nm;
+  nm.n = P.n; nm.c = P.c; nm.npad = P.npad; nm.reml = o->reml ? 1 : 0;
+  nm.optim_interval = o->optim_interval < 1 ? 1 : o->optim_interval;
+  nm.prior_a = o->prior_variance; nm.prior_b = o->prior_sample_size;
+  return nm;
+}
+
+int grid_to_device(blmm_ctx* ctx, const double* h2_grid_host, int64_t ngrid, double** out) {
+  if (!h2_grid_host || ngrid < 1) return fail(ctx, BLMM_ERR_INVALID, "h2 grid is empty");
+  for (int64_t g = 0; g < ngrid; ++g) {
+    const double h = h2_grid_host[g];
+    if (std::isinf(h / (1.0 - h))) return fail(ctx, BLMM_ERR_H2_ONE, "Heritability of 1 is not allowed.");
+  }
+  int rc = ensure(ctx, ctx->gridd, sizeof(double) * ngrid);
+  if (rc) return rc;
+  BLMM_HIP(hipMemcpyAsync(ctx->gridd.p, h2_grid_host, sizeof(double) * ngrid, hipMemcpyHostToDevice, ctx->stream));
+  // the source is caller memory: make sure the copy has left it before we return
+  BLMM_HIP(hipStreamSynchronize(ctx->stream));
+  *out = ptr<double>(ctx->gridd);
+  return BLMM_OK;
+}
+
+ScanArgs scan_args(const Pipe& P, const double* panels, int64_t ldp, double* L, int64_t ldL, int64_t m) {
+  ScanArgs a;
+  a.Xt = P.Xt; a.ldx = P.ldx; a.P = panels; a.ldp = ldp; a.pstride = (int64_t)P.npad * ldp;
+  a.ks = P.npad / 4; a.n = P.n; a.p = P.p; a.m = m; a.L = L; a.ldL = ldL;
+  a.isx = nullptr; a.ld_isx = 0; a.bin = nullptr; a.stat = P.stat;
+  return a;
+}
+
+}  // namespace
+
+extern "C" {
+
+int blmm_version(void) { return BLMM_VERSION; }
+
+int blmm_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+const char* blmm_err_string(int code) {
+  switch (code) {
+    case BLMM_OK: return "ok";
+    case BLMM_ERR_INVALID: return "invalid argument";
+    case BLMM_ERR_DIM: return "Dimension mismatch.";
+    case BLMM_ERR_H2_ONE: return "Heritability of 1 is not allowed.";
+    case BLMM_ERR_DECOMP: return "Please choose either `eigen` or `svd` for decomposition of the kinship matrix.";
+    case BLMM_ERR_METHOD: return "unknown bulkscan method";
+    case BLMM_ERR_ONE_TRAIT: return "Can only handle one trait.";
+    case BLMM_ERR_NO_INTERCEPT: return "Intercept has to be added when no other covariate is given.";
+    case BLMM_ERR_ZERO_NORM: return "Dividing by zeros: the input vector can not contain any zeros!";
+    case BLMM_ERR_NPERMS: return "The required number of permutations must be a positive integer.";
+    case BLMM_ERR_UNSUPPORTED: return "unsupported configuration";
+    case BLMM_ERR_NO_DEVICE: return "no usable HIP device";
+    case BLMM_ERR_HIP: return "HIP runtime error";
+    case BLMM_ERR_ALLOC: return "device allocation failed";
+  }
+  return "unknown error";
+}
+
+int blmm_create(int device_id, void* hip_stream, blmm_ctx** out) {
+  if (!out) return BLMM_ERR_INVALID;
+  *out = nullptr;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device_id < 0 || device_id >= ndev) return BLMM_ERR_NO_DEVICE;
+  if (hipSetDevice(device_id) != hipSuccess) return BLMM_ERR_NO_DEVICE;
+  blmm_ctx* ctx = new blmm_ctx();
+  ctx->device = device_id;
+  if (hip_stream) {
+    ctx->stream = reinterpret_cast<hipStream_t>(hip_stream);
+  } else {
+    if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { delete ctx; return BLMM_ERR_HIP; }
+    ctx->own_stream = true;
+  }
+  *out = ctx;
+  return BLMM_OK;
+}
+
+void blmm_destroy(blmm_ctx* ctx) {
+  if (!ctx) return;
+  hipSetDevice(ctx->device);
+  hipStreamSynchronize(ctx->stream);
+  DevBuf* bufs[] = {&ctx->Ks, &ctx->V, &ctx->lam, &ctx->U, &ctx->Zs, &ctx->Z0, &ctx->Rp, &ctx->Yt, &ctx->Xt, &ctx->panels,
+                    &ctx->iyy, &ctx->h2, &ctx->h2idx, &ctx->sig2, &ctx->ell, &ctx->isx, &ctx->stat, &ctx->gridd, &ctx->misc,
+                    &ctx->EllTab, &ctx->inY, &ctx->inG, &ctx->inK, &ctx->inCov, &ctx->inW, &ctx->outL, &ctx->outH2,
+                    &ctx->tmpA, &ctx->tmpB, &ctx->tmpC, &ctx->perm, &ctx->r0, &ctx->altbuf};
+  for (DevBuf* b : bufs) if (b->p) hipFree(b->p);
+  for (auto& s : ctx->evsets) for (auto& e : s.e) (void)hipEventDestroy(e);
+  if (ctx->own_stream) hipStreamDestroy(ctx->stream);
+  delete ctx;
+}
+
+const char* blmm_last_error(const blmm_ctx* ctx) { return ctx ? ctx->err.c_str() : "ctx is NULL"; }
+
+int blmm_set_stream(blmm_ctx* ctx, void* hip_stream) {
+  if (!ctx) return BLMM_ERR_INVALID;
+  hipStreamSynchronize(ctx->stream);
+  if (ctx->own_stream) { hipStreamDestroy(ctx->stream); ctx->own_stream = false; }
+  if (hip_stream) ctx->stream = reinterpret_cast<hipStream_t>(hip_stream);
+  else {
+    if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) return fail(ctx, BLMM_ERR_HIP, "hipStreamCreate");
+    ctx->own_stream = true;
+  }
+  return BLMM_OK;
+}
+
+int blmm_set_timing(blmm_ctx* ctx, int on) {
+  if (!ctx) return BLMM_ERR_INVALID;
+  ctx->timing = on != 0;
+  return BLMM_OK;
+}
+
+int blmm_read_timings(blmm_ctx* ctx, double* sums_ms, int64_t* ncalls) {
+  if (!ctx || !sums_ms || !ncalls) return BLMM_ERR_INVALID;
+  BLMM_HIP(hipStreamSynchronize(ctx->stream));
+  for (int i = 0; i < 6; ++i) sums_ms[i] = 0.0;
+  for (size_t k = 0; k < ctx->ev_used; ++k) {
+    double t[6];
+    phase_times(ctx->evsets[k], t);
+    for (int i = 0; i < 6; ++i) sums_ms[i] += t[i];
+  }
+  *ncalls = (int64_t)ctx->ev_used;
+  ctx->ev_used = 0;
+  return BLMM_OK;
+}
+
+int blmm_synchronize(blmm_ctx* ctx) {
+  if (!ctx) return BLMM_ERR_INVALID;
+  BLMM_HIP(hipStreamSynchronize(ctx->stream));
+  return BLMM_OK;
+}
+
+void blmm_default_opts(blmm_opts* o) {
+  if (!o) return;
+  std::memset(o, 0, sizeof(*o));
+  o->method = BLMM_NULL_GRID; o->reml = 0; o->add_intercept = 1; o->decomp_scheme = BLMM_EIGEN;
+  o->optim_interval = 1; o->compat_flags = 0; o->prior_variance = 1.0; o->prior_sample_size = 0.0;
+}
+
+// ---------------------------------------------------------------------------------------------------
+int blmm_kinship_dev(blmm_ctx* ctx, const double* dG, int64_t n, int64_t p, double* dK_out) {
+  if (!ctx) return BLMM_ERR_INVALID;
+  if (!dG || !dK_out || n < 1 || p < 1) return fail(ctx, BLMM_ERR_INVALID, "calcKinship: bad arguments");
+  BLMM_HIP(hipSetDevice(ctx->device));
+  int rc = ensure(ctx, ctx->tmpA, sizeof(double) * (size_t)64 * n * n);
+  if (rc) return rc;
+  return launch_kinship(ctx, dG, n, p, dK_out, ptr<double>(ctx->tmpA));
+}
+
+int blmm_kinship(blmm_ctx* ctx, const double* G, int64_t n, int64_t p, double* K_out) {
+  if (!ctx) return BLMM_ERR_INVALID;
+  if (!G || !K_out || n < 1 || p < 1) return fail(ctx, BLMM_ERR_INVALID, "calcKinship: bad arguments");
+  BLMM_HIP(hipSetDevice(ctx->device));
+  int rc;
+  if ((rc = ensure(ctx, ctx->inG, sizeof(double) * n * p))) return rc;
+  if ((rc = ensure(ctx, ctx->inK, sizeof(double) * n * n))) return rc;
+  BLMM_HIP(hipMemcpyAsync(ctx->inG.p, G, sizeof(double) * n * p, hipMemcpyHostToDevice, ctx->stream));
+  if ((rc = blmm_kinship_dev(ctx, ptr<double>(ctx->inG), n, p, ptr<double>(ctx->inK)))) return rc;
+  BLMM_HIP(hipMemcpyAsync(K_out, ctx->inK.p, sizeof(double) * n * n, hipMemcpyDeviceToHost, ctx->stream));
+  BLMM_HIP(hipStreamSynchronize(ctx->stream));
+  return BLMM_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------
+int blmm_bulkscan_dev(blmm_ctx* ctx, const blmm_opts* opts, const double* dY, int64_t n, int64_t m, const double* dG,
+                      int64_t p, const double* dCovar, int64_t ncov, const double* dK, const double* dweights,
+                      const double* h2_grid_host, int64_t ngrid, double* dL_out, int64_t ldL, double* dh2_out,
+                      blmm_status* status) {
+  if (!ctx) return BLMM_ERR_INVALID;
+  int rc = check_opts(ctx, opts);
+  if (rc) return rc;
+  if (!dY || !dG || !dK || !dL_out || !dh2_out) return fail(ctx, BLMM_ERR_INVALID, "bulkscan: NULL buffer");
+  if (ldL < p) return fail(ctx, BLMM_ERR_INVALID, "bulkscan: ldL < p");
+  if (opts->method != BLMM_NULL_EXACT && opts->method != BLMM_NULL_GRID && opts->method != BLMM_ALT_GRID)
+    return fail(ctx, BLMM_ERR_METHOD, "Unknown method; choose null-exact, null-grid or alt-grid.");
+  BLMM_HIP(hipSetDevice(ctx->device));
+  Timer tm(ctx);
+  Pipe P;
+  double* dgrid = nullptr;
+  if (opts->method != BLMM_NULL_EXACT) {
+    if ((rc = grid_to_device(ctx, h2_grid_host, ngrid, &dgrid))) return rc;
+  }
+  if ((rc = prepare(ctx, opts, dY, n, m, dG, p, dCovar, ncov, dK, dweights, 1, P, tm))) return rc;
+  const NullModel nm = null_model(P, opts);
+  const int64_t ldp = P.ldy;
+  if (m == 0 || p == 0) { tm.mark(); tm.mark(); tm.mark(); return finish_status(ctx, status, &tm); }
+
+  if (opts->method == BLMM_NULL_EXACT) {
+    if ((rc = launch_brent(ctx, nm, P.Yt, P.ldy, m, P.Z0, P.lam, dh2_out, nullptr, nullptr, P.stat))) return rc;
+    tm.mark();
+    if ((rc = ensure(ctx, ctx->panels, sizeof(double) * (size_t)(2 + P.c) * P.npad * ldp))) return rc;
+    if ((rc = launch_panels(ctx, nm, P.Yt, P.ldy, m, P.Z0, P.lam, dh2_out, 1, ptr<double>(ctx->panels), ldp, P.stat))) return rc;
+    tm.mark();
+    ScanArgs a = scan_args(P, ptr<double>(ctx->panels), ldp, dL_out, ldL, m);
+    if ((rc = launch_scan_exact(ctx, a, P.c))) return rc;
+    tm.mark();
+  } else if (opts->method == BLMM_NULL_GRID) {
+    if ((rc = ensure(ctx, ctx->h2idx, sizeof(int) * (size_t)m))) return rc;
+    if ((rc = launch_loglik_grid(ctx, nm, P.Yt, P.ldy, m, P.Z0, P.lam, dgrid, (int)ngrid, nullptr, ptr<int>(ctx->h2idx), dh2_out, P.stat))) return rc;
+    tm.mark();
+    if ((rc = ensure(ctx, ctx->panels, sizeof(double) * (size_t)P.npad * ldp))) return rc;
+    if ((rc = launch_panels(ctx, nm, P.Yt, P.ldy, m, P.Z0, P.lam, dh2_out, 0, ptr<double>(ctx->panels), ldp, P.stat))) return rc;
+    if ((rc = ensure(ctx, ctx->isx, sizeof(double) * (size_t)ngrid * P.ldx))) return rc;
+    if ((rc = launch_isx(ctx, nm, P.Xt, P.ldx, p, P.Z0, P.lam, dgrid, (int)ngrid, ptr<double>(ctx->isx), P.ldx, P.stat))) return rc;
+    tm.mark();
+    ScanArgs a = scan_args(P, ptr<double>(ctx->panels), ldp, dL_out, ldL, m);
+    a.isx = ptr<double>(ctx->isx); a.ld_isx = P.ldx; a.bin = ptr<int>(ctx->h2idx);
+    if ((rc = launch_scan_table(ctx, a))) return rc;
+    tm.mark();
+  } else {  // alt-grid
+    if ((rc = ensure(ctx, ctx->EllTab, sizeof(double) * (size_t)ngrid * m))) return rc;
+    if ((rc = launch_loglik_grid(ctx, nm, P.Yt, P.ldy, m, P.Z0, P.lam, dgrid, (int)ngrid, ptr<double>(ctx->EllTab), nullptr, nullptr, P.stat))) return rc;
+    tm.mark();
+    if ((rc = ensure(ctx, ctx->panels, sizeof(double) * (size_t)ngrid * P.npad * ldp))) return rc;
+    if ((rc = ensure(ctx, ctx->h2, sizeof(double) * (size_t)m))) return rc;
+    for (int64_t g = 0; g < ngrid; ++g) {
+      if ((rc = fill(ctx, ptr<double>(ctx->h2), m, h2_grid_host[g]))) return rc;
+      if ((rc = launch_panels(ctx, nm, P.Yt, P.ldy, m, P.Z0, P.lam, ptr<double>(ctx->h2), 0,
+                              ptr<double>(ctx->panels) + (size_t)g * P.npad * ldp, ldp, P.stat))) return rc;
+    }
+    if ((rc = ensure(ctx, ctx->isx, sizeof(double) * (size_t)ngrid * P.ldx))) return rc;
+    if ((rc = launch_isx(ctx, nm, P.Xt, P.ldx, p, P.Z0, P.lam, dgrid, (int)ngrid, ptr<double>(ctx->isx), P.ldx, P.stat))) return rc;
+    tm.mark();
+    AltArgs aa;
+    aa.s = scan_args(P, ptr<double>(ctx->panels), ldp, dL_out, ldL, m);
+    aa.s.isx = ptr<double>(ctx->isx); aa.s.ld_isx = P.ldx;
+    aa.ngrid = (int)ngrid; aa.EllTab = ptr<double>(ctx->EllTab); aa.grid_dev = dgrid; aa.H2 = dh2_out; aa.ldH = p;
+    aa.counter_quirk = (opts->compat_flags & BLMM_COMPAT_ALT_COUNTER) ? 1 : 0;
+    if ((rc = launch_scan_alt(ctx, aa))) return rc;
+    tm.mark();
+  }
+  return finish_status(ctx, status, &tm);
+}
+
+int blmm_bulkscan(blmm_ctx* ctx, const blmm_opts* opts, const double* Y, int64_t n, int64_t m, const double* G, int64_t p,
+                  const double* Covar, int64_t ncov, const double* K, const double* weights, const double* h2_grid,
+                  int64_t ngrid, double* L_out, double* h2_out, blmm_status* status) {
+  if (!ctx) return BLMM_ERR_INVALID;
+  if (!opts) return fail(ctx, BLMM_ERR_INVALID, "opts is NULL");
+  if (!Y || !G || !K || !L_out || !h2_out) return fail(ctx, BLMM_ERR_INVALID, "bulkscan: NULL buffer");
+  if (n < 1 || m < 0 || p < 0) return fail(ctx, BLMM_ERR_DIM, "Dimension mismatch.");
+  BLMM_HIP(hipSetDevice(ctx->device));
+  int rc;
+  const bool alt = opts->method == BLMM_ALT_GRID;
+  const size_t h2_elems = alt ? (size_t)p * m : (size_t)m;
+  if ((rc = ensure(ctx, ctx->inY, sizeof(double) * n * (m > 0 ? m : 1)))) return rc;
+  if ((rc = ensure(ctx, ctx->inG, sizeof(double) * n * (p > 0 ? p : 1)))) return rc;
+  if ((rc = ensure(ctx, ctx->inK, sizeof(double) * n * n))) return rc;
+  if ((rc = ensure(ctx, ctx->outL, sizeof(double) * (size_t)p * m))) return rc;
+  if ((rc = ensure(ctx, ctx->outH2, sizeof(double) * h2_elems))) return rc;
+  BLMM_HIP(hipMemcpyAsync(ctx->inY.p, Y, sizeof(double) * n * m, hipMemcpyHostToDevice, ctx->stream));
+  BLMM_HIP(hipMemcpyAsync(ctx->inG.p, G, sizeof(double) * n * p, hipMemcpyHostToDevice, ctx->stream));
+  BLMM_HIP(hipMemcpyAsync(ctx->inK.p, K, sizeof(double) * n * n, hipMemcpyHostToDevice, ctx->stream));
+  const double* dCov = nullptr; const double* dW = nullptr;
+  if (Covar && ncov > 0) {
+    if ((rc = ensure(ctx, ctx->inCov, sizeof(double) * n * ncov))) return rc;
+    BLMM_HIP(hipMemcpyAsync(ctx->inCov.p, Covar, sizeof(double) * n * ncov, hipMemcpyHostToDevice, ctx->stream));
+    dCov = ptr<double>(ctx->inCov);
+  }
+  if (weights) {
+    if ((rc = ensure(ctx, ctx->inW, sizeof(double) * n))) return rc;
+    BLMM_HIP(hipMemcpyAsync(ctx->inW.p, weights, sizeof(double) * n, hipMemcpyHostToDevice, ctx->stream));
+    dW = ptr<double>(ctx->inW);
+  }
+  rc = blmm_bulkscan_dev(ctx, opts, ptr<double>(ctx->inY), n, m, ptr<double>(ctx->inG), p, dCov, dCov ? ncov : 0,
+                         ptr<double>(ctx->inK), dW, h2_grid, ngrid, ptr<double>(ctx->outL), p, ptr<double>(ctx->outH2), status);
+  if (rc) { hipStreamSynchronize(ctx->stream); return rc; }
+  if ((size_t)p * m > 0) BLMM_HIP(hipMemcpyAsync(L_out, ctx->outL.p, sizeof(double) * (size_t)p * m, hipMemcpyDeviceToHost, ctx->stream));
+  if (h2_elems > 0) BLMM_HIP(hipMemcpyAsync(h2_out, ctx->outH2.p, sizeof(double) * h2_elems, hipMemcpyDeviceToHost, ctx->stream));
+  BLMM_HIP(hipStreamSynchronize(ctx->stream));
+  return BLMM_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------
+int blmm_scan_perms_dev(blmm_ctx* ctx, const blmm_opts* opts, const double* dy, int64_t n, const double* dG, int64_t p,
+                        const double* dCovar, int64_t ncov, const double* dK, const double* dweights, int64_t nperms,
+                        uint64_t seed, const int32_t* dperm_idx, double* dscalars_out, double* dlod_out,
+                        double* dLperms_out, blmm_status* status) {
+  if (!ctx) return BLMM_ERR_INVALID;
+  int rc = check_opts(ctx, opts);
+  if (rc) return rc;
+  if (nperms < 0) return fail(ctx, BLMM_ERR_NPERMS, "The required number of permutations must be a positive integer.");
+  if (!dy || !dG || !dK || !dscalars_out || !dlod_out || (nperms > 0 && !dLperms_out))
+    return fail(ctx, BLMM_ERR_INVALID, "scan_perms: NULL buffer");
+  BLMM_HIP(hipSetDevice(ctx->device));
+  Timer tm(ctx);
+  Pipe P;
+  if ((rc = prepare(ctx, opts, dy, n, 1, dG, p, dCovar, ncov, dK, dweights, 1, P, tm))) return rc;
+  const NullModel nm = null_model(P, opts);
+  // scalars: [sigma2_e, h2_null]
+  if ((rc = launch_brent(ctx, nm, P.Yt, P.ldy, 1, P.Z0, P.lam, dscalars_out + 1, dscalars_out, nullptr, P.stat))) return rc;
+  tm.mark();
+  const int64_t ldp0 = 128, ldp1 = round_up(nperms > 0 ? nperms : 1, 128);
+  if ((rc = ensure(ctx, ctx->panels, sizeof(double) * (size_t)P.npad * (ldp0 + ldp1)))) return rc;
+  double* pan0 = ptr<double>(ctx->panels);
+  double* pan1 = pan0 + (size_t)P.npad * ldp0;
+  if ((rc = launch_perm_panel(ctx, nm, P.Yt, P.ldy, P.Z0, P.lam, dscalars_out + 1, nullptr, 0, seed, 1, pan0, ldp0, P.stat))) return rc;
+  if (nperms > 0)
+    if ((rc = launch_perm_panel(ctx, nm, P.Yt, P.ldy, P.Z0, P.lam, dscalars_out + 1, dperm_idx, nperms, seed, 0, pan1, ldp1, P.stat))) return rc;
+  if ((rc = ensure(ctx, ctx->isx, sizeof(double) * (size_t)P.ldx))) return rc;
+  if ((rc = launch_isx(ctx, nm, P.Xt, P.ldx, p, P.Z0, P.lam, dscalars_out + 1, 1, ptr<double>(ctx->isx), P.ldx, P.stat))) return rc;
+  tm.mark();
+  if (p > 0) {
+    ScanArgs a = scan_args(P, pan0, ldp0, dlod_out, p, 1);
+    a.isx = ptr<double>(ctx->isx); a.ld_isx = P.ldx;
+    if ((rc = launch_scan_table(ctx, a))) return rc;
+    if (nperms > 0) {
+      ScanArgs b = scan_args(P, pan1, ldp1, dLperms_out, p, nperms);
+      b.isx = ptr<double>(ctx->isx); b.ld_isx = P.ldx;
+      if ((rc = launch_scan_table(ctx, b))) return rc;
+    }
+  }
+  tm.mark();
+  return finish_status(ctx, status, &tm);
+}
+
+int blmm_scan_perms(blmm_ctx* ctx, const blmm_opts* opts, const double* y, int64_t n, const double* G, int64_t p,
+                    const double* Covar, int64_t ncov, const double* K, const double* weights, int64_t nperms, uint64_t seed,
+                    const int32_t* perm_idx, double* scalars_out, double* lod_out, double* Lperms_out, blmm_status* status) {
+  if (!ctx) return BLMM_ERR_INVALID;
+  if (!opts) return fail(ctx, BLMM_ERR_INVALID, "opts is NULL");
+  if (nperms < 0) return fail(ctx, BLMM_ERR_NPERMS, "The required number of permutations must be a positive integer.");
+  if (!y || !G || !K || !scalars_out || !lod_out || (nperms > 0 && !Lperms_out)) return fail(ctx, BLMM_ERR_INVALID, "scan_perms: NULL buffer");
+  if (n < 1 || p < 0) return fail(ctx, BLMM_ERR_DIM, "Dimension mismatch.");
+  BLMM_HIP(hipSetDevice(ctx->device));
+  int rc;
+  if ((rc = ensure(ctx, ctx->inY, sizeof(double) * n))) return rc;
+  if ((rc = ensure(ctx, ctx->inG, sizeof(double) * n * (p > 0 ? p : 1)))) return rc;
+  if ((rc = ensure(ctx, ctx->inK, sizeof(double) * n * n))) return rc;
+  if ((rc = ensure(ctx, ctx->outL, sizeof(double) * (size_t)p * (nperms + 1)))) return rc;
+  if ((rc = ensure(ctx, ctx->outH2, sizeof(double) * 2))) return rc;
+  BLMM_HIP(hipMemcpyAsync(ctx->inY.p, y, sizeof(double) * n, hipMemcpyHostToDevice, ctx->stream));
+  BLMM_HIP(hipMemcpyAsync(ctx->inG.p, G, sizeof(double) * n * p, hipMemcpyHostToDevice, ctx->stream));
+  BLMM_HIP(hipMemcpyAsync(ctx->inK.p, K, sizeof(double) * n * n, hipMemcpyHostToDevice, ctx->stream));
+  const double* dCov = nullptr; const double* dW = nullptr; const int32_t* dperm = nullptr;
+  if (Covar && ncov > 0) {
+    if ((rc = ensure(ctx, ctx->inCov, sizeof(double) * n * ncov))) return rc;
+    BLMM_HIP(hipMemcpyAsync(ctx->inCov.p, Covar, sizeof(double) * n * ncov, hipMemcpyHostToDevice, ctx->stream));
+    dCov = ptr<double>(ctx->inCov);
+  }
+  if (weights) {
+    if ((rc = ensure(ctx, ctx->inW, sizeof(double) * n))) return rc;
+    BLMM_HIP(hipMemcpyAsync(ctx->inW.p, weights, sizeof(double) * n, hipMemcpyHostToDevice, ctx->stream));
+    dW = ptr<double>(ctx->inW);
+  }
+  if (perm_idx && nperms > 0) {
+    if ((rc = ensure(ctx, ctx->tmpC, sizeof(int32_t) * (size_t)n * nperms))) return rc;
+    BLMM_HIP(hipMemcpyAsync(ctx->tmpC.p, perm_idx, sizeof(int32_t) * (size_t)n * nperms, hipMemcpyHostToDevice, ctx->stream));
+    dperm = ptr<int32_t>(ctx->tmpC);
+  }
+  double* dL = ptr<double>(ctx->outL);
+  rc = blmm_scan_perms_dev(ctx, opts, ptr<double>(ctx->inY), n, ptr<double>(ctx->inG), p, dCov, dCov ? ncov : 0,
+                           ptr<double>(ctx->inK), dW, nperms, seed, dperm, ptr<double>(ctx->outH2), dL, dL + p, status);
+  if (rc) { hipStreamSynchronize(ctx->stream); return rc; }
+  BLMM_HIP(hipMemcpyAsync(scalars_out, ctx->outH2.p, sizeof(double) * 2, hipMemcpyDeviceToHost, ctx->stream));
+  if (p > 0) BLMM_HIP(hipMemcpyAsync(lod_out, dL, sizeof(double) * p, hipMemcpyDeviceToHost, ctx->stream));
+  if (p > 0 && nperms > 0) BLMM_HIP(hipMemcpyAsync(Lperms_out, dL + p, sizeof(double) * (size_t)p * nperms, hipMemcpyDeviceToHost, ctx->stream));
+  BLMM_HIP(hipStreamSynchronize(ctx->stream));
+  return BLMM_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// lower-level seams (host pointers)
+// ---------------------------------------------------------------------------------------------------
+int blmm_rotate(blmm_ctx* ctx, const blmm_opts* opts, const double* Y, int64_t n, int64_t m, const double* G, int64_t p,
+                const double* Covar, int64_t ncov, const double* K, double* Y0_out, double* X0_out, double* lambda_out,
+                blmm_status* status) {
+  if (!ctx) return BLMM_ERR_INVALID;
+  int rc = check_opts(ctx, opts);
+  if (rc) return rc;
+  if (!Y || !G || !K || !Y0_out || !X0_out || !lambda_out) return fail(ctx, BLMM_ERR_INVALID, "rotate: NULL buffer");
+  if (n < 1 || m < 1 || p < 1) return fail(ctx, BLMM_ERR_DIM, "Dimension mismatch.");
+  BLMM_HIP(hipSetDevice(ctx->device));
+  if ((rc = ensure(ctx, ctx->inY, sizeof(double) * n * m))) return rc;
+  if ((rc = ensure(ctx, ctx->inG, sizeof(double) * n * p))) return rc;
+  if ((rc = ensure(ctx, ctx->inK, sizeof(double) * n * n))) return rc;
+  BLMM_HIP(hipMemcpyAsync(ctx->inY.p, Y, sizeof(double) * n * m, hipMemcpyHostToDevice, ctx->stream));
+  BLMM_HIP(hipMemcpyAsync(ctx->inG.p, G, sizeof(double) * n * p, hipMemcpyHostToDevice, ctx->stream));
+  BLMM_HIP(hipMemcpyAsync(ctx->inK.p, K, sizeof(double) * n * n, hipMemcpyHostToDevice, ctx->stream));
+  const double* dCov = nullptr;
+  if (Covar && ncov > 0) {
+    if ((rc = ensure(ctx, ctx->inCov, sizeof(double) * n * ncov))) return rc;
+    BLMM_HIP(hipMemcpyAsync(ctx->inCov.p, Covar, sizeof(double) * n * ncov, hipMemcpyHostToDevice, ctx->stream));
+    dCov = ptr<double>(ctx->inCov);
+  }
+  Timer tm(ctx);
+  Pipe P;
+  if ((rc = prepare(ctx, opts, ptr<double>(ctx->inY), n, m, ptr<double>(ctx->inG), p, dCov, dCov ? ncov : 0,
+                    ptr<double>(ctx->inK), nullptr, 0, P, tm))) return rc;
+  if ((rc = ensure(ctx, ctx->outL, sizeof(double) * n * (size_t)(m > p ? m : p)))) return rc;
+  double* tmp = ptr<double>(ctx->outL);
+  if ((rc = launch_untranspose(ctx, P.Yt, P.ldy, (int)n, m, tmp))) return rc;
+  BLMM_HIP(hipMemcpyAsync(Y0_out, tmp, sizeof(double) * n * m, hipMemcpyDeviceToHost, ctx->stream));
+  BLMM_HIP(hipStreamSynchronize(ctx->stream));
+  if ((rc = launch_untranspose(ctx, P.Xt, P.ldx, (int)n, p, tmp))) return rc;
+  BLMM_HIP(hipMemcpyAsync(X0_out + (size_t)n * P.c, tmp, sizeof(double) * n * p, hipMemcpyDeviceToHost, ctx->stream));
+  BLMM_HIP(hipMemcpyAsync(X0_out, P.Z0, sizeof(double) * n * P.c, hipMemcpyDeviceToHost, ctx->stream));
+  BLMM_HIP(hipMemcpyAsync(lambda_out, P.lam, sizeof(double) * n, hipMemcpyDeviceToHost, ctx->stream));
+  BLMM_HIP(hipStreamSynchronize(ctx->stream));
+  return finish_status(ctx, status, nullptr);
+}
+
+namespace {
+// uploads rotated host inputs into the pipeline's internal layouts (no eigen / rotation)
+int upload_rotated(blmm_ctx* ctx, const double* Y0, int64_t n, int64_t m, const double* Z0, int64_t c, const double* X0m,
+                   int64_t p, const double* lambda, Pipe& P) {
+  if (n < 1 || m < 1 || c < 1 || c > CMAX || c >= n) return fail(ctx, BLMM_ERR_DIM, "Dimension mismatch.");
+  P.n = (int)n; P.c = (int)c; P.npad = (int)round_up(n, 4); P.ldr = (int)round_up(P.npad, 16);
+  P.m = m; P.p = p; P.ldy = round_up(m, 128); P.ldx = round_up(p > 0 ? p : 1, 128);
+  int rc;
+  if ((rc = ensure(ctx, ctx->inY, sizeof(double) * n * m))) return rc;
+  if ((rc = ensure(ctx, ctx->Yt, sizeof(double) * (size_t)P.npad * P.ldy))) return rc;
+  if ((rc = ensure(ctx, ctx->Z0, sizeof(double) * n * c))) return rc;
+  if ((rc = ensure(ctx, ctx->lam, sizeof(double) * n))) return rc;
+  if ((rc = reset_stat(ctx, &P.stat))) return rc;
+  P.Yt = ptr<double>(ctx->Yt); P.Z0 = ptr<double>(ctx->Z0); P.lam = ptr<double>(ctx->lam);
+  BLMM_HIP(hipMemcpyAsync(ctx->inY.p, Y0, sizeof(double) * n * m, hipMemcpyHostToDevice, ctx->stream));
+  BLMM_HIP(hipMemcpyAsync(P.Z0, Z0, sizeof(double) * n * c, hipMemcpyHostToDevice, ctx->stream));
+  BLMM_HIP(hipMemcpyAsync(P.lam, lambda, sizeof(double) * n, hipMemcpyHostToDevice, ctx->stream));
+  if ((rc = to_rowmajor(ctx, ptr<double>(ctx->inY), (int)n, m, P.Yt, P.npad, P.ldy))) return rc;
+  if (X0m && p > 0) {
+    if ((rc = ensure(ctx, ctx->inG, sizeof(double) * n * p))) return rc;
+    if ((rc = ensure(ctx, ctx->Xt, sizeof(double) * (size_t)P.npad * P.ldx))) return rc;
+    P.Xt = ptr<double>(ctx->Xt);
+    BLMM_HIP(hipMemcpyAsync(ctx->inG.p, X0m, sizeof(double) * n * p, hipMemcpyHostToDevice, ctx->stream));
+    if ((rc = to_rowmajor(ctx, ptr<double>(ctx->inG), (int)n, p, P.Xt, P.npad, P.ldx))) return rc;
+  }
+  return BLMM_OK;
+}
+}  // namespace
+
+int blmm_null_h2_brent(blmm_ctx* ctx, const blmm_opts* opts, const double* Y0, int64_t n, int64_t m, const double* Z0,
+                       int64_t c, const double* lambda, double* h2_out, double* sigma2_out, double* ell_out, blmm_status* status) {
+  if (!ctx) return BLMM_ERR_INVALID;
+  if (!opts || !Y0 || !Z0 || !lambda || !h2_out) return fail(ctx, BLMM_ERR_INVALID, "null_h2_brent: NULL buffer");
+  BLMM_HIP(hipSetDevice(ctx->device));
+  Pipe P;
+  int rc = upload_rotated(ctx, Y0, n, m, Z0, c, nullptr, 0, lambda, P);
+  if (rc) return rc;
+  const NullModel nm = null_model(P, opts);
+  if ((rc = ensure(ctx, ctx->h2, sizeof(double) * m))) return rc;
+  if ((rc = ensure(ctx, ctx->sig2, sizeof(double) * m))) return rc;
+  if ((rc = ensure(ctx, ctx->ell, sizeof(double) * m))) return rc;
+  if ((rc = launch_brent(ctx, nm, P.Yt, P.ldy, m, P.Z0, P.lam, ptr<double>(ctx->h2), ptr<double>(ctx->sig2), ptr<double>(ctx->ell), P.stat))) return rc;
+  BLMM_HIP(hipMemcpyAsync(h2_out, ctx->h2.p, sizeof(double) * m, hipMemcpyDeviceToHost, ctx->stream));
+  if (sigma2_out) BLMM_HIP(hipMemcpyAsync(sigma2_out, ctx->sig2.p, sizeof(double) * m, hipMemcpyDeviceToHost, ctx->stream));
+  if (ell_out) BLMM_HIP(hipMemcpyAsync(ell_out, ctx->ell.p, sizeof(double) * m, hipMemcpyDeviceToHost, ctx->stream));
+  BLMM_HIP(hipStreamSynchronize(ctx->stream));
+  return finish_status(ctx, status, nullptr);
+}
+
+int blmm_null_loglik_grid(blmm_ctx* ctx, const blmm_opts* opts, const double* Y0, int64_t n, int64_t m, const double* Z0,
+                          int64_t c, const double* lambda, const double* h2_grid, int64_t ngrid, double* Ell_out, blmm_status* status) {
+  if (!ctx) return BLMM_ERR_INVALID;
+  if (!opts || !Y0 || !Z0 || !lambda || !Ell_out) return fail(ctx, BLMM_ERR_INVALID, "null_loglik_grid: NULL buffer");
+  BLMM_HIP(hipSetDevice(ctx->device));
+  double* dgrid = nullptr;
+  int rc = grid_to_device(ctx, h2_grid, ngrid, &dgrid);
+  if (rc) return rc;
+  Pipe P;
+  if ((rc = upload_rotated(ctx, Y0, n, m, Z0, c, nullptr, 0, lambda, P))) return rc;
+  const NullModel nm = null_model(P, opts);
+  if ((rc = ensure(ctx, ctx->EllTab, sizeof(double) * (size_t)ngrid * m))) return rc;
+  if ((rc = launch_loglik_grid(ctx, nm, P.Yt, P.ldy, m, P.Z0, P.lam, dgrid, (int)ngrid, ptr<double>(ctx->EllTab), nullptr, nullptr, P.stat))) return rc;
+  BLMM_HIP(hipMemcpyAsync(Ell_out, ctx->EllTab.p, sizeof(double) * (size_t)ngrid * m, hipMemcpyDeviceToHost, ctx->stream));
+  BLMM_HIP(hipStreamSynchronize(ctx->stream));
+  return finish_status(ctx, status, nullptr);
+}
+
+int blmm_weighted_liteqtl(blmm_ctx* ctx, const double* Y0, int64_t n, int64_t m, const double* X0, int64_t c, int64_t p,
+                          const double* lambda, double hsq, double* LOD_out, blmm_status* status) {
+  if (!ctx) return BLMM_ERR_INVALID;
+  if (!Y0 || !X0 || !lambda || !LOD_out || p < 1) return fail(ctx, BLMM_ERR_INVALID, "weighted_liteqtl: bad arguments");
+  if (std::isinf(hsq / (1.0 - hsq))) return fail(ctx, BLMM_ERR_H2_ONE, "Heritability of 1 is not allowed.");
+  BLMM_HIP(hipSetDevice(ctx->device));
+  Pipe P;
+  int rc = upload_rotated(ctx, Y0, n, m, X0, c, X0 + (size_t)n * c, p, lambda, P);
+  if (rc) return rc;
+  blmm_opts o; blmm_default_opts(&o);
+  const NullModel nm = null_model(P, &o);
+  if ((rc = ensure(ctx, ctx->h2, sizeof(double) * m))) return rc;
+  if ((rc = fill(ctx, ptr<double>(ctx->h2), m, hsq))) return rc;
+  if ((rc = ensure(ctx, ctx->panels, sizeof(double) * (size_t)P.npad * P.ldy))) return rc;
+  if ((rc = launch_panels(ctx, nm, P.Yt, P.ldy, m, P.Z0, P.lam, ptr<double>(ctx->h2), 0, ptr<double>(ctx->panels), P.ldy, P.stat))) return rc;
+  if ((rc = ensure(ctx, ctx->isx, sizeof(double) * (size_t)P.ldx))) return rc;
+  if ((rc = launch_isx(ctx, nm, P.Xt, P.ldx, p, P.Z0, P.lam, ptr<double>(ctx->h2), 1, ptr<double>(ctx->isx), P.ldx, P.stat))) return rc;
+  if ((rc = ensure(ctx, ctx->outL, sizeof(double) * (size_t)p * m))) return rc;
+  ScanArgs a = scan_args(P, ptr<double>(ctx->panels), P.ldy, ptr<double>(ctx->outL), p, m);
+  a.isx = ptr<double>(ctx->isx); a.ld_isx = P.ldx;
+  if ((rc = launch_scan_table(ctx, a))) return rc;
+  BLMM_HIP(hipMemcpyAsync(LOD_out, ctx->outL.p, sizeof(double) * (size_t)p * m, hipMemcpyDeviceToHost, ctx->stream));
+  BLMM_HIP(hipStreamSynchronize(ctx->stream));
+  return finish_status(ctx, status, nullptr);
+}
+
+int blmm_liteqtl_given_h2(blmm_ctx* ctx, const double* Y0, int64_t n, int64_t m, const double* X0, int64_t c, int64_t p,
+                          const double* lambda, const double* h2, double* LOD_out, blmm_status* status) {
+  if (!ctx) return BLMM_ERR_INVALID;
+  if (!Y0 || !X0 || !lambda || !h2 || !LOD_out || p < 1) return fail(ctx, BLMM_ERR_INVALID, "liteqtl_given_h2: bad arguments");
+  for (int64_t j = 0; j < m; ++j)
+    if (std::isinf(h2[j] / (1.0 - h2[j]))) return fail(ctx, BLMM_ERR_H2_ONE, "Heritability of 1 is not allowed.");
+  BLMM_HIP(hipSetDevice(ctx->device));
+  Pipe P;
+  int rc = upload_rotated(ctx, Y0, n, m, X0, c, X0 + (size_t)n * c, p, lambda, P);
+  if (rc) return rc;
+  blmm_opts o; blmm_default_opts(&o);
+  const NullModel nm = null_model(P, &o);
+  if ((rc = ensure(ctx, ctx->h2, sizeof(double) * m))) return rc;
+  BLMM_HIP(hipMemcpyAsync(ctx->h2.p, h2, sizeof(double) * m, hipMemcpyHostToDevice, ctx->stream));
+  if ((rc = ensure(ctx, ctx->panels, sizeof(double) * (size_t)(2 + P.c) * P.npad * P.ldy))) return rc;
+  if ((rc = launch_panels(ctx, nm, P.Yt, P.ldy, m, P.Z0, P.lam, ptr<double>(ctx->h2), 1, ptr<double>(ctx->panels), P.ldy, P.stat))) return rc;
+  if ((rc = ensure(ctx, ctx->outL, sizeof(double) * (size_t)p * m))) return rc;
+  ScanArgs a = scan_args(P, ptr<double>(ctx->panels), P.ldy, ptr<double>(ctx->outL), p, m);
+  if ((rc = launch_scan_exact(ctx, a, P.c))) return rc;
+  BLMM_HIP(hipMemcpyAsync(LOD_out, ctx->outL.p, sizeof(double) * (size_t)p * m, hipMemcpyDeviceToHost, ctx->stream));
+  BLMM_HIP(hipStreamSynchronize(ctx->stream));
+  return finish_status(ctx, status, nullptr);
+}
+
+}  // extern "C"

@@ -1,0 +1,125 @@
+// Internal declarations shared by the HIP translation units of libbulklmm_hip.so.
+// Not part of the public ABI (that is include/bulklmm_hip.h).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+#include <vector>
+#include "../../include/bulklmm_hip.h"
+
+namespace blmm {
+
+typedef double d2 __attribute__((ext_vector_type(2)));
+typedef double d4 __attribute__((ext_vector_type(4)));
+
+constexpr int CMAX = 4;          // null covariates (incl. intercept) the kernels are instantiated for
+constexpr int TILE_T = 64;       // traits per workgroup tile of the scan kernels
+constexpr int TILE_I = 128;      // markers per workgroup tile of the scan kernels
+constexpr int NSTAT = 8;         // device status counters
+
+enum StatIdx { ST_NEG_EIG = 0, ST_NONPOS_W = 1, ST_ZERO_NORM = 2, ST_NAN_LOD = 3, ST_BRENT_MAXIT = 4, ST_JACOBI_SWEEPS = 5 };
+
+inline int64_t round_up(int64_t x, int64_t q) { return (x + q - 1) / q * q; }
+
+struct DevBuf {
+  void* p = nullptr;
+  size_t cap = 0;
+};
+
+}  // namespace blmm
+
+struct blmm_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+  bool timing = false;
+  std::string err;
+  // grow-only workspace
+  blmm::DevBuf Ks, V, lam, U, Zs, Z0, Rp, Yt, Xt, panels, iyy, h2, h2idx, sig2, ell, isx, stat, gridd, misc, EllTab,
+      inY, inG, inK, inCov, inW, outL, outH2, tmpA, tmpB, tmpC, perm, r0, altbuf;
+  // event sets: one per timed call since the last blmm_read_timings (grown on demand, reused afterwards)
+  struct EvSet { hipEvent_t e[8]; int n; };
+  std::vector<EvSet> evsets;
+  size_t ev_used = 0;
+};
+
+namespace blmm {
+
+// ---- error helpers -------------------------------------------------------------------------------
+int fail(blmm_ctx* ctx, int code, const std::string& msg);
+#define BLMM_HIP(call)                                                                              \
+  do {                                                                                              \
+    hipError_t e__ = (call);                                                                        \
+    if (e__ != hipSuccess)                                                                          \
+      return blmm::fail(ctx, BLMM_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e__));     \
+  } while (0)
+
+int ensure(blmm_ctx* ctx, DevBuf& b, size_t bytes);
+template <typename T>
+inline T* ptr(DevBuf& b) { return reinterpret_cast<T*>(b.p); }
+
+// ---- kernel launchers (kernels_prep.hip) ----------------------------------------------------------
+struct Design {
+  int n = 0, c = 0, npad = 0;   // npad: n rounded up to 4 (K dimension of the f64 MFMA)
+  int ldr = 0;                  // leading dimension of Rp (npad rounded up to 16)
+};
+
+// Builds Zs = wd .* [1 Covar] (n x c) and Ks = wd_i wd_j K_ij (n x n).
+int launch_design(blmm_ctx* ctx, const double* dK, const double* dCovar, int ncov, int add_intercept,
+                  const double* dweights, int n, double* Ks, double* Zs);
+// One-sided Jacobi eigen-decomposition of the symmetric n x n matrix in A (destroyed); V gets the eigenvectors
+// (unsorted), then post_eigen sorts/derives everything the rotation needs.
+int launch_jacobi(blmm_ctx* ctx, double* A, double* V, int n, int64_t* stat);
+// lambda (ascending, or |lambda| descending for svd), U sorted, Z0 = U' Zs, Rp = (centered ? Q U' Wd : U' Wd)'
+int launch_post_eigen(blmm_ctx* ctx, const double* A, const double* V, const double* Zs, const double* dweights, int n,
+                      int c, int npad, int ldr, int decomp, int centered, double* lam, double* U, double* Z0, double* Rp,
+                      int64_t* stat);
+// Out (row-major, npad x ldo) = R * In  (In column-major n x ncols); pads with zeros up to ncols_pad / npad.
+int launch_rotate(blmm_ctx* ctx, const double* Rp, int ldr, int n, int npad, const double* In, int64_t ncols,
+                  double* Out, int64_t ldo, int64_t ncols_pad);
+// row-major (npad x ld) -> column-major (n x ncols)
+int launch_untranspose(blmm_ctx* ctx, const double* In, int64_t ld, int n, int64_t ncols, double* Out);
+
+struct NullModel {
+  int n, c, npad, reml, optim_interval;
+  double prior_a, prior_b;
+};
+// per-trait Brent h2 (fitlmm) from centred/rotated Yt; outputs m each (sigma2/ell may be null)
+int launch_brent(blmm_ctx* ctx, const NullModel& nm, const double* Yt, int64_t ldy, int64_t m, const double* Z0,
+                 const double* lam, double* h2, double* sigma2, double* ell, int64_t* stat);
+// Ell[g, j] for every grid point and first-argmax; EllTab (ngrid x m, ld = ngrid) may be null
+int launch_loglik_grid(blmm_ctx* ctx, const NullModel& nm, const double* Yt, int64_t ldy, int64_t m, const double* Z0,
+                       const double* lam, const double* grid_dev, int ngrid, double* EllTab, int* h2idx, double* h2,
+                       int64_t* stat);
+// A-side panels for the scan kernels from per-trait h2: panel 0 = w.*resid/sqrt(yy); if full: panel 1 = w,
+// panels 2..1+c = w .* (Z0 Linv')_q.  panels: [np][npad][ldp]
+int launch_panels(blmm_ctx* ctx, const NullModel& nm, const double* Yt, int64_t ldy, int64_t m, const double* Z0,
+                  const double* lam, const double* h2, int full, double* panels, int64_t ldp, int64_t* stat);
+// isx[g][i] = 1/||P_g sqrt(w_g) x_i|| for every grid point
+int launch_isx(blmm_ctx* ctx, const NullModel& nm, const double* Xt, int64_t ldx, int64_t p, const double* Z0,
+               const double* lam, const double* grid_dev, int ngrid, double* isx, int64_t ld_isx, int64_t* stat);
+int launch_kinship(blmm_ctx* ctx, const double* dG, int64_t n, int64_t p, double* dK, double* partial);
+// permutation panel: column b = sqrt(w) .* P_w( pi_b(r0) ) / ||r0||  etc.  (see kernels_prep.hip)
+int launch_perm_panel(blmm_ctx* ctx, const NullModel& nm, const double* Yt, int64_t ldy, const double* Z0,
+                      const double* lam, const double* h2, const int32_t* perm_idx, int64_t nperms, uint64_t seed,
+                      int orig, double* panel, int64_t ldp, int64_t* stat);
+
+// ---- kernel launchers (kernels_scan.hip) ----------------------------------------------------------
+struct ScanArgs {
+  const double* Xt; int64_t ldx;           // markers, row-major npad x ldx (unweighted, centred, rotated)
+  const double* P; int64_t ldp; int64_t pstride;  // A-side panels [np][npad][ldp]
+  int ks;                                  // npad / 4
+  int n;                                   // sample size (LOD scale = -n/2)
+  int64_t p, m;
+  double* L; int64_t ldL;
+  const double* isx; int64_t ld_isx; const int* bin;  // table mode
+  int64_t* stat;
+};
+int launch_scan_exact(blmm_ctx* ctx, const ScanArgs& a, int c);
+int launch_scan_table(blmm_ctx* ctx, const ScanArgs& a);
+struct AltArgs {
+  ScanArgs s; int ngrid; const double* EllTab; /* ngrid x m */ const double* grid_dev; double* H2; int64_t ldH; int counter_quirk;
+};
+int launch_scan_alt(blmm_ctx* ctx, const AltArgs& a);
+
+}  // namespace blmm

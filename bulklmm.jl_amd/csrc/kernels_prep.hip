@@ -1,0 +1,1006 @@
+// kernels_prep.hip -- everything that runs once per scan before the LOD kernels:
+//   design/weights, device eigensolver (one-sided Jacobi), rotation matrix, rotation GEMM (f64 MFMA),
+//   per-trait null-model h2 (Optim-style Brent / grid), A-side panels, per-grid marker norms, kinship.
+// gfx950 only.  Reference anchors are cited per kernel (paths relative to the BulkLMM.jl checkout).
+#include "blmm_internal.h"
+#include <cmath>
+
+namespace blmm {
+
+#define KCHECK()                                                                                      \
+  do {                                                                                                \
+    hipError_t e__ = hipGetLastError();                                                               \
+    if (e__ != hipSuccess) return fail(ctx, BLMM_ERR_HIP, std::string("kernel launch: ") + hipGetErrorString(e__)); \
+  } while (0)
+
+// ------------------------------------------------------------------------------------------------
+// design: Zs = wd .* [1 Covar], Ks = wd wd' .* K        (src/bulkscan.jl:231-250, src/scan.jl:201-221)
+// ------------------------------------------------------------------------------------------------
+__global__ void k_design(const double* __restrict__ K, const double* __restrict__ Covar, int ncov, int add_intercept,
+                         const double* __restrict__ wd, int n, double* __restrict__ Ks, double* __restrict__ Zs) {
+  const int64_t tid = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t e = tid; e < (int64_t)n * n; e += stride) {
+    const int i = (int)(e % n), j = (int)(e / n);
+    double v = K[e];
+    if (wd) v *= wd[i] * wd[j];
+    Ks[e] = v;
+  }
+  const int c = ncov + (add_intercept ? 1 : 0);
+  for (int64_t e = tid; e < (int64_t)n * c; e += stride) {
+    const int i = (int)(e % n), q = (int)(e / n);
+    double v;
+    if (add_intercept) v = (q == 0) ? 1.0 : Covar[(int64_t)(q - 1) * n + i];
+    else v = Covar[(int64_t)q * n + i];
+    if (wd) v *= wd[i];
+    Zs[e] = v;
+  }
+}
+
+int launch_design(blmm_ctx* ctx, const double* dK, const double* dCovar, int ncov, int add_intercept,
+                  const double* dweights, int n, double* Ks, double* Zs) {
+  int blocks = (int)std::min<int64_t>(1024, ((int64_t)n * n + 255) / 256);
+  hipLaunchKernelGGL(k_design, dim3(blocks), dim3(256), 0, ctx->stream, dK, dCovar, ncov, add_intercept, dweights, n, Ks, Zs);
+  KCHECK();
+  return BLMM_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Eigen-decomposition of the symmetric kinship: one-sided (Hestenes) Jacobi, one workgroup.
+// Replaces LAPACK `eigen(K)` / `svd(K)` of src/transform_helpers.jl:21-49.  LODs do not depend on the
+// eigenbasis chosen, only on K = U diag(lambda) U' holding to rounding.
+// A (n x n, column-major) starts as K and ends as K*V = V*diag(lambda); V accumulates the rotations.
+// ------------------------------------------------------------------------------------------------
+template <bool USE_LDS>
+__global__ void __launch_bounds__(1024) k_jacobi(double* __restrict__ Ag, double* __restrict__ Vg, int n, int64_t* stat) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  __shared__ int s_rot;
+  double* A = USE_LDS ? smem : Ag;
+  double* V = USE_LDS ? smem + (size_t)n * n : Vg;
+  const int tid = threadIdx.x;
+  const int l16 = tid & 15, grp = tid >> 4, ngrp = blockDim.x >> 4;
+  for (int e = tid; e < n * n; e += blockDim.x) {
+    if (USE_LDS) A[e] = Ag[e];
+    V[e] = ((e % n) == (e / n)) ? 1.0 : 0.0;
+  }
+  __syncthreads();
+  const int N = n + (n & 1);
+  const double tol = sqrt((double)n) * 2.220446049250313e-16;
+  int sweep = 0;
+  for (; sweep < 40; ++sweep) {
+    if (tid == 0) s_rot = 0;
+    __syncthreads();
+    for (int round = 0; round < N - 1; ++round) {
+      for (int pr = grp; pr < N / 2; pr += ngrp) {
+        int i, j;
+        if (pr == 0) { i = N - 1; j = round; }
+        else { i = (round + pr) % (N - 1); j = (round - pr + (N - 1)) % (N - 1); }
+        if (i > j) { int t = i; i = j; j = t; }
+        if (j >= n) continue;  // padded player
+        double* ai = A + (size_t)i * n;
+        double* aj = A + (size_t)j * n;
+        double alpha = 0, beta = 0, gamma = 0;
+        for (int k = l16; k < n; k += 16) {
+          const double x = ai[k], y = aj[k];
+          alpha = fma(x, x, alpha); beta = fma(y, y, beta); gamma = fma(x, y, gamma);
+        }
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1) {
+          alpha += __shfl_xor(alpha, o, 16); beta += __shfl_xor(beta, o, 16); gamma += __shfl_xor(gamma, o, 16);
+        }
+        if (gamma != 0.0 && fabs(gamma) > tol * sqrt(alpha * beta)) {
+          if (l16 == 0) s_rot = 1;
+          const double zeta = (beta - alpha) / (2.0 * gamma);
+          const double t = copysign(1.0, zeta) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+          const double c = 1.0 / sqrt(1.0 + t * t), s = c * t;
+          double* vi = V + (size_t)i * n;
+          double* vj = V + (size_t)j * n;
+          for (int k = l16; k < n; k += 16) {
+            const double x = ai[k], y = aj[k];
+            ai[k] = c * x - s * y; aj[k] = s * x + c * y;
+            const double u = vi[k], w = vj[k];
+            vi[k] = c * u - s * w; vj[k] = s * u + c * w;
+          }
+        }
+      }
+      __syncthreads();
+    }
+    const int rot = s_rot;
+    __syncthreads();
+    if (!rot) break;
+  }
+  if (USE_LDS) {
+    for (int e = tid; e < n * n; e += blockDim.x) { Ag[e] = A[e]; Vg[e] = V[e]; }
+  }
+  if (tid == 0) stat[ST_JACOBI_SWEEPS] = sweep + 1;
+}
+
+int launch_jacobi(blmm_ctx* ctx, double* A, double* V, int n, int64_t* stat) {
+  const size_t lds = (size_t)2 * n * n * sizeof(double);
+  if (lds <= 150 * 1024) {
+    BLMM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_jacobi<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(k_jacobi<true>, dim3(1), dim3(1024), lds, ctx->stream, A, V, n, stat);
+  } else {
+    hipLaunchKernelGGL(k_jacobi<false>, dim3(1), dim3(1024), 0, ctx->stream, A, V, n, stat);
+  }
+  KCHECK();
+  return BLMM_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// post-eigen: eigenvalues, ordering, Z0 = U' Zs, and the rotation matrix
+//   R = Q U' Wd,  Q = I - Z0 (Z0'Z0)^-1 Z0'  (centered = 1; the LOD statistic and the null likelihood are
+//   invariant to this unweighted projection -- SURVEY.md A.4 -- it only tames cancellation), or
+//   R = U' Wd (centered = 0; literal transform_rotation, src/transform_helpers.jl:34).
+// Rp[i*ldr + k] = R[k, i], zero padded to npad x ldr (the A-operand layout of k_rotate).
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(1024) k_post_eigen(const double* __restrict__ A, const double* __restrict__ V,
+                                                     const double* __restrict__ Zs, const double* __restrict__ wd, int n,
+                                                     int c, int npad, int ldr, int decomp, int centered,
+                                                     double* __restrict__ lam, double* __restrict__ U,
+                                                     double* __restrict__ Z0, double* __restrict__ Rp,
+                                                     double* __restrict__ tmp /* n + c*n */, int64_t* stat) {
+  __shared__ double Ginv[CMAX * CMAX];
+  __shared__ int s_neg;
+  const int tid = threadIdx.x, nt = blockDim.x;
+  double* lraw = tmp;          // n
+  double* Bq = tmp + n;        // c x n : Ginv * (Zs' Wd)
+  if (tid == 0) s_neg = 0;
+  for (int i = tid; i < n; i += nt) {
+    double s = 0;
+    for (int k = 0; k < n; ++k) s = fma(V[(size_t)i * n + k], A[(size_t)i * n + k], s);
+    lraw[i] = (decomp == BLMM_SVD) ? fabs(s) : s;
+  }
+  __syncthreads();
+  for (int i = tid; i < n; i += nt) {
+    const double li = lraw[i];
+    int rank = 0;
+    for (int j = 0; j < n; ++j) {
+      const double lj = lraw[j];
+      if (decomp == BLMM_SVD) rank += (lj > li) || (lj == li && j < i);
+      else rank += (lj < li) || (lj == li && j < i);
+    }
+    lam[rank] = li;
+    if (li < -1e-7) atomicAdd(&s_neg, 1);
+    // deterministic sign: the largest-magnitude component of every eigenvector is positive (LAPACK leaves the
+    // sign unspecified; only the permutation test depends on it)
+    double big = 0.0;
+    for (int k = 0; k < n; ++k) { const double v = V[(size_t)i * n + k]; if (fabs(v) > fabs(big)) big = v; }
+    const double sg = (big < 0.0) ? -1.0 : 1.0;
+    for (int k = 0; k < n; ++k) U[(size_t)rank * n + k] = sg * V[(size_t)i * n + k];
+  }
+  __syncthreads();
+  if (tid == 0 && s_neg) stat[ST_NEG_EIG] += s_neg;
+  // Z0[k,q] = sum_i U[i,k] Zs[i,q]
+  for (int e = tid; e < n * c; e += nt) {
+    const int k = e % n, q = e / n;
+    double s = 0;
+    for (int i = 0; i < n; ++i) s = fma(U[(size_t)k * n + i], Zs[(size_t)q * n + i], s);
+    Z0[e] = s;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    // Gram = Z0'Z0, inverse by Gauss-Jordan (c <= CMAX)
+    double G[CMAX][2 * CMAX];
+    for (int a = 0; a < c; ++a)
+      for (int b = 0; b < c; ++b) {
+        double s = 0;
+        for (int k = 0; k < n; ++k) s = fma(Z0[(size_t)a * n + k], Z0[(size_t)b * n + k], s);
+        G[a][b] = s; G[a][c + b] = (a == b) ? 1.0 : 0.0;
+      }
+    for (int a = 0; a < c; ++a) {
+      int piv = a;
+      for (int r = a + 1; r < c; ++r) if (fabs(G[r][a]) > fabs(G[piv][a])) piv = r;
+      if (piv != a) for (int b = 0; b < 2 * c; ++b) { double t = G[a][b]; G[a][b] = G[piv][b]; G[piv][b] = t; }
+      const double d = 1.0 / G[a][a];
+      for (int b = 0; b < 2 * c; ++b) G[a][b] *= d;
+      for (int r = 0; r < c; ++r) if (r != a) { const double f = G[r][a]; for (int b = 0; b < 2 * c; ++b) G[r][b] -= f * G[a][b]; }
+    }
+    for (int a = 0; a < c; ++a) for (int b = 0; b < c; ++b) Ginv[a * CMAX + b] = G[a][c + b];
+  }
+  __syncthreads();
+  // Bq[q,i] = sum_r Ginv[q,r] * (Z0' U' Wd)[r,i] = sum_r Ginv[q,r] * Zs[i,r] * wd_i   (U Z0 = Zs)
+  for (int e = tid; e < n * c; e += nt) {
+    const int i = e % n, q = e / n;
+    double s = 0;
+    for (int r = 0; r < c; ++r) s = fma(Ginv[q * CMAX + r], Zs[(size_t)r * n + i], s);
+    Bq[(size_t)q * n + i] = s * (wd ? wd[i] : 1.0);
+  }
+  __syncthreads();
+  for (int e = tid; e < npad * ldr; e += nt) {
+    const int k = e % ldr, i = e / ldr;
+    double v = 0.0;
+    if (i < n && k < n) {
+      v = U[(size_t)k * n + i] * (wd ? wd[i] : 1.0);
+      if (centered)
+        for (int q = 0; q < c; ++q) v = fma(-Z0[(size_t)q * n + k], Bq[(size_t)q * n + i], v);
+    }
+    Rp[e] = v;
+  }
+}
+
+int launch_post_eigen(blmm_ctx* ctx, const double* A, const double* V, const double* Zs, const double* dweights, int n,
+                      int c, int npad, int ldr, int decomp, int centered, double* lam, double* U, double* Z0, double* Rp,
+                      int64_t* stat) {
+  int rc = ensure(ctx, ctx->misc, sizeof(double) * ((size_t)n + (size_t)c * n + 64));
+  if (rc) return rc;
+  hipLaunchKernelGGL(k_post_eigen, dim3(1), dim3(1024), 0, ctx->stream, A, V, Zs, dweights, n, c, npad, ldr, decomp,
+                     centered, lam, U, Z0, Rp, ptr<double>(ctx->misc), stat);
+  KCHECK();
+  return BLMM_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// rotation GEMM on the f64 matrix cores:  Out[k][j] = sum_i R[k,i] * In[i,j]
+//   (Ut*y, Ut*X of src/transform_helpers.jl:34, with the centring folded into R).
+// One wave = 16 input columns x (MBLK x 16) output rows; v_mfma_f64_16x16x4_f64:
+//   A frag: lane l holds A[row = l&15][k = l>>4];  B frag: B[k = l>>4][col = l&15];
+//   D: col = l&15, row = (l>>4) + 4*reg   (cdna_hip_programming.md §3, verified by tools/mb_f64.hip).
+// In is column-major n x ncols; Out is row-major (npad rows) with leading dimension ldo.
+// ------------------------------------------------------------------------------------------------
+template <int MBLK>
+__global__ void __launch_bounds__(256) k_rotate(const double* __restrict__ Rp, int ldr, int n, int npad,
+                                                const double* __restrict__ In, int64_t ncols,
+                                                double* __restrict__ Out, int64_t ldo, int64_t ncols_pad) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t col = ((int64_t)blockIdx.x * 4 + wave) * 16 + (lane & 15);
+  const int rb0 = blockIdx.y * MBLK;  // first 16-row block of this wave
+  const int kk = lane >> 4;
+  d4 acc[MBLK];
+#pragma unroll
+  for (int b = 0; b < MBLK; ++b) acc[b] = (d4){0, 0, 0, 0};
+  const bool colok = col < ncols;
+  const double* pin = In + (colok ? col : 0) * (int64_t)n;
+  for (int i0 = 0; i0 < npad; i0 += 4) {
+    const int i = i0 + kk;
+    const double bv = (colok && i < n) ? pin[i] : 0.0;
+    const double* pr = Rp + (size_t)i * ldr + (lane & 15);
+#pragma unroll
+    for (int b = 0; b < MBLK; ++b) {
+      const int r0 = (rb0 + b) * 16;
+      const double av = (r0 < ldr) ? pr[r0] : 0.0;
+      acc[b] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc[b], 0, 0, 0);
+    }
+  }
+  if (col < ncols_pad) {
+#pragma unroll
+    for (int b = 0; b < MBLK; ++b)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = (rb0 + b) * 16 + kk + 4 * r;
+        if (row < npad) Out[(int64_t)row * ldo + col] = acc[b][r];
+      }
+  }
+}
+
+int launch_rotate(blmm_ctx* ctx, const double* Rp, int ldr, int n, int npad, const double* In, int64_t ncols,
+                  double* Out, int64_t ldo, int64_t ncols_pad) {
+  constexpr int MBLK = 5;
+  const int nrb = (npad + 15) / 16;
+  dim3 grid((unsigned)((ncols_pad + 63) / 64), (unsigned)((nrb + MBLK - 1) / MBLK));
+  hipLaunchKernelGGL(k_rotate<MBLK>, grid, dim3(256), 0, ctx->stream, Rp, ldr, n, npad, In, ncols, Out, ldo, ncols_pad);
+  KCHECK();
+  return BLMM_OK;
+}
+
+__global__ void k_untranspose(const double* __restrict__ In, int64_t ld, int n, int64_t ncols, double* __restrict__ Out) {
+  __shared__ double tile[32][33];
+  const int64_t c0 = (int64_t)blockIdx.x * 32;
+  const int r0 = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+  for (int r = ty; r < 32; r += 8) {
+    const int row = r0 + r; const int64_t col = c0 + tx;
+    tile[r][tx] = (row < n && col < ncols) ? In[(int64_t)row * ld + col] : 0.0;
+  }
+  __syncthreads();
+  for (int cc = ty; cc < 32; cc += 8) {
+    const int64_t col = c0 + cc; const int row = r0 + tx;
+    if (row < n && col < ncols) Out[col * n + row] = tile[tx][cc];
+  }
+}
+
+int launch_untranspose(blmm_ctx* ctx, const double* In, int64_t ld, int n, int64_t ncols, double* Out) {
+  dim3 grid((unsigned)((ncols + 31) / 32), (unsigned)((n + 31) / 32));
+  hipLaunchKernelGGL(k_untranspose, grid, dim3(256), 0, ctx->stream, In, ld, n, ncols, Out);
+  KCHECK();
+  return BLMM_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Null model: -ell(h2) for one trait, LPT lanes per trait            (src/wls.jl:27-97, src/lmm.jl:15-33)
+//   w_k = 1/(delta lambda_k + 1);  A = Z0'WZ0, v = Z0'Wy, Syy = y'Wy;  rss = Syy - v'A^-1 v
+//   sigma2 = (rss + a b)/(n [-c] + b_df);  ell = -1/2 [(n+b) ln sigma2 - sum ln w + (rss + a b)/sigma2]
+//   REML: + 1/2 [c ln sigma2 - ln det A]
+// ------------------------------------------------------------------------------------------------
+struct EllOut { double ell, sigma2, yy; };
+
+template <int C, int LPT>
+__device__ __forceinline__ EllOut null_ell(double h2, const double* __restrict__ ycol, int64_t ystride, int sub, int n,
+                                           const double* __restrict__ sZ /* [C][n] */, const double* __restrict__ sLam,
+                                           double prior_a, double prior_b, int reml, int* nonpos) {
+  constexpr int NA = C * (C + 1) / 2;
+  const double delta = h2 / (1.0 - h2);
+  double A[NA], v[C], syy = 0.0, logsum = 0.0, prod = 1.0;
+#pragma unroll
+  for (int a = 0; a < NA; ++a) A[a] = 0.0;
+#pragma unroll
+  for (int q = 0; q < C; ++q) v[q] = 0.0;
+  int cnt = 0, bad = 0;
+  for (int k = sub; k < n; k += LPT) {
+    const double t = fma(delta, sLam[k], 1.0);
+    const double w = 1.0 / t;
+    bad |= !(w > 0.0);
+    prod *= t;
+    if (++cnt == 8) { logsum += log(prod); prod = 1.0; cnt = 0; }
+    const double y = ycol[(int64_t)k * ystride];
+    const double wy = w * y;
+    syy = fma(wy, y, syy);
+#pragma unroll
+    for (int q = 0; q < C; ++q) {
+      const double zq = sZ[q * n + k];
+      v[q] = fma(wy, zq, v[q]);
+      const double wz = w * zq;
+#pragma unroll
+      for (int r = 0; r <= q; ++r) A[q * (q + 1) / 2 + r] = fma(wz, sZ[r * n + k], A[q * (q + 1) / 2 + r]);
+    }
+  }
+  logsum += log(prod);
+#pragma unroll
+  for (int o = 1; o < LPT; o <<= 1) {
+    syy += __shfl_xor(syy, o, LPT); logsum += __shfl_xor(logsum, o, LPT);
+#pragma unroll
+    for (int a = 0; a < NA; ++a) A[a] += __shfl_xor(A[a], o, LPT);
+#pragma unroll
+    for (int q = 0; q < C; ++q) v[q] += __shfl_xor(v[q], o, LPT);
+  }
+  if (bad && nonpos) *nonpos = 1;
+  // Cholesky A = L L', t = L^-1 v
+  double L[NA], t[C], logdet = 0.0, tt = 0.0;
+#pragma unroll
+  for (int q = 0; q < C; ++q) {
+#pragma unroll
+    for (int r = 0; r <= q; ++r) {
+      double s = A[q * (q + 1) / 2 + r];
+#pragma unroll
+      for (int u = 0; u < r; ++u) s = fma(-L[q * (q + 1) / 2 + u], L[r * (r + 1) / 2 + u], s);
+      if (r == q) { L[q * (q + 1) / 2 + q] = sqrt(s); logdet += log(s); }
+      else L[q * (q + 1) / 2 + r] = s / L[r * (r + 1) / 2 + r];
+    }
+    double s = v[q];
+#pragma unroll
+    for (int u = 0; u < q; ++u) s = fma(-L[q * (q + 1) / 2 + u], t[u], s);
+    t[q] = s / L[q * (q + 1) / 2 + q];
+    tt = fma(t[q], t[q], tt);
+  }
+  const double rss = syy - tt;
+  const double prior_df = prior_b > 0.0 ? prior_b + 2.0 : prior_b;
+  const double num = rss + prior_a * prior_b;
+  const double sigma2 = num / ((reml ? (double)(n - C) : (double)n) + prior_df);
+  const double ls = log(sigma2);
+  double ell = -0.5 * (((double)n + prior_b) * ls + logsum + num / sigma2);  // -sum ln w = +sum ln t
+  if (reml) ell += 0.5 * ((double)C * ls - logdet);
+  EllOut o; o.ell = ell; o.sigma2 = sigma2; o.yy = rss;
+  return o;
+}
+
+constexpr int BRENT_LPT = 4;
+
+// Optim.jl Brent() restated (third-party; see oracle/bulklmm_oracle.py:brent_optim and SURVEY.md A.3),
+// gridbrent sub-intervals (src/gridbrent.jl:9-24), final wls at the minimiser (src/lmm.jl:84).
+template <int C>
+__global__ void __launch_bounds__(256) k_brent(NullModel nm, const double* __restrict__ Yt, int64_t ldy, int64_t m,
+                                               const double* __restrict__ Z0, const double* __restrict__ lam,
+                                               double* __restrict__ h2out, double* __restrict__ s2out,
+                                               double* __restrict__ ellout, int64_t* stat) {
+  extern __shared__ __attribute__((aligned(16))) double sh[];
+  const int n = nm.n;
+  double* sLam = sh;       // n
+  double* sZ = sh + n;     // C*n
+  for (int e = threadIdx.x; e < n; e += blockDim.x) sLam[e] = lam[e];
+  for (int e = threadIdx.x; e < n * C; e += blockDim.x) sZ[e] = Z0[e];
+  __syncthreads();
+  constexpr int LPT = BRENT_LPT;
+  const int64_t j = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / LPT;
+  const int sub = threadIdx.x % LPT;
+  const bool valid = j < m;
+  const double* ycol = Yt + (valid ? j : 0);
+  int nonpos = 0;
+  auto f = [&](double h2) { return -null_ell<C, LPT>(h2, ycol, ldy, sub, n, sZ, sLam, nm.prior_a, nm.prior_b, nm.reml, &nonpos).ell; };
+
+  const double golden = 0.5 * (3.0 - sqrt(5.0));
+  const double rel_tol = 1.4901161193847656e-08, abs_tol = 2.220446049250313e-16;
+  double best_x = 0.0, best_f = INFINITY;
+  int hit_max = 0;
+  const int nint = nm.optim_interval < 1 ? 1 : nm.optim_interval;
+  for (int iv = 0; iv < nint; ++iv) {
+    // points = range(0, 1, length = nint+1)
+    double x_lower = (double)iv / (double)nint, x_upper = (iv + 1 == nint) ? 1.0 : (double)(iv + 1) / (double)nint;
+    double new_minimizer = x_lower + golden * (x_upper - x_lower);
+    double new_minimum = f(new_minimizer);
+    double step = 0.0, old_step = 0.0;
+    double old_minimizer = new_minimizer, old_old_minimizer = new_minimizer;
+    double old_minimum = new_minimum, old_old_minimum = new_minimum;
+    bool done = !valid;
+    int it = 0;
+    for (; it < 1000; ++it) {
+      double p = 0.0, q = 0.0;
+      const double x_tol = rel_tol * fabs(new_minimizer) + abs_tol;
+      const double x_mid = (x_upper + x_lower) / 2;
+      if (fabs(new_minimizer - x_mid) <= 2 * x_tol - (x_upper - x_lower) / 2) done = true;
+      if (__all(done)) break;
+      if (fabs(old_step) > x_tol) {
+        const double r = (new_minimizer - old_minimizer) * (new_minimum - old_old_minimum);
+        q = (new_minimizer - old_old_minimizer) * (new_minimum - old_minimum);
+        p = (new_minimizer - old_old_minimizer) * q - (new_minimizer - old_minimizer) * r;
+        q = 2 * (q - r);
+        if (q > 0) p = -p; else q = -q;
+      }
+      double nstep, nold;
+      if (fabs(p) < fabs(q * old_step / 2) && p < q * (x_upper - new_minimizer) && p < q * (new_minimizer - x_lower)) {
+        nold = step;
+        nstep = p / q;
+        const double x_temp = new_minimizer + nstep;
+        if ((x_temp - x_lower) < 2 * x_tol || (x_upper - x_temp) < 2 * x_tol) nstep = (new_minimizer < x_mid) ? x_tol : -x_tol;
+      } else {
+        nold = (new_minimizer < x_mid) ? x_upper - new_minimizer : x_lower - new_minimizer;
+        nstep = golden * nold;
+      }
+      const double new_x = (fabs(nstep) >= x_tol) ? new_minimizer + nstep : new_minimizer + ((nstep > 0) ? x_tol : -x_tol);
+      const double new_f = f(done ? new_minimizer : new_x);
+      if (!done) {
+        old_step = nold; step = nstep;
+        if (new_f < new_minimum) {
+          if (new_x < new_minimizer) x_upper = new_minimizer; else x_lower = new_minimizer;
+          old_old_minimizer = old_minimizer; old_old_minimum = old_minimum;
+          old_minimizer = new_minimizer; old_minimum = new_minimum;
+          new_minimizer = new_x; new_minimum = new_f;
+        } else {
+          if (new_x < new_minimizer) x_lower = new_x; else x_upper = new_x;
+          if (new_f <= old_minimum || old_minimizer == new_minimizer) {
+            old_old_minimizer = old_minimizer; old_old_minimum = old_minimum;
+            old_minimizer = new_x; old_minimum = new_f;
+          } else if (new_f <= old_old_minimum || old_old_minimizer == new_minimizer || old_old_minimizer == old_minimizer) {
+            old_old_minimizer = new_x; old_old_minimum = new_f;
+          }
+        }
+      }
+    }
+    if (it >= 1000 && !done) hit_max = 1;
+    if (new_minimum < best_f || iv == 0) { best_f = new_minimum; best_x = new_minimizer; }  // argmin: first wins
+  }
+  const EllOut fin = null_ell<C, LPT>(best_x, ycol, ldy, sub, n, sZ, sLam, nm.prior_a, nm.prior_b, nm.reml, &nonpos);
+  if (valid && sub == 0) {
+    h2out[j] = best_x;
+    if (s2out) s2out[j] = fin.sigma2;
+    if (ellout) ellout[j] = fin.ell;
+    if (hit_max) atomicAdd((unsigned long long*)&stat[ST_BRENT_MAXIT], 1ull);
+    if (nonpos) atomicAdd((unsigned long long*)&stat[ST_NONPOS_W], 1ull);
+  }
+}
+
+template <int C>
+static int launch_brent_c(blmm_ctx* ctx, const NullModel& nm, const double* Yt, int64_t ldy, int64_t m, const double* Z0,
+                          const double* lam, double* h2, double* sigma2, double* ell, int64_t* stat) {
+  const int64_t threads = m * BRENT_LPT;
+  const unsigned blocks = (unsigned)((threads + 255) / 256);
+  const size_t lds = sizeof(double) * (size_t)nm.n * (1 + C);
+  hipLaunchKernelGGL(k_brent<C>, dim3(blocks), dim3(256), lds, ctx->stream, nm, Yt, ldy, m, Z0, lam, h2, sigma2, ell, stat);
+  KCHECK();
+  return BLMM_OK;
+}
+
+int launch_brent(blmm_ctx* ctx, const NullModel& nm, const double* Yt, int64_t ldy, int64_t m, const double* Z0,
+                 const double* lam, double* h2, double* sigma2, double* ell, int64_t* stat) {
+  switch (nm.c) {
+    case 1: return launch_brent_c<1>(ctx, nm, Yt, ldy, m, Z0, lam, h2, sigma2, ell, stat);
+    case 2: return launch_brent_c<2>(ctx, nm, Yt, ldy, m, Z0, lam, h2, sigma2, ell, stat);
+    case 3: return launch_brent_c<3>(ctx, nm, Yt, ldy, m, Z0, lam, h2, sigma2, ell, stat);
+    case 4: return launch_brent_c<4>(ctx, nm, Yt, ldy, m, Z0, lam, h2, sigma2, ell, stat);
+  }
+  return fail(ctx, BLMM_ERR_UNSUPPORTED, "number of null covariates (incl. intercept) must be 1..4");
+}
+
+// Ell[g, j] = wls_multivar(Y0, Z0, makeweights(grid[g]), prior).Ell  (src/bulkscan_helpers.jl:267-269),
+// per-trait first arg-max (find_optim_h2, src/bulkscan_helpers.jl:204-211).
+template <int C>
+__global__ void __launch_bounds__(256) k_loglik_grid(NullModel nm, const double* __restrict__ Yt, int64_t ldy, int64_t m,
+                                                     const double* __restrict__ Z0, const double* __restrict__ lam,
+                                                     const double* __restrict__ grid, int ngrid,
+                                                     double* __restrict__ EllTab, int* __restrict__ h2idx,
+                                                     double* __restrict__ h2out, int64_t* stat) {
+  extern __shared__ __attribute__((aligned(16))) double sh[];
+  const int n = nm.n;
+  double* sLam = sh;
+  double* sZ = sh + n;
+  for (int e = threadIdx.x; e < n; e += blockDim.x) sLam[e] = lam[e];
+  for (int e = threadIdx.x; e < n * C; e += blockDim.x) sZ[e] = Z0[e];
+  __syncthreads();
+  constexpr int LPT = BRENT_LPT;
+  const int64_t j = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / LPT;
+  const int sub = threadIdx.x % LPT;
+  const bool valid = j < m;
+  const double* ycol = Yt + (valid ? j : 0);
+  int nonpos = 0, best = 0;
+  double bestv = -INFINITY;
+  for (int g = 0; g < ngrid; ++g) {
+    const EllOut e = null_ell<C, LPT>(grid[g], ycol, ldy, sub, n, sZ, sLam, nm.prior_a, nm.prior_b, nm.reml, &nonpos);
+    if (valid && sub == 0 && EllTab) EllTab[j * (int64_t)ngrid + g] = e.ell;
+    if (g == 0 || e.ell > bestv) { bestv = e.ell; best = g; }
+  }
+  if (valid && sub == 0) {
+    if (h2idx) h2idx[j] = best;
+    if (h2out) h2out[j] = grid[best];
+    if (nonpos) atomicAdd((unsigned long long*)&stat[ST_NONPOS_W], 1ull);
+  }
+}
+
+int launch_loglik_grid(blmm_ctx* ctx, const NullModel& nm, const double* Yt, int64_t ldy, int64_t m, const double* Z0,
+                       const double* lam, const double* grid_dev, int ngrid, double* EllTab, int* h2idx, double* h2,
+                       int64_t* stat) {
+  const int64_t threads = m * BRENT_LPT;
+  const unsigned blocks = (unsigned)((threads + 255) / 256);
+  const size_t lds = sizeof(double) * (size_t)nm.n * (1 + nm.c);
+#define LG(C) hipLaunchKernelGGL(k_loglik_grid<C>, dim3(blocks), dim3(256), lds, ctx->stream, nm, Yt, ldy, m, Z0, lam, grid_dev, ngrid, EllTab, h2idx, h2, stat)
+  switch (nm.c) {
+    case 1: LG(1); break;
+    case 2: LG(2); break;
+    case 3: LG(3); break;
+    case 4: LG(4); break;
+    default: return fail(ctx, BLMM_ERR_UNSUPPORTED, "number of null covariates (incl. intercept) must be 1..4");
+  }
+#undef LG
+  KCHECK();
+  return BLMM_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// A-side panels for the LOD kernels (src/bulkscan_helpers.jl:138-145 and :182-196 rewritten as GEMM
+// operands).  With w = makeweights(h2_j), beta = (Z0'WZ0)^-1 Z0'Wy, A = L L':
+//   panel 0 [k][j] = w_k (y - Z0 beta)_k / sqrt(yy),  yy = y'Wy - |L^-1 Z0'Wy|^2    -> num  = x' panel0
+//   panel 1 [k][j] = w_k                                                              -> Sxx  = (x.^2)' panel1
+//   panel 2+q [k][j] = w_k (Z0 L^-T)_kq                                               -> u_q  = x' panel(2+q)
+// so that r = num / sqrt(Sxx - sum_q u_q^2)  is the correlation of computeR_LMM (src/bulkscan_helpers.jl:47-64).
+// One thread per trait; rows of the panels are written coalesced.
+// ------------------------------------------------------------------------------------------------
+template <int C>
+__global__ void __launch_bounds__(256) k_panels(NullModel nm, const double* __restrict__ Yt, int64_t ldy, int64_t m,
+                                                const double* __restrict__ Z0, const double* __restrict__ lam,
+                                                const double* __restrict__ h2v, int full, double* __restrict__ P,
+                                                int64_t ldp, int64_t* stat) {
+  extern __shared__ __attribute__((aligned(16))) double sh[];
+  const int n = nm.n, npad = nm.npad;
+  double* sLam = sh;
+  double* sZ = sh + n;
+  for (int e = threadIdx.x; e < n; e += blockDim.x) sLam[e] = lam[e];
+  for (int e = threadIdx.x; e < n * C; e += blockDim.x) sZ[e] = Z0[e];
+  __syncthreads();
+  const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= ldp) return;
+  const int64_t pstride = (int64_t)npad * ldp;
+  const int np = full ? 2 + C : 1;
+  if (j >= m) {  // padding columns
+    for (int q = 0; q < np; ++q)
+      for (int k = 0; k < npad; ++k) P[q * pstride + (int64_t)k * ldp + j] = 0.0;
+    return;
+  }
+  constexpr int NA = C * (C + 1) / 2;
+  const double h2 = h2v[j];
+  const double delta = h2 / (1.0 - h2);
+  double A[NA], v[C], syy = 0.0;
+#pragma unroll
+  for (int a = 0; a < NA; ++a) A[a] = 0.0;
+#pragma unroll
+  for (int q = 0; q < C; ++q) v[q] = 0.0;
+  for (int k = 0; k < n; ++k) {
+    const double w = fabs(1.0 / fma(delta, sLam[k], 1.0));  // sqrt.(abs.(makeweights)) squared, src/bulkscan_helpers.jl:138
+    const double y = Yt[(int64_t)k * ldy + j];
+    const double wy = w * y;
+    syy = fma(wy, y, syy);
+#pragma unroll
+    for (int q = 0; q < C; ++q) {
+      const double zq = sZ[q * n + k];
+      v[q] = fma(wy, zq, v[q]);
+      const double wz = w * zq;
+#pragma unroll
+      for (int r = 0; r <= q; ++r) A[q * (q + 1) / 2 + r] = fma(wz, sZ[r * n + k], A[q * (q + 1) / 2 + r]);
+    }
+  }
+  // L (lower Cholesky), Linv (lower), t = L^-1 v, beta = L^-T t
+  double L[NA], Li[NA], t[C], beta[C], tt = 0.0;
+#pragma unroll
+  for (int q = 0; q < C; ++q) {
+#pragma unroll
+    for (int r = 0; r <= q; ++r) {
+      double s = A[q * (q + 1) / 2 + r];
+#pragma unroll
+      for (int u = 0; u < r; ++u) s = fma(-L[q * (q + 1) / 2 + u], L[r * (r + 1) / 2 + u], s);
+      L[q * (q + 1) / 2 + r] = (r == q) ? sqrt(s) : s / L[r * (r + 1) / 2 + r];
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < C; ++q) {
+    // row q of Linv
+#pragma unroll
+    for (int r = 0; r <= q; ++r) {
+      double s = (r == q) ? 1.0 : 0.0;
+#pragma unroll
+      for (int u = r; u < q; ++u) s = fma(-L[q * (q + 1) / 2 + u], Li[u * (u + 1) / 2 + r], s);
+      Li[q * (q + 1) / 2 + r] = s / L[q * (q + 1) / 2 + q];
+    }
+    double s = 0.0;
+#pragma unroll
+    for (int r = 0; r <= q; ++r) s = fma(Li[q * (q + 1) / 2 + r], v[r], s);
+    t[q] = s;
+    tt = fma(s, s, tt);
+  }
+#pragma unroll
+  for (int q = 0; q < C; ++q) {
+    double s = 0.0;
+#pragma unroll
+    for (int u = q; u < C; ++u) s = fma(Li[u * (u + 1) / 2 + q], t[u], s);
+    beta[q] = s;
+  }
+  const double yy = syy - tt;
+  if (!(sqrt(fabs(yy)) > 2.220446049250313e-16)) atomicAdd((unsigned long long*)&stat[ST_ZERO_NORM], 1ull);
+  const double isy = 1.0 / sqrt(yy);
+  for (int k = 0; k < npad; ++k) {
+    double p0 = 0.0, w = 0.0;
+    double zl[C];
+#pragma unroll
+    for (int q = 0; q < C; ++q) zl[q] = 0.0;
+    if (k < n) {
+      w = fabs(1.0 / fma(delta, sLam[k], 1.0));
+      double res = Yt[(int64_t)k * ldy + j];
+#pragma unroll
+      for (int q = 0; q < C; ++q) res = fma(-beta[q], sZ[q * n + k], res);
+      p0 = w * res * isy;
+#pragma unroll
+      for (int q = 0; q < C; ++q) {
+        double s = 0.0;
+#pragma unroll
+        for (int r = 0; r <= q; ++r) s = fma(Li[q * (q + 1) / 2 + r], sZ[r * n + k], s);
+        zl[q] = w * s;
+      }
+    }
+    P[(int64_t)k * ldp + j] = p0;
+    if (full) {
+      P[pstride + (int64_t)k * ldp + j] = w;
+#pragma unroll
+      for (int q = 0; q < C; ++q) P[(2 + q) * pstride + (int64_t)k * ldp + j] = zl[q];
+    }
+  }
+}
+
+int launch_panels(blmm_ctx* ctx, const NullModel& nm, const double* Yt, int64_t ldy, int64_t m, const double* Z0,
+                  const double* lam, const double* h2, int full, double* panels, int64_t ldp, int64_t* stat) {
+  const unsigned blocks = (unsigned)((ldp + 255) / 256);
+  const size_t lds = sizeof(double) * (size_t)nm.n * (1 + nm.c);
+#define PN(C) hipLaunchKernelGGL(k_panels<C>, dim3(blocks), dim3(256), lds, ctx->stream, nm, Yt, ldy, m, Z0, lam, h2, full, panels, ldp, stat)
+  switch (nm.c) {
+    case 1: PN(1); break;
+    case 2: PN(2); break;
+    case 3: PN(3); break;
+    case 4: PN(4); break;
+    default: return fail(ctx, BLMM_ERR_UNSUPPORTED, "number of null covariates (incl. intercept) must be 1..4");
+  }
+#undef PN
+  KCHECK();
+  return BLMM_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// isx[g][i] = 1 / || P_g (sqrt(w_g) .* x_i) ||  for every grid point g and marker i: the marker-side
+// normalisation of computeR_LMM (src/bulkscan_helpers.jl:51,55,58) under the shared weights of
+// weighted_liteqtl (src/bulkscan_helpers.jl:182-193).  grid = (p/256, ngrid).
+// ------------------------------------------------------------------------------------------------
+template <int C>
+__global__ void __launch_bounds__(256) k_isx(NullModel nm, const double* __restrict__ Xt, int64_t ldx, int64_t p,
+                                             const double* __restrict__ Z0, const double* __restrict__ lam,
+                                             const double* __restrict__ grid, double* __restrict__ isx, int64_t ld_isx,
+                                             int64_t* stat) {
+  extern __shared__ __attribute__((aligned(16))) double sh[];
+  const int n = nm.n;
+  double* sW = sh;        // n
+  double* sZ = sh + n;    // C*n
+  __shared__ double sLi[CMAX * CMAX];
+  const int g = blockIdx.y;
+  const double h2 = grid[g];
+  const double delta = h2 / (1.0 - h2);
+  for (int e = threadIdx.x; e < n; e += blockDim.x) sW[e] = fabs(1.0 / fma(delta, lam[e], 1.0));
+  for (int e = threadIdx.x; e < n * C; e += blockDim.x) sZ[e] = Z0[e];
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    constexpr int NA = C * (C + 1) / 2;
+    double A[NA], L[NA], Li[NA];
+    for (int a = 0; a < NA; ++a) A[a] = 0.0;
+    for (int k = 0; k < n; ++k)
+      for (int q = 0; q < C; ++q)
+        for (int r = 0; r <= q; ++r) A[q * (q + 1) / 2 + r] = fma(sW[k] * sZ[q * n + k], sZ[r * n + k], A[q * (q + 1) / 2 + r]);
+    for (int q = 0; q < C; ++q)
+      for (int r = 0; r <= q; ++r) {
+        double s = A[q * (q + 1) / 2 + r];
+        for (int u = 0; u < r; ++u) s = fma(-L[q * (q + 1) / 2 + u], L[r * (r + 1) / 2 + u], s);
+        L[q * (q + 1) / 2 + r] = (r == q) ? sqrt(s) : s / L[r * (r + 1) / 2 + r];
+      }
+    for (int q = 0; q < C; ++q)
+      for (int r = 0; r <= q; ++r) {
+        double s = (r == q) ? 1.0 : 0.0;
+        for (int u = r; u < q; ++u) s = fma(-L[q * (q + 1) / 2 + u], Li[u * (u + 1) / 2 + r], s);
+        Li[q * (q + 1) / 2 + r] = s / L[q * (q + 1) / 2 + q];
+      }
+    for (int q = 0; q < C; ++q)
+      for (int r = 0; r < C; ++r) sLi[q * CMAX + r] = (r <= q) ? Li[q * (q + 1) / 2 + r] : 0.0;
+  }
+  __syncthreads();
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= ld_isx) return;
+  double out = 0.0;
+  if (i < p) {
+    double sxx = 0.0, sxz[C];
+#pragma unroll
+    for (int q = 0; q < C; ++q) sxz[q] = 0.0;
+    for (int k = 0; k < n; ++k) {
+      const double x = Xt[(int64_t)k * ldx + i];
+      const double wx = sW[k] * x;
+      sxx = fma(wx, x, sxx);
+#pragma unroll
+      for (int q = 0; q < C; ++q) sxz[q] = fma(wx, sZ[q * n + k], sxz[q]);
+    }
+    double uu = 0.0;
+#pragma unroll
+    for (int q = 0; q < C; ++q) {
+      double u = 0.0;
+#pragma unroll
+      for (int r = 0; r <= q; ++r) u = fma(sLi[q * CMAX + r], sxz[r], u);
+      uu = fma(u, u, uu);
+    }
+    const double xx = sxx - uu;
+    if (!(sqrt(fabs(xx)) > 2.220446049250313e-16)) atomicAdd((unsigned long long*)&stat[ST_ZERO_NORM], 1ull);
+    out = 1.0 / sqrt(xx);
+  }
+  isx[(int64_t)g * ld_isx + i] = out;
+}
+
+int launch_isx(blmm_ctx* ctx, const NullModel& nm, const double* Xt, int64_t ldx, int64_t p, const double* Z0,
+               const double* lam, const double* grid_dev, int ngrid, double* isx, int64_t ld_isx, int64_t* stat) {
+  dim3 grid((unsigned)((ld_isx + 255) / 256), (unsigned)ngrid);
+  const size_t lds = sizeof(double) * (size_t)nm.n * (1 + nm.c);
+#define IX(C) hipLaunchKernelGGL(k_isx<C>, grid, dim3(256), lds, ctx->stream, nm, Xt, ldx, p, Z0, lam, grid_dev, isx, ld_isx, stat)
+  switch (nm.c) {
+    case 1: IX(1); break;
+    case 2: IX(2); break;
+    case 3: IX(3); break;
+    case 4: IX(4); break;
+    default: return fail(ctx, BLMM_ERR_UNSUPPORTED, "number of null covariates (incl. intercept) must be 1..4");
+  }
+#undef IX
+  KCHECK();
+  return BLMM_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// calcKinship (src/kinship.jl:4-14): K = 2 (G-1/2)(G-1/2)'/p + 1/2, diag = 1.
+// Stage 1: each block sums a slice of markers for a 32x32 output tile (deterministic, no atomics);
+// stage 2: sums the slices in fixed order and applies the affine map.
+// ------------------------------------------------------------------------------------------------
+constexpr int KIN_SPLITS = 64;
+__global__ void __launch_bounds__(256) k_kinship_partial(const double* __restrict__ G, int64_t n, int64_t p,
+                                                         double* __restrict__ part) {
+  __shared__ double sa[32][33], sb[32][33];
+  const int ti = blockIdx.x, tj = blockIdx.y, sp = blockIdx.z;
+  if (tj > ti) return;  // symmetric: lower tiles only
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+  const int64_t chunk = (p + KIN_SPLITS - 1) / KIN_SPLITS;
+  const int64_t k0 = sp * chunk, k1 = (k0 + chunk < p) ? k0 + chunk : p;
+  double acc[4] = {0, 0, 0, 0};
+  for (int64_t kb = k0; kb < k1; kb += 32) {
+    for (int r = ty; r < 32; r += 8) {
+      const int64_t k = kb + r;
+      const int64_t ia = (int64_t)ti * 32 + tx, ib = (int64_t)tj * 32 + tx;
+      sa[r][tx] = (k < k1 && ia < n) ? G[k * n + ia] - 0.5 : 0.0;
+      sb[r][tx] = (k < k1 && ib < n) ? G[k * n + ib] - 0.5 : 0.0;
+    }
+    __syncthreads();
+#pragma unroll 8
+    for (int r = 0; r < 32; ++r) {
+      const double a = sa[r][tx];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) acc[u] = fma(a, sb[r][ty + 8 * u], acc[u]);
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const int64_t i = (int64_t)ti * 32 + tx, j = (int64_t)tj * 32 + ty + 8 * u;
+    if (i < n && j < n) part[((int64_t)sp * n + j) * n + i] = acc[u];
+  }
+}
+__global__ void k_kinship_final(const double* __restrict__ part, int64_t n, int64_t p, double* __restrict__ K) {
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n * n) return;
+  int64_t i = e % n, j = e / n;
+  if (i == j) { K[e] = 1.0; return; }
+  if (i / 32 < j / 32) { const int64_t t = i; i = j; j = t; }  // only lower tiles were computed
+  double s = 0.0;
+  for (int sp = 0; sp < KIN_SPLITS; ++sp) s += part[((int64_t)sp * n + j) * n + i];
+  K[e] = 2.0 * s / (double)p + 0.5;
+}
+
+int launch_kinship(blmm_ctx* ctx, const double* dG, int64_t n, int64_t p, double* dK, double* partial) {
+  const unsigned nt = (unsigned)((n + 31) / 32);
+  hipLaunchKernelGGL(k_kinship_partial, dim3(nt, nt, KIN_SPLITS), dim3(256), 0, ctx->stream, dG, n, p, partial);
+  KCHECK();
+  hipLaunchKernelGGL(k_kinship_final, dim3((unsigned)((n * n + 255) / 256)), dim3(256), 0, ctx->stream, partial, n, p, dK);
+  KCHECK();
+  return BLMM_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Permutation panel for scan_perms_lite (src/scan.jl:521-542, src/transform_helpers.jl:57-102):
+//   r0 = sqrt(w) .* (y0 - Z0 beta_w)  (weighted-LS residual),  r0perm_b = pi_b(r0),  column 0 = original.
+//   L[:, b] = X00' r0perm_b / (||X00_i|| ||r0||),  X00 = P (sqrt(w) .* X0m)
+//            = sum_k x_ik * [ sqrt(w_k) (P r0perm_b)_k ] / (...)          (P symmetric idempotent)
+// so the A-side panel column b is  sqrt(w) .* (P pi_b(r0)) / ||r0||  and the marker side stays the shared,
+// unweighted Xt with the per-marker scale isx (k_isx at the fitted h2).
+// One thread per permutation column.  perm_idx == nullptr: Fisher-Yates from a splitmix64 counter stream.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint64_t splitmix64(uint64_t& s) {
+  uint64_t z = (s += 0x9E3779B97F4A7C15ull);
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  return z ^ (z >> 31);
+}
+
+template <int C>
+__global__ void __launch_bounds__(64) k_perm_panel(NullModel nm, const double* __restrict__ Yt, int64_t ldy,
+                                                   const double* __restrict__ Z0, const double* __restrict__ lam,
+                                                   const double* __restrict__ h2p, const int32_t* __restrict__ perm_idx,
+                                                   int64_t nperms, uint64_t seed, int orig, double* __restrict__ P,
+                                                   int64_t ldp, double* __restrict__ r0buf /* n */,
+                                                   int32_t* __restrict__ permbuf, int64_t* stat) {
+  const int n = nm.n, npad = nm.npad;
+  // orig = 1: column 0 = the un-permuted residual, every other column zero;
+  // orig = 0: column b = permutation b (b < nperms), zero beyond.
+  const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= ldp) return;
+  if ((orig && b > 0) || (!orig && b >= nperms)) {
+    for (int k = 0; k < npad; ++k) P[(int64_t)k * ldp + b] = 0.0;
+    return;
+  }
+  constexpr int NA = C * (C + 1) / 2;
+  const double h2 = h2p[0];
+  const double delta = h2 / (1.0 - h2);
+  // weighted normal equations for the permuted residual vector v = pi_b(r0): coefficients of sqrt(w) Z0
+  double A[NA], g[C];
+  for (int a = 0; a < NA; ++a) A[a] = 0.0;
+  for (int q = 0; q < C; ++q) g[q] = 0.0;
+  int32_t* myperm = permbuf ? permbuf + b * (int64_t)n : nullptr;
+  if (!orig && !perm_idx) {
+    uint64_t s = seed * 0xD1342543DE82EF95ull + (uint64_t)(b + 1);
+    for (int k = 0; k < n; ++k) myperm[k] = k;
+    for (int k = n - 1; k > 0; --k) {
+      const int r = (int)(splitmix64(s) % (uint64_t)(k + 1));
+      const int32_t t = myperm[k]; myperm[k] = myperm[r]; myperm[r] = t;
+    }
+  }
+  double rr = 0.0;
+  for (int k = 0; k < n; ++k) {
+    const double w = 1.0 / fma(delta, lam[k], 1.0);
+    const double sw = sqrt(w);
+    const int src = orig ? k : (perm_idx ? perm_idx[b * (int64_t)n + k] : myperm[k]);
+    const double v = r0buf[src];
+    rr = fma(v, v, rr);
+    for (int q = 0; q < C; ++q) {
+      const double zq = sw * Z0[q * n + k];
+      g[q] = fma(zq, v, g[q]);
+      for (int r = 0; r <= q; ++r) A[q * (q + 1) / 2 + r] = fma(zq, sw * Z0[r * n + k], A[q * (q + 1) / 2 + r]);
+    }
+  }
+  // solve A beta = g by Cholesky
+  double L[NA], t[C], beta[C];
+  for (int q = 0; q < C; ++q) {
+    for (int r = 0; r <= q; ++r) {
+      double s = A[q * (q + 1) / 2 + r];
+      for (int u = 0; u < r; ++u) s = fma(-L[q * (q + 1) / 2 + u], L[r * (r + 1) / 2 + u], s);
+      L[q * (q + 1) / 2 + r] = (r == q) ? sqrt(s) : s / L[r * (r + 1) / 2 + r];
+    }
+    double s = g[q];
+    for (int u = 0; u < q; ++u) s = fma(-L[q * (q + 1) / 2 + u], t[u], s);
+    t[q] = s / L[q * (q + 1) / 2 + q];
+  }
+  for (int q = C - 1; q >= 0; --q) {
+    double s = t[q];
+    for (int u = q + 1; u < C; ++u) s = fma(-L[u * (u + 1) / 2 + q], beta[u], s);
+    beta[q] = s / L[q * (q + 1) / 2 + q];
+  }
+  const double inr = 1.0 / sqrt(rr);
+  if (orig && !(sqrt(rr) > 2.220446049250313e-16)) atomicAdd((unsigned long long*)&stat[ST_ZERO_NORM], 1ull);
+  for (int k = 0; k < npad; ++k) {
+    double out = 0.0;
+    if (k < n) {
+      const double w = 1.0 / fma(delta, lam[k], 1.0);
+      const double sw = sqrt(w);
+      const int src = orig ? k : (perm_idx ? perm_idx[b * (int64_t)n + k] : myperm[k]);
+      double v = r0buf[src];
+      for (int q = 0; q < C; ++q) v = fma(-beta[q], sw * Z0[q * n + k], v);
+      out = sw * v * inr;
+    }
+    P[(int64_t)k * ldp + b] = out;
+  }
+}
+
+// r0 = sqrt(w) .* (y0 - Z0 beta_w) for the single trait in Yt[:, 0]; scalars[0] = sigma2 (given), [1] = h2 (given)
+template <int C>
+__global__ void k_perm_r0(NullModel nm, const double* __restrict__ Yt, int64_t ldy, const double* __restrict__ Z0,
+                          const double* __restrict__ lam, const double* __restrict__ h2p, double* __restrict__ r0buf) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  const int n = nm.n;
+  constexpr int NA = C * (C + 1) / 2;
+  const double h2 = h2p[0];
+  const double delta = h2 / (1.0 - h2);
+  double A[NA], g[C];
+  for (int a = 0; a < NA; ++a) A[a] = 0.0;
+  for (int q = 0; q < C; ++q) g[q] = 0.0;
+  for (int k = 0; k < n; ++k) {
+    const double w = 1.0 / fma(delta, lam[k], 1.0);
+    const double y = Yt[(int64_t)k * ldy];
+    for (int q = 0; q < C; ++q) {
+      const double wz = w * Z0[q * n + k];
+      g[q] = fma(wz, y, g[q]);
+      for (int r = 0; r <= q; ++r) A[q * (q + 1) / 2 + r] = fma(wz, Z0[r * n + k], A[q * (q + 1) / 2 + r]);
+    }
+  }
+  double L[NA], t[C], beta[C];
+  for (int q = 0; q < C; ++q) {
+    for (int r = 0; r <= q; ++r) {
+      double s = A[q * (q + 1) / 2 + r];
+      for (int u = 0; u < r; ++u) s = fma(-L[q * (q + 1) / 2 + u], L[r * (r + 1) / 2 + u], s);
+      L[q * (q + 1) / 2 + r] = (r == q) ? sqrt(s) : s / L[r * (r + 1) / 2 + r];
+    }
+    double s = g[q];
+    for (int u = 0; u < q; ++u) s = fma(-L[q * (q + 1) / 2 + u], t[u], s);
+    t[q] = s / L[q * (q + 1) / 2 + q];
+  }
+  for (int q = C - 1; q >= 0; --q) {
+    double s = t[q];
+    for (int u = q + 1; u < C; ++u) s = fma(-L[u * (u + 1) / 2 + q], beta[u], s);
+    beta[q] = s / L[q * (q + 1) / 2 + q];
+  }
+  for (int k = 0; k < n; ++k) {
+    const double w = 1.0 / fma(delta, lam[k], 1.0);
+    double v = Yt[(int64_t)k * ldy];
+    for (int q = 0; q < C; ++q) v = fma(-beta[q], Z0[q * n + k], v);
+    r0buf[k] = sqrt(w) * v;
+  }
+}
+
+int launch_perm_panel(blmm_ctx* ctx, const NullModel& nm, const double* Yt, int64_t ldy, const double* Z0,
+                      const double* lam, const double* h2, const int32_t* perm_idx, int64_t nperms, uint64_t seed,
+                      int orig, double* panel, int64_t ldp, int64_t* stat) {
+  int rc = ensure(ctx, ctx->r0, sizeof(double) * (size_t)nm.n);
+  if (rc) return rc;
+  int32_t* permbuf = nullptr;
+  if (!perm_idx && !orig) {
+    rc = ensure(ctx, ctx->perm, sizeof(int32_t) * (size_t)nm.n * (size_t)(nperms + 1));
+    if (rc) return rc;
+    permbuf = ptr<int32_t>(ctx->perm);
+  }
+  double* r0 = ptr<double>(ctx->r0);
+  const unsigned blocks = (unsigned)((ldp + 63) / 64);
+#define PP(C)                                                                                                     \
+  if (orig) hipLaunchKernelGGL(k_perm_r0<C>, dim3(1), dim3(64), 0, ctx->stream, nm, Yt, ldy, Z0, lam, h2, r0);   \
+  hipLaunchKernelGGL(k_perm_panel<C>, dim3(blocks), dim3(64), 0, ctx->stream, nm, Yt, ldy, Z0, lam, h2, perm_idx, \
+                     nperms, seed, orig, panel, ldp, r0, permbuf, stat)
+  switch (nm.c) {
+    case 1: PP(1); break;
+    case 2: PP(2); break;
+    case 3: PP(3); break;
+    case 4: PP(4); break;
+    default: return fail(ctx, BLMM_ERR_UNSUPPORTED, "number of null covariates (incl. intercept) must be 1..4");
+  }
+#undef PP
+  KCHECK();
+  return BLMM_OK;
+}
+
+}  // namespace blmm

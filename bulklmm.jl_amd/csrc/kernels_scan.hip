@@ -1,0 +1,318 @@
+// kernels_scan.hip -- the LOD kernels: every (trait, marker) test of the bulkscan hot path.
+//
+//   L[i, j] = -(n/2) * log10(1 - r_ij^2)                                   (r2lod, src/bulkscan_helpers.jl:22-24)
+//   r_ij    = <P x~_i, P y~_j> / (|P x~_i| |P y~_j|)                         (computeR_LMM, src/bulkscan_helpers.jl:47-64)
+//
+// rewritten as a markers x traits contraction over the n individuals on the f64 matrix cores
+// (v_mfma_f64_16x16x4_f64), with the projection / normalisation / r -> LOD map fused into the epilogue:
+//
+//   exact (per-trait weights; univar_liteqtl, src/bulkscan_helpers.jl:127-150):
+//       num = x_i' a0_j,  Sxx = (x_i.^2)' a1_j,  u_q = x_i' a(2+q)_j,   r^2 = num^2 / (Sxx - sum_q u_q^2)
+//   table (shared weights; weighted_liteqtl :175-201, scan_perms_lite src/scan.jl:542):
+//       r = (x_i' a0_j) * isx[bin_j][i]
+//   alt   (bulkscan_alt_grid, src/bulkscan.jl:495-522 with tmax!, src/bulkscan_helpers.jl:330-350):
+//       running max over the h2 grid of  ln10 * LOD_g + Ell[g, j]
+//
+// Operand layout (both row-major "k-major", produced by k_rotate / k_panels):
+//   Xt[k][i]  markers,  ld = ldx (padded to the tile);     P[q][k][j]  A-side panels, ld = ldp.
+// MFMA roles: A (16 rows) = traits, B (16 cols) = markers, so that D's 16 lanes of a register hold 16
+// marker slots of ONE trait column of L.  Marker <-> (block nb, col c) is permuted to ibase + NB*c + nb and
+// trait <-> (block mb, row r) to tbase + MB*r + mb, so every lane owns NB consecutive markers (vector
+// loads of Xt, 32-byte stores of L; 16 lanes = 512 contiguous bytes of one L column) and MB consecutive
+// traits (vector loads of the panels).
+// Workgroup = 4 waves (2 x 2) = (32*MB) traits x (32*NB) markers; no LDS: fragments come straight from
+// L2/L1 (a 64-cycle f64 MFMA leaves the operand traffic at a few bytes/clk/CU).
+#include "blmm_internal.h"
+#include <cmath>
+
+namespace blmm {
+
+#define KCHECK()                                                                                      \
+  do {                                                                                                \
+    hipError_t e__ = hipGetLastError();                                                               \
+    if (e__ != hipSuccess) return fail(ctx, BLMM_ERR_HIP, std::string("kernel launch: ") + hipGetErrorString(e__)); \
+  } while (0)
+
+template <int N> struct VecD;
+template <> struct VecD<1> { typedef double type; };
+template <> struct VecD<2> { typedef double type __attribute__((ext_vector_type(2))); };
+template <> struct VecD<4> { typedef double type __attribute__((ext_vector_type(4))); };
+
+template <int N>
+__device__ __forceinline__ void loadv(double (&dst)[N], const double* __restrict__ p) {
+  if constexpr (N == 1) {
+    dst[0] = p[0];
+  } else if constexpr (N == 2) {
+    const d2 v = *reinterpret_cast<const d2*>(p);
+    dst[0] = v[0]; dst[1] = v[1];
+  } else {
+    const d2 v0 = *reinterpret_cast<const d2*>(p);
+    const d2 v1 = *reinterpret_cast<const d2*>(p + 2);
+    dst[0] = v0[0]; dst[1] = v0[1]; dst[2] = v1[0]; dst[3] = v1[1];
+  }
+}
+
+// 8-byte-aligned 16-byte vector (columns of L start at arbitrary multiples of 8 bytes: ld = p is odd for BXD)
+typedef double d2u __attribute__((ext_vector_type(2), aligned(8)));
+
+__device__ __forceinline__ int64_t xcd_swizzle(int64_t bid, int64_t nwg) {
+  // Workgroups are dealt round-robin over the 8 XCDs (bid % 8).  Give each XCD a contiguous range of tiles
+  // so the A-side panels of a trait tile stay in ONE XCD's L2 (speed only; any placement is correct).
+  const int64_t q = nwg >> 3;
+  return (bid < (q << 3)) ? (bid & 7) * q + (bid >> 3) : bid;
+}
+
+template <int NX, int MB, int NB, bool TABLE>
+__global__ void __launch_bounds__(256, 2) k_scan(ScanArgs a, int ntile_i, int64_t nwg) {
+  constexpr int NP = 1 + NX;  // A-side panels consumed
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t bid = xcd_swizzle(blockIdx.x, nwg);
+  const int64_t tile_t = bid / ntile_i;
+  const int tile_i = (int)(bid % ntile_i);
+  const int64_t t0 = tile_t * (32 * MB) + (wave >> 1) * (16 * MB);
+  const int64_t i0 = (int64_t)tile_i * (32 * NB) + (wave & 1) * (16 * NB);
+  const int r = lane & 15, kk = lane >> 4;
+
+  d4 acc[NP][MB][NB];
+#pragma unroll
+  for (int q = 0; q < NP; ++q)
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) acc[q][mb][nb] = (d4){0, 0, 0, 0};
+
+  const double* pa = a.P + (int64_t)kk * a.ldp + t0 + MB * r;
+  const double* pb = a.Xt + (int64_t)kk * a.ldx + i0 + NB * r;
+  const int64_t sa = 4 * a.ldp, sb = 4 * a.ldx;
+
+  double av[NP][MB], bv[NB];
+#pragma unroll
+  for (int q = 0; q < NP; ++q) loadv<MB>(av[q], pa + q * a.pstride);
+  loadv<NB>(bv, pb);
+  for (int ks = 0; ks < a.ks; ++ks) {
+    double an[NP][MB], bn[NB];
+    if (ks + 1 < a.ks) {
+      pa += sa; pb += sb;
+#pragma unroll
+      for (int q = 0; q < NP; ++q) loadv<MB>(an[q], pa + q * a.pstride);
+      loadv<NB>(bn, pb);
+    } else {
+#pragma unroll
+      for (int q = 0; q < NP; ++q)
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb) an[q][mb] = 0.0;
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) bn[nb] = 0.0;
+    }
+    double b2[NB];
+    if constexpr (NX > 0) {
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) b2[nb] = bv[nb] * bv[nb];
+    }
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) {
+        acc[0][mb][nb] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[0][mb], bv[nb], acc[0][mb][nb], 0, 0, 0);
+        if constexpr (NX > 0) {
+          acc[1][mb][nb] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[1][mb], b2[nb], acc[1][mb][nb], 0, 0, 0);
+#pragma unroll
+          for (int q = 2; q < NP; ++q)
+            acc[q][mb][nb] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[q][mb], bv[nb], acc[q][mb][nb], 0, 0, 0);
+        }
+      }
+#pragma unroll
+    for (int q = 0; q < NP; ++q)
+#pragma unroll
+      for (int mb = 0; mb < MB; ++mb) av[q][mb] = an[q][mb];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) bv[nb] = bn[nb];
+  }
+
+  // ---- epilogue: projection, normalisation, r -> LOD, 32-byte stores ---------------------------------
+  const double scale = -0.5 * (double)a.n;
+  const int64_t ibase = i0 + NB * r;
+  int nnan = 0;
+#pragma unroll
+  for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) {
+      const int64_t trait = t0 + MB * (kk + 4 * reg) + mb;
+      if (trait >= a.m) continue;
+      double sc[NB];
+      if constexpr (TABLE) {
+        const int64_t b = a.bin ? (int64_t)a.bin[trait] : 0;
+        loadv<NB>(sc, a.isx + b * a.ld_isx + ibase);
+      }
+      double out[NB];
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) {
+        const double num = acc[0][mb][nb][reg];
+        double r2;
+        if constexpr (TABLE) {
+          const double rr = num * sc[nb];
+          r2 = rr * rr;
+        } else {
+          double xx = acc[1][mb][nb][reg];
+#pragma unroll
+          for (int q = 2; q < NP; ++q) xx = fma(-acc[q][mb][nb][reg], acc[q][mb][nb][reg], xx);
+          r2 = (num * num) / xx;
+        }
+        const double lod = scale * log10(1.0 - r2);
+        out[nb] = lod;
+        nnan += (lod != lod) && (ibase + nb < a.p);
+      }
+      double* dst = a.L + trait * a.ldL + ibase;
+      if (ibase + NB <= a.p) {
+        if constexpr (NB == 4) {
+          __builtin_nontemporal_store((d2u){out[0], out[1]}, reinterpret_cast<d2u*>(dst));
+          __builtin_nontemporal_store((d2u){out[2], out[3]}, reinterpret_cast<d2u*>(dst + 2));
+        } else if constexpr (NB == 2) {
+          __builtin_nontemporal_store((d2u){out[0], out[1]}, reinterpret_cast<d2u*>(dst));
+        } else {
+          __builtin_nontemporal_store(out[0], dst);
+        }
+      } else {
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+          if (ibase + nb < a.p) dst[nb] = out[nb];
+      }
+    }
+  if (nnan) atomicAdd((unsigned long long*)&a.stat[ST_NAN_LOD], (unsigned long long)nnan);
+}
+
+template <int NX, bool TABLE, int MB>
+static int launch_scan_t(blmm_ctx* ctx, const ScanArgs& a) {
+  constexpr int NB = 4;
+  static_assert(32 * MB <= 128 && 32 * NB == TILE_I, "tile constants (operands are padded to 128)");
+  const int64_t ntile_t = (a.m + 32 * MB - 1) / (32 * MB);
+  const int64_t ntile_i = (a.p + TILE_I - 1) / TILE_I;
+  const int64_t nwg = ntile_t * ntile_i;
+  if (nwg <= 0) return BLMM_OK;
+  if (nwg > 0x7fffffffLL) return fail(ctx, BLMM_ERR_INVALID, "problem too large for one launch");
+  hipLaunchKernelGGL((k_scan<NX, MB, NB, TABLE>), dim3((unsigned)nwg), dim3(256), 0, ctx->stream, a, (int)ntile_i, nwg);
+  KCHECK();
+  return BLMM_OK;
+}
+
+int launch_scan_exact(blmm_ctx* ctx, const ScanArgs& a, int c) {
+  switch (c) {
+    // accumulators per lane: (2 + c) * MB * 4 blocks * 8 VGPRs; MB = 1 beyond c = 1 keeps 2 waves/SIMD spill-free
+    case 1: return launch_scan_t<2, false, 2>(ctx, a);
+    case 2: return launch_scan_t<3, false, 1>(ctx, a);
+    case 3: return launch_scan_t<4, false, 1>(ctx, a);
+    case 4: return launch_scan_t<5, false, 1>(ctx, a);
+  }
+  return fail(ctx, BLMM_ERR_UNSUPPORTED, "number of null covariates (incl. intercept) must be 1..4");
+}
+
+int launch_scan_table(blmm_ctx* ctx, const ScanArgs& a) { return launch_scan_t<0, true, 2>(ctx, a); }
+
+// ------------------------------------------------------------------------------------------------
+// alt-grid: for every (trait, marker) the maximum over the h2 grid of  ln10*LOD_g + Ell[g, j];
+//   L = (max_g logL1_g - max_g Ell[g, j]) / ln10,  h2_panel = grid value at the first arg-max
+// (src/bulkscan.jl:495-522).  counter_quirk reproduces tmax!'s improvement counter.
+// Panels: P[g][k][j] = panel 0 under h2 = grid[g].
+// ------------------------------------------------------------------------------------------------
+template <int MB, int NB>
+__global__ void __launch_bounds__(256, 2) k_scan_alt(AltArgs aa, int ntile_i, int64_t nwg) {
+  const ScanArgs& a = aa.s;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t bid = xcd_swizzle(blockIdx.x, nwg);
+  const int64_t tile_t = bid / ntile_i;
+  const int tile_i = (int)(bid % ntile_i);
+  const int64_t t0 = tile_t * (32 * MB) + (wave >> 1) * (16 * MB);
+  const int64_t i0 = (int64_t)tile_i * (32 * NB) + (wave & 1) * (16 * NB);
+  const int r = lane & 15, kk = lane >> 4;
+  const double scale = -0.5 * (double)a.n;
+  const double ln10 = 2.302585092994046;  // log(10)
+  const int64_t ibase = i0 + NB * r;
+
+  double best[MB][NB][4];
+  int bidx[MB][NB][4];
+#pragma unroll
+  for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) { best[mb][nb][reg] = 0.0; bidx[mb][nb][reg] = 0; }
+  int nnan = 0;
+
+  for (int g = 0; g < aa.ngrid; ++g) {
+    d4 acc[MB][NB];
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) acc[mb][nb] = (d4){0, 0, 0, 0};
+    const double* pa = a.P + (int64_t)g * a.pstride + (int64_t)kk * a.ldp + t0 + MB * r;
+    const double* pb = a.Xt + (int64_t)kk * a.ldx + i0 + NB * r;
+    for (int ks = 0; ks < a.ks; ++ks) {
+      double av[MB], bv[NB];
+      loadv<MB>(av, pa);
+      loadv<NB>(bv, pb);
+      pa += 4 * a.ldp; pb += 4 * a.ldx;
+#pragma unroll
+      for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+          acc[mb][nb] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[mb], bv[nb], acc[mb][nb], 0, 0, 0);
+    }
+    double sc[NB];
+    loadv<NB>(sc, a.isx + (int64_t)g * a.ld_isx + ibase);
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) {
+        const int64_t trait = t0 + MB * (kk + 4 * reg) + mb;
+        const double ell = (trait < a.m) ? aa.EllTab[trait * (int64_t)aa.ngrid + g] : 0.0;
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+          const double rr = acc[mb][nb][reg] * sc[nb];
+          const double lod = scale * log10(1.0 - rr * rr);
+          const double l1 = lod * ln10 + ell;
+          if (g == 0) {
+            best[mb][nb][reg] = l1;
+          } else if (best[mb][nb][reg] < l1) {
+            best[mb][nb][reg] = l1;
+            bidx[mb][nb][reg] = aa.counter_quirk ? bidx[mb][nb][reg] + 1 : g;
+          }
+        }
+      }
+  }
+#pragma unroll
+  for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) {
+      const int64_t trait = t0 + MB * (kk + 4 * reg) + mb;
+      if (trait >= a.m) continue;
+      double l0 = aa.EllTab[trait * (int64_t)aa.ngrid];
+      for (int g = 1; g < aa.ngrid; ++g) l0 = fmax(l0, aa.EllTab[trait * (int64_t)aa.ngrid + g]);
+      double* dst = a.L + trait * a.ldL + ibase;
+      double* dh = aa.H2 + trait * aa.ldH + ibase;
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) {
+        if (ibase + nb < a.p) {
+          const double v = (best[mb][nb][reg] - l0) / ln10;
+          nnan += (v != v);
+          dst[nb] = v;
+          dh[nb] = aa.grid_dev[bidx[mb][nb][reg]];
+        }
+      }
+    }
+  if (nnan) atomicAdd((unsigned long long*)&a.stat[ST_NAN_LOD], (unsigned long long)nnan);
+}
+
+int launch_scan_alt(blmm_ctx* ctx, const AltArgs& aa) {
+  constexpr int MB = 2, NB = 4;
+  const ScanArgs& a = aa.s;
+  const int64_t ntile_t = (a.m + TILE_T - 1) / TILE_T;
+  const int64_t ntile_i = (a.p + TILE_I - 1) / TILE_I;
+  const int64_t nwg = ntile_t * ntile_i;
+  if (nwg <= 0) return BLMM_OK;
+  if (nwg > 0x7fffffffLL) return fail(ctx, BLMM_ERR_INVALID, "problem too large for one launch");
+  hipLaunchKernelGGL((k_scan_alt<MB, NB>), dim3((unsigned)nwg), dim3(256), 0, ctx->stream, aa, (int)ntile_i, nwg);
+  KCHECK();
+  return BLMM_OK;
+}
+
+}  // namespace blmm

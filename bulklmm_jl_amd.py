@@ -1,0 +1,12 @@
+"""Import shim: the package directory is `bulklmm.jl_amd/` (a dot is not importable), so this module
+loads it under the name `bulklmm_jl_amd`."""
+import importlib.util
+import os
+import sys
+
+_dir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "bulklmm.jl_amd")
+_spec = importlib.util.spec_from_file_location("bulklmm_jl_amd", os.path.join(_dir, "__init__.py"),
+                                               submodule_search_locations=[_dir])
+_mod = importlib.util.module_from_spec(_spec)
+sys.modules["bulklmm_jl_amd"] = _mod
+_spec.loader.exec_module(_mod)

@@ -1,0 +1,159 @@
+/*
+ * bulklmm_hip.h -- C ABI of libbulklmm_hip.so: the MI355X (gfx950) bulkscan engine.
+ *
+ * This is the drop-in boundary for the `bulkscan` hot path of senresearch/BulkLMM.jl v1.2.0
+ * (pure Julia; it has no FFI of its own, so the seam is placed under its exported API,
+ * src/BulkLMM.jl:9-47).  A Julia host binds these entry points with `ccall`
+ * (bulklmm.jl_amd/julia/BulkLMMHIP.jl); the Python host mirror
+ * (bulklmm.jl_amd/api.py) binds the same symbols with ctypes.
+ *
+ * Conventions
+ *   - every matrix is dense float64, column-major, leading dimension = row count unless an
+ *     explicit `ld` argument is given (Julia Array{Float64,2} / NumPy order='F');
+ *   - sizes are int64_t (Julia Int64);
+ *   - the caller owns every buffer; the library never retains a caller pointer after return;
+ *   - functions return 0 on success or a negative blmm_err code; blmm_last_error(ctx) gives the
+ *     message (the reference's own message strings are used where the reference throws);
+ *   - `*_dev` entry points take DEVICE pointers (HBM-resident operands, e.g. torch tensors) and
+ *     enqueue on the context's stream without synchronising it; the un-suffixed entry points take
+ *     HOST pointers, copy in/out and return when the outputs are complete in caller memory;
+ *   - a blmm_ctx is bound to one GPU and is not thread-safe (one call at a time per ctx).
+ */
+#ifndef BULKLMM_HIP_H
+#define BULKLMM_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BLMM_VERSION 100 /* 0.1.0 */
+
+typedef struct blmm_ctx blmm_ctx;
+
+enum blmm_err {
+  BLMM_OK = 0,
+  BLMM_ERR_INVALID = -1,       /* bad argument */
+  BLMM_ERR_DIM = -2,           /* "Dimension mismatch."                      src/transform_helpers.jl:9-11 */
+  BLMM_ERR_H2_ONE = -3,        /* "Heritability of 1 is not allowed."        src/lmm.jl:19-21 */
+  BLMM_ERR_DECOMP = -4,        /* "Please choose either `eigen` or `svd`..." src/transform_helpers.jl:51 */
+  BLMM_ERR_METHOD = -5,        /* unknown bulkscan method                    src/bulkscan.jl:126-154 */
+  BLMM_ERR_ONE_TRAIT = -6,     /* "Can only handle one trait."               src/scan.jl:496-498 */
+  BLMM_ERR_NO_INTERCEPT = -7,  /* "Intercept has to be added when no other covariate is given." src/scan.jl:167-169 */
+  BLMM_ERR_ZERO_NORM = -8,     /* "Dividing by zeros: the input vector can not contain any zeros!" src/util.jl:69-71 */
+  BLMM_ERR_NPERMS = -9,        /* "The required number of permutations must be a positive integer." src/scan.jl:528-530 */
+  BLMM_ERR_UNSUPPORTED = -10,  /* e.g. more null covariates than the kernels are instantiated for */
+  BLMM_ERR_NO_DEVICE = -11,    /* no usable gfx950 device */
+  BLMM_ERR_HIP = -12,          /* a HIP runtime call failed */
+  BLMM_ERR_ALLOC = -13
+};
+
+enum blmm_method { BLMM_NULL_EXACT = 0, BLMM_NULL_GRID = 1, BLMM_ALT_GRID = 2 };
+enum blmm_decomp { BLMM_EIGEN = 0, BLMM_SVD = 1 };
+
+/* compat_flags bits */
+#define BLMM_COMPAT_ALT_COUNTER 1 /* B2: h2_panel indexed by an improvement counter, src/bulkscan_helpers.jl:342-343 */
+
+/* Mirrors the keyword arguments of bulkscan()/scan() 1:1 (src/bulkscan.jl:81-92, src/scan.jl:94-109).
+ * `nb` and `nt_blas` (thread blocking knobs of the CPU reference) have no meaning here. */
+typedef struct blmm_opts {
+  int32_t method;         /* blmm_method; bulkscan(...; method=)           */
+  int32_t reml;           /* reml::Bool                                     */
+  int32_t add_intercept;  /* addIntercept::Bool (Covar given)               */
+  int32_t decomp_scheme;  /* blmm_decomp; decomp_scheme::String             */
+  int32_t optim_interval; /* optim_interval::Int64 (null-exact, scan)       */
+  int32_t compat_flags;   /* BLMM_COMPAT_*                                  */
+  double prior_variance;    /* prior_variance::Float64                      */
+  double prior_sample_size; /* prior_sample_size::Float64                   */
+} blmm_opts;
+
+/* Counters behind the reference's warnings / exceptions, plus per-phase device timings (ms)
+ * measured with HIP events when blmm_set_timing(ctx, 1) is on (0 otherwise). */
+typedef struct blmm_status {
+  int64_t n_neg_eig;       /* eigenvalues < -1e-7           -> warning, src/transform_helpers.jl:27-30 */
+  int64_t n_nonpos_weight; /* weights <= 0                  -> warning, src/wls.jl:35-37               */
+  int64_t n_zero_norm;     /* |column norm| <= eps          -> error,   src/util.jl:47-71              */
+  int64_t n_nan_lod;       /* r^2 > 1 (DomainError in the reference, NaN here), src/bulkscan_helpers.jl:23 */
+  int64_t n_brent_maxiter; /* traits whose Brent search hit 1000 iterations                            */
+  int64_t jacobi_sweeps;   /* sweeps used by the device eigensolver                                   */
+  double t_eigen_ms, t_rotate_ms, t_h2_ms, t_prep_ms, t_scan_ms, t_total_ms;
+} blmm_status;
+
+/* ---- library / context ------------------------------------------------------------------ */
+int blmm_version(void);
+int blmm_device_count(void);
+/* Creates a context on HIP device `device_id`.  stream == NULL: the library creates its own stream. */
+int blmm_create(int device_id, void* hip_stream, blmm_ctx** out);
+void blmm_destroy(blmm_ctx* ctx);
+const char* blmm_last_error(const blmm_ctx* ctx);
+const char* blmm_err_string(int code);
+int blmm_set_stream(blmm_ctx* ctx, void* hip_stream);
+/* on = 1: HIP events are recorded on the context's stream at every phase boundary of each bulkscan / scan call
+ * (no synchronisation).  blmm_status then carries the LAST call's phase times, and blmm_read_timings() returns the
+ * SUM over all calls since the previous read together with their count (it synchronises the stream). */
+int blmm_set_timing(blmm_ctx* ctx, int on);
+/* sums_ms[6] = {eigen, rotate, h2, prep, scan, total}; *ncalls = calls accumulated. */
+int blmm_read_timings(blmm_ctx* ctx, double* sums_ms, int64_t* ncalls);
+int blmm_synchronize(blmm_ctx* ctx);
+void blmm_default_opts(blmm_opts* o); /* bulkscan() defaults: null-grid, ML, prior (1.0, 0.0), eigen */
+
+/* ---- calcKinship(G)  (src/kinship.jl:4-14) ----------------------------------------------- */
+int blmm_kinship(blmm_ctx* ctx, const double* G, int64_t n, int64_t p, double* K_out);
+int blmm_kinship_dev(blmm_ctx* ctx, const double* dG, int64_t n, int64_t p, double* dK_out);
+
+/* ---- bulkscan(Y, G, [Covar], K; ...)  (src/bulkscan.jl:81-162, 188-314, 321-397, 428-526) --
+ * Y n x m, G n x p, Covar n x ncov (NULL/0 = none: the intercept is the only null covariate),
+ * K n x n, weights n (NULL = missing), h2_grid ngrid doubles in HOST memory for both variants
+ * (ignored by null-exact).
+ * Outputs: L p x m (column j = trait j, leading dimension ldL >= p); h2_out: m doubles
+ * (h2_null_list; null-exact / null-grid) or p x m, ld = p (h2_panel; alt-grid). */
+int blmm_bulkscan(blmm_ctx* ctx, const blmm_opts* opts, const double* Y, int64_t n, int64_t m, const double* G,
+                  int64_t p, const double* Covar, int64_t ncov, const double* K, const double* weights,
+                  const double* h2_grid, int64_t ngrid, double* L_out, double* h2_out, blmm_status* status);
+int blmm_bulkscan_dev(blmm_ctx* ctx, const blmm_opts* opts, const double* dY, int64_t n, int64_t m,
+                      const double* dG, int64_t p, const double* dCovar, int64_t ncov, const double* dK,
+                      const double* dweights, const double* h2_grid_host, int64_t ngrid, double* dL_out,
+                      int64_t ldL, double* dh2_out, blmm_status* status);
+
+/* ---- scan(y, G, [Covar], K; permutation_test=true)  (src/scan.jl:485-557) ------------------
+ * perm_idx: n x nperms int32, 0-based, column b = permutation b (r0perm[:, b+1] = r0[perm_idx[:, b]]);
+ * NULL = the library draws them from its own counter-based generator seeded by `seed`
+ * (Julia's MersenneTwister stream is not reproducible outside Julia).
+ * Outputs: scalars[0] = sigma2_e, scalars[1] = h2_null; lod_out p; Lperms_out p x nperms (ld = p). */
+int blmm_scan_perms(blmm_ctx* ctx, const blmm_opts* opts, const double* y, int64_t n, const double* G, int64_t p,
+                    const double* Covar, int64_t ncov, const double* K, const double* weights, int64_t nperms,
+                    uint64_t seed, const int32_t* perm_idx, double* scalars_out, double* lod_out,
+                    double* Lperms_out, blmm_status* status);
+int blmm_scan_perms_dev(blmm_ctx* ctx, const blmm_opts* opts, const double* dy, int64_t n, const double* dG,
+                        int64_t p, const double* dCovar, int64_t ncov, const double* dK, const double* dweights,
+                        int64_t nperms, uint64_t seed, const int32_t* dperm_idx, double* dscalars_out,
+                        double* dlod_out, double* dLperms_out, blmm_status* status);
+
+/* ---- lower-level seams (1:1 with the reference's internal functions; used by the parity tests) ---- */
+/* transform_rotation(y, [Z G], K)  (src/transform_helpers.jl:1-54): Y0 n x m, X0 n x (c+p) (first c
+ * columns = rotated null covariates, intercept first when add_intercept), lambda n. */
+int blmm_rotate(blmm_ctx* ctx, const blmm_opts* opts, const double* Y, int64_t n, int64_t m, const double* G,
+                int64_t p, const double* Covar, int64_t ncov, const double* K, double* Y0_out, double* X0_out,
+                double* lambda_out, blmm_status* status);
+/* fitlmm over every column of Y0 (src/lmm.jl:56-86, src/gridbrent.jl:9-24): h2, sigma2, ell: m each. */
+int blmm_null_h2_brent(blmm_ctx* ctx, const blmm_opts* opts, const double* Y0, int64_t n, int64_t m,
+                       const double* Z0, int64_t c, const double* lambda, double* h2_out, double* sigma2_out,
+                       double* ell_out, blmm_status* status);
+/* wls_multivar(Y0, Z0, makeweights(h2_g), prior).Ell for every grid point (src/wls.jl:103-176,
+ * src/bulkscan_helpers.jl:267-269): Ell_out ngrid x m (ld = ngrid). */
+int blmm_null_loglik_grid(blmm_ctx* ctx, const blmm_opts* opts, const double* Y0, int64_t n, int64_t m,
+                          const double* Z0, int64_t c, const double* lambda, const double* h2_grid, int64_t ngrid,
+                          double* Ell_out, blmm_status* status);
+/* weighted_liteqtl(Y0, X0, lambda, hsq; num_of_covar)  (src/bulkscan_helpers.jl:175-201): X0 n x (c+p). */
+int blmm_weighted_liteqtl(blmm_ctx* ctx, const double* Y0, int64_t n, int64_t m, const double* X0, int64_t c,
+                          int64_t p, const double* lambda, double hsq, double* LOD_out, blmm_status* status);
+/* univar_liteqtl over every column of Y0 with the per-trait h2 supplied by the caller
+ * (src/bulkscan_helpers.jl:138-146): the exact-weights LOD kernel on its own. */
+int blmm_liteqtl_given_h2(blmm_ctx* ctx, const double* Y0, int64_t n, int64_t m, const double* X0, int64_t c,
+                          int64_t p, const double* lambda, const double* h2, double* LOD_out, blmm_status* status);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BULKLMM_HIP_H */

@@ -1,0 +1,73 @@
+"""Shared helpers for the test-suite: seeded synthetic data and the parity criterion."""
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+GOLDEN = os.path.join(HERE, "golden")
+
+# parity criterion of SURVEY.md §8(c): |L_gpu - L_ref| <= 1e-6*|L_ref| + 1e-10 (fp64)
+RTOL = 1e-6
+ATOL = 1e-10
+
+
+def bxd_kinship() -> np.ndarray:
+    """The real BXD kinship (79 x 79) held by the reference's tests: test/ref_data_for_tests/kinship_ref.he
+    (Helium: 56-byte header, column-major float64), rounded to 12 digits as test/kinship_test.jl:5 does."""
+    raw = open(os.path.join(GOLDEN, "bxd_kinship_ref.he"), "rb").read()
+    nrow, ncol = np.frombuffer(raw[:16], dtype="<i8")
+    K = np.frombuffer(raw[56:56 + 8 * nrow * ncol], dtype="<f8").reshape((ncol, nrow)).T.copy()
+    return np.round(K, 12)
+
+
+def make_geno(n: int, p: int, rng) -> np.ndarray:
+    """RIL-like genotype probabilities: two-state Markov chain along markers (switch prob 0.01),
+    2 % of entries replaced by U(0,1)."""
+    sw = rng.random((n, p)) < 0.01
+    sw[:, 0] = rng.random(n) < 0.5
+    G = (np.cumsum(sw, axis=1) % 2).astype(np.float64)
+    unc = rng.random((n, p)) < 0.02
+    G[unc] = rng.random(int(unc.sum()))
+    return G
+
+
+def kinship_of(G: np.ndarray) -> np.ndarray:
+    X = G - 0.5
+    K = 2.0 * (X @ X.T) / X.shape[1] + 0.5
+    np.fill_diagonal(K, 1.0)
+    return np.round(K, 12)
+
+
+def make_data(n=79, p=300, m=40, seed=20240, bxd=True, ncov=0):
+    rng = np.random.Generator(np.random.PCG64(seed))
+    G = make_geno(n, p, rng)
+    K = bxd_kinship() if (bxd and n == 79) else kinship_of(G)
+    lam, U = np.linalg.eigh(K)
+    lam = np.maximum(lam, 0)
+    h2 = rng.uniform(0.0, 0.9, size=m)
+    g = (U * np.sqrt(lam)) @ rng.standard_normal((n, m)) * np.sqrt(h2 / (1 - h2))
+    e = rng.standard_normal((n, m))
+    Y = g + e
+    causal = rng.random(m) < 0.3
+    q = rng.integers(0, p, size=m)
+    beta = rng.standard_normal(m) * 1.5
+    Y[:, causal] += G[:, q[causal]] * beta[causal]
+    Y += 10.0  # a non-zero mean (the intercept matters)
+    Covar = rng.standard_normal((n, ncov)) if ncov else None
+    if ncov:
+        Y += Covar @ rng.standard_normal((ncov, m))
+    return Y, G, K, Covar
+
+
+def assert_lod_close(got, ref, rtol=RTOL, atol=ATOL, what="LOD"):
+    got = np.asarray(got)
+    ref = np.asarray(ref)
+    assert got.shape == ref.shape, (got.shape, ref.shape)
+    err = np.abs(got - ref)
+    bound = rtol * np.abs(ref) + atol
+    bad = ~(err <= bound)
+    if bad.any():
+        i = np.unravel_index(np.argmax(np.where(bad, err, 0)), err.shape)
+        raise AssertionError(f"{what}: {int(bad.sum())}/{bad.size} outside |d| <= {rtol}*|ref| + {atol}; "
+                             f"worst at {i}: got {got[i]!r} ref {ref[i]!r} |d| {err[i]:.3e}; max rel "
+                             f"{np.nanmax(err / np.maximum(np.abs(ref), 1e-300)):.3e}")
