@@ -3,6 +3,7 @@
 // Mirrors bulkscan / bulkscan_null / bulkscan_null_grid / bulkscan_alt_grid (src/bulkscan.jl) and
 // scan_perms_lite (src/scan.jl:485-557) of BulkLMM.jl; nothing here falls back to a CPU path.
 #include "blmm_internal.h"
+#include "fastmath.h"
 #include <cmath>
 #include <cstring>
 #include <limits>
@@ -134,6 +135,7 @@ int finish_status(blmm_ctx* ctx, blmm_status* st, Timer* tm) {
   st->n_nan_lod = h[ST_NAN_LOD];
   st->n_brent_maxiter = h[ST_BRENT_MAXIT];
   st->jacobi_sweeps = h[ST_JACOBI_SWEEPS];
+  st->jacobi_cycles = h[6]; st->jacobi_ticks_100mhz = h[7];
   if (tm && tm->set && tm->set->n >= 2) {
     double t[6];
     phase_times(*tm->set, t);
@@ -158,7 +160,8 @@ int prepare(blmm_ctx* ctx, const blmm_opts* o, const double* dY, int64_t n, int6
   P.m = m; P.p = p; P.ldy = round_up(m > 0 ? m : 1, 128); P.ldx = round_up(p > 0 ? p : 1, 128);
   int rc;
   if ((rc = ensure(ctx, ctx->Ks, sizeof(double) * n * n))) return rc;
-  if ((rc = ensure(ctx, ctx->V, sizeof(double) * n * n))) return rc;
+  if ((rc = ensure(ctx, ctx->V, sizeof(double) * (n * n + 4 * n + 16)))) return rc;
+  if ((rc = ensure(ctx, ctx->lraw, sizeof(double) * n))) return rc;
   if ((rc = ensure(ctx, ctx->U, sizeof(double) * n * n))) return rc;
   if ((rc = ensure(ctx, ctx->lam, sizeof(double) * n))) return rc;
   if ((rc = ensure(ctx, ctx->Zs, sizeof(double) * n * c))) return rc;
@@ -170,8 +173,8 @@ int prepare(blmm_ctx* ctx, const blmm_opts* o, const double* dY, int64_t n, int6
   P.Yt = ptr<double>(ctx->Yt); P.Xt = ptr<double>(ctx->Xt); P.Z0 = ptr<double>(ctx->Z0); P.lam = ptr<double>(ctx->lam);
   tm.mark();
   if ((rc = launch_design(ctx, dK, dCovar, (int)ncov, add_int, dweights, (int)n, ptr<double>(ctx->Ks), ptr<double>(ctx->Zs)))) return rc;
-  if ((rc = launch_jacobi(ctx, ptr<double>(ctx->Ks), ptr<double>(ctx->V), (int)n, P.stat))) return rc;
-  if ((rc = launch_post_eigen(ctx, ptr<double>(ctx->Ks), ptr<double>(ctx->V), ptr<double>(ctx->Zs), dweights, (int)n, c,
+  if ((rc = launch_jacobi(ctx, ptr<double>(ctx->Ks), ptr<double>(ctx->V), (int)n, ptr<double>(ctx->lraw), P.stat))) return rc;
+  if ((rc = launch_post_eigen(ctx, ptr<double>(ctx->lraw), ptr<double>(ctx->V), ptr<double>(ctx->Zs), dweights, (int)n, c,
                               P.npad, P.ldr, o->decomp_scheme, centered, P.lam, ptr<double>(ctx->U), P.Z0,
                               ptr<double>(ctx->Rp), P.stat))) return rc;
   tm.mark();
@@ -204,11 +207,11 @@ int grid_to_device(blmm_ctx* ctx, const double* h2_grid_host, int64_t ngrid, dou
   return BLMM_OK;
 }
 
-ScanArgs scan_args(const Pipe& P, const double* panels, int64_t ldp, double* L, int64_t ldL, int64_t m) {
+ScanArgs scan_args(blmm_ctx* ctx, const Pipe& P, const double* panels, int64_t ldp, double* L, int64_t ldL, int64_t m) {
   ScanArgs a;
   a.Xt = P.Xt; a.ldx = P.ldx; a.P = panels; a.ldp = ldp; a.pstride = (int64_t)P.npad * ldp;
   a.ks = P.npad / 4; a.n = P.n; a.p = P.p; a.m = m; a.L = L; a.ldL = ldL;
-  a.isx = nullptr; a.ld_isx = 0; a.bin = nullptr; a.stat = P.stat;
+  a.isx = nullptr; a.ld_isx = 0; a.bin = nullptr; a.stat = P.stat; a.logtab = ptr<double>(ctx->logtab);
   return a;
 }
 
@@ -258,6 +261,11 @@ int blmm_create(int device_id, void* hip_stream, blmm_ctx** out) {
     if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { delete ctx; return BLMM_ERR_HIP; }
     ctx->own_stream = true;
   }
+  if (ensure(ctx, ctx->logtab, sizeof(blmm_log_table_host)) != BLMM_OK ||
+      hipMemcpy(ctx->logtab.p, blmm_log_table_host, sizeof(blmm_log_table_host), hipMemcpyHostToDevice) != hipSuccess) {
+    blmm_destroy(ctx);
+    return BLMM_ERR_HIP;
+  }
   *out = ctx;
   return BLMM_OK;
 }
@@ -269,7 +277,7 @@ void blmm_destroy(blmm_ctx* ctx) {
   DevBuf* bufs[] = {&ctx->Ks, &ctx->V, &ctx->lam, &ctx->U, &ctx->Zs, &ctx->Z0, &ctx->Rp, &ctx->Yt, &ctx->Xt, &ctx->panels,
                     &ctx->iyy, &ctx->h2, &ctx->h2idx, &ctx->sig2, &ctx->ell, &ctx->isx, &ctx->stat, &ctx->gridd, &ctx->misc,
                     &ctx->EllTab, &ctx->inY, &ctx->inG, &ctx->inK, &ctx->inCov, &ctx->inW, &ctx->outL, &ctx->outH2,
-                    &ctx->tmpA, &ctx->tmpB, &ctx->tmpC, &ctx->perm, &ctx->r0, &ctx->altbuf};
+                    &ctx->tmpA, &ctx->tmpB, &ctx->tmpC, &ctx->perm, &ctx->r0, &ctx->altbuf, &ctx->logtab, &ctx->lraw};
   for (DevBuf* b : bufs) if (b->p) hipFree(b->p);
   for (auto& s : ctx->evsets) for (auto& e : s.e) (void)hipEventDestroy(e);
   if (ctx->own_stream) hipStreamDestroy(ctx->stream);
@@ -377,7 +385,7 @@ int blmm_bulkscan_dev(blmm_ctx* ctx, const blmm_opts* opts, const double* dY, in
     if ((rc = ensure(ctx, ctx->panels, sizeof(double) * (size_t)(2 + P.c) * P.npad * ldp))) return rc;
     if ((rc = launch_panels(ctx, nm, P.Yt, P.ldy, m, P.Z0, P.lam, dh2_out, 1, ptr<double>(ctx->panels), ldp, P.stat))) return rc;
     tm.mark();
-    ScanArgs a = scan_args(P, ptr<double>(ctx->panels), ldp, dL_out, ldL, m);
+    ScanArgs a = scan_args(ctx, P, ptr<double>(ctx->panels), ldp, dL_out, ldL, m);
     if ((rc = launch_scan_exact(ctx, a, P.c))) return rc;
     tm.mark();
   } else if (opts->method == BLMM_NULL_GRID) {
@@ -389,7 +397,7 @@ int blmm_bulkscan_dev(blmm_ctx* ctx, const blmm_opts* opts, const double* dY, in
     if ((rc = ensure(ctx, ctx->isx, sizeof(double) * (size_t)ngrid * P.ldx))) return rc;
     if ((rc = launch_isx(ctx, nm, P.Xt, P.ldx, p, P.Z0, P.lam, dgrid, (int)ngrid, ptr<double>(ctx->isx), P.ldx, P.stat))) return rc;
     tm.mark();
-    ScanArgs a = scan_args(P, ptr<double>(ctx->panels), ldp, dL_out, ldL, m);
+    ScanArgs a = scan_args(ctx, P, ptr<double>(ctx->panels), ldp, dL_out, ldL, m);
     a.isx = ptr<double>(ctx->isx); a.ld_isx = P.ldx; a.bin = ptr<int>(ctx->h2idx);
     if ((rc = launch_scan_table(ctx, a))) return rc;
     tm.mark();
@@ -408,7 +416,7 @@ int blmm_bulkscan_dev(blmm_ctx* ctx, const blmm_opts* opts, const double* dY, in
     if ((rc = launch_isx(ctx, nm, P.Xt, P.ldx, p, P.Z0, P.lam, dgrid, (int)ngrid, ptr<double>(ctx->isx), P.ldx, P.stat))) return rc;
     tm.mark();
     AltArgs aa;
-    aa.s = scan_args(P, ptr<double>(ctx->panels), ldp, dL_out, ldL, m);
+    aa.s = scan_args(ctx, P, ptr<double>(ctx->panels), ldp, dL_out, ldL, m);
     aa.s.isx = ptr<double>(ctx->isx); aa.s.ld_isx = P.ldx;
     aa.ngrid = (int)ngrid; aa.EllTab = ptr<double>(ctx->EllTab); aa.grid_dev = dgrid; aa.H2 = dh2_out; aa.ldH = p;
     aa.counter_quirk = (opts->compat_flags & BLMM_COMPAT_ALT_COUNTER) ? 1 : 0;
@@ -487,11 +495,11 @@ int blmm_scan_perms_dev(blmm_ctx* ctx, const blmm_opts* opts, const double* dy, 
   if ((rc = launch_isx(ctx, nm, P.Xt, P.ldx, p, P.Z0, P.lam, dscalars_out + 1, 1, ptr<double>(ctx->isx), P.ldx, P.stat))) return rc;
   tm.mark();
   if (p > 0) {
-    ScanArgs a = scan_args(P, pan0, ldp0, dlod_out, p, 1);
+    ScanArgs a = scan_args(ctx, P, pan0, ldp0, dlod_out, p, 1);
     a.isx = ptr<double>(ctx->isx); a.ld_isx = P.ldx;
     if ((rc = launch_scan_table(ctx, a))) return rc;
     if (nperms > 0) {
-      ScanArgs b = scan_args(P, pan1, ldp1, dLperms_out, p, nperms);
+      ScanArgs b = scan_args(ctx, P, pan1, ldp1, dLperms_out, p, nperms);
       b.isx = ptr<double>(ctx->isx); b.ld_isx = P.ldx;
       if ((rc = launch_scan_table(ctx, b))) return rc;
     }
@@ -671,7 +679,7 @@ int blmm_weighted_liteqtl(blmm_ctx* ctx, const double* Y0, int64_t n, int64_t m,
   if ((rc = ensure(ctx, ctx->isx, sizeof(double) * (size_t)P.ldx))) return rc;
   if ((rc = launch_isx(ctx, nm, P.Xt, P.ldx, p, P.Z0, P.lam, ptr<double>(ctx->h2), 1, ptr<double>(ctx->isx), P.ldx, P.stat))) return rc;
   if ((rc = ensure(ctx, ctx->outL, sizeof(double) * (size_t)p * m))) return rc;
-  ScanArgs a = scan_args(P, ptr<double>(ctx->panels), P.ldy, ptr<double>(ctx->outL), p, m);
+  ScanArgs a = scan_args(ctx, P, ptr<double>(ctx->panels), P.ldy, ptr<double>(ctx->outL), p, m);
   a.isx = ptr<double>(ctx->isx); a.ld_isx = P.ldx;
   if ((rc = launch_scan_table(ctx, a))) return rc;
   BLMM_HIP(hipMemcpyAsync(LOD_out, ctx->outL.p, sizeof(double) * (size_t)p * m, hipMemcpyDeviceToHost, ctx->stream));
@@ -696,7 +704,7 @@ int blmm_liteqtl_given_h2(blmm_ctx* ctx, const double* Y0, int64_t n, int64_t m,
   if ((rc = ensure(ctx, ctx->panels, sizeof(double) * (size_t)(2 + P.c) * P.npad * P.ldy))) return rc;
   if ((rc = launch_panels(ctx, nm, P.Yt, P.ldy, m, P.Z0, P.lam, ptr<double>(ctx->h2), 1, ptr<double>(ctx->panels), P.ldy, P.stat))) return rc;
   if ((rc = ensure(ctx, ctx->outL, sizeof(double) * (size_t)p * m))) return rc;
-  ScanArgs a = scan_args(P, ptr<double>(ctx->panels), P.ldy, ptr<double>(ctx->outL), p, m);
+  ScanArgs a = scan_args(ctx, P, ptr<double>(ctx->panels), P.ldy, ptr<double>(ctx->outL), p, m);
   if ((rc = launch_scan_exact(ctx, a, P.c))) return rc;
   BLMM_HIP(hipMemcpyAsync(LOD_out, ctx->outL.p, sizeof(double) * (size_t)p * m, hipMemcpyDeviceToHost, ctx->stream));
   BLMM_HIP(hipStreamSynchronize(ctx->stream));

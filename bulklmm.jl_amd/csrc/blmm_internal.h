@@ -36,7 +36,7 @@ struct blmm_ctx {
   std::string err;
   // grow-only workspace
   blmm::DevBuf Ks, V, lam, U, Zs, Z0, Rp, Yt, Xt, panels, iyy, h2, h2idx, sig2, ell, isx, stat, gridd, misc, EllTab,
-      inY, inG, inK, inCov, inW, outL, outH2, tmpA, tmpB, tmpC, perm, r0, altbuf;
+      inY, inG, inK, inCov, inW, outL, outH2, tmpA, tmpB, tmpC, perm, r0, altbuf, logtab, lraw;
   // event sets: one per timed call since the last blmm_read_timings (grown on demand, reused afterwards)
   struct EvSet { hipEvent_t e[8]; int n; };
   std::vector<EvSet> evsets;
@@ -69,9 +69,9 @@ int launch_design(blmm_ctx* ctx, const double* dK, const double* dCovar, int nco
                   const double* dweights, int n, double* Ks, double* Zs);
 // One-sided Jacobi eigen-decomposition of the symmetric n x n matrix in A (destroyed); V gets the eigenvectors
 // (unsorted), then post_eigen sorts/derives everything the rotation needs.
-int launch_jacobi(blmm_ctx* ctx, double* A, double* V, int n, int64_t* stat);
+int launch_jacobi(blmm_ctx* ctx, double* A, double* V, int n, double* lraw, int64_t* stat);
 // lambda (ascending, or |lambda| descending for svd), U sorted, Z0 = U' Zs, Rp = (centered ? Q U' Wd : U' Wd)'
-int launch_post_eigen(blmm_ctx* ctx, const double* A, const double* V, const double* Zs, const double* dweights, int n,
+int launch_post_eigen(blmm_ctx* ctx, const double* lraw, const double* V, const double* Zs, const double* dweights, int n,
                       int c, int npad, int ldr, int decomp, int centered, double* lam, double* U, double* Z0, double* Rp,
                       int64_t* stat);
 // Out (row-major, npad x ldo) = R * In  (In column-major n x ncols); pads with zeros up to ncols_pad / npad.
@@ -113,6 +113,7 @@ struct ScanArgs {
   int64_t p, m;
   double* L; int64_t ldL;
   const double* isx; int64_t ld_isx; const int* bin;  // table mode
+  const double* logtab;                    // device copy of log_table.h
   int64_t* stat;
 };
 int launch_scan_exact(blmm_ctx* ctx, const ScanArgs& a, int c);

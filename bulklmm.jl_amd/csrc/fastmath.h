@@ -1,0 +1,56 @@
+// fastmath.h -- table-driven fp64 logarithms and Newton reciprocal for the gfx950 kernels.
+// On MI355X the fp64 MFMA and fp64 VALU instructions execute exclusively of each other on a SIMD
+// (tools/mb2_f64.hip), so every VALU instruction of an epilogue is paid in matrix-pipe time: the OCML
+// log10 (~50 instruction slots) and IEEE division (~16) are replaced by a 128-entry table + degree-8
+// polynomial (~20 slots, <= 1 ulp-ish, full relative accuracy as x -> 1) and rcp + 2 Newton steps.
+// Table: log_table.h (tools/gen_log_table.py).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "log_table.h"
+
+namespace blmm {
+
+typedef double dpair __attribute__((ext_vector_type(2)));
+
+// stage {invc, log10(c)} (LOG10 = true) or {invc, ln(c)} pairs into LDS: 128 x 16 bytes.
+// gtab: device copy of blmm_log_table_host (blmm_ctx::logtab, uploaded by blmm_create)
+template <bool LOG10>
+__device__ __forceinline__ void stage_log_table(dpair* lds, const double* __restrict__ gtab) {
+  for (int i = threadIdx.x; i < BLMM_LOG_TABLE_N; i += blockDim.x)
+    lds[i] = (dpair){gtab[3 * i], gtab[3 * i + (LOG10 ? 2 : 1)]};
+}
+
+// log10(x) (LOG10) or ln(x) for a positive, finite, normal x.  lds: table staged by stage_log_table.
+template <bool LOG10>
+__device__ __forceinline__ double fast_log(double x, const dpair* __restrict__ lds) {
+  const uint32_t hi = (uint32_t)__double2hiint(x), lo = (uint32_t)__double2loint(x);
+  const uint32_t tmp = hi - 0x3fe60000u;
+  const int i = (int)((tmp >> 13) & 127u);
+  const int k = (int)tmp >> 20;
+  const double z = __hiloint2double((int)(hi - (tmp & 0xfff00000u)), (int)lo);
+  const dpair e = lds[i];
+  const double r = fma(z, e[0], -1.0);
+  constexpr double S = LOG10 ? BLMM_INV_LN10 : 1.0;
+  double p = -S / 8.0;
+  p = fma(p, r, S / 7.0);
+  p = fma(p, r, -S / 6.0);
+  p = fma(p, r, S / 5.0);
+  p = fma(p, r, -S / 4.0);
+  p = fma(p, r, S / 3.0);
+  p = fma(p, r, -S / 2.0);
+  p = fma(p, r, S);
+  const double t = fma((double)k, LOG10 ? BLMM_LOG10_2 : BLMM_LN2, e[1]);
+  return fma(r, p, t);
+}
+
+// 1/x to ~1 ulp: v_rcp_f64 seed + two Newton steps (x finite, non-zero, normal)
+__device__ __forceinline__ double fast_rcp(double x) {
+  double y = __builtin_amdgcn_rcp(x);
+  double e = fma(-x, y, 1.0);
+  y = fma(y, e, y);
+  e = fma(-x, y, 1.0);
+  return fma(y, e, y);
+}
+
+}  // namespace blmm

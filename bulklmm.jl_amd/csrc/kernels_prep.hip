@@ -3,6 +3,7 @@
 //   per-trait null-model h2 (Optim-style Brent / grid), A-side panels, per-grid marker norms, kinship.
 // gfx950 only.  Reference anchors are cited per kernel (paths relative to the BulkLMM.jl checkout).
 #include "blmm_internal.h"
+#include "fastmath.h"
 #include <cmath>
 
 namespace blmm {
@@ -46,82 +47,271 @@ int launch_design(blmm_ctx* ctx, const double* dK, const double* dCovar, int nco
 }
 
 // ------------------------------------------------------------------------------------------------
-// Eigen-decomposition of the symmetric kinship: one-sided (Hestenes) Jacobi, one workgroup.
+// Eigen-decomposition of the symmetric kinship: two-sided cyclic Jacobi with the round-robin parallel
+// ordering, one workgroup, A and V resident in LDS (n <= ~100) or in global memory (larger n).
 // Replaces LAPACK `eigen(K)` / `svd(K)` of src/transform_helpers.jl:21-49.  LODs do not depend on the
-// eigenbasis chosen, only on K = U diag(lambda) U' holding to rounding.
-// A (n x n, column-major) starts as K and ends as K*V = V*diag(lambda); V accumulates the rotations.
+// eigenbasis chosen, only on K = V diag(lambda) V' holding to rounding.
+// Per round (N/2 disjoint pairs): (1) one lane per pair computes (c, s) from a_pp, a_qq, a_pq;
+// (2) columns p,q of A and V are rotated; (3) rows p,q of A are rotated.  No cross-lane reductions.
+// The work-item -> (pair slot, matrix, row) map is the same in every round and is kept in registers.
 // ------------------------------------------------------------------------------------------------
-template <bool USE_LDS>
-__global__ void __launch_bounds__(1024) k_jacobi(double* __restrict__ Ag, double* __restrict__ Vg, int n, int64_t* stat) {
+__device__ __forceinline__ double nr_rsqrt(double x) {  // 1/sqrt(x), x > 0 normal: v_rsq_f64 + two Newton steps
+  double y = __builtin_amdgcn_rsq(x);
+  double h = 0.5 * x * y;
+  y = fma(y, fma(-h, y, 0.5), y);
+  h = 0.5 * x * y;
+  return fma(y, fma(-h, y, 0.5), y);
+}
+__device__ __forceinline__ double nr_rcp(double x) {
+  double y = __builtin_amdgcn_rcp(x);
+  double e = fma(-x, y, 1.0);
+  y = fma(y, e, y);
+  e = fma(-x, y, 1.0);
+  return fma(y, e, y);
+}
+
+// LDS variant (n <= JAC_NMAX): every workgroup of the launch runs the SAME deterministic iteration on its own LDS
+// copy of A (bitwise identical rotations, so no inter-workgroup synchronisation is ever needed) and accumulates
+// the rotations only into its own slice of the rows of V (rows of V are independent under column rotations).
+//   A update: one thread per 2x2 block between two pair slots, B' = J1' B J2 (both triangles are stored);
+//   schedule: the round-robin pairing (p, q) of every (round, slot) is tabulated once in LDS.
+constexpr int JAC_NMAX = 112;
+constexpr int JAC_NWG = 8;
+
+__global__ void __launch_bounds__(1024) k_jacobi_lds(const double* __restrict__ Ag, double* __restrict__ Vg, int n,
+                                                     double* __restrict__ lraw, int64_t* stat) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
-  __shared__ int s_rot;
-  double* A = USE_LDS ? smem : Ag;
-  double* V = USE_LDS ? smem + (size_t)n * n : Vg;
-  const int tid = threadIdx.x;
-  const int l16 = tid & 15, grp = tid >> 4, ngrp = blockDim.x >> 4;
-  for (int e = tid; e < n * n; e += blockDim.x) {
-    if (USE_LDS) A[e] = Ag[e];
-    V[e] = ((e % n) == (e / n)) ? 1.0 : 0.0;
+  __shared__ int s_flag[2];
+  __shared__ double s_anorm;
+  const int tid = threadIdx.x, nt = blockDim.x;
+  const unsigned long long dbg_t0 = __builtin_amdgcn_s_memtime(), dbg_r0 = __builtin_amdgcn_s_memrealtime();
+  const int N = n + (n & 1), NP2 = N / 2, ld = N + 1;  // odd leading dimension
+  const int rows_per = (n + gridDim.x - 1) / gridDim.x;
+  const int r0 = blockIdx.x * rows_per, r1 = min(n, r0 + rows_per), nr = max(0, r1 - r0);
+  double* A = smem;                               // N x ld (column j at j*ld); the pad row/col of an odd n stays zero
+  double* Vs = A + N * ld;                        // rows_per x ld : Vs[r*ld + col]
+  double* rec = Vs + rows_per * ld;               // NP2 x 4 : {c, s, (p*ld | q*ld), (p | q)} per pair slot
+  double* relmax = rec + 4 * NP2;                 // NP2
+  unsigned short* sched = reinterpret_cast<unsigned short*>(relmax + NP2);  // (N-1) x NP2 x 2
+  const int nblk = NP2 * (NP2 + 1) / 2;
+  unsigned short* blk = sched + 2 * (N - 1) * NP2;                           // nblk x 2 : (s1 <= s2)
+  for (int row = tid; row < NP2; row += nt)
+    for (int b = 0; b <= row; ++b) { const int e = row * (row + 1) / 2 + b; blk[2 * e] = (unsigned short)b; blk[2 * e + 1] = (unsigned short)row; }
+  for (int e = tid; e < N * ld; e += nt) A[e] = 0.0;
+  for (int e = tid; e < rows_per * ld; e += nt) Vs[e] = 0.0;
+  __syncthreads();
+  for (int e = tid; e < n * n; e += nt) { const int i = e % n, j = e / n; A[j * ld + i] = Ag[e]; }
+  for (int r = tid; r < nr; r += nt) Vs[r * ld + (r0 + r)] = 1.0;
+  for (int e = tid; e < (N - 1) * NP2; e += nt) {
+    const int round = e / NP2, slot = e % NP2;
+    int p, q;
+    if (slot == 0) { p = N - 1; q = round; }
+    else { p = (round + slot) % (N - 1); q = (round - slot + (N - 1)) % (N - 1); }
+    if (p > q) { const int t = p; p = q; q = t; }
+    sched[2 * e] = (unsigned short)p; sched[2 * e + 1] = (unsigned short)q;
   }
   __syncthreads();
-  const int N = n + (n & 1);
-  const double tol = sqrt((double)n) * 2.220446049250313e-16;
+  if (tid == 0) {
+    double m = 0.0;
+    for (int i = 0; i < n; ++i) m = fmax(m, fabs(A[i * ld + i]));
+    s_anorm = m;
+  }
+  __syncthreads();
+  const double eps = 2.220446049250313e-16;
+  const double tol2 = (4.0 * eps) * (4.0 * eps);
+  const double floor2 = (eps * s_anorm) * (eps * s_anorm);
+  // fixed thread -> work maps (identical in every round)
+  int bs1 = -1, bs2 = -1;                               // first A block of this thread
+  if (tid < nblk) { bs1 = blk[2 * tid]; bs2 = blk[2 * tid + 1]; }
+  const int nvit = NP2 * nr;                            // V items (slot, local row), dealt from the last thread down
+  const int vitem = nt - 1 - tid;
+  const int vslot = (vitem < nvit) ? vitem / max(nr, 1) : -1, vrow = (vitem < nvit) ? vitem % max(nr, 1) : 0;
   int sweep = 0;
-  for (; sweep < 40; ++sweep) {
-    if (tid == 0) s_rot = 0;
-    __syncthreads();
+  for (; sweep < 30; ++sweep) {
+    double myrel = 0.0;
     for (int round = 0; round < N - 1; ++round) {
-      for (int pr = grp; pr < N / 2; pr += ngrp) {
-        int i, j;
-        if (pr == 0) { i = N - 1; j = round; }
-        else { i = (round + pr) % (N - 1); j = (round - pr + (N - 1)) % (N - 1); }
-        if (i > j) { int t = i; i = j; j = t; }
-        if (j >= n) continue;  // padded player
-        double* ai = A + (size_t)i * n;
-        double* aj = A + (size_t)j * n;
-        double alpha = 0, beta = 0, gamma = 0;
-        for (int k = l16; k < n; k += 16) {
-          const double x = ai[k], y = aj[k];
-          alpha = fma(x, x, alpha); beta = fma(y, y, beta); gamma = fma(x, y, gamma);
+      const unsigned short* sc = sched + 2 * round * NP2;
+      // ---- (1) rotation angles: one lane per pair ---------------------------------------------------
+      if (tid < NP2) {
+        const int p = sc[2 * tid], q = sc[2 * tid + 1];
+        const double app = A[p * ld + p], aqq = A[q * ld + q], apq = A[q * ld + p];
+        double c = 1.0, s = 0.0;
+        const double pp = fmax(fabs(app * aqq), floor2), a2 = apq * apq;
+        if (a2 > tol2 * pp) {
+          const double d = aqq - app;
+          const double g = fma(d, d, 4.0 * a2);
+          const double h = g * nr_rsqrt(g);                       // sqrt(d^2 + 4 apq^2)
+          const double t = copysign(2.0 * apq, apq * copysign(1.0, d)) * nr_rcp(fabs(d) + h);
+          c = nr_rsqrt(fma(t, t, 1.0));
+          s = t * c;
+          myrel = fmax(myrel, a2 * __builtin_amdgcn_rcp(pp));     // ~relative off-diagonal^2 (only gates the stop rule)
         }
-#pragma unroll
-        for (int o = 1; o < 16; o <<= 1) {
-          alpha += __shfl_xor(alpha, o, 16); beta += __shfl_xor(beta, o, 16); gamma += __shfl_xor(gamma, o, 16);
-        }
-        if (gamma != 0.0 && fabs(gamma) > tol * sqrt(alpha * beta)) {
-          if (l16 == 0) s_rot = 1;
-          const double zeta = (beta - alpha) / (2.0 * gamma);
-          const double t = copysign(1.0, zeta) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
-          const double c = 1.0 / sqrt(1.0 + t * t), s = c * t;
-          double* vi = V + (size_t)i * n;
-          double* vj = V + (size_t)j * n;
-          for (int k = l16; k < n; k += 16) {
-            const double x = ai[k], y = aj[k];
-            ai[k] = c * x - s * y; aj[k] = s * x + c * y;
-            const double u = vi[k], w = vj[k];
-            vi[k] = c * u - s * w; vj[k] = s * u + c * w;
+        rec[4 * tid] = c; rec[4 * tid + 1] = s;
+        reinterpret_cast<int*>(rec + 4 * tid + 2)[0] = p * ld; reinterpret_cast<int*>(rec + 4 * tid + 2)[1] = q * ld;
+        reinterpret_cast<int*>(rec + 4 * tid + 3)[0] = p; reinterpret_cast<int*>(rec + 4 * tid + 3)[1] = q;
+      }
+      __syncthreads();
+      // ---- (2) A: block (s1, s2):  B' = J1' B J2 ;  V slice: columns p, q of every local row -----
+      for (int b = tid; b < nblk; b += nt) {
+        const int s1 = (b == tid) ? bs1 : blk[2 * b], s2 = (b == tid) ? bs2 : blk[2 * b + 1];
+        const dpair cs1 = *reinterpret_cast<const dpair*>(rec + 4 * s1), cs2 = *reinterpret_cast<const dpair*>(rec + 4 * s2);
+        if (cs1[1] != 0.0 || cs2[1] != 0.0) {
+          const int4 i1 = *reinterpret_cast<const int4*>(rec + 4 * s1 + 2), i2 = *reinterpret_cast<const int4*>(rec + 4 * s2 + 2);
+          const double c1 = cs1[0], sn1 = cs1[1], c2 = cs2[0], sn2 = cs2[1];
+          // i.x = p*ld, i.y = q*ld, i.z = p, i.w = q
+          if (s1 == s2) {
+            const double app = A[i1.x + i1.z], aqq = A[i1.y + i1.w], apq = A[i1.y + i1.z];
+            const double cc = c1 * c1, ss = sn1 * sn1, x = 2.0 * c1 * sn1 * apq;
+            A[i1.x + i1.z] = fma(cc, app, fma(ss, aqq, -x));
+            A[i1.y + i1.w] = fma(ss, app, fma(cc, aqq, x));
+            A[i1.y + i1.z] = 0.0; A[i1.x + i1.w] = 0.0;
+          } else {
+            // B = [[b00 b01],[b10 b11]] rows (p1,q1), cols (p2,q2)
+            const double b00 = A[i2.x + i1.z], b01 = A[i2.y + i1.z];
+            const double b10 = A[i2.x + i1.w], b11 = A[i2.y + i1.w];
+            const double t00 = fma(c2, b00, -sn2 * b01), t01 = fma(sn2, b00, c2 * b01);
+            const double t10 = fma(c2, b10, -sn2 * b11), t11 = fma(sn2, b10, c2 * b11);
+            const double n00 = fma(c1, t00, -sn1 * t10), n01 = fma(c1, t01, -sn1 * t11);
+            const double n10 = fma(sn1, t00, c1 * t10), n11 = fma(sn1, t01, c1 * t11);
+            A[i2.x + i1.z] = n00; A[i2.y + i1.z] = n01; A[i2.x + i1.w] = n10; A[i2.y + i1.w] = n11;
+            A[i1.x + i2.z] = n00; A[i1.x + i2.w] = n01; A[i1.y + i2.z] = n10; A[i1.y + i2.w] = n11;
           }
+        }
+      }
+      for (int item = vitem; item < nvit; item += nt) {
+        const int slot = (item == vitem) ? vslot : item / nr, r = (item == vitem) ? vrow : item % nr;
+        const dpair csv = *reinterpret_cast<const dpair*>(rec + 4 * slot);
+        if (csv[1] != 0.0) {
+          const int2 pqv = *reinterpret_cast<const int2*>(rec + 4 * slot + 3);
+          double* vr = Vs + r * ld;
+          const double x = vr[pqv.x], y = vr[pqv.y];
+          vr[pqv.x] = fma(csv[0], x, -csv[1] * y);
+          vr[pqv.y] = fma(csv[1], x, csv[0] * y);
         }
       }
       __syncthreads();
     }
+    // sweep verdict: the largest relative off-diagonal (squared) any pair met in this sweep
+    if (tid < NP2) relmax[tid] = myrel;
+    __syncthreads();
+    double mx = 0.0;
+    for (int i = 0; i < NP2; ++i) mx = fmax(mx, relmax[i]);
+    __syncthreads();
+    // Jacobi converges quadratically: once every relative off-diagonal met in a sweep was below 1e-9 the sweep left
+    // them at rounding level, and a further (verification) sweep would not rotate anything
+    if (mx < 1e-18) break;
+  }
+  if (blockIdx.x == 0) {
+    for (int i = tid; i < n; i += nt) lraw[i] = A[i * ld + i];
+    if (tid == 0) {
+      stat[ST_JACOBI_SWEEPS] = sweep + 1;
+      stat[6] = (int64_t)(__builtin_amdgcn_s_memtime() - dbg_t0);      // shader cycles spent in the eigensolver
+      stat[7] = (int64_t)(__builtin_amdgcn_s_memrealtime() - dbg_r0);  // 100 MHz ticks
+    }
+  }
+  // eigenvectors, compact n x n column-major: Vg[col*n + row]
+  for (int e = tid; e < nr * n; e += nt) {
+    const int r = e % nr, col = e / nr;
+    Vg[(size_t)col * n + (r0 + r)] = Vs[r * ld + col];
+  }
+}
+
+// Global-memory variant for larger n (one workgroup; A, V in L2): the straightforward column/row form.
+__global__ void __launch_bounds__(1024) k_jacobi_glb(double* __restrict__ A, double* __restrict__ V, int n,
+                                                     double* __restrict__ lraw, int64_t* stat) {
+  __shared__ int s_rot;
+  __shared__ double s_anorm;
+  const int tid = threadIdx.x, nt = blockDim.x;
+  const int N = n + (n & 1), NP2 = N / 2, ld = n;
+  double* cs = V + (size_t)n * n;                        // NP2 x 2 (the caller allocates n*n + 4n + 16)
+  int* pq = reinterpret_cast<int*>(cs + 2 * NP2);       // NP2 x 2
+  if (tid == 0) { s_rot = 0; s_anorm = 0.0; }
+  for (int e = tid; e < n * n; e += nt) V[e] = ((e % n) == (e / n)) ? 1.0 : 0.0;
+  __syncthreads();
+  if (tid == 0) {
+    double m = 0.0;
+    for (int i = 0; i < n; ++i) m = fmax(m, fabs(A[(size_t)i * ld + i]));
+    s_anorm = m;
+  }
+  __syncthreads();
+  const double eps = 2.220446049250313e-16;
+  const double tol2 = (4.0 * eps) * (4.0 * eps);
+  const double floor2 = (eps * s_anorm) * (eps * s_anorm);
+  int sweep = 0;
+  for (; sweep < 30; ++sweep) {
+    for (int round = 0; round < N - 1; ++round) {
+      for (int slot = tid; slot < NP2; slot += nt) {
+        int p, q;
+        if (slot == 0) { p = N - 1; q = round; }
+        else { p = (round + slot) % (N - 1); q = (round - slot + (N - 1)) % (N - 1); }
+        if (p > q) { const int t = p; p = q; q = t; }
+        double c = 1.0, s = 0.0;
+        if (q < n) {
+          const double app = A[(size_t)p * ld + p], aqq = A[(size_t)q * ld + q], apq = A[(size_t)q * ld + p];
+          const double pp = fabs(app * aqq), a2 = apq * apq;
+          if (a2 > tol2 * fmax(pp, floor2)) {
+            const double d = aqq - app;
+            const double h = sqrt(fma(d, d, 4.0 * a2));
+            const double t = copysign(2.0 * apq, apq * copysign(1.0, d)) / (fabs(d) + h);
+            c = 1.0 / sqrt(fma(t, t, 1.0));
+            s = t * c;
+            s_rot = 1;
+          }
+        } else { q = p; }
+        cs[2 * slot] = c; cs[2 * slot + 1] = s;
+        pq[2 * slot] = p; pq[2 * slot + 1] = q;
+      }
+      __threadfence_block();
+      __syncthreads();
+      for (int item = tid; item < NP2 * n * 2; item += nt) {
+        const int slot = item / (2 * n), off = item % (2 * n);
+        const double s = cs[2 * slot + 1];
+        if (s != 0.0) {
+          const double c = cs[2 * slot];
+          const int p = pq[2 * slot], q = pq[2 * slot + 1];
+          double* M = (off >= n) ? V : A;
+          const int k = (off >= n) ? off - n : off;
+          const double x = M[(size_t)p * ld + k], y = M[(size_t)q * ld + k];
+          M[(size_t)p * ld + k] = fma(c, x, -s * y);
+          M[(size_t)q * ld + k] = fma(s, x, c * y);
+        }
+      }
+      __threadfence_block();
+      __syncthreads();
+      for (int item = tid; item < NP2 * n; item += nt) {
+        const int slot = item / n, j = item - slot * n;
+        const double s = cs[2 * slot + 1];
+        if (s != 0.0) {
+          const double c = cs[2 * slot];
+          const int p = pq[2 * slot], q = pq[2 * slot + 1];
+          const double x = A[(size_t)j * ld + p], y = A[(size_t)j * ld + q];
+          A[(size_t)j * ld + p] = fma(c, x, -s * y);
+          A[(size_t)j * ld + q] = fma(s, x, c * y);
+        }
+      }
+      __threadfence_block();
+      __syncthreads();
+    }
     const int rot = s_rot;
+    __syncthreads();
+    if (tid == 0) s_rot = 0;
     __syncthreads();
     if (!rot) break;
   }
-  if (USE_LDS) {
-    for (int e = tid; e < n * n; e += blockDim.x) { Ag[e] = A[e]; Vg[e] = V[e]; }
-  }
+  for (int i = tid; i < n; i += nt) lraw[i] = A[(size_t)i * ld + i];
   if (tid == 0) stat[ST_JACOBI_SWEEPS] = sweep + 1;
 }
 
-int launch_jacobi(blmm_ctx* ctx, double* A, double* V, int n, int64_t* stat) {
-  const size_t lds = (size_t)2 * n * n * sizeof(double);
-  if (lds <= 150 * 1024) {
-    BLMM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_jacobi<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(k_jacobi<true>, dim3(1), dim3(1024), lds, ctx->stream, A, V, n, stat);
+int launch_jacobi(blmm_ctx* ctx, double* A, double* V, int n, double* lraw, int64_t* stat) {
+  if (n <= JAC_NMAX) {
+    const int N = n + (n & 1), NP2 = N / 2, ld = N + 1;
+    const int rows_per = (n + JAC_NWG - 1) / JAC_NWG;
+    const size_t lds = sizeof(double) * ((size_t)N * ld + (size_t)rows_per * ld + 5 * NP2) +
+                       sizeof(unsigned short) * (2 * (size_t)(N - 1) * NP2 + (size_t)NP2 * (NP2 + 1)) + 64;
+    BLMM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_jacobi_lds), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(k_jacobi_lds, dim3(JAC_NWG), dim3(1024), lds, ctx->stream, A, V, n, lraw, stat);
   } else {
-    hipLaunchKernelGGL(k_jacobi<false>, dim3(1), dim3(1024), 0, ctx->stream, A, V, n, stat);
+    hipLaunchKernelGGL(k_jacobi_glb, dim3(1), dim3(1024), 0, ctx->stream, A, V, n, lraw, stat);
   }
   KCHECK();
   return BLMM_OK;
@@ -134,7 +324,7 @@ int launch_jacobi(blmm_ctx* ctx, double* A, double* V, int n, int64_t* stat) {
 //   R = U' Wd (centered = 0; literal transform_rotation, src/transform_helpers.jl:34).
 // Rp[i*ldr + k] = R[k, i], zero padded to npad x ldr (the A-operand layout of k_rotate).
 // ------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(1024) k_post_eigen(const double* __restrict__ A, const double* __restrict__ V,
+__global__ void __launch_bounds__(1024) k_post_eigen(const double* __restrict__ lraw_in, const double* __restrict__ V,
                                                      const double* __restrict__ Zs, const double* __restrict__ wd, int n,
                                                      int c, int npad, int ldr, int decomp, int centered,
                                                      double* __restrict__ lam, double* __restrict__ U,
@@ -146,11 +336,7 @@ __global__ void __launch_bounds__(1024) k_post_eigen(const double* __restrict__ 
   double* lraw = tmp;          // n
   double* Bq = tmp + n;        // c x n : Ginv * (Zs' Wd)
   if (tid == 0) s_neg = 0;
-  for (int i = tid; i < n; i += nt) {
-    double s = 0;
-    for (int k = 0; k < n; ++k) s = fma(V[(size_t)i * n + k], A[(size_t)i * n + k], s);
-    lraw[i] = (decomp == BLMM_SVD) ? fabs(s) : s;
-  }
+  for (int i = tid; i < n; i += nt) lraw[i] = (decomp == BLMM_SVD) ? fabs(lraw_in[i]) : lraw_in[i];
   __syncthreads();
   for (int i = tid; i < n; i += nt) {
     const double li = lraw[i];
@@ -219,12 +405,12 @@ __global__ void __launch_bounds__(1024) k_post_eigen(const double* __restrict__ 
   }
 }
 
-int launch_post_eigen(blmm_ctx* ctx, const double* A, const double* V, const double* Zs, const double* dweights, int n,
+int launch_post_eigen(blmm_ctx* ctx, const double* lraw, const double* V, const double* Zs, const double* dweights, int n,
                       int c, int npad, int ldr, int decomp, int centered, double* lam, double* U, double* Z0, double* Rp,
                       int64_t* stat) {
   int rc = ensure(ctx, ctx->misc, sizeof(double) * ((size_t)n + (size_t)c * n + 64));
   if (rc) return rc;
-  hipLaunchKernelGGL(k_post_eigen, dim3(1), dim3(1024), 0, ctx->stream, A, V, Zs, dweights, n, c, npad, ldr, decomp,
+  hipLaunchKernelGGL(k_post_eigen, dim3(1), dim3(1024), 0, ctx->stream, lraw, V, Zs, dweights, n, c, npad, ldr, decomp,
                      centered, lam, U, Z0, Rp, ptr<double>(ctx->misc), stat);
   KCHECK();
   return BLMM_OK;

@@ -23,6 +23,7 @@
 // Workgroup = 4 waves (2 x 2) = (32*MB) traits x (32*NB) markers; no LDS: fragments come straight from
 // L2/L1 (a 64-cycle f64 MFMA leaves the operand traffic at a few bytes/clk/CU).
 #include "blmm_internal.h"
+#include "fastmath.h"
 #include <cmath>
 
 namespace blmm {
@@ -52,6 +53,33 @@ __device__ __forceinline__ void loadv(double (&dst)[N], const double* __restrict
   }
 }
 
+// Fragment loads through buffer descriptors: the 128-bit SRD is built from wave-uniform scalars only (kernel
+// arguments, blockIdx, the loop counter), every per-lane part sits in ONE 32-bit voffset, so the K loop carries two
+// address VGPRs instead of a 64-bit pointer per panel (cdna_hip_programming.md T8/T20).
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_srd(const double* p) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(p), /*stride*/ 0, /*bytes*/ 0xffffffffu, 0x00020000);
+}
+
+template <int N>
+__device__ __forceinline__ void bufload(double (&dst)[N], __amdgpu_buffer_rsrc_t srd, uint32_t voff) {
+  if constexpr (N == 1) {
+    const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(srd, voff, 0, 0);
+    dst[0] = __builtin_bit_cast(double, v);
+  } else if constexpr (N == 2) {
+    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(srd, voff, 0, 0);
+    const d2 w = __builtin_bit_cast(d2, v);
+    dst[0] = w[0]; dst[1] = w[1];
+  } else {
+    const u32x4 v0 = __builtin_amdgcn_raw_buffer_load_b128(srd, voff, 0, 0);
+    const u32x4 v1 = __builtin_amdgcn_raw_buffer_load_b128(srd, voff + 16, 0, 0);
+    const d2 w0 = __builtin_bit_cast(d2, v0), w1 = __builtin_bit_cast(d2, v1);
+    dst[0] = w0[0]; dst[1] = w0[1]; dst[2] = w1[0]; dst[3] = w1[1];
+  }
+}
+
 // 8-byte-aligned 16-byte vector (columns of L start at arbitrary multiples of 8 bytes: ld = p is odd for BXD)
 typedef double d2u __attribute__((ext_vector_type(2), aligned(8)));
 
@@ -65,6 +93,8 @@ __device__ __forceinline__ int64_t xcd_swizzle(int64_t bid, int64_t nwg) {
 template <int NX, int MB, int NB, bool TABLE>
 __global__ void __launch_bounds__(256, 2) k_scan(ScanArgs a, int ntile_i, int64_t nwg) {
   constexpr int NP = 1 + NX;  // A-side panels consumed
+  __shared__ dpair s_log[BLMM_LOG_TABLE_N];
+  stage_log_table<true>(s_log, a.logtab);  // read after the K loop; the barrier sits right before the epilogue
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int64_t bid = xcd_swizzle(blockIdx.x, nwg);
   const int64_t tile_t = bid / ntile_i;
@@ -81,55 +111,56 @@ __global__ void __launch_bounds__(256, 2) k_scan(ScanArgs a, int ntile_i, int64_
 #pragma unroll
       for (int nb = 0; nb < NB; ++nb) acc[q][mb][nb] = (d4){0, 0, 0, 0};
 
-  const double* pa = a.P + (int64_t)kk * a.ldp + t0 + MB * r;
-  const double* pb = a.Xt + (int64_t)kk * a.ldx + i0 + NB * r;
+  // uniform tile bases (blockIdx-derived) for the descriptors; per-lane byte offsets (wave, lane) in voffset
+  const double* PA = a.P + tile_t * (32 * MB);
+  const double* PB = a.Xt + (int64_t)tile_i * (32 * NB);
+  const uint32_t voffA = (uint32_t)(((int64_t)kk * a.ldp + (wave >> 1) * (16 * MB) + MB * r) * 8);
+  const uint32_t voffB = (uint32_t)(((int64_t)kk * a.ldx + (wave & 1) * (16 * NB) + NB * r) * 8);
   const int64_t sa = 4 * a.ldp, sb = 4 * a.ldx;
 
-  double av[NP][MB], bv[NB];
+  // K loop, two fragment sets: the loads of step ks+1 are issued before the MFMAs of step ks and are only waited
+  // for after them (sched_barrier keeps hipcc from sinking the loads below the MFMA block)
+  auto load_set = [&](double (&A)[NP][MB], double (&B)[NB], int step) {
 #pragma unroll
-  for (int q = 0; q < NP; ++q) loadv<MB>(av[q], pa + q * a.pstride);
-  loadv<NB>(bv, pb);
-  for (int ks = 0; ks < a.ks; ++ks) {
-    double an[NP][MB], bn[NB];
-    if (ks + 1 < a.ks) {
-      pa += sa; pb += sb;
-#pragma unroll
-      for (int q = 0; q < NP; ++q) loadv<MB>(an[q], pa + q * a.pstride);
-      loadv<NB>(bn, pb);
-    } else {
-#pragma unroll
-      for (int q = 0; q < NP; ++q)
-#pragma unroll
-        for (int mb = 0; mb < MB; ++mb) an[q][mb] = 0.0;
-#pragma unroll
-      for (int nb = 0; nb < NB; ++nb) bn[nb] = 0.0;
-    }
+    for (int q = 0; q < NP; ++q) bufload<MB>(A[q], make_srd(PA + q * a.pstride + step * sa), voffA);
+    bufload<NB>(B, make_srd(PB + step * sb), voffB);
+  };
+  auto mfma_set = [&](const double (&A)[NP][MB], const double (&B)[NB]) {
     double b2[NB];
     if constexpr (NX > 0) {
 #pragma unroll
-      for (int nb = 0; nb < NB; ++nb) b2[nb] = bv[nb] * bv[nb];
+      for (int nb = 0; nb < NB; ++nb) b2[nb] = B[nb] * B[nb];
     }
 #pragma unroll
     for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
       for (int nb = 0; nb < NB; ++nb) {
-        acc[0][mb][nb] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[0][mb], bv[nb], acc[0][mb][nb], 0, 0, 0);
+        acc[0][mb][nb] = __builtin_amdgcn_mfma_f64_16x16x4f64(A[0][mb], B[nb], acc[0][mb][nb], 0, 0, 0);
         if constexpr (NX > 0) {
-          acc[1][mb][nb] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[1][mb], b2[nb], acc[1][mb][nb], 0, 0, 0);
+          acc[1][mb][nb] = __builtin_amdgcn_mfma_f64_16x16x4f64(A[1][mb], b2[nb], acc[1][mb][nb], 0, 0, 0);
 #pragma unroll
           for (int q = 2; q < NP; ++q)
-            acc[q][mb][nb] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[q][mb], bv[nb], acc[q][mb][nb], 0, 0, 0);
+            acc[q][mb][nb] = __builtin_amdgcn_mfma_f64_16x16x4f64(A[q][mb], B[nb], acc[q][mb][nb], 0, 0, 0);
         }
       }
-#pragma unroll
-    for (int q = 0; q < NP; ++q)
-#pragma unroll
-      for (int mb = 0; mb < MB; ++mb) av[q][mb] = an[q][mb];
-#pragma unroll
-    for (int nb = 0; nb < NB; ++nb) bv[nb] = bn[nb];
+  };
+  double a0[NP][MB], b0[NB], a1[NP][MB], b1[NB];
+  load_set(a0, b0, 0);
+  int ks = 0;
+  for (; ks + 2 <= a.ks; ks += 2) {
+    load_set(a1, b1, ks + 1);
+    __builtin_amdgcn_sched_barrier(0);
+    mfma_set(a0, b0);
+    __builtin_amdgcn_sched_barrier(0);
+    load_set(a0, b0, (ks + 2 < a.ks) ? ks + 2 : ks);  // unconditional (clamped): keeps the vmcnt bookkeeping static
+    __builtin_amdgcn_sched_barrier(0);
+    mfma_set(a1, b1);
+    __builtin_amdgcn_sched_barrier(0);
   }
+  if (ks < a.ks) mfma_set(a0, b0);
 
   // ---- epilogue: projection, normalisation, r -> LOD, 32-byte stores ---------------------------------
+  __syncthreads();
   const double scale = -0.5 * (double)a.n;
   const int64_t ibase = i0 + NB * r;
   int nnan = 0;
@@ -156,9 +187,12 @@ __global__ void __launch_bounds__(256, 2) k_scan(ScanArgs a, int ntile_i, int64_
           double xx = acc[1][mb][nb][reg];
 #pragma unroll
           for (int q = 2; q < NP; ++q) xx = fma(-acc[q][mb][nb][reg], acc[q][mb][nb][reg], xx);
-          r2 = (num * num) / xx;
+          r2 = (num * num) * fast_rcp(xx);
         }
-        const double lod = scale * log10(1.0 - r2);
+        // r2lod (src/bulkscan_helpers.jl:22-24): -(n/2) * log10(1.0 - r^2), same operation order
+        const double u = 1.0 - r2;
+        double lod = scale * fast_log<true>(u, s_log);
+        if (!(u > 0.0)) lod = (u == 0.0) ? INFINITY : NAN;  // r^2 = 1 -> +Inf; r^2 > 1 -> DomainError in Julia, NaN here
         out[nb] = lod;
         nnan += (lod != lod) && (ibase + nb < a.p);
       }
@@ -217,6 +251,9 @@ int launch_scan_table(blmm_ctx* ctx, const ScanArgs& a) { return launch_scan_t<0
 template <int MB, int NB>
 __global__ void __launch_bounds__(256, 2) k_scan_alt(AltArgs aa, int ntile_i, int64_t nwg) {
   const ScanArgs& a = aa.s;
+  __shared__ dpair s_log[BLMM_LOG_TABLE_N];
+  stage_log_table<true>(s_log, a.logtab);
+  __syncthreads();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int64_t bid = xcd_swizzle(blockIdx.x, nwg);
   const int64_t tile_t = bid / ntile_i;
@@ -268,7 +305,9 @@ __global__ void __launch_bounds__(256, 2) k_scan_alt(AltArgs aa, int ntile_i, in
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) {
           const double rr = acc[mb][nb][reg] * sc[nb];
-          const double lod = scale * log10(1.0 - rr * rr);
+          const double u = 1.0 - rr * rr;
+          double lod = scale * fast_log<true>(u, s_log);
+          if (!(u > 0.0)) lod = (u == 0.0) ? INFINITY : NAN;
           const double l1 = lod * ln10 + ell;
           if (g == 0) {
             best[mb][nb][reg] = l1;

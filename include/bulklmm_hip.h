@@ -77,6 +77,8 @@ typedef struct blmm_status {
   int64_t n_nan_lod;       /* r^2 > 1 (DomainError in the reference, NaN here), src/bulkscan_helpers.jl:23 */
   int64_t n_brent_maxiter; /* traits whose Brent search hit 1000 iterations                            */
   int64_t jacobi_sweeps;   /* sweeps used by the device eigensolver                                   */
+  int64_t jacobi_cycles;   /* shader cycles / 100 MHz ticks spent inside the eigensolver (diagnostic)  */
+  int64_t jacobi_ticks_100mhz;
   double t_eigen_ms, t_rotate_ms, t_h2_ms, t_prep_ms, t_scan_ms, t_total_ms;
 } blmm_status;
 
