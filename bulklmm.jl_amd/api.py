@@ -138,7 +138,6 @@ def calcKinship(geno, ctx: Optional[Context] = None) -> np.ndarray:
 
 def _bulkscan_call(method, Y, G, K, Covar, h2_grid, addIntercept, weights, prior_variance, prior_sample_size, reml,
                    optim_interval, decomp_scheme, compat_flags, ctx, return_status=False):
-    ctx = ctx or default_context()
     Y = _F(Y)
     G = _F(G)
     K = _F(K)
@@ -164,6 +163,7 @@ def _bulkscan_call(method, Y, G, K, Covar, h2_grid, addIntercept, weights, prior
         grid = np.ascontiguousarray(np.asarray(h2_grid, dtype=np.float64).ravel())
         ngrid = grid.shape[0]
     o = _opts(method, reml, addIntercept, decomp_scheme, optim_interval, prior_variance, prior_sample_size, compat_flags)
+    ctx = ctx or default_context()  # after the argument checks: those must not need a GPU
     Lout = np.empty((p, m), dtype=np.float64, order="F")
     h2 = np.empty((p, m) if method == L.BLMM_ALT_GRID else (m,), dtype=np.float64, order="F")
     st = L.blmm_status()
@@ -247,7 +247,6 @@ def scan(y, g, K, covar=None, *, weights=None, prior_variance: float = 0.0, prio
     kernels (Brent + exact-weights LOD kernel with m = 1), and the permutation test (src/scan.jl:485-557).
     `perm_idx` (n x nperms, 0-based) supplies the permutations; otherwise the library draws them from
     `rndseed` with its own generator (Julia's MersenneTwister stream is not reproducible)."""
-    ctx = ctx or default_context()
     y = _F(y)
     if covar is None and not addIntercept:
         raise BulkLMMError("Intercept has to be added when no other covariate is given.", -7)  # src/scan.jl:167-169
@@ -284,6 +283,7 @@ def scan(y, g, K, covar=None, *, weights=None, prior_variance: float = 0.0, prio
         pidx = np.asfortranarray(np.asarray(perm_idx, dtype=np.int32))
         if pidx.shape != (n, nperms):
             raise BulkLMMError("Dimension mismatch.", -2)
+    ctx = ctx or default_context()
     scal = np.zeros(2)
     lod = np.empty(p)
     Lp = np.empty((p, max(nperms, 1)), order="F")

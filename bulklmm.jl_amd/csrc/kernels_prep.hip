@@ -569,35 +569,110 @@ __device__ __forceinline__ EllOut null_ell(double h2, const double* __restrict__
   return o;
 }
 
+// ---- register-resident variant -----------------------------------------------------------------------
+// LPT lanes share one trait; lane `sub` owns individuals k = sub + LPT*i, i < NK, held in registers
+// (lambda, y and the C covariate columns; padding rows have lambda = y = z = 0 and contribute nothing).
+// All divisions are rcp + 2 Newton steps and all logarithms the table-driven fast_log (fastmath.h).
+constexpr int NULL_NK = 20;
+
+template <int LPT>
+__device__ __forceinline__ double lpt_sum(double x) {
+#pragma unroll
+  for (int o = 1; o < LPT; o <<= 1) x += __shfl_xor(x, o, LPT);
+  return x;
+}
+
+template <int C, int LPT>
+struct NullRegs {
+  double lam[NULL_NK], y[NULL_NK], z[C][NULL_NK];
+  __device__ __forceinline__ void load(const double* __restrict__ ycol, int64_t ystride, int sub, int n,
+                                       const double* __restrict__ Z0, const double* __restrict__ lamv, bool valid) {
+#pragma unroll
+    for (int i = 0; i < NULL_NK; ++i) {
+      const int k = sub + LPT * i;
+      const bool ok = k < n;
+      lam[i] = ok ? lamv[k] : 0.0;
+      y[i] = (ok && valid) ? ycol[(int64_t)k * ystride] : 0.0;
+#pragma unroll
+      for (int q = 0; q < C; ++q) z[q][i] = ok ? Z0[q * n + k] : 0.0;
+    }
+  }
+};
+
+template <int C, int LPT>
+__device__ __forceinline__ EllOut null_ell_reg(double h2, const NullRegs<C, LPT>& R, int n, double prior_a, double prior_b,
+                                               int reml, const dpair* __restrict__ s_ln, int* nonpos) {
+  constexpr int NA = C * (C + 1) / 2;
+  const double delta = h2 * fast_rcp(1.0 - h2);
+  double A[NA], v[C], syy = 0.0, p1 = 1.0, p2 = 1.0;
+#pragma unroll
+  for (int a = 0; a < NA; ++a) A[a] = 0.0;
+#pragma unroll
+  for (int q = 0; q < C; ++q) v[q] = 0.0;
+  int bad = 0;
+#pragma unroll
+  for (int i = 0; i < NULL_NK; ++i) {
+    const double t = fma(delta, R.lam[i], 1.0);
+    const double w = fast_rcp(t);
+    bad |= !(t > 0.0);
+    if (i < NULL_NK / 2) p1 *= t; else p2 *= t;   // sum ln t = ln(prod t): two partial products stay far from overflow
+    const double wy = w * R.y[i];
+    syy = fma(wy, R.y[i], syy);
+#pragma unroll
+    for (int q = 0; q < C; ++q) {
+      v[q] = fma(wy, R.z[q][i], v[q]);
+      const double wz = w * R.z[q][i];
+#pragma unroll
+      for (int r = 0; r <= q; ++r) A[q * (q + 1) / 2 + r] = fma(wz, R.z[r][i], A[q * (q + 1) / 2 + r]);
+    }
+  }
+  double logsum = fast_log<false>(p1, s_ln) + fast_log<false>(p2, s_ln);
+  syy = lpt_sum<LPT>(syy); logsum = lpt_sum<LPT>(logsum);
+#pragma unroll
+  for (int a = 0; a < NA; ++a) A[a] = lpt_sum<LPT>(A[a]);
+#pragma unroll
+  for (int q = 0; q < C; ++q) v[q] = lpt_sum<LPT>(v[q]);
+  if (bad && nonpos) *nonpos = 1;
+  double L[NA], t[C], detA = 1.0, tt = 0.0;
+#pragma unroll
+  for (int q = 0; q < C; ++q) {
+#pragma unroll
+    for (int r = 0; r <= q; ++r) {
+      double s = A[q * (q + 1) / 2 + r];
+#pragma unroll
+      for (int u = 0; u < r; ++u) s = fma(-L[q * (q + 1) / 2 + u], L[r * (r + 1) / 2 + u], s);
+      if (r == q) { detA *= s; L[q * (q + 1) / 2 + q] = nr_rsqrt(s); }   // store 1/L_qq
+      else L[q * (q + 1) / 2 + r] = s * L[r * (r + 1) / 2 + r];
+    }
+    double s = v[q];
+#pragma unroll
+    for (int u = 0; u < q; ++u) s = fma(-L[q * (q + 1) / 2 + u], t[u], s);
+    t[q] = s * L[q * (q + 1) / 2 + q];
+    tt = fma(t[q], t[q], tt);
+  }
+  const double rss = syy - tt;
+  const double prior_df = prior_b > 0.0 ? prior_b + 2.0 : prior_b;
+  const double num = rss + prior_a * prior_b;
+  const double den = (reml ? (double)(n - C) : (double)n) + prior_df;
+  const double sigma2 = num * fast_rcp(den);
+  const double ls = (sigma2 > 0.0) ? fast_log<false>(sigma2, s_ln) : log(sigma2);
+  double ell = -0.5 * (((double)n + prior_b) * ls + logsum + den);  // (rss + a b)/sigma2 = den
+  if (reml) ell += 0.5 * ((double)C * ls - ((detA > 0.0) ? fast_log<false>(detA, s_ln) : log(detA)));
+  EllOut o; o.ell = ell; o.sigma2 = sigma2; o.yy = rss;
+  return o;
+}
+
 constexpr int BRENT_LPT = 4;
 
-// Optim.jl Brent() restated (third-party; see oracle/bulklmm_oracle.py:brent_optim and SURVEY.md A.3),
-// gridbrent sub-intervals (src/gridbrent.jl:9-24), final wls at the minimiser (src/lmm.jl:84).
-template <int C>
-__global__ void __launch_bounds__(256) k_brent(NullModel nm, const double* __restrict__ Yt, int64_t ldy, int64_t m,
-                                               const double* __restrict__ Z0, const double* __restrict__ lam,
-                                               double* __restrict__ h2out, double* __restrict__ s2out,
-                                               double* __restrict__ ellout, int64_t* stat) {
-  extern __shared__ __attribute__((aligned(16))) double sh[];
-  const int n = nm.n;
-  double* sLam = sh;       // n
-  double* sZ = sh + n;     // C*n
-  for (int e = threadIdx.x; e < n; e += blockDim.x) sLam[e] = lam[e];
-  for (int e = threadIdx.x; e < n * C; e += blockDim.x) sZ[e] = Z0[e];
-  __syncthreads();
-  constexpr int LPT = BRENT_LPT;
-  const int64_t j = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / LPT;
-  const int sub = threadIdx.x % LPT;
-  const bool valid = j < m;
-  const double* ycol = Yt + (valid ? j : 0);
-  int nonpos = 0;
-  auto f = [&](double h2) { return -null_ell<C, LPT>(h2, ycol, ldy, sub, n, sZ, sLam, nm.prior_a, nm.prior_b, nm.reml, &nonpos).ell; };
-
+// Optim.jl Brent() restated (third-party; see oracle/bulklmm_oracle.py:brent_optim and SURVEY.md A.3) on the
+// gridbrent sub-intervals (src/gridbrent.jl:9-24).  Every lane of the wave runs the same number of function
+// evaluations (converged lanes keep evaluating at their minimiser and discard the value), so the cross-lane
+// reductions inside `f` stay convergent.  Returns the minimiser of the best sub-interval (first wins).
+template <typename F>
+__device__ __forceinline__ double brent_search(F& f, int nint, bool valid, int* hit_max) {
   const double golden = 0.5 * (3.0 - sqrt(5.0));
   const double rel_tol = 1.4901161193847656e-08, abs_tol = 2.220446049250313e-16;
   double best_x = 0.0, best_f = INFINITY;
-  int hit_max = 0;
-  const int nint = nm.optim_interval < 1 ? 1 : nm.optim_interval;
   for (int iv = 0; iv < nint; ++iv) {
     // points = range(0, 1, length = nint+1)
     double x_lower = (double)iv / (double)nint, x_upper = (iv + 1 == nint) ? 1.0 : (double)(iv + 1) / (double)nint;
@@ -651,10 +726,49 @@ __global__ void __launch_bounds__(256) k_brent(NullModel nm, const double* __res
         }
       }
     }
-    if (it >= 1000 && !done) hit_max = 1;
+    if (it >= 1000 && !done) *hit_max = 1;
     if (new_minimum < best_f || iv == 0) { best_f = new_minimum; best_x = new_minimizer; }  // argmin: first wins
   }
-  const EllOut fin = null_ell<C, LPT>(best_x, ycol, ldy, sub, n, sZ, sLam, nm.prior_a, nm.prior_b, nm.reml, &nonpos);
+  return best_x;
+}
+
+// fitlmm for every trait (src/lmm.jl:56-86): Brent search, then the final wls at the minimiser (:84).
+// REG: the register-resident evaluator (n <= LPT * NULL_NK); otherwise operands are re-read every evaluation.
+template <int C, int LPT, bool REG>
+__global__ void __launch_bounds__(256) k_brent(NullModel nm, const double* __restrict__ Yt, int64_t ldy, int64_t m,
+                                               const double* __restrict__ Z0, const double* __restrict__ lam,
+                                               const double* __restrict__ logtab, double* __restrict__ h2out,
+                                               double* __restrict__ s2out, double* __restrict__ ellout, int64_t* stat) {
+  extern __shared__ __attribute__((aligned(16))) double sh[];
+  __shared__ dpair s_ln[BLMM_LOG_TABLE_N];
+  const int n = nm.n;
+  double* sLam = sh;       // n      (generic evaluator only)
+  double* sZ = sh + n;     // C*n
+  if (!REG) {
+    for (int e = threadIdx.x; e < n; e += blockDim.x) sLam[e] = lam[e];
+    for (int e = threadIdx.x; e < n * C; e += blockDim.x) sZ[e] = Z0[e];
+  }
+  stage_log_table<false>(s_ln, logtab);
+  __syncthreads();
+  const int64_t j = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / LPT;
+  const int sub = threadIdx.x % LPT;
+  const bool valid = j < m;
+  const double* ycol = Yt + (valid ? j : 0);
+  int nonpos = 0, hit_max = 0;
+  const int nint = nm.optim_interval < 1 ? 1 : nm.optim_interval;
+  double best_x;
+  EllOut fin;
+  if constexpr (REG) {
+    NullRegs<C, LPT> R;
+    R.load(ycol, ldy, sub, n, Z0, lam, valid);
+    auto f = [&](double h2) { return -null_ell_reg<C, LPT>(h2, R, n, nm.prior_a, nm.prior_b, nm.reml, s_ln, &nonpos).ell; };
+    best_x = brent_search(f, nint, valid, &hit_max);
+    fin = null_ell_reg<C, LPT>(best_x, R, n, nm.prior_a, nm.prior_b, nm.reml, s_ln, &nonpos);
+  } else {
+    auto f = [&](double h2) { return -null_ell<C, LPT>(h2, ycol, ldy, sub, n, sZ, sLam, nm.prior_a, nm.prior_b, nm.reml, &nonpos).ell; };
+    best_x = brent_search(f, nint, valid, &hit_max);
+    fin = null_ell<C, LPT>(best_x, ycol, ldy, sub, n, sZ, sLam, nm.prior_a, nm.prior_b, nm.reml, &nonpos);
+  }
   if (valid && sub == 0) {
     h2out[j] = best_x;
     if (s2out) s2out[j] = fin.sigma2;
@@ -664,15 +778,28 @@ __global__ void __launch_bounds__(256) k_brent(NullModel nm, const double* __res
   }
 }
 
+template <int C, int LPT, bool REG>
+static int launch_brent_t(blmm_ctx* ctx, const NullModel& nm, const double* Yt, int64_t ldy, int64_t m, const double* Z0,
+                          const double* lam, double* h2, double* sigma2, double* ell, int64_t* stat) {
+  const int64_t threads = m * LPT;
+  const unsigned blocks = (unsigned)((threads + 255) / 256);
+  const size_t lds = REG ? 16 : sizeof(double) * (size_t)nm.n * (1 + C);
+  hipLaunchKernelGGL((k_brent<C, LPT, REG>), dim3(blocks), dim3(256), lds, ctx->stream, nm, Yt, ldy, m, Z0, lam,
+                     ptr<double>(ctx->logtab), h2, sigma2, ell, stat);
+  KCHECK();
+  return BLMM_OK;
+}
+
 template <int C>
 static int launch_brent_c(blmm_ctx* ctx, const NullModel& nm, const double* Yt, int64_t ldy, int64_t m, const double* Z0,
                           const double* lam, double* h2, double* sigma2, double* ell, int64_t* stat) {
-  const int64_t threads = m * BRENT_LPT;
-  const unsigned blocks = (unsigned)((threads + 255) / 256);
-  const size_t lds = sizeof(double) * (size_t)nm.n * (1 + C);
-  hipLaunchKernelGGL(k_brent<C>, dim3(blocks), dim3(256), lds, ctx->stream, nm, Yt, ldy, m, Z0, lam, h2, sigma2, ell, stat);
-  KCHECK();
-  return BLMM_OK;
+  const int n = nm.n;
+  if (n <= 4 * NULL_NK) return launch_brent_t<C, 4, true>(ctx, nm, Yt, ldy, m, Z0, lam, h2, sigma2, ell, stat);
+  if (n <= 8 * NULL_NK) return launch_brent_t<C, 8, true>(ctx, nm, Yt, ldy, m, Z0, lam, h2, sigma2, ell, stat);
+  if (n <= 16 * NULL_NK) return launch_brent_t<C, 16, true>(ctx, nm, Yt, ldy, m, Z0, lam, h2, sigma2, ell, stat);
+  if (n <= 32 * NULL_NK) return launch_brent_t<C, 32, true>(ctx, nm, Yt, ldy, m, Z0, lam, h2, sigma2, ell, stat);
+  if (n <= 64 * NULL_NK) return launch_brent_t<C, 64, true>(ctx, nm, Yt, ldy, m, Z0, lam, h2, sigma2, ell, stat);
+  return launch_brent_t<C, BRENT_LPT, false>(ctx, nm, Yt, ldy, m, Z0, lam, h2, sigma2, ell, stat);
 }
 
 int launch_brent(blmm_ctx* ctx, const NullModel& nm, const double* Yt, int64_t ldy, int64_t m, const double* Z0,

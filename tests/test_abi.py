@@ -1,0 +1,91 @@
+"""CPU tests of the drop-in boundary: the C-ABI library builds, loads and exports every symbol include/*.h declares
+(no compute calls without a GPU), and the host mirror's argument checking raises the reference's messages."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def header_symbols():
+    txt = open(os.path.join(ROOT, "include", "bulklmm_hip.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(blmm_[a-z0-9_]+)\s*\(", txt)))
+
+
+def test_library_exports_every_declared_symbol(blmm):
+    lib = blmm.load()
+    syms = header_symbols()
+    assert len(syms) >= 20
+    for s in syms:
+        assert hasattr(lib, s), s
+    assert sorted(blmm.EXPORTS) == syms
+    assert lib.blmm_version() == 100
+
+
+def test_struct_layouts_match_header(blmm):
+    from bulklmm_jl_amd import _lib as L
+    assert C.sizeof(L.blmm_opts) == 6 * 4 + 2 * 8
+    assert C.sizeof(L.blmm_status) == 8 * 8 + 6 * 8
+    o = L.blmm_opts()
+    blmm.load().blmm_default_opts(C.byref(o))
+    assert (o.method, o.reml, o.add_intercept, o.decomp_scheme, o.optim_interval) == (1, 0, 1, 0, 1)
+    assert (o.prior_variance, o.prior_sample_size) == (1.0, 0.0)  # bulkscan defaults, src/bulkscan.jl:81-92
+
+
+def test_error_strings(blmm):
+    lib = blmm.load()
+    assert lib.blmm_err_string(-2).decode() == "Dimension mismatch."
+    assert lib.blmm_err_string(-3).decode() == "Heritability of 1 is not allowed."
+    assert lib.blmm_err_string(-6).decode() == "Can only handle one trait."
+    assert lib.blmm_err_string(-8).decode() == "Dividing by zeros: the input vector can not contain any zeros!"
+
+
+def test_no_gpu_fails_loudly(blmm):
+    """Without a GPU the product path must refuse to run (there is no CPU fallback)."""
+    lib = blmm.load()
+    if lib.blmm_device_count() > 0:
+        pytest.skip("a GPU is present")
+    with pytest.raises(blmm.BulkLMMError):
+        blmm.Context(0)
+    with pytest.raises(blmm.BulkLMMError):
+        blmm.bulkscan_null(np.zeros((5, 2)), np.zeros((5, 3)), np.eye(5))
+
+
+def test_product_path_never_touches_the_oracle():
+    pkg = os.path.join(ROOT, "bulklmm.jl_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp", ".jl")):
+                txt = open(os.path.join(dirpath, f), errors="ignore").read()
+                assert "import oracle" not in txt and "from oracle" not in txt, f
+
+
+def test_host_mirror_argument_checks(blmm):
+    Y = np.zeros((6, 2)); G = np.zeros((6, 3)); K = np.eye(6)
+    with pytest.raises(blmm.BulkLMMError) as e:
+        blmm.scan(np.zeros((6, 2)), G, K)
+    assert e.value.msg == "Can only handle one trait."
+    with pytest.raises(blmm.BulkLMMError) as e:
+        blmm.scan(Y[:, 0], G, K, addIntercept=False)
+    assert e.value.msg == "Intercept has to be added when no other covariate is given."
+    with pytest.raises(blmm.BulkLMMError) as e:
+        blmm.scan(Y[:, 0], G, K, assumption="nope")
+    assert e.value.msg == "Assumption keyword is not supported. Please enter null or alt."
+    with pytest.raises(blmm.BulkLMMError):
+        blmm.bulkscan(Y, G, K, method="nope")
+    with pytest.raises(blmm.BulkLMMError) as e:
+        blmm.bulkscan_null(Y[:-1], G, K)
+    assert e.value.msg == "Dimension mismatch."
+
+
+def test_trait_sharding_helper(blmm):
+    for m, w in [(35554, 8), (10, 3), (7, 8), (0, 2)]:
+        parts = [blmm.trait_shard(m, r, w) for r in range(w)]
+        assert parts[0][0] == 0 and parts[-1][1] == m
+        assert all(parts[i][1] == parts[i + 1][0] for i in range(w - 1))
+        sizes = [b - a for a, b in parts]
+        assert max(sizes) - min(sizes) <= 1

@@ -270,3 +270,23 @@ def test_zero_norm_marker_raises(blmm):
     with pytest.raises(blmm.BulkLMMError) as e:
         blmm.bulkscan_null_grid(Y, G, K, [0.0, 0.5])
     assert e.value.msg == "Dividing by zeros: the input vector can not contain any zeros!"
+
+
+def test_golden_fixture(blmm):
+    """tests/golden/bulkscan_small.npz: committed inputs + oracle outputs for every method."""
+    import os
+    from common import GOLDEN
+    z = np.load(os.path.join(GOLDEN, "bulkscan_small.npz"))
+    Y, G, K, Cov, grid = z["Y"], z["G"], z["K"], z["Cov"], list(z["grid"])
+    ex = blmm.bulkscan_null(Y, G, K, prior_variance=1.0, prior_sample_size=0.1)
+    assert np.abs(ex.h2_null_list - z["exact_h2"]).max() <= 1e-6
+    assert np.sum((ex.L - z["exact_L"]) ** 2, axis=0).max() <= 1e-7
+    exc = blmm.bulkscan_null(Y, G, K, Cov, reml=True)
+    assert np.abs(exc.h2_null_list - z["exact_cov_reml_h2"]).max() <= 1e-6
+    assert np.sum((exc.L - z["exact_cov_reml_L"]) ** 2, axis=0).max() <= 1e-7
+    gr = blmm.bulkscan_null_grid(Y, G, K, grid)
+    assert np.array_equal(gr.h2_null_list, z["grid_h2"])
+    assert_lod_close(gr.L, z["grid_L"])
+    al = blmm.bulkscan_alt_grid(Y, G, K, grid)
+    assert_lod_close(al.L, z["alt_L"], atol=1e-9)
+    assert (al.h2_panel != z["alt_h2"]).mean() <= 1e-3

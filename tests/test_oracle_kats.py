@@ -1,0 +1,190 @@
+"""CPU tests: the oracle against every known-answer test / fixture of the reference that can be run without the
+(absent) BXD genotype and phenotype CSVs, plus the reference's cross-path identities re-created on synthetic
+data with the real BXD kinship.  No GPU needed."""
+import os
+import warnings
+
+import numpy as np
+import pytest
+
+from common import GOLDEN, bxd_kinship, make_data, make_geno
+from oracle import bulklmm_oracle as O
+
+
+def test_r2lod_roundtrip_kat():
+    # test/bulkscan_test.jl:9-19
+    assert abs(O.r2lod(O.lod2r(3.0, 79), 79) - 3.0) <= 1e-7
+
+
+def test_computeR_LMM_equals_pearson():
+    # test/bulkscan_test.jl:25-54
+    rng = np.random.default_rng(1234)
+    X = rng.standard_normal((100, 100))
+    Y = rng.standard_normal((100, 100))
+    R = O.computeR_LMM(Y, X, np.ones((100, 1)))
+    C = np.corrcoef(X.T, Y.T)[:100, 100:]
+    assert np.sum((R - C) ** 2) <= 1e-8
+    x = rng.standard_normal((100, 1))
+    y = 3 * x + rng.standard_normal()
+    assert abs(O.computeR_LMM(y, x, np.ones((100, 1)))[0, 0] - np.corrcoef(x[:, 0], y[:, 0])[0, 1]) <= 1e-7
+
+
+def test_resid_rss_vs_backslash():
+    # test/wls_basic_test.jl:30-74
+    rng = np.random.default_rng(7)
+    X = rng.standard_normal((60, 4))
+    Y = rng.standard_normal((60, 3))
+    b = np.linalg.lstsq(X, Y, rcond=None)[0]
+    assert np.abs(O.resid(Y, X) - (Y - X @ b)).max() <= 1e-10
+    assert np.abs(O.rss(Y, X) - np.sum((Y - X @ b) ** 2, axis=0)).max() <= 1e-8
+    assert np.abs(O.resid(Y, X, method="cholesky") - O.resid(Y, X, method="qr")).max() <= 1e-8
+
+
+def test_wls_vs_scaled_ols():
+    # test/wls_results_test.jl:89-117
+    rng = np.random.default_rng(11)
+    n = 200
+    X = np.hstack([np.ones((n, 1)), rng.standard_normal((n, 2))])
+    beta = np.array([[1.0], [2.0], [-1.0]])
+    w = rng.uniform(0.2, 3.0, n)
+    y = X @ beta + rng.standard_normal((n, 1)) / np.sqrt(w)[:, None]
+    est = O.wls(y, X, w, [0.0, 0.0])
+    sw = np.sqrt(w)[:, None]
+    b = np.linalg.lstsq(X * sw, y * sw, rcond=None)[0]
+    assert np.abs(est.b - b).max() <= 1e-4
+    assert np.abs(est.b - beta).max() <= 0.3
+    mv = O.wls_multivar(np.hstack([y, 2 * y]), X, w, [1.0, 0.1], reml=True)
+    one = O.wls(2 * y, X, w, [1.0, 0.1], reml=True)
+    assert abs(mv.Ell[0, 1] - one.ell) <= 1e-9 and abs(mv.Sigma2[0, 1] - one.sigma2) <= 1e-12
+
+
+def test_gridbrent_kat():
+    # test/gridbrent_test.jl:1-12
+    f = lambda x: -(x ** 3 + 0.2 * (x - 2) ** 2 + 3)  # noqa: E731
+    assert abs(O.gridbrent(f, -3.0, 1.0, 100).minimizer - 1.0) <= 1e-6
+    # a plain quadratic: Brent must land on the minimiser to sqrt(eps)
+    r = O.brent_optim(lambda x: (x - 0.3) ** 2, 0.0, 1.0)
+    assert r.converged and abs(r.minimizer - 0.3) <= 1e-7
+
+
+def test_makeweights_error_string():
+    # test/lmm_test.jl:12-18
+    with pytest.raises(O.BulkLMMError) as e:
+        O.makeweights(1.0, [0.0])
+    assert e.value.msg == "Heritability of 1 is not allowed."
+    assert np.allclose(O.makeweights(0.5, [0.0, 1.0, 3.0]), [1.0, 0.5, 0.25])
+
+
+def test_bxd_kinship_fixture():
+    # test/kinship_test.jl:5-7 -- the stored Helium matrix (79 x 79), rounded to 12 digits
+    K = bxd_kinship()
+    assert K.shape == (79, 79) and np.array_equal(K, K.T) and np.array_equal(np.diag(K), np.ones(79))
+    lam = np.linalg.eigvalsh(K)
+    assert abs(lam[0] - 0.02146) <= 1e-4 and abs(lam[-1] - 40.62) <= 1e-2
+    assert np.array_equal(O.read_he(os.path.join(GOLDEN, "bxd_kinship_ref.he")).round(12), K)
+
+
+def test_calc_kinship_properties():
+    rng = np.random.default_rng(5)
+    G = make_geno(30, 400, rng)
+    K = O.calcKinship(G)
+    assert np.array_equal(np.diag(K), np.ones(30)) and np.allclose(K, K.T)
+    assert abs(K[0, 1] - (2 * np.dot(G[0] - .5, G[1] - .5) / 400 + .5)) <= 1e-14
+
+
+def test_transform_rotation_checks():
+    # test/transform_helpers_test.jl:12-53
+    Y, G, K, _ = make_data(p=20, m=3)
+    with pytest.raises(O.BulkLMMError) as e:
+        O.transform_rotation(Y[:-1], G, K)
+    assert e.value.msg == "Dimension mismatch."
+    with pytest.raises(O.BulkLMMError) as e:
+        O.transform_rotation(Y, G, K, decomp_scheme="lu")
+    assert e.value.msg == "Please choose either `eigen` or `svd` for decomposition of the kinship matrix."
+    Y0, X0, lam = O.transform_rotation(Y, G, K)
+    vals, vecs = np.linalg.eigh(K)
+    assert np.allclose(Y0, vecs.T @ Y) and np.allclose(X0[:, 1:], vecs.T @ G) and np.allclose(lam, vals)
+
+
+def test_bulkscan_null_equals_scan_null():
+    # test/bulkscan_test.jl:60-80 incl. the prior's scale equivariance
+    Y, G, K, _ = make_data(p=120, m=4, seed=31)
+    got = O.bulkscan_null(O.colStandardize(Y), O.colStandardize(G), K, prior_variance=1.0, prior_sample_size=0.1)
+    for j in (0, 3):
+        y = Y[:, [j]]
+        s = O.scan(y, G, K, prior_variance=float(np.var(y, ddof=1)), prior_sample_size=0.1)
+        assert np.sum((s["lod"] - got.L[:, j]) ** 2) <= 1e-7
+
+
+def test_null_grid_with_exact_h2():
+    # test/bulkscan_test.jl:86-107
+    Y, G, K, _ = make_data(p=80, m=3, seed=52)
+    ex = O.bulkscan_null(Y, G, K)
+    grid = list(np.arange(0.0, 1.0, 0.05)) + list(ex.h2_null_list)
+    gr = O.bulkscan_null_grid(Y, G, K, grid)
+    same = gr.h2_null_list == ex.h2_null_list
+    assert same.any()
+    assert np.abs(gr.L[:, same] - ex.L[:, same]).max() <= 1e-12
+
+
+def test_weights_equal_prescaled_and_svd_equal_eigen():
+    # test/weighted_error_test.jl:42-127, test/scan_covar_test.jl:27-40
+    Y, G, K, _ = make_data(p=60, m=3, seed=81)
+    n = Y.shape[0]
+    w = np.random.default_rng(1).uniform(0.5, 2.0, n)
+    W = np.diag(w)
+    a = O.bulkscan_null(Y, G, K, weights=w)
+    b = O.bulkscan_null(W @ Y, W @ G, W @ K @ W, Covar=W @ np.ones((n, 1)), addIntercept=False)
+    assert np.abs(a.L - b.L).max() <= 1e-3
+    e = O.bulkscan_null(Y, G, K, decomp_scheme="eigen")
+    s = O.bulkscan_null(Y, G, K, decomp_scheme="svd")
+    assert np.abs(e.L - s.L).mean() <= 1e-8
+
+
+def test_alt_grid_dominates_null_grid_and_dispatcher():
+    # alt-grid maximises over the same grid per marker, so it can only raise the log-likelihood ratio
+    Y, G, K, _ = make_data(p=50, m=5, seed=61)
+    grid = [i / 10.0 for i in range(10)]
+    al = O.bulkscan_alt_grid(Y, G, K, grid)
+    gr = O.bulkscan_null_grid(Y, G, K, grid)
+    assert (al.L >= gr.L - 1e-9).all()
+    assert set(np.unique(al.h2_panel)).issubset(set(grid))
+    d = O.bulkscan(Y, G, K, method="null-grid")
+    assert np.array_equal(d["L"], O.bulkscan_null_grid(Y, G, K, grid).L)
+    with pytest.raises(O.BulkLMMError):
+        O.bulkscan(Y, G, K, method="bogus")
+
+
+def test_scan_errors_and_perms():
+    Y, G, K, _ = make_data(p=40, m=2, seed=9)
+    with pytest.raises(O.BulkLMMError) as e:
+        O.scan(Y, G, K, permutation_test=True)
+    assert e.value.msg == "Can only handle one trait."
+    with pytest.raises(O.BulkLMMError) as e:
+        O.scan(Y[:, 0], G, K, addIntercept=False)
+    assert e.value.msg == "Intercept has to be added when no other covariate is given."
+    with pytest.raises(O.BulkLMMError) as e:
+        O.scan(Y[:, 0], G, K, assumption="x")
+    assert e.value.msg == "Assumption keyword is not supported. Please enter null or alt."
+    r = O.scan(Y[:, 0], G, K, permutation_test=True, nperms=5)
+    s = O.scan(Y[:, 0], G, K)
+    assert r["L_perms"].shape == (40, 5) and np.sum((r["lod"] - s["lod"]) ** 2) <= 1e-7
+
+
+def test_zero_column_raises():
+    # src/util.jl:69-71 via computeR_LMM's colDivide!
+    Y, G, K, _ = make_data(p=20, m=2, seed=3)
+    G = G.copy()
+    G[:, 4] = 0.0
+    with pytest.raises(O.BulkLMMError) as e:
+        O.bulkscan_null_grid(Y, G, K, [0.0, 0.5])
+    assert e.value.msg == "Dividing by zeros: the input vector can not contain any zeros!"
+
+
+def test_golden_fixture_reproduces():
+    # tests/golden/bulkscan_small.npz (tests/golden/make_golden.py)
+    z = np.load(os.path.join(GOLDEN, "bulkscan_small.npz"))
+    ex = O.bulkscan_null(z["Y"][:, :6], z["G"], z["K"], prior_variance=1.0, prior_sample_size=0.1)
+    assert np.abs(ex.L - z["exact_L"][:, :6]).max() <= 1e-9 and np.abs(ex.h2_null_list - z["exact_h2"][:6]).max() <= 1e-9
+    gr = O.bulkscan_null_grid(z["Y"], z["G"], z["K"], list(z["grid"]))
+    assert np.array_equal(gr.h2_null_list, z["grid_h2"]) and np.abs(gr.L - z["grid_L"]).max() <= 1e-10

@@ -1,12 +1,17 @@
-import numpy as np, sys
+import numpy as np, sys, ctypes as C
 sys.path.insert(0,'.'); sys.path.insert(0,'tests')
 from common import make_data
 import bulklmm_jl_amd as B
 from bulklmm_jl_amd import api, _lib as L
 Y,G,K,Cov=make_data(p=500,m=300,seed=1)
+Y=np.asfortranarray(Y); G=np.asfortranarray(G); K=np.asfortranarray(K)
+n,m=Y.shape; p=G.shape[1]
 ctx=B.default_context(); ctx.set_timing(True)
+o=api._opts(L.BLMM_NULL_EXACT)
+Lo=np.empty((p,m),order='F'); h2=np.empty(m); st=L.blmm_status()
 for rep in range(2):
-    Lo,h2,st=api._bulkscan_call(L.BLMM_NULL_EXACT,Y,G,K,None,None,True,None,1.0,0.0,False,1,"eigen",0,ctx,return_status=True)
-print("jacobi cycles", st.jacobi_cycles, "ticks", st.jacobi_ticks_100mhz, "MHz", st.jacobi_cycles/max(st.jacobi_ticks_100mhz,1)*100)
-print("jacobi sweeps", st.jacobi_sweeps, "eigen ms", st.t_eigen_ms, "h2 ms", st.t_h2_ms, "scan", st.t_scan_ms)
-print("h2 quantiles", np.quantile(h2,[0,0.1,0.5,0.9,1]))
+    rc=ctx.lib.blmm_bulkscan(ctx.h,C.byref(o),api._p(Y),n,m,api._p(G),p,None,0,api._p(K),None,None,0,api._p(Lo),api._p(h2),C.byref(st))
+    assert rc==0
+print("jacobi cycles", st.jacobi_cycles, "MHz", st.jacobi_cycles/max(st.jacobi_ticks_100mhz,1)*100, "sweeps", st.jacobi_sweeps)
+print("phase cycles angle/update/barrier:", st.n_nonpos_weight, st.n_zero_norm, st.n_nan_lod)
+print("eigen ms", st.t_eigen_ms, "h2 ms", st.t_h2_ms, "scan", st.t_scan_ms)
