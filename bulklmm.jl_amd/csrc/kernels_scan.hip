@@ -90,6 +90,19 @@ __device__ __forceinline__ int64_t xcd_swizzle(int64_t bid, int64_t nwg) {
   return (bid < (q << 3)) ? (bid & 7) * q + (bid >> 3) : bid;
 }
 
+// Tile walk inside an XCD's range: groups of GT trait tiles; inside a group the marker tile is the slow index and
+// the trait tile the fast one.  The GT trait tiles' A-side panels (GT x ~120 KB) stay in the 4 MB L2 while each
+// 80 KB marker tile of Xt is fetched once per group instead of once per trait tile (HBM/MALL fetch / ~GT).
+constexpr int GT = 16;
+__device__ __forceinline__ void tile_of(int64_t id, int64_t ntile_t, int ntile_i, int64_t& tile_t, int& tile_i) {
+  const int64_t per_group = (int64_t)GT * ntile_i;
+  const int64_t g = id / per_group, rem = id - g * per_group;
+  const int64_t t_first = g * GT;
+  const int gt = (int)((ntile_t - t_first < GT) ? (ntile_t - t_first) : GT);  // last group may be short
+  tile_i = (int)(rem / gt);
+  tile_t = t_first + (rem - (int64_t)tile_i * gt);
+}
+
 template <int NX, int MB, int NB, bool TABLE>
 __global__ void __launch_bounds__(256, 2) k_scan(ScanArgs a, int ntile_i, int64_t nwg) {
   constexpr int NP = 1 + NX;  // A-side panels consumed
@@ -97,8 +110,8 @@ __global__ void __launch_bounds__(256, 2) k_scan(ScanArgs a, int ntile_i, int64_
   stage_log_table<true>(s_log, a.logtab);  // read after the K loop; the barrier sits right before the epilogue
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int64_t bid = xcd_swizzle(blockIdx.x, nwg);
-  const int64_t tile_t = bid / ntile_i;
-  const int tile_i = (int)(bid % ntile_i);
+  int64_t tile_t; int tile_i;
+  tile_of(bid, nwg / ntile_i, ntile_i, tile_t, tile_i);
   const int64_t t0 = tile_t * (32 * MB) + (wave >> 1) * (16 * MB);
   const int64_t i0 = (int64_t)tile_i * (32 * NB) + (wave & 1) * (16 * NB);
   const int r = lane & 15, kk = lane >> 4;
@@ -256,8 +269,8 @@ __global__ void __launch_bounds__(256, 2) k_scan_alt(AltArgs aa, int ntile_i, in
   __syncthreads();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int64_t bid = xcd_swizzle(blockIdx.x, nwg);
-  const int64_t tile_t = bid / ntile_i;
-  const int tile_i = (int)(bid % ntile_i);
+  int64_t tile_t; int tile_i;
+  tile_of(bid, nwg / ntile_i, ntile_i, tile_t, tile_i);
   const int64_t t0 = tile_t * (32 * MB) + (wave >> 1) * (16 * MB);
   const int64_t i0 = (int64_t)tile_i * (32 * NB) + (wave & 1) * (16 * NB);
   const int r = lane & 15, kk = lane >> 4;
