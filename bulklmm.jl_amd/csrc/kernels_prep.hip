@@ -73,146 +73,189 @@ __device__ __forceinline__ double nr_rcp(double x) {
 // LDS variant (n <= JAC_NMAX): every workgroup of the launch runs the SAME deterministic iteration on its own LDS
 // copy of A (bitwise identical rotations, so no inter-workgroup synchronisation is ever needed) and accumulates
 // the rotations only into its own slice of the rows of V (rows of V are independent under column rotations).
-//   A update: one thread per 2x2 block between two pair slots, B' = J1' B J2 (both triangles are stored);
-//   schedule: the round-robin pairing (p, q) of every (round, slot) is tabulated once in LDS.
-constexpr int JAC_NMAX = 112;
+//
+// Brent-Luk form of the round-robin ordering: the pairs of a round are always the ADJACENT positions (2s, 2s+1);
+// instead of changing the index pairs, every round moves the data by the fixed permutation
+//     pi: top_0 stays, top_s -> top_{s+1}, top_last -> bottom_last, bottom_s -> bottom_{s-1}, bottom_0 -> top_1
+// (rows and columns of A, columns of V), ping-ponging between two LDS copies.  One thread per 2x2 block between
+// pair slots (s1 <= s2): two 16-byte reads, B' = J1' B J2, eight 8-byte writes to round-independent addresses
+// (only the upper triangle is stored: half the LDS writes, which bound the round).  One lane per slot computes (c, s) from its 2x2 diagonal block, no reductions.
+constexpr int JAC_NMAX = 92;   // 2 ping-pong copies of A (2 N^2 doubles) + V slices must fit 160 KB of LDS
 constexpr int JAC_NWG = 8;
+
+__device__ __forceinline__ int jac_pi(int pos, int NP2) {
+  if (NP2 <= 1 || pos == 0) return pos;
+  const int s = pos >> 1;
+  if (pos & 1) return (s == 0) ? 2 : 2 * (s - 1) + 1;        // bottoms move down the slot index, bottom_0 -> top_1
+  return (s == NP2 - 1) ? 2 * s + 1 : 2 * (s + 1);            // tops move up, the last top -> last bottom
+}
 
 __global__ void __launch_bounds__(1024) k_jacobi_lds(const double* __restrict__ Ag, double* __restrict__ Vg, int n,
                                                      double* __restrict__ lraw, int64_t* stat) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
-  __shared__ int s_flag[2];
   __shared__ double s_anorm;
   const int tid = threadIdx.x, nt = blockDim.x;
   const unsigned long long dbg_t0 = __builtin_amdgcn_s_memtime(), dbg_r0 = __builtin_amdgcn_s_memrealtime();
-  const int N = n + (n & 1), NP2 = N / 2, ld = N + 1;  // odd leading dimension
+  const int N = n + (n & 1), NP2 = N / 2, ld = N + 1;       // odd ld: row- and column-strided LDS walks are conflict-free
   const int rows_per = (n + gridDim.x - 1) / gridDim.x;
   const int r0 = blockIdx.x * rows_per, r1 = min(n, r0 + rows_per), nr = max(0, r1 - r0);
-  double* A = smem;                               // N x ld (column j at j*ld); the pad row/col of an odd n stays zero
-  double* Vs = A + N * ld;                        // rows_per x ld : Vs[r*ld + col]
-  double* rec = Vs + rows_per * ld;               // NP2 x 4 : {c, s, (p*ld | q*ld), (p | q)} per pair slot
-  double* relmax = rec + 4 * NP2;                 // NP2
-  unsigned short* sched = reinterpret_cast<unsigned short*>(relmax + NP2);  // (N-1) x NP2 x 2
-  const int nblk = NP2 * (NP2 + 1) / 2;
-  unsigned short* blk = sched + 2 * (N - 1) * NP2;                           // nblk x 2 : (s1 <= s2)
-  for (int row = tid; row < NP2; row += nt)
-    for (int b = 0; b <= row; ++b) { const int e = row * (row + 1) / 2 + b; blk[2 * e] = (unsigned short)b; blk[2 * e + 1] = (unsigned short)row; }
-  for (int e = tid; e < N * ld; e += nt) A[e] = 0.0;
-  for (int e = tid; e < rows_per * ld; e += nt) Vs[e] = 0.0;
+  // All buffers are addressed as smem[offset] so that hipcc keeps them in the LDS address space (a runtime-selected
+  // pointer array degrades every access to flat_load/flat_store).
+  //   A ping/pong: column-major upper triangle, element (row <= col) at col*ld + row;  V slices: row-major Vs[r*ld + pos]
+  const int AO = N * ld;                              // size of one A copy
+  const int VO = rows_per * ld;                       // size of one V slice copy
+  const int V0 = 2 * AO;                              // first V copy
+  const int REC = (2 * AO + 2 * VO + 1) & ~1;         // NP2 x 2 : (c, s) per slot, 16-byte aligned
+  const int REL = REC + 2 * NP2;                      // NP2
+  for (int e = tid; e < 2 * N * ld + 2 * rows_per * ld; e += nt) smem[e] = 0.0;
   __syncthreads();
-  for (int e = tid; e < n * n; e += nt) { const int i = e % n, j = e / n; A[j * ld + i] = Ag[e]; }
-  for (int r = tid; r < nr; r += nt) Vs[r * ld + (r0 + r)] = 1.0;
-  for (int e = tid; e < (N - 1) * NP2; e += nt) {
-    const int round = e / NP2, slot = e % NP2;
-    int p, q;
-    if (slot == 0) { p = N - 1; q = round; }
-    else { p = (round + slot) % (N - 1); q = (round - slot + (N - 1)) % (N - 1); }
-    if (p > q) { const int t = p; p = q; q = t; }
-    sched[2 * e] = (unsigned short)p; sched[2 * e + 1] = (unsigned short)q;
-  }
+  for (int e = tid; e < n * n; e += nt) { const int i = e % n, j = e / n; if (i <= j) smem[j * ld + i] = Ag[e]; }
+  for (int r = tid; r < nr; r += nt) smem[V0 + r * ld + (r0 + r)] = 1.0;
   __syncthreads();
   if (tid == 0) {
     double m = 0.0;
-    for (int i = 0; i < n; ++i) m = fmax(m, fabs(A[i * ld + i]));
+    for (int i = 0; i < n; ++i) m = fmax(m, fabs(smem[i * ld + i]));
     s_anorm = m;
   }
   __syncthreads();
   const double eps = 2.220446049250313e-16;
   const double tol2 = (4.0 * eps) * (4.0 * eps);
   const double floor2 = (eps * s_anorm) * (eps * s_anorm);
-  // fixed thread -> work maps (identical in every round)
-  int bs1 = -1, bs2 = -1;                               // first A block of this thread
-  if (tid < nblk) { bs1 = blk[2 * tid]; bs2 = blk[2 * tid + 1]; }
-  const int nvit = NP2 * nr;                            // V items (slot, local row), dealt from the last thread down
+  // ---- fixed thread -> work maps (identical in every round) -------------------------------------------
+  const int nblk = NP2 * (NP2 + 1) / 2;
+  constexpr int MAXB = 2;                               // blocks per thread: NP2 <= 46 -> nblk <= 1081 <= 2048
+  int b_s1[MAXB], b_s2[MAXB], b_src0[MAXB], b_src1[MAXB], b_dst[MAXB][4];
+#pragma unroll
+  for (int u = 0; u < MAXB; ++u) {
+    const int b = tid + u * nt;
+    b_s1[u] = -1; b_s2[u] = 0; b_src0[u] = b_src1[u] = 0;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) b_dst[u][w] = 0;
+    if (b < nblk) {
+      int row = (int)((sqrt(8.0 * b + 1.0) - 1.0) * 0.5);
+      while (row * (row + 1) / 2 > b) --row;
+      while ((row + 1) * (row + 2) / 2 <= b) ++row;
+      const int s2 = row, s1 = b - row * (row + 1) / 2;   // s1 <= s2
+      b_s1[u] = s1; b_s2[u] = s2;
+      b_src0[u] = (2 * s2) * ld + 2 * s1;                // column 2*s2,   rows 2*s1, 2*s1+1
+      b_src1[u] = (2 * s2 + 1) * ld + 2 * s1;            // column 2*s2+1, rows 2*s1, 2*s1+1
+      const int rp = jac_pi(2 * s1, NP2), rq = jac_pi(2 * s1 + 1, NP2), cp = jac_pi(2 * s2, NP2), cq = jac_pi(2 * s2 + 1, NP2);
+      // only the upper triangle is stored: element (r, c) lives at max(r,c)*ld + min(r,c)
+      b_dst[u][0] = max(rp, cp) * ld + min(rp, cp); b_dst[u][1] = max(rp, cq) * ld + min(rp, cq);
+      b_dst[u][2] = max(rq, cp) * ld + min(rq, cp); b_dst[u][3] = max(rq, cq) * ld + min(rq, cq);
+    }
+  }
+  // V items (slot, local row), dealt from the last thread downwards
+  const int nvit = NP2 * nr;
   const int vitem = nt - 1 - tid;
-  const int vslot = (vitem < nvit) ? vitem / max(nr, 1) : -1, vrow = (vitem < nvit) ? vitem % max(nr, 1) : 0;
-  int sweep = 0;
+  int v_slot = -1, v_src = 0, v_d0 = 0, v_d1 = 0;
+  if (vitem < nvit) {
+    v_slot = vitem / nr; const int r = vitem % nr;
+    v_src = r * ld + 2 * v_slot; v_d0 = r * ld + jac_pi(2 * v_slot, NP2); v_d1 = r * ld + jac_pi(2 * v_slot + 1, NP2);
+  }
+  int cur = 0, sweep = 0, dpos = N - 1;                 // dpos: where the zero pad row/col of an odd n currently sits
   for (; sweep < 30; ++sweep) {
     double myrel = 0.0;
     for (int round = 0; round < N - 1; ++round) {
-      const unsigned short* sc = sched + 2 * round * NP2;
-      // ---- (1) rotation angles: one lane per pair ---------------------------------------------------
+      const double* A = smem + (cur ? AO : 0);
+      double* An = smem + (cur ? 0 : AO);
+      const double* rec = smem + REC;
+      // ---- (1) rotation angles: one lane per slot, from the 2x2 diagonal block ---------------------------
       if (tid < NP2) {
-        const int p = sc[2 * tid], q = sc[2 * tid + 1];
-        const double app = A[p * ld + p], aqq = A[q * ld + q], apq = A[q * ld + p];
+        const double app = A[(2 * tid) * ld + 2 * tid], aqq = A[(2 * tid + 1) * ld + 2 * tid + 1], apq = A[(2 * tid + 1) * ld + 2 * tid];
         double c = 1.0, s = 0.0;
         const double pp = fmax(fabs(app * aqq), floor2), a2 = apq * apq;
         if (a2 > tol2 * pp) {
+          // cos 2phi = |d|/h, sin 2phi = sign(d) 2 apq / h, |phi| <= pi/4
           const double d = aqq - app;
-          const double g = fma(d, d, 4.0 * a2);
-          const double h = g * nr_rsqrt(g);                       // sqrt(d^2 + 4 apq^2)
-          const double t = copysign(2.0 * apq, apq * copysign(1.0, d)) * nr_rcp(fabs(d) + h);
-          c = nr_rsqrt(fma(t, t, 1.0));
-          s = t * c;
-          myrel = fmax(myrel, a2 * __builtin_amdgcn_rcp(pp));     // ~relative off-diagonal^2 (only gates the stop rule)
+          const double ih = nr_rsqrt(fma(d, d, 4.0 * a2));
+          const double c2 = fma(0.5 * fabs(d), ih, 0.5);
+          const double ic = nr_rsqrt(c2);
+          c = c2 * ic;
+          s = copysign(apq * ih, apq * copysign(1.0, d)) * ic;
+          myrel = fmax(myrel, a2 * __builtin_amdgcn_rcp(pp));   // ~ (relative off-diagonal)^2; only gates the stop rule
         }
-        rec[4 * tid] = c; rec[4 * tid + 1] = s;
-        reinterpret_cast<int*>(rec + 4 * tid + 2)[0] = p * ld; reinterpret_cast<int*>(rec + 4 * tid + 2)[1] = q * ld;
-        reinterpret_cast<int*>(rec + 4 * tid + 3)[0] = p; reinterpret_cast<int*>(rec + 4 * tid + 3)[1] = q;
+        *reinterpret_cast<dpair*>(smem + REC + 2 * tid) = (dpair){c, s};
       }
       __syncthreads();
-      // ---- (2) A: block (s1, s2):  B' = J1' B J2 ;  V slice: columns p, q of every local row -----
-      for (int b = tid; b < nblk; b += nt) {
-        const int s1 = (b == tid) ? bs1 : blk[2 * b], s2 = (b == tid) ? bs2 : blk[2 * b + 1];
-        const dpair cs1 = *reinterpret_cast<const dpair*>(rec + 4 * s1), cs2 = *reinterpret_cast<const dpair*>(rec + 4 * s2);
-        if (cs1[1] != 0.0 || cs2[1] != 0.0) {
-          const int4 i1 = *reinterpret_cast<const int4*>(rec + 4 * s1 + 2), i2 = *reinterpret_cast<const int4*>(rec + 4 * s2 + 2);
+      // ---- (2) A: B' = J1' B J2 written through pi;  V slice: columns (2s, 2s+1) of every local row -------
+#pragma unroll
+      for (int u = 0; u < MAXB; ++u) {
+        if (b_s1[u] >= 0) {
+          const dpair cs1 = *reinterpret_cast<const dpair*>(rec + 2 * b_s1[u]);
+          const dpair cs2 = *reinterpret_cast<const dpair*>(rec + 2 * b_s2[u]);
+          const dpair x0 = (dpair){A[b_src0[u]], A[b_src0[u] + 1]};   // (b00, b10): column 2*s2
+          const dpair x1 = (dpair){A[b_src1[u]], A[b_src1[u] + 1]};   // (b01, b11): column 2*s2+1
           const double c1 = cs1[0], sn1 = cs1[1], c2 = cs2[0], sn2 = cs2[1];
-          // i.x = p*ld, i.y = q*ld, i.z = p, i.w = q
-          if (s1 == s2) {
-            const double app = A[i1.x + i1.z], aqq = A[i1.y + i1.w], apq = A[i1.y + i1.z];
-            const double cc = c1 * c1, ss = sn1 * sn1, x = 2.0 * c1 * sn1 * apq;
-            A[i1.x + i1.z] = fma(cc, app, fma(ss, aqq, -x));
-            A[i1.y + i1.w] = fma(ss, app, fma(cc, aqq, x));
-            A[i1.y + i1.z] = 0.0; A[i1.x + i1.w] = 0.0;
+          double n00, n01, n10, n11;
+          if (b_s1[u] == b_s2[u]) {
+            const double app = x0[0], apq = x1[0], aqq = x1[1];
+            const double cc = c1 * c1, ss = sn1 * sn1, xx = 2.0 * c1 * sn1 * apq;
+            n00 = fma(cc, app, fma(ss, aqq, -xx));
+            n11 = fma(ss, app, fma(cc, aqq, xx));
+            n01 = n10 = (sn1 != 0.0) ? 0.0 : apq;
           } else {
-            // B = [[b00 b01],[b10 b11]] rows (p1,q1), cols (p2,q2)
-            const double b00 = A[i2.x + i1.z], b01 = A[i2.y + i1.z];
-            const double b10 = A[i2.x + i1.w], b11 = A[i2.y + i1.w];
-            const double t00 = fma(c2, b00, -sn2 * b01), t01 = fma(sn2, b00, c2 * b01);
-            const double t10 = fma(c2, b10, -sn2 * b11), t11 = fma(sn2, b10, c2 * b11);
-            const double n00 = fma(c1, t00, -sn1 * t10), n01 = fma(c1, t01, -sn1 * t11);
-            const double n10 = fma(sn1, t00, c1 * t10), n11 = fma(sn1, t01, c1 * t11);
-            A[i2.x + i1.z] = n00; A[i2.y + i1.z] = n01; A[i2.x + i1.w] = n10; A[i2.y + i1.w] = n11;
-            A[i1.x + i2.z] = n00; A[i1.x + i2.w] = n01; A[i1.y + i2.z] = n10; A[i1.y + i2.w] = n11;
+            const double t00 = fma(c2, x0[0], -sn2 * x1[0]), t01 = fma(sn2, x0[0], c2 * x1[0]);
+            const double t10 = fma(c2, x0[1], -sn2 * x1[1]), t11 = fma(sn2, x0[1], c2 * x1[1]);
+            n00 = fma(c1, t00, -sn1 * t10); n01 = fma(c1, t01, -sn1 * t11);
+            n10 = fma(sn1, t00, c1 * t10); n11 = fma(sn1, t01, c1 * t11);
           }
+          An[b_dst[u][0]] = n00; An[b_dst[u][1]] = n01; An[b_dst[u][3]] = n11;
+          if (b_s1[u] != b_s2[u]) An[b_dst[u][2]] = n10;   // (the diagonal block's n10 is the mirror of n01)
         }
       }
-      for (int item = vitem; item < nvit; item += nt) {
-        const int slot = (item == vitem) ? vslot : item / nr, r = (item == vitem) ? vrow : item % nr;
-        const dpair csv = *reinterpret_cast<const dpair*>(rec + 4 * slot);
-        if (csv[1] != 0.0) {
-          const int2 pqv = *reinterpret_cast<const int2*>(rec + 4 * slot + 3);
-          double* vr = Vs + r * ld;
-          const double x = vr[pqv.x], y = vr[pqv.y];
-          vr[pqv.x] = fma(csv[0], x, -csv[1] * y);
-          vr[pqv.y] = fma(csv[1], x, csv[0] * y);
+      {
+        const double* Vc = smem + V0 + (cur ? VO : 0);
+        double* Vn = smem + V0 + (cur ? 0 : VO);
+        if (v_slot >= 0) {
+          const dpair csv = *reinterpret_cast<const dpair*>(rec + 2 * v_slot);
+          const dpair xy = (dpair){Vc[v_src], Vc[v_src + 1]};
+          Vn[v_d0] = fma(csv[0], xy[0], -csv[1] * xy[1]);
+          Vn[v_d1] = fma(csv[1], xy[0], csv[0] * xy[1]);
+        }
+        for (int item = vitem + nt; item < nvit; item += nt) {   // only when NP2 * rows_per > 1024
+          const int slot = item / nr, r = item % nr;
+          const dpair csv = *reinterpret_cast<const dpair*>(rec + 2 * slot);
+          const dpair xy = (dpair){Vc[r * ld + 2 * slot], Vc[r * ld + 2 * slot + 1]};
+          Vn[r * ld + jac_pi(2 * slot, NP2)] = fma(csv[0], xy[0], -csv[1] * xy[1]);
+          Vn[r * ld + jac_pi(2 * slot + 1, NP2)] = fma(csv[1], xy[0], csv[0] * xy[1]);
         }
       }
+      dpos = jac_pi(dpos, NP2);
+      cur ^= 1;
       __syncthreads();
     }
     // sweep verdict: the largest relative off-diagonal (squared) any pair met in this sweep
-    if (tid < NP2) relmax[tid] = myrel;
+    if (tid < NP2) smem[REL + tid] = myrel;
     __syncthreads();
     double mx = 0.0;
-    for (int i = 0; i < NP2; ++i) mx = fmax(mx, relmax[i]);
+    for (int i = 0; i < NP2; ++i) mx = fmax(mx, smem[REL + i]);
     __syncthreads();
     // Jacobi converges quadratically: once every relative off-diagonal met in a sweep was below 1e-9 the sweep left
     // them at rounding level, and a further (verification) sweep would not rotate anything
     if (mx < 1e-18) break;
   }
+  // positions -> compact output (skip the pad position of an odd n): eigenvalue = diagonal, eigenvector = V column
+  const double* A = smem + (cur ? AO : 0);
+  const double* Vc = smem + V0 + (cur ? VO : 0);
+  const bool odd = (n & 1) != 0;
   if (blockIdx.x == 0) {
-    for (int i = tid; i < n; i += nt) lraw[i] = A[i * ld + i];
+    for (int pos = tid; pos < N; pos += nt) {
+      if (odd && pos == dpos) continue;
+      const int o = (odd && pos > dpos) ? pos - 1 : pos;
+      lraw[o] = A[pos * ld + pos];
+    }
     if (tid == 0) {
       stat[ST_JACOBI_SWEEPS] = sweep + 1;
       stat[6] = (int64_t)(__builtin_amdgcn_s_memtime() - dbg_t0);      // shader cycles spent in the eigensolver
       stat[7] = (int64_t)(__builtin_amdgcn_s_memrealtime() - dbg_r0);  // 100 MHz ticks
     }
   }
-  // eigenvectors, compact n x n column-major: Vg[col*n + row]
-  for (int e = tid; e < nr * n; e += nt) {
-    const int r = e % nr, col = e / nr;
-    Vg[(size_t)col * n + (r0 + r)] = Vs[r * ld + col];
+  for (int e = tid; e < nr * N; e += nt) {
+    const int r = e % nr, pos = e / nr;
+    if (odd && pos == dpos) continue;
+    const int o = (odd && pos > dpos) ? pos - 1 : pos;
+    Vg[(size_t)o * n + (r0 + r)] = Vc[r * ld + pos];      // compact n x n column-major: Vg[col*n + row]
   }
 }
 
@@ -306,8 +349,7 @@ int launch_jacobi(blmm_ctx* ctx, double* A, double* V, int n, double* lraw, int6
   if (n <= JAC_NMAX) {
     const int N = n + (n & 1), NP2 = N / 2, ld = N + 1;
     const int rows_per = (n + JAC_NWG - 1) / JAC_NWG;
-    const size_t lds = sizeof(double) * ((size_t)N * ld + (size_t)rows_per * ld + 5 * NP2) +
-                       sizeof(unsigned short) * (2 * (size_t)(N - 1) * NP2 + (size_t)NP2 * (NP2 + 1)) + 64;
+    const size_t lds = sizeof(double) * ((size_t)2 * N * ld + (size_t)2 * rows_per * ld + 3 * NP2 + 2) + 64;
     BLMM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_jacobi_lds), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(k_jacobi_lds, dim3(JAC_NWG), dim3(1024), lds, ctx->stream, A, V, n, lraw, stat);
   } else {

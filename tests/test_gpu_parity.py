@@ -290,3 +290,16 @@ def test_golden_fixture(blmm):
     al = blmm.bulkscan_alt_grid(Y, G, K, grid)
     assert_lod_close(al.L, z["alt_L"], atol=1e-9)
     assert (al.h2_panel != z["alt_h2"]).mean() <= 1e-3
+
+
+@pytest.mark.parametrize("n", [130, 333])
+def test_larger_sample_sizes(blmm, n):
+    """n > 112 takes the global-memory eigensolver and the wider lanes-per-trait Brent variants."""
+    Y, G, K, _ = make_data(n=n, p=150, m=21, seed=500 + n, bxd=False)
+    got = blmm.bulkscan_null(Y, G, K)
+    check_null_exact(got, Y, G, K)
+    grid = [i / 10.0 for i in range(10)]
+    gg = blmm.bulkscan_null_grid(Y, G, K, grid)
+    gr = O.bulkscan_null_grid(Y, G, K, grid)
+    assert np.array_equal(gg.h2_null_list, gr.h2_null_list)
+    assert_lod_close(gg.L, gr.L)
