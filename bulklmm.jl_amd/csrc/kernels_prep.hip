@@ -122,7 +122,7 @@ __global__ void __launch_bounds__(1024) k_jacobi_lds(const double* __restrict__ 
   const double tol2 = (4.0 * eps) * (4.0 * eps);
   const double floor2 = (eps * s_anorm) * (eps * s_anorm);
   // ---- fixed thread -> work maps (identical in every round) -------------------------------------------
-  const int nblk = NP2 * (NP2 + 1) / 2;
+  const int nblk = NP2 * (NP2 - 1) / 2;                 // off-diagonal slot pairs s1 < s2 (diagonal blocks: phase 1)
   constexpr int MAXB = 2;                               // blocks per thread: NP2 <= 46 -> nblk <= 1081 <= 2048
   int b_s1[MAXB], b_s2[MAXB], b_src0[MAXB], b_src1[MAXB], b_dst[MAXB][4];
 #pragma unroll
@@ -135,7 +135,7 @@ __global__ void __launch_bounds__(1024) k_jacobi_lds(const double* __restrict__ 
       int row = (int)((sqrt(8.0 * b + 1.0) - 1.0) * 0.5);
       while (row * (row + 1) / 2 > b) --row;
       while ((row + 1) * (row + 2) / 2 <= b) ++row;
-      const int s2 = row, s1 = b - row * (row + 1) / 2;   // s1 <= s2
+      const int s2 = row + 1, s1 = b - row * (row + 1) / 2;   // s1 < s2
       b_s1[u] = s1; b_s2[u] = s2;
       b_src0[u] = (2 * s2) * ld + 2 * s1;                // column 2*s2,   rows 2*s1, 2*s1+1
       b_src1[u] = (2 * s2 + 1) * ld + 2 * s1;            // column 2*s2+1, rows 2*s1, 2*s1+1
@@ -152,6 +152,11 @@ __global__ void __launch_bounds__(1024) k_jacobi_lds(const double* __restrict__ 
   if (vitem < nvit) {
     v_slot = vitem / nr; const int r = vitem % nr;
     v_src = r * ld + 2 * v_slot; v_d0 = r * ld + jac_pi(2 * v_slot, NP2); v_d1 = r * ld + jac_pi(2 * v_slot + 1, NP2);
+  }
+  int d_pp = 0, d_qq = 0, d_pq = 0;                     // where slot tid's diagonal block goes (upper triangle)
+  if (tid < NP2) {
+    const int rp = jac_pi(2 * tid, NP2), rq = jac_pi(2 * tid + 1, NP2);
+    d_pp = rp * ld + rp; d_qq = rq * ld + rq; d_pq = max(rp, rq) * ld + min(rp, rq);
   }
   int cur = 0, sweep = 0, dpos = N - 1;                 // dpos: where the zero pad row/col of an odd n currently sits
   for (; sweep < 30; ++sweep) {
@@ -176,6 +181,11 @@ __global__ void __launch_bounds__(1024) k_jacobi_lds(const double* __restrict__ 
           myrel = fmax(myrel, a2 * __builtin_amdgcn_rcp(pp));   // ~ (relative off-diagonal)^2; only gates the stop rule
         }
         *reinterpret_cast<dpair*>(smem + REC + 2 * tid) = (dpair){c, s};
+        // the slot's own 2x2 diagonal block, rotated and moved through pi (upper triangle)
+        const double cc = c * c, ss = s * s, xx = 2.0 * c * s * apq;
+        An[d_pp] = fma(cc, app, fma(ss, aqq, -xx));
+        An[d_qq] = fma(ss, app, fma(cc, aqq, xx));
+        An[d_pq] = (s != 0.0) ? 0.0 : apq;
       }
       __syncthreads();
       // ---- (2) A: B' = J1' B J2 written through pi;  V slice: columns (2s, 2s+1) of every local row -------
@@ -187,21 +197,10 @@ __global__ void __launch_bounds__(1024) k_jacobi_lds(const double* __restrict__ 
           const dpair x0 = (dpair){A[b_src0[u]], A[b_src0[u] + 1]};   // (b00, b10): column 2*s2
           const dpair x1 = (dpair){A[b_src1[u]], A[b_src1[u] + 1]};   // (b01, b11): column 2*s2+1
           const double c1 = cs1[0], sn1 = cs1[1], c2 = cs2[0], sn2 = cs2[1];
-          double n00, n01, n10, n11;
-          if (b_s1[u] == b_s2[u]) {
-            const double app = x0[0], apq = x1[0], aqq = x1[1];
-            const double cc = c1 * c1, ss = sn1 * sn1, xx = 2.0 * c1 * sn1 * apq;
-            n00 = fma(cc, app, fma(ss, aqq, -xx));
-            n11 = fma(ss, app, fma(cc, aqq, xx));
-            n01 = n10 = (sn1 != 0.0) ? 0.0 : apq;
-          } else {
-            const double t00 = fma(c2, x0[0], -sn2 * x1[0]), t01 = fma(sn2, x0[0], c2 * x1[0]);
-            const double t10 = fma(c2, x0[1], -sn2 * x1[1]), t11 = fma(sn2, x0[1], c2 * x1[1]);
-            n00 = fma(c1, t00, -sn1 * t10); n01 = fma(c1, t01, -sn1 * t11);
-            n10 = fma(sn1, t00, c1 * t10); n11 = fma(sn1, t01, c1 * t11);
-          }
-          An[b_dst[u][0]] = n00; An[b_dst[u][1]] = n01; An[b_dst[u][3]] = n11;
-          if (b_s1[u] != b_s2[u]) An[b_dst[u][2]] = n10;   // (the diagonal block's n10 is the mirror of n01)
+          const double t00 = fma(c2, x0[0], -sn2 * x1[0]), t01 = fma(sn2, x0[0], c2 * x1[0]);
+          const double t10 = fma(c2, x0[1], -sn2 * x1[1]), t11 = fma(sn2, x0[1], c2 * x1[1]);
+          An[b_dst[u][0]] = fma(c1, t00, -sn1 * t10); An[b_dst[u][1]] = fma(c1, t01, -sn1 * t11);
+          An[b_dst[u][2]] = fma(sn1, t00, c1 * t10); An[b_dst[u][3]] = fma(sn1, t01, c1 * t11);
         }
       }
       {
