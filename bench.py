@@ -82,7 +82,8 @@ def main():
     ap.add_argument("--n", type=int, default=79)
     ap.add_argument("--p", type=int, default=7321)
     ap.add_argument("--m", type=int, default=35554)
-    ap.add_argument("--method", default="null-exact", choices=["null-exact", "null-grid", "alt-grid"])
+    ap.add_argument("--method", default="null-exact", choices=["null-exact", "null-grid", "alt-grid", "perms"],
+                    help="perms: scan(...; permutation_test=true) with --m permutations of ONE trait (BASELINE.json configs[4])")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
     ap.add_argument("--gather", action="store_true", help="put the RCCL all-gather of the LOD shards inside the step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -138,13 +139,22 @@ def main():
         dLfull = torch.empty((world, m_local, p), dtype=torch.float64, device=dev) if world > 1 else None
     dL = dLfull[rank] if world > 1 else torch.empty((m_local, p), dtype=torch.float64, device=dev)
     dH = torch.empty((m_local, p) if alt else (m_local,), dtype=torch.float64, device=dev)
-    grid = [i / 16.0 for i in range(16)] if a.method != "null-exact" else None
+    grid = [i / 16.0 for i in range(16)] if a.method in ("null-grid", "alt-grid") else None
 
     stream = torch.cuda.current_stream()
     ctx = B.Context(local_rank, stream.cuda_stream)
 
+    perms = a.method == "perms"
+    if perms:
+        dy1 = dY[0].contiguous()
+        dsc = torch.empty(2, dtype=torch.float64, device=dev)
+        dlod = torch.empty(p, dtype=torch.float64, device=dev)
+
     def step(gather):
-        B.bulkscan_dev(ctx, dY, dG, dK, dL, dH, method=a.method, h2_grid=grid)
+        if perms:
+            B.scan_perms_dev(ctx, dy1, dG, dK, dsc, dlod, dL, nperms=m_local, seed=1 + rank)
+        else:
+            B.bulkscan_dev(ctx, dY, dG, dK, dL, dH, method=a.method, h2_grid=grid)
         if gather and world > 1:
             dist.all_gather_into_tensor(dLfull.view(-1), dL.reshape(-1))
 
@@ -189,7 +199,7 @@ def main():
         c = 1
         if a.method == "null-exact":
             flops_launch = 2.0 * n * (2 + c) * p * m_local       # 2n(2+c) flops per test
-        elif a.method == "null-grid":
+        elif a.method in ("null-grid", "perms"):
             flops_launch = 2.0 * n * p * m_local
         else:
             flops_launch = 2.0 * n * len(grid) * p * m_local

@@ -415,3 +415,25 @@ def bulkscan_dev(ctx: Context, Y, G, K, L_out, h2_out, *, method: str = "null-ex
                                         None if weights is None else weights.data_ptr(), _p(grid), ngrid,
                                         L_out.data_ptr(), p, h2_out.data_ptr(), C.byref(st) if status else None))
     return st
+
+
+def scan_perms_dev(ctx: Context, y, G, K, scalars_out, lod_out, Lperms_out, *, nperms: int, seed: int = 0, perm_idx=None,
+                   Covar=None, weights=None, addIntercept: bool = True, prior_variance: float = 0.0,
+                   prior_sample_size: float = 0.0, reml: bool = False, optim_interval: int = 1,
+                   decomp_scheme: str = "eigen", status: bool = False):
+    """blmm_scan_perms_dev on torch CUDA tensors: y (n,), G (p, n) [= n x p column-major], K (n, n),
+    scalars_out (2,), lod_out (p,), Lperms_out (nperms, p) [= p x nperms column-major], perm_idx (nperms, n) int32."""
+    n = y.shape[0]
+    p = G.shape[0]
+    ncov = 0 if Covar is None else Covar.shape[0]
+    if Covar is None:
+        addIntercept = True
+    o = _opts(L.BLMM_NULL_EXACT, reml, addIntercept, decomp_scheme, optim_interval, prior_variance, prior_sample_size)
+    st = L.blmm_status() if status else None
+    ctx.check(ctx.lib.blmm_scan_perms_dev(ctx.h, C.byref(o), y.data_ptr(), n, G.data_ptr(), p,
+                                          None if Covar is None else Covar.data_ptr(), ncov, K.data_ptr(),
+                                          None if weights is None else weights.data_ptr(), int(nperms), C.c_uint64(int(seed)),
+                                          None if perm_idx is None else perm_idx.data_ptr(), scalars_out.data_ptr(),
+                                          lod_out.data_ptr(), None if Lperms_out is None else Lperms_out.data_ptr(),
+                                          C.byref(st) if status else None))
+    return st

@@ -7,6 +7,8 @@
 #include <cmath>
 #include <cstring>
 #include <limits>
+#include <dlfcn.h>
+#include <cstdlib>
 
 using namespace blmm;
 
@@ -145,6 +147,38 @@ int finish_status(blmm_ctx* ctx, blmm_status* st, Timer* tm) {
   return BLMM_OK;
 }
 
+// Eigen-decomposition for n beyond the LDS Jacobi: rocSOLVER dsyevd (the reference calls LAPACK here,
+// src/transform_helpers.jl:23); loaded lazily so that the common small-n path carries no rocBLAS start-up cost.
+// On return A holds the eigenvectors (columns) and lraw the eigenvalues.
+int eigen_rocsolver(blmm_ctx* ctx, double* A, int n, double* lraw, int64_t* stat) {
+  if (!ctx->rs_tried) {
+    ctx->rs_tried = true;
+    ctx->rb_lib = dlopen("librocblas.so", RTLD_NOW | RTLD_GLOBAL);
+    if (!ctx->rb_lib) ctx->rb_lib = dlopen("/opt/rocm/lib/librocblas.so", RTLD_NOW | RTLD_GLOBAL);
+    ctx->rs_lib = dlopen("librocsolver.so", RTLD_NOW | RTLD_GLOBAL);
+    if (!ctx->rs_lib) ctx->rs_lib = dlopen("/opt/rocm/lib/librocsolver.so", RTLD_NOW | RTLD_GLOBAL);
+    if (ctx->rb_lib && ctx->rs_lib) {
+      auto create = reinterpret_cast<int (*)(void**)>(dlsym(ctx->rb_lib, "rocblas_create_handle"));
+      ctx->rb_destroy = reinterpret_cast<int (*)(void*)>(dlsym(ctx->rb_lib, "rocblas_destroy_handle"));
+      ctx->rb_set_stream = reinterpret_cast<int (*)(void*, hipStream_t)>(dlsym(ctx->rb_lib, "rocblas_set_stream"));
+      ctx->rs_dsyevd = reinterpret_cast<int (*)(void*, int, int, int, double*, int, double*, double*, int*)>(dlsym(ctx->rs_lib, "rocsolver_dsyevd"));
+      if (create && ctx->rb_destroy && ctx->rb_set_stream && ctx->rs_dsyevd) {
+        if (create(&ctx->rb_handle) != 0) ctx->rb_handle = nullptr;
+      }
+    }
+  }
+  if (!ctx->rb_handle || !ctx->rs_dsyevd) return BLMM_ERR_UNSUPPORTED;
+  int rc = ensure(ctx, ctx->tmpB, sizeof(double) * (size_t)n + 64);
+  if (rc) return rc;
+  if (ctx->rb_set_stream(ctx->rb_handle, ctx->stream) != 0) return fail(ctx, BLMM_ERR_HIP, "rocblas_set_stream failed");
+  double* E = ptr<double>(ctx->tmpB);
+  int* info = reinterpret_cast<int*>(E + n);
+  const int st = ctx->rs_dsyevd(ctx->rb_handle, /*evect_original*/ 211, /*fill_lower*/ 122, n, A, n, lraw, E, info);
+  if (st != 0) return fail(ctx, BLMM_ERR_HIP, "rocsolver_dsyevd failed with status " + std::to_string(st));
+  (void)stat;
+  return BLMM_OK;
+}
+
 // design -> eigen -> rotation of Y and G.  centered = 1: the rotation also removes the unweighted projection
 // on the null covariates (kernels_prep.hip:k_post_eigen).
 int prepare(blmm_ctx* ctx, const blmm_opts* o, const double* dY, int64_t n, int64_t m, const double* dG, int64_t p,
@@ -173,8 +207,21 @@ int prepare(blmm_ctx* ctx, const blmm_opts* o, const double* dY, int64_t n, int6
   P.Yt = ptr<double>(ctx->Yt); P.Xt = ptr<double>(ctx->Xt); P.Z0 = ptr<double>(ctx->Z0); P.lam = ptr<double>(ctx->lam);
   tm.mark();
   if ((rc = launch_design(ctx, dK, dCovar, (int)ncov, add_int, dweights, (int)n, ptr<double>(ctx->Ks), ptr<double>(ctx->Zs)))) return rc;
-  if ((rc = launch_jacobi(ctx, ptr<double>(ctx->Ks), ptr<double>(ctx->V), (int)n, ptr<double>(ctx->lraw), P.stat))) return rc;
-  if ((rc = launch_post_eigen(ctx, ptr<double>(ctx->lraw), ptr<double>(ctx->V), ptr<double>(ctx->Zs), dweights, (int)n, c,
+  const double* evec = ptr<double>(ctx->V);
+  // n <= 92: LDS Jacobi; up to 384: the single-workgroup global-memory Jacobi (tens to hundreds of ms, but no
+  // library start-up); beyond: rocSOLVER dsyevd (its first use in a process costs ~2 min of code-object loading on
+  // this image, afterwards ~12 ms at n = 500).  BLMM_EIGEN=rocsolver|jacobi overrides the choice.
+  static const char* eig_env = getenv("BLMM_EIGEN");
+  const bool want_rs = eig_env ? (std::strcmp(eig_env, "rocsolver") == 0 && n > jacobi_lds_max_n())
+                               : n > 384;
+  if (want_rs && !(eig_env && std::strcmp(eig_env, "jacobi") == 0) &&
+      eigen_rocsolver(ctx, ptr<double>(ctx->Ks), (int)n, ptr<double>(ctx->lraw), P.stat) == BLMM_OK) {
+    evec = ptr<double>(ctx->Ks);  // dsyevd leaves the eigenvectors in place of K
+  } else {
+    if (n > 2048) return fail(ctx, BLMM_ERR_UNSUPPORTED, "n > 2048 needs librocsolver.so for the eigen-decomposition");
+    if ((rc = launch_jacobi(ctx, ptr<double>(ctx->Ks), ptr<double>(ctx->V), (int)n, ptr<double>(ctx->lraw), P.stat))) return rc;
+  }
+  if ((rc = launch_post_eigen(ctx, ptr<double>(ctx->lraw), evec, ptr<double>(ctx->Zs), dweights, (int)n, c,
                               P.npad, P.ldr, o->decomp_scheme, centered, P.lam, ptr<double>(ctx->U), P.Z0,
                               ptr<double>(ctx->Rp), P.stat))) return rc;
   tm.mark();
@@ -280,6 +327,7 @@ void blmm_destroy(blmm_ctx* ctx) {
                     &ctx->tmpA, &ctx->tmpB, &ctx->tmpC, &ctx->perm, &ctx->r0, &ctx->altbuf, &ctx->logtab, &ctx->lraw};
   for (DevBuf* b : bufs) if (b->p) hipFree(b->p);
   for (auto& s : ctx->evsets) for (auto& e : s.e) (void)hipEventDestroy(e);
+  if (ctx->rb_handle && ctx->rb_destroy) ctx->rb_destroy(ctx->rb_handle);
   if (ctx->own_stream) hipStreamDestroy(ctx->stream);
   delete ctx;
 }

@@ -41,6 +41,11 @@ struct blmm_ctx {
   struct EvSet { hipEvent_t e[8]; int n; };
   std::vector<EvSet> evsets;
   size_t ev_used = 0;
+  // rocSOLVER (dlopen'ed lazily; only used for the eigen-decomposition when n exceeds the LDS Jacobi's range)
+  void* rs_lib = nullptr; void* rb_lib = nullptr; void* rb_handle = nullptr; bool rs_tried = false;
+  int (*rb_destroy)(void*) = nullptr;
+  int (*rb_set_stream)(void*, hipStream_t) = nullptr;
+  int (*rs_dsyevd)(void*, int, int, int, double*, int, double*, double*, int*) = nullptr;
 };
 
 namespace blmm {
@@ -70,6 +75,7 @@ int launch_design(blmm_ctx* ctx, const double* dK, const double* dCovar, int nco
 // One-sided Jacobi eigen-decomposition of the symmetric n x n matrix in A (destroyed); V gets the eigenvectors
 // (unsorted), then post_eigen sorts/derives everything the rotation needs.
 int launch_jacobi(blmm_ctx* ctx, double* A, double* V, int n, double* lraw, int64_t* stat);
+int jacobi_lds_max_n();
 // lambda (ascending, or |lambda| descending for svd), U sorted, Z0 = U' Zs, Rp = (centered ? Q U' Wd : U' Wd)'
 int launch_post_eigen(blmm_ctx* ctx, const double* lraw, const double* V, const double* Zs, const double* dweights, int n,
                       int c, int npad, int ldr, int decomp, int centered, double* lam, double* U, double* Z0, double* Rp,

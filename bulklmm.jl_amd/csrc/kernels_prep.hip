@@ -344,6 +344,8 @@ __global__ void __launch_bounds__(1024) k_jacobi_glb(double* __restrict__ A, dou
   if (tid == 0) stat[ST_JACOBI_SWEEPS] = sweep + 1;
 }
 
+int jacobi_lds_max_n() { return JAC_NMAX; }
+
 int launch_jacobi(blmm_ctx* ctx, double* A, double* V, int n, double* lraw, int64_t* stat) {
   if (n <= JAC_NMAX) {
     const int N = n + (n & 1), NP2 = N / 2, ld = N + 1;
