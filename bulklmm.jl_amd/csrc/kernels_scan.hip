@@ -25,6 +25,7 @@
 #include "blmm_internal.h"
 #include "fastmath.h"
 #include <cmath>
+#include <cstdlib>
 
 namespace blmm {
 
@@ -107,7 +108,7 @@ template <int NX, int MB, int NB, bool TABLE>
 __global__ void __launch_bounds__(256, 2) k_scan(ScanArgs a, int ntile_i, int64_t nwg) {
   constexpr int NP = 1 + NX;  // A-side panels consumed
   __shared__ dpair s_log[BLMM_LOG_TABLE_N];
-  stage_log_table<true>(s_log, a.logtab);  // read after the K loop; the barrier sits right before the epilogue
+  stage_lod_table(s_log, a.logtab, -0.5 * (double)a.n);  // read after the K loop; the barrier sits right before the epilogue
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int64_t bid = xcd_swizzle(blockIdx.x, nwg);
   int64_t tile_t; int tile_i;
@@ -174,7 +175,7 @@ __global__ void __launch_bounds__(256, 2) k_scan(ScanArgs a, int ntile_i, int64_
 
   // ---- epilogue: projection, normalisation, r -> LOD, 32-byte stores ---------------------------------
   __syncthreads();
-  const double scale = -0.5 * (double)a.n;
+  const LodPoly lp = make_lod_poly(-0.5 * (double)a.n);
   const int64_t ibase = i0 + NB * r;
   int nnan = 0;
 #pragma unroll
@@ -204,10 +205,12 @@ __global__ void __launch_bounds__(256, 2) k_scan(ScanArgs a, int ntile_i, int64_
         }
         // r2lod (src/bulkscan_helpers.jl:22-24): -(n/2) * log10(1.0 - r^2), same operation order
         const double u = 1.0 - r2;
-        double lod = scale * fast_log<true>(u, s_log);
-        if (!(u > 0.0)) lod = (u == 0.0) ? INFINITY : NAN;  // r^2 = 1 -> +Inf; r^2 > 1 -> DomainError in Julia, NaN here
+        double lod = fast_lod(u, s_log, lp);
+        if (__builtin_expect(!(u > 0.0), 0)) {  // r^2 = 1 -> +Inf; r^2 > 1 -> DomainError in Julia, NaN here
+          lod = (u == 0.0) ? INFINITY : NAN;
+          nnan += (u != 0.0) && (ibase + nb < a.p);
+        }
         out[nb] = lod;
-        nnan += (lod != lod) && (ibase + nb < a.p);
       }
       double* dst = a.L + trait * a.ldL + ibase;
       if (ibase + NB <= a.p) {
@@ -253,7 +256,12 @@ int launch_scan_exact(blmm_ctx* ctx, const ScanArgs& a, int c) {
   return fail(ctx, BLMM_ERR_UNSUPPORTED, "number of null covariates (incl. intercept) must be 1..4");
 }
 
-int launch_scan_table(blmm_ctx* ctx, const ScanArgs& a) { return launch_scan_t<0, true, 2>(ctx, a); }
+int launch_scan_table(blmm_ctx* ctx, const ScanArgs& a) {
+  static const int mb = getenv("BLMM_TABLE_MB") ? atoi(getenv("BLMM_TABLE_MB")) : 2;
+  if (mb == 4) return launch_scan_t<0, true, 4>(ctx, a);
+  if (mb == 1) return launch_scan_t<0, true, 1>(ctx, a);
+  return launch_scan_t<0, true, 2>(ctx, a);
+}
 
 // ------------------------------------------------------------------------------------------------
 // alt-grid: for every (trait, marker) the maximum over the h2 grid of  ln10*LOD_g + Ell[g, j];
@@ -280,33 +288,38 @@ __global__ void __launch_bounds__(256, 2) k_scan_alt(AltArgs aa, int ntile_i, in
 
   double best[MB][NB][4];
   int bidx[MB][NB][4];
+  d4 acc[MB][NB];
 #pragma unroll
   for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
-    for (int nb = 0; nb < NB; ++nb)
+    for (int nb = 0; nb < NB; ++nb) {
+      acc[mb][nb] = (d4){0, 0, 0, 0};
 #pragma unroll
       for (int reg = 0; reg < 4; ++reg) { best[mb][nb][reg] = 0.0; bidx[mb][nb][reg] = 0; }
-  int nnan = 0;
+    }
 
-  for (int g = 0; g < aa.ngrid; ++g) {
-    d4 acc[MB][NB];
+  // one flat loop over (grid point g, K step ks) with the same two-fragment-set prefetch as k_scan; the prefetch
+  // runs across grid points, the running-max epilogue fires after the last K step of every g
+  const double* PA = a.P + tile_t * (32 * MB);
+  const double* PB = a.Xt + (int64_t)tile_i * (32 * NB);
+  const uint32_t voffA = (uint32_t)(((int64_t)kk * a.ldp + (wave >> 1) * (16 * MB) + MB * r) * 8);
+  const uint32_t voffB = (uint32_t)(((int64_t)kk * a.ldx + (wave & 1) * (16 * NB) + NB * r) * 8);
+  const int64_t sa = 4 * a.ldp, sb = 4 * a.ldx;
+  const int KS = a.ks, G = aa.ngrid;
+  int gl = 0, kl = 0;  // load cursor
+  auto load_next = [&](double (&A)[MB], double (&B)[NB]) {
+    bufload<MB>(A, make_srd(PA + (int64_t)gl * a.pstride + kl * sa), voffA);
+    bufload<NB>(B, make_srd(PB + kl * sb), voffB);
+    if (++kl == KS) { kl = 0; if (gl + 1 < G) ++gl; else kl = KS - 1; }   // clamp at the very end (harmless re-load)
+  };
+  auto mfma_set = [&](const double (&A)[MB], const double (&B)[NB]) {
 #pragma unroll
     for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
-      for (int nb = 0; nb < NB; ++nb) acc[mb][nb] = (d4){0, 0, 0, 0};
-    const double* pa = a.P + (int64_t)g * a.pstride + (int64_t)kk * a.ldp + t0 + MB * r;
-    const double* pb = a.Xt + (int64_t)kk * a.ldx + i0 + NB * r;
-    for (int ks = 0; ks < a.ks; ++ks) {
-      double av[MB], bv[NB];
-      loadv<MB>(av, pa);
-      loadv<NB>(bv, pb);
-      pa += 4 * a.ldp; pb += 4 * a.ldx;
-#pragma unroll
-      for (int mb = 0; mb < MB; ++mb)
-#pragma unroll
-        for (int nb = 0; nb < NB; ++nb)
-          acc[mb][nb] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[mb], bv[nb], acc[mb][nb], 0, 0, 0);
-    }
+      for (int nb = 0; nb < NB; ++nb)
+        acc[mb][nb] = __builtin_amdgcn_mfma_f64_16x16x4f64(A[mb], B[nb], acc[mb][nb], 0, 0, 0);
+  };
+  auto fold = [&](int g) {  // logL1_g = ln10*LOD_g + Ell[g, j]; keep the running maximum (tmax!, strict <)
     double sc[NB];
     loadv<NB>(sc, a.isx + (int64_t)g * a.ld_isx + ibase);
 #pragma unroll
@@ -314,31 +327,61 @@ __global__ void __launch_bounds__(256, 2) k_scan_alt(AltArgs aa, int ntile_i, in
 #pragma unroll
       for (int reg = 0; reg < 4; ++reg) {
         const int64_t trait = t0 + MB * (kk + 4 * reg) + mb;
-        const double ell = (trait < a.m) ? aa.EllTab[trait * (int64_t)aa.ngrid + g] : 0.0;
+        const double ell = (trait < a.m) ? aa.EllTab[trait * (int64_t)G + g] : 0.0;
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) {
           const double rr = acc[mb][nb][reg] * sc[nb];
           const double u = 1.0 - rr * rr;
           double lod = scale * fast_log<true>(u, s_log);
           if (!(u > 0.0)) lod = (u == 0.0) ? INFINITY : NAN;
-          const double l1 = lod * ln10 + ell;
-          if (g == 0) {
-            best[mb][nb][reg] = l1;
-          } else if (best[mb][nb][reg] < l1) {
-            best[mb][nb][reg] = l1;
-            bidx[mb][nb][reg] = aa.counter_quirk ? bidx[mb][nb][reg] + 1 : g;
-          }
+          const double l1 = fma(lod, ln10, ell);
+          const bool first = g == 0;
+          const bool better = best[mb][nb][reg] < l1;
+          if (first || better) best[mb][nb][reg] = l1;
+          if (!first && better) bidx[mb][nb][reg] = aa.counter_quirk ? bidx[mb][nb][reg] + 1 : g;
         }
       }
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) acc[mb][nb] = (d4){0, 0, 0, 0};
+  };
+  double a0[MB], b0[NB], a1[MB], b1[NB];
+  load_next(a0, b0);
+  for (int g = 0; g < G; ++g) {
+    int ks = 0;
+    for (; ks + 2 <= KS; ks += 2) {
+      load_next(a1, b1);                   // (g, ks+1)
+      __builtin_amdgcn_sched_barrier(0);
+      mfma_set(a0, b0);
+      __builtin_amdgcn_sched_barrier(0);
+      load_next(a0, b0);                   // (g, ks+2), or the first step of g+1
+      __builtin_amdgcn_sched_barrier(0);
+      mfma_set(a1, b1);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (ks < KS) {                         // odd KS: a0/b0 hold the last step of g; fetch (g+1, 0) and rotate the sets
+      load_next(a1, b1);
+      __builtin_amdgcn_sched_barrier(0);
+      mfma_set(a0, b0);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int mb = 0; mb < MB; ++mb) a0[mb] = a1[mb];
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) b0[nb] = b1[nb];
+    }
+    fold(g);
   }
+
+  int nnan = 0;
 #pragma unroll
   for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
     for (int reg = 0; reg < 4; ++reg) {
       const int64_t trait = t0 + MB * (kk + 4 * reg) + mb;
       if (trait >= a.m) continue;
-      double l0 = aa.EllTab[trait * (int64_t)aa.ngrid];
-      for (int g = 1; g < aa.ngrid; ++g) l0 = fmax(l0, aa.EllTab[trait * (int64_t)aa.ngrid + g]);
+      double l0 = aa.EllTab[trait * (int64_t)G];
+      for (int g = 1; g < G; ++g) l0 = fmax(l0, aa.EllTab[trait * (int64_t)G + g]);
       double* dst = a.L + trait * a.ldL + ibase;
       double* dh = aa.H2 + trait * aa.ldH + ibase;
 #pragma unroll
@@ -346,8 +389,8 @@ __global__ void __launch_bounds__(256, 2) k_scan_alt(AltArgs aa, int ntile_i, in
         if (ibase + nb < a.p) {
           const double v = (best[mb][nb][reg] - l0) / ln10;
           nnan += (v != v);
-          dst[nb] = v;
-          dh[nb] = aa.grid_dev[bidx[mb][nb][reg]];
+          __builtin_nontemporal_store(v, dst + nb);
+          __builtin_nontemporal_store(aa.grid_dev[bidx[mb][nb][reg]], dh + nb);
         }
       }
     }
@@ -355,9 +398,10 @@ __global__ void __launch_bounds__(256, 2) k_scan_alt(AltArgs aa, int ntile_i, in
 }
 
 int launch_scan_alt(blmm_ctx* ctx, const AltArgs& aa) {
-  constexpr int MB = 2, NB = 4;
+  // MB = 1 (16 traits x 64 markers per wave): accumulators + running max + arg-max stay in registers at 2+ waves/SIMD
+  constexpr int MB = 1, NB = 4;
   const ScanArgs& a = aa.s;
-  const int64_t ntile_t = (a.m + TILE_T - 1) / TILE_T;
+  const int64_t ntile_t = (a.m + 32 * MB - 1) / (32 * MB);
   const int64_t ntile_i = (a.p + TILE_I - 1) / TILE_I;
   const int64_t nwg = ntile_t * ntile_i;
   if (nwg <= 0) return BLMM_OK;
