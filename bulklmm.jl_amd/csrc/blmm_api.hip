@@ -138,6 +138,8 @@ int finish_status(blmm_ctx* ctx, blmm_status* st, Timer* tm) {
   st->n_brent_maxiter = h[ST_BRENT_MAXIT];
   st->jacobi_sweeps = h[ST_JACOBI_SWEEPS];
   st->jacobi_cycles = h[6]; st->jacobi_ticks_100mhz = h[7];
+  st->lowrank_rank = h[8];
+  { double r2; std::memcpy(&r2, &h[9], sizeof(double)); st->lowrank_resid = std::sqrt(r2 < 0 ? 0.0 : r2); }
   if (tm && tm->set && tm->set->n >= 2) {
     double t[6];
     phase_times(*tm->set, t);
@@ -190,7 +192,7 @@ int prepare(blmm_ctx* ctx, const blmm_opts* o, const double* dY, int64_t n, int6
   const int c = (int)ncov + add_int;
   if (c < 1 || c > CMAX) return fail(ctx, BLMM_ERR_UNSUPPORTED, "number of null covariates (incl. intercept) must be 1..4");
   if (c >= n) return fail(ctx, BLMM_ERR_DIM, "Dimension mismatch.");
-  P.n = (int)n; P.c = c; P.npad = (int)round_up(n, 4); P.ldr = (int)round_up(P.npad, 16);
+  P.n = (int)n; P.c = c; P.npad = (int)round_up(n, 8); P.ldr = (int)round_up(P.npad, 16);   // K padded to 8: even K-step count
   P.m = m; P.p = p; P.ldy = round_up(m > 0 ? m : 1, 128); P.ldx = round_up(p > 0 ? p : 1, 128);
   int rc;
   if ((rc = ensure(ctx, ctx->Ks, sizeof(double) * n * n))) return rc;
@@ -308,6 +310,13 @@ int blmm_create(int device_id, void* hip_stream, blmm_ctx** out) {
     if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { delete ctx; return BLMM_ERR_HIP; }
     ctx->own_stream = true;
   }
+  if (hipStreamCreateWithFlags(&ctx->side, hipStreamNonBlocking) != hipSuccess ||
+      hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&ctx->ev_xt, hipEventDisableTiming) != hipSuccess) {
+    blmm_destroy(ctx);
+    return BLMM_ERR_HIP;
+  }
   if (ensure(ctx, ctx->logtab, sizeof(blmm_log_table_host)) != BLMM_OK ||
       hipMemcpy(ctx->logtab.p, blmm_log_table_host, sizeof(blmm_log_table_host), hipMemcpyHostToDevice) != hipSuccess) {
     blmm_destroy(ctx);
@@ -324,10 +333,15 @@ void blmm_destroy(blmm_ctx* ctx) {
   DevBuf* bufs[] = {&ctx->Ks, &ctx->V, &ctx->lam, &ctx->U, &ctx->Zs, &ctx->Z0, &ctx->Rp, &ctx->Yt, &ctx->Xt, &ctx->panels,
                     &ctx->iyy, &ctx->h2, &ctx->h2idx, &ctx->sig2, &ctx->ell, &ctx->isx, &ctx->stat, &ctx->gridd, &ctx->misc,
                     &ctx->EllTab, &ctx->inY, &ctx->inG, &ctx->inK, &ctx->inCov, &ctx->inW, &ctx->outL, &ctx->outH2,
-                    &ctx->tmpA, &ctx->tmpB, &ctx->tmpC, &ctx->perm, &ctx->r0, &ctx->altbuf, &ctx->logtab, &ctx->lraw};
+                    &ctx->tmpA, &ctx->tmpB, &ctx->tmpC, &ctx->perm, &ctx->r0, &ctx->altbuf, &ctx->logtab, &ctx->lraw,
+                    &ctx->wbQ, &ctx->wbW, &ctx->wbRk, &ctx->lrT, &ctx->lrC, &ctx->lrL};
   for (DevBuf* b : bufs) if (b->p) hipFree(b->p);
   for (auto& s : ctx->evsets) for (auto& e : s.e) (void)hipEventDestroy(e);
   if (ctx->rb_handle && ctx->rb_destroy) ctx->rb_destroy(ctx->rb_handle);
+  if (ctx->side) { (void)hipStreamSynchronize(ctx->side); (void)hipStreamDestroy(ctx->side); }
+  if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
+  if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
+  if (ctx->ev_xt) (void)hipEventDestroy(ctx->ev_xt);
   if (ctx->own_stream) hipStreamDestroy(ctx->stream);
   delete ctx;
 }
@@ -428,14 +442,51 @@ int blmm_bulkscan_dev(blmm_ctx* ctx, const blmm_opts* opts, const double* dY, in
   if (m == 0 || p == 0) { tm.mark(); tm.mark(); tm.mark(); return finish_status(ctx, status, &tm); }
 
   if (opts->method == BLMM_NULL_EXACT) {
-    if ((rc = launch_brent(ctx, nm, P.Yt, P.ldy, m, P.Z0, P.lam, dh2_out, nullptr, nullptr, P.stat))) return rc;
-    tm.mark();
-    if ((rc = ensure(ctx, ctx->panels, sizeof(double) * (size_t)(2 + P.c) * P.npad * ldp))) return rc;
-    if ((rc = launch_panels(ctx, nm, P.Yt, P.ldy, m, P.Z0, P.lam, dh2_out, 1, ptr<double>(ctx->panels), ldp, P.stat))) return rc;
-    tm.mark();
-    ScanArgs a = scan_args(ctx, P, ptr<double>(ctx->panels), ldp, dL_out, ldL, m);
-    if ((rc = launch_scan_exact(ctx, a, P.c))) return rc;
-    tm.mark();
+    static const char* exact_env = getenv("BLMM_EXACT");   // "full": the (2+c) full-length contractions (A/B testing)
+    const bool lowrank = !(exact_env && std::strcmp(exact_env, "full") == 0) && P.c <= 3;   // c = 4 would spill
+    if (lowrank) {
+      // low-rank weights form (kernels_lowrank.hip).  The basis of {w(delta)} needs only the eigenvalues and the
+      // marker-side products only (Q, Xt): both run on the side stream beside the per-trait Brent search.
+      const int64_t tstride = (int64_t)P.npad * P.ldx;
+      if ((rc = ensure(ctx, ctx->wbQ, sizeof(double) * (size_t)P.npad * n))) return rc;
+      if ((rc = ensure(ctx, ctx->wbW, sizeof(double) * (size_t)n * 256))) return rc;
+      if ((rc = ensure(ctx, ctx->wbRk, sizeof(int) * 4))) return rc;
+      if ((rc = ensure(ctx, ctx->lrT, sizeof(double) * (size_t)(1 + P.c) * tstride))) return rc;
+      if ((rc = ensure(ctx, ctx->lrC, sizeof(double) * (size_t)P.npad * ldp))) return rc;
+      if ((rc = ensure(ctx, ctx->lrL, sizeof(double) * (size_t)(P.c * (P.c + 1) / 2) * ldp))) return rc;
+      if ((rc = ensure(ctx, ctx->panels, sizeof(double) * (size_t)P.npad * ldp))) return rc;
+      int* rk = ptr<int>(ctx->wbRk);
+      hipStream_t main_stream = ctx->stream;
+      BLMM_HIP(hipEventRecord(ctx->ev_fork, main_stream));            // eigenvalues + rotated operands are ready
+      BLMM_HIP(hipStreamWaitEvent(ctx->side, ctx->ev_fork, 0));
+      ctx->stream = ctx->side;                                         // the launchers enqueue on ctx->stream
+      rc = launch_wbasis(ctx, P.lam, (int)n, ptr<double>(ctx->wbW), ptr<double>(ctx->wbQ), rk, P.stat);
+      if (!rc) rc = launch_lr_tpanels(ctx, P.Xt, P.ldx, p, (int)n, P.c, P.npad, P.Z0, ptr<double>(ctx->wbQ), rk, ptr<double>(ctx->lrT), tstride);
+      ctx->stream = main_stream;
+      if (rc) return rc;
+      BLMM_HIP(hipEventRecord(ctx->ev_join, ctx->side));
+      if ((rc = launch_brent(ctx, nm, P.Yt, P.ldy, m, P.Z0, P.lam, dh2_out, nullptr, nullptr, P.stat))) return rc;
+      tm.mark();
+      BLMM_HIP(hipStreamWaitEvent(main_stream, ctx->ev_join, 0));
+      if ((rc = launch_lr_panels(ctx, nm, P.Yt, P.ldy, m, P.Z0, P.lam, dh2_out, ptr<double>(ctx->wbQ), rk, ptr<double>(ctx->panels),
+                                 ptr<double>(ctx->lrC), ptr<double>(ctx->lrL), ldp, P.stat))) return rc;
+      tm.mark();
+      LrArgs la;
+      la.s = scan_args(ctx, P, ptr<double>(ctx->panels), ldp, dL_out, ldL, m);
+      la.Cp = ptr<double>(ctx->lrC); la.T = ptr<double>(ctx->lrT); la.tstride = tstride; la.Ls = ptr<double>(ctx->lrL);
+      la.rk = rk; la.c = P.c;
+      if ((rc = launch_scan_lr(ctx, la))) return rc;
+      tm.mark();
+    } else {
+      if ((rc = launch_brent(ctx, nm, P.Yt, P.ldy, m, P.Z0, P.lam, dh2_out, nullptr, nullptr, P.stat))) return rc;
+      tm.mark();
+      if ((rc = ensure(ctx, ctx->panels, sizeof(double) * (size_t)(2 + P.c) * P.npad * ldp))) return rc;
+      if ((rc = launch_panels(ctx, nm, P.Yt, P.ldy, m, P.Z0, P.lam, dh2_out, 1, ptr<double>(ctx->panels), ldp, P.stat))) return rc;
+      tm.mark();
+      ScanArgs a = scan_args(ctx, P, ptr<double>(ctx->panels), ldp, dL_out, ldL, m);
+      if ((rc = launch_scan_exact(ctx, a, P.c))) return rc;
+      tm.mark();
+    }
   } else if (opts->method == BLMM_NULL_GRID) {
     if ((rc = ensure(ctx, ctx->h2idx, sizeof(int) * (size_t)m))) return rc;
     if ((rc = launch_loglik_grid(ctx, nm, P.Yt, P.ldy, m, P.Z0, P.lam, dgrid, (int)ngrid, nullptr, ptr<int>(ctx->h2idx), dh2_out, P.stat))) return rc;
@@ -647,7 +698,7 @@ namespace {
 int upload_rotated(blmm_ctx* ctx, const double* Y0, int64_t n, int64_t m, const double* Z0, int64_t c, const double* X0m,
                    int64_t p, const double* lambda, Pipe& P) {
   if (n < 1 || m < 1 || c < 1 || c > CMAX || c >= n) return fail(ctx, BLMM_ERR_DIM, "Dimension mismatch.");
-  P.n = (int)n; P.c = (int)c; P.npad = (int)round_up(n, 4); P.ldr = (int)round_up(P.npad, 16);
+  P.n = (int)n; P.c = (int)c; P.npad = (int)round_up(n, 8); P.ldr = (int)round_up(P.npad, 16);
   P.m = m; P.p = p; P.ldy = round_up(m, 128); P.ldx = round_up(p > 0 ? p : 1, 128);
   int rc;
   if ((rc = ensure(ctx, ctx->inY, sizeof(double) * n * m))) return rc;

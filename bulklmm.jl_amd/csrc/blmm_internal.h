@@ -15,7 +15,7 @@ typedef double d4 __attribute__((ext_vector_type(4)));
 constexpr int CMAX = 4;          // null covariates (incl. intercept) the kernels are instantiated for
 constexpr int TILE_T = 64;       // traits per workgroup tile of the scan kernels
 constexpr int TILE_I = 128;      // markers per workgroup tile of the scan kernels
-constexpr int NSTAT = 8;         // device status counters
+constexpr int NSTAT = 12;        // device status counters ([6],[7]: eigensolver clocks, [8]: weight-basis rank, [9]: its residual)
 
 enum StatIdx { ST_NEG_EIG = 0, ST_NONPOS_W = 1, ST_ZERO_NORM = 2, ST_NAN_LOD = 3, ST_BRENT_MAXIT = 4, ST_JACOBI_SWEEPS = 5 };
 
@@ -36,7 +36,7 @@ struct blmm_ctx {
   std::string err;
   // grow-only workspace
   blmm::DevBuf Ks, V, lam, U, Zs, Z0, Rp, Yt, Xt, panels, iyy, h2, h2idx, sig2, ell, isx, stat, gridd, misc, EllTab,
-      inY, inG, inK, inCov, inW, outL, outH2, tmpA, tmpB, tmpC, perm, r0, altbuf, logtab, lraw;
+      inY, inG, inK, inCov, inW, outL, outH2, tmpA, tmpB, tmpC, perm, r0, altbuf, logtab, lraw, wbQ, wbW, wbRk, lrT, lrC, lrL;
   // event sets: one per timed call since the last blmm_read_timings (grown on demand, reused afterwards)
   struct EvSet { hipEvent_t e[8]; int n; };
   std::vector<EvSet> evsets;
@@ -46,6 +46,9 @@ struct blmm_ctx {
   int (*rb_destroy)(void*) = nullptr;
   int (*rb_set_stream)(void*, hipStream_t) = nullptr;
   int (*rs_dsyevd)(void*, int, int, int, double*, int, double*, double*, int*) = nullptr;
+  // side stream: work that only depends on the eigenvalues / rotated markers runs beside the per-trait Brent search
+  hipStream_t side = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_xt = nullptr;
 };
 
 namespace blmm {
@@ -123,6 +126,22 @@ struct ScanArgs {
   int64_t* stat;
 };
 int launch_scan_exact(blmm_ctx* ctx, const ScanArgs& a, int c);
+struct LrArgs {
+  ScanArgs s;                       // s.P = panel 0 only
+  const double* Cp;                 // weight-basis coefficients [4*KR][ldp]
+  const double* T; int64_t tstride; // marker-side basis products [1+c][4*KR][ldx]
+  const double* Ls;                 // packed L_j^-1 [c(c+1)/2][ldp]
+  const int* rk;                    // {R, KR} on the device
+  int c;
+};
+int launch_scan_lr(blmm_ctx* ctx, const LrArgs& la);
+// kernels_lowrank.hip
+int launch_wbasis(blmm_ctx* ctx, const double* lam, int n, double* Wk, double* Q, int* rk, int64_t* stat);
+int launch_lr_tpanels(blmm_ctx* ctx, const double* Xt, int64_t ldx, int64_t p, int n, int c, int npad, const double* Z0,
+                      const double* Q, const int* rk, double* T, int64_t tstride);
+int launch_lr_panels(blmm_ctx* ctx, const NullModel& nm, const double* Yt, int64_t ldy, int64_t m, const double* Z0,
+                     const double* lam, const double* h2, const double* Q, const int* rk, double* P0, double* Cp,
+                     double* Ls, int64_t ldp, int64_t* stat);
 int launch_scan_table(blmm_ctx* ctx, const ScanArgs& a);
 struct AltArgs {
   ScanArgs s; int ngrid; const double* EllTab; /* ngrid x m */ const double* grid_dev; double* H2; int64_t ldH; int counter_quirk;

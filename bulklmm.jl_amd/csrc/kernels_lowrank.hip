@@ -1,0 +1,374 @@
+// kernels_lowrank.hip -- low-rank form of the per-trait weights for the exact (null-exact) LOD kernel.
+//
+// Per-trait weights enter the marker-side sums only through  w_j = 1 ./ (delta_j*lambda + 1):
+//     Sxx[i,j] = sum_k x_ik^2 w_jk ,      s_q[i,j] = sum_k x_ik z_qk w_jk          
+// and the one-parameter family { w(delta) : delta >= 0 } has a numerical rank R far below n (BXD kinship spectrum:
+// 23 at 1e-15 of 79; tools/ and DESIGN.md §4.3).  With an orthonormal basis Q (n x R) of that family,
+// w_j = Q c_j (c_j = Q'w_j) to rounding, hence
+//     Sxx = (Q'(X.^2))' C ,   s_q = (Q'(X.*z_q))' C            -- contractions of length R instead of n.
+// Only  num = x' a0  (a0 depends on the trait's y) keeps length n: 2n + 2(1+c)R flops per test instead of 2n(2+c).
+// R is found on the device by a greedy pivoted Gram-Schmidt over 256 sampled deltas (stops at a 1e-15 relative
+// residual, or at R = n where the form is exact by construction), so one code path serves every kinship; the
+// per-trait approximation residual is reported in blmm_status.lowrank_resid.
+#include "blmm_internal.h"
+#include "fastmath.h"
+#include <cmath>
+
+namespace blmm {
+
+#define KCHECK()                                                                                      \
+  do {                                                                                                \
+    hipError_t e__ = hipGetLastError();                                                               \
+    if (e__ != hipSuccess) return fail(ctx, BLMM_ERR_HIP, std::string("kernel launch: ") + hipGetErrorString(e__)); \
+  } while (0)
+
+constexpr int WB_NS = 256;  // sampled deltas (one per thread) when the sample columns live in global memory
+constexpr int WB_QCAP = 48; // basis vectors mirrored in LDS for the re-orthogonalisation (further ones: global)
+
+__device__ __forceinline__ double wave_sum(double x) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o, 64);
+  return x;
+}
+
+// Greedy pivoted Gram-Schmidt over NS = blockDim.x sampled deltas.  Q: r-major, Q[r*n + k]; rk[0] = R, rk[1] = KR.
+// WLDS: the n x NS sample columns (k-major) live in LDS (n*NS*8 bytes), else in the global workspace Wg.
+template <bool WLDS>
+__global__ void __launch_bounds__(WB_NS) k_wbasis(const double* __restrict__ lam, int n, double* __restrict__ Wg,
+                                                  double* __restrict__ Q, int* __restrict__ rk, int64_t* stat) {
+  extern __shared__ __attribute__((aligned(16))) double sh[];
+  const int NS = blockDim.x;
+  double* sq = sh;              // n : the pivot column / new basis vector
+  double* sd = sh + n;          // n : re-orthogonalisation coefficients
+  double* Ql = sh + 2 * n;      // WB_QCAP x n : LDS mirror of the first basis vectors
+  double* Wl = Ql + WB_QCAP * n; // n x NS (WLDS only)
+  __shared__ double s_red[WB_NS];
+  __shared__ int s_arg[WB_NS];
+  __shared__ int s_neg;
+  const int s = threadIdx.x, lane = s & 63, wave = s >> 6, nwave = NS >> 6;
+  // a kinship with negative eigenvalues leaves the smooth family (poles at delta = -1/lambda): use the identity basis,
+  // for which the low-rank form is the full-rank form
+  if (s == 0) s_neg = 0;
+  __syncthreads();
+  for (int k = s; k < n; k += NS) if (lam[k] < -1e-12) s_neg = 1;
+  __syncthreads();
+  if (s_neg) {
+    for (int e = s; e < n * n; e += NS) Q[e] = ((e / n) == (e % n)) ? 1.0 : 0.0;
+    if (s == 0) { rk[0] = n; rk[1] = (n + 3) / 4; stat[8] = n; }
+    return;
+  }
+#define WK(k) (WLDS ? Wl[(k) * NS + s] : Wg[(size_t)(k) * NS + s])
+  // delta_0 = 0 (w = 1), then log-spaced over [1e-6, 1e9]: h2 from 1e-6 to 1 - 1e-9
+  const double delta = (s == 0) ? 0.0 : exp(2.302585092994046 * (-6.0 + 15.0 * (double)(s - 1) / (double)(NS - 2)));
+  double nrm = 0.0;
+  for (int k = 0; k < n; ++k) { const double w = 1.0 / fma(delta, fabs(lam[k]), 1.0); WK(k) = w; nrm = fma(w, w, nrm); }
+  const double inv = 1.0 / sqrt(nrm);
+  for (int k = 0; k < n; ++k) WK(k) *= inv;
+  double res2 = 1.0;
+  // stop at a ~4e-15 relative residual (squared; scaled with n: the rounding floor of the deflated columns grows with it)
+  const double tol2 = 2e-31 * (double)n;
+  int R = 0;
+  for (; R < n; ++R) {
+    // arg-max of the residual norms (first maximum wins)
+    s_red[s] = res2; s_arg[s] = s;
+    __syncthreads();
+    for (int o = NS / 2; o > 0; o >>= 1) {
+      if (s < o && (s_red[s + o] > s_red[s] || (s_red[s + o] == s_red[s] && s_arg[s + o] < s_arg[s]))) { s_red[s] = s_red[s + o]; s_arg[s] = s_arg[s + o]; }
+      __syncthreads();
+    }
+    const double mx = s_red[0];
+    const int piv = s_arg[0];
+    __syncthreads();
+    if (!(mx > tol2)) break;
+    for (int k = s; k < n; k += NS) sq[k] = WLDS ? Wl[k * NS + piv] : Wg[(size_t)k * NS + piv];
+    __syncthreads();
+    for (int pass = 0; pass < 2; ++pass) {   // classical Gram-Schmidt twice: Q stays orthonormal to rounding even for
+                                              // the last, noise-dominated pivots
+      for (int t = s; t < R; t += NS) {        // one lane per existing basis vector (LDS copy; the rest: global)
+        const double* qt = (t < WB_QCAP) ? Ql + t * n : Q + (size_t)t * n;
+        double d0 = 0.0, d1 = 0.0;
+        int k = 0;
+        for (; k + 1 < n; k += 2) { d0 = fma(qt[k], sq[k], d0); d1 = fma(qt[k + 1], sq[k + 1], d1); }
+        if (k < n) d0 = fma(qt[k], sq[k], d0);
+        sd[t] = d0 + d1;
+      }
+      __syncthreads();
+      for (int k = s; k < n; k += NS) {
+        double v = sq[k];
+        const int rl = R < WB_QCAP ? R : WB_QCAP;
+        for (int t = 0; t < rl; ++t) v = fma(-sd[t], Ql[t * n + k], v);
+        for (int t = rl; t < R; ++t) v = fma(-sd[t], Q[(size_t)t * n + k], v);
+        sq[k] = v;
+      }
+      __syncthreads();
+    }
+    double part = 0.0;
+    for (int k = s; k < n; k += NS) part = fma(sq[k], sq[k], part);
+    part = wave_sum(part);
+    if (lane == 0) s_red[wave] = part;
+    __syncthreads();
+    double tot = 0.0;
+    for (int w = 0; w < nwave; ++w) tot += s_red[w];
+    const double qn = 1.0 / sqrt(tot);
+    __syncthreads();
+    // a pivot that loses > 99.99 % of its norm in the re-orthogonalisation was rounding noise: the family is exhausted
+    if (!(tot > 1e-8 * mx)) break;
+    for (int k = s; k < n; k += NS) { const double v = sq[k] * qn; sq[k] = v; Q[(size_t)R * n + k] = v; if (R < WB_QCAP) Ql[R * n + k] = v; }
+    __syncthreads();
+    // deflate every sample column
+    double c = 0.0;
+    for (int k = 0; k < n; ++k) c = fma(sq[k], WK(k), c);
+    double r2 = 0.0;
+    for (int k = 0; k < n; ++k) { const double v = fma(-c, sq[k], WK(k)); WK(k) = v; r2 = fma(v, v, r2); }
+    res2 = r2;
+    __syncthreads();
+  }
+#undef WK
+  if (s == 0) { rk[0] = R; rk[1] = (R + 3) / 4; stat[8] = R; }
+}
+
+int launch_wbasis(blmm_ctx* ctx, const double* lam, int n, double* Wk, double* Q, int* rk, int64_t* stat) {
+  // sample columns in LDS when at least 128 of them fit beside the two work vectors
+  const size_t fixed = sizeof(double) * ((size_t)2 * n + (size_t)WB_QCAP * n);
+  int ns = fixed < 150 * 1024 ? (int)((150 * 1024 - fixed) / (8 * (size_t)n)) : 0;
+  ns = ns >= 256 ? 256 : (ns / 64) * 64;
+  if (ns >= 128) {
+    const size_t lds = fixed + sizeof(double) * (size_t)n * ns;
+    BLMM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wbasis<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(k_wbasis<true>, dim3(1), dim3(ns), lds, ctx->stream, lam, n, Wk, Q, rk, stat);
+  } else {
+    if (fixed > 150 * 1024) return fail(ctx, BLMM_ERR_UNSUPPORTED, "n too large for the weight-basis kernel");
+    BLMM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wbasis<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)fixed));
+    hipLaunchKernelGGL(k_wbasis<false>, dim3(1), dim3(WB_NS), fixed, ctx->stream, lam, n, Wk, Q, rk, stat);
+  }
+  KCHECK();
+  return BLMM_OK;
+}
+
+// T[q][r][i]: q = 0: sum_k Q[r][k] x_ik^2 ; q = 1..c: sum_k Q[r][k] x_ik z_(q-1)k.   Rows r >= R (up to 4*KR) are zero.
+// grid = (ldx/256, ceil(4*KRmax/16)); the kernel reads R from rk and returns early for chunks beyond it.
+template <int C>
+__global__ void __launch_bounds__(256) k_lr_tpanels(const double* __restrict__ Xt, int64_t ldx, int64_t p, int n,
+                                                    const double* __restrict__ Z0, const double* __restrict__ Q,
+                                                    const int* __restrict__ rk, double* __restrict__ T, int64_t tstride) {
+  const int R = rk[0], R4 = rk[1] * 4;
+  const int r0 = blockIdx.y * 16;
+  if (r0 >= R4) return;
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= ldx) return;
+  double acc[1 + C][16];
+#pragma unroll
+  for (int q = 0; q <= C; ++q)
+#pragma unroll
+    for (int t = 0; t < 16; ++t) acc[q][t] = 0.0;
+  if (i < p) {
+    for (int k = 0; k < n; ++k) {
+      const double x = Xt[(int64_t)k * ldx + i];
+      double xv[1 + C];
+      xv[0] = x * x;
+#pragma unroll
+      for (int q = 0; q < C; ++q) xv[1 + q] = x * Z0[q * n + k];
+#pragma unroll
+      for (int t = 0; t < 16; ++t) {
+        const double qv = (r0 + t < R) ? Q[(size_t)(r0 + t) * n + k] : 0.0;   // wave-uniform
+#pragma unroll
+        for (int q = 0; q <= C; ++q) acc[q][t] = fma(qv, xv[q], acc[q][t]);
+      }
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < 16; ++t)
+    if (r0 + t < R4)
+#pragma unroll
+      for (int q = 0; q <= C; ++q) T[q * tstride + (int64_t)(r0 + t) * ldx + i] = acc[q][t];
+}
+
+int launch_lr_tpanels(blmm_ctx* ctx, const double* Xt, int64_t ldx, int64_t p, int n, int c, int npad, const double* Z0,
+                      const double* Q, const int* rk, double* T, int64_t tstride) {
+  dim3 grid((unsigned)((ldx + 255) / 256), (unsigned)((npad + 15) / 16));
+#define TP(C) hipLaunchKernelGGL(k_lr_tpanels<C>, grid, dim3(256), 0, ctx->stream, Xt, ldx, p, n, Z0, Q, rk, T, tstride)
+  switch (c) {
+    case 1: TP(1); break;
+    case 2: TP(2); break;
+    case 3: TP(3); break;
+    case 4: TP(4); break;
+    default: return fail(ctx, BLMM_ERR_UNSUPPORTED, "number of null covariates (incl. intercept) must be 1..4");
+  }
+#undef TP
+  KCHECK();
+  return BLMM_OK;
+}
+
+// Per trait (one thread each), from h2_j:  panel0[k][j] = w_k (y - Z0 beta_w)_k / sqrt(yy)   (as k_panels),
+// Cp[r][j] = (Q' w_j)_r for r < R (zero up to 4*KR),  Ls[e][j] = packed lower-triangular L_j^-1 (A_j = Z0'W_jZ0 = L L').
+template <int C>
+__global__ void __launch_bounds__(64) k_lr_panels(NullModel nm, const double* __restrict__ Yt, int64_t ldy, int64_t m,
+                                                   const double* __restrict__ Z0, const double* __restrict__ lam,
+                                                   const double* __restrict__ h2v, const double* __restrict__ Q,
+                                                   const int* __restrict__ rk, int qcap, double* __restrict__ P0,
+                                                   double* __restrict__ Cp, double* __restrict__ Ls, int64_t ldp,
+                                                   int64_t* stat) {
+  extern __shared__ __attribute__((aligned(16))) double sh[];
+  const int n = nm.n, npad = nm.npad;
+  double* sLam = sh;
+  double* sZ = sh + n;
+  double* sQ = sZ + n * C;                     // min(R, qcap) x n : basis rows (the rest is read from global memory)
+  const int R = rk[0], R4 = rk[1] * 4;
+  const int rl = R < qcap ? R : qcap;
+  for (int e = threadIdx.x; e < n; e += blockDim.x) sLam[e] = lam[e];
+  for (int e = threadIdx.x; e < n * C; e += blockDim.x) sZ[e] = Z0[e];
+  for (int e = threadIdx.x; e < rl * n; e += blockDim.x) sQ[e] = Q[e];
+  __syncthreads();
+  const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= ldp) return;
+  constexpr int NA = C * (C + 1) / 2;
+  if (j >= m) {  // padding columns
+    for (int k = 0; k < npad; ++k) P0[(int64_t)k * ldp + j] = 0.0;
+    for (int r = 0; r < R4; ++r) Cp[(int64_t)r * ldp + j] = 0.0;
+    for (int e = 0; e < NA; ++e) Ls[(int64_t)e * ldp + j] = 0.0;
+    return;
+  }
+  const double h2 = h2v[j];
+  const double delta = h2 / (1.0 - h2);
+  double A[NA], v[C], syy = 0.0, ww = 0.0;
+#pragma unroll
+  for (int a = 0; a < NA; ++a) A[a] = 0.0;
+#pragma unroll
+  for (int q = 0; q < C; ++q) v[q] = 0.0;
+  for (int k = 0; k < n; ++k) {
+    const double w = fabs(1.0 / fma(delta, sLam[k], 1.0));  // sqrt.(abs.(makeweights)) squared, src/bulkscan_helpers.jl:138
+    ww = fma(w, w, ww);
+    const double y = Yt[(int64_t)k * ldy + j];
+    const double wy = w * y;
+    syy = fma(wy, y, syy);
+#pragma unroll
+    for (int q = 0; q < C; ++q) {
+      const double zq = sZ[q * n + k];
+      v[q] = fma(wy, zq, v[q]);
+      const double wz = w * zq;
+#pragma unroll
+      for (int r = 0; r <= q; ++r) A[q * (q + 1) / 2 + r] = fma(wz, sZ[r * n + k], A[q * (q + 1) / 2 + r]);
+    }
+  }
+  double L[NA], Li[NA], t[C], beta[C], tt = 0.0;
+#pragma unroll
+  for (int q = 0; q < C; ++q) {
+#pragma unroll
+    for (int r = 0; r <= q; ++r) {
+      double s = A[q * (q + 1) / 2 + r];
+#pragma unroll
+      for (int u = 0; u < r; ++u) s = fma(-L[q * (q + 1) / 2 + u], L[r * (r + 1) / 2 + u], s);
+      L[q * (q + 1) / 2 + r] = (r == q) ? sqrt(s) : s / L[r * (r + 1) / 2 + r];
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < C; ++q) {
+#pragma unroll
+    for (int r = 0; r <= q; ++r) {
+      double s = (r == q) ? 1.0 : 0.0;
+#pragma unroll
+      for (int u = r; u < q; ++u) s = fma(-L[q * (q + 1) / 2 + u], Li[u * (u + 1) / 2 + r], s);
+      Li[q * (q + 1) / 2 + r] = s / L[q * (q + 1) / 2 + q];
+    }
+    double s = 0.0;
+#pragma unroll
+    for (int r = 0; r <= q; ++r) s = fma(Li[q * (q + 1) / 2 + r], v[r], s);
+    t[q] = s;
+    tt = fma(s, s, tt);
+  }
+#pragma unroll
+  for (int q = 0; q < C; ++q) {
+    double s = 0.0;
+#pragma unroll
+    for (int u = q; u < C; ++u) s = fma(Li[u * (u + 1) / 2 + q], t[u], s);
+    beta[q] = s;
+  }
+  const double yy = syy - tt;
+  if (!(sqrt(fabs(yy)) > 2.220446049250313e-16)) atomicAdd((unsigned long long*)&stat[ST_ZERO_NORM], 1ull);
+  const double isy = 1.0 / sqrt(yy);
+  for (int k = 0; k < npad; ++k) {
+    double p0 = 0.0;
+    if (k < n) {
+      const double w = fabs(1.0 / fma(delta, sLam[k], 1.0));
+      double res = Yt[(int64_t)k * ldy + j];
+#pragma unroll
+      for (int q = 0; q < C; ++q) res = fma(-beta[q], sZ[q * n + k], res);
+      p0 = w * res * isy;
+    }
+    P0[(int64_t)k * ldp + j] = p0;
+  }
+#pragma unroll
+  for (int e = 0; e < NA; ++e) Ls[(int64_t)e * ldp + j] = Li[e];
+  // coefficients in the weight basis, 8 at a time (the weights are recomputed per chunk: rcp + 2 Newton steps).
+  // Rows below `rl` come from the LDS copy of Q; the (rare) rest from global memory in a separate loop so that the
+  // fast loop carries no global load at all.
+  const int rl8 = (rl / 8) * 8;
+  for (int rb = 0; rb < rl8; rb += 8) {
+    double c8[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) c8[u] = 0.0;
+    for (int k = 0; k < n; ++k) {
+      const double w = fabs(fast_rcp(fma(delta, sLam[k], 1.0)));
+#pragma unroll
+      for (int u = 0; u < 8; ++u) c8[u] = fma(sQ[(rb + u) * n + k], w, c8[u]);
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) Cp[(int64_t)(rb + u) * ldp + j] = c8[u];
+  }
+  for (int r = rl8; r < R4; ++r) {
+    double c = 0.0;
+    if (r < R) {
+      const double* qr = (r < rl) ? sQ + r * n : Q + (size_t)r * n;
+      for (int k = 0; k < n; ++k) c = fma(qr[k], fabs(fast_rcp(fma(delta, sLam[k], 1.0))), c);
+    }
+    Cp[(int64_t)r * ldp + j] = c;
+  }
+}
+
+// Diagnostic: relative residual |w_j - Q c_j| / |w_j| of the weight-basis expansion, evaluated directly (one wave per
+// sampled trait, every `stride`-th) and max-reduced into stat[9] (as the bits of the squared value).
+__global__ void __launch_bounds__(64) k_lr_resid(int n, int64_t m, int64_t stride, const double* __restrict__ lam,
+                                                 const double* __restrict__ h2v, const double* __restrict__ Q,
+                                                 const int* __restrict__ rk, const double* __restrict__ Cp, int64_t ldp,
+                                                 int64_t* stat) {
+  const int64_t j = (int64_t)blockIdx.x * stride;
+  if (j >= m) return;
+  const int R = rk[0], lane = threadIdx.x;
+  const double h2 = h2v[j];
+  const double delta = h2 / (1.0 - h2);
+  double rr = 0.0, ww = 0.0;
+  for (int k = lane; k < n; k += 64) {
+    const double w = fabs(1.0 / fma(delta, lam[k], 1.0));
+    double v = w;
+    for (int r = 0; r < R; ++r) v = fma(-Q[(size_t)r * n + k], Cp[(int64_t)r * ldp + j], v);
+    rr = fma(v, v, rr); ww = fma(w, w, ww);
+  }
+  rr = wave_sum(rr); ww = wave_sum(ww);
+  if (lane == 0) atomicMax((unsigned long long*)&stat[9], (unsigned long long)__double_as_longlong(rr / ww));
+}
+
+int launch_lr_panels(blmm_ctx* ctx, const NullModel& nm, const double* Yt, int64_t ldy, int64_t m, const double* Z0,
+                     const double* lam, const double* h2, const double* Q, const int* rk, double* P0, double* Cp,
+                     double* Ls, int64_t ldp, int64_t* stat) {
+  // 64 threads per block (more blocks than CUs even at m ~ 35k); basis rows in LDS up to 56 KB
+  const unsigned blocks = (unsigned)((ldp + 63) / 64);
+  const int qcap = (int)std::min<size_t>((size_t)nm.n, (56 * 1024) / (sizeof(double) * (size_t)nm.n));
+  const size_t lds = sizeof(double) * ((size_t)nm.n * (1 + nm.c) + (size_t)qcap * nm.n);
+#define LP(C) hipLaunchKernelGGL(k_lr_panels<C>, dim3(blocks), dim3(64), lds, ctx->stream, nm, Yt, ldy, m, Z0, lam, h2, Q, rk, qcap, P0, Cp, Ls, ldp, stat)
+  switch (nm.c) {
+    case 1: LP(1); break;
+    case 2: LP(2); break;
+    case 3: LP(3); break;
+    case 4: LP(4); break;
+    default: return fail(ctx, BLMM_ERR_UNSUPPORTED, "number of null covariates (incl. intercept) must be 1..4");
+  }
+#undef LP
+  KCHECK();
+  const int64_t stride = 61;
+  hipLaunchKernelGGL(k_lr_resid, dim3((unsigned)((m + stride - 1) / stride)), dim3(64), 0, ctx->stream, nm.n, m, stride, lam, h2, Q, rk,
+                     Cp, ldp, stat);
+  KCHECK();
+  return BLMM_OK;
+}
+
+}  // namespace blmm

@@ -104,8 +104,8 @@ __device__ __forceinline__ void tile_of(int64_t id, int64_t ntile_t, int ntile_i
   tile_t = t_first + (rem - (int64_t)tile_i * gt);
 }
 
-template <int NX, int MB, int NB, bool TABLE>
-__global__ void __launch_bounds__(256, 2) k_scan(ScanArgs a, int ntile_i, int64_t nwg) {
+template <int NX, int MB, int NB, bool TABLE, int W2>
+__global__ void __launch_bounds__(64 * W2 * W2, 2) k_scan(ScanArgs a, int ntile_i, int64_t nwg) {
   constexpr int NP = 1 + NX;  // A-side panels consumed
   __shared__ dpair s_log[BLMM_LOG_TABLE_N];
   stage_lod_table(s_log, a.logtab, -0.5 * (double)a.n);  // read after the K loop; the barrier sits right before the epilogue
@@ -113,8 +113,9 @@ __global__ void __launch_bounds__(256, 2) k_scan(ScanArgs a, int ntile_i, int64_
   const int64_t bid = xcd_swizzle(blockIdx.x, nwg);
   int64_t tile_t; int tile_i;
   tile_of(bid, nwg / ntile_i, ntile_i, tile_t, tile_i);
-  const int64_t t0 = tile_t * (32 * MB) + (wave >> 1) * (16 * MB);
-  const int64_t i0 = (int64_t)tile_i * (32 * NB) + (wave & 1) * (16 * NB);
+  const int wt = (W2 == 2) ? (wave >> 1) : 0, wi = (W2 == 2) ? (wave & 1) : 0;
+  const int64_t t0 = tile_t * (16 * W2 * MB) + wt * (16 * MB);
+  const int64_t i0 = (int64_t)tile_i * (16 * W2 * NB) + wi * (16 * NB);
   const int r = lane & 15, kk = lane >> 4;
 
   d4 acc[NP][MB][NB];
@@ -126,10 +127,10 @@ __global__ void __launch_bounds__(256, 2) k_scan(ScanArgs a, int ntile_i, int64_
       for (int nb = 0; nb < NB; ++nb) acc[q][mb][nb] = (d4){0, 0, 0, 0};
 
   // uniform tile bases (blockIdx-derived) for the descriptors; per-lane byte offsets (wave, lane) in voffset
-  const double* PA = a.P + tile_t * (32 * MB);
-  const double* PB = a.Xt + (int64_t)tile_i * (32 * NB);
-  const uint32_t voffA = (uint32_t)(((int64_t)kk * a.ldp + (wave >> 1) * (16 * MB) + MB * r) * 8);
-  const uint32_t voffB = (uint32_t)(((int64_t)kk * a.ldx + (wave & 1) * (16 * NB) + NB * r) * 8);
+  const double* PA = a.P + tile_t * (16 * W2 * MB);
+  const double* PB = a.Xt + (int64_t)tile_i * (16 * W2 * NB);
+  const uint32_t voffA = (uint32_t)(((int64_t)kk * a.ldp + wt * (16 * MB) + MB * r) * 8);
+  const uint32_t voffB = (uint32_t)(((int64_t)kk * a.ldx + wi * (16 * NB) + NB * r) * 8);
   const int64_t sa = 4 * a.ldp, sb = 4 * a.ldx;
 
   // K loop, two fragment sets: the loads of step ks+1 are issued before the MFMAs of step ks and are only waited
@@ -231,16 +232,16 @@ __global__ void __launch_bounds__(256, 2) k_scan(ScanArgs a, int ntile_i, int64_
   if (nnan) atomicAdd((unsigned long long*)&a.stat[ST_NAN_LOD], (unsigned long long)nnan);
 }
 
-template <int NX, bool TABLE, int MB>
+template <int NX, bool TABLE, int MB, int W2 = 2>
 static int launch_scan_t(blmm_ctx* ctx, const ScanArgs& a) {
   constexpr int NB = 4;
-  static_assert(32 * MB <= 128 && 32 * NB == TILE_I, "tile constants (operands are padded to 128)");
-  const int64_t ntile_t = (a.m + 32 * MB - 1) / (32 * MB);
-  const int64_t ntile_i = (a.p + TILE_I - 1) / TILE_I;
+  static_assert(16 * W2 * MB <= 128 && 16 * W2 * NB <= TILE_I, "tile constants (operands are padded to 128)");
+  const int64_t ntile_t = (a.m + 16 * W2 * MB - 1) / (16 * W2 * MB);
+  const int64_t ntile_i = (a.p + 16 * W2 * NB - 1) / (16 * W2 * NB);
   const int64_t nwg = ntile_t * ntile_i;
   if (nwg <= 0) return BLMM_OK;
   if (nwg > 0x7fffffffLL) return fail(ctx, BLMM_ERR_INVALID, "problem too large for one launch");
-  hipLaunchKernelGGL((k_scan<NX, MB, NB, TABLE>), dim3((unsigned)nwg), dim3(256), 0, ctx->stream, a, (int)ntile_i, nwg);
+  hipLaunchKernelGGL((k_scan<NX, MB, NB, TABLE, W2>), dim3((unsigned)nwg), dim3(64 * W2 * W2), 0, ctx->stream, a, (int)ntile_i, nwg);
   KCHECK();
   return BLMM_OK;
 }
@@ -248,10 +249,190 @@ static int launch_scan_t(blmm_ctx* ctx, const ScanArgs& a) {
 int launch_scan_exact(blmm_ctx* ctx, const ScanArgs& a, int c) {
   switch (c) {
     // accumulators per lane: (2 + c) * MB * 4 blocks * 8 VGPRs; MB = 1 beyond c = 1 keeps 2 waves/SIMD spill-free
-    case 1: return launch_scan_t<2, false, 2>(ctx, a);
+    case 1: {
+      static const int w1 = getenv("BLMM_SCAN_W1") ? atoi(getenv("BLMM_SCAN_W1")) : 0;
+      return w1 ? launch_scan_t<2, false, 2, 1>(ctx, a) : launch_scan_t<2, false, 2, 2>(ctx, a);
+    }
     case 2: return launch_scan_t<3, false, 1>(ctx, a);
     case 3: return launch_scan_t<4, false, 1>(ctx, a);
     case 4: return launch_scan_t<5, false, 1>(ctx, a);
+  }
+  return fail(ctx, BLMM_ERR_UNSUPPORTED, "number of null covariates (incl. intercept) must be 1..4");
+}
+
+// ------------------------------------------------------------------------------------------------
+// exact kernel, low-rank weights form (kernels_lowrank.hip):
+//   phase 1 (n long):   num  = x_i' a0_j                         A = P0 panel,  B = Xt
+//   phase 2 (R long):   Sxx  = (Q'x_i.^2)' c_j ,  s_q = (Q'(x_i.*z_q))' c_j      A = Cp panel,  B = T[0], T[1+q]
+//   epilogue:           u = L_j^-1 s ;  r^2 = num^2 / (Sxx - |u|^2) ;  LOD
+// Same tiling, fragment maps and store path as k_scan.  KR = ceil(R/4) is read from device memory (rk[1]).
+// ------------------------------------------------------------------------------------------------
+template <int C, int MB, int NB>
+__global__ void __launch_bounds__(256, 2) k_scan_lr(LrArgs la, int ntile_i, int64_t nwg) {
+  const ScanArgs& a = la.s;
+  constexpr int NACC = 2 + C;
+  __shared__ dpair s_log[BLMM_LOG_TABLE_N];
+  stage_lod_table(s_log, a.logtab, -0.5 * (double)a.n);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t bid = xcd_swizzle(blockIdx.x, nwg);
+  int64_t tile_t; int tile_i;
+  tile_of(bid, nwg / ntile_i, ntile_i, tile_t, tile_i);
+  const int wt = wave >> 1, wi = wave & 1;
+  const int64_t t0 = tile_t * (32 * MB) + wt * (16 * MB);
+  const int64_t i0 = (int64_t)tile_i * (32 * NB) + wi * (16 * NB);
+  const int r = lane & 15, kk = lane >> 4;
+
+  d4 acc[NACC][MB][NB];
+#pragma unroll
+  for (int q = 0; q < NACC; ++q)
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) acc[q][mb][nb] = (d4){0, 0, 0, 0};
+
+  const double* PA = a.P + tile_t * (32 * MB);
+  const double* PB = a.Xt + (int64_t)tile_i * (32 * NB);
+  const double* PC = la.Cp + tile_t * (32 * MB);
+  const double* PT = la.T + (int64_t)tile_i * (32 * NB);
+  const uint32_t voffA = (uint32_t)(((int64_t)kk * a.ldp + wt * (16 * MB) + MB * r) * 8);
+  const uint32_t voffB = (uint32_t)(((int64_t)kk * a.ldx + wi * (16 * NB) + NB * r) * 8);
+  const int64_t sa = 4 * a.ldp, sb = 4 * a.ldx;
+
+  // ---- phase 1: num, two K steps per fragment set (a.ks is even: the K dimension is padded to 8) -----------
+  {
+    auto load1 = [&](double (&A)[2][MB], double (&B)[2][NB], int step2) {
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        bufload<MB>(A[h], make_srd(PA + (int64_t)(2 * step2 + h) * sa), voffA);
+        bufload<NB>(B[h], make_srd(PB + (int64_t)(2 * step2 + h) * sb), voffB);
+      }
+    };
+    auto mfma1 = [&](const double (&A)[2][MB], const double (&B)[2][NB]) {
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+          for (int nb = 0; nb < NB; ++nb)
+            acc[0][mb][nb] = __builtin_amdgcn_mfma_f64_16x16x4f64(A[h][mb], B[h][nb], acc[0][mb][nb], 0, 0, 0);
+    };
+    const int K2 = a.ks / 2;
+    double a0[2][MB], b0[2][NB], a1[2][MB], b1[2][NB];
+    load1(a0, b0, 0);
+    int s2 = 0;
+    for (; s2 + 2 <= K2; s2 += 2) {
+      load1(a1, b1, s2 + 1);
+      __builtin_amdgcn_sched_barrier(0);
+      mfma1(a0, b0);
+      __builtin_amdgcn_sched_barrier(0);
+      load1(a0, b0, (s2 + 2 < K2) ? s2 + 2 : s2);
+      __builtin_amdgcn_sched_barrier(0);
+      mfma1(a1, b1);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (s2 < K2) mfma1(a0, b0);
+  }
+  // ---- phase 2: Sxx and s_q over the weight basis ------------------------------------------------------
+  {
+    const int KR = la.rk[1];
+    auto load2 = [&](double (&A)[MB], double (&B)[1 + C][NB], int step) {
+      bufload<MB>(A, make_srd(PC + (int64_t)step * sa), voffA);
+#pragma unroll
+      for (int q = 0; q <= C; ++q) bufload<NB>(B[q], make_srd(PT + q * la.tstride + (int64_t)step * sb), voffB);
+    };
+    auto mfma2 = [&](const double (&A)[MB], const double (&B)[1 + C][NB]) {
+#pragma unroll
+      for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+          for (int q = 0; q <= C; ++q)
+            acc[1 + q][mb][nb] = __builtin_amdgcn_mfma_f64_16x16x4f64(A[mb], B[q][nb], acc[1 + q][mb][nb], 0, 0, 0);
+    };
+    double a0[MB], b0[1 + C][NB], a1[MB], b1[1 + C][NB];
+    load2(a0, b0, 0);
+    int ks = 0;
+    for (; ks + 2 <= KR; ks += 2) {
+      load2(a1, b1, ks + 1);
+      __builtin_amdgcn_sched_barrier(0);
+      mfma2(a0, b0);
+      __builtin_amdgcn_sched_barrier(0);
+      load2(a0, b0, (ks + 2 < KR) ? ks + 2 : ks);
+      __builtin_amdgcn_sched_barrier(0);
+      mfma2(a1, b1);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (ks < KR) mfma2(a0, b0);
+  }
+
+  // ---- epilogue ---------------------------------------------------------------------------------------------
+  __syncthreads();
+  const LodPoly lp = make_lod_poly(-0.5 * (double)a.n);
+  const int64_t ibase = i0 + NB * r;
+  int nnan = 0;
+  constexpr int NL = C * (C + 1) / 2;
+#pragma unroll
+  for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) {
+      const int64_t trait = t0 + MB * (kk + 4 * reg) + mb;
+      if (trait >= a.m) continue;
+      double li[NL];
+#pragma unroll
+      for (int e = 0; e < NL; ++e) li[e] = la.Ls[(int64_t)e * a.ldp + trait];
+      double out[NB];
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) {
+        const double num = acc[0][mb][nb][reg];
+        double xx = acc[1][mb][nb][reg];
+#pragma unroll
+        for (int q = 0; q < C; ++q) {
+          double u = 0.0;
+#pragma unroll
+          for (int e = 0; e <= q; ++e) u = fma(li[q * (q + 1) / 2 + e], acc[2 + e][mb][nb][reg], u);
+          xx = fma(-u, u, xx);
+        }
+        const double r2 = (num * num) * fast_rcp(xx);
+        const double u1 = 1.0 - r2;  // r2lod (src/bulkscan_helpers.jl:22-24): -(n/2) * log10(1.0 - r^2)
+        double lod = fast_lod(u1, s_log, lp);
+        if (__builtin_expect(!(u1 > 0.0), 0)) {
+          lod = (u1 == 0.0) ? INFINITY : NAN;
+          nnan += (u1 != 0.0) && (ibase + nb < a.p);
+        }
+        out[nb] = lod;
+      }
+      double* dst = a.L + trait * a.ldL + ibase;
+      if (ibase + NB <= a.p) {
+        __builtin_nontemporal_store((d2u){out[0], out[1]}, reinterpret_cast<d2u*>(dst));
+        __builtin_nontemporal_store((d2u){out[2], out[3]}, reinterpret_cast<d2u*>(dst + 2));
+      } else {
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+          if (ibase + nb < a.p) dst[nb] = out[nb];
+      }
+    }
+  if (nnan) atomicAdd((unsigned long long*)&a.stat[ST_NAN_LOD], (unsigned long long)nnan);
+}
+
+template <int C, int MB>
+static int launch_scan_lr_t(blmm_ctx* ctx, const LrArgs& la) {
+  constexpr int NB = 4;
+  const ScanArgs& a = la.s;
+  const int64_t ntile_t = (a.m + 32 * MB - 1) / (32 * MB);
+  const int64_t ntile_i = (a.p + 32 * NB - 1) / (32 * NB);
+  const int64_t nwg = ntile_t * ntile_i;
+  if (nwg <= 0) return BLMM_OK;
+  if (nwg > 0x7fffffffLL) return fail(ctx, BLMM_ERR_INVALID, "problem too large for one launch");
+  hipLaunchKernelGGL((k_scan_lr<C, MB, NB>), dim3((unsigned)nwg), dim3(256), 0, ctx->stream, la, (int)ntile_i, nwg);
+  KCHECK();
+  return BLMM_OK;
+}
+
+int launch_scan_lr(blmm_ctx* ctx, const LrArgs& la) {
+  switch (la.c) {
+    case 1: return launch_scan_lr_t<1, 2>(ctx, la);
+    case 2: return launch_scan_lr_t<2, 1>(ctx, la);
+    case 3: return launch_scan_lr_t<3, 1>(ctx, la);
   }
   return fail(ctx, BLMM_ERR_UNSUPPORTED, "number of null covariates (incl. intercept) must be 1..4");
 }

@@ -79,6 +79,8 @@ typedef struct blmm_status {
   int64_t jacobi_sweeps;   /* sweeps used by the device eigensolver                                   */
   int64_t jacobi_cycles;   /* shader cycles / 100 MHz ticks spent inside the eigensolver (diagnostic)  */
   int64_t jacobi_ticks_100mhz;
+  int64_t lowrank_rank;    /* rank R of the weight-family basis used by the null-exact kernel (kernels_lowrank.hip) */
+  double lowrank_resid;    /* largest relative residual |w_j - Q Q'w_j| / |w_j| over the traits (diagnostic)           */
   double t_eigen_ms, t_rotate_ms, t_h2_ms, t_prep_ms, t_scan_ms, t_total_ms;
 } blmm_status;
 

@@ -29,7 +29,7 @@ def test_library_exports_every_declared_symbol(blmm):
 def test_struct_layouts_match_header(blmm):
     from bulklmm_jl_amd import _lib as L
     assert C.sizeof(L.blmm_opts) == 6 * 4 + 2 * 8
-    assert C.sizeof(L.blmm_status) == 8 * 8 + 6 * 8
+    assert C.sizeof(L.blmm_status) == 9 * 8 + 7 * 8
     o = L.blmm_opts()
     blmm.load().blmm_default_opts(C.byref(o))
     assert (o.method, o.reml, o.add_intercept, o.decomp_scheme, o.optim_interval) == (1, 0, 1, 0, 1)
