@@ -150,6 +150,8 @@ def main():
         dsc = torch.empty(2, dtype=torch.float64, device=dev)
         dlod = torch.empty(p, dtype=torch.float64, device=dev)
 
+    lr_rank = None
+
     def step(gather):
         if perms:
             B.scan_perms_dev(ctx, dy1, dG, dK, dsc, dlod, dL, nperms=m_local, seed=1 + rank)
@@ -173,6 +175,10 @@ def main():
     dt = time.perf_counter() - t0
     phases, ncalls = ctx.read_timings()
     ctx.set_timing(False)
+    if a.method == "null-exact":   # one extra (untimed) call with a status read-back: rank of the weight basis
+        st = B.bulkscan_dev(ctx, dY, dG, dK, dL, dH, method=a.method, h2_grid=grid, status=True)
+        lr_rank = int(st.lowrank_rank)
+        lr_resid = float(st.lowrank_resid)
 
     ag_ms = None
     if world > 1:
@@ -197,8 +203,17 @@ def main():
         ms_step = dt / a.steps * 1e3
         tests = p * m_total
         c = 1
+        survey_flops = None
         if a.method == "null-exact":
-            flops_launch = 2.0 * n * (2 + c) * p * m_local       # 2n(2+c) flops per test
+            # executed contraction: num over the padded n, Sxx and s over the weight basis;
+            # SURVEY.md §8(d)'s figure for the reference formulation is 2n(2+c) flops per test
+            npad8 = -(-n // 8) * 8
+            survey_flops = 2.0 * n * (2 + c) * p * m_local
+            if lr_rank:
+                kr4 = 4 * (-(-lr_rank // 4))
+                flops_launch = 2.0 * (npad8 + (1 + c) * kr4) * p * m_local
+            else:   # BLMM_EXACT=full: the (2+c) full-length contractions
+                flops_launch = survey_flops
         elif a.method in ("null-grid", "perms"):
             flops_launch = 2.0 * n * p * m_local
         else:
@@ -207,11 +222,19 @@ def main():
         roof = {"bound": "mfma", "achieved": flops_launch / (scan_ms * 1e-3) / 1e12 if scan_ms > 0 else None,
                 "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": (flops_launch / (scan_ms * 1e-3) / 1e12 / FP64_MFMA_PEAK_TFLOPS) if scan_ms > 0 else None,
-                "traffic": None, "kernel": "k_scan (exact)" if a.method == "null-exact" else "k_scan",
+                "traffic": None, "kernel": "k_scan_lr (exact, low-rank weights)" if a.method == "null-exact" else "k_scan",
                 "kernel_ms": scan_ms, "alg_flops_per_launch": flops_launch,
                 "alg_bytes_per_launch": 8.0 * p * m_local,
                 "hbm_write_GBps": 8.0 * p * m_local / (scan_ms * 1e-3) / 1e9 if scan_ms > 0 else None,
                 "hbm_peak_GBps": HBM_PEAK_GBS}
+        if survey_flops:
+            roof["flops_per_test_executed"] = flops_launch / (p * m_local)
+            roof["weight_basis_rank"] = lr_rank
+            roof["weight_basis_resid"] = lr_resid
+            roof["reference_formulation_flops_per_launch"] = survey_flops   # 2n(2+c) per test, SURVEY.md §8(d)
+            roof["reference_formulation_equiv_TFLOPs"] = survey_flops / (scan_ms * 1e-3) / 1e12 if scan_ms > 0 else None
+            roof["note"] = ("achieved/frac count the flops the kernel EXECUTES (low-rank weights form); the same launch "
+                            "delivers the reference formulation's 2n(2+c) flops/test at reference_formulation_equiv_TFLOPs")
         tp = os.path.join(ROOT, "profiles", "traffic_latest.json")
         if os.path.exists(tp):
             try:

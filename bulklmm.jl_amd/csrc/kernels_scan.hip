@@ -298,71 +298,86 @@ __global__ void __launch_bounds__(256, 2) k_scan_lr(LrArgs la, int ntile_i, int6
   const uint32_t voffB = (uint32_t)(((int64_t)kk * a.ldx + wi * (16 * NB) + NB * r) * 8);
   const int64_t sa = 4 * a.ldp, sb = 4 * a.ldx;
 
-  // ---- phase 1: num, two K steps per fragment set (a.ks is even: the K dimension is padded to 8) -----------
-  {
-    auto load1 = [&](double (&A)[2][MB], double (&B)[2][NB], int step2) {
+  // ---- phase 1: num, two K steps per fragment set (a.ks is even: the K dimension is padded to 8);
+  //      phase 2: Sxx and s_q over the weight basis.  The first fragment set of phase 2 is fetched under the last
+  //      MFMAs of phase 1, so the only exposed load latency of a tile is its very first set.
+  auto load1 = [&](double (&A)[2][MB], double (&B)[2][NB], int step2) {
 #pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        bufload<MB>(A[h], make_srd(PA + (int64_t)(2 * step2 + h) * sa), voffA);
-        bufload<NB>(B[h], make_srd(PB + (int64_t)(2 * step2 + h) * sb), voffB);
-      }
-    };
-    auto mfma1 = [&](const double (&A)[2][MB], const double (&B)[2][NB]) {
-#pragma unroll
-      for (int h = 0; h < 2; ++h)
-#pragma unroll
-        for (int mb = 0; mb < MB; ++mb)
-#pragma unroll
-          for (int nb = 0; nb < NB; ++nb)
-            acc[0][mb][nb] = __builtin_amdgcn_mfma_f64_16x16x4f64(A[h][mb], B[h][nb], acc[0][mb][nb], 0, 0, 0);
-    };
-    const int K2 = a.ks / 2;
-    double a0[2][MB], b0[2][NB], a1[2][MB], b1[2][NB];
-    load1(a0, b0, 0);
-    int s2 = 0;
-    for (; s2 + 2 <= K2; s2 += 2) {
-      load1(a1, b1, s2 + 1);
-      __builtin_amdgcn_sched_barrier(0);
-      mfma1(a0, b0);
-      __builtin_amdgcn_sched_barrier(0);
-      load1(a0, b0, (s2 + 2 < K2) ? s2 + 2 : s2);
-      __builtin_amdgcn_sched_barrier(0);
-      mfma1(a1, b1);
-      __builtin_amdgcn_sched_barrier(0);
+    for (int h = 0; h < 2; ++h) {
+      bufload<MB>(A[h], make_srd(PA + (int64_t)(2 * step2 + h) * sa), voffA);
+      bufload<NB>(B[h], make_srd(PB + (int64_t)(2 * step2 + h) * sb), voffB);
     }
-    if (s2 < K2) mfma1(a0, b0);
-  }
-  // ---- phase 2: Sxx and s_q over the weight basis ------------------------------------------------------
-  {
-    const int KR = la.rk[1];
-    auto load2 = [&](double (&A)[MB], double (&B)[1 + C][NB], int step) {
-      bufload<MB>(A, make_srd(PC + (int64_t)step * sa), voffA);
+  };
+  auto mfma1 = [&](const double (&A)[2][MB], const double (&B)[2][NB]) {
 #pragma unroll
-      for (int q = 0; q <= C; ++q) bufload<NB>(B[q], make_srd(PT + q * la.tstride + (int64_t)step * sb), voffB);
-    };
-    auto mfma2 = [&](const double (&A)[MB], const double (&B)[1 + C][NB]) {
+    for (int h = 0; h < 2; ++h)
 #pragma unroll
       for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb)
+          acc[0][mb][nb] = __builtin_amdgcn_mfma_f64_16x16x4f64(A[h][mb], B[h][nb], acc[0][mb][nb], 0, 0, 0);
+  };
+  auto load2 = [&](double (&A)[MB], double (&B)[1 + C][NB], int step) {
+    bufload<MB>(A, make_srd(PC + (int64_t)step * sa), voffA);
 #pragma unroll
-          for (int q = 0; q <= C; ++q)
-            acc[1 + q][mb][nb] = __builtin_amdgcn_mfma_f64_16x16x4f64(A[mb], B[q][nb], acc[1 + q][mb][nb], 0, 0, 0);
-    };
-    double a0[MB], b0[1 + C][NB], a1[MB], b1[1 + C][NB];
-    load2(a0, b0, 0);
+    for (int q = 0; q <= C; ++q) bufload<NB>(B[q], make_srd(PT + q * la.tstride + (int64_t)step * sb), voffB);
+  };
+  auto mfma2 = [&](const double (&A)[MB], const double (&B)[1 + C][NB]) {
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+        for (int q = 0; q <= C; ++q)
+          acc[1 + q][mb][nb] = __builtin_amdgcn_mfma_f64_16x16x4f64(A[mb], B[q][nb], acc[1 + q][mb][nb], 0, 0, 0);
+  };
+  const int K2 = a.ks / 2;
+  const int KR = la.rk[1];
+  double c0[MB], d0[1 + C][NB];
+  {
+    double a0[2][MB], b0[2][NB], a1[2][MB], b1[2][NB];
+    load1(a0, b0, 0);
+    int s2 = 0;
+    while (s2 + 2 < K2) {   // a following pair exists
+      load1(a1, b1, s2 + 1);
+      __builtin_amdgcn_sched_barrier(0);
+      mfma1(a0, b0);
+      __builtin_amdgcn_sched_barrier(0);
+      load1(a0, b0, s2 + 2);
+      __builtin_amdgcn_sched_barrier(0);
+      mfma1(a1, b1);
+      __builtin_amdgcn_sched_barrier(0);
+      s2 += 2;
+    }
+    if (K2 - s2 == 2) {
+      load1(a1, b1, s2 + 1);
+      __builtin_amdgcn_sched_barrier(0);
+      mfma1(a0, b0);
+      __builtin_amdgcn_sched_barrier(0);
+      load2(c0, d0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      mfma1(a1, b1);
+    } else {
+      load2(c0, d0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      mfma1(a0, b0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  {
+    double c1[MB], d1[1 + C][NB];
     int ks = 0;
     for (; ks + 2 <= KR; ks += 2) {
-      load2(a1, b1, ks + 1);
+      load2(c1, d1, ks + 1);
       __builtin_amdgcn_sched_barrier(0);
-      mfma2(a0, b0);
+      mfma2(c0, d0);
       __builtin_amdgcn_sched_barrier(0);
-      load2(a0, b0, (ks + 2 < KR) ? ks + 2 : ks);
+      load2(c0, d0, (ks + 2 < KR) ? ks + 2 : ks);
       __builtin_amdgcn_sched_barrier(0);
-      mfma2(a1, b1);
+      mfma2(c1, d1);
       __builtin_amdgcn_sched_barrier(0);
     }
-    if (ks < KR) mfma2(a0, b0);
+    if (ks < KR) mfma2(c0, d0);
   }
 
   // ---- epilogue ---------------------------------------------------------------------------------------------
