@@ -5,6 +5,7 @@
 #include "blmm_internal.h"
 #include "fastmath.h"
 #include <cmath>
+#include <cstdlib>
 
 namespace blmm {
 
@@ -837,6 +838,9 @@ template <int C>
 static int launch_brent_c(blmm_ctx* ctx, const NullModel& nm, const double* Yt, int64_t ldy, int64_t m, const double* Z0,
                           const double* lam, double* h2, double* sigma2, double* ell, int64_t* stat) {
   const int n = nm.n;
+  static const int lpt_env = getenv("BLMM_BRENT_LPT") ? atoi(getenv("BLMM_BRENT_LPT")) : 0;
+  if (lpt_env == 8 && n <= 8 * NULL_NK) return launch_brent_t<C, 8, true>(ctx, nm, Yt, ldy, m, Z0, lam, h2, sigma2, ell, stat);
+  if (lpt_env == 16 && n <= 16 * NULL_NK) return launch_brent_t<C, 16, true>(ctx, nm, Yt, ldy, m, Z0, lam, h2, sigma2, ell, stat);
   if (n <= 4 * NULL_NK) return launch_brent_t<C, 4, true>(ctx, nm, Yt, ldy, m, Z0, lam, h2, sigma2, ell, stat);
   if (n <= 8 * NULL_NK) return launch_brent_t<C, 8, true>(ctx, nm, Yt, ldy, m, Z0, lam, h2, sigma2, ell, stat);
   if (n <= 16 * NULL_NK) return launch_brent_t<C, 16, true>(ctx, nm, Yt, ldy, m, Z0, lam, h2, sigma2, ell, stat);
