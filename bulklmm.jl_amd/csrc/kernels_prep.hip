@@ -92,7 +92,7 @@ __device__ __forceinline__ int jac_pi(int pos, int NP2) {
 }
 
 __global__ void __launch_bounds__(1024) k_jacobi_lds(const double* __restrict__ Ag, double* __restrict__ Vg, int n,
-                                                     double* __restrict__ lraw, int64_t* stat) {
+                                                     double* __restrict__ lraw, int64_t* stat, double stop2) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   __shared__ double s_anorm;
   const int tid = threadIdx.x, nt = blockDim.x;
@@ -159,6 +159,7 @@ __global__ void __launch_bounds__(1024) k_jacobi_lds(const double* __restrict__ 
     const int rp = jac_pi(2 * tid, NP2), rq = jac_pi(2 * tid + 1, NP2);
     d_pp = rp * ld + rp; d_qq = rq * ld + rq; d_pq = max(rp, rq) * ld + min(rp, rq);
   }
+  const double jac_stop2 = stop2;
   int cur = 0, sweep = 0, dpos = N - 1;                 // dpos: where the zero pad row/col of an odd n currently sits
   for (; sweep < 30; ++sweep) {
     double myrel = 0.0;
@@ -231,9 +232,10 @@ __global__ void __launch_bounds__(1024) k_jacobi_lds(const double* __restrict__ 
     double mx = 0.0;
     for (int i = 0; i < NP2; ++i) mx = fmax(mx, smem[REL + i]);
     __syncthreads();
-    // Jacobi converges quadratically: once every relative off-diagonal met in a sweep was below 1e-9 the sweep left
-    // them at rounding level, and a further (verification) sweep would not rotate anything
-    if (mx < 1e-18) break;
+    // Jacobi converges quadratically: once every relative off-diagonal met in a sweep was below ~3e-8 (stop2 = 1e-15 on
+    // the squared value) the sweep left them at rounding level, and a further (verification) sweep would not rotate
+    // anything (tests/test_gpu_parity.py::test_eigensolver_accuracy)
+    if (mx < jac_stop2) break;
   }
   // positions -> compact output (skip the pad position of an odd n): eigenvalue = diagonal, eigenvector = V column
   const double* A = smem + (cur ? AO : 0);
@@ -353,7 +355,8 @@ int launch_jacobi(blmm_ctx* ctx, double* A, double* V, int n, double* lraw, int6
     const int rows_per = (n + JAC_NWG - 1) / JAC_NWG;
     const size_t lds = sizeof(double) * ((size_t)2 * N * ld + (size_t)2 * rows_per * ld + 3 * NP2 + 2) + 64;
     BLMM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_jacobi_lds), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(k_jacobi_lds, dim3(JAC_NWG), dim3(1024), lds, ctx->stream, A, V, n, lraw, stat);
+    static const double stop2 = getenv("BLMM_JAC_STOP2") ? atof(getenv("BLMM_JAC_STOP2")) : 1e-15;
+    hipLaunchKernelGGL(k_jacobi_lds, dim3(JAC_NWG), dim3(1024), lds, ctx->stream, A, V, n, lraw, stat, stop2);
   } else {
     hipLaunchKernelGGL(k_jacobi_glb, dim3(1), dim3(1024), 0, ctx->stream, A, V, n, lraw, stat);
   }
@@ -368,17 +371,35 @@ int launch_jacobi(blmm_ctx* ctx, double* A, double* V, int n, double* lraw, int6
 //   R = U' Wd (centered = 0; literal transform_rotation, src/transform_helpers.jl:34).
 // Rp[i*ldr + k] = R[k, i], zero padded to npad x ldr (the A-operand layout of k_rotate).
 // ------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(1024) k_post_eigen(const double* __restrict__ lraw_in, const double* __restrict__ V,
-                                                     const double* __restrict__ Zs, const double* __restrict__ wd, int n,
+template <bool VLDS>
+__global__ void __launch_bounds__(1024) k_post_eigen(const double* __restrict__ lraw_in, const double* __restrict__ Vg,
+                                                     const double* __restrict__ Zs_g, const double* __restrict__ wd, int n,
                                                      int c, int npad, int ldr, int decomp, int centered,
-                                                     double* __restrict__ lam, double* __restrict__ U,
-                                                     double* __restrict__ Z0, double* __restrict__ Rp,
+                                                     double* __restrict__ lam, double* __restrict__ Ug,
+                                                     double* __restrict__ Z0g, double* __restrict__ Rp,
                                                      double* __restrict__ tmp /* n + c*n */, int64_t* stat) {
   __shared__ double Ginv[CMAX * CMAX];
   __shared__ int s_neg;
+  extern __shared__ __attribute__((aligned(16))) double shv[];
   const int tid = threadIdx.x, nt = blockDim.x;
-  double* lraw = tmp;          // n
-  double* Bq = tmp + n;        // c x n : Ginv * (Zs' Wd)
+  // VLDS: V, U, Zs, Z0, Bq and the raw eigenvalues live in LDS (the loops below walk them with stride n and would
+  // otherwise pay a global-memory round trip per phase); results are also written to their global buffers.
+  double* Vl = shv;                    // n x n
+  double* Ul = shv + (size_t)n * n;    // n x n
+  double* Zsl = Ul + (size_t)n * n;    // n x c
+  double* Z0l = Zsl + (size_t)n * c;   // n x c
+  double* Bql = Z0l + (size_t)n * c;   // c x n
+  double* lrl = Bql + (size_t)n * c;   // n
+  if (VLDS) {
+    for (int e = tid; e < n * n; e += nt) Vl[e] = Vg[e];
+    for (int e = tid; e < n * c; e += nt) Zsl[e] = Zs_g[e];
+  }
+  const double* V = VLDS ? Vl : Vg;
+  const double* Zs = VLDS ? Zsl : Zs_g;
+  double* U = VLDS ? Ul : Ug;
+  double* Z0 = VLDS ? Z0l : Z0g;
+  double* lraw = VLDS ? lrl : tmp;          // n
+  double* Bq = VLDS ? Bql : tmp + n;        // c x n : Ginv * (Zs' Wd)
   if (tid == 0) s_neg = 0;
   for (int i = tid; i < n; i += nt) lraw[i] = (decomp == BLMM_SVD) ? fabs(lraw_in[i]) : lraw_in[i];
   __syncthreads();
@@ -401,12 +422,14 @@ __global__ void __launch_bounds__(1024) k_post_eigen(const double* __restrict__ 
   }
   __syncthreads();
   if (tid == 0 && s_neg) stat[ST_NEG_EIG] += s_neg;
+  if (VLDS) { for (int e = tid; e < n * n; e += nt) Ug[e] = Ul[e]; }
   // Z0[k,q] = sum_i U[i,k] Zs[i,q]
   for (int e = tid; e < n * c; e += nt) {
     const int k = e % n, q = e / n;
     double s = 0;
     for (int i = 0; i < n; ++i) s = fma(U[(size_t)k * n + i], Zs[(size_t)q * n + i], s);
     Z0[e] = s;
+    if (VLDS) Z0g[e] = s;
   }
   __syncthreads();
   if (tid == 0) {
@@ -454,8 +477,15 @@ int launch_post_eigen(blmm_ctx* ctx, const double* lraw, const double* V, const 
                       int64_t* stat) {
   int rc = ensure(ctx, ctx->misc, sizeof(double) * ((size_t)n + (size_t)c * n + 64));
   if (rc) return rc;
-  hipLaunchKernelGGL(k_post_eigen, dim3(1), dim3(1024), 0, ctx->stream, lraw, V, Zs, dweights, n, c, npad, ldr, decomp,
-                     centered, lam, U, Z0, Rp, ptr<double>(ctx->misc), stat);
+  const size_t lds = sizeof(double) * ((size_t)2 * n * n + (size_t)3 * n * c + n);
+  if (lds <= 150 * 1024) {
+    BLMM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_post_eigen<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(k_post_eigen<true>, dim3(1), dim3(1024), lds, ctx->stream, lraw, V, Zs, dweights, n, c, npad, ldr, decomp,
+                       centered, lam, U, Z0, Rp, ptr<double>(ctx->misc), stat);
+  } else {
+    hipLaunchKernelGGL(k_post_eigen<false>, dim3(1), dim3(1024), 0, ctx->stream, lraw, V, Zs, dweights, n, c, npad, ldr, decomp,
+                       centered, lam, U, Z0, Rp, ptr<double>(ctx->misc), stat);
+  }
   KCHECK();
   return BLMM_OK;
 }

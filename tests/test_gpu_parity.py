@@ -312,3 +312,15 @@ def test_rocsolver_eigen_path(blmm):
     Y, G, K, _ = make_data(n=420, p=100, m=9, seed=77, bxd=False)
     got = blmm.bulkscan_null(Y, G, K)
     check_null_exact(got, Y, G, K)
+
+
+@pytest.mark.parametrize("n,bxd", [(79, True), (64, False), (130, False)])
+def test_eigensolver_accuracy(blmm, n, bxd):
+    """The device eigensolver (replacing LAPACK eigen, src/transform_helpers.jl:23): rotating the identity returns U'."""
+    Y, G, K, _ = make_data(n=n, p=90, m=2, seed=900 + n, bxd=bxd)
+    Y0, X0, lam = blmm.transform_rotation(np.eye(n), G, K)
+    U = Y0.T
+    assert np.abs(U.T @ U - np.eye(n)).max() <= 5e-14
+    assert np.abs((U * lam) @ U.T - K).max() <= 2e-13 * np.abs(K).max() * n
+    assert np.abs(np.sort(lam) - np.linalg.eigvalsh(K)).max() <= 1e-12 * np.abs(lam).max()
+    assert np.all(np.diff(lam) >= 0)
