@@ -300,6 +300,24 @@ def scan(y, g, K, covar=None, *, weights=None, prior_variance: float = 0.0, prio
     return out
 
 
+def lod_colmax(L_mat, ctx: Optional[Context] = None):
+    """Per-column maximum of an LOD matrix and the (0-based) marker where it sits, computed on the GPU."""
+    ctx = ctx or default_context()
+    Lm = _F(L_mat)
+    p, m = Lm.shape
+    mx = np.empty(m)
+    arg = np.empty(m, dtype=np.int64)
+    ctx.check(ctx.lib.blmm_lod_colmax(ctx.h, _p(Lm), p, m, _p(mx), arg.ctypes.data_as(C.c_void_p)))
+    return mx, arg
+
+
+def get_thresholds(L_perms, signif_level, ctx: Optional[Context] = None):
+    """src/analysis_helpers/single_trait_analysis.jl:13-23: quantiles of the per-permutation peak LODs."""
+    peaks, _ = lod_colmax(L_perms, ctx=ctx)
+    thr_probs = 1.0 - np.asarray(signif_level, dtype=np.float64)
+    return {"probs": thr_probs, "thrs": np.quantile(peaks, thr_probs)}  # Julia's default quantile = linear interpolation
+
+
 # ---- lower-level seams ------------------------------------------------------------------------------
 
 def transform_rotation(y, g, K, *, addIntercept: bool = True, decomp_scheme: str = "eigen", ctx: Optional[Context] = None):

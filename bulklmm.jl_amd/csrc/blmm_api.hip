@@ -418,6 +418,30 @@ int blmm_kinship(blmm_ctx* ctx, const double* G, int64_t n, int64_t p, double* K
 }
 
 // ---------------------------------------------------------------------------------------------------
+int blmm_lod_colmax_dev(blmm_ctx* ctx, const double* dL, int64_t p, int64_t m, int64_t ldL, double* dmax_out, int64_t* dargmax_out) {
+  if (!ctx) return BLMM_ERR_INVALID;
+  if (!dL || !dmax_out || p < 1 || m < 0 || ldL < p) return fail(ctx, BLMM_ERR_INVALID, "lod_colmax: bad arguments");
+  BLMM_HIP(hipSetDevice(ctx->device));
+  return launch_colmax(ctx, dL, p, m, ldL, dmax_out, dargmax_out);
+}
+
+int blmm_lod_colmax(blmm_ctx* ctx, const double* L, int64_t p, int64_t m, double* max_out, int64_t* argmax_out) {
+  if (!ctx) return BLMM_ERR_INVALID;
+  if (!L || !max_out || p < 1 || m < 0) return fail(ctx, BLMM_ERR_INVALID, "lod_colmax: bad arguments");
+  BLMM_HIP(hipSetDevice(ctx->device));
+  int rc;
+  if ((rc = ensure(ctx, ctx->outL, sizeof(double) * (size_t)p * (m > 0 ? m : 1)))) return rc;
+  if ((rc = ensure(ctx, ctx->tmpA, sizeof(double) * (size_t)(m > 0 ? m : 1)))) return rc;
+  if ((rc = ensure(ctx, ctx->tmpB, sizeof(int64_t) * (size_t)(m > 0 ? m : 1)))) return rc;
+  BLMM_HIP(hipMemcpyAsync(ctx->outL.p, L, sizeof(double) * (size_t)p * m, hipMemcpyHostToDevice, ctx->stream));
+  if ((rc = launch_colmax(ctx, ptr<double>(ctx->outL), p, m, p, ptr<double>(ctx->tmpA), ptr<int64_t>(ctx->tmpB)))) return rc;
+  BLMM_HIP(hipMemcpyAsync(max_out, ctx->tmpA.p, sizeof(double) * (size_t)m, hipMemcpyDeviceToHost, ctx->stream));
+  if (argmax_out) BLMM_HIP(hipMemcpyAsync(argmax_out, ctx->tmpB.p, sizeof(int64_t) * (size_t)m, hipMemcpyDeviceToHost, ctx->stream));
+  BLMM_HIP(hipStreamSynchronize(ctx->stream));
+  return BLMM_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------
 int blmm_bulkscan_dev(blmm_ctx* ctx, const blmm_opts* opts, const double* dY, int64_t n, int64_t m, const double* dG,
                       int64_t p, const double* dCovar, int64_t ncov, const double* dK, const double* dweights,
                       const double* h2_grid_host, int64_t ngrid, double* dL_out, int64_t ldL, double* dh2_out,

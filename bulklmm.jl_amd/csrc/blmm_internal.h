@@ -108,6 +108,7 @@ int launch_panels(blmm_ctx* ctx, const NullModel& nm, const double* Yt, int64_t 
 int launch_isx(blmm_ctx* ctx, const NullModel& nm, const double* Xt, int64_t ldx, int64_t p, const double* Z0,
                const double* lam, const double* grid_dev, int ngrid, double* isx, int64_t ld_isx, int64_t* stat);
 int launch_kinship(blmm_ctx* ctx, const double* dG, int64_t n, int64_t p, double* dK, double* partial);
+int launch_colmax(blmm_ctx* ctx, const double* L, int64_t p, int64_t m, int64_t ldL, double* mx, int64_t* arg);
 // permutation panel: column b = sqrt(w) .* P_w( pi_b(r0) ) / ||r0||  etc.  (see kernels_prep.hip)
 int launch_perm_panel(blmm_ctx* ctx, const NullModel& nm, const double* Yt, int64_t ldy, const double* Z0,
                       const double* lam, const double* h2, const int32_t* perm_idx, int64_t nperms, uint64_t seed,

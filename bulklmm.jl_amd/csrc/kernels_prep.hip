@@ -1393,4 +1393,38 @@ int launch_perm_panel(blmm_ctx* ctx, const NullModel& nm, const double* Yt, int6
   return BLMM_OK;
 }
 
+// ------------------------------------------------------------------------------------------------
+// Column maxima of an LOD matrix (p x m, ld = ldL): per-trait / per-permutation peak and the marker where it sits.
+// The consumer behind get_thresholds (src/analysis_helpers/single_trait_analysis.jl:13-23) and the usual
+// "max LOD per trait" summary, so the 2 GB matrix need not leave HBM.  One wave per column,
+// 16-byte loads, first maximum wins; NaNs are ignored (a column of NaNs gives -inf, marker -1).
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_colmax(const double* __restrict__ L, int64_t p, int64_t m, int64_t ldL,
+                                                double* __restrict__ mx, int64_t* __restrict__ arg) {
+  const int lane = threadIdx.x & 63;
+  const int64_t j = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (j >= m) return;
+  const double* col = L + j * ldL;
+  double best = -INFINITY;
+  int64_t bi = -1;
+  for (int64_t i = lane; i < p; i += 64) {
+    const double v = col[i];
+    if (v > best) { best = v; bi = i; }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const double ob = __shfl_xor(best, o, 64);
+    const int64_t oi = __shfl_xor(bi, o, 64);
+    if (ob > best || (ob == best && oi >= 0 && (bi < 0 || oi < bi))) { best = ob; bi = oi; }
+  }
+  if (lane == 0) { mx[j] = best; if (arg) arg[j] = bi; }
+}
+
+int launch_colmax(blmm_ctx* ctx, const double* L, int64_t p, int64_t m, int64_t ldL, double* mx, int64_t* arg) {
+  if (m <= 0) return BLMM_OK;
+  hipLaunchKernelGGL(k_colmax, dim3((unsigned)((m + 3) / 4)), dim3(256), 0, ctx->stream, L, p, m, ldL, mx, arg);
+  KCHECK();
+  return BLMM_OK;
+}
+
 }  // namespace blmm

@@ -445,7 +445,10 @@ static int launch_scan_lr_t(blmm_ctx* ctx, const LrArgs& la) {
 
 int launch_scan_lr(blmm_ctx* ctx, const LrArgs& la) {
   switch (la.c) {
-    case 1: return launch_scan_lr_t<1, 2>(ctx, la);
+    case 1: {
+      static const int mb1 = getenv("BLMM_LR_MB1") ? atoi(getenv("BLMM_LR_MB1")) : 0;
+      return mb1 ? launch_scan_lr_t<1, 1>(ctx, la) : launch_scan_lr_t<1, 2>(ctx, la);
+    }
     case 2: return launch_scan_lr_t<2, 1>(ctx, la);
     case 3: return launch_scan_lr_t<3, 1>(ctx, la);
   }

@@ -134,6 +134,12 @@ int blmm_scan_perms_dev(blmm_ctx* ctx, const blmm_opts* opts, const double* dy, 
                         int64_t nperms, uint64_t seed, const int32_t* dperm_idx, double* dscalars_out,
                         double* dlod_out, double* dLperms_out, blmm_status* status);
 
+/* ---- on-device consumer of L: column maxima (per-trait / per-permutation peak LOD and its marker, 0-based) -------
+ * The reduction behind get_thresholds (src/analysis_helpers/single_trait_analysis.jl:13-23); argmax_out may be NULL. */
+int blmm_lod_colmax(blmm_ctx* ctx, const double* L, int64_t p, int64_t m, double* max_out, int64_t* argmax_out);
+int blmm_lod_colmax_dev(blmm_ctx* ctx, const double* dL, int64_t p, int64_t m, int64_t ldL, double* dmax_out,
+                        int64_t* dargmax_out);
+
 /* ---- lower-level seams (1:1 with the reference's internal functions; used by the parity tests) ---- */
 /* transform_rotation(y, [Z G], K)  (src/transform_helpers.jl:1-54): Y0 n x m, X0 n x (c+p) (first c
  * columns = rotated null covariates, intercept first when add_intercept), lambda n. */

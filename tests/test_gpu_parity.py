@@ -324,3 +324,17 @@ def test_eigensolver_accuracy(blmm, n, bxd):
     assert np.abs((U * lam) @ U.T - K).max() <= 2e-13 * np.abs(K).max() * n
     assert np.abs(np.sort(lam) - np.linalg.eigvalsh(K)).max() <= 1e-12 * np.abs(lam).max()
     assert np.all(np.diff(lam) >= 0)
+
+
+def test_lod_colmax_and_thresholds(blmm):
+    """test/analysis_helpers_test.jl (get_thresholds): per-permutation peaks and their quantiles."""
+    rng = np.random.default_rng(5)
+    Lm = rng.random((1003, 77)) * 5
+    Lm[17, 3] = np.nan
+    Lm[500, 9] = Lm[20, 9] = 9.0   # a tie: the first marker wins
+    mx, arg = blmm.lod_colmax(Lm)
+    assert np.array_equal(mx, np.nanmax(Lm, axis=0)) and arg[9] == 20
+    assert np.array_equal(arg[:9], np.nanargmax(Lm[:, :9], axis=0))
+    thr = blmm.get_thresholds(Lm[:, 10:], [0.10, 0.05])
+    peaks = Lm[:, 10:].max(axis=0)
+    assert np.allclose(thr["thrs"], np.quantile(peaks, [0.90, 0.95])) and np.allclose(thr["probs"], [0.90, 0.95])
