@@ -107,7 +107,7 @@ __global__ void __launch_bounds__(1024) k_jacobi_lds(const double* __restrict__ 
   const int VO = rows_per * ld;                       // size of one V slice copy
   const int V0 = 2 * AO;                              // first V copy
   const int REC = (2 * AO + 2 * VO + 1) & ~1;         // NP2 x 2 : (c, s) per slot, 16-byte aligned
-  const int REL = REC + 2 * NP2;                      // NP2
+  const int REL = REC + 4 * NP2;                      // NP2 (behind the two (c, s) tables)
   for (int e = tid; e < 2 * N * ld + 2 * rows_per * ld; e += nt) smem[e] = 0.0;
   __syncthreads();
   for (int e = tid; e < n * n; e += nt) { const int i = e % n, j = e / n; if (i <= j) smem[j * ld + i] = Ag[e]; }
@@ -148,49 +148,67 @@ __global__ void __launch_bounds__(1024) k_jacobi_lds(const double* __restrict__ 
   }
   // V items (slot, local row), dealt from the last thread downwards
   const int nvit = NP2 * nr;
-  const int vitem = nt - 1 - tid;
+  const int nvthr = nt - 64;                            // the last wave is reserved for the angle lanes
+  const int vitem = (tid < nvthr) ? nvthr - 1 - tid : -1;
   int v_slot = -1, v_src = 0, v_d0 = 0, v_d1 = 0;
-  if (vitem < nvit) {
+  if (vitem >= 0 && vitem < nvit) {
     v_slot = vitem / nr; const int r = vitem % nr;
     v_src = r * ld + 2 * v_slot; v_d0 = r * ld + jac_pi(2 * v_slot, NP2); v_d1 = r * ld + jac_pi(2 * v_slot + 1, NP2);
   }
-  int d_pp = 0, d_qq = 0, d_pq = 0;                     // where slot tid's diagonal block goes (upper triangle)
-  if (tid < NP2) {
-    const int rp = jac_pi(2 * tid, NP2), rq = jac_pi(2 * tid + 1, NP2);
+  // ---- angle lanes: the last wave; lane `at` owns pair slot `at` ------------------------------------------
+  // In round r lane `at` (i) rotates its own diagonal block with its (c, s)_r and (ii) ALREADY derives (c, s)_{r+1}:
+  // the next diagonal block of slot `at` is made of three elements of A_{r+1} = pi(J' A_r J) -- the rotated diagonal
+  // entries of the two slots its positions come from and one element of the rotated block between them -- which it
+  // recomputes from A_r and (c, s)_r with the very expressions the owning threads use.  Blocks, V and angles thus
+  // all read round-r data only: ONE barrier per round.
+  const int at = tid - (nt - 64);
+  const bool angle_lane = at >= 0 && at < NP2;
+  // the angle wave runs one long dependent fp64 chain per round and shares its SIMD with three block waves: let it win
+  // the issue arbitration (cdna_hip_programming.md T5, static form)
+  if (__builtin_amdgcn_readfirstlane(tid >> 6) == (nt >> 6) - 1) __builtin_amdgcn_s_setprio(3);
+  int d_pp = 0, d_qq = 0, d_pq = 0;                     // where slot at's diagonal block goes (upper triangle)
+  int o_pp = 0, o_qq = 0, o_pq = 0;                     // ... and where it sits now
+  int sa = 0, sb = 0, ia = 0, ib = 0, sx = 0, sy = 0, ix = 0, iy = 0, xc0 = 0, xc1 = 0;
+  if (angle_lane) {
+    const int rp = jac_pi(2 * at, NP2), rq = jac_pi(2 * at + 1, NP2);
     d_pp = rp * ld + rp; d_qq = rq * ld + rq; d_pq = max(rp, rq) * ld + min(rp, rq);
+    o_pp = (2 * at) * ld + 2 * at; o_qq = (2 * at + 1) * ld + 2 * at + 1; o_pq = (2 * at + 1) * ld + 2 * at;
+    int pa = 0, pb = 0;                                 // pre-images of positions 2*at, 2*at+1 under pi
+    for (int pos = 0; pos < N; ++pos) { const int q = jac_pi(pos, NP2); if (q == 2 * at) pa = pos; if (q == 2 * at + 1) pb = pos; }
+    sa = pa >> 1; ia = pa & 1; sb = pb >> 1; ib = pb & 1;
+    if (sa < sb) { sx = sa; ix = ia; sy = sb; iy = ib; } else { sx = sb; ix = ib; sy = sa; iy = ia; }
+    xc0 = (2 * sy) * ld + 2 * sx; xc1 = (2 * sy + 1) * ld + 2 * sx;
   }
+  const int REC1 = REC + 2 * NP2;                       // second (c, s) table (ping-pong with the A copies)
+  auto angle_of = [&](double app, double aqq, double apq, double& c, double& sn, double& rel) {
+    c = 1.0; sn = 0.0;
+    const double pp = fmax(fabs(app * aqq), floor2), a2 = apq * apq;
+    if (a2 > tol2 * pp) {
+      // cos 2phi = |d|/h, sin 2phi = sign(d) 2 apq / h, |phi| <= pi/4
+      const double d = aqq - app;
+      const double ih = nr_rsqrt(fma(d, d, 4.0 * a2));
+      const double c2 = fma(0.5 * fabs(d), ih, 0.5);
+      const double ic = nr_rsqrt(c2);
+      c = c2 * ic;
+      sn = copysign(apq * ih, apq * copysign(1.0, d)) * ic;
+      rel = fmax(rel, a2 * __builtin_amdgcn_rcp(pp));   // ~ (relative off-diagonal)^2; only gates the stop rule
+    }
+  };
   const double jac_stop2 = stop2;
   int cur = 0, sweep = 0, dpos = N - 1;                 // dpos: where the zero pad row/col of an odd n currently sits
+  double mc = 1.0, ms = 0.0, myrel = 0.0;               // this lane's (c, s) for the current round
+  if (angle_lane) {                                     // prologue: angles of round 0 straight from A_0
+    angle_of(smem[o_pp], smem[o_qq], smem[o_pq], mc, ms, myrel);
+    *reinterpret_cast<dpair*>(smem + REC + 2 * at) = (dpair){mc, ms};
+  }
+  __syncthreads();
   for (; sweep < 30; ++sweep) {
-    double myrel = 0.0;
     for (int round = 0; round < N - 1; ++round) {
       const double* A = smem + (cur ? AO : 0);
       double* An = smem + (cur ? 0 : AO);
-      const double* rec = smem + REC;
-      // ---- (1) rotation angles: one lane per slot, from the 2x2 diagonal block ---------------------------
-      if (tid < NP2) {
-        const double app = A[(2 * tid) * ld + 2 * tid], aqq = A[(2 * tid + 1) * ld + 2 * tid + 1], apq = A[(2 * tid + 1) * ld + 2 * tid];
-        double c = 1.0, s = 0.0;
-        const double pp = fmax(fabs(app * aqq), floor2), a2 = apq * apq;
-        if (a2 > tol2 * pp) {
-          // cos 2phi = |d|/h, sin 2phi = sign(d) 2 apq / h, |phi| <= pi/4
-          const double d = aqq - app;
-          const double ih = nr_rsqrt(fma(d, d, 4.0 * a2));
-          const double c2 = fma(0.5 * fabs(d), ih, 0.5);
-          const double ic = nr_rsqrt(c2);
-          c = c2 * ic;
-          s = copysign(apq * ih, apq * copysign(1.0, d)) * ic;
-          myrel = fmax(myrel, a2 * __builtin_amdgcn_rcp(pp));   // ~ (relative off-diagonal)^2; only gates the stop rule
-        }
-        *reinterpret_cast<dpair*>(smem + REC + 2 * tid) = (dpair){c, s};
-        // the slot's own 2x2 diagonal block, rotated and moved through pi (upper triangle)
-        const double cc = c * c, ss = s * s, xx = 2.0 * c * s * apq;
-        An[d_pp] = fma(cc, app, fma(ss, aqq, -xx));
-        An[d_qq] = fma(ss, app, fma(cc, aqq, xx));
-        An[d_pq] = (s != 0.0) ? 0.0 : apq;
-      }
-      __syncthreads();
-      // ---- (2) A: B' = J1' B J2 written through pi;  V slice: columns (2s, 2s+1) of every local row -------
+      const double* rec = smem + (cur ? REC1 : REC);
+      double* recn = smem + (cur ? REC : REC1);
+      // ---- A: off-diagonal blocks B' = J1' B J2 written through pi -------------------------------------------
 #pragma unroll
       for (int u = 0; u < MAXB; ++u) {
         if (b_s1[u] >= 0) {
@@ -205,6 +223,7 @@ __global__ void __launch_bounds__(1024) k_jacobi_lds(const double* __restrict__ 
           An[b_dst[u][2]] = fma(sn1, t00, c1 * t10); An[b_dst[u][3]] = fma(sn1, t01, c1 * t11);
         }
       }
+      // ---- V slice: columns (2s, 2s+1) of every local row -------------------------------------------------------
       {
         const double* Vc = smem + V0 + (cur ? VO : 0);
         double* Vn = smem + V0 + (cur ? 0 : VO);
@@ -214,7 +233,7 @@ __global__ void __launch_bounds__(1024) k_jacobi_lds(const double* __restrict__ 
           Vn[v_d0] = fma(csv[0], xy[0], -csv[1] * xy[1]);
           Vn[v_d1] = fma(csv[1], xy[0], csv[0] * xy[1]);
         }
-        for (int item = vitem + nt; item < nvit; item += nt) {   // only when NP2 * rows_per > 1024
+        if (vitem >= 0) for (int item = vitem + nvthr; item < nvit; item += nvthr) {   // only when NP2 * rows_per exceeds the lanes left
           const int slot = item / nr, r = item % nr;
           const dpair csv = *reinterpret_cast<const dpair*>(rec + 2 * slot);
           const dpair xy = (dpair){Vc[r * ld + 2 * slot], Vc[r * ld + 2 * slot + 1]};
@@ -222,12 +241,40 @@ __global__ void __launch_bounds__(1024) k_jacobi_lds(const double* __restrict__ 
           Vn[r * ld + jac_pi(2 * slot + 1, NP2)] = fma(csv[1], xy[0], csv[0] * xy[1]);
         }
       }
+      // ---- angle lanes: own diagonal block of round r, then (c, s) of round r+1 -----------------------------------
+      if (angle_lane) {
+        auto rot_diag = [&](double c, double sn, double app, double aqq, double apq, double& npp, double& nqq) {
+          const double cc = c * c, ss = sn * sn, xx = 2.0 * c * sn * apq;
+          npp = fma(cc, app, fma(ss, aqq, -xx));
+          nqq = fma(ss, app, fma(cc, aqq, xx));
+        };
+        {
+          const double app = A[o_pp], aqq = A[o_qq], apq = A[o_pq];
+          double npp, nqq;
+          rot_diag(mc, ms, app, aqq, apq, npp, nqq);
+          An[d_pp] = npp; An[d_qq] = nqq; An[d_pq] = (ms != 0.0) ? 0.0 : apq;
+        }
+        const dpair ca = *reinterpret_cast<const dpair*>(rec + 2 * sa);
+        const dpair cb = *reinterpret_cast<const dpair*>(rec + 2 * sb);
+        double a_pp, a_qq, b_pp, b_qq;
+        rot_diag(ca[0], ca[1], A[(2 * sa) * ld + 2 * sa], A[(2 * sa + 1) * ld + 2 * sa + 1], A[(2 * sa + 1) * ld + 2 * sa], a_pp, a_qq);
+        rot_diag(cb[0], cb[1], A[(2 * sb) * ld + 2 * sb], A[(2 * sb + 1) * ld + 2 * sb + 1], A[(2 * sb + 1) * ld + 2 * sb], b_pp, b_qq);
+        const double napp = ia ? a_qq : a_pp, naqq = ib ? b_qq : b_pp;
+        const dpair cx = (sa < sb) ? ca : cb, cy = (sa < sb) ? cb : ca;
+        const double b00 = A[xc0], b10 = A[xc0 + 1], b01 = A[xc1], b11 = A[xc1 + 1];
+        const double c1 = cx[0], sn1 = cx[1], c2 = cy[0], sn2 = cy[1];
+        const double t0 = iy ? fma(sn2, b00, c2 * b01) : fma(c2, b00, -sn2 * b01);
+        const double t1 = iy ? fma(sn2, b10, c2 * b11) : fma(c2, b10, -sn2 * b11);
+        const double napq = ix ? fma(sn1, t0, c1 * t1) : fma(c1, t0, -sn1 * t1);
+        angle_of(napp, naqq, napq, mc, ms, myrel);
+        *reinterpret_cast<dpair*>(recn + 2 * at) = (dpair){mc, ms};
+      }
       dpos = jac_pi(dpos, NP2);
       cur ^= 1;
       __syncthreads();
     }
-    // sweep verdict: the largest relative off-diagonal (squared) any pair met in this sweep
-    if (tid < NP2) smem[REL + tid] = myrel;
+    // sweep verdict: the largest relative off-diagonal (squared) any pair met while its angles were derived
+    if (angle_lane) { smem[REL + at] = myrel; myrel = 0.0; }
     __syncthreads();
     double mx = 0.0;
     for (int i = 0; i < NP2; ++i) mx = fmax(mx, smem[REL + i]);
@@ -353,7 +400,7 @@ int launch_jacobi(blmm_ctx* ctx, double* A, double* V, int n, double* lraw, int6
   if (n <= JAC_NMAX) {
     const int N = n + (n & 1), NP2 = N / 2, ld = N + 1;
     const int rows_per = (n + JAC_NWG - 1) / JAC_NWG;
-    const size_t lds = sizeof(double) * ((size_t)2 * N * ld + (size_t)2 * rows_per * ld + 3 * NP2 + 2) + 64;
+    const size_t lds = sizeof(double) * ((size_t)2 * N * ld + (size_t)2 * rows_per * ld + 5 * NP2 + 2) + 64;
     BLMM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_jacobi_lds), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     static const double stop2 = getenv("BLMM_JAC_STOP2") ? atof(getenv("BLMM_JAC_STOP2")) : 1e-15;
     hipLaunchKernelGGL(k_jacobi_lds, dim3(JAC_NWG), dim3(1024), lds, ctx->stream, A, V, n, lraw, stat, stop2);
