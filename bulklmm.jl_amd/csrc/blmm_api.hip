@@ -184,7 +184,8 @@ int eigen_rocsolver(blmm_ctx* ctx, double* A, int n, double* lraw, int64_t* stat
 // design -> eigen -> rotation of Y and G.  centered = 1: the rotation also removes the unweighted projection
 // on the null covariates (kernels_prep.hip:k_post_eigen).
 int prepare(blmm_ctx* ctx, const blmm_opts* o, const double* dY, int64_t n, int64_t m, const double* dG, int64_t p,
-            const double* dCovar, int64_t ncov, const double* dK, const double* dweights, int centered, Pipe& P, Timer& tm) {
+            const double* dCovar, int64_t ncov, const double* dK, const double* dweights, int centered, Pipe& P, Timer& tm,
+            bool early_wbasis = false) {
   if (n < 1 || m < 0 || p < 0 || ncov < 0) return fail(ctx, BLMM_ERR_DIM, "Dimension mismatch.");
   if (n > 46000) return fail(ctx, BLMM_ERR_UNSUPPORTED, "n too large");
   int add_int = o->add_intercept ? 1 : 0;
@@ -227,6 +228,20 @@ int prepare(blmm_ctx* ctx, const blmm_opts* o, const double* dY, int64_t n, int6
                               P.npad, P.ldr, o->decomp_scheme, centered, P.lam, ptr<double>(ctx->U), P.Z0,
                               ptr<double>(ctx->Rp), P.stat))) return rc;
   tm.mark();
+  if (early_wbasis && m > 0 && p > 0) {
+    // null-exact, low-rank weights form: the basis of the weight family needs only the sorted eigenvalues, so it
+    // starts on the side stream here, beside the rotation and the Brent search (joined before k_lr_panels)
+    if ((rc = ensure(ctx, ctx->wbQ, sizeof(double) * (size_t)P.npad * n))) return rc;
+    if ((rc = ensure(ctx, ctx->wbW, sizeof(double) * (size_t)n * (256 + 16)))) return rc;
+    if ((rc = ensure(ctx, ctx->wbRk, sizeof(int) * 4))) return rc;
+    hipStream_t main_stream = ctx->stream;
+    BLMM_HIP(hipEventRecord(ctx->ev_xt, main_stream));
+    BLMM_HIP(hipStreamWaitEvent(ctx->side, ctx->ev_xt, 0));
+    ctx->stream = ctx->side;                                           // the launchers enqueue on ctx->stream
+    rc = launch_wbasis(ctx, P.lam, (int)n, ptr<double>(ctx->wbW), ptr<double>(ctx->wbQ), ptr<int>(ctx->wbRk), P.stat);
+    ctx->stream = main_stream;
+    if (rc) return rc;
+  }
   if ((rc = launch_rotate(ctx, ptr<double>(ctx->Rp), P.ldr, (int)n, P.npad, dY, m, P.Yt, P.ldy, P.ldy))) return rc;
   if ((rc = launch_rotate(ctx, ptr<double>(ctx->Rp), P.ldr, (int)n, P.npad, dG, p, P.Xt, P.ldx, P.ldx))) return rc;
   tm.mark();
@@ -460,32 +475,32 @@ int blmm_bulkscan_dev(blmm_ctx* ctx, const blmm_opts* opts, const double* dY, in
   if (opts->method != BLMM_NULL_EXACT) {
     if ((rc = grid_to_device(ctx, h2_grid_host, ngrid, &dgrid))) return rc;
   }
-  if ((rc = prepare(ctx, opts, dY, n, m, dG, p, dCovar, ncov, dK, dweights, 1, P, tm))) return rc;
+  // null-exact runs the low-rank weights form (kernels_lowrank.hip) unless BLMM_EXACT=full (A/B testing), c = 4 (the
+  // kernel would spill) or n is beyond what the basis kernel keeps in LDS
+  static const char* exact_env = getenv("BLMM_EXACT");
+  const int c_eff = (int)((ncov == 0 || !dCovar) ? 1 : ncov + (opts->add_intercept ? 1 : 0));
+  const bool lowrank = opts->method == BLMM_NULL_EXACT && !(exact_env && std::strcmp(exact_env, "full") == 0) &&
+                       c_eff <= 3 && n <= 6000;
+  if ((rc = prepare(ctx, opts, dY, n, m, dG, p, dCovar, ncov, dK, dweights, 1, P, tm, lowrank))) return rc;
   const NullModel nm = null_model(P, opts);
   const int64_t ldp = P.ldy;
   if (m == 0 || p == 0) { tm.mark(); tm.mark(); tm.mark(); return finish_status(ctx, status, &tm); }
 
   if (opts->method == BLMM_NULL_EXACT) {
-    static const char* exact_env = getenv("BLMM_EXACT");   // "full": the (2+c) full-length contractions (A/B testing)
-    const bool lowrank = !(exact_env && std::strcmp(exact_env, "full") == 0) && P.c <= 3;   // c = 4 would spill
     if (lowrank) {
-      // low-rank weights form (kernels_lowrank.hip).  The basis of {w(delta)} needs only the eigenvalues and the
-      // marker-side products only (Q, Xt): both run on the side stream beside the per-trait Brent search.
+      // the basis (started in prepare) and the marker-side products (Q, Xt) run on the side stream beside the
+      // per-trait Brent search
       const int64_t tstride = (int64_t)P.npad * P.ldx;
-      if ((rc = ensure(ctx, ctx->wbQ, sizeof(double) * (size_t)P.npad * n))) return rc;
-      if ((rc = ensure(ctx, ctx->wbW, sizeof(double) * (size_t)n * 256))) return rc;
-      if ((rc = ensure(ctx, ctx->wbRk, sizeof(int) * 4))) return rc;
       if ((rc = ensure(ctx, ctx->lrT, sizeof(double) * (size_t)(1 + P.c) * tstride))) return rc;
       if ((rc = ensure(ctx, ctx->lrC, sizeof(double) * (size_t)P.npad * ldp))) return rc;
       if ((rc = ensure(ctx, ctx->lrL, sizeof(double) * (size_t)(P.c * (P.c + 1) / 2) * ldp))) return rc;
       if ((rc = ensure(ctx, ctx->panels, sizeof(double) * (size_t)P.npad * ldp))) return rc;
       int* rk = ptr<int>(ctx->wbRk);
       hipStream_t main_stream = ctx->stream;
-      BLMM_HIP(hipEventRecord(ctx->ev_fork, main_stream));            // eigenvalues + rotated operands are ready
+      BLMM_HIP(hipEventRecord(ctx->ev_fork, main_stream));            // rotated operands are ready
       BLMM_HIP(hipStreamWaitEvent(ctx->side, ctx->ev_fork, 0));
-      ctx->stream = ctx->side;                                         // the launchers enqueue on ctx->stream
-      rc = launch_wbasis(ctx, P.lam, (int)n, ptr<double>(ctx->wbW), ptr<double>(ctx->wbQ), rk, P.stat);
-      if (!rc) rc = launch_lr_tpanels(ctx, P.Xt, P.ldx, p, (int)n, P.c, P.npad, P.Z0, ptr<double>(ctx->wbQ), rk, ptr<double>(ctx->lrT), tstride);
+      ctx->stream = ctx->side;
+      rc = launch_lr_tpanels(ctx, P.Xt, P.ldx, p, (int)n, P.c, P.npad, P.Z0, ptr<double>(ctx->wbQ), rk, ptr<double>(ctx->lrT), tstride);
       ctx->stream = main_stream;
       if (rc) return rc;
       BLMM_HIP(hipEventRecord(ctx->ev_join, ctx->side));

@@ -23,7 +23,8 @@ namespace blmm {
   } while (0)
 
 constexpr int WB_NS = 256;  // sampled deltas (one per thread) when the sample columns live in global memory
-constexpr int WB_QCAP = 48; // basis vectors mirrored in LDS for the re-orthogonalisation (further ones: global)
+constexpr int WB_QCAP = 48; // at most this many basis vectors are mirrored in LDS for the re-orthogonalisation
+                            // (fewer when n is large; further ones are read from global memory)
 
 __device__ __forceinline__ double wave_sum(double x) {
 #pragma unroll
@@ -31,81 +32,94 @@ __device__ __forceinline__ double wave_sum(double x) {
   return x;
 }
 
-// Greedy pivoted Gram-Schmidt over NS = blockDim.x sampled deltas.  Q: r-major, Q[r*n + k]; rk[0] = R, rk[1] = KR.
+// Greedy pivoted Gram-Schmidt over NS = blockDim.x / TPS sampled deltas (TPS adjacent lanes share one sample column and
+// split its rows k = part, part + TPS, ...).  Q: r-major, Q[r*n + k]; rk[0] = R, rk[1] = KR.
 // WLDS: the n x NS sample columns (k-major) live in LDS (n*NS*8 bytes), else in the global workspace Wg.
-template <bool WLDS>
-__global__ void __launch_bounds__(WB_NS) k_wbasis(const double* __restrict__ lam, int n, double* __restrict__ Wg,
-                                                  double* __restrict__ Q, int* __restrict__ rk, int64_t* stat) {
+template <bool WLDS, int TPS>
+__global__ void __launch_bounds__(WB_NS * TPS) k_wbasis(const double* __restrict__ lam, int n, double* __restrict__ Wg,
+                                                        double* __restrict__ Q, int* __restrict__ rk, int64_t* stat,
+                                                        int qcap) {
   extern __shared__ __attribute__((aligned(16))) double sh[];
-  const int NS = blockDim.x;
+  const int NT = blockDim.x, NS = NT / TPS;
   double* sq = sh;              // n : the pivot column / new basis vector
   double* sd = sh + n;          // n : re-orthogonalisation coefficients
-  double* Ql = sh + 2 * n;      // WB_QCAP x n : LDS mirror of the first basis vectors
-  double* Wl = Ql + WB_QCAP * n; // n x NS (WLDS only)
+  double* Ql = sh + 2 * n;      // qcap x n : LDS mirror of the first basis vectors
+  double* Wl = Ql + qcap * n;   // n x NS (WLDS only)
   __shared__ double s_red[WB_NS];
   __shared__ int s_arg[WB_NS];
   __shared__ int s_neg;
-  const int s = threadIdx.x, lane = s & 63, wave = s >> 6, nwave = NS >> 6;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6, nwave = NT >> 6;
+  const int s = t / TPS, part = t % TPS;
   // a kinship with negative eigenvalues leaves the smooth family (poles at delta = -1/lambda): use the identity basis,
   // for which the low-rank form is the full-rank form
-  if (s == 0) s_neg = 0;
+  if (t == 0) s_neg = 0;
   __syncthreads();
-  for (int k = s; k < n; k += NS) if (lam[k] < -1e-12) s_neg = 1;
+  for (int k = t; k < n; k += NT) if (lam[k] < -1e-12) s_neg = 1;
   __syncthreads();
   if (s_neg) {
-    for (int e = s; e < n * n; e += NS) Q[e] = ((e / n) == (e % n)) ? 1.0 : 0.0;
-    if (s == 0) { rk[0] = n; rk[1] = (n + 3) / 4; stat[8] = n; }
+    for (int e = t; e < n * n; e += NT) Q[e] = ((e / n) == (e % n)) ? 1.0 : 0.0;
+    if (t == 0) { rk[0] = n; rk[1] = (n + 3) / 4; stat[8] = n; }
     return;
   }
-#define WK(k) (WLDS ? Wl[(k) * NS + s] : Wg[(size_t)(k) * NS + s])
+  // leading dimension of the sample columns: NS + 16 doubles.  In LDS the TPS row groups of a half-wave then fall into
+  // disjoint banks; in global memory it avoids the 2 KB row stride that maps every row to the same L2 channel / L1 set
+  // (measured: 140 us instead of ~15 us per basis vector at n = 500)
+  const int ldw = NS + 16;
+#define WK(k) (WLDS ? Wl[(k) * ldw + s] : Wg[(size_t)(k) * ldw + s])
+#define TPS_SUM(x)                                                    \
+  do {                                                                \
+    _Pragma("unroll") for (int o__ = 1; o__ < TPS; o__ <<= 1) x += __shfl_xor(x, o__, 64); \
+  } while (0)
   // delta_0 = 0 (w = 1), then log-spaced over [1e-6, 1e9]: h2 from 1e-6 to 1 - 1e-9
   const double delta = (s == 0) ? 0.0 : exp(2.302585092994046 * (-6.0 + 15.0 * (double)(s - 1) / (double)(NS - 2)));
   double nrm = 0.0;
-  for (int k = 0; k < n; ++k) { const double w = 1.0 / fma(delta, fabs(lam[k]), 1.0); WK(k) = w; nrm = fma(w, w, nrm); }
+  for (int k = part; k < n; k += TPS) { const double w = 1.0 / fma(delta, fabs(lam[k]), 1.0); WK(k) = w; nrm = fma(w, w, nrm); }
+  TPS_SUM(nrm);
   const double inv = 1.0 / sqrt(nrm);
-  for (int k = 0; k < n; ++k) WK(k) *= inv;
+  for (int k = part; k < n; k += TPS) WK(k) *= inv;
   double res2 = 1.0;
   // stop at a ~4e-15 relative residual (squared; scaled with n: the rounding floor of the deflated columns grows with it)
   const double tol2 = 2e-31 * (double)n;
   int R = 0;
   for (; R < n; ++R) {
     // arg-max of the residual norms (first maximum wins)
-    s_red[s] = res2; s_arg[s] = s;
+    if (part == 0) { s_red[s] = res2; s_arg[s] = s; }
     __syncthreads();
-    for (int o = NS / 2; o > 0; o >>= 1) {
-      if (s < o && (s_red[s + o] > s_red[s] || (s_red[s + o] == s_red[s] && s_arg[s + o] < s_arg[s]))) { s_red[s] = s_red[s + o]; s_arg[s] = s_arg[s + o]; }
+    for (int cnt = NS; cnt > 1;) {             // NS may be 128, 192 or 256: halve with round-up
+      const int o = (cnt + 1) >> 1;
+      if (t + o < cnt && (s_red[t + o] > s_red[t] || (s_red[t + o] == s_red[t] && s_arg[t + o] < s_arg[t]))) { s_red[t] = s_red[t + o]; s_arg[t] = s_arg[t + o]; }
+      cnt = o;
       __syncthreads();
     }
     const double mx = s_red[0];
     const int piv = s_arg[0];
     __syncthreads();
     if (!(mx > tol2)) break;
-    for (int k = s; k < n; k += NS) sq[k] = WLDS ? Wl[k * NS + piv] : Wg[(size_t)k * NS + piv];
+    for (int k = t; k < n; k += NT) sq[k] = WLDS ? Wl[k * ldw + piv] : Wg[(size_t)k * ldw + piv];
     __syncthreads();
     for (int pass = 0; pass < 2; ++pass) {   // classical Gram-Schmidt twice: Q stays orthonormal to rounding even for
                                               // the last, noise-dominated pivots
-      for (int t = s; t < R; t += NS) {        // one lane per existing basis vector (LDS copy; the rest: global)
-        const double* qt = (t < WB_QCAP) ? Ql + t * n : Q + (size_t)t * n;
-        double d0 = 0.0, d1 = 0.0;
-        int k = 0;
-        for (; k + 1 < n; k += 2) { d0 = fma(qt[k], sq[k], d0); d1 = fma(qt[k + 1], sq[k + 1], d1); }
-        if (k < n) d0 = fma(qt[k], sq[k], d0);
-        sd[t] = d0 + d1;
+      for (int r = wave; r < R; r += nwave) {  // one wave per existing basis vector (LDS copy; the rest: global)
+        const double* qt = (r < qcap) ? Ql + r * n : Q + (size_t)r * n;
+        double d = 0.0;
+        for (int k = lane; k < n; k += 64) d = fma(qt[k], sq[k], d);
+        d = wave_sum(d);
+        if (lane == 0) sd[r] = d;
       }
       __syncthreads();
-      for (int k = s; k < n; k += NS) {
+      for (int k = t; k < n; k += NT) {
         double v = sq[k];
-        const int rl = R < WB_QCAP ? R : WB_QCAP;
-        for (int t = 0; t < rl; ++t) v = fma(-sd[t], Ql[t * n + k], v);
-        for (int t = rl; t < R; ++t) v = fma(-sd[t], Q[(size_t)t * n + k], v);
+        const int rl = R < qcap ? R : qcap;
+        for (int r = 0; r < rl; ++r) v = fma(-sd[r], Ql[r * n + k], v);
+        for (int r = rl; r < R; ++r) v = fma(-sd[r], Q[(size_t)r * n + k], v);
         sq[k] = v;
       }
       __syncthreads();
     }
-    double part = 0.0;
-    for (int k = s; k < n; k += NS) part = fma(sq[k], sq[k], part);
-    part = wave_sum(part);
-    if (lane == 0) s_red[wave] = part;
+    double pn = 0.0;
+    for (int k = t; k < n; k += NT) pn = fma(sq[k], sq[k], pn);
+    pn = wave_sum(pn);
+    if (lane == 0) s_red[wave] = pn;
     __syncthreads();
     double tot = 0.0;
     for (int w = 0; w < nwave; ++w) tot += s_red[w];
@@ -113,33 +127,64 @@ __global__ void __launch_bounds__(WB_NS) k_wbasis(const double* __restrict__ lam
     __syncthreads();
     // a pivot that loses > 99.99 % of its norm in the re-orthogonalisation was rounding noise: the family is exhausted
     if (!(tot > 1e-8 * mx)) break;
-    for (int k = s; k < n; k += NS) { const double v = sq[k] * qn; sq[k] = v; Q[(size_t)R * n + k] = v; if (R < WB_QCAP) Ql[R * n + k] = v; }
+    for (int k = t; k < n; k += NT) { const double v = sq[k] * qn; sq[k] = v; Q[(size_t)R * n + k] = v; if (R < qcap) Ql[R * n + k] = v; }
     __syncthreads();
-    // deflate every sample column
+    // deflate every sample column (loads batched 8 deep: the global-memory variant is latency bound otherwise, and the
+    // compiler may not move a load of W above the preceding store to W)
     double c = 0.0;
-    for (int k = 0; k < n; ++k) c = fma(sq[k], WK(k), c);
+    {
+      int k = part;
+      for (; k + 7 * TPS < n; k += 8 * TPS) {
+        double wv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) wv[u] = WK(k + u * TPS);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) c = fma(sq[k + u * TPS], wv[u], c);
+      }
+      for (; k < n; k += TPS) c = fma(sq[k], WK(k), c);
+    }
+    TPS_SUM(c);
     double r2 = 0.0;
-    for (int k = 0; k < n; ++k) { const double v = fma(-c, sq[k], WK(k)); WK(k) = v; r2 = fma(v, v, r2); }
+    {
+      int k = part;
+      for (; k + 7 * TPS < n; k += 8 * TPS) {
+        double wv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) wv[u] = WK(k + u * TPS);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { const double v = fma(-c, sq[k + u * TPS], wv[u]); WK(k + u * TPS) = v; r2 = fma(v, v, r2); }
+      }
+      for (; k < n; k += TPS) { const double v = fma(-c, sq[k], WK(k)); WK(k) = v; r2 = fma(v, v, r2); }
+    }
+    TPS_SUM(r2);
     res2 = r2;
     __syncthreads();
   }
 #undef WK
-  if (s == 0) { rk[0] = R; rk[1] = (R + 3) / 4; stat[8] = R; }
+#undef TPS_SUM
+  if (t == 0) { rk[0] = R; rk[1] = (R + 3) / 4; stat[8] = R; }
 }
 
 int launch_wbasis(blmm_ctx* ctx, const double* lam, int n, double* Wk, double* Q, int* rk, int64_t* stat) {
-  // sample columns in LDS when at least 128 of them fit beside the two work vectors
-  const size_t fixed = sizeof(double) * ((size_t)2 * n + (size_t)WB_QCAP * n);
-  int ns = fixed < 150 * 1024 ? (int)((150 * 1024 - fixed) / (8 * (size_t)n)) : 0;
-  ns = ns >= 256 ? 256 : (ns / 64) * 64;
-  if (ns >= 128) {
-    const size_t lds = fixed + sizeof(double) * (size_t)n * ns;
-    BLMM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wbasis<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(k_wbasis<true>, dim3(1), dim3(ns), lds, ctx->stream, lam, n, Wk, Q, rk, stat);
+  // LDS budget (156 KB dynamic): two work vectors, the sample columns when 256, 192 or 128 of them fit (padded to
+  // ns + 16 per row) beside at least 16 mirrored basis vectors, then as many mirrored basis vectors as fit (<= WB_QCAP)
+  const size_t budget = 156 * 1024, work = sizeof(double) * (size_t)2 * n, row = sizeof(double) * (size_t)n;
+  if (work + row > budget) return fail(ctx, BLMM_ERR_UNSUPPORTED, "n too large for the weight-basis kernel");
+  int ns = 0;
+  for (int cand : {256, 192, 128})
+    if (work + row * (size_t)(cand + 16) + row * 16 <= budget) { ns = cand; break; }
+  if (ns) {
+    const size_t wbytes = row * (size_t)(ns + 16);
+    const int qcap = (int)std::min<size_t>(WB_QCAP, (budget - work - wbytes) / row);
+    const size_t lds = work + row * qcap + wbytes;
+    BLMM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wbasis<true, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL((k_wbasis<true, 4>), dim3(1), dim3(ns * 4), lds, ctx->stream, lam, n, Wk, Q, rk, stat, qcap);
   } else {
-    if (fixed > 150 * 1024) return fail(ctx, BLMM_ERR_UNSUPPORTED, "n too large for the weight-basis kernel");
-    BLMM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wbasis<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)fixed));
-    hipLaunchKernelGGL(k_wbasis<false>, dim3(1), dim3(WB_NS), fixed, ctx->stream, lam, n, Wk, Q, rk, stat);
+    // sample columns in global memory (L2-resident)
+    const int qcap = (int)std::min<size_t>(WB_QCAP, (budget - work) / row);
+    const size_t lds = work + row * qcap;
+    BLMM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wbasis<false, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL((k_wbasis<false, 4>), dim3(1), dim3(WB_NS * 4), lds, ctx->stream, lam, n, Wk, Q, rk, stat, qcap);
   }
   KCHECK();
   return BLMM_OK;
