@@ -28,6 +28,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 FP64_MFMA_PEAK_TFLOPS = 78.6   # AMD MI355X datasheet, FP64 matrix (dense); measured sustained: see DESIGN.md
+FP32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: FP32 matrix, v_mfma_f32_32x32x2_f32 (exact fp32)
 HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
@@ -84,6 +85,8 @@ def main():
     ap.add_argument("--m", type=int, default=35554)
     ap.add_argument("--method", default="null-exact", choices=["null-exact", "null-grid", "alt-grid", "perms"],
                     help="perms: scan(...; permutation_test=true) with --m permutations of ONE trait (BASELINE.json configs[4])")
+    ap.add_argument("--perm-dtype", default="f64", choices=["f64", "f32"],
+                    help="--method perms: precision of the permutation LOD matrix (f32 = BASELINE.json configs[4])")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
     ap.add_argument("--gather", action="store_true", help="put the RCCL all-gather of the LOD shards inside the step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -137,7 +140,10 @@ def main():
     if a.gather or True:
         # the gathered matrix: shards are contiguous column blocks of the column-major p x m_total L
         dLfull = torch.empty((world, m_local, p), dtype=torch.float64, device=dev) if world > 1 else None
-    dL = dLfull[rank] if world > 1 else torch.empty((m_local, p), dtype=torch.float64, device=dev)
+    f32 = a.method == "perms" and a.perm_dtype == "f32"
+    if f32:   # fp32 permutation matrix (the all-gather, if any, moves fp32 too)
+        dLfull = torch.empty((world, m_local, p), dtype=torch.float32, device=dev) if world > 1 else None
+    dL = dLfull[rank] if world > 1 else torch.empty((m_local, p), dtype=torch.float32 if f32 else torch.float64, device=dev)
     dH = torch.empty((m_local, p) if alt else (m_local,), dtype=torch.float64, device=dev)
     grid = [i / 16.0 for i in range(16)] if a.method in ("null-grid", "alt-grid") else None
 
@@ -220,12 +226,12 @@ def main():
             flops_launch = 2.0 * n * len(grid) * p * m_local
         scan_ms = phases["scan"] / max(ncalls, 1)
         roof = {"bound": "mfma", "achieved": flops_launch / (scan_ms * 1e-3) / 1e12 if scan_ms > 0 else None,
-                "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                "frac": (flops_launch / (scan_ms * 1e-3) / 1e12 / FP64_MFMA_PEAK_TFLOPS) if scan_ms > 0 else None,
-                "traffic": None, "kernel": "k_scan_lr (exact, low-rank weights)" if a.method == "null-exact" else "k_scan",
+                "peak": FP32_MFMA_PEAK_TFLOPS if f32 else FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": (flops_launch / (scan_ms * 1e-3) / 1e12 / (FP32_MFMA_PEAK_TFLOPS if f32 else FP64_MFMA_PEAK_TFLOPS)) if scan_ms > 0 else None,
+                "traffic": None, "kernel": "k_scan_lr (exact, low-rank weights)" if a.method == "null-exact" else ("k_scan_f32" if f32 else "k_scan"),
                 "kernel_ms": scan_ms, "alg_flops_per_launch": flops_launch,
-                "alg_bytes_per_launch": 8.0 * p * m_local,
-                "hbm_write_GBps": 8.0 * p * m_local / (scan_ms * 1e-3) / 1e9 if scan_ms > 0 else None,
+                "alg_bytes_per_launch": (4.0 if f32 else 8.0) * p * m_local,
+                "hbm_write_GBps": (4.0 if f32 else 8.0) * p * m_local / (scan_ms * 1e-3) / 1e9 if scan_ms > 0 else None,
                 "hbm_peak_GBps": HBM_PEAK_GBS}
         if survey_flops:
             roof["flops_per_test_executed"] = flops_launch / (p * m_local)
@@ -247,7 +253,7 @@ def main():
         out = {
             "metric": "trait x marker LOD tests/sec", "value": tests / (dt / a.steps), "unit": "tests/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms_step, "higher_is_better": True,
-            "scaling": a.scaling, "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "scaling": a.scaling, "vs_baseline": None, "dtype": "f32" if f32 else "f64", "data": "synthetic",
             "config": {"workload": f"bulkscan_null-shaped: method={a.method} n={n} p={p} m={m_total} fp64 "
                                    f"(BASELINE.json configs[1]; {m_local} traits per GPU)",
                        "n": n, "p": p, "m": m_total, "m_per_gpu": m_local, "method": a.method,

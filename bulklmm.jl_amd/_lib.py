@@ -17,7 +17,7 @@ EXPORTS = [
     "blmm_version", "blmm_device_count", "blmm_create", "blmm_destroy", "blmm_last_error", "blmm_err_string",
     "blmm_set_stream", "blmm_set_timing", "blmm_read_timings", "blmm_synchronize", "blmm_default_opts",
     "blmm_kinship", "blmm_kinship_dev", "blmm_bulkscan", "blmm_bulkscan_dev", "blmm_scan_perms",
-    "blmm_scan_perms_dev", "blmm_lod_colmax", "blmm_lod_colmax_dev", "blmm_rotate", "blmm_null_h2_brent", "blmm_null_loglik_grid",
+    "blmm_scan_perms_dev", "blmm_scan_perms_f32", "blmm_scan_perms_f32_dev", "blmm_lod_colmax", "blmm_lod_colmax_dev", "blmm_rotate", "blmm_null_h2_brent", "blmm_null_loglik_grid",
     "blmm_weighted_liteqtl", "blmm_liteqtl_given_h2",
 ]
 
@@ -94,6 +94,8 @@ def load():
     lib.blmm_bulkscan_dev.argtypes = [vp, op, vp, i64, i64, vp, i64, vp, i64, vp, vp, vp, i64, vp, i64, vp, sp]
     lib.blmm_scan_perms.argtypes = [vp, op, vp, i64, vp, i64, vp, i64, vp, vp, i64, C.c_uint64, vp, vp, vp, vp, sp]
     lib.blmm_scan_perms_dev.argtypes = [vp, op, vp, i64, vp, i64, vp, i64, vp, vp, i64, C.c_uint64, vp, vp, vp, vp, sp]
+    lib.blmm_scan_perms_f32.argtypes = [vp, op, vp, i64, vp, i64, vp, i64, vp, vp, i64, C.c_uint64, vp, vp, vp, vp, sp]
+    lib.blmm_scan_perms_f32_dev.argtypes = [vp, op, vp, i64, vp, i64, vp, i64, vp, vp, i64, C.c_uint64, vp, vp, vp, vp, sp]
     lib.blmm_lod_colmax.argtypes = [vp, vp, i64, i64, vp, vp]
     lib.blmm_lod_colmax_dev.argtypes = [vp, vp, i64, i64, i64, vp, vp]
     lib.blmm_rotate.argtypes = [vp, op, vp, i64, i64, vp, i64, vp, i64, vp, vp, vp, vp, sp]

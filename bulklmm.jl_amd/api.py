@@ -242,11 +242,14 @@ def bulkscan(Y, G, K, Covar=None, *, method: str = "null-grid", h2_grid=None, nb
 def scan(y, g, K, covar=None, *, weights=None, prior_variance: float = 0.0, prior_sample_size: float = 0.0,
          addIntercept: bool = True, reml: bool = False, assumption: str = "null", method: str = "qr", optim_interval: int = 1,
          permutation_test: bool = False, nperms: int = 1024, rndseed: int = 0, decomp_scheme: str = "eigen",
-         output_pvals: bool = False, chisq_df: int = 1, perm_idx=None, ctx: Optional[Context] = None) -> dict:
+         output_pvals: bool = False, chisq_df: int = 1, perm_idx=None, perm_precision: str = "f64",
+         ctx: Optional[Context] = None) -> dict:
     """src/scan.jl:94-271 for assumption == "null": the single-trait scan routed through the same GPU
     kernels (Brent + exact-weights LOD kernel with m = 1), and the permutation test (src/scan.jl:485-557).
     `perm_idx` (n x nperms, 0-based) supplies the permutations; otherwise the library draws them from
-    `rndseed` with its own generator (Julia's MersenneTwister stream is not reproducible)."""
+    `rndseed` with its own generator (Julia's MersenneTwister stream is not reproducible).
+    `perm_precision="f32"` (not in the reference; BASELINE.json configs[4]) computes L_perms on the fp32 matrix cores
+    and returns it as float32; the null model and `lod` stay fp64."""
     y = _F(y)
     if covar is None and not addIntercept:
         raise BulkLMMError("Intercept has to be added when no other covariate is given.", -7)  # src/scan.jl:167-169
@@ -283,11 +286,15 @@ def scan(y, g, K, covar=None, *, weights=None, prior_variance: float = 0.0, prio
         pidx = np.asfortranarray(np.asarray(perm_idx, dtype=np.int32))
         if pidx.shape != (n, nperms):
             raise BulkLMMError("Dimension mismatch.", -2)
+    if perm_precision not in ("f64", "f32"):
+        raise BulkLMMError("perm_precision must be \"f64\" or \"f32\".")
     ctx = ctx or default_context()
     scal = np.zeros(2)
     lod = np.empty(p)
-    Lp = np.empty((p, max(nperms, 1)), order="F")
-    ctx.check(ctx.lib.blmm_scan_perms(ctx.h, C.byref(o), _p(y), n, _p(G), p, _p(cov), ncov, _p(K), _p(w), nperms,
+    f32 = perm_precision == "f32"
+    Lp = np.empty((p, max(nperms, 1)), order="F", dtype=np.float32 if f32 else np.float64)
+    fn = ctx.lib.blmm_scan_perms_f32 if f32 else ctx.lib.blmm_scan_perms
+    ctx.check(fn(ctx.h, C.byref(o), _p(y), n, _p(G), p, _p(cov), ncov, _p(K), _p(w), nperms,
                                       C.c_uint64(int(rndseed)), _p(pidx), _p(scal), _p(lod), _p(Lp), C.byref(st)))
     _raise_status(st)
     out = {"sigma2_e": float(scal[0]), "h2_null": float(scal[1]), "lod": lod}
@@ -440,7 +447,8 @@ def scan_perms_dev(ctx: Context, y, G, K, scalars_out, lod_out, Lperms_out, *, n
                    prior_sample_size: float = 0.0, reml: bool = False, optim_interval: int = 1,
                    decomp_scheme: str = "eigen", status: bool = False):
     """blmm_scan_perms_dev on torch CUDA tensors: y (n,), G (p, n) [= n x p column-major], K (n, n),
-    scalars_out (2,), lod_out (p,), Lperms_out (nperms, p) [= p x nperms column-major], perm_idx (nperms, n) int32."""
+    scalars_out (2,), lod_out (p,), Lperms_out (nperms, p) [= p x nperms column-major], perm_idx (nperms, n) int32.
+    A float32 Lperms_out selects the fp32 permutation kernel (blmm_scan_perms_f32_dev)."""
     n = y.shape[0]
     p = G.shape[0]
     ncov = 0 if Covar is None else Covar.shape[0]
@@ -448,7 +456,10 @@ def scan_perms_dev(ctx: Context, y, G, K, scalars_out, lod_out, Lperms_out, *, n
         addIntercept = True
     o = _opts(L.BLMM_NULL_EXACT, reml, addIntercept, decomp_scheme, optim_interval, prior_variance, prior_sample_size)
     st = L.blmm_status() if status else None
-    ctx.check(ctx.lib.blmm_scan_perms_dev(ctx.h, C.byref(o), y.data_ptr(), n, G.data_ptr(), p,
+    import torch
+    f32 = Lperms_out is not None and Lperms_out.dtype == torch.float32
+    fn = ctx.lib.blmm_scan_perms_f32_dev if f32 else ctx.lib.blmm_scan_perms_dev
+    ctx.check(fn(ctx.h, C.byref(o), y.data_ptr(), n, G.data_ptr(), p,
                                           None if Covar is None else Covar.data_ptr(), ncov, K.data_ptr(),
                                           None if weights is None else weights.data_ptr(), int(nperms), C.c_uint64(int(seed)),
                                           None if perm_idx is None else perm_idx.data_ptr(), scalars_out.data_ptr(),

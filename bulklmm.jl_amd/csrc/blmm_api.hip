@@ -349,7 +349,7 @@ void blmm_destroy(blmm_ctx* ctx) {
                     &ctx->iyy, &ctx->h2, &ctx->h2idx, &ctx->sig2, &ctx->ell, &ctx->isx, &ctx->stat, &ctx->gridd, &ctx->misc,
                     &ctx->EllTab, &ctx->inY, &ctx->inG, &ctx->inK, &ctx->inCov, &ctx->inW, &ctx->outL, &ctx->outH2,
                     &ctx->tmpA, &ctx->tmpB, &ctx->tmpC, &ctx->perm, &ctx->r0, &ctx->altbuf, &ctx->logtab, &ctx->lraw,
-                    &ctx->wbQ, &ctx->wbW, &ctx->wbRk, &ctx->lrT, &ctx->lrC, &ctx->lrL};
+                    &ctx->wbQ, &ctx->wbW, &ctx->wbRk, &ctx->lrT, &ctx->lrC, &ctx->lrL, &ctx->xf32, &ctx->pf32};
   for (DevBuf* b : bufs) if (b->p) hipFree(b->p);
   for (auto& s : ctx->evsets) for (auto& e : s.e) (void)hipEventDestroy(e);
   if (ctx->rb_handle && ctx->rb_destroy) ctx->rb_destroy(ctx->rb_handle);
@@ -604,15 +604,16 @@ int blmm_bulkscan(blmm_ctx* ctx, const blmm_opts* opts, const double* Y, int64_t
 }
 
 // ---------------------------------------------------------------------------------------------------
-int blmm_scan_perms_dev(blmm_ctx* ctx, const blmm_opts* opts, const double* dy, int64_t n, const double* dG, int64_t p,
-                        const double* dCovar, int64_t ncov, const double* dK, const double* dweights, int64_t nperms,
-                        uint64_t seed, const int32_t* dperm_idx, double* dscalars_out, double* dlod_out,
-                        double* dLperms_out, blmm_status* status) {
+// dLperms_out (fp64) or dLperms32_out (fp32, kernels_scan_f32.hip): exactly one of them when nperms > 0
+static int scan_perms_impl(blmm_ctx* ctx, const blmm_opts* opts, const double* dy, int64_t n, const double* dG, int64_t p,
+                           const double* dCovar, int64_t ncov, const double* dK, const double* dweights, int64_t nperms,
+                           uint64_t seed, const int32_t* dperm_idx, double* dscalars_out, double* dlod_out,
+                           double* dLperms_out, float* dLperms32_out, blmm_status* status) {
   if (!ctx) return BLMM_ERR_INVALID;
   int rc = check_opts(ctx, opts);
   if (rc) return rc;
   if (nperms < 0) return fail(ctx, BLMM_ERR_NPERMS, "The required number of permutations must be a positive integer.");
-  if (!dy || !dG || !dK || !dscalars_out || !dlod_out || (nperms > 0 && !dLperms_out))
+  if (!dy || !dG || !dK || !dscalars_out || !dlod_out || (nperms > 0 && !dLperms_out && !dLperms32_out))
     return fail(ctx, BLMM_ERR_INVALID, "scan_perms: NULL buffer");
   BLMM_HIP(hipSetDevice(ctx->device));
   Timer tm(ctx);
@@ -636,7 +637,16 @@ int blmm_scan_perms_dev(blmm_ctx* ctx, const blmm_opts* opts, const double* dy, 
     ScanArgs a = scan_args(ctx, P, pan0, ldp0, dlod_out, p, 1);
     a.isx = ptr<double>(ctx->isx); a.ld_isx = P.ldx;
     if ((rc = launch_scan_table(ctx, a))) return rc;
-    if (nperms > 0) {
+    if (nperms > 0 && dLperms32_out) {
+      // fp32 path: fp32 fragment-major copies of the rotated markers and of the permutation panel, fp32 MFMA, fp32 L
+      const int64_t ldxf = round_up(p, 256), ldpf = ldp1;
+      if ((rc = ensure(ctx, ctx->xf32, sizeof(float) * (size_t)P.npad * ldxf))) return rc;
+      if ((rc = ensure(ctx, ctx->pf32, sizeof(float) * (size_t)P.npad * ldpf))) return rc;
+      if ((rc = launch_cvt_f32(ctx, P.Xt, P.ldx, P.n, p, ptr<float>(ctx->xf32), ldxf, P.npad / 8))) return rc;
+      if ((rc = launch_cvt_f32(ctx, pan1, ldp1, P.n, nperms, ptr<float>(ctx->pf32), ldpf, P.npad / 8))) return rc;
+      if ((rc = launch_scan_f32(ctx, ptr<float>(ctx->xf32), ldxf, ptr<float>(ctx->pf32), ldpf, P.npad, P.n, p, nperms,
+                                ptr<double>(ctx->isx), dLperms32_out, p, P.stat))) return rc;
+    } else if (nperms > 0) {
       ScanArgs b = scan_args(ctx, P, pan1, ldp1, dLperms_out, p, nperms);
       b.isx = ptr<double>(ctx->isx); b.ld_isx = P.ldx;
       if ((rc = launch_scan_table(ctx, b))) return rc;
@@ -646,20 +656,40 @@ int blmm_scan_perms_dev(blmm_ctx* ctx, const blmm_opts* opts, const double* dy, 
   return finish_status(ctx, status, &tm);
 }
 
-int blmm_scan_perms(blmm_ctx* ctx, const blmm_opts* opts, const double* y, int64_t n, const double* G, int64_t p,
-                    const double* Covar, int64_t ncov, const double* K, const double* weights, int64_t nperms, uint64_t seed,
-                    const int32_t* perm_idx, double* scalars_out, double* lod_out, double* Lperms_out, blmm_status* status) {
+int blmm_scan_perms_dev(blmm_ctx* ctx, const blmm_opts* opts, const double* dy, int64_t n, const double* dG, int64_t p,
+                        const double* dCovar, int64_t ncov, const double* dK, const double* dweights, int64_t nperms,
+                        uint64_t seed, const int32_t* dperm_idx, double* dscalars_out, double* dlod_out,
+                        double* dLperms_out, blmm_status* status) {
+  if (ctx && nperms > 0 && !dLperms_out) return fail(ctx, BLMM_ERR_INVALID, "scan_perms: NULL buffer");
+  return scan_perms_impl(ctx, opts, dy, n, dG, p, dCovar, ncov, dK, dweights, nperms, seed, dperm_idx, dscalars_out,
+                         dlod_out, dLperms_out, nullptr, status);
+}
+
+int blmm_scan_perms_f32_dev(blmm_ctx* ctx, const blmm_opts* opts, const double* dy, int64_t n, const double* dG, int64_t p,
+                            const double* dCovar, int64_t ncov, const double* dK, const double* dweights, int64_t nperms,
+                            uint64_t seed, const int32_t* dperm_idx, double* dscalars_out, double* dlod_out,
+                            float* dLperms_out, blmm_status* status) {
+  if (ctx && nperms > 0 && !dLperms_out) return fail(ctx, BLMM_ERR_INVALID, "scan_perms: NULL buffer");
+  return scan_perms_impl(ctx, opts, dy, n, dG, p, dCovar, ncov, dK, dweights, nperms, seed, dperm_idx, dscalars_out,
+                         dlod_out, nullptr, dLperms_out, status);
+}
+
+static int scan_perms_host(blmm_ctx* ctx, const blmm_opts* opts, const double* y, int64_t n, const double* G, int64_t p,
+                           const double* Covar, int64_t ncov, const double* K, const double* weights, int64_t nperms,
+                           uint64_t seed, const int32_t* perm_idx, double* scalars_out, double* lod_out, void* Lperms_out,
+                           bool f32, blmm_status* status) {
   if (!ctx) return BLMM_ERR_INVALID;
   if (!opts) return fail(ctx, BLMM_ERR_INVALID, "opts is NULL");
   if (nperms < 0) return fail(ctx, BLMM_ERR_NPERMS, "The required number of permutations must be a positive integer.");
   if (!y || !G || !K || !scalars_out || !lod_out || (nperms > 0 && !Lperms_out)) return fail(ctx, BLMM_ERR_INVALID, "scan_perms: NULL buffer");
   if (n < 1 || p < 0) return fail(ctx, BLMM_ERR_DIM, "Dimension mismatch.");
   BLMM_HIP(hipSetDevice(ctx->device));
+  const size_t esz = f32 ? sizeof(float) : sizeof(double);
   int rc;
   if ((rc = ensure(ctx, ctx->inY, sizeof(double) * n))) return rc;
   if ((rc = ensure(ctx, ctx->inG, sizeof(double) * n * (p > 0 ? p : 1)))) return rc;
   if ((rc = ensure(ctx, ctx->inK, sizeof(double) * n * n))) return rc;
-  if ((rc = ensure(ctx, ctx->outL, sizeof(double) * (size_t)p * (nperms + 1)))) return rc;
+  if ((rc = ensure(ctx, ctx->outL, sizeof(double) * (size_t)p + esz * (size_t)p * nperms))) return rc;
   if ((rc = ensure(ctx, ctx->outH2, sizeof(double) * 2))) return rc;
   BLMM_HIP(hipMemcpyAsync(ctx->inY.p, y, sizeof(double) * n, hipMemcpyHostToDevice, ctx->stream));
   BLMM_HIP(hipMemcpyAsync(ctx->inG.p, G, sizeof(double) * n * p, hipMemcpyHostToDevice, ctx->stream));
@@ -681,14 +711,30 @@ int blmm_scan_perms(blmm_ctx* ctx, const blmm_opts* opts, const double* y, int64
     dperm = ptr<int32_t>(ctx->tmpC);
   }
   double* dL = ptr<double>(ctx->outL);
-  rc = blmm_scan_perms_dev(ctx, opts, ptr<double>(ctx->inY), n, ptr<double>(ctx->inG), p, dCov, dCov ? ncov : 0,
-                           ptr<double>(ctx->inK), dW, nperms, seed, dperm, ptr<double>(ctx->outH2), dL, dL + p, status);
+  void* dLp = dL + p;                       // 8-byte aligned; the fp32 kernel needs 4
+  rc = scan_perms_impl(ctx, opts, ptr<double>(ctx->inY), n, ptr<double>(ctx->inG), p, dCov, dCov ? ncov : 0,
+                       ptr<double>(ctx->inK), dW, nperms, seed, dperm, ptr<double>(ctx->outH2), dL,
+                       f32 ? nullptr : reinterpret_cast<double*>(dLp), f32 ? reinterpret_cast<float*>(dLp) : nullptr, status);
   if (rc) { hipStreamSynchronize(ctx->stream); return rc; }
   BLMM_HIP(hipMemcpyAsync(scalars_out, ctx->outH2.p, sizeof(double) * 2, hipMemcpyDeviceToHost, ctx->stream));
   if (p > 0) BLMM_HIP(hipMemcpyAsync(lod_out, dL, sizeof(double) * p, hipMemcpyDeviceToHost, ctx->stream));
-  if (p > 0 && nperms > 0) BLMM_HIP(hipMemcpyAsync(Lperms_out, dL + p, sizeof(double) * (size_t)p * nperms, hipMemcpyDeviceToHost, ctx->stream));
+  if (p > 0 && nperms > 0) BLMM_HIP(hipMemcpyAsync(Lperms_out, dLp, esz * (size_t)p * nperms, hipMemcpyDeviceToHost, ctx->stream));
   BLMM_HIP(hipStreamSynchronize(ctx->stream));
   return BLMM_OK;
+}
+
+int blmm_scan_perms(blmm_ctx* ctx, const blmm_opts* opts, const double* y, int64_t n, const double* G, int64_t p,
+                    const double* Covar, int64_t ncov, const double* K, const double* weights, int64_t nperms, uint64_t seed,
+                    const int32_t* perm_idx, double* scalars_out, double* lod_out, double* Lperms_out, blmm_status* status) {
+  return scan_perms_host(ctx, opts, y, n, G, p, Covar, ncov, K, weights, nperms, seed, perm_idx, scalars_out, lod_out,
+                         Lperms_out, false, status);
+}
+
+int blmm_scan_perms_f32(blmm_ctx* ctx, const blmm_opts* opts, const double* y, int64_t n, const double* G, int64_t p,
+                        const double* Covar, int64_t ncov, const double* K, const double* weights, int64_t nperms, uint64_t seed,
+                        const int32_t* perm_idx, double* scalars_out, double* lod_out, float* Lperms_out, blmm_status* status) {
+  return scan_perms_host(ctx, opts, y, n, G, p, Covar, ncov, K, weights, nperms, seed, perm_idx, scalars_out, lod_out,
+                         Lperms_out, true, status);
 }
 
 // ---------------------------------------------------------------------------------------------------

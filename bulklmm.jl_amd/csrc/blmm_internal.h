@@ -36,7 +36,7 @@ struct blmm_ctx {
   std::string err;
   // grow-only workspace
   blmm::DevBuf Ks, V, lam, U, Zs, Z0, Rp, Yt, Xt, panels, iyy, h2, h2idx, sig2, ell, isx, stat, gridd, misc, EllTab,
-      inY, inG, inK, inCov, inW, outL, outH2, tmpA, tmpB, tmpC, perm, r0, altbuf, logtab, lraw, wbQ, wbW, wbRk, lrT, lrC, lrL;
+      inY, inG, inK, inCov, inW, outL, outH2, tmpA, tmpB, tmpC, perm, r0, altbuf, logtab, lraw, wbQ, wbW, wbRk, lrT, lrC, lrL, xf32, pf32;
   // event sets: one per timed call since the last blmm_read_timings (grown on demand, reused afterwards)
   struct EvSet { hipEvent_t e[8]; int n; };
   std::vector<EvSet> evsets;
@@ -136,6 +136,11 @@ struct LrArgs {
   int c;
 };
 int launch_scan_lr(blmm_ctx* ctx, const LrArgs& la);
+// kernels_scan_f32.hip: fp32 permutation LOD kernel and the fp64 k-major -> fp32 fragment-major conversion
+int launch_cvt_f32(blmm_ctx* ctx, const double* M, int64_t ld_in, int rows_valid, int64_t cols_valid, float* F,
+                   int64_t ld_out, int kblocks);
+int launch_scan_f32(blmm_ctx* ctx, const float* XF, int64_t ldxf, const float* PF, int64_t ldpf, int npad, int n,
+                    int64_t p, int64_t m, const double* isx, float* L, int64_t ldL, int64_t* stat);
 // kernels_lowrank.hip
 int launch_wbasis(blmm_ctx* ctx, const double* lam, int n, double* Wk, double* Q, int* rk, int64_t* stat);
 int launch_lr_tpanels(blmm_ctx* ctx, const double* Xt, int64_t ldx, int64_t p, int n, int c, int npad, const double* Z0,

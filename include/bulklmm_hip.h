@@ -134,6 +134,18 @@ int blmm_scan_perms_dev(blmm_ctx* ctx, const blmm_opts* opts, const double* dy, 
                         int64_t nperms, uint64_t seed, const int32_t* dperm_idx, double* dscalars_out,
                         double* dlod_out, double* dLperms_out, blmm_status* status);
 
+/* fp32 permutation matrix (BASELINE.json configs[4]): the null model, rotation, panel construction and the original
+ * trait's lod_out stay fp64; the p x nperms contraction runs on the fp32 matrix cores and Lperms_out is float
+ * (p x nperms, ld = p).  Expected agreement with the fp64 path: |d| <= 1e-3 |ref| + 1e-4. */
+int blmm_scan_perms_f32(blmm_ctx* ctx, const blmm_opts* opts, const double* y, int64_t n, const double* G, int64_t p,
+                        const double* Covar, int64_t ncov, const double* K, const double* weights, int64_t nperms,
+                        uint64_t seed, const int32_t* perm_idx, double* scalars_out, double* lod_out,
+                        float* Lperms_out, blmm_status* status);
+int blmm_scan_perms_f32_dev(blmm_ctx* ctx, const blmm_opts* opts, const double* dy, int64_t n, const double* dG,
+                            int64_t p, const double* dCovar, int64_t ncov, const double* dK, const double* dweights,
+                            int64_t nperms, uint64_t seed, const int32_t* dperm_idx, double* dscalars_out,
+                            double* dlod_out, float* dLperms_out, blmm_status* status);
+
 /* ---- on-device consumer of L: column maxima (per-trait / per-permutation peak LOD and its marker, 0-based) -------
  * The reduction behind get_thresholds (src/analysis_helpers/single_trait_analysis.jl:13-23); argmax_out may be NULL. */
 int blmm_lod_colmax(blmm_ctx* ctx, const double* L, int64_t p, int64_t m, double* max_out, int64_t* argmax_out);

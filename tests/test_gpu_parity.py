@@ -244,6 +244,29 @@ def test_scan_perms_matches_oracle(blmm, ncov):
     assert_lod_close(got["L_perms"], pin["L_perms"])
 
 
+@pytest.mark.parametrize("n,p,nperms,ncov", [(79, 250, 37, 0), (130, 515, 300, 1)])
+def test_scan_perms_f32_matches_fp64(blmm, n, p, nperms, ncov):
+    """fp32 permutation kernel (BASELINE.json configs[4]): |d| <= 1e-3 |ref| + 1e-4 against the fp64
+    oracle on the shared rotation, ragged tile edges included (p, nperms not multiples of the 256 x 128 tile)."""
+    Y, G, K, Cov = make_data(n=n, p=p, m=1, seed=301 + n, ncov=ncov, bxd=(n == 79))
+    pidx = O.make_perm_idx(n, nperms, 11)
+    got = blmm.scan(Y[:, 0], G, K, Cov, permutation_test=True, nperms=nperms, perm_idx=pidx, perm_precision="f32")
+    assert got["L_perms"].dtype == np.float32 and got["L_perms"].shape == (p, nperms)
+    cov1 = np.ones((n, 1)) if Cov is None else np.hstack([np.ones((n, 1)), Cov])
+    rot = blmm.transform_rotation(Y, np.hstack([cov1, G]), K, addIntercept=False)
+    pin = O.scan(Y[:, 0], G, K, covar=cov1, addIntercept=False, permutation_test=True, nperms=nperms, perm_idx=pidx,
+                 h2_override=got["h2_null"], rotation_override=rot)
+    assert_lod_close(got["lod"], pin["lod"])                       # the original trait stays fp64
+    ref = pin["L_perms"]
+    err = np.abs(got["L_perms"].astype(np.float64) - ref)
+    assert np.all(err <= 1e-3 * np.abs(ref) + 1e-4), float(err.max())
+    # and the fp64 kernel on the same call agrees with it to the same bar
+    g64 = blmm.scan(Y[:, 0], G, K, Cov, permutation_test=True, nperms=nperms, perm_idx=pidx)
+    assert np.all(np.abs(got["L_perms"] - g64["L_perms"]) <= 1e-3 * np.abs(g64["L_perms"]) + 1e-4)
+    with pytest.raises(blmm.BulkLMMError):
+        blmm.scan(Y[:, 0], G, K, permutation_test=True, nperms=4, perm_precision="f16")
+
+
 def test_scan_single_trait_and_own_rng(blmm):
     Y, G, K, _ = make_data(p=180, m=1, seed=111)
     s = blmm.scan(Y[:, 0], G, K)
