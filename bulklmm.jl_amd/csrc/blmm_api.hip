@@ -139,6 +139,7 @@ int finish_status(blmm_ctx* ctx, blmm_status* st, Timer* tm) {
   st->jacobi_sweeps = h[ST_JACOBI_SWEEPS];
   st->jacobi_cycles = h[6]; st->jacobi_ticks_100mhz = h[7];
   st->lowrank_rank = h[8];
+  if (h[8] < 0) return fail(ctx, BLMM_ERR_HIP, "weight-basis kernel: a workgroup timed out at the grid barrier");
   { double r2; std::memcpy(&r2, &h[9], sizeof(double)); st->lowrank_resid = std::sqrt(r2 < 0 ? 0.0 : r2); }
   if (tm && tm->set && tm->set->n >= 2) {
     double t[6];
@@ -164,6 +165,8 @@ int eigen_rocsolver(blmm_ctx* ctx, double* A, int n, double* lraw, int64_t* stat
       ctx->rb_destroy = reinterpret_cast<int (*)(void*)>(dlsym(ctx->rb_lib, "rocblas_destroy_handle"));
       ctx->rb_set_stream = reinterpret_cast<int (*)(void*, hipStream_t)>(dlsym(ctx->rb_lib, "rocblas_set_stream"));
       ctx->rs_dsyevd = reinterpret_cast<int (*)(void*, int, int, int, double*, int, double*, double*, int*)>(dlsym(ctx->rs_lib, "rocsolver_dsyevd"));
+      ctx->rb_dgemm = reinterpret_cast<int (*)(void*, int, int, int, int, int, const double*, const double*, int, const double*, int,
+                                               const double*, double*, int)>(dlsym(ctx->rb_lib, "rocblas_dgemm"));
       if (create && ctx->rb_destroy && ctx->rb_set_stream && ctx->rs_dsyevd) {
         if (create(&ctx->rb_handle) != 0) ctx->rb_handle = nullptr;
       }
@@ -179,6 +182,24 @@ int eigen_rocsolver(blmm_ctx* ctx, double* A, int n, double* lraw, int64_t* stat
   if (st != 0) return fail(ctx, BLMM_ERR_HIP, "rocsolver_dsyevd failed with status " + std::to_string(st));
   (void)stat;
   return BLMM_OK;
+}
+
+// Out (k-major, npad x ldo) = R * In for large n: a plain GEMM, handed to rocBLAS when it is loaded anyway (n beyond
+// the Jacobi range, where rocSOLVER did the eigen-decomposition); k_rotate otherwise.  In column-major terms
+// Out' (ncols x npad, ld = ldo) = In' (n x ncols, ld = n)' * R' with R = Rp viewed column-major (npad x n, ld = ldr).
+int rotate_any(blmm_ctx* ctx, bool use_blas, const double* Rp, int ldr, int n, int npad, const double* In, int64_t ncols,
+               double* Out, int64_t ldo, int64_t ncols_pad) {
+  if (use_blas && ctx->rb_handle && ctx->rb_dgemm && ncols >= 256 && ncols < 0x7fffffffLL && ldo < 0x7fffffffLL) {
+    if (ncols_pad > ncols)   // the pad columns of every row must read as zero
+      BLMM_HIP(hipMemset2DAsync(Out + ncols, sizeof(double) * ldo, 0, sizeof(double) * (ncols_pad - ncols), npad, ctx->stream));
+    const double one = 1.0, zero = 0.0;
+    if (ctx->rb_set_stream(ctx->rb_handle, ctx->stream) != 0) return fail(ctx, BLMM_ERR_HIP, "rocblas_set_stream failed");
+    const int st = ctx->rb_dgemm(ctx->rb_handle, /*transpose*/ 112, /*transpose*/ 112, (int)ncols, npad, n, &one, In, n, Rp, ldr,
+                                 &zero, Out, (int)ldo);
+    if (st != 0) return fail(ctx, BLMM_ERR_HIP, "rocblas_dgemm failed with status " + std::to_string(st));
+    return BLMM_OK;
+  }
+  return launch_rotate(ctx, Rp, ldr, n, npad, In, ncols, Out, ldo, ncols_pad);
 }
 
 // design -> eigen -> rotation of Y and G.  centered = 1: the rotation also removes the unweighted projection
@@ -217,9 +238,11 @@ int prepare(blmm_ctx* ctx, const blmm_opts* o, const double* dY, int64_t n, int6
   static const char* eig_env = getenv("BLMM_EIGEN");
   const bool want_rs = eig_env ? (std::strcmp(eig_env, "rocsolver") == 0 && n > jacobi_lds_max_n())
                                : n > 384;
+  bool used_rs = false;
   if (want_rs && !(eig_env && std::strcmp(eig_env, "jacobi") == 0) &&
       eigen_rocsolver(ctx, ptr<double>(ctx->Ks), (int)n, ptr<double>(ctx->lraw), P.stat) == BLMM_OK) {
     evec = ptr<double>(ctx->Ks);  // dsyevd leaves the eigenvectors in place of K
+    used_rs = true;
   } else {
     if (n > 2048) return fail(ctx, BLMM_ERR_UNSUPPORTED, "n > 2048 needs librocsolver.so for the eigen-decomposition");
     if ((rc = launch_jacobi(ctx, ptr<double>(ctx->Ks), ptr<double>(ctx->V), (int)n, ptr<double>(ctx->lraw), P.stat))) return rc;
@@ -242,8 +265,10 @@ int prepare(blmm_ctx* ctx, const blmm_opts* o, const double* dY, int64_t n, int6
     ctx->stream = main_stream;
     if (rc) return rc;
   }
-  if ((rc = launch_rotate(ctx, ptr<double>(ctx->Rp), P.ldr, (int)n, P.npad, dY, m, P.Yt, P.ldy, P.ldy))) return rc;
-  if ((rc = launch_rotate(ctx, ptr<double>(ctx->Rp), P.ldr, (int)n, P.npad, dG, p, P.Xt, P.ldx, P.ldx))) return rc;
+  static const char* rot_env = getenv("BLMM_ROTATE");   // "own": k_rotate for every n (A/B testing)
+  const bool blas = used_rs && !(rot_env && std::strcmp(rot_env, "own") == 0);
+  if ((rc = rotate_any(ctx, blas, ptr<double>(ctx->Rp), P.ldr, (int)n, P.npad, dY, m, P.Yt, P.ldy, P.ldy))) return rc;
+  if ((rc = rotate_any(ctx, blas, ptr<double>(ctx->Rp), P.ldr, (int)n, P.npad, dG, p, P.Xt, P.ldx, P.ldx))) return rc;
   tm.mark();
   return BLMM_OK;
 }

@@ -46,6 +46,8 @@ struct blmm_ctx {
   int (*rb_destroy)(void*) = nullptr;
   int (*rb_set_stream)(void*, hipStream_t) = nullptr;
   int (*rs_dsyevd)(void*, int, int, int, double*, int, double*, double*, int*) = nullptr;
+  int (*rb_dgemm)(void*, int, int, int, int, int, const double*, const double*, int, const double*, int, const double*,
+                  double*, int) = nullptr;
   // side stream: work that only depends on the eigenvalues / rotated markers runs beside the per-trait Brent search
   hipStream_t side = nullptr;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_xt = nullptr;

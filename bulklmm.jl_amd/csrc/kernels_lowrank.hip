@@ -13,6 +13,8 @@
 #include "blmm_internal.h"
 #include "fastmath.h"
 #include <cmath>
+#include <cstdlib>
+#include <cstring>
 
 namespace blmm {
 
@@ -165,6 +167,150 @@ __global__ void __launch_bounds__(WB_NS * TPS) k_wbasis(const double* __restrict
   if (t == 0) { rk[0] = R; rk[1] = (R + 3) / 4; stat[8] = R; }
 }
 
+// Multi-workgroup variant for n beyond the single-workgroup LDS budget.  The 256 sample columns are dealt S per
+// workgroup and stay in LDS (one wave per column: rows across the lanes); every workgroup runs the SAME greedy
+// iteration and builds the SAME Q (bitwise: identical inputs, identical instruction sequence), so the only exchange per
+// basis vector is "which column is the pivot": each workgroup publishes its best residual and that column, ONE grid
+// barrier (monotonic counter, agent-scope release/acquire), then all read the G candidates and take the same winner.
+// G <= 64 workgroups of one CU each: co-resident on any MI355X partition that runs the scan at all; a workgroup that
+// waits longer than 2^22 polls (seconds) gives up (rk = {-1, 0}: the scan writes NaN and blmm_status reports the failure)
+// rather than hang the device.
+struct WbExch {                 // global exchange area, double-buffered by iteration parity
+  double* val;                  // [2][G]   best residual norm^2 of the workgroup
+  double* col;                  // [2][G][n] the corresponding (deflated) sample column
+  unsigned int* cnt;            // arrival counter (zeroed by the launcher)
+};
+
+__global__ void __launch_bounds__(1024) k_wbasis_mw(const double* __restrict__ lam, int n, int S, int qcap,
+                                                    double* __restrict__ Q, int* __restrict__ rk, int64_t* stat,
+                                                    WbExch x) {
+  extern __shared__ __attribute__((aligned(16))) double sh[];
+  const int G = gridDim.x, g = blockIdx.x, NS = G * S;
+  double* sq = sh;                       // n
+  double* sd = sh + n;                   // n
+  double* Ql = sh + 2 * n;               // qcap x n
+  double* Wl = Ql + (size_t)qcap * n;    // S x n, sample-major
+  __shared__ double s_res[16], s_red[16], s_val[64];
+  __shared__ int s_i0, s_i1;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6, NT = blockDim.x, nwave = NT >> 6;
+  // negative eigenvalues: identity basis (see k_wbasis); every workgroup takes the same branch, no barrier involved
+  if (t == 0) s_i0 = 0;
+  __syncthreads();
+  for (int k = t; k < n; k += NT) if (lam[k] < -1e-12) s_i0 = 1;
+  __syncthreads();
+  if (s_i0) {
+    for (size_t e = (size_t)g * NT + t; e < (size_t)n * n; e += (size_t)G * NT) Q[e] = ((e / n) == (e % n)) ? 1.0 : 0.0;
+    if (g == 0 && t == 0) { rk[0] = n; rk[1] = (n + 3) / 4; stat[8] = n; }
+    return;
+  }
+  // sample columns of this workgroup: global sample index s = g * S + ss (the log-spaced deltas of k_wbasis)
+  for (int ss = wave; ss < S; ss += nwave) {
+    const int s = g * S + ss;
+    const double delta = (s == 0) ? 0.0 : exp(2.302585092994046 * (-6.0 + 15.0 * (double)(s - 1) / (double)(NS - 2)));
+    double nrm = 0.0;
+    for (int k = lane; k < n; k += 64) { const double w = 1.0 / fma(delta, fabs(lam[k]), 1.0); Wl[(size_t)ss * n + k] = w; nrm = fma(w, w, nrm); }
+    nrm = wave_sum(nrm);
+    const double inv = 1.0 / sqrt(nrm);
+    for (int k = lane; k < n; k += 64) Wl[(size_t)ss * n + k] *= inv;
+    if (lane == 0) s_res[ss] = 1.0;
+  }
+  const double tol2 = 2e-31 * (double)n;
+  int R = 0;
+  bool aborted = false;
+  for (; R < n; ++R) {
+    const int par = R & 1;
+    __syncthreads();
+    // publish this workgroup's best column
+    if (t == 0) {
+      int b = 0;
+      for (int ss = 1; ss < S; ++ss) if (s_res[ss] > s_res[b]) b = ss;
+      s_i0 = b;
+      x.val[par * G + g] = s_res[b];
+    }
+    __syncthreads();
+    {
+      const double* wb = Wl + (size_t)s_i0 * n;
+      double* dst = x.col + ((size_t)par * G + g) * n;
+      for (int k = t; k < n; k += NT) dst[k] = wb[k];
+    }
+    __threadfence();
+    __syncthreads();
+    if (t == 0) {
+      __hip_atomic_fetch_add(x.cnt, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+      const unsigned int target = (unsigned int)G * (unsigned int)(R + 1);
+      int ok = 0;
+      for (int spin = 0; spin < (1 << 22); ++spin) {
+        if (__hip_atomic_load(x.cnt, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) >= target) { ok = 1; break; }
+        __builtin_amdgcn_s_sleep(2);
+      }
+      s_i1 = ok;
+    }
+    __syncthreads();
+    if (!s_i1) { aborted = true; break; }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    // the same winner in every workgroup: largest residual, lowest workgroup (= lowest sample index) on ties
+    if (t < G) s_val[t] = x.val[par * G + t];
+    __syncthreads();
+    if (t == 0) {
+      int b = 0;
+      for (int w = 1; w < G; ++w) if (s_val[w] > s_val[b]) b = w;
+      s_i0 = b;
+    }
+    __syncthreads();
+    const double mx = s_val[s_i0];
+    if (!(mx > tol2)) break;
+    {
+      const double* src = x.col + ((size_t)par * G + s_i0) * n;
+      for (int k = t; k < n; k += NT) sq[k] = src[k];
+    }
+    __syncthreads();
+    for (int pass = 0; pass < 2; ++pass) {     // classical Gram-Schmidt twice (as k_wbasis)
+      for (int r = wave; r < R; r += nwave) {
+        const double* qt = (r < qcap) ? Ql + (size_t)r * n : Q + (size_t)r * n;
+        double d = 0.0;
+        for (int k = lane; k < n; k += 64) d = fma(qt[k], sq[k], d);
+        d = wave_sum(d);
+        if (lane == 0) sd[r] = d;
+      }
+      __syncthreads();
+      for (int k = t; k < n; k += NT) {
+        double v = sq[k];
+        const int rl = R < qcap ? R : qcap;
+        for (int r = 0; r < rl; ++r) v = fma(-sd[r], Ql[(size_t)r * n + k], v);
+        for (int r = rl; r < R; ++r) v = fma(-sd[r], Q[(size_t)r * n + k], v);
+        sq[k] = v;
+      }
+      __syncthreads();
+    }
+    double pn = 0.0;
+    for (int k = t; k < n; k += NT) pn = fma(sq[k], sq[k], pn);
+    pn = wave_sum(pn);
+    if (lane == 0) s_red[wave] = pn;
+    __syncthreads();
+    double tot = 0.0;
+    for (int w = 0; w < nwave; ++w) tot += s_red[w];
+    const double qn = 1.0 / sqrt(tot);
+    if (!(tot > 1e-8 * mx)) break;             // noise pivot: the family is exhausted (uniform: same data everywhere)
+    // every workgroup writes the same bytes of Q[R] (benign) and reads back only what its own threads wrote
+    for (int k = t; k < n; k += NT) { const double v = sq[k] * qn; sq[k] = v; Q[(size_t)R * n + k] = v; if (R < qcap) Ql[(size_t)R * n + k] = v; }
+    __syncthreads();
+    for (int ss = wave; ss < S; ss += nwave) {   // deflate this workgroup's sample columns, one wave per column
+      double* w = Wl + (size_t)ss * n;
+      double c = 0.0;
+      for (int k = lane; k < n; k += 64) c = fma(sq[k], w[k], c);
+      c = wave_sum(c);
+      double r2 = 0.0;
+      for (int k = lane; k < n; k += 64) { const double v = fma(-c, sq[k], w[k]); w[k] = v; r2 = fma(v, v, r2); }
+      r2 = wave_sum(r2);
+      if (lane == 0) s_res[ss] = r2;
+    }
+  }
+  if (g == 0 && t == 0) {
+    if (aborted) { rk[0] = -1; rk[1] = 0; stat[8] = -1; }
+    else { rk[0] = R; rk[1] = (R + 3) / 4; stat[8] = R; }
+  }
+}
+
 int launch_wbasis(blmm_ctx* ctx, const double* lam, int n, double* Wk, double* Q, int* rk, int64_t* stat) {
   // LDS budget (156 KB dynamic): two work vectors, the sample columns when 256, 192 or 128 of them fit (padded to
   // ns + 16 per row) beside at least 16 mirrored basis vectors, then as many mirrored basis vectors as fit (<= WB_QCAP)
@@ -173,14 +319,36 @@ int launch_wbasis(blmm_ctx* ctx, const double* lam, int n, double* Wk, double* Q
   int ns = 0;
   for (int cand : {256, 192, 128})
     if (work + row * (size_t)(cand + 16) + row * 16 <= budget) { ns = cand; break; }
+  static const char* mw_env = getenv("BLMM_WBASIS");   // "single": never take the multi-workgroup variant (A/B testing)
   if (ns) {
     const size_t wbytes = row * (size_t)(ns + 16);
     const int qcap = (int)std::min<size_t>(WB_QCAP, (budget - work - wbytes) / row);
     const size_t lds = work + row * qcap + wbytes;
     BLMM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wbasis<true, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL((k_wbasis<true, 4>), dim3(1), dim3(ns * 4), lds, ctx->stream, lam, n, Wk, Q, rk, stat, qcap);
-  } else {
-    // sample columns in global memory (L2-resident)
+    KCHECK();
+    return BLMM_OK;
+  }
+  // multi-workgroup variant: S = 16, 8 or 4 sample columns per workgroup (G = 16, 32, 64), at least 2 mirrored basis rows
+  int S = 0;
+  for (int cand : {16, 8, 4})
+    if (work + row * (size_t)cand + row * 2 <= budget) { S = cand; break; }
+  if (S && !(mw_env && std::strcmp(mw_env, "single") == 0)) {
+    const int G = 256 / S;
+    const int qcap = (int)std::min<size_t>(WB_QCAP, (budget - work - row * S) / row);
+    const size_t lds = work + row * qcap + row * S;
+    // exchange area inside the sample workspace Wk (n x 272 doubles >= 2 G (n + 1) doubles + the counter)
+    WbExch x;
+    x.val = Wk; x.col = Wk + 2 * G; x.cnt = reinterpret_cast<unsigned int*>(Wk + 2 * G + (size_t)2 * G * n);
+    BLMM_HIP(hipMemsetAsync(x.cnt, 0, sizeof(unsigned int) * 2, ctx->stream));
+    BLMM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wbasis_mw), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(k_wbasis_mw, dim3(G), dim3(1024), lds, ctx->stream, lam, n, S, qcap, Q, rk, stat, x);
+    KCHECK();
+    return BLMM_OK;
+  }
+  {
+    // sample columns in global memory (L2-resident), one workgroup: slow (~0.1 ms per basis vector) but has no
+    // co-residency requirement
     const int qcap = (int)std::min<size_t>(WB_QCAP, (budget - work) / row);
     const size_t lds = work + row * qcap;
     BLMM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wbasis<false, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));

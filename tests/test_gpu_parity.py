@@ -332,7 +332,7 @@ def test_larger_sample_sizes(blmm, n):
                     reason="rocSOLVER's first use in a process takes minutes on this image; set BLMM_TEST_ROCSOLVER=1")
 def test_rocsolver_eigen_path(blmm):
     """n > 384 takes rocSOLVER dsyevd for the kinship eigen-decomposition."""
-    Y, G, K, _ = make_data(n=500, p=100, m=9, seed=77, bxd=False)
+    Y, G, K, _ = make_data(n=500, p=300, m=9, seed=77, bxd=False)   # p >= 256: the marker rotation goes through rocBLAS dgemm
     got = blmm.bulkscan_null(Y, G, K)
     check_null_exact(got, Y, G, K)
 
