@@ -56,7 +56,10 @@ __device__ __forceinline__ LodPoly make_lod_poly(double scale) {
   const double s = scale * BLMM_INV_LN10;
   LodPoly p;
   p.k2 = scale * BLMM_LOG10_2;
-  p.c1 = s; p.c2 = -s / 2.0; p.c3 = s / 3.0; p.c4 = -s / 4.0; p.c5 = s / 5.0; p.c6 = -s / 6.0; p.c7 = s / 7.0;
+  // reciprocals as constants: an IEEE division by 3, 5, 6, 7 costs ~25 instructions each, once per tile, for a last-bit
+  // difference in coefficients whose terms are <= 2^-24 of the result
+  p.c1 = s; p.c2 = -s * 0.5; p.c3 = s * (1.0 / 3.0); p.c4 = -s * 0.25; p.c5 = s * (1.0 / 5.0); p.c6 = -s * (1.0 / 6.0);
+  p.c7 = s * (1.0 / 7.0);
   return p;
 }
 __device__ __forceinline__ double fast_lod(double x, const dpair* __restrict__ lds, const LodPoly& P) {

@@ -185,6 +185,7 @@ __global__ void __launch_bounds__(64 * W2 * W2, 2) k_scan(ScanArgs a, int ntile_
     for (int reg = 0; reg < 4; ++reg) {
       const int64_t trait = t0 + MB * (kk + 4 * reg) + mb;
       if (trait >= a.m) continue;
+      // (prefetching these before the K loop costs 64 VGPRs = half the occupancy: 1.15 ms instead of 0.96 ms at BXD)
       double sc[NB];
       if constexpr (TABLE) {
         const int64_t b = a.bin ? (int64_t)a.bin[trait] : 0;
@@ -271,12 +272,18 @@ template <int C, int MB, int NB>
 __global__ void __launch_bounds__(256, 2) k_scan_lr(LrArgs la, int ntile_i, int64_t nwg) {
   const ScanArgs& a = la.s;
   constexpr int NACC = 2 + C;
+  constexpr int NL = C * (C + 1) / 2;
   __shared__ dpair s_log[BLMM_LOG_TABLE_N];
+  __shared__ double s_li[NL][32 * MB];      // packed L_j^-1 of the tile's traits (read in the epilogue)
   stage_lod_table(s_log, a.logtab, -0.5 * (double)a.n);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int64_t bid = xcd_swizzle(blockIdx.x, nwg);
   int64_t tile_t; int tile_i;
   tile_of(bid, nwg / ntile_i, ntile_i, tile_t, tile_i);
+  // staged here (Ls is padded to ldp, a multiple of the tile): in the epilogue these loads would sit behind the
+  // stores of the previous row (possible aliasing) and expose one global-memory round trip per row
+  for (int e = threadIdx.x; e < NL * 32 * MB; e += 256)
+    s_li[e / (32 * MB)][e % (32 * MB)] = la.Ls[(int64_t)(e / (32 * MB)) * a.ldp + tile_t * (32 * MB) + (e % (32 * MB))];
   const int wt = wave >> 1, wi = wave & 1;
   const int64_t t0 = tile_t * (32 * MB) + wt * (16 * MB);
   const int64_t i0 = (int64_t)tile_i * (32 * NB) + wi * (16 * NB);
@@ -385,7 +392,6 @@ __global__ void __launch_bounds__(256, 2) k_scan_lr(LrArgs la, int ntile_i, int6
   const LodPoly lp = make_lod_poly(-0.5 * (double)a.n);
   const int64_t ibase = i0 + NB * r;
   int nnan = 0;
-  constexpr int NL = C * (C + 1) / 2;
 #pragma unroll
   for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
@@ -394,7 +400,7 @@ __global__ void __launch_bounds__(256, 2) k_scan_lr(LrArgs la, int ntile_i, int6
       if (trait >= a.m) continue;
       double li[NL];
 #pragma unroll
-      for (int e = 0; e < NL; ++e) li[e] = la.Ls[(int64_t)e * a.ldp + trait];
+      for (int e = 0; e < NL; ++e) li[e] = s_li[e][wt * (16 * MB) + MB * (kk + 4 * reg) + mb];
       double out[NB];
 #pragma unroll
       for (int nb = 0; nb < NB; ++nb) {
