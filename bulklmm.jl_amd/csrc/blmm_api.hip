@@ -232,7 +232,7 @@ int prepare(blmm_ctx* ctx, const blmm_opts* o, const double* dY, int64_t n, int6
   tm.mark();
   if ((rc = launch_design(ctx, dK, dCovar, (int)ncov, add_int, dweights, (int)n, ptr<double>(ctx->Ks), ptr<double>(ctx->Zs)))) return rc;
   const double* evec = ptr<double>(ctx->V);
-  // n <= 92: LDS Jacobi; up to 384: the single-workgroup global-memory Jacobi (tens to hundreds of ms, but no
+  // n <= 124: LDS Jacobi; up to 384: the single-workgroup global-memory Jacobi (tens to hundreds of ms, but no
   // library start-up); beyond: rocSOLVER dsyevd (its first use in a process costs ~2 min of code-object loading on
   // this image, afterwards ~12 ms at n = 500).  BLMM_EIGEN=rocsolver|jacobi overrides the choice.
   static const char* eig_env = getenv("BLMM_EIGEN");

@@ -79,10 +79,17 @@ __device__ __forceinline__ double nr_rcp(double x) {
 // instead of changing the index pairs, every round moves the data by the fixed permutation
 //     pi: top_0 stays, top_s -> top_{s+1}, top_last -> bottom_last, bottom_s -> bottom_{s-1}, bottom_0 -> top_1
 // (rows and columns of A, columns of V), ping-ponging between two LDS copies.  One thread per 2x2 block between
-// pair slots (s1 <= s2): two 16-byte reads, B' = J1' B J2, eight 8-byte writes to round-independent addresses
-// (only the upper triangle is stored: half the LDS writes, which bound the round).  One lane per slot computes (c, s) from its 2x2 diagonal block, no reductions.
-constexpr int JAC_NMAX = 92;   // 2 ping-pong copies of A (2 N^2 doubles) + V slices must fit 160 KB of LDS
-constexpr int JAC_NWG = 8;
+// pair slots (s1 < s2): B' = J1' B J2, four 8-byte reads and four 8-byte writes to round-independent addresses.
+// One lane per slot computes (c, s) from its 2x2 diagonal block, no reductions.
+//
+// LDS layout of A ("planar blocks", upper triangle only): the four entries of the off-diagonal block (s1, s2) live in
+// four planes at the SAME index tri(s1, s2) = s2 (s2 - 1)/2 + s1 -- which is also the index of the thread that owns
+// the block -- and the diagonal blocks in three arrays (a_pp, a_qq, a_pq per slot).  Consecutive lanes therefore
+// read consecutive 8-byte words of each plane, and since pi moves tops up and bottoms down by one slot, they also
+// write consecutive words of the destination planes: reads and writes are bank-conflict free (the previous
+// column-major layout, 16-byte lane stride, ran the round at ~2.7x the LDS-throughput bound, which is what limits it).
+constexpr int JAC_NMAX = 124;  // NP2 = 62: 1891 off-diagonal blocks on 2 x 960 worker threads; ~140 KB of LDS
+constexpr int JAC_NWG = 20;    // >= 20: at n = 79 the V items + the blocks are one item per worker thread
 
 __device__ __forceinline__ int jac_pi(int pos, int NP2) {
   if (NP2 <= 1 || pos == 0) return pos;
@@ -97,25 +104,34 @@ __global__ void __launch_bounds__(1024) k_jacobi_lds(const double* __restrict__ 
   __shared__ double s_anorm;
   const int tid = threadIdx.x, nt = blockDim.x;
   const unsigned long long dbg_t0 = __builtin_amdgcn_s_memtime(), dbg_r0 = __builtin_amdgcn_s_memrealtime();
-  const int N = n + (n & 1), NP2 = N / 2, ld = N + 1;       // odd ld: row- and column-strided LDS walks are conflict-free
+  const int N = n + (n & 1), NP2 = N / 2, ld = N + 1;       // ld: leading dimension of the V slices (odd)
   const int rows_per = (n + gridDim.x - 1) / gridDim.x;
   const int r0 = blockIdx.x * rows_per, r1 = min(n, r0 + rows_per), nr = max(0, r1 - r0);
   // All buffers are addressed as smem[offset] so that hipcc keeps them in the LDS address space (a runtime-selected
   // pointer array degrades every access to flat_load/flat_store).
-  //   A ping/pong: column-major upper triangle, element (row <= col) at col*ld + row;  V slices: row-major Vs[r*ld + pos]
-  const int AO = N * ld;                              // size of one A copy
+  //   A ping/pong: planar blocks (see above);  V slices: row-major Vs[r*ld + pos]
+  const int PL = (NP2 * (NP2 - 1) / 2 + 1) & ~1;      // plane size (off-diagonal blocks), even
+  const int DG = 4 * PL;                              // a_pp[NP2], a_qq[NP2], a_pq[NP2] behind the planes
+  const int AO = (4 * PL + 3 * NP2 + 1) & ~1;         // size of one A copy
   const int VO = rows_per * ld;                       // size of one V slice copy
   const int V0 = 2 * AO;                              // first V copy
   const int REC = (2 * AO + 2 * VO + 1) & ~1;         // NP2 x 2 : (c, s) per slot, 16-byte aligned
   const int REL = REC + 4 * NP2;                      // NP2 (behind the two (c, s) tables)
-  for (int e = tid; e < 2 * N * ld + 2 * rows_per * ld; e += nt) smem[e] = 0.0;
+  // offset of element (r, c) of the symmetric matrix inside one A copy
+  auto aidx = [&](int r, int c) -> int {
+    if (r > c) { const int t = r; r = c; c = t; }
+    const int sr = r >> 1, sc = c >> 1;
+    if (sr == sc) return DG + ((r == c) ? ((r & 1) ? NP2 + sr : sr) : 2 * NP2 + sr);
+    return ((r & 1) * 2 + (c & 1)) * PL + sc * (sc - 1) / 2 + sr;
+  };
+  for (int e = tid; e < 2 * AO + 2 * VO; e += nt) smem[e] = 0.0;
   __syncthreads();
-  for (int e = tid; e < n * n; e += nt) { const int i = e % n, j = e / n; if (i <= j) smem[j * ld + i] = Ag[e]; }
+  for (int e = tid; e < n * n; e += nt) { const int i = e % n, j = e / n; if (i <= j) smem[aidx(i, j)] = Ag[e]; }
   for (int r = tid; r < nr; r += nt) smem[V0 + r * ld + (r0 + r)] = 1.0;
   __syncthreads();
   if (tid == 0) {
     double m = 0.0;
-    for (int i = 0; i < n; ++i) m = fmax(m, fabs(smem[i * ld + i]));
+    for (int i = 0; i < n; ++i) m = fmax(m, fabs(smem[aidx(i, i)]));
     s_anorm = m;
   }
   __syncthreads();
@@ -124,12 +140,13 @@ __global__ void __launch_bounds__(1024) k_jacobi_lds(const double* __restrict__ 
   const double floor2 = (eps * s_anorm) * (eps * s_anorm);
   // ---- fixed thread -> work maps (identical in every round) -------------------------------------------
   const int nblk = NP2 * (NP2 - 1) / 2;                 // off-diagonal slot pairs s1 < s2 (diagonal blocks: phase 1)
-  constexpr int MAXB = 2;                               // blocks per thread: NP2 <= 46 -> nblk <= 1081 <= 2048
-  int b_s1[MAXB], b_s2[MAXB], b_src0[MAXB], b_src1[MAXB], b_dst[MAXB][4];
+  constexpr int MAXB = 2;                               // blocks per thread: NP2 <= 62 -> nblk <= 1891 <= 2 x 960
+  const int NW = nt - 64;                               // worker threads (the last wave is reserved for the angle lanes)
+  int b_s1[MAXB], b_s2[MAXB], b_src[MAXB], b_dst[MAXB][4];
 #pragma unroll
   for (int u = 0; u < MAXB; ++u) {
-    const int b = tid + u * nt;
-    b_s1[u] = -1; b_s2[u] = 0; b_src0[u] = b_src1[u] = 0;
+    const int b = (tid < NW) ? tid + u * NW : nblk;
+    b_s1[u] = -1; b_s2[u] = 0; b_src[u] = 0;
 #pragma unroll
     for (int w = 0; w < 4; ++w) b_dst[u][w] = 0;
     if (b < nblk) {
@@ -138,17 +155,15 @@ __global__ void __launch_bounds__(1024) k_jacobi_lds(const double* __restrict__ 
       while ((row + 1) * (row + 2) / 2 <= b) ++row;
       const int s2 = row + 1, s1 = b - row * (row + 1) / 2;   // s1 < s2
       b_s1[u] = s1; b_s2[u] = s2;
-      b_src0[u] = (2 * s2) * ld + 2 * s1;                // column 2*s2,   rows 2*s1, 2*s1+1
-      b_src1[u] = (2 * s2 + 1) * ld + 2 * s1;            // column 2*s2+1, rows 2*s1, 2*s1+1
+      b_src[u] = b;                                       // = tri(s1, s2): the block's index in every plane
       const int rp = jac_pi(2 * s1, NP2), rq = jac_pi(2 * s1 + 1, NP2), cp = jac_pi(2 * s2, NP2), cq = jac_pi(2 * s2 + 1, NP2);
-      // only the upper triangle is stored: element (r, c) lives at max(r,c)*ld + min(r,c)
-      b_dst[u][0] = max(rp, cp) * ld + min(rp, cp); b_dst[u][1] = max(rp, cq) * ld + min(rp, cq);
-      b_dst[u][2] = max(rq, cp) * ld + min(rq, cp); b_dst[u][3] = max(rq, cq) * ld + min(rq, cq);
+      b_dst[u][0] = aidx(rp, cp); b_dst[u][1] = aidx(rp, cq);
+      b_dst[u][2] = aidx(rq, cp); b_dst[u][3] = aidx(rq, cq);
     }
   }
   // V items (slot, local row), dealt from the last thread downwards
   const int nvit = NP2 * nr;
-  const int nvthr = nt - 64;                            // the last wave is reserved for the angle lanes
+  const int nvthr = NW;
   const int vitem = (tid < nvthr) ? nvthr - 1 - tid : -1;
   int v_slot = -1, v_src = 0, v_d0 = 0, v_d1 = 0;
   if (vitem >= 0 && vitem < nvit) {
@@ -166,18 +181,19 @@ __global__ void __launch_bounds__(1024) k_jacobi_lds(const double* __restrict__ 
   // the angle wave runs one long dependent fp64 chain per round and shares its SIMD with three block waves: let it win
   // the issue arbitration (cdna_hip_programming.md T5, static form)
   if (__builtin_amdgcn_readfirstlane(tid >> 6) == (nt >> 6) - 1) __builtin_amdgcn_s_setprio(3);
-  int d_pp = 0, d_qq = 0, d_pq = 0;                     // where slot at's diagonal block goes (upper triangle)
+  int d_pp = 0, d_qq = 0, d_pq = 0;                     // where slot at's diagonal block goes
   int o_pp = 0, o_qq = 0, o_pq = 0;                     // ... and where it sits now
-  int sa = 0, sb = 0, ia = 0, ib = 0, sx = 0, sy = 0, ix = 0, iy = 0, xc0 = 0, xc1 = 0;
+  int sa = 0, sb = 0, ia = 0, ib = 0, ix = 0, iy = 0, xb = 0;
   if (angle_lane) {
     const int rp = jac_pi(2 * at, NP2), rq = jac_pi(2 * at + 1, NP2);
-    d_pp = rp * ld + rp; d_qq = rq * ld + rq; d_pq = max(rp, rq) * ld + min(rp, rq);
-    o_pp = (2 * at) * ld + 2 * at; o_qq = (2 * at + 1) * ld + 2 * at + 1; o_pq = (2 * at + 1) * ld + 2 * at;
+    d_pp = aidx(rp, rp); d_qq = aidx(rq, rq); d_pq = aidx(rp, rq);
+    o_pp = DG + at; o_qq = DG + NP2 + at; o_pq = DG + 2 * NP2 + at;
     int pa = 0, pb = 0;                                 // pre-images of positions 2*at, 2*at+1 under pi
     for (int pos = 0; pos < N; ++pos) { const int q = jac_pi(pos, NP2); if (q == 2 * at) pa = pos; if (q == 2 * at + 1) pb = pos; }
     sa = pa >> 1; ia = pa & 1; sb = pb >> 1; ib = pb & 1;
+    int sx, sy;
     if (sa < sb) { sx = sa; ix = ia; sy = sb; iy = ib; } else { sx = sb; ix = ib; sy = sa; iy = ia; }
-    xc0 = (2 * sy) * ld + 2 * sx; xc1 = (2 * sy + 1) * ld + 2 * sx;
+    xb = sy * (sy - 1) / 2 + sx;                        // the block between the two source slots, in every plane
   }
   const int REC1 = REC + 2 * NP2;                       // second (c, s) table (ping-pong with the A copies)
   auto angle_of = [&](double app, double aqq, double apq, double& c, double& sn, double& rel) {
@@ -214,8 +230,8 @@ __global__ void __launch_bounds__(1024) k_jacobi_lds(const double* __restrict__ 
         if (b_s1[u] >= 0) {
           const dpair cs1 = *reinterpret_cast<const dpair*>(rec + 2 * b_s1[u]);
           const dpair cs2 = *reinterpret_cast<const dpair*>(rec + 2 * b_s2[u]);
-          const dpair x0 = (dpair){A[b_src0[u]], A[b_src0[u] + 1]};   // (b00, b10): column 2*s2
-          const dpair x1 = (dpair){A[b_src1[u]], A[b_src1[u] + 1]};   // (b01, b11): column 2*s2+1
+          const dpair x0 = (dpair){A[b_src[u]], A[2 * PL + b_src[u]]};            // (b00, b10): column 2*s2
+          const dpair x1 = (dpair){A[PL + b_src[u]], A[3 * PL + b_src[u]]};       // (b01, b11): column 2*s2+1
           const double c1 = cs1[0], sn1 = cs1[1], c2 = cs2[0], sn2 = cs2[1];
           const double t00 = fma(c2, x0[0], -sn2 * x1[0]), t01 = fma(sn2, x0[0], c2 * x1[0]);
           const double t10 = fma(c2, x0[1], -sn2 * x1[1]), t11 = fma(sn2, x0[1], c2 * x1[1]);
@@ -257,11 +273,11 @@ __global__ void __launch_bounds__(1024) k_jacobi_lds(const double* __restrict__ 
         const dpair ca = *reinterpret_cast<const dpair*>(rec + 2 * sa);
         const dpair cb = *reinterpret_cast<const dpair*>(rec + 2 * sb);
         double a_pp, a_qq, b_pp, b_qq;
-        rot_diag(ca[0], ca[1], A[(2 * sa) * ld + 2 * sa], A[(2 * sa + 1) * ld + 2 * sa + 1], A[(2 * sa + 1) * ld + 2 * sa], a_pp, a_qq);
-        rot_diag(cb[0], cb[1], A[(2 * sb) * ld + 2 * sb], A[(2 * sb + 1) * ld + 2 * sb + 1], A[(2 * sb + 1) * ld + 2 * sb], b_pp, b_qq);
+        rot_diag(ca[0], ca[1], A[DG + sa], A[DG + NP2 + sa], A[DG + 2 * NP2 + sa], a_pp, a_qq);
+        rot_diag(cb[0], cb[1], A[DG + sb], A[DG + NP2 + sb], A[DG + 2 * NP2 + sb], b_pp, b_qq);
         const double napp = ia ? a_qq : a_pp, naqq = ib ? b_qq : b_pp;
         const dpair cx = (sa < sb) ? ca : cb, cy = (sa < sb) ? cb : ca;
-        const double b00 = A[xc0], b10 = A[xc0 + 1], b01 = A[xc1], b11 = A[xc1 + 1];
+        const double b00 = A[xb], b01 = A[PL + xb], b10 = A[2 * PL + xb], b11 = A[3 * PL + xb];
         const double c1 = cx[0], sn1 = cx[1], c2 = cy[0], sn2 = cy[1];
         const double t0 = iy ? fma(sn2, b00, c2 * b01) : fma(c2, b00, -sn2 * b01);
         const double t1 = iy ? fma(sn2, b10, c2 * b11) : fma(c2, b10, -sn2 * b11);
@@ -292,7 +308,7 @@ __global__ void __launch_bounds__(1024) k_jacobi_lds(const double* __restrict__ 
     for (int pos = tid; pos < N; pos += nt) {
       if (odd && pos == dpos) continue;
       const int o = (odd && pos > dpos) ? pos - 1 : pos;
-      lraw[o] = A[pos * ld + pos];
+      lraw[o] = A[aidx(pos, pos)];
     }
     if (tid == 0) {
       stat[ST_JACOBI_SWEEPS] = sweep + 1;
@@ -399,11 +415,14 @@ int jacobi_lds_max_n() { return JAC_NMAX; }
 int launch_jacobi(blmm_ctx* ctx, double* A, double* V, int n, double* lraw, int64_t* stat) {
   if (n <= JAC_NMAX) {
     const int N = n + (n & 1), NP2 = N / 2, ld = N + 1;
-    const int rows_per = (n + JAC_NWG - 1) / JAC_NWG;
-    const size_t lds = sizeof(double) * ((size_t)2 * N * ld + (size_t)2 * rows_per * ld + 5 * NP2 + 2) + 64;
+    static const int nwg_env = getenv("BLMM_JAC_NWG") ? atoi(getenv("BLMM_JAC_NWG")) : 0;
+    const int nwg = (nwg_env >= 1 && nwg_env <= 64) ? nwg_env : JAC_NWG;
+    const int rows_per = (n + nwg - 1) / nwg;
+    const int PL = (NP2 * (NP2 - 1) / 2 + 1) & ~1, AO = (4 * PL + 3 * NP2 + 1) & ~1;
+    const size_t lds = sizeof(double) * ((size_t)2 * AO + (size_t)2 * rows_per * ld + 5 * NP2 + 2) + 64;
     BLMM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_jacobi_lds), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     static const double stop2 = getenv("BLMM_JAC_STOP2") ? atof(getenv("BLMM_JAC_STOP2")) : 1e-15;
-    hipLaunchKernelGGL(k_jacobi_lds, dim3(JAC_NWG), dim3(1024), lds, ctx->stream, A, V, n, lraw, stat, stop2);
+    hipLaunchKernelGGL(k_jacobi_lds, dim3(nwg), dim3(1024), lds, ctx->stream, A, V, n, lraw, stat, stop2);
   } else {
     hipLaunchKernelGGL(k_jacobi_glb, dim3(1), dim3(1024), 0, ctx->stream, A, V, n, lraw, stat);
   }

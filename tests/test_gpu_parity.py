@@ -337,7 +337,7 @@ def test_rocsolver_eigen_path(blmm):
     check_null_exact(got, Y, G, K)
 
 
-@pytest.mark.parametrize("n,bxd", [(79, True), (64, False), (130, False)])
+@pytest.mark.parametrize("n,bxd", [(79, True), (64, False), (93, False), (124, False), (130, False)])
 def test_eigensolver_accuracy(blmm, n, bxd):
     """The device eigensolver (replacing LAPACK eigen, src/transform_helpers.jl:23): rotating the identity returns U'."""
     Y, G, K, _ = make_data(n=n, p=90, m=2, seed=900 + n, bxd=bxd)
