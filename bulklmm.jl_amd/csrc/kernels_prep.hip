@@ -211,6 +211,7 @@ __global__ void __launch_bounds__(1024) k_jacobi_lds(const double* __restrict__ 
     }
   };
   const double jac_stop2 = stop2;
+  const bool is_angle_wave = __builtin_amdgcn_readfirstlane(tid >> 6) == (nt >> 6) - 1;
   int cur = 0, sweep = 0, dpos = N - 1;                 // dpos: where the zero pad row/col of an odd n currently sits
   double mc = 1.0, ms = 0.0, myrel = 0.0;               // this lane's (c, s) for the current round
   if (angle_lane) {                                     // prologue: angles of round 0 straight from A_0
@@ -224,6 +225,9 @@ __global__ void __launch_bounds__(1024) k_jacobi_lds(const double* __restrict__ 
       double* An = smem + (cur ? 0 : AO);
       const double* rec = smem + (cur ? REC1 : REC);
       double* recn = smem + (cur ? REC : REC1);
+      // The angle wave and the worker waves take wave-uniform (scalar) branches: a wave must not walk the other role's
+      // code with an empty exec mask (its LDS instructions would still take issue slots on the critical path).
+      if (!is_angle_wave) {
       // ---- A: off-diagonal blocks B' = J1' B J2 written through pi -------------------------------------------
 #pragma unroll
       for (int u = 0; u < MAXB; ++u) {
@@ -257,33 +261,37 @@ __global__ void __launch_bounds__(1024) k_jacobi_lds(const double* __restrict__ 
           Vn[r * ld + jac_pi(2 * slot + 1, NP2)] = fma(csv[1], xy[0], csv[0] * xy[1]);
         }
       }
+      } else if (angle_lane) {
       // ---- angle lanes: own diagonal block of round r, then (c, s) of round r+1 -----------------------------------
-      if (angle_lane) {
         auto rot_diag = [&](double c, double sn, double app, double aqq, double apq, double& npp, double& nqq) {
           const double cc = c * c, ss = sn * sn, xx = 2.0 * c * sn * apq;
           npp = fma(cc, app, fma(ss, aqq, -xx));
           nqq = fma(ss, app, fma(cc, aqq, xx));
         };
-        {
-          const double app = A[o_pp], aqq = A[o_qq], apq = A[o_pq];
-          double npp, nqq;
-          rot_diag(mc, ms, app, aqq, apq, npp, nqq);
-          An[d_pp] = npp; An[d_qq] = nqq; An[d_pq] = (ms != 0.0) ? 0.0 : apq;
-        }
+        // every LDS read first (one round trip; a read placed after the writes below would have to wait for them:
+        // A and An alias as far as the compiler can tell), then the critical path -- the angles of round r+1 -- and the
+        // lane's own diagonal block last
+        const double app = A[o_pp], aqq = A[o_qq], apq = A[o_pq];
         const dpair ca = *reinterpret_cast<const dpair*>(rec + 2 * sa);
         const dpair cb = *reinterpret_cast<const dpair*>(rec + 2 * sb);
+        const double a0 = A[DG + sa], a1 = A[DG + NP2 + sa], a2 = A[DG + 2 * NP2 + sa];
+        const double e0 = A[DG + sb], e1 = A[DG + NP2 + sb], e2 = A[DG + 2 * NP2 + sb];
+        const double b00 = A[xb], b01 = A[PL + xb], b10 = A[2 * PL + xb], b11 = A[3 * PL + xb];
         double a_pp, a_qq, b_pp, b_qq;
-        rot_diag(ca[0], ca[1], A[DG + sa], A[DG + NP2 + sa], A[DG + 2 * NP2 + sa], a_pp, a_qq);
-        rot_diag(cb[0], cb[1], A[DG + sb], A[DG + NP2 + sb], A[DG + 2 * NP2 + sb], b_pp, b_qq);
+        rot_diag(ca[0], ca[1], a0, a1, a2, a_pp, a_qq);
+        rot_diag(cb[0], cb[1], e0, e1, e2, b_pp, b_qq);
         const double napp = ia ? a_qq : a_pp, naqq = ib ? b_qq : b_pp;
         const dpair cx = (sa < sb) ? ca : cb, cy = (sa < sb) ? cb : ca;
-        const double b00 = A[xb], b01 = A[PL + xb], b10 = A[2 * PL + xb], b11 = A[3 * PL + xb];
         const double c1 = cx[0], sn1 = cx[1], c2 = cy[0], sn2 = cy[1];
         const double t0 = iy ? fma(sn2, b00, c2 * b01) : fma(c2, b00, -sn2 * b01);
         const double t1 = iy ? fma(sn2, b10, c2 * b11) : fma(c2, b10, -sn2 * b11);
         const double napq = ix ? fma(sn1, t0, c1 * t1) : fma(c1, t0, -sn1 * t1);
+        const double omc = mc, oms = ms;                  // this round's (c, s) of the lane's own pair
         angle_of(napp, naqq, napq, mc, ms, myrel);
         *reinterpret_cast<dpair*>(recn + 2 * at) = (dpair){mc, ms};
+        double npp, nqq;
+        rot_diag(omc, oms, app, aqq, apq, npp, nqq);
+        An[d_pp] = npp; An[d_qq] = nqq; An[d_pq] = (oms != 0.0) ? 0.0 : apq;
       }
       dpos = jac_pi(dpos, NP2);
       cur ^= 1;
@@ -422,7 +430,13 @@ int launch_jacobi(blmm_ctx* ctx, double* A, double* V, int n, double* lraw, int6
     const size_t lds = sizeof(double) * ((size_t)2 * AO + (size_t)2 * rows_per * ld + 5 * NP2 + 2) + 64;
     BLMM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_jacobi_lds), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     static const double stop2 = getenv("BLMM_JAC_STOP2") ? atof(getenv("BLMM_JAC_STOP2")) : 1e-15;
-    hipLaunchKernelGGL(k_jacobi_lds, dim3(nwg), dim3(1024), lds, ctx->stream, A, V, n, lraw, stat, stop2);
+    // 768 threads (11 worker waves + the angle wave) when two items per worker thread cover the blocks: fewer waves at
+    // the barrier and in the LDS queue measured ~8 % faster than 1024 at n = 79.  BLMM_JAC_NT overrides.
+    static const int nt_env = getenv("BLMM_JAC_NT") ? atoi(getenv("BLMM_JAC_NT")) : 0;
+    const int nblk = NP2 * (NP2 - 1) / 2;
+    int nthr = (nblk <= 2 * (768 - 64)) ? 768 : 1024;
+    if (nt_env >= 256 && nt_env <= 1024 && nt_env % 64 == 0 && nblk <= 2 * (nt_env - 64)) nthr = nt_env;
+    hipLaunchKernelGGL(k_jacobi_lds, dim3(nwg), dim3(nthr), lds, ctx->stream, A, V, n, lraw, stat, stop2);
   } else {
     hipLaunchKernelGGL(k_jacobi_glb, dim3(1), dim3(1024), 0, ctx->stream, A, V, n, lraw, stat);
   }
