@@ -156,7 +156,8 @@ end
 function scan(y::Array{Float64, 1}, g::Array{Float64, 2}, K::Array{Float64, 2};
               weights = missing, prior_variance::Float64 = 0.0, prior_sample_size::Float64 = 0.0, addIntercept::Bool = true,
               reml::Bool = false, assumption::String = "null", optim_interval::Int64 = 1,
-              permutation_test::Bool = false, nperms::Int64 = 1024, rndseed::Int64 = 0, decomp_scheme::String = "eigen")
+              permutation_test::Bool = false, nperms::Int64 = 1024, rndseed::Int64 = 0, decomp_scheme::String = "eigen",
+              perm_precision::String = "f64")   # "f32": L_perms on the fp32 matrix cores, returned as Float32
     addIntercept || error("Intercept has to be added when no other covariate is given.")
     assumption == "null" || error(assumption == "alt" ? "scan_alt is not part of the GPU path" :
                                   "Assumption keyword is not supported. Please enter null or alt.")
@@ -164,7 +165,21 @@ function scan(y::Array{Float64, 1}, g::Array{Float64, 2}, K::Array{Float64, 2};
     np = permutation_test ? nperms : 0
     np < 0 && error("The required number of permutations must be a positive integer.")
     o = BlmmOpts(NULL_EXACT, reml, true, decomp(decomp_scheme), optim_interval, 0, prior_variance, prior_sample_size)
-    scal = zeros(2); lod = Array{Float64, 1}(undef, p); Lp = Array{Float64, 2}(undef, p, max(np, 1)); st = BlmmStatus()
+    perm_precision in ("f64", "f32") || error("perm_precision must be \"f64\" or \"f32\".")
+    scal = zeros(2); lod = Array{Float64, 1}(undef, p); st = BlmmStatus()
+    if perm_precision == "f32"
+        Lp32 = Array{Float32, 2}(undef, p, max(np, 1))
+        GC.@preserve y g K weights scal lod Lp32 begin
+            check(ccall((:blmm_scan_perms_f32, libblmm), Cint,
+                        (Ptr{Cvoid}, Ref{BlmmOpts}, Ptr{Float64}, Int64, Ptr{Float64}, Int64, Ptr{Float64}, Int64, Ptr{Float64},
+                         Ptr{Float64}, Int64, UInt64, Ptr{Int32}, Ptr{Float64}, Ptr{Float64}, Ptr{Float32}, Ref{BlmmStatus}),
+                        context(), o, y, n, g, p, C_NULL, 0, K, ptr_or_null(weights), np, UInt64(rndseed), C_NULL, scal, lod, Lp32, st))
+        end
+        raise_status(st)
+        return permutation_test ? (sigma2_e = scal[1], h2_null = scal[2], lod = lod, L_perms = Lp32[:, 1:np]) :
+                                  (sigma2_e = scal[1], h2_null = scal[2], lod = lod)
+    end
+    Lp = Array{Float64, 2}(undef, p, max(np, 1))
     GC.@preserve y g K weights scal lod Lp begin
         check(ccall((:blmm_scan_perms, libblmm), Cint,
                     (Ptr{Cvoid}, Ref{BlmmOpts}, Ptr{Float64}, Int64, Ptr{Float64}, Int64, Ptr{Float64}, Int64, Ptr{Float64},
