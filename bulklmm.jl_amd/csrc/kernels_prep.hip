@@ -829,7 +829,11 @@ __device__ __forceinline__ EllOut null_ell_reg(double h2, const NullRegs<C, LPT>
   return o;
 }
 
+#ifndef BRENT_MINW
+#define BRENT_MINW 2
+#endif
 constexpr int BRENT_LPT = 4;
+constexpr int BRENT_PHASE1 = 26;   // iterations before the unfinished traits of a workgroup are repacked (k_brent)
 
 // Optim.jl Brent() restated (third-party; see oracle/bulklmm_oracle.py:brent_optim and SURVEY.md A.3) on the
 // gridbrent sub-intervals (src/gridbrent.jl:9-24).  Every lane of the wave runs the same number of function
@@ -899,10 +903,78 @@ __device__ __forceinline__ double brent_search(F& f, int nint, bool valid, int* 
   return best_x;
 }
 
+// The same iteration as a resumable state machine (one sub-interval): brent_run advances every lane of the wave by the
+// same number of iterations (until all lanes are done or `max_it` more iterations), so a trait can be moved to another
+// lane group between two calls.
+struct BrentState {
+  double xl, xu, x, fx, step, old_step, ox, oox, ofx, oofx;
+  int done;
+};
+template <typename F>
+__device__ __forceinline__ void brent_init(F& f, BrentState& S, double a, double b, bool valid) {
+  const double golden = 0.5 * (3.0 - sqrt(5.0));
+  S.xl = a; S.xu = b;
+  S.x = a + golden * (b - a);
+  S.fx = f(S.x);
+  S.step = 0.0; S.old_step = 0.0;
+  S.ox = S.x; S.oox = S.x; S.ofx = S.fx; S.oofx = S.fx;
+  S.done = !valid;
+}
+template <typename F>
+__device__ __forceinline__ int brent_run(F& f, BrentState& S, int max_it) {
+  const double golden = 0.5 * (3.0 - sqrt(5.0));
+  const double rel_tol = 1.4901161193847656e-08, abs_tol = 2.220446049250313e-16;
+  int it = 0;
+  for (; it < max_it; ++it) {
+    double p = 0.0, q = 0.0;
+    const double x_tol = rel_tol * fabs(S.x) + abs_tol;
+    const double x_mid = (S.xu + S.xl) / 2;
+    if (fabs(S.x - x_mid) <= 2 * x_tol - (S.xu - S.xl) / 2) S.done = 1;
+    if (__all(S.done)) break;
+    if (fabs(S.old_step) > x_tol) {
+      const double r = (S.x - S.ox) * (S.fx - S.oofx);
+      q = (S.x - S.oox) * (S.fx - S.ofx);
+      p = (S.x - S.oox) * q - (S.x - S.ox) * r;
+      q = 2 * (q - r);
+      if (q > 0) p = -p; else q = -q;
+    }
+    double nstep, nold;
+    if (fabs(p) < fabs(q * S.old_step / 2) && p < q * (S.xu - S.x) && p < q * (S.x - S.xl)) {
+      nold = S.step;
+      nstep = p / q;
+      const double x_temp = S.x + nstep;
+      if ((x_temp - S.xl) < 2 * x_tol || (S.xu - x_temp) < 2 * x_tol) nstep = (S.x < x_mid) ? x_tol : -x_tol;
+    } else {
+      nold = (S.x < x_mid) ? S.xu - S.x : S.xl - S.x;
+      nstep = golden * nold;
+    }
+    const double new_x = (fabs(nstep) >= x_tol) ? S.x + nstep : S.x + ((nstep > 0) ? x_tol : -x_tol);
+    const double new_f = f(S.done ? S.x : new_x);
+    if (!S.done) {
+      S.old_step = nold; S.step = nstep;
+      if (new_f < S.fx) {
+        if (new_x < S.x) S.xu = S.x; else S.xl = S.x;
+        S.oox = S.ox; S.oofx = S.ofx;
+        S.ox = S.x; S.ofx = S.fx;
+        S.x = new_x; S.fx = new_f;
+      } else {
+        if (new_x < S.x) S.xl = new_x; else S.xu = new_x;
+        if (new_f <= S.ofx || S.ox == S.x) {
+          S.oox = S.ox; S.oofx = S.ofx;
+          S.ox = new_x; S.ofx = new_f;
+        } else if (new_f <= S.oofx || S.oox == S.x || S.oox == S.ox) {
+          S.oox = new_x; S.oofx = new_f;
+        }
+      }
+    }
+  }
+  return it;
+}
+
 // fitlmm for every trait (src/lmm.jl:56-86): Brent search, then the final wls at the minimiser (:84).
 // REG: the register-resident evaluator (n <= LPT * NULL_NK); otherwise operands are re-read every evaluation.
 template <int C, int LPT, bool REG>
-__global__ void __launch_bounds__(256) k_brent(NullModel nm, const double* __restrict__ Yt, int64_t ldy, int64_t m,
+__global__ void __launch_bounds__(256, BRENT_MINW) k_brent(NullModel nm, const double* __restrict__ Yt, int64_t ldy, int64_t m,
                                                const double* __restrict__ Z0, const double* __restrict__ lam,
                                                const double* __restrict__ logtab, double* __restrict__ h2out,
                                                double* __restrict__ s2out, double* __restrict__ ellout, int64_t* stat) {
@@ -925,6 +997,71 @@ __global__ void __launch_bounds__(256) k_brent(NullModel nm, const double* __res
   const int nint = nm.optim_interval < 1 ? 1 : nm.optim_interval;
   double best_x;
   EllOut fin;
+  if constexpr (REG && (64 / LPT) > 1) {
+    if (nint == 1) {
+      // Two phases with a repack in between.  On eQTL-like data the evaluation count is bimodal: about half of the
+      // traits converge in 12-25 evaluations, the other half (minimum at the h2 = 0 boundary, where x_tol shrinks
+      // with x) needs 72-77; a wave runs until its slowest trait is done, so with 16 traits per wave nearly every wave
+      // ran ~76.  After BRENT_PHASE1 iterations the unfinished traits of the workgroup are packed into as few waves
+      // as possible and the other waves retire.  Every trait still sees exactly the Optim.jl iteration sequence.
+      constexpr int TPW = 256 / LPT;            // traits per workgroup
+      constexpr int TPV = 64 / LPT;             // traits per wave
+      __shared__ double s_bst[10][TPW];
+      __shared__ int s_bit[TPW], s_blist[TPW], s_bnp[TPW], s_bcnt;
+      NullRegs<C, LPT> R;
+      R.load(ycol, ldy, sub, n, Z0, lam, valid);
+      auto f = [&](double h2) { return -null_ell_reg<C, LPT>(h2, R, n, nm.prior_a, nm.prior_b, nm.reml, s_ln, &nonpos).ell; };
+      BrentState S;
+      brent_init(f, S, 0.0, 1.0, valid);
+      const int it1 = brent_run(f, S, BRENT_PHASE1);
+      fin = null_ell_reg<C, LPT>(S.x, R, n, nm.prior_a, nm.prior_b, nm.reml, s_ln, &nonpos);
+      const int ts = threadIdx.x / LPT;
+      if (sub == 0) {
+        if (valid && S.done) {
+          h2out[j] = S.x;
+          if (s2out) s2out[j] = fin.sigma2;
+          if (ellout) ellout[j] = fin.ell;
+          if (nonpos) atomicAdd((unsigned long long*)&stat[ST_NONPOS_W], 1ull);
+        }
+        s_bst[0][ts] = S.xl; s_bst[1][ts] = S.xu; s_bst[2][ts] = S.x; s_bst[3][ts] = S.fx; s_bst[4][ts] = S.step;
+        s_bst[5][ts] = S.old_step; s_bst[6][ts] = S.ox; s_bst[7][ts] = S.oox; s_bst[8][ts] = S.ofx; s_bst[9][ts] = S.oofx;
+        s_bit[ts] = S.done ? -1 : it1;
+        s_bnp[ts] = nonpos;
+      }
+      __syncthreads();
+      if (threadIdx.x == 0) {
+        int cnt = 0;
+        for (int e = 0; e < TPW; ++e) if (s_bit[e] >= 0) s_blist[cnt++] = e;
+        s_bcnt = cnt;
+      }
+      __syncthreads();
+      const int U = s_bcnt;
+      // the surviving waves rotate with the workgroup index: the four waves of a workgroup sit on the four SIMDs of its
+      // CU, and always keeping waves 0.. would leave all of phase 2 on SIMDs 0 and 1
+      const int wave = ((threadIdx.x >> 6) + 4 - (int)(blockIdx.x & 3)) & 3;
+      if (wave * TPV >= U) return;                // wave-uniform: this wave has nothing left
+      const int qslot = wave * TPV + (threadIdx.x & 63) / LPT;
+      const bool valid2 = qslot < U;
+      const int src = s_blist[valid2 ? qslot : 0];
+      const int64_t j2 = (int64_t)blockIdx.x * TPW + src;
+      R.load(Yt + j2, ldy, sub, n, Z0, lam, true);
+      S.xl = s_bst[0][src]; S.xu = s_bst[1][src]; S.x = s_bst[2][src]; S.fx = s_bst[3][src]; S.step = s_bst[4][src];
+      S.old_step = s_bst[5][src]; S.ox = s_bst[6][src]; S.oox = s_bst[7][src]; S.ofx = s_bst[8][src]; S.oofx = s_bst[9][src];
+      S.done = !valid2;
+      nonpos = s_bnp[src];
+      const int it0 = s_bit[src];
+      const int it2 = brent_run(f, S, 1000 - it0);
+      fin = null_ell_reg<C, LPT>(S.x, R, n, nm.prior_a, nm.prior_b, nm.reml, s_ln, &nonpos);
+      if (valid2 && sub == 0) {
+        h2out[j2] = S.x;
+        if (s2out) s2out[j2] = fin.sigma2;
+        if (ellout) ellout[j2] = fin.ell;
+        if (it0 + it2 >= 1000 && !S.done) atomicAdd((unsigned long long*)&stat[ST_BRENT_MAXIT], 1ull);
+        if (nonpos) atomicAdd((unsigned long long*)&stat[ST_NONPOS_W], 1ull);
+      }
+      return;
+    }
+  }
   if constexpr (REG) {
     NullRegs<C, LPT> R;
     R.load(ycol, ldy, sub, n, Z0, lam, valid);
