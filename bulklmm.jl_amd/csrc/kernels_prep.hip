@@ -727,6 +727,13 @@ __device__ __forceinline__ EllOut null_ell(double h2, const double* __restrict__
 // LPT lanes share one trait; lane `sub` owns individuals k = sub + LPT*i, i < NK, held in registers
 // (lambda, y and the C covariate columns; padding rows have lambda = y = z = 0 and contribute nothing).
 // All divisions are rcp + 2 Newton steps and all logarithms the table-driven fast_log (fastmath.h).
+// build knobs of k_brent (A/B testing: make EXTRA="-DBRENT_MINW=2 -DBRENT_UNROLL=5")
+#ifndef BRENT_MINW
+#define BRENT_MINW 3
+#endif
+#ifndef BRENT_UNROLL
+#define BRENT_UNROLL 1     // quads of the evaluator loop unrolled together
+#endif
 constexpr int NULL_NK = 20;
 
 template <int LPT>
@@ -738,20 +745,33 @@ __device__ __forceinline__ double lpt_sum(double x) {
 
 template <int C, int LPT>
 struct NullRegs {
-  double lam[NULL_NK], y[NULL_NK], z[C][NULL_NK];
-  __device__ __forceinline__ void load(const double* __restrict__ ycol, int64_t ystride, int sub, int n,
-                                       const double* __restrict__ Z0, const double* __restrict__ lamv, bool valid) {
-#pragma unroll
-    for (int i = 0; i < NULL_NK; ++i) {
-      const int k = sub + LPT * i;
-      const bool ok = k < n;
-      lam[i] = ok ? lamv[k] : 0.0;
-      y[i] = (ok && valid) ? ycol[(int64_t)k * ystride] : 0.0;
-#pragma unroll
-      for (int q = 0; q < C; ++q) z[q][i] = ok ? Z0[q * n + k] : 0.0;
-    }
-  }
+  // Operands of the register-free evaluator, all in LDS (the name is historical: they used to be 60 (1 + ..) VGPRs per
+  // lane, which held the kernel at one wave per SIMD):
+  //   yp[i * 256]                          : y_k of this lane's trait, k = sub + LPT * i   (thread-major: conflict-free)
+  //   lz[i * (1 + C)] = {lambda_k, z_0k, ..} : trait-independent, one table per lane-group position (16-lane broadcasts)
+  const double* yp;
+  const double* lz;
 };
+// Stages one trait's y into the workgroup's LDS slab: thread t owns column t of sY[NULL_NK][256].
+template <int LPT>
+__device__ __forceinline__ void stage_null_y(double* sY, const double* __restrict__ ycol, int64_t ystride, int sub, int n, bool valid) {
+#pragma unroll
+  for (int i = 0; i < NULL_NK; ++i) {
+    const int k = sub + LPT * i;
+    sY[i * 256 + threadIdx.x] = (k < n && valid) ? ycol[(int64_t)k * ystride] : 0.0;
+  }
+}
+// fills the LDS table of NullRegs (all threads of the workgroup; the caller synchronises)
+template <int C, int LPT>
+__device__ __forceinline__ void stage_null_lz(double* lzbase, int n, const double* __restrict__ Z0, const double* __restrict__ lamv) {
+  for (int e = threadIdx.x; e < LPT * NULL_NK; e += blockDim.x) {
+    const int sub = e / NULL_NK, i = e % NULL_NK, k = sub + LPT * i;
+    double* d = lzbase + (size_t)e * (1 + C);
+    d[0] = (k < n) ? lamv[k] : 0.0;
+#pragma unroll
+    for (int q = 0; q < C; ++q) d[1 + q] = (k < n) ? Z0[q * n + k] : 0.0;
+  }
+}
 
 template <int C, int LPT>
 __device__ __forceinline__ EllOut null_ell_reg(double h2, const NullRegs<C, LPT>& R, int n, double prior_a, double prior_b,
@@ -768,10 +788,27 @@ __device__ __forceinline__ EllOut null_ell_reg(double h2, const NullRegs<C, LPT>
   // w = 1/t four at a time from ONE reciprocal (of the product): 22 instruction slots per four elements instead of 40
   // (v_rcp_f64 is quarter rate); the product also feeds sum ln t = ln(prod t), kept as two partial products that stay
   // far from overflow.  Each w carries ~3 extra roundings (4e-16 relative), below the rounding of the sums it enters.
-#pragma unroll
+  // the pointers are laundered once per evaluation: otherwise the loads are loop-invariant for the Brent iteration and
+  // hipcc hoists all of them back into registers
+  const double* lzp = R.lz;
+  const double* yp = R.yp;
+  asm volatile("" : "+v"(lzp), "+v"(yp));
+#pragma unroll BRENT_UNROLL
   for (int i0 = 0; i0 < NULL_NK; i0 += 4) {
-    const double t0 = fma(delta, R.lam[i0], 1.0), t1 = fma(delta, R.lam[i0 + 1], 1.0);
-    const double t2 = fma(delta, R.lam[i0 + 2], 1.0), t3 = fma(delta, R.lam[i0 + 3], 1.0);
+    double lz[4][1 + C], yv[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      yv[j] = yp[(i0 + j) * 256];
+      if constexpr (C == 1) {
+        const dpair e = *reinterpret_cast<const dpair*>(lzp + (i0 + j) * 2);
+        lz[j][0] = e[0]; lz[j][1] = e[1];
+      } else {
+#pragma unroll
+        for (int q = 0; q <= C; ++q) lz[j][q] = lzp[(i0 + j) * (1 + C) + q];
+      }
+    }
+    const double t0 = fma(delta, lz[0][0], 1.0), t1 = fma(delta, lz[1][0], 1.0);
+    const double t2 = fma(delta, lz[2][0], 1.0), t3 = fma(delta, lz[3][0], 1.0);
     bad |= !(t0 > 0.0) | !(t1 > 0.0) | !(t2 > 0.0) | !(t3 > 0.0);
     const double ab = t0 * t1, cd = t2 * t3, q4 = ab * cd;
     const double rq = fast_rcp(q4);
@@ -780,16 +817,15 @@ __device__ __forceinline__ EllOut null_ell_reg(double h2, const NullRegs<C, LPT>
     if (i0 < NULL_NK / 2) p1 *= q4; else p2 *= q4;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      const int i = i0 + j;
       const double w = wv[j];
-      const double wy = w * R.y[i];
-      syy = fma(wy, R.y[i], syy);
+      const double wy = w * yv[j];
+      syy = fma(wy, yv[j], syy);
 #pragma unroll
       for (int q = 0; q < C; ++q) {
-        v[q] = fma(wy, R.z[q][i], v[q]);
-        const double wz = w * R.z[q][i];
+        v[q] = fma(wy, lz[j][1 + q], v[q]);
+        const double wz = w * lz[j][1 + q];
 #pragma unroll
-        for (int r = 0; r <= q; ++r) A[q * (q + 1) / 2 + r] = fma(wz, R.z[r][i], A[q * (q + 1) / 2 + r]);
+        for (int r = 0; r <= q; ++r) A[q * (q + 1) / 2 + r] = fma(wz, lz[j][1 + r], A[q * (q + 1) / 2 + r]);
       }
     }
   }
@@ -829,9 +865,6 @@ __device__ __forceinline__ EllOut null_ell_reg(double h2, const NullRegs<C, LPT>
   return o;
 }
 
-#ifndef BRENT_MINW
-#define BRENT_MINW 2
-#endif
 constexpr int BRENT_LPT = 4;
 constexpr int BRENT_PHASE1 = 26;   // iterations before the unfinished traits of a workgroup are repacked (k_brent)
 
@@ -986,6 +1019,8 @@ __global__ void __launch_bounds__(256, BRENT_MINW) k_brent(NullModel nm, const d
   if (!REG) {
     for (int e = threadIdx.x; e < n; e += blockDim.x) sLam[e] = lam[e];
     for (int e = threadIdx.x; e < n * C; e += blockDim.x) sZ[e] = Z0[e];
+  } else {
+    stage_null_lz<C, LPT>(sh, n, Z0, lam);      // sh: LPT * NULL_NK * (1 + C) doubles, then sY[NULL_NK][256]
   }
   stage_log_table<false>(s_ln, logtab);
   __syncthreads();
@@ -997,6 +1032,11 @@ __global__ void __launch_bounds__(256, BRENT_MINW) k_brent(NullModel nm, const d
   const int nint = nm.optim_interval < 1 ? 1 : nm.optim_interval;
   double best_x;
   EllOut fin;
+  double* sY = sh + LPT * NULL_NK * (1 + C);
+  if constexpr (REG) {
+    stage_null_y<LPT>(sY, ycol, ldy, sub, n, valid);   // own column only: no barrier needed before the lane reads it back
+    __syncthreads();                                   // (the repacking path reads other lanes' columns later)
+  }
   if constexpr (REG && (64 / LPT) > 1) {
     if (nint == 1) {
       // Two phases with a repack in between.  On eQTL-like data the evaluation count is bimodal: about half of the
@@ -1009,7 +1049,8 @@ __global__ void __launch_bounds__(256, BRENT_MINW) k_brent(NullModel nm, const d
       __shared__ double s_bst[10][TPW];
       __shared__ int s_bit[TPW], s_blist[TPW], s_bnp[TPW], s_bcnt;
       NullRegs<C, LPT> R;
-      R.load(ycol, ldy, sub, n, Z0, lam, valid);
+      R.lz = sh + sub * NULL_NK * (1 + C);
+      R.yp = sY + threadIdx.x;
       auto f = [&](double h2) { return -null_ell_reg<C, LPT>(h2, R, n, nm.prior_a, nm.prior_b, nm.reml, s_ln, &nonpos).ell; };
       BrentState S;
       brent_init(f, S, 0.0, 1.0, valid);
@@ -1044,7 +1085,7 @@ __global__ void __launch_bounds__(256, BRENT_MINW) k_brent(NullModel nm, const d
       const bool valid2 = qslot < U;
       const int src = s_blist[valid2 ? qslot : 0];
       const int64_t j2 = (int64_t)blockIdx.x * TPW + src;
-      R.load(Yt + j2, ldy, sub, n, Z0, lam, true);
+      R.yp = sY + src * LPT + sub;                // the trait's y is already in the workgroup's slab
       S.xl = s_bst[0][src]; S.xu = s_bst[1][src]; S.x = s_bst[2][src]; S.fx = s_bst[3][src]; S.step = s_bst[4][src];
       S.old_step = s_bst[5][src]; S.ox = s_bst[6][src]; S.oox = s_bst[7][src]; S.ofx = s_bst[8][src]; S.oofx = s_bst[9][src];
       S.done = !valid2;
@@ -1064,7 +1105,8 @@ __global__ void __launch_bounds__(256, BRENT_MINW) k_brent(NullModel nm, const d
   }
   if constexpr (REG) {
     NullRegs<C, LPT> R;
-    R.load(ycol, ldy, sub, n, Z0, lam, valid);
+    R.lz = sh + sub * NULL_NK * (1 + C);
+    R.yp = sY + threadIdx.x;
     auto f = [&](double h2) { return -null_ell_reg<C, LPT>(h2, R, n, nm.prior_a, nm.prior_b, nm.reml, s_ln, &nonpos).ell; };
     best_x = brent_search(f, nint, valid, &hit_max);
     fin = null_ell_reg<C, LPT>(best_x, R, n, nm.prior_a, nm.prior_b, nm.reml, s_ln, &nonpos);
@@ -1087,7 +1129,9 @@ static int launch_brent_t(blmm_ctx* ctx, const NullModel& nm, const double* Yt, 
                           const double* lam, double* h2, double* sigma2, double* ell, int64_t* stat) {
   const int64_t threads = m * LPT;
   const unsigned blocks = (unsigned)((threads + 255) / 256);
-  const size_t lds = REG ? 16 : sizeof(double) * (size_t)nm.n * (1 + C);
+  const size_t lds = REG ? sizeof(double) * ((size_t)LPT * NULL_NK * (1 + C) + (size_t)NULL_NK * 256) : sizeof(double) * (size_t)nm.n * (1 + C);
+  if (lds > 48 * 1024)
+    BLMM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_brent<C, LPT, REG>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   hipLaunchKernelGGL((k_brent<C, LPT, REG>), dim3(blocks), dim3(256), lds, ctx->stream, nm, Yt, ldy, m, Z0, lam,
                      ptr<double>(ctx->logtab), h2, sigma2, ell, stat);
   KCHECK();
