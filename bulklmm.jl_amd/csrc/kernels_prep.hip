@@ -731,6 +731,12 @@ __device__ __forceinline__ EllOut null_ell(double h2, const double* __restrict__
 #ifndef BRENT_MINW
 #define BRENT_MINW 3
 #endif
+#ifndef BRENT_UNROLL2
+#define BRENT_UNROLL2 5    // ... in k_brent2 (about one wave per SIMD: latency bound, wants the ILP)
+#endif
+#ifndef BRENT_MINW2
+#define BRENT_MINW2 2
+#endif
 #ifndef BRENT_UNROLL
 #define BRENT_UNROLL 1     // quads of the evaluator loop unrolled together
 #endif
@@ -747,10 +753,10 @@ template <int C, int LPT>
 struct NullRegs {
   // Operands of the register-free evaluator, all in LDS (the name is historical: they used to be 60 (1 + ..) VGPRs per
   // lane, which held the kernel at one wave per SIMD):
-  //   yp[i * 256]                          : y_k of this lane's trait, k = sub + LPT * i   (thread-major: conflict-free)
-  //   lz[i * (1 + C)] = {lambda_k, z_0k, ..} : trait-independent, one table per lane-group position (16-lane broadcasts)
-  const double* yp;
-  const double* lz;
+  //   base[yo + i * 256]                   : y_k of this lane's trait, k = sub + LPT * i   (thread-major: conflict-free)
+  //   base[lo + i * (1 + C)] = {lambda_k, z_0k, ..} : trait-independent, one table per lane-group position (16-lane broadcasts)
+  const double* base;   // the kernel's dynamic LDS array (kept un-laundered: the compiler must see the LDS address space)
+  int yo, lo;           // offsets of yp / lz in it
 };
 // Stages one trait's y into the workgroup's LDS slab: thread t owns column t of sY[NULL_NK][256].
 template <int LPT>
@@ -773,7 +779,7 @@ __device__ __forceinline__ void stage_null_lz(double* lzbase, int n, const doubl
   }
 }
 
-template <int C, int LPT>
+template <int C, int LPT, int UNR = BRENT_UNROLL>
 __device__ __forceinline__ EllOut null_ell_reg(double h2, const NullRegs<C, LPT>& R, int n, double prior_a, double prior_b,
                                                int reml, const dpair* __restrict__ s_ln, int* nonpos) {
   constexpr int NA = C * (C + 1) / 2;
@@ -790,10 +796,13 @@ __device__ __forceinline__ EllOut null_ell_reg(double h2, const NullRegs<C, LPT>
   // far from overflow.  Each w carries ~3 extra roundings (4e-16 relative), below the rounding of the sums it enters.
   // the pointers are laundered once per evaluation: otherwise the loads are loop-invariant for the Brent iteration and
   // hipcc hoists all of them back into registers
-  const double* lzp = R.lz;
-  const double* yp = R.yp;
-  asm volatile("" : "+v"(lzp), "+v"(yp));
-#pragma unroll BRENT_UNROLL
+  // (the OFFSETS are laundered, not the pointers: a laundered pointer loses its address space and every access
+  // becomes a flat_load -- several hundred cycles each on the critical path of a latency-bound kernel)
+  int lo = R.lo, yo = R.yo;
+  asm volatile("" : "+v"(lo), "+v"(yo));
+  const double* lzp = R.base + lo;
+  const double* yp = R.base + yo;
+#pragma unroll UNR
   for (int i0 = 0; i0 < NULL_NK; i0 += 4) {
     double lz[4][1 + C], yv[4];
 #pragma unroll
@@ -1006,11 +1015,21 @@ __device__ __forceinline__ int brent_run(F& f, BrentState& S, int max_it) {
 
 // fitlmm for every trait (src/lmm.jl:56-86): Brent search, then the final wls at the minimiser (:84).
 // REG: the register-resident evaluator (n <= LPT * NULL_NK); otherwise operands are re-read every evaluation.
+// Continuation area of the two-kernel form: traits unfinished after BRENT_PHASE1 iterations are appended to `list`
+// with their Brent state (st[f * m + j], f < 12: the ten doubles of BrentState, the iteration count, the non-positive
+// weight flag) and finished by k_brent2 in densely packed lane groups.  list == nullptr: repack inside the workgroup.
+struct BrentCont {
+  double* st;
+  int* list;
+  unsigned int* cnt;
+};
+
 template <int C, int LPT, bool REG>
 __global__ void __launch_bounds__(256, BRENT_MINW) k_brent(NullModel nm, const double* __restrict__ Yt, int64_t ldy, int64_t m,
                                                const double* __restrict__ Z0, const double* __restrict__ lam,
                                                const double* __restrict__ logtab, double* __restrict__ h2out,
-                                               double* __restrict__ s2out, double* __restrict__ ellout, int64_t* stat) {
+                                               double* __restrict__ s2out, double* __restrict__ ellout, int64_t* stat,
+                                               BrentCont cont) {
   extern __shared__ __attribute__((aligned(16))) double sh[];
   __shared__ dpair s_ln[BLMM_LOG_TABLE_N];
   const int n = nm.n;
@@ -1049,8 +1068,7 @@ __global__ void __launch_bounds__(256, BRENT_MINW) k_brent(NullModel nm, const d
       __shared__ double s_bst[10][TPW];
       __shared__ int s_bit[TPW], s_blist[TPW], s_bnp[TPW], s_bcnt;
       NullRegs<C, LPT> R;
-      R.lz = sh + sub * NULL_NK * (1 + C);
-      R.yp = sY + threadIdx.x;
+      R.base = sh; R.lo = sub * NULL_NK * (1 + C); R.yo = LPT * NULL_NK * (1 + C) + threadIdx.x;
       auto f = [&](double h2) { return -null_ell_reg<C, LPT>(h2, R, n, nm.prior_a, nm.prior_b, nm.reml, s_ln, &nonpos).ell; };
       BrentState S;
       brent_init(f, S, 0.0, 1.0, valid);
@@ -1077,6 +1095,20 @@ __global__ void __launch_bounds__(256, BRENT_MINW) k_brent(NullModel nm, const d
       }
       __syncthreads();
       const int U = s_bcnt;
+      if (cont.list) {
+        // two-kernel form: hand the unfinished traits over (one atomic per workgroup; the order of the list depends on
+        // the scheduling, the per-trait results do not)
+        __shared__ unsigned int s_bbase;
+        if (threadIdx.x == 0 && U > 0) s_bbase = atomicAdd(cont.cnt, (unsigned int)U);
+        __syncthreads();
+        for (int e = threadIdx.x; e < U; e += blockDim.x) cont.list[s_bbase + e] = (int)(blockIdx.x * TPW + s_blist[e]);
+        for (int e = threadIdx.x; e < U * 12; e += blockDim.x) {
+          const int fi = e / U, src = s_blist[e % U];
+          const int64_t jt = (int64_t)blockIdx.x * TPW + src;
+          cont.st[(int64_t)fi * m + jt] = (fi < 10) ? s_bst[fi][src] : (fi == 10 ? (double)s_bit[src] : (double)s_bnp[src]);
+        }
+        return;
+      }
       // the surviving waves rotate with the workgroup index: the four waves of a workgroup sit on the four SIMDs of its
       // CU, and always keeping waves 0.. would leave all of phase 2 on SIMDs 0 and 1
       const int wave = ((threadIdx.x >> 6) + 4 - (int)(blockIdx.x & 3)) & 3;
@@ -1085,7 +1117,7 @@ __global__ void __launch_bounds__(256, BRENT_MINW) k_brent(NullModel nm, const d
       const bool valid2 = qslot < U;
       const int src = s_blist[valid2 ? qslot : 0];
       const int64_t j2 = (int64_t)blockIdx.x * TPW + src;
-      R.yp = sY + src * LPT + sub;                // the trait's y is already in the workgroup's slab
+      R.yo = LPT * NULL_NK * (1 + C) + src * LPT + sub;   // the trait's y is already in the workgroup's slab
       S.xl = s_bst[0][src]; S.xu = s_bst[1][src]; S.x = s_bst[2][src]; S.fx = s_bst[3][src]; S.step = s_bst[4][src];
       S.old_step = s_bst[5][src]; S.ox = s_bst[6][src]; S.oox = s_bst[7][src]; S.ofx = s_bst[8][src]; S.oofx = s_bst[9][src];
       S.done = !valid2;
@@ -1105,8 +1137,7 @@ __global__ void __launch_bounds__(256, BRENT_MINW) k_brent(NullModel nm, const d
   }
   if constexpr (REG) {
     NullRegs<C, LPT> R;
-    R.lz = sh + sub * NULL_NK * (1 + C);
-    R.yp = sY + threadIdx.x;
+    R.base = sh; R.lo = sub * NULL_NK * (1 + C); R.yo = LPT * NULL_NK * (1 + C) + threadIdx.x;
     auto f = [&](double h2) { return -null_ell_reg<C, LPT>(h2, R, n, nm.prior_a, nm.prior_b, nm.reml, s_ln, &nonpos).ell; };
     best_x = brent_search(f, nint, valid, &hit_max);
     fin = null_ell_reg<C, LPT>(best_x, R, n, nm.prior_a, nm.prior_b, nm.reml, s_ln, &nonpos);
@@ -1124,6 +1155,49 @@ __global__ void __launch_bounds__(256, BRENT_MINW) k_brent(NullModel nm, const d
   }
 }
 
+// Second kernel of the two-kernel form: finishes the traits k_brent handed over, LPT lanes per list entry.
+template <int C, int LPT>
+__global__ void __launch_bounds__(256, BRENT_MINW2) k_brent2(NullModel nm, const double* __restrict__ Yt, int64_t ldy, int64_t m,
+                                                const double* __restrict__ Z0, const double* __restrict__ lam,
+                                                const double* __restrict__ logtab, double* __restrict__ h2out,
+                                                double* __restrict__ s2out, double* __restrict__ ellout, int64_t* stat,
+                                                BrentCont cont) {
+  extern __shared__ __attribute__((aligned(16))) double sh[];
+  __shared__ dpair s_ln[BLMM_LOG_TABLE_N];
+  constexpr int TPW = 256 / LPT;
+  const unsigned int U = *cont.cnt;
+  if ((unsigned int)blockIdx.x * TPW >= U) return;          // workgroup-uniform
+  const int n = nm.n;
+  stage_null_lz<C, LPT>(sh, n, Z0, lam);
+  stage_log_table<false>(s_ln, logtab);
+  double* sY = sh + LPT * NULL_NK * (1 + C);
+  const unsigned int q = (unsigned int)blockIdx.x * TPW + threadIdx.x / LPT;
+  const int sub = threadIdx.x % LPT;
+  const bool valid = q < U;
+  const int64_t j = cont.list[valid ? q : (unsigned int)blockIdx.x * TPW];
+  stage_null_y<LPT>(sY, Yt + j, ldy, sub, n, true);
+  __syncthreads();
+  int nonpos = (int)cont.st[(int64_t)11 * m + j];
+  NullRegs<C, LPT> R;
+  R.base = sh; R.lo = sub * NULL_NK * (1 + C); R.yo = LPT * NULL_NK * (1 + C) + threadIdx.x;
+  auto f = [&](double h2) { return -null_ell_reg<C, LPT, BRENT_UNROLL2>(h2, R, n, nm.prior_a, nm.prior_b, nm.reml, s_ln, &nonpos).ell; };
+  BrentState S;
+  S.xl = cont.st[j]; S.xu = cont.st[m + j]; S.x = cont.st[2 * m + j]; S.fx = cont.st[3 * m + j];
+  S.step = cont.st[4 * m + j]; S.old_step = cont.st[5 * m + j]; S.ox = cont.st[6 * m + j]; S.oox = cont.st[7 * m + j];
+  S.ofx = cont.st[8 * m + j]; S.oofx = cont.st[9 * m + j];
+  S.done = !valid;
+  const int it0 = (int)cont.st[(int64_t)10 * m + j];
+  const int it2 = brent_run(f, S, 1000 - it0);
+  const EllOut fin = null_ell_reg<C, LPT, BRENT_UNROLL2>(S.x, R, n, nm.prior_a, nm.prior_b, nm.reml, s_ln, &nonpos);
+  if (valid && sub == 0) {
+    h2out[j] = S.x;
+    if (s2out) s2out[j] = fin.sigma2;
+    if (ellout) ellout[j] = fin.ell;
+    if (it0 + it2 >= 1000 && !S.done) atomicAdd((unsigned long long*)&stat[ST_BRENT_MAXIT], 1ull);
+    if (nonpos) atomicAdd((unsigned long long*)&stat[ST_NONPOS_W], 1ull);
+  }
+}
+
 template <int C, int LPT, bool REG>
 static int launch_brent_t(blmm_ctx* ctx, const NullModel& nm, const double* Yt, int64_t ldy, int64_t m, const double* Z0,
                           const double* lam, double* h2, double* sigma2, double* ell, int64_t* stat) {
@@ -1132,9 +1206,30 @@ static int launch_brent_t(blmm_ctx* ctx, const NullModel& nm, const double* Yt, 
   const size_t lds = REG ? sizeof(double) * ((size_t)LPT * NULL_NK * (1 + C) + (size_t)NULL_NK * 256) : sizeof(double) * (size_t)nm.n * (1 + C);
   if (lds > 48 * 1024)
     BLMM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_brent<C, LPT, REG>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  BrentCont cont{nullptr, nullptr, nullptr};
+  static const char* two_env = getenv("BLMM_BRENT_TWO");   // "0": keep the single-kernel form (A/B testing)
+  const bool two = REG && (64 / LPT) > 1 && nm.optim_interval <= 1 && m >= 1024 && !(two_env && two_env[0] == '0');
+  if (two) {
+    int rc = ensure(ctx, ctx->brSt, sizeof(double) * (size_t)12 * m);
+    if (!rc) rc = ensure(ctx, ctx->brList, sizeof(int) * (size_t)m + 16);
+    if (rc) return rc;
+    cont.st = ptr<double>(ctx->brSt);
+    cont.cnt = ptr<unsigned int>(ctx->brList);
+    cont.list = ptr<int>(ctx->brList) + 4;
+    BLMM_HIP(hipMemsetAsync(cont.cnt, 0, 16, ctx->stream));
+  }
   hipLaunchKernelGGL((k_brent<C, LPT, REG>), dim3(blocks), dim3(256), lds, ctx->stream, nm, Yt, ldy, m, Z0, lam,
-                     ptr<double>(ctx->logtab), h2, sigma2, ell, stat);
+                     ptr<double>(ctx->logtab), h2, sigma2, ell, stat, cont);
   KCHECK();
+  if constexpr (REG) {
+    if (two) {
+      if (lds > 48 * 1024)
+        BLMM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_brent2<C, LPT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      hipLaunchKernelGGL((k_brent2<C, LPT>), dim3(blocks), dim3(256), lds, ctx->stream, nm, Yt, ldy, m, Z0, lam,
+                         ptr<double>(ctx->logtab), h2, sigma2, ell, stat, cont);
+      KCHECK();
+    }
+  }
   return BLMM_OK;
 }
 

@@ -122,6 +122,17 @@ def test_liteqtl_given_h2_matches_oracle(blmm):
     assert_lod_close(got, ref)
 
 
+def test_bulkscan_null_two_kernel_brent(blmm):
+    """m >= 1024 takes the two-kernel Brent (unfinished traits handed to a second, densely packed kernel): every trait
+    must still get the oracle's h2, whatever list position it lands on; ragged m (last lane groups partly empty)."""
+    Y, G, K, _ = make_data(p=24, m=1100, seed=4242)
+    got = blmm.bulkscan_null(Y, G, K)
+    ref = O.bulkscan_null(Y, G, K)
+    assert np.abs(got.h2_null_list - ref.h2_null_list).max() <= 1e-6
+    pin = O.bulkscan_null(Y, G, K, h2_override=got.h2_null_list)
+    assert_lod_close(got.L, pin.L)
+
+
 def test_bulkscan_null_reml_and_odd_sizes(blmm):
     Y, G, K, _ = make_data(n=53, p=130, m=3, seed=21, bxd=False)
     got = blmm.bulkscan_null(Y, G, K, reml=True)
