@@ -535,11 +535,20 @@ int blmm_bulkscan_dev(blmm_ctx* ctx, const blmm_opts* opts, const double* dY, in
       if ((rc = launch_lr_panels(ctx, nm, P.Yt, P.ldy, m, P.Z0, P.lam, dh2_out, ptr<double>(ctx->wbQ), rk, ptr<double>(ctx->panels),
                                  ptr<double>(ctx->lrC), ptr<double>(ctx->lrL), ldp, P.stat))) return rc;
       tm.mark();
+      // residual diagnostic of the weight basis: side stream, beside the scan kernel; joined below
+      BLMM_HIP(hipEventRecord(ctx->ev_fork, main_stream));
+      BLMM_HIP(hipStreamWaitEvent(ctx->side, ctx->ev_fork, 0));
+      ctx->stream = ctx->side;
+      rc = launch_lr_resid(ctx, nm, m, P.lam, dh2_out, ptr<double>(ctx->wbQ), rk, ptr<double>(ctx->lrC), ldp, P.stat);
+      ctx->stream = main_stream;
+      if (rc) return rc;
+      BLMM_HIP(hipEventRecord(ctx->ev_join, ctx->side));
       LrArgs la;
       la.s = scan_args(ctx, P, ptr<double>(ctx->panels), ldp, dL_out, ldL, m);
       la.Cp = ptr<double>(ctx->lrC); la.T = ptr<double>(ctx->lrT); la.tstride = tstride; la.Ls = ptr<double>(ctx->lrL);
       la.rk = rk; la.c = P.c;
       if ((rc = launch_scan_lr(ctx, la))) return rc;
+      BLMM_HIP(hipStreamWaitEvent(main_stream, ctx->ev_join, 0));
       tm.mark();
     } else {
       if ((rc = launch_brent(ctx, nm, P.Yt, P.ldy, m, P.Z0, P.lam, dh2_out, nullptr, nullptr, P.stat))) return rc;

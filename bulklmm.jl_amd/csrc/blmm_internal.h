@@ -138,6 +138,8 @@ struct LrArgs {
   int c;
 };
 int launch_scan_lr(blmm_ctx* ctx, const LrArgs& la);
+int launch_lr_resid(blmm_ctx* ctx, const NullModel& nm, int64_t m, const double* lam, const double* h2, const double* Q,
+                    const int* rk, const double* Cp, int64_t ldp, int64_t* stat);
 // kernels_scan_f32.hip: fp32 permutation LOD kernel and the fp64 k-major -> fp32 fragment-major conversion
 int launch_cvt_f32(blmm_ctx* ctx, const double* M, int64_t ld_in, int rows_valid, int64_t cols_valid, float* F,
                    int64_t ld_out, int kblocks);

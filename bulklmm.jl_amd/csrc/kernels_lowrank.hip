@@ -449,7 +449,7 @@ __global__ void __launch_bounds__(64) k_lr_panels(NullModel nm, const double* __
 #pragma unroll
   for (int q = 0; q < C; ++q) v[q] = 0.0;
   for (int k = 0; k < n; ++k) {
-    const double w = fabs(1.0 / fma(delta, sLam[k], 1.0));  // sqrt.(abs.(makeweights)) squared, src/bulkscan_helpers.jl:138
+    const double w = fabs(fast_rcp(fma(delta, sLam[k], 1.0)));  // sqrt.(abs.(makeweights)) squared, src/bulkscan_helpers.jl:138
     ww = fma(w, w, ww);
     const double y = Yt[(int64_t)k * ldy + j];
     const double wy = w * y;
@@ -502,7 +502,7 @@ __global__ void __launch_bounds__(64) k_lr_panels(NullModel nm, const double* __
   for (int k = 0; k < npad; ++k) {
     double p0 = 0.0;
     if (k < n) {
-      const double w = fabs(1.0 / fma(delta, sLam[k], 1.0));
+      const double w = fabs(fast_rcp(fma(delta, sLam[k], 1.0)));
       double res = Yt[(int64_t)k * ldy + j];
 #pragma unroll
       for (int q = 0; q < C; ++q) res = fma(-beta[q], sZ[q * n + k], res);
@@ -577,6 +577,12 @@ int launch_lr_panels(blmm_ctx* ctx, const NullModel& nm, const double* Yt, int64
   }
 #undef LP
   KCHECK();
+  return BLMM_OK;
+}
+
+// Diagnostic only (blmm_status.lowrank_resid): the caller runs it on the side stream beside the scan kernel.
+int launch_lr_resid(blmm_ctx* ctx, const NullModel& nm, int64_t m, const double* lam, const double* h2, const double* Q,
+                    const int* rk, const double* Cp, int64_t ldp, int64_t* stat) {
   const int64_t stride = 61;
   hipLaunchKernelGGL(k_lr_resid, dim3((unsigned)((m + stride - 1) / stride)), dim3(64), 0, ctx->stream, nm.n, m, stride, lam, h2, Q, rk,
                      Cp, ldp, stat);
