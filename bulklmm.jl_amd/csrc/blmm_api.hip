@@ -232,12 +232,12 @@ int prepare(blmm_ctx* ctx, const blmm_opts* o, const double* dY, int64_t n, int6
   tm.mark();
   if ((rc = launch_design(ctx, dK, dCovar, (int)ncov, add_int, dweights, (int)n, ptr<double>(ctx->Ks), ptr<double>(ctx->Zs)))) return rc;
   const double* evec = ptr<double>(ctx->V);
-  // n <= 124: LDS Jacobi; up to 384: the single-workgroup global-memory Jacobi (tens to hundreds of ms, but no
-  // library start-up); beyond: rocSOLVER dsyevd (its first use in a process costs ~2 min of code-object loading on
-  // this image, afterwards ~12 ms at n = 500).  BLMM_EIGEN=rocsolver|jacobi overrides the choice.
+  // n <= 124: LDS Jacobi; beyond: rocSOLVER dsyevd (2.3 ms at n = 130, 8 ms at n = 333, 14 ms at n = 500; its first use
+  // in a process loads the library: seconds, minutes on a cold machine).  The single-workgroup global-memory Jacobi
+  // (37 ms at n = 130, 0.74 s at n = 333) is the fallback when librocsolver.so cannot be loaded, up to n = 2048.
+  // BLMM_EIGEN=rocsolver|jacobi overrides the choice (the GPU tests pin "jacobi" to stay independent of the library).
   static const char* eig_env = getenv("BLMM_EIGEN");
-  const bool want_rs = eig_env ? (std::strcmp(eig_env, "rocsolver") == 0 && n > jacobi_lds_max_n())
-                               : n > 384;
+  const bool want_rs = n > jacobi_lds_max_n();
   bool used_rs = false;
   if (want_rs && !(eig_env && std::strcmp(eig_env, "jacobi") == 0) &&
       eigen_rocsolver(ctx, ptr<double>(ctx->Ks), (int)n, ptr<double>(ctx->lraw), P.stat) == BLMM_OK) {

@@ -328,7 +328,8 @@ def test_golden_fixture(blmm):
 
 @pytest.mark.parametrize("n", [130, 333])
 def test_larger_sample_sizes(blmm, n):
-    """n > 112 takes the global-memory eigensolver and the wider lanes-per-trait Brent variants."""
+    """n > 124: eigensolver outside the LDS Jacobi (global-memory Jacobi here, rocSOLVER with BLMM_TEST_ROCSOLVER=1), the
+    multi-workgroup weight basis and the wider lanes-per-trait Brent variants."""
     Y, G, K, _ = make_data(n=n, p=150, m=21, seed=500 + n, bxd=False)
     got = blmm.bulkscan_null(Y, G, K)
     check_null_exact(got, Y, G, K)
@@ -342,7 +343,7 @@ def test_larger_sample_sizes(blmm, n):
 @pytest.mark.skipif(not __import__("os").environ.get("BLMM_TEST_ROCSOLVER"),
                     reason="rocSOLVER's first use in a process takes minutes on this image; set BLMM_TEST_ROCSOLVER=1")
 def test_rocsolver_eigen_path(blmm):
-    """n > 384 takes rocSOLVER dsyevd for the kinship eigen-decomposition."""
+    """n > 124 takes rocSOLVER dsyevd for the kinship eigen-decomposition (and rocBLAS dgemm for the rotation)."""
     Y, G, K, _ = make_data(n=500, p=300, m=9, seed=77, bxd=False)   # p >= 256: the marker rotation goes through rocBLAS dgemm
     got = blmm.bulkscan_null(Y, G, K)
     check_null_exact(got, Y, G, K)
