@@ -122,14 +122,15 @@ def test_liteqtl_given_h2_matches_oracle(blmm):
     assert_lod_close(got, ref)
 
 
-def test_bulkscan_null_two_kernel_brent(blmm):
+@pytest.mark.parametrize("ncov", [0, 1])
+def test_bulkscan_null_two_kernel_brent(blmm, ncov):
     """m >= 1024 takes the two-kernel Brent (unfinished traits handed to a second, densely packed kernel): every trait
     must still get the oracle's h2, whatever list position it lands on; ragged m (last lane groups partly empty)."""
-    Y, G, K, _ = make_data(p=24, m=1100, seed=4242)
-    got = blmm.bulkscan_null(Y, G, K)
-    ref = O.bulkscan_null(Y, G, K)
+    Y, G, K, Cov = make_data(p=24, m=1100, seed=4242 + ncov, ncov=ncov)
+    got = blmm.bulkscan_null(Y, G, K, Cov)
+    ref = O.bulkscan_null(Y, G, K, Covar=Cov)
     assert np.abs(got.h2_null_list - ref.h2_null_list).max() <= 1e-6
-    pin = O.bulkscan_null(Y, G, K, h2_override=got.h2_null_list)
+    pin = O.bulkscan_null(Y, G, K, Covar=Cov, h2_override=got.h2_null_list)
     assert_lod_close(got.L, pin.L)
 
 
@@ -345,6 +346,10 @@ def test_larger_sample_sizes(blmm, n):
 def test_rocsolver_eigen_path(blmm):
     """n > 124 takes rocSOLVER dsyevd for the kinship eigen-decomposition (and rocBLAS dgemm for the rotation)."""
     Y, G, K, _ = make_data(n=500, p=300, m=9, seed=77, bxd=False)   # p >= 256: the marker rotation goes through rocBLAS dgemm
+    got = blmm.bulkscan_null(Y, G, K)
+    check_null_exact(got, Y, G, K)
+    # n = 1100: the multi-workgroup weight basis with 8 sample columns per workgroup (32 workgroups), 64 lanes per trait
+    Y, G, K, _ = make_data(n=1100, p=260, m=5, seed=78, bxd=False)
     got = blmm.bulkscan_null(Y, G, K)
     check_null_exact(got, Y, G, K)
 
