@@ -552,6 +552,126 @@ __global__ void __launch_bounds__(1024) k_post_eigen(const double* __restrict__ 
   }
 }
 
+// ---- the same steps as k_post_eigen for n beyond its LDS budget, spread over the chip (k_post_eigen<false>, one
+//      workgroup walking n^2 strided global accesses, took 0.9 ms at n = 500 and 3.9 ms at n = 1000) ---------------------
+// (1) rank of every eigenvalue (ascending; svd: |lambda| descending; ties by index) -> lam[rank], rankof[i]
+__global__ void __launch_bounds__(256) k_pe_rank(const double* __restrict__ lraw_in, int n, int decomp, double* __restrict__ lam,
+                                                 int* __restrict__ rankof, int64_t* stat) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const bool svd = decomp == BLMM_SVD;
+  const double li = svd ? fabs(lraw_in[i]) : lraw_in[i];
+  int rank = 0;
+  for (int j = 0; j < n; ++j) {
+    const double lj = svd ? fabs(lraw_in[j]) : lraw_in[j];
+    if (svd) rank += (lj > li) || (lj == li && j < i);
+    else rank += (lj < li) || (lj == li && j < i);
+  }
+  lam[rank] = li;
+  rankof[i] = rank;
+  if (li < -1e-7) atomicAdd((unsigned long long*)&stat[ST_NEG_EIG], 1ull);
+}
+// (2) one workgroup per eigenvector i: sign (largest-magnitude component positive, first one on ties), U[rank] = sg V[i],
+//     Z0[q][rank] = <U[rank], Zs[q]>
+__global__ void __launch_bounds__(256) k_pe_cols(const double* __restrict__ V, const int* __restrict__ rankof,
+                                                 const double* __restrict__ Zs, int n, int c, double* __restrict__ U,
+                                                 double* __restrict__ Z0) {
+  __shared__ double s_v[256];
+  __shared__ int s_k[256];
+  __shared__ double s_z[CMAX][4];
+  const int i = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const double* v = V + (size_t)i * n;
+  double big = 0.0; int bk = n;
+  for (int k = t; k < n; k += 256) { const double x = v[k]; if (fabs(x) > fabs(big)) { big = x; bk = k; } }
+  s_v[t] = big; s_k[t] = bk;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (t < o) {
+      const double a = s_v[t], b = s_v[t + o];
+      if (fabs(b) > fabs(a) || (fabs(b) == fabs(a) && s_k[t + o] < s_k[t])) { s_v[t] = b; s_k[t] = s_k[t + o]; }
+    }
+    __syncthreads();
+  }
+  const double sg = (s_v[0] < 0.0) ? -1.0 : 1.0;
+  const int rank = rankof[i];
+  double zacc[CMAX] = {0.0, 0.0, 0.0, 0.0};
+  for (int k = t; k < n; k += 256) {
+    const double u = sg * v[k];
+    U[(size_t)rank * n + k] = u;
+    for (int q = 0; q < c; ++q) zacc[q] = fma(u, Zs[(size_t)q * n + k], zacc[q]);
+  }
+  for (int q = 0; q < c; ++q) {
+    double z = zacc[q];
+    for (int o = 32; o > 0; o >>= 1) z += __shfl_xor(z, o, 64);
+    if (lane == 0) s_z[q][wave] = z;
+  }
+  __syncthreads();
+  if (t < c) Z0[(size_t)t * n + rank] = (s_z[t][0] + s_z[t][1]) + (s_z[t][2] + s_z[t][3]);
+}
+// (3) Ginv = (Z0'Z0)^-1 and Bq = Ginv (Zs' Wd)   (one workgroup; c <= CMAX)
+__global__ void __launch_bounds__(256) k_pe_bq(const double* __restrict__ Z0, const double* __restrict__ Zs,
+                                               const double* __restrict__ wd, int n, int c, double* __restrict__ Bq) {
+  __shared__ double Ginv[CMAX * CMAX], s_g[CMAX * CMAX][4];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  for (int ab = 0; ab < c * c; ++ab) {
+    const int a = ab / c, b = ab % c;
+    double g = 0.0;
+    for (int k = t; k < n; k += 256) g = fma(Z0[(size_t)a * n + k], Z0[(size_t)b * n + k], g);
+    for (int o = 32; o > 0; o >>= 1) g += __shfl_xor(g, o, 64);
+    if (lane == 0) s_g[ab][wave] = g;
+  }
+  __syncthreads();
+  if (t == 0) {
+    double G[CMAX][2 * CMAX];
+    for (int a = 0; a < c; ++a)
+      for (int b = 0; b < c; ++b) {
+        const int ab = a * c + b;
+        G[a][b] = (s_g[ab][0] + s_g[ab][1]) + (s_g[ab][2] + s_g[ab][3]);
+        G[a][c + b] = (a == b) ? 1.0 : 0.0;
+      }
+    for (int a = 0; a < c; ++a) {
+      int piv = a;
+      for (int r = a + 1; r < c; ++r) if (fabs(G[r][a]) > fabs(G[piv][a])) piv = r;
+      if (piv != a) for (int b = 0; b < 2 * c; ++b) { double tt = G[a][b]; G[a][b] = G[piv][b]; G[piv][b] = tt; }
+      const double d = 1.0 / G[a][a];
+      for (int b = 0; b < 2 * c; ++b) G[a][b] *= d;
+      for (int r = 0; r < c; ++r) if (r != a) { const double f = G[r][a]; for (int b = 0; b < 2 * c; ++b) G[r][b] -= f * G[a][b]; }
+    }
+    for (int a = 0; a < c; ++a) for (int b = 0; b < c; ++b) Ginv[a * CMAX + b] = G[a][c + b];
+  }
+  __syncthreads();
+  for (int e = t; e < n * c; e += 256) {
+    const int i = e % n, q = e / n;
+    double sacc = 0;
+    for (int r = 0; r < c; ++r) sacc = fma(Ginv[q * CMAX + r], Zs[(size_t)r * n + i], sacc);
+    Bq[(size_t)q * n + i] = sacc * (wd ? wd[i] : 1.0);
+  }
+}
+// (4) Rp[i][k] = U[k][i] wd_i - sum_q Z0[q][k] Bq[q][i]   (32 x 32 tiles through LDS: both sides coalesced)
+__global__ void __launch_bounds__(256) k_pe_rp(const double* __restrict__ U, const double* __restrict__ Z0,
+                                               const double* __restrict__ Bq, const double* __restrict__ wd, int n, int c,
+                                               int npad, int ldr, int centered, double* __restrict__ Rp) {
+  __shared__ double tile[32][33];
+  const int k0 = blockIdx.x * 32, i0 = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
+  for (int r = ty; r < 32; r += 8) {                        // U[k0 + r][i0 + tx]
+    const int k = k0 + r, i = i0 + tx;
+    tile[r][tx] = (k < n && i < n) ? U[(size_t)k * n + i] : 0.0;
+  }
+  __syncthreads();
+  for (int r = ty; r < 32; r += 8) {                        // Rp[i0 + r][k0 + tx]
+    const int i = i0 + r, k = k0 + tx;
+    if (i >= npad || k >= ldr) continue;
+    double v = 0.0;
+    if (i < n && k < n) {
+      v = tile[tx][r] * (wd ? wd[i] : 1.0);
+      if (centered)
+        for (int q = 0; q < c; ++q) v = fma(-Z0[(size_t)q * n + k], Bq[(size_t)q * n + i], v);
+    }
+    Rp[(size_t)i * ldr + k] = v;
+  }
+}
+
 int launch_post_eigen(blmm_ctx* ctx, const double* lraw, const double* V, const double* Zs, const double* dweights, int n,
                       int c, int npad, int ldr, int decomp, int centered, double* lam, double* U, double* Z0, double* Rp,
                       int64_t* stat) {
@@ -563,8 +683,13 @@ int launch_post_eigen(blmm_ctx* ctx, const double* lraw, const double* V, const 
     hipLaunchKernelGGL(k_post_eigen<true>, dim3(1), dim3(1024), lds, ctx->stream, lraw, V, Zs, dweights, n, c, npad, ldr, decomp,
                        centered, lam, U, Z0, Rp, ptr<double>(ctx->misc), stat);
   } else {
-    hipLaunchKernelGGL(k_post_eigen<false>, dim3(1), dim3(1024), 0, ctx->stream, lraw, V, Zs, dweights, n, c, npad, ldr, decomp,
-                       centered, lam, U, Z0, Rp, ptr<double>(ctx->misc), stat);
+    double* Bq = ptr<double>(ctx->misc);                        // c x n
+    int* rankof = reinterpret_cast<int*>(Bq + (size_t)c * n);   // n ints (the workspace holds n more doubles)
+    hipLaunchKernelGGL(k_pe_rank, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, lraw, n, decomp, lam, rankof, stat);
+    hipLaunchKernelGGL(k_pe_cols, dim3((unsigned)n), dim3(256), 0, ctx->stream, V, rankof, Zs, n, c, U, Z0);
+    hipLaunchKernelGGL(k_pe_bq, dim3(1), dim3(256), 0, ctx->stream, Z0, Zs, dweights, n, c, Bq);
+    hipLaunchKernelGGL(k_pe_rp, dim3((unsigned)((ldr + 31) / 32), (unsigned)((npad + 31) / 32)), dim3(256), 0, ctx->stream, U, Z0,
+                       Bq, dweights, n, c, npad, ldr, centered, Rp);
   }
   KCHECK();
   return BLMM_OK;
