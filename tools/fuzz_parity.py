@@ -1,0 +1,59 @@
+"""Randomised parity sweep (developer tool, run on the GPU box): random shapes / options through the host mirror against
+the oracle with the criteria of tests/test_gpu_parity.py.  python tools/fuzz_parity.py [ncases] [seed]"""
+import sys, os, time, traceback
+sys.path.insert(0, "."); sys.path.insert(0, "tests")
+os.environ.setdefault("BLMM_EIGEN", "jacobi")
+import numpy as np
+import bulklmm_jl_amd as blmm
+import oracle.bulklmm_oracle as O
+from common import make_data, assert_lod_close
+
+ncases = int(sys.argv[1]) if len(sys.argv) > 1 else 60
+seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+rng = np.random.default_rng(seed0)
+fails = 0
+t0 = time.time()
+for case in range(ncases):
+    n = int(rng.choice([5, 8, 13, 31, 47, 64, 79, 80, 93, 100, 111, 124, 125, 140]))
+    p = int(rng.choice([1, 2, 7, 63, 64, 65, 129, 300]))
+    m = int(rng.choice([1, 2, 15, 16, 17, 63, 70, 1030]))
+    ncov = int(rng.choice([0, 0, 1, 2]))
+    if ncov + 2 >= n: ncov = 0
+    method = str(rng.choice(["null-exact", "null-exact", "null-grid", "alt-grid"]))
+    reml = bool(rng.random() < 0.25)
+    svd = bool(rng.random() < 0.15)
+    use_w = bool(rng.random() < 0.2)
+    prior = (1.0, 0.1) if rng.random() < 0.2 else (1.0, 0.0)
+    if m > 100 and (n > 100 or method == "alt-grid"): m = 70          # keep the oracle quick
+    desc = f"case {case}: n={n} p={p} m={m} ncov={ncov} {method} reml={reml} svd={svd} weights={use_w} prior={prior}"
+    try:
+        Y, G, K, Cov = make_data(n=n, p=p, m=m, seed=1000 + case + 7919 * seed0, ncov=ncov, bxd=(n == 79))
+        w = rng.uniform(0.5, 2.0, size=n) if use_w else None
+        kw = dict(reml=reml, decomp_scheme="svd" if svd else "eigen", prior_variance=prior[0], prior_sample_size=prior[1])
+        grid = [i / 10.0 for i in range(10)]
+        if method == "null-exact":
+            got = blmm.bulkscan_null(Y, G, K, Cov, weights=w, **kw)
+            ref = O.bulkscan_null(Y, G, K, Covar=Cov, weights=w, **kw)
+            assert np.abs(got.h2_null_list - ref.h2_null_list).max() <= 1e-6, "h2"
+            assert np.sum((got.L - ref.L) ** 2, axis=0).max() <= 1e-7, "sum d^2"
+            pin = O.bulkscan_null(Y, G, K, Covar=Cov, weights=w, h2_override=got.h2_null_list, **kw)
+            assert_lod_close(got.L, pin.L)
+        elif method == "null-grid":
+            got = blmm.bulkscan_null_grid(Y, G, K, grid, Cov, weights=w, **kw)
+            ref = O.bulkscan_null_grid(Y, G, K, grid, Covar=Cov, weights=w, **kw)
+            same = got.h2_null_list == ref.h2_null_list      # Ell ties between grid points may resolve differently
+            assert same.mean() >= 0.98, "grid choice"
+            assert_lod_close(got.L[:, same], ref.L[:, same])
+        else:
+            if ncov > 0 and Cov is not None and Cov.shape[1] + 1 > 1:
+                pass
+            got = blmm.bulkscan_alt_grid(Y, G, K, grid, Cov, weights=w, **kw)
+            ref = O.bulkscan_alt_grid(Y, G, K, grid, Covar=Cov, weights=w, **kw)
+            assert_lod_close(got.L, ref.L, atol=1e-9)
+        print("ok  ", desc, flush=True)
+    except Exception as e:   # noqa: BLE001
+        fails += 1
+        print("FAIL", desc, "->", repr(e)[:300], flush=True)
+        traceback.print_exc(limit=2)
+print(f"{ncases - fails}/{ncases} ok in {time.time() - t0:.0f} s")
+sys.exit(1 if fails else 0)
