@@ -123,10 +123,17 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the bulkscan path has no CPU fallback)")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # BLMM_BENCH_BACKEND=gloo: rehearsal of the N > 1 control flow on a box with fewer GPUs than ranks (ranks share
+    # devices, the collectives go through host tensors, the all-gather is skipped); the measured path is always nccl.
+    backend = os.environ.get("BLMM_BENCH_BACKEND", "nccl")
+    dev_index = local_rank if backend == "nccl" else local_rank % max(torch.cuda.device_count(), 1)
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     def barrier():
         if world > 1:
@@ -148,7 +155,7 @@ def main():
     grid = [i / 16.0 for i in range(16)] if a.method in ("null-grid", "alt-grid") else None
 
     stream = torch.cuda.current_stream()
-    ctx = B.Context(local_rank, stream.cuda_stream)
+    ctx = B.Context(dev_index, stream.cuda_stream)
 
     perms = a.method == "perms"
     if perms:
@@ -163,7 +170,7 @@ def main():
             B.scan_perms_dev(ctx, dy1, dG, dK, dsc, dlod, dL, nperms=m_local, seed=1 + rank)
         else:
             B.bulkscan_dev(ctx, dY, dG, dK, dL, dH, method=a.method, h2_grid=grid)
-        if gather and world > 1:
+        if gather and world > 1 and backend == "nccl":
             dist.all_gather_into_tensor(dLfull.view(-1), dL.reshape(-1))
 
     for _ in range(max(a.warmup, 1)):
@@ -187,7 +194,7 @@ def main():
         lr_resid = float(st.lowrank_resid)
 
     ag_ms = None
-    if world > 1:
+    if world > 1 and backend == "nccl":
         torch.cuda.synchronize(); barrier()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         dist.all_gather_into_tensor(dLfull.view(-1), dL.reshape(-1))
@@ -198,7 +205,7 @@ def main():
         torch.cuda.synchronize()
         ag_ms = e0.elapsed_time(e1)
 
-    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+    tmax = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
