@@ -509,7 +509,18 @@ int blmm_bulkscan_dev(blmm_ctx* ctx, const blmm_opts* opts, const double* dY, in
   if ((rc = prepare(ctx, opts, dY, n, m, dG, p, dCovar, ncov, dK, dweights, 1, P, tm, lowrank))) return rc;
   const NullModel nm = null_model(P, opts);
   const int64_t ldp = P.ldy;
-  if (m == 0 || p == 0) { tm.mark(); tm.mark(); tm.mark(); return finish_status(ctx, status, &tm); }
+  if (m == 0) { tm.mark(); tm.mark(); tm.mark(); return finish_status(ctx, status, &tm); }
+  if (p == 0) {
+    // no markers: only the per-trait null model (h2_null_list does not depend on G); alt-grid's h2_panel is p x m = empty
+    if (opts->method == BLMM_NULL_EXACT) {
+      if ((rc = launch_brent(ctx, nm, P.Yt, P.ldy, m, P.Z0, P.lam, dh2_out, nullptr, nullptr, P.stat))) return rc;
+    } else if (opts->method == BLMM_NULL_GRID) {
+      if ((rc = ensure(ctx, ctx->h2idx, sizeof(int) * (size_t)m))) return rc;
+      if ((rc = launch_loglik_grid(ctx, nm, P.Yt, P.ldy, m, P.Z0, P.lam, dgrid, (int)ngrid, nullptr, ptr<int>(ctx->h2idx), dh2_out, P.stat))) return rc;
+    }
+    tm.mark(); tm.mark(); tm.mark();
+    return finish_status(ctx, status, &tm);
+  }
 
   if (opts->method == BLMM_NULL_EXACT) {
     if (lowrank) {

@@ -298,6 +298,51 @@ def test_scan_single_trait_and_own_rng(blmm):
     assert e.value.msg == "Intercept has to be added when no other covariate is given."
 
 
+def test_indefinite_kinship_warns_and_matches(blmm):
+    """A kinship with negative eigenvalues (src/transform_helpers.jl:27-31 only warns): the grid scan keeps working as
+    long as the weights stay positive on the grid, and the exact scan switches its weight basis to the identity."""
+    import warnings
+    Y, G, K, _ = make_data(p=120, m=30, seed=606)
+    lam = np.linalg.eigvalsh(K)
+    Kn = K - (lam[0] + 0.05) * np.eye(K.shape[0])          # smallest eigenvalue = -0.05
+    assert np.linalg.eigvalsh(Kn)[0] < -0.04
+    grid = [i / 10.0 for i in range(10)]                    # delta <= 9: 1 + delta * lambda >= 0.55
+    with warnings.catch_warnings(record=True) as rec:
+        warnings.simplefilter("always")
+        got = blmm.bulkscan_null_grid(Y, G, Kn, grid)
+        ref = O.bulkscan_null_grid(Y, G, Kn, grid)
+    assert any("Negative eigenvalues exist" in str(w.message) for w in rec)
+    assert np.array_equal(got.h2_null_list, ref.h2_null_list)
+    assert_lod_close(got.L, ref.L)
+    # the per-(trait, marker) grid scan shares the kernels' table path
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        al = blmm.bulkscan_alt_grid(Y, G, Kn, grid)
+        ar = O.bulkscan_alt_grid(Y, G, Kn, grid)
+    assert_lod_close(al.L, ar.L, atol=1e-9)
+    # exact LOD kernel with the identity weight basis (negative eigenvalues leave the smooth weight family): the seam
+    # with per-trait h2 on the grid
+    h2 = np.asarray(got.h2_null_list)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        Y0, X0, lamr = blmm.transform_rotation(Y, G, Kn)
+        ex = blmm.liteqtl_given_h2(Y0, X0, lamr, h2)
+    assert_lod_close(ex, got.L)
+
+
+def test_empty_inputs(blmm):
+    """No traits / no markers: empty results, no launch with a zero-sized grid."""
+    Y, G, K, _ = make_data(p=20, m=5, seed=707)
+    r = blmm.bulkscan_null(Y[:, :0], G, K)
+    assert r.L.shape == (20, 0) and r.h2_null_list.shape == (0,)
+    r = blmm.bulkscan_null_grid(Y, G[:, :0], K, [0.0, 0.5])
+    assert r.L.shape == (0, 5) and r.h2_null_list.shape == (5,)
+    ref = O.bulkscan_null_grid(Y, G[:, :1], K, [0.0, 0.5])
+    assert np.array_equal(r.h2_null_list, ref.h2_null_list)    # h2 does not depend on the markers
+    s = blmm.scan(Y[:, 0], G, K, permutation_test=True, nperms=0)
+    assert s["L_perms"].shape == (20, 0)
+
+
 def test_zero_norm_marker_raises(blmm):
     Y, G, K, _ = make_data(p=40, m=3, seed=121)
     G = G.copy()
