@@ -478,7 +478,7 @@ template <int MB, int NB>
 __global__ void __launch_bounds__(256, 2) k_scan_alt(AltArgs aa, int ntile_i, int64_t nwg) {
   const ScanArgs& a = aa.s;
   __shared__ dpair s_log[BLMM_LOG_TABLE_N];
-  stage_log_table<true>(s_log, a.logtab);
+  stage_lod_table(s_log, a.logtab, -0.5 * (double)a.n);   // scale folded into the table: fast_lod returns -(n/2) log10(u)
   __syncthreads();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int64_t bid = xcd_swizzle(blockIdx.x, nwg);
@@ -487,7 +487,7 @@ __global__ void __launch_bounds__(256, 2) k_scan_alt(AltArgs aa, int ntile_i, in
   const int64_t t0 = tile_t * (32 * MB) + (wave >> 1) * (16 * MB);
   const int64_t i0 = (int64_t)tile_i * (32 * NB) + (wave & 1) * (16 * NB);
   const int r = lane & 15, kk = lane >> 4;
-  const double scale = -0.5 * (double)a.n;
+  const LodPoly lp = make_lod_poly(-0.5 * (double)a.n);
   const double ln10 = 2.302585092994046;  // log(10)
   const int64_t ibase = i0 + NB * r;
 
@@ -524,20 +524,30 @@ __global__ void __launch_bounds__(256, 2) k_scan_alt(AltArgs aa, int ntile_i, in
       for (int nb = 0; nb < NB; ++nb)
         acc[mb][nb] = __builtin_amdgcn_mfma_f64_16x16x4f64(A[mb], B[nb], acc[mb][nb], 0, 0, 0);
   };
-  auto fold = [&](int g) {  // logL1_g = ln10*LOD_g + Ell[g, j]; keep the running maximum (tmax!, strict <)
-    double sc[NB];
+  // operands of fold(g) -- the marker norms of grid point g and Ell[g, trait] of the lane's 4*MB traits -- are fetched
+  // at the START of g's K loop: at fold time they used to cost one exposed global round trip per grid point
+  double sc[NB], ellv[MB][4];
+  auto fold_fetch = [&](int g) {
     loadv<NB>(sc, a.isx + (int64_t)g * a.ld_isx + ibase);
 #pragma unroll
     for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
       for (int reg = 0; reg < 4; ++reg) {
         const int64_t trait = t0 + MB * (kk + 4 * reg) + mb;
-        const double ell = (trait < a.m) ? aa.EllTab[trait * (int64_t)G + g] : 0.0;
+        ellv[mb][reg] = (trait < a.m) ? aa.EllTab[trait * (int64_t)G + g] : 0.0;
+      }
+  };
+  auto fold = [&](int g) {  // logL1_g = ln10*LOD_g + Ell[g, j]; keep the running maximum (tmax!, strict <)
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) {
+        const double ell = ellv[mb][reg];
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) {
           const double rr = acc[mb][nb][reg] * sc[nb];
           const double u = 1.0 - rr * rr;
-          double lod = scale * fast_log<true>(u, s_log);
+          double lod = fast_lod(u, s_log, lp);
           if (!(u > 0.0)) lod = (u == 0.0) ? INFINITY : NAN;
           const double l1 = fma(lod, ln10, ell);
           const bool first = g == 0;
@@ -554,6 +564,8 @@ __global__ void __launch_bounds__(256, 2) k_scan_alt(AltArgs aa, int ntile_i, in
   double a0[MB], b0[NB], a1[MB], b1[NB];
   load_next(a0, b0);
   for (int g = 0; g < G; ++g) {
+    fold_fetch(g);
+    __builtin_amdgcn_sched_barrier(0);
     int ks = 0;
     for (; ks + 2 <= KS; ks += 2) {
       load_next(a1, b1);                   // (g, ks+1)
@@ -602,9 +614,12 @@ __global__ void __launch_bounds__(256, 2) k_scan_alt(AltArgs aa, int ntile_i, in
   if (nnan) atomicAdd((unsigned long long*)&a.stat[ST_NAN_LOD], (unsigned long long)nnan);
 }
 
+#ifndef ALT_MB
+#define ALT_MB 1
+#endif
 int launch_scan_alt(blmm_ctx* ctx, const AltArgs& aa) {
   // MB = 1 (16 traits x 64 markers per wave): accumulators + running max + arg-max stay in registers at 2+ waves/SIMD
-  constexpr int MB = 1, NB = 4;
+  constexpr int MB = ALT_MB, NB = 4;
   const ScanArgs& a = aa.s;
   const int64_t ntile_t = (a.m + 32 * MB - 1) / (32 * MB);
   const int64_t ntile_i = (a.p + TILE_I - 1) / TILE_I;
