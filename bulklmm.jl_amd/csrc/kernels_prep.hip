@@ -1418,9 +1418,87 @@ __global__ void __launch_bounds__(256) k_loglik_grid(NullModel nm, const double*
   }
 }
 
+// The same with the operands staged in LDS once per trait and the batched-reciprocal evaluator of k_brent (the generic
+// evaluator above re-reads y from global memory for every grid point: one exposed round trip per element and point).
+template <int C, int LPT>
+__global__ void __launch_bounds__(256, BRENT_MINW) k_loglik_grid_lds(NullModel nm, const double* __restrict__ Yt, int64_t ldy,
+                                                         int64_t m, const double* __restrict__ Z0,
+                                                         const double* __restrict__ lam, const double* __restrict__ logtab,
+                                                         const double* __restrict__ grid, int ngrid,
+                                                         double* __restrict__ EllTab, int* __restrict__ h2idx,
+                                                         double* __restrict__ h2out, int64_t* stat) {
+  extern __shared__ __attribute__((aligned(16))) double sh[];
+  __shared__ dpair s_ln[BLMM_LOG_TABLE_N];
+  const int n = nm.n;
+  stage_null_lz<C, LPT>(sh, n, Z0, lam);
+  stage_log_table<false>(s_ln, logtab);
+  double* sY = sh + LPT * NULL_NK * (1 + C);
+  const int64_t j = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / LPT;
+  const int sub = threadIdx.x % LPT;
+  const bool valid = j < m;
+  stage_null_y<LPT>(sY, Yt + (valid ? j : 0), ldy, sub, n, valid);
+  __syncthreads();
+  NullRegs<C, LPT> R;
+  R.base = sh; R.lo = sub * NULL_NK * (1 + C); R.yo = LPT * NULL_NK * (1 + C) + threadIdx.x;
+  int nonpos = 0, best = 0;
+  double bestv = -INFINITY;
+  for (int g = 0; g < ngrid; ++g) {
+    const EllOut e = null_ell_reg<C, LPT>(grid[g], R, n, nm.prior_a, nm.prior_b, nm.reml, s_ln, &nonpos);
+    if (valid && sub == 0 && EllTab) EllTab[j * (int64_t)ngrid + g] = e.ell;
+    if (g == 0 || e.ell > bestv) { bestv = e.ell; best = g; }
+  }
+  if (valid && sub == 0) {
+    if (h2idx) h2idx[j] = best;
+    if (h2out) h2out[j] = grid[best];
+    if (nonpos) atomicAdd((unsigned long long*)&stat[ST_NONPOS_W], 1ull);
+  }
+}
+
+template <int C, int LPT>
+static int launch_loglik_grid_lds(blmm_ctx* ctx, const NullModel& nm, const double* Yt, int64_t ldy, int64_t m, const double* Z0,
+                                  const double* lam, const double* grid_dev, int ngrid, double* EllTab, int* h2idx,
+                                  double* h2, int64_t* stat) {
+  const int64_t threads = m * LPT;
+  const unsigned blocks = (unsigned)((threads + 255) / 256);
+  const size_t lds = sizeof(double) * ((size_t)LPT * NULL_NK * (1 + C) + (size_t)NULL_NK * 256);
+  if (lds > 48 * 1024)
+    BLMM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_loglik_grid_lds<C, LPT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL((k_loglik_grid_lds<C, LPT>), dim3(blocks), dim3(256), lds, ctx->stream, nm, Yt, ldy, m, Z0, lam,
+                     ptr<double>(ctx->logtab), grid_dev, ngrid, EllTab, h2idx, h2, stat);
+  KCHECK();
+  return BLMM_OK;
+}
+template <int C>
+static int launch_loglik_grid_c(blmm_ctx* ctx, const NullModel& nm, const double* Yt, int64_t ldy, int64_t m, const double* Z0,
+                                const double* lam, const double* grid_dev, int ngrid, double* EllTab, int* h2idx, double* h2,
+                                int64_t* stat, bool* done) {
+  const int n = nm.n;
+  *done = true;
+  if (n <= 4 * NULL_NK) return launch_loglik_grid_lds<C, 4>(ctx, nm, Yt, ldy, m, Z0, lam, grid_dev, ngrid, EllTab, h2idx, h2, stat);
+  if (n <= 8 * NULL_NK) return launch_loglik_grid_lds<C, 8>(ctx, nm, Yt, ldy, m, Z0, lam, grid_dev, ngrid, EllTab, h2idx, h2, stat);
+  if (n <= 16 * NULL_NK) return launch_loglik_grid_lds<C, 16>(ctx, nm, Yt, ldy, m, Z0, lam, grid_dev, ngrid, EllTab, h2idx, h2, stat);
+  if (n <= 32 * NULL_NK) return launch_loglik_grid_lds<C, 32>(ctx, nm, Yt, ldy, m, Z0, lam, grid_dev, ngrid, EllTab, h2idx, h2, stat);
+  if (n <= 64 * NULL_NK) return launch_loglik_grid_lds<C, 64>(ctx, nm, Yt, ldy, m, Z0, lam, grid_dev, ngrid, EllTab, h2idx, h2, stat);
+  *done = false;
+  return BLMM_OK;
+}
+
 int launch_loglik_grid(blmm_ctx* ctx, const NullModel& nm, const double* Yt, int64_t ldy, int64_t m, const double* Z0,
                        const double* lam, const double* grid_dev, int ngrid, double* EllTab, int* h2idx, double* h2,
                        int64_t* stat) {
+  static const char* gen_env = getenv("BLMM_LOGLIK_GENERIC");   // "1": the generic evaluator for every n (A/B testing)
+  if (!(gen_env && gen_env[0] == '1')) {
+    bool done = false;
+    int rc = BLMM_OK;
+    switch (nm.c) {
+      case 1: rc = launch_loglik_grid_c<1>(ctx, nm, Yt, ldy, m, Z0, lam, grid_dev, ngrid, EllTab, h2idx, h2, stat, &done); break;
+      case 2: rc = launch_loglik_grid_c<2>(ctx, nm, Yt, ldy, m, Z0, lam, grid_dev, ngrid, EllTab, h2idx, h2, stat, &done); break;
+      case 3: rc = launch_loglik_grid_c<3>(ctx, nm, Yt, ldy, m, Z0, lam, grid_dev, ngrid, EllTab, h2idx, h2, stat, &done); break;
+      case 4: rc = launch_loglik_grid_c<4>(ctx, nm, Yt, ldy, m, Z0, lam, grid_dev, ngrid, EllTab, h2idx, h2, stat, &done); break;
+      default: return fail(ctx, BLMM_ERR_UNSUPPORTED, "number of null covariates (incl. intercept) must be 1..4");
+    }
+    if (rc || done) return rc;
+  }
   const int64_t threads = m * BRENT_LPT;
   const unsigned blocks = (unsigned)((threads + 255) / 256);
   const size_t lds = sizeof(double) * (size_t)nm.n * (1 + nm.c);
