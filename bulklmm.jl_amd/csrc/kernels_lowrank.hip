@@ -448,19 +448,30 @@ __global__ void __launch_bounds__(64) k_lr_panels(NullModel nm, const double* __
   for (int a = 0; a < NA; ++a) A[a] = 0.0;
 #pragma unroll
   for (int q = 0; q < C; ++q) v[q] = 0.0;
-  for (int k = 0; k < n; ++k) {
-    const double w = fabs(fast_rcp(fma(delta, sLam[k], 1.0)));  // sqrt.(abs.(makeweights)) squared, src/bulkscan_helpers.jl:138
-    ww = fma(w, w, ww);
-    const double y = Yt[(int64_t)k * ldy + j];
-    const double wy = w * y;
-    syy = fma(wy, y, syy);
+  // y is read eight rows at a time (independent loads first): one thread walks a whole column, and a load placed next
+  // to its use costs a global round trip per row
+  for (int k0 = 0; k0 < n; k0 += 8) {
+    double yv[8];
 #pragma unroll
-    for (int q = 0; q < C; ++q) {
-      const double zq = sZ[q * n + k];
-      v[q] = fma(wy, zq, v[q]);
-      const double wz = w * zq;
+    for (int u = 0; u < 8; ++u) yv[u] = (k0 + u < n) ? Yt[(int64_t)(k0 + u) * ldy + j] : 0.0;
 #pragma unroll
-      for (int r = 0; r <= q; ++r) A[q * (q + 1) / 2 + r] = fma(wz, sZ[r * n + k], A[q * (q + 1) / 2 + r]);
+    for (int u = 0; u < 8; ++u) {
+      const int k = k0 + u;
+      if (k < n) {
+        const double w = fabs(fast_rcp(fma(delta, sLam[k], 1.0)));  // sqrt.(abs.(makeweights)) squared, src/bulkscan_helpers.jl:138
+        ww = fma(w, w, ww);
+        const double y = yv[u];
+        const double wy = w * y;
+        syy = fma(wy, y, syy);
+#pragma unroll
+        for (int q = 0; q < C; ++q) {
+          const double zq = sZ[q * n + k];
+          v[q] = fma(wy, zq, v[q]);
+          const double wz = w * zq;
+#pragma unroll
+          for (int r = 0; r <= q; ++r) A[q * (q + 1) / 2 + r] = fma(wz, sZ[r * n + k], A[q * (q + 1) / 2 + r]);
+        }
+      }
     }
   }
   double L[NA], Li[NA], t[C], beta[C], tt = 0.0;
@@ -499,16 +510,25 @@ __global__ void __launch_bounds__(64) k_lr_panels(NullModel nm, const double* __
   const double yy = syy - tt;
   if (!(sqrt(fabs(yy)) > 2.220446049250313e-16)) atomicAdd((unsigned long long*)&stat[ST_ZERO_NORM], 1ull);
   const double isy = 1.0 / sqrt(yy);
-  for (int k = 0; k < npad; ++k) {
-    double p0 = 0.0;
-    if (k < n) {
-      const double w = fabs(fast_rcp(fma(delta, sLam[k], 1.0)));
-      double res = Yt[(int64_t)k * ldy + j];
+  for (int k0 = 0; k0 < npad; k0 += 8) {
+    double yv[8];
 #pragma unroll
-      for (int q = 0; q < C; ++q) res = fma(-beta[q], sZ[q * n + k], res);
-      p0 = w * res * isy;
+    for (int u = 0; u < 8; ++u) yv[u] = (k0 + u < n) ? Yt[(int64_t)(k0 + u) * ldy + j] : 0.0;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int k = k0 + u;
+      if (k < npad) {
+        double p0 = 0.0;
+        if (k < n) {
+          const double w = fabs(fast_rcp(fma(delta, sLam[k], 1.0)));
+          double res = yv[u];
+#pragma unroll
+          for (int q = 0; q < C; ++q) res = fma(-beta[q], sZ[q * n + k], res);
+          p0 = w * res * isy;
+        }
+        P0[(int64_t)k * ldp + j] = p0;
+      }
     }
-    P0[(int64_t)k * ldp + j] = p0;
   }
 #pragma unroll
   for (int e = 0; e < NA; ++e) Ls[(int64_t)e * ldp + j] = Li[e];
