@@ -5,6 +5,8 @@
 #include "blmm_internal.h"
 #include "fastmath.h"
 #include <cmath>
+#include <cstring>
+#include <algorithm>
 #include <cstdlib>
 
 namespace blmm {
@@ -1936,6 +1938,166 @@ __global__ void k_perm_r0(NullModel nm, const double* __restrict__ Yt, int64_t l
   }
 }
 
+// ---- the same panel for large n x nperms, spread over the chip.  The one-thread-per-column kernels above walk n
+//      rows serially (0.7 ms per launch at n = 1000 whatever the number of columns, 0.36 ms for r0 on a single thread). ----
+template <int C>
+__global__ void __launch_bounds__(256) k_perm_r0_wg(NullModel nm, const double* __restrict__ Yt, int64_t ldy,
+                                                    const double* __restrict__ Z0, const double* __restrict__ lam,
+                                                    const double* __restrict__ h2p, double* __restrict__ r0buf) {
+  constexpr int NA = C * (C + 1) / 2;
+  __shared__ double s_part[NA + C][4], s_beta[C];
+  const int n = nm.n, t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const double h2 = h2p[0];
+  const double delta = h2 / (1.0 - h2);
+  double A[NA], g[C];
+  for (int a = 0; a < NA; ++a) A[a] = 0.0;
+  for (int q = 0; q < C; ++q) g[q] = 0.0;
+  for (int k = t; k < n; k += 256) {
+    const double w = 1.0 / fma(delta, lam[k], 1.0);
+    const double y = Yt[(int64_t)k * ldy];
+    for (int q = 0; q < C; ++q) {
+      const double wz = w * Z0[q * n + k];
+      g[q] = fma(wz, y, g[q]);
+      for (int r = 0; r <= q; ++r) A[q * (q + 1) / 2 + r] = fma(wz, Z0[r * n + k], A[q * (q + 1) / 2 + r]);
+    }
+  }
+  for (int a = 0; a < NA + C; ++a) {
+    double v = (a < NA) ? A[a] : g[a - NA];
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    if (lane == 0) s_part[a][wave] = v;
+  }
+  __syncthreads();
+  if (t == 0) {
+    for (int a = 0; a < NA; ++a) A[a] = (s_part[a][0] + s_part[a][1]) + (s_part[a][2] + s_part[a][3]);
+    for (int q = 0; q < C; ++q) g[q] = (s_part[NA + q][0] + s_part[NA + q][1]) + (s_part[NA + q][2] + s_part[NA + q][3]);
+    double L[NA], tt[C], beta[C];
+    for (int q = 0; q < C; ++q) {
+      for (int r = 0; r <= q; ++r) {
+        double sacc = A[q * (q + 1) / 2 + r];
+        for (int u = 0; u < r; ++u) sacc = fma(-L[q * (q + 1) / 2 + u], L[r * (r + 1) / 2 + u], sacc);
+        L[q * (q + 1) / 2 + r] = (r == q) ? sqrt(sacc) : sacc / L[r * (r + 1) / 2 + r];
+      }
+      double sacc = g[q];
+      for (int u = 0; u < q; ++u) sacc = fma(-L[q * (q + 1) / 2 + u], tt[u], sacc);
+      tt[q] = sacc / L[q * (q + 1) / 2 + q];
+    }
+    for (int q = C - 1; q >= 0; --q) {
+      double sacc = tt[q];
+      for (int u = q + 1; u < C; ++u) sacc = fma(-L[u * (u + 1) / 2 + q], beta[u], sacc);
+      beta[q] = sacc / L[q * (q + 1) / 2 + q];
+      s_beta[q] = beta[q];
+    }
+  }
+  __syncthreads();
+  for (int k = t; k < n; k += 256) {
+    const double w = 1.0 / fma(delta, lam[k], 1.0);
+    double v = Yt[(int64_t)k * ldy];
+    for (int q = 0; q < C; ++q) v = fma(-s_beta[q], Z0[q * n + k], v);
+    r0buf[k] = sqrt(w) * v;
+  }
+}
+
+// Fisher-Yates per permutation column with the index array in LDS (16-bit entries, k-major), the SAME splitmix64 stream and
+// swap sequence as k_perm_panel; writes permbuf[b * n + k].
+__global__ void __launch_bounds__(64) k_perm_gen(int n, int64_t nperms, uint64_t seed, int cols, int32_t* __restrict__ permbuf) {
+  extern __shared__ unsigned short s_perm[];
+  const int t = threadIdx.x;
+  const int64_t b = (int64_t)blockIdx.x * cols + t;
+  if (t >= cols || b >= nperms) return;
+  for (int k = 0; k < n; ++k) s_perm[k * cols + t] = (unsigned short)k;
+  uint64_t st = seed * 0xD1342543DE82EF95ull + (uint64_t)(b + 1);
+  for (int k = n - 1; k > 0; --k) {
+    const int r = (int)(splitmix64(st) % (uint64_t)(k + 1));
+    const unsigned short tmp = s_perm[k * cols + t]; s_perm[k * cols + t] = s_perm[r * cols + t]; s_perm[r * cols + t] = tmp;
+  }
+  for (int k = 0; k < n; ++k) permbuf[b * (int64_t)n + k] = (int32_t)s_perm[k * cols + t];
+}
+
+// One wave per column b: beta_b (coefficients of sqrt(w) Z0 for v = pi_b(r0)) and 1 / ||v||  -> coef[b][C + 1]
+template <int C>
+__global__ void __launch_bounds__(256) k_perm_coef(NullModel nm, const double* __restrict__ Z0, const double* __restrict__ lam,
+                                                   const double* __restrict__ h2p, const int32_t* __restrict__ perm,
+                                                   int64_t ncols, int orig, const double* __restrict__ r0buf,
+                                                   double* __restrict__ coef, int64_t* stat) {
+  constexpr int NA = C * (C + 1) / 2;
+  const int n = nm.n, lane = threadIdx.x & 63;
+  const int64_t b = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (b >= ncols) return;
+  const double h2 = h2p[0];
+  const double delta = h2 / (1.0 - h2);
+  double A[NA], g[C], rr = 0.0;
+  for (int a = 0; a < NA; ++a) A[a] = 0.0;
+  for (int q = 0; q < C; ++q) g[q] = 0.0;
+  for (int k = lane; k < n; k += 64) {
+    const double w = 1.0 / fma(delta, lam[k], 1.0);
+    const double sw = sqrt(w);
+    const int src = orig ? k : perm[b * (int64_t)n + k];
+    const double v = r0buf[src];
+    rr = fma(v, v, rr);
+    for (int q = 0; q < C; ++q) {
+      const double zq = sw * Z0[q * n + k];
+      g[q] = fma(zq, v, g[q]);
+      for (int r = 0; r <= q; ++r) A[q * (q + 1) / 2 + r] = fma(zq, sw * Z0[r * n + k], A[q * (q + 1) / 2 + r]);
+    }
+  }
+  for (int o = 32; o > 0; o >>= 1) {
+    rr += __shfl_xor(rr, o, 64);
+    for (int a = 0; a < NA; ++a) A[a] += __shfl_xor(A[a], o, 64);
+    for (int q = 0; q < C; ++q) g[q] += __shfl_xor(g[q], o, 64);
+  }
+  if (lane == 0) {
+    double L[NA], tt[C], beta[C];
+    for (int q = 0; q < C; ++q) {
+      for (int r = 0; r <= q; ++r) {
+        double sacc = A[q * (q + 1) / 2 + r];
+        for (int u = 0; u < r; ++u) sacc = fma(-L[q * (q + 1) / 2 + u], L[r * (r + 1) / 2 + u], sacc);
+        L[q * (q + 1) / 2 + r] = (r == q) ? sqrt(sacc) : sacc / L[r * (r + 1) / 2 + r];
+      }
+      double sacc = g[q];
+      for (int u = 0; u < q; ++u) sacc = fma(-L[q * (q + 1) / 2 + u], tt[u], sacc);
+      tt[q] = sacc / L[q * (q + 1) / 2 + q];
+    }
+    for (int q = C - 1; q >= 0; --q) {
+      double sacc = tt[q];
+      for (int u = q + 1; u < C; ++u) sacc = fma(-L[u * (u + 1) / 2 + q], beta[u], sacc);
+      beta[q] = sacc / L[q * (q + 1) / 2 + q];
+      coef[b * (C + 1) + q] = beta[q];
+    }
+    coef[b * (C + 1) + C] = 1.0 / sqrt(rr);
+    if (orig && !(sqrt(rr) > 2.220446049250313e-16)) atomicAdd((unsigned long long*)&stat[ST_ZERO_NORM], 1ull);
+  }
+}
+
+// P[k][b] = sqrt(w_k) (v_k - sum_q beta_bq sqrt(w_k) z_qk) / ||v||, v = pi_b(r0); zero beyond ncols / n.  Threads along b.
+template <int C>
+__global__ void __launch_bounds__(256) k_perm_fill(NullModel nm, const double* __restrict__ Z0, const double* __restrict__ lam,
+                                                   const double* __restrict__ h2p, const int32_t* __restrict__ perm,
+                                                   int64_t ncols, int orig, const double* __restrict__ r0buf,
+                                                   const double* __restrict__ coef, double* __restrict__ P, int64_t ldp) {
+  const int n = nm.n, npad = nm.npad;
+  const int64_t b = (int64_t)blockIdx.x * 64 + (threadIdx.x & 63);
+  const int k0 = (blockIdx.y * 4 + (threadIdx.x >> 6)) * 16;
+  if (b >= ldp) return;
+  const double h2 = h2p[0];
+  const double delta = h2 / (1.0 - h2);
+  const bool live = b < ncols;
+  double beta[C], inr = 0.0;
+  for (int q = 0; q < C; ++q) beta[q] = live ? coef[b * (C + 1) + q] : 0.0;
+  if (live) inr = coef[b * (C + 1) + C];
+  for (int k = k0; k < k0 + 16 && k < npad; ++k) {
+    double out = 0.0;
+    if (live && k < n) {
+      const double w = 1.0 / fma(delta, lam[k], 1.0);
+      const double sw = sqrt(w);
+      const int src = orig ? k : perm[b * (int64_t)n + k];
+      double v = r0buf[src];
+      for (int q = 0; q < C; ++q) v = fma(-beta[q], sw * Z0[q * n + k], v);
+      out = sw * v * inr;
+    }
+    P[(int64_t)k * ldp + b] = out;
+  }
+}
+
 int launch_perm_panel(blmm_ctx* ctx, const NullModel& nm, const double* Yt, int64_t ldy, const double* Z0,
                       const double* lam, const double* h2, const int32_t* perm_idx, int64_t nperms, uint64_t seed,
                       int orig, double* panel, int64_t ldp, int64_t* stat) {
@@ -1948,6 +2110,41 @@ int launch_perm_panel(blmm_ctx* ctx, const NullModel& nm, const double* Yt, int6
     permbuf = ptr<int32_t>(ctx->perm);
   }
   double* r0 = ptr<double>(ctx->r0);
+  // large n: the multi-kernel form (BLMM_PERM_PATH=old|new forces one; read per call so that a test can compare them)
+  const char* path_env = getenv("BLMM_PERM_PATH");
+  const bool newpath = path_env ? std::strcmp(path_env, "new") == 0 : nm.n > 256;
+  if (newpath && nm.n <= 65535) {
+    const int64_t ncols = orig ? 1 : nperms;
+    rc = ensure(ctx, ctx->tmpB, sizeof(double) * (size_t)(ncols > 0 ? ncols : 1) * (CMAX + 1) + 64);
+    if (rc) return rc;
+    double* coef = ptr<double>(ctx->tmpB);
+    const int32_t* pidx = perm_idx;
+    if (!orig && !perm_idx && nperms > 0) {
+      int cols = (int)std::min<size_t>(64, (150 * 1024) / (sizeof(unsigned short) * (size_t)nm.n));
+      if (cols < 1) cols = 1;
+      const size_t lds = sizeof(unsigned short) * (size_t)nm.n * cols;
+      BLMM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_perm_gen), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      hipLaunchKernelGGL(k_perm_gen, dim3((unsigned)((nperms + cols - 1) / cols)), dim3(64), lds, ctx->stream, nm.n, nperms, seed, cols, permbuf);
+      KCHECK();
+      pidx = permbuf;
+    }
+    dim3 fgrid((unsigned)((ldp + 63) / 64), (unsigned)((nm.npad + 63) / 64));
+#define PN(C)                                                                                                              \
+    if (orig) hipLaunchKernelGGL(k_perm_r0_wg<C>, dim3(1), dim3(256), 0, ctx->stream, nm, Yt, ldy, Z0, lam, h2, r0);       \
+    if (ncols > 0) hipLaunchKernelGGL(k_perm_coef<C>, dim3((unsigned)((ncols + 3) / 4)), dim3(256), 0, ctx->stream, nm, Z0, lam, h2, pidx, ncols, orig, r0, coef, stat); \
+    hipLaunchKernelGGL(k_perm_fill<C>, fgrid, dim3(256), 0, ctx->stream, nm, Z0, lam, h2, pidx, ncols, orig, r0, coef, P_, ldp)
+    double* P_ = panel;
+    switch (nm.c) {
+      case 1: PN(1); break;
+      case 2: PN(2); break;
+      case 3: PN(3); break;
+      case 4: PN(4); break;
+      default: return fail(ctx, BLMM_ERR_UNSUPPORTED, "number of null covariates (incl. intercept) must be 1..4");
+    }
+#undef PN
+    KCHECK();
+    return BLMM_OK;
+  }
   const unsigned blocks = (unsigned)((ldp + 63) / 64);
 #define PP(C)                                                                                                     \
   if (orig) hipLaunchKernelGGL(k_perm_r0<C>, dim3(1), dim3(64), 0, ctx->stream, nm, Yt, ldy, Z0, lam, h2, r0);   \

@@ -279,6 +279,33 @@ def test_scan_perms_f32_matches_fp64(blmm, n, p, nperms, ncov):
         blmm.scan(Y[:, 0], G, K, permutation_test=True, nperms=4, perm_precision="f16")
 
 
+@pytest.mark.parametrize("ncov", [0, 2])
+def test_scan_perms_multi_kernel_panel_equals_single_kernel(blmm, ncov, monkeypatch):
+    """The permutation panel has a one-thread-per-column form (small n) and a multi-kernel form (n > 256: Fisher-Yates
+    in LDS, one wave per column for the coefficients, an element-wise fill).  Same RNG stream, same arithmetic per
+    element up to the order of the sums: the two must agree to rounding, with supplied indices and with the own RNG."""
+    Y, G, K, Cov = make_data(n=61, p=97, m=1, seed=515 + ncov, ncov=ncov, bxd=False)
+    pidx = O.make_perm_idx(61, 70, 3)
+    out = {}
+    for path in ("old", "new"):
+        monkeypatch.setenv("BLMM_PERM_PATH", path)
+        a = blmm.scan(Y[:, 0], G, K, Cov, permutation_test=True, nperms=70, perm_idx=pidx)
+        b = blmm.scan(Y[:, 0], G, K, Cov, permutation_test=True, nperms=133, rndseed=9)
+        out[path] = (a, b)
+    for i in (0, 1):
+        assert_lod_close(out["new"][i]["lod"], out["old"][i]["lod"], rtol=1e-11, atol=1e-12)
+        assert_lod_close(out["new"][i]["L_perms"], out["old"][i]["L_perms"], rtol=1e-9, atol=1e-12)
+    # and against the oracle on the shared rotation
+    monkeypatch.setenv("BLMM_PERM_PATH", "new")
+    n = 61
+    cov1 = np.ones((n, 1)) if Cov is None else np.hstack([np.ones((n, 1)), Cov])
+    rot = blmm.transform_rotation(Y, np.hstack([cov1, G]), K, addIntercept=False)
+    got = out["new"][0]
+    pin = O.scan(Y[:, 0], G, K, covar=cov1, addIntercept=False, permutation_test=True, nperms=70, perm_idx=pidx,
+                 h2_override=got["h2_null"], rotation_override=rot)
+    assert_lod_close(got["L_perms"], pin["L_perms"])
+
+
 def test_scan_single_trait_and_own_rng(blmm):
     Y, G, K, _ = make_data(p=180, m=1, seed=111)
     s = blmm.scan(Y[:, 0], G, K)
