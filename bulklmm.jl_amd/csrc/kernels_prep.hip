@@ -740,8 +740,33 @@ __global__ void __launch_bounds__(256) k_rotate(const double* __restrict__ Rp, i
   }
 }
 
+// A handful of columns at large n (the single trait of scan / scan_perms): one matrix-vector product per column, rows of
+// the output across the lanes, the contraction split over the four waves (k_rotate would walk n/4 dependent steps on a
+// single wave column: 0.41 ms at n = 1000).
+__global__ void __launch_bounds__(256) k_rotate_vec(const double* __restrict__ Rp, int ldr, int n, int npad,
+                                                    const double* __restrict__ In, int64_t col, double* __restrict__ Out,
+                                                    int64_t ldo) {
+  __shared__ double s_acc[4][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int k = blockIdx.x * 64 + lane;
+  const double* x = In + col * (int64_t)n;
+  double acc = 0.0;
+  if (k < npad)
+    for (int i = wave; i < n; i += 4) acc = fma(Rp[(size_t)i * ldr + k], x[i], acc);
+  s_acc[wave][lane] = acc;
+  __syncthreads();
+  if (wave == 0 && k < npad) Out[(int64_t)k * ldo + col] = (s_acc[0][lane] + s_acc[1][lane]) + (s_acc[2][lane] + s_acc[3][lane]);
+}
+
 int launch_rotate(blmm_ctx* ctx, const double* Rp, int ldr, int n, int npad, const double* In, int64_t ncols,
                   double* Out, int64_t ldo, int64_t ncols_pad) {
+  if (ncols > 0 && ncols <= 4 && n > 256) {
+    BLMM_HIP(hipMemsetAsync(Out, 0, sizeof(double) * (size_t)npad * ldo, ctx->stream));   // pad columns read as zero
+    for (int64_t col = 0; col < ncols; ++col)
+      hipLaunchKernelGGL(k_rotate_vec, dim3((unsigned)((npad + 63) / 64)), dim3(256), 0, ctx->stream, Rp, ldr, n, npad, In, col, Out, ldo);
+    KCHECK();
+    return BLMM_OK;
+  }
   constexpr int MBLK = 5;
   const int nrb = (npad + 15) / 16;
   dim3 grid((unsigned)((ncols_pad + 63) / 64), (unsigned)((nrb + MBLK - 1) / MBLK));

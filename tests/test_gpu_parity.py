@@ -306,6 +306,23 @@ def test_scan_perms_multi_kernel_panel_equals_single_kernel(blmm, ncov, monkeypa
     assert_lod_close(got["L_perms"], pin["L_perms"])
 
 
+def test_scan_single_trait_large_n(blmm):
+    """n > 256: the single trait is rotated by the matrix-vector kernel, the permutation panel takes its multi-kernel
+    form, Brent runs with 16 lanes per trait."""
+    n = 300
+    Y, G, K, _ = make_data(n=n, p=64, m=1, seed=3300, bxd=False)
+    pidx = O.make_perm_idx(n, 40, 5)
+    got = blmm.scan(Y[:, 0], G, K, permutation_test=True, nperms=40, perm_idx=pidx)
+    ref = O.scan(Y[:, 0], G, K)
+    assert abs(got["h2_null"] - ref["h2_null"]) <= 1e-6
+    assert np.sum((got["lod"] - ref["lod"]) ** 2) <= 1e-7
+    rot = blmm.transform_rotation(Y, np.hstack([np.ones((n, 1)), G]), K, addIntercept=False)
+    pin = O.scan(Y[:, 0], G, K, covar=np.ones((n, 1)), addIntercept=False, permutation_test=True, nperms=40, perm_idx=pidx,
+                 h2_override=got["h2_null"], rotation_override=rot)
+    assert_lod_close(got["lod"], pin["lod"])
+    assert_lod_close(got["L_perms"], pin["L_perms"])
+
+
 def test_scan_single_trait_and_own_rng(blmm):
     Y, G, K, _ = make_data(p=180, m=1, seed=111)
     s = blmm.scan(Y[:, 0], G, K)
