@@ -87,6 +87,9 @@ def main():
                     help="perms: scan(...; permutation_test=true) with --m permutations of ONE trait (BASELINE.json configs[4])")
     ap.add_argument("--perm-dtype", default="f64", choices=["f64", "f32"],
                     help="--method perms: precision of the permutation LOD matrix (f32 = BASELINE.json configs[4])")
+    ap.add_argument("--streams", type=int, default=1,
+                    help="issue consecutive (independent) steps round-robin on this many contexts/streams; 1 = every step "
+                         "is one complete bulkscan wall-time (the reported default), > 1 = pipelined throughput")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
     ap.add_argument("--gather", action="store_true", help="put the RCCL all-gather of the LOD shards inside the step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -164,12 +167,21 @@ def main():
         dlod = torch.empty(p, dtype=torch.float64, device=dev)
 
     lr_rank = None
+    # --streams S > 1: S independent contexts (own stream, own workspace, own outputs); step i runs on context i % S
+    extra = []
+    for _ in range(max(a.streams, 1) - 1):
+        st_i = torch.cuda.Stream(device=dev)
+        extra.append((B.Context(dev_index, st_i.cuda_stream), torch.empty_like(dL), torch.empty_like(dH)))
+    step_no = [0]
 
     def step(gather):
+        k = step_no[0] % (1 + len(extra))
+        step_no[0] += 1
+        c_k, L_k, H_k = (ctx, dL, dH) if k == 0 else extra[k - 1]
         if perms:
-            B.scan_perms_dev(ctx, dy1, dG, dK, dsc, dlod, dL, nperms=m_local, seed=1 + rank)
+            B.scan_perms_dev(c_k, dy1, dG, dK, dsc, dlod, L_k, nperms=m_local, seed=1 + rank)
         else:
-            B.bulkscan_dev(ctx, dY, dG, dK, dL, dH, method=a.method, h2_grid=grid)
+            B.bulkscan_dev(c_k, dY, dG, dK, L_k, H_k, method=a.method, h2_grid=grid)
         if gather and world > 1 and backend == "nccl":
             dist.all_gather_into_tensor(dLfull.view(-1), dL.reshape(-1))
 
@@ -264,7 +276,8 @@ def main():
             "config": {"workload": f"bulkscan_null-shaped: method={a.method} n={n} p={p} m={m_total} fp64 "
                                    f"(BASELINE.json configs[1]; {m_local} traits per GPU)",
                        "n": n, "p": p, "m": m_total, "m_per_gpu": m_local, "method": a.method,
-                       "parallelism": f"traits sharded over {world} GPU(s)", "gather_in_step": bool(a.gather)},
+                       "parallelism": f"traits sharded over {world} GPU(s)", "gather_in_step": bool(a.gather),
+                       "streams": max(a.streams, 1)},
             "phases_ms": {k: v / max(ncalls, 1) for k, v in phases.items()},
             "allgather_ms": ag_ms, "output_finite": bool(chk),
             "roofline": roof, "cpu_baseline": cpu,
