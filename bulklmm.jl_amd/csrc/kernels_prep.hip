@@ -718,16 +718,25 @@ __global__ void __launch_bounds__(256) k_rotate(const double* __restrict__ Rp, i
   for (int b = 0; b < MBLK; ++b) acc[b] = (d4){0, 0, 0, 0};
   const bool colok = col < ncols;
   const double* pin = In + (colok ? col : 0) * (int64_t)n;
-  for (int i0 = 0; i0 < npad; i0 += 4) {
-    const int i = i0 + kk;
-    const double bv = (colok && i < n) ? pin[i] : 0.0;
-    const double* pr = Rp + (size_t)i * ldr + (lane & 15);
+  // four K steps per trip, every operand load of the trip issued before its first MFMA: a load placed next to its use
+  // exposes one L2 round trip per K step (the kernel runs at ~2 waves per SIMD)
+  for (int i0 = 0; i0 < npad; i0 += 16) {
+    double bv[4], av[4][MBLK];
 #pragma unroll
-    for (int b = 0; b < MBLK; ++b) {
-      const int r0 = (rb0 + b) * 16;
-      const double av = (r0 < ldr) ? pr[r0] : 0.0;
-      acc[b] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc[b], 0, 0, 0);
+    for (int u = 0; u < 4; ++u) {
+      const int i = i0 + 4 * u + kk;
+      bv[u] = (colok && i < n) ? pin[i] : 0.0;
+      const double* pr = Rp + (size_t)(i < npad ? i : 0) * ldr + (lane & 15);
+#pragma unroll
+      for (int b = 0; b < MBLK; ++b) {
+        const int r0 = (rb0 + b) * 16;
+        av[u][b] = (r0 < ldr && i < npad) ? pr[r0] : 0.0;
+      }
     }
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int b = 0; b < MBLK; ++b) acc[b] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u][b], bv[u], acc[b], 0, 0, 0);
   }
   if (col < ncols_pad) {
 #pragma unroll
