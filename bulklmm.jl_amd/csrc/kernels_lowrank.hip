@@ -167,6 +167,113 @@ __global__ void __launch_bounds__(WB_NS * TPS) k_wbasis(const double* __restrict
   if (t == 0) { rk[0] = R; rk[1] = (R + 3) / 4; stat[8] = R; }
 }
 
+// Register-resident variant for n <= 4 * NKR: the 256 sample columns live in the registers of their 4 lanes (NKR values
+// each), so the deflation of every column -- the bulk of an iteration -- touches LDS only for the new basis vector.  Same
+// greedy sequence as k_wbasis (same samples when that one runs with 256 of them, same pivot rule).
+template <int NKR>
+__global__ void __launch_bounds__(1024) k_wbasis_reg(const double* __restrict__ lam, int n, double* __restrict__ Q,
+                                                     int* __restrict__ rk, int64_t* stat, int qcap) {
+  extern __shared__ __attribute__((aligned(16))) double sh[];
+  constexpr int TPS = 4, NS = 256, NT = 1024;
+  double* sq = sh;              // n : the pivot column / new basis vector
+  double* sd = sh + n;          // n : re-orthogonalisation coefficients
+  double* Ql = sh + 2 * n;      // qcap x n : LDS mirror of the first basis vectors
+  __shared__ double s_red[NS];
+  __shared__ int s_arg[NS];
+  __shared__ int s_neg;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6, nwave = NT >> 6;
+  const int s = t / TPS, part = t % TPS;
+  if (t == 0) s_neg = 0;
+  __syncthreads();
+  for (int k = t; k < n; k += NT) if (lam[k] < -1e-12) s_neg = 1;
+  __syncthreads();
+  if (s_neg) {
+    for (int e = t; e < n * n; e += NT) Q[e] = ((e / n) == (e % n)) ? 1.0 : 0.0;
+    if (t == 0) { rk[0] = n; rk[1] = (n + 3) / 4; stat[8] = n; }
+    return;
+  }
+  const double delta = (s == 0) ? 0.0 : exp(2.302585092994046 * (-6.0 + 15.0 * (double)(s - 1) / (double)(NS - 2)));
+  double wv[NKR];
+  double nrm = 0.0;
+#pragma unroll
+  for (int i = 0; i < NKR; ++i) {
+    const int k = part + TPS * i;
+    wv[i] = (k < n) ? 1.0 / fma(delta, fabs(lam[k]), 1.0) : 0.0;
+    nrm = fma(wv[i], wv[i], nrm);
+  }
+  nrm += __shfl_xor(nrm, 1, 64); nrm += __shfl_xor(nrm, 2, 64);
+  const double inv = 1.0 / sqrt(nrm);
+#pragma unroll
+  for (int i = 0; i < NKR; ++i) wv[i] *= inv;
+  double res2 = 1.0;
+  const double tol2 = 2e-31 * (double)n;
+  int R = 0;
+  for (; R < n; ++R) {
+    if (part == 0) { s_red[s] = res2; s_arg[s] = s; }
+    __syncthreads();
+    for (int o = NS / 2; o > 0; o >>= 1) {     // arg-max of the residual norms (first maximum wins)
+      if (t < o && (s_red[t + o] > s_red[t] || (s_red[t + o] == s_red[t] && s_arg[t + o] < s_arg[t]))) { s_red[t] = s_red[t + o]; s_arg[t] = s_arg[t + o]; }
+      __syncthreads();
+    }
+    const double mx = s_red[0];
+    const int piv = s_arg[0];
+    __syncthreads();
+    if (!(mx > tol2)) break;
+    if (s == piv) {
+#pragma unroll
+      for (int i = 0; i < NKR; ++i) { const int k = part + TPS * i; if (k < n) sq[k] = wv[i]; }
+    }
+    __syncthreads();
+    for (int pass = 0; pass < 2; ++pass) {     // classical Gram-Schmidt twice (as k_wbasis)
+      for (int r = wave; r < R; r += nwave) {
+        const double* qt = (r < qcap) ? Ql + r * n : Q + (size_t)r * n;
+        double d = 0.0;
+        for (int k = lane; k < n; k += 64) d = fma(qt[k], sq[k], d);
+        d = wave_sum(d);
+        if (lane == 0) sd[r] = d;
+      }
+      __syncthreads();
+      for (int k = t; k < n; k += NT) {
+        double v = sq[k];
+        const int rl = R < qcap ? R : qcap;
+        for (int r = 0; r < rl; ++r) v = fma(-sd[r], Ql[r * n + k], v);
+        for (int r = rl; r < R; ++r) v = fma(-sd[r], Q[(size_t)r * n + k], v);
+        sq[k] = v;
+      }
+      __syncthreads();
+    }
+    double pn = 0.0;
+    for (int k = t; k < n; k += NT) pn = fma(sq[k], sq[k], pn);
+    pn = wave_sum(pn);
+    if (lane == 0) s_red[wave] = pn;
+    __syncthreads();
+    double tot = 0.0;
+    for (int w = 0; w < nwave; ++w) tot += s_red[w];
+    const double qn = 1.0 / sqrt(tot);
+    __syncthreads();
+    if (!(tot > 1e-8 * mx)) break;             // noise pivot: the family is exhausted
+    for (int k = t; k < n; k += NT) { const double v = sq[k] * qn; sq[k] = v; Q[(size_t)R * n + k] = v; if (R < qcap) Ql[R * n + k] = v; }
+    __syncthreads();
+    // deflate this lane group's sample column (registers) against the new basis vector (LDS, 4 addresses per wave)
+    double qv[NKR];
+    double c = 0.0;
+#pragma unroll
+    for (int i = 0; i < NKR; ++i) {
+      const int k = part + TPS * i;
+      qv[i] = (k < n) ? sq[k] : 0.0;
+      c = fma(qv[i], wv[i], c);
+    }
+    c += __shfl_xor(c, 1, 64); c += __shfl_xor(c, 2, 64);
+    double r2 = 0.0;
+#pragma unroll
+    for (int i = 0; i < NKR; ++i) { wv[i] = fma(-c, qv[i], wv[i]); r2 = fma(wv[i], wv[i], r2); }
+    r2 += __shfl_xor(r2, 1, 64); r2 += __shfl_xor(r2, 2, 64);
+    res2 = r2;
+    __syncthreads();
+  }
+  if (t == 0) { rk[0] = R; rk[1] = (R + 3) / 4; stat[8] = R; }
+}
+
 // Multi-workgroup variant for n beyond the single-workgroup LDS budget.  The 256 sample columns are dealt S per
 // workgroup and stay in LDS (one wave per column: rows across the lanes); every workgroup runs the SAME greedy
 // iteration and builds the SAME Q (bitwise: identical inputs, identical instruction sequence), so the only exchange per
@@ -319,7 +426,16 @@ int launch_wbasis(blmm_ctx* ctx, const double* lam, int n, double* Wk, double* Q
   int ns = 0;
   for (int cand : {256, 192, 128})
     if (work + row * (size_t)(cand + 16) + row * 16 <= budget) { ns = cand; break; }
-  static const char* mw_env = getenv("BLMM_WBASIS");   // "single": never take the multi-workgroup variant (A/B testing)
+  static const char* mw_env = getenv("BLMM_WBASIS");   // "single": never take the multi-workgroup variant; "lds": never the register one (A/B testing)
+  if (n <= 80 && !(mw_env && std::strcmp(mw_env, "lds") == 0)) {
+    // sample columns in registers (20 per lane; 32 for n <= 128 would spill at 1024 threads)
+    const int qcap = (int)std::min<size_t>(WB_QCAP, (budget - work) / row);
+    const size_t lds = work + row * qcap;
+    BLMM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wbasis_reg<20>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(k_wbasis_reg<20>, dim3(1), dim3(1024), lds, ctx->stream, lam, n, Q, rk, stat, qcap);
+    KCHECK();
+    return BLMM_OK;
+  }
   if (ns) {
     const size_t wbytes = row * (size_t)(ns + 16);
     const int qcap = (int)std::min<size_t>(WB_QCAP, (budget - work - wbytes) / row);
