@@ -455,6 +455,49 @@ def test_eigensolver_accuracy(blmm, n, bxd):
     assert np.all(np.diff(lam) >= 0)
 
 
+def test_plain_c_caller_through_the_abi(blmm, tmp_path):
+    """The boundary without Python in the way: a gcc-compiled C program (tests/c_abi/c_abi_smoke.c) includes
+    include/bulklmm_hip.h, links libbulklmm_hip.so and calls the host-pointer entry points like a Julia `ccall` would;
+    its outputs must equal the ctypes mirror's bit for bit (same library, same inputs) and match the oracle."""
+    import subprocess, os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    libdir = os.path.join(root, "bulklmm.jl_amd", "csrc")
+    exe = str(tmp_path / "c_abi_smoke")
+    cc = subprocess.run(["gcc", "-O1", "-std=c99", "-Wall", "-Werror", "-I", os.path.join(root, "include"),
+                         os.path.join(root, "tests", "c_abi", "c_abi_smoke.c"), "-o", exe, "-L", libdir, "-lbulklmm_hip",
+                         "-Wl,-rpath," + libdir], capture_output=True, text=True)
+    assert cc.returncode == 0, cc.stderr
+    Y, G, _, _ = make_data(p=130, m=37, seed=8080)
+    n, m = Y.shape
+    p = G.shape[1]
+    grid = np.array([i / 10.0 for i in range(10)])
+    fin, fout = tmp_path / "in.bin", tmp_path / "out.bin"
+    with open(fin, "wb") as f:
+        np.array([n, m, p, len(grid)], dtype=np.int64).tofile(f)
+        np.asfortranarray(Y).ravel(order="F").tofile(f)
+        np.asfortranarray(G).ravel(order="F").tofile(f)
+        grid.tofile(f)
+    run = subprocess.run([exe, str(fin), str(fout)], capture_output=True, text=True, timeout=300)
+    assert run.returncode == 0, run.stdout + run.stderr
+    raw = np.fromfile(fout, dtype=np.float64)
+    o = 0
+    K = raw[o:o + n * n].reshape((n, n), order="F"); o += n * n
+    L1 = raw[o:o + p * m].reshape((p, m), order="F"); o += p * m
+    h1 = raw[o:o + m]; o += m
+    L2 = raw[o:o + p * m].reshape((p, m), order="F"); o += p * m
+    h2 = raw[o:o + m]; o += m
+    assert o == raw.size
+    Kp = blmm.calcKinship(G)
+    assert np.array_equal(K, Kp)
+    g = blmm.bulkscan_null_grid(Y, G, Kp, list(grid))
+    e = blmm.bulkscan_null(Y, G, Kp)
+    assert np.array_equal(L1, g.L) and np.array_equal(h1, g.h2_null_list)
+    assert np.array_equal(h2, e.h2_null_list) and np.array_equal(L2, e.L)
+    ref = O.bulkscan_null_grid(Y, G, O.calcKinship(G), list(grid))
+    assert np.array_equal(h1, ref.h2_null_list)
+    assert_lod_close(L1, ref.L)
+
+
 def test_lod_colmax_and_thresholds(blmm):
     """test/analysis_helpers_test.jl (get_thresholds): per-permutation peaks and their quantiles."""
     rng = np.random.default_rng(5)
