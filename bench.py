@@ -10,11 +10,14 @@ BASELINE.json configs[1]) whose inputs are already resident in HBM; the p x m LO
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
-N > 1: one process per GPU, traits sharded (weak scaling: every rank scans its own BXD-shaped shard of
-m traits; no data-path collective in the timed region).  The north_star's optional final step -- an RCCL
-all-gather of the LOD column shards over xGMI -- is timed once OUTSIDE the timed region and reported as
-`allgather_ms` (add --gather to put it inside the step).
-Rank 0 prints ONE JSON line."""
+N > 1: one process per GPU.  Without WORLD_SIZE in the environment `--gpus N` starts the N ranks itself
+(torch.distributed.run as a child process, BEFORE anything touches the GPU in this one).  The headline for N > 1 is
+STRONG scaling of the ONE BXD-shaped problem (BASELINE.json's metric: "full BXD-shaped bulkscan wall-time at 1/2/4/8
+GPUs"): rank r scans the trait block sharding.trait_shard(m, r, N); no data-path collective in the timed region.  The
+north_star's optional final step -- an RCCL all-gather of the LOD column blocks over xGMI -- is timed separately
+(`allgather_ms`) and a second timed loop with the gather inside the step gives `gathered_ms_per_step`; `weak` holds the
+weak-scaling figure (every rank scans a full BXD-shaped batch) measured in the same run.  `--scaling weak` makes that
+one the headline instead.  Rank 0 prints ONE JSON line."""
 import argparse
 import json
 import os
@@ -90,31 +93,45 @@ def main():
     ap.add_argument("--streams", type=int, default=1,
                     help="issue consecutive (independent) steps round-robin on this many contexts/streams; 1 = every step "
                          "is one complete bulkscan wall-time (the reported default), > 1 = pipelined throughput")
-    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
+    ap.add_argument("--scaling", default=None, choices=["weak", "strong"],
+                    help="N > 1 only; default strong (one BXD problem sharded over the ranks)")
+    ap.add_argument("--no-host-api", action="store_true", help="skip the end-to-end (host pointers in, host L out) timing")
     ap.add_argument("--gather", action="store_true", help="put the RCCL all-gather of the LOD shards inside the step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=15.0)
     a = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and a.gpus > 1:
+        # start the ranks ourselves; nothing in this process has touched the GPU yet (no torch import, no HIP call)
+        import socket
+        import subprocess
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        raise SystemExit(subprocess.run(cmd).returncode)
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != a.gpus and world > 1:
         a.gpus = world
+    if a.scaling is None:
+        a.scaling = "strong" if world > 1 else "weak"   # N = 1: the two coincide
 
     n, p = a.n, a.p
-    m_local = a.m if a.scaling == "weak" else -(-a.m // world)
-    m_total = m_local * world if a.scaling == "weak" else a.m
-    # every rank draws its own shard (rank-dependent seed under weak scaling, a slice under strong scaling)
+    # ONE problem, generated identically on every rank (fixed seed); rank r owns the trait block trait_shard(m, r, N)
+    Yf, G, K = synth(n, p, a.m, 20240 + 1)
+    spec = __import__("importlib.util").util.spec_from_file_location("blmm_sharding", os.path.join(ROOT, "bulklmm.jl_amd", "sharding.py"))
+    sharding = __import__("importlib.util").util.module_from_spec(spec)
+    spec.loader.exec_module(sharding)          # pure Python: importing it does not touch the GPU
+    lo, hi = sharding.trait_shard(a.m, rank, world)
+    sizes = sharding.shard_sizes(a.m, world)
+    mx = max(sizes)
     if a.scaling == "weak":
-        Y, G, K = synth(n, p, m_local, 20240 + 1 + 1000 * rank)
-        if rank > 0:  # all ranks share the markers and the kinship of rank 0's draw
-            _, G, K = synth(n, p, 1, 20240 + 1)
+        Y = Yf; m_local = a.m; m_total = a.m * world
     else:
-        Yf, G, K = synth(n, p, a.m, 20240 + 1)
-        lo = min(rank * m_local, a.m)
-        Y = np.ascontiguousarray(Yf[:, lo:min(lo + m_local, a.m)])
-        m_local = Y.shape[1]
+        Y = np.ascontiguousarray(Yf[:, lo:hi]); m_local = hi - lo; m_total = a.m
 
     cpu = None
     if rank == 0 and world == 1 and not a.no_cpu_baseline and a.method == "null-exact":
@@ -142,87 +159,146 @@ def main():
         if world > 1:
             dist.barrier()
 
+    alt = a.method == "alt-grid"
+    perms = a.method == "perms"
+    f32 = perms and a.perm_dtype == "f32"
+    ldt = torch.float32 if f32 else torch.float64
     # column-major device operands: a (cols, rows) contiguous tensor IS the rows x cols column-major matrix
-    dY = torch.from_numpy(np.ascontiguousarray(Y.T)).to(dev)
     dG = torch.from_numpy(np.ascontiguousarray(G.T)).to(dev)
     dK = torch.from_numpy(np.ascontiguousarray(K.T)).to(dev)
-    alt = a.method == "alt-grid"
-    if a.gather or True:
-        # the gathered matrix: shards are contiguous column blocks of the column-major p x m_total L
-        dLfull = torch.empty((world, m_local, p), dtype=torch.float64, device=dev) if world > 1 else None
-    f32 = a.method == "perms" and a.perm_dtype == "f32"
-    if f32:   # fp32 permutation matrix (the all-gather, if any, moves fp32 too)
-        dLfull = torch.empty((world, m_local, p), dtype=torch.float32, device=dev) if world > 1 else None
-    dL = dLfull[rank] if world > 1 else torch.empty((m_local, p), dtype=torch.float32 if f32 else torch.float64, device=dev)
-    dH = torch.empty((m_local, p) if alt else (m_local,), dtype=torch.float64, device=dev)
     grid = [i / 16.0 for i in range(16)] if a.method in ("null-grid", "alt-grid") else None
-
     stream = torch.cuda.current_stream()
-    ctx = B.Context(dev_index, stream.cuda_stream)
+    ctx = B.Context(dev_index, stream.cuda_stream)   # torch's current stream (handle 0 = the legacy default stream is adopted as such)
 
-    perms = a.method == "perms"
-    if perms:
-        dy1 = dY[0].contiguous()
-        dsc = torch.empty(2, dtype=torch.float64, device=dev)
-        dlod = torch.empty(p, dtype=torch.float64, device=dev)
+    class Work:
+        """One rank's operands and outputs for a trait block Ycols (n x mloc)."""
+        def __init__(self, Ycols, slot_cols=None):
+            self.m = Ycols.shape[1]
+            self.dY = torch.from_numpy(np.ascontiguousarray(Ycols.T)).to(dev)
+            # gathered layout: `world` slots of slot_cols columns each (the largest shard: ragged shards leave pad columns
+            # at the end of their slot); this rank scans straight into its slot, the all-gather is in place
+            self.slot = slot_cols
+            if world > 1 and slot_cols is not None:
+                self.full = torch.empty((world, slot_cols, p), dtype=ldt, device=dev)
+                self.dL = self.full[rank][: self.m]
+            else:
+                self.full = None
+                self.dL = torch.empty((self.m, p), dtype=ldt, device=dev)
+            self.dH = torch.empty((self.m, p) if alt else (max(self.m, 1),), dtype=torch.float64, device=dev)
+            if perms:
+                self.dy1 = self.dY[0].contiguous()
+                self.dsc = torch.empty(2, dtype=torch.float64, device=dev)
+                self.dlod = torch.empty(p, dtype=torch.float64, device=dev)
 
-    lr_rank = None
+        def scan(self, c=None, L=None, H=None):
+            c = c or ctx; L = self.dL if L is None else L; H = self.dH if H is None else H
+            if perms:
+                B.scan_perms_dev(c, self.dy1, dG, dK, self.dsc, self.dlod, L, nperms=self.m, seed=1 + rank)
+            else:
+                B.bulkscan_dev(c, self.dY, dG, dK, L, H, method=a.method, h2_grid=grid)
+
+        def gather(self):
+            if self.full is not None and backend == "nccl":
+                dist.all_gather_into_tensor(self.full.view(-1), self.full[rank].reshape(-1))
+
+    work = Work(Y, mx if a.scaling == "strong" else a.m)
+
     # --streams S > 1: S independent contexts (own stream, own workspace, own outputs); step i runs on context i % S
     extra = []
     for _ in range(max(a.streams, 1) - 1):
         st_i = torch.cuda.Stream(device=dev)
-        extra.append((B.Context(dev_index, st_i.cuda_stream), torch.empty_like(dL), torch.empty_like(dH)))
+        extra.append((B.Context(dev_index, st_i.cuda_stream), torch.empty_like(work.dL), torch.empty_like(work.dH)))
     step_no = [0]
 
-    def step(gather):
+    def step(w, gather):
         k = step_no[0] % (1 + len(extra))
         step_no[0] += 1
-        c_k, L_k, H_k = (ctx, dL, dH) if k == 0 else extra[k - 1]
-        if perms:
-            B.scan_perms_dev(c_k, dy1, dG, dK, dsc, dlod, L_k, nperms=m_local, seed=1 + rank)
+        if k == 0:
+            w.scan()
         else:
-            B.bulkscan_dev(c_k, dY, dG, dK, L_k, H_k, method=a.method, h2_grid=grid)
-        if gather and world > 1 and backend == "nccl":
-            dist.all_gather_into_tensor(dLfull.view(-1), dL.reshape(-1))
+            w.scan(*extra[k - 1])
+        if gather:
+            w.gather()
 
-    for _ in range(max(a.warmup, 1)):
-        step(a.gather)
-    torch.cuda.synchronize()
-    ctx.set_timing(True)
-    ctx.read_timings()
-    barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        step(a.gather)
-    torch.cuda.synchronize()
-    barrier()
-    dt = time.perf_counter() - t0
-    phases, ncalls = ctx.read_timings()
-    ctx.set_timing(False)
-    if a.method == "null-exact":   # one extra (untimed) call with a status read-back: rank of the weight basis
-        st = B.bulkscan_dev(ctx, dY, dG, dK, dL, dH, method=a.method, h2_grid=grid, status=True)
-        lr_rank = int(st.lowrank_rank)
-        lr_resid = float(st.lowrank_resid)
-
-    ag_ms = None
-    if world > 1 and backend == "nccl":
-        torch.cuda.synchronize(); barrier()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        dist.all_gather_into_tensor(dLfull.view(-1), dL.reshape(-1))
-        torch.cuda.synchronize(); barrier()
-        e0.record()
-        dist.all_gather_into_tensor(dLfull.view(-1), dL.reshape(-1))
-        e1.record()
+    def timed(w, gather, steps, warmup):
+        """`steps` steps bracketed by barrier + synchronize on both sides; the MAX over ranks of the wall time."""
+        for _ in range(max(warmup, 1)):
+            step(w, gather)
         torch.cuda.synchronize()
-        ag_ms = e0.elapsed_time(e1)
+        ctx.set_timing(True)
+        ctx.read_timings()
+        barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step(w, gather)
+        torch.cuda.synchronize()
+        barrier()
+        dt = time.perf_counter() - t0
+        ph, nc = ctx.read_timings()
+        ctx.set_timing(False)
+        tmax = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+        if world > 1:
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        return float(tmax.item()), ph, nc
 
-    tmax = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
-    if world > 1:
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    dt = float(tmax.item())
+    dt, phases, ncalls = timed(work, a.gather, a.steps, a.warmup)
+    lr_rank = lr_resid = lr_fallback = None
+    if a.method == "null-exact":   # one extra (untimed) call with a status read-back: the weight basis and its guard
+        st = B.bulkscan_dev(ctx, work.dY, dG, dK, work.dL, work.dH, method=a.method, h2_grid=grid, status=True)
+        lr_rank, lr_resid, lr_fallback = int(st.lowrank_rank), float(st.lowrank_resid), int(st.lowrank_fallback)
     # sanity: the output must be finite (a fast kernel with wrong results is not a result)
-    chk = torch.isfinite(dL[: min(64, m_local)]).all().item()
+    chk = torch.isfinite(work.dL[: min(64, work.m)]).all().item()
+
+    ag_ms = gathered_ms = None
+    weak = None
+    if world > 1:
+        if backend == "nccl":
+            work.gather(); torch.cuda.synchronize(); barrier()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(); work.gather(); e1.record()
+            torch.cuda.synchronize()
+            agt = torch.tensor([e0.elapsed_time(e1)], dtype=torch.float64, device=dev)
+            dist.all_reduce(agt, op=dist.ReduceOp.MAX)
+            ag_ms = float(agt.item())
+            if not a.gather:
+                dtg, _, _ = timed(work, True, a.steps, 1)
+                gathered_ms = dtg / a.steps * 1e3
+        # the other scaling mode in the same run, as an extra field
+        other = "weak" if a.scaling == "strong" else "strong"
+        w2 = Work(Yf if other == "weak" else np.ascontiguousarray(Yf[:, lo:hi]), None)
+        dt2, _, _ = timed(w2, False, a.steps, 1)
+        tests2 = p * (a.m * world if other == "weak" else a.m)
+        weak = {"scaling": other, "value": tests2 / (dt2 / a.steps), "ms_per_step": dt2 / a.steps * 1e3,
+                "m_per_gpu": a.m if other == "weak" else mx}
+        del w2
+
+    host_api = None
+    if rank == 0 and world == 1 and not a.no_host_api and not perms and a.streams == 1:
+        # SURVEY.md §8(d)'s third time: host inputs -> host L through the drop-in entry point (H2D of Y/G/K, the same
+        # kernels, D2H of L into caller memory); once into a fresh pageable array, once into a pinned (registered) one
+        Lh = np.empty((p, m_local), order="F")
+        Lh[:] = 0.0                                    # touch the pages: the caller's allocation cost is not ours
+        meth = {"null-exact": B._lib.BLMM_NULL_EXACT, "null-grid": B._lib.BLMM_NULL_GRID, "alt-grid": B._lib.BLMM_ALT_GRID}[a.method]
+        hctx = B.Context(dev_index)
+        def host_call(out):
+            t0 = time.perf_counter()
+            B.api.bulkscan_into(hctx, meth, Y, G, K, out, h2_grid=grid)
+            return (time.perf_counter() - t0) * 1e3
+        host_call(Lh)
+        t_page = min(host_call(Lh) for _ in range(2))
+        t_pin = None
+        try:
+            B.api.host_register(Lh)
+            host_call(Lh)
+            t_pin = min(host_call(Lh) for _ in range(2))
+            B.api.host_unregister(Lh)
+        except Exception as e:   # noqa: BLE001
+            t_pin = None
+        host_api = {"end_to_end_ms_pageable_out": t_page, "end_to_end_ms_pinned_out": t_pin,
+                    "tests_per_s_end_to_end": p * m_local / ((t_pin or t_page) * 1e-3),
+                    "note": "host Y/G/K in, host L out (2.08 GB over PCIe at BXD size); never `value`"}
+        hctx.close()
 
     if rank == 0:
         ms_step = dt / a.steps * 1e3
@@ -251,11 +327,15 @@ def main():
                 "kernel_ms": scan_ms, "alg_flops_per_launch": flops_launch,
                 "alg_bytes_per_launch": (4.0 if f32 else 8.0) * p * m_local,
                 "hbm_write_GBps": (4.0 if f32 else 8.0) * p * m_local / (scan_ms * 1e-3) / 1e9 if scan_ms > 0 else None,
-                "hbm_peak_GBps": HBM_PEAK_GBS}
+                "hbm_peak_GBps": HBM_PEAK_GBS,
+                "clock": "HIP events around the scan phase on the launching stream, averaged over the timed steps "
+                         "(the rocprofv3 --kernel-trace average of the same kernel, which runs at the profiler's lower "
+                         "clock, is in profiles/ and in frac_rocprof when profiles/traffic_latest.json matches)"}
         if survey_flops:
             roof["flops_per_test_executed"] = flops_launch / (p * m_local)
             roof["weight_basis_rank"] = lr_rank
             roof["weight_basis_resid"] = lr_resid
+            roof["traits_rescanned_full_rank"] = lr_fallback
             roof["reference_formulation_flops_per_launch"] = survey_flops   # 2n(2+c) per test, SURVEY.md §8(d)
             roof["reference_formulation_equiv_TFLOPs"] = survey_flops / (scan_ms * 1e-3) / 1e12 if scan_ms > 0 else None
             roof["note"] = ("achieved/frac count the flops the kernel EXECUTES (low-rank weights form); the same launch "
@@ -267,6 +347,9 @@ def main():
                 if tj.get("method") == a.method and tj.get("m") == m_local and tj.get("p") == p:
                     roof["traffic"] = tj.get("hbm_bytes_per_launch")
                     roof["traffic_source"] = tj.get("source")
+                    if tj.get("rocprof_kernel_avg_ms"):
+                        roof["kernel_ms_rocprof"] = tj["rocprof_kernel_avg_ms"]
+                        roof["frac_rocprof"] = flops_launch / (tj["rocprof_kernel_avg_ms"] * 1e-3) / 1e12 / roof["peak"]
             except Exception:
                 pass
         out = {
@@ -274,13 +357,18 @@ def main():
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms_step, "higher_is_better": True,
             "scaling": a.scaling, "vs_baseline": None, "dtype": "f32" if f32 else "f64", "data": "synthetic",
             "config": {"workload": f"bulkscan_null-shaped: method={a.method} n={n} p={p} m={m_total} fp64 "
-                                   f"(BASELINE.json configs[1]; {m_local} traits per GPU)",
+                                   f"(BASELINE.json configs[1]; {m_local} traits on rank 0)",
                        "n": n, "p": p, "m": m_total, "m_per_gpu": m_local, "method": a.method,
                        "parallelism": f"traits sharded over {world} GPU(s)", "gather_in_step": bool(a.gather),
                        "streams": max(a.streams, 1)},
             "phases_ms": {k: v / max(ncalls, 1) for k, v in phases.items()},
-            "allgather_ms": ag_ms, "output_finite": bool(chk),
+            "allgather_ms": ag_ms, "gathered_ms_per_step": gathered_ms, "other_scaling": weak, "output_finite": bool(chk),
+            "host_api": host_api,
             "roofline": roof, "cpu_baseline": cpu,
+            # the only number the reference publishes for this shape (default null-grid, 10-point grid, 16 Julia threads,
+            # Xeon Silver 4214): 2.112 s -- different method and hardware, so it is context, not a vs_baseline
+            "reference_published": {"tests_per_s": 260290834 / 2.112011, "seconds": 2.112011, "method": "null-grid (10-point grid)",
+                                    "hardware": "Intel Xeon Silver 4214, 16 Julia threads", "source": "README.md:336-339"},
         }
         print(json.dumps(out))
     if world > 1:

@@ -19,11 +19,15 @@ EXPORTS = [
     "blmm_kinship", "blmm_kinship_dev", "blmm_bulkscan", "blmm_bulkscan_dev", "blmm_scan_perms",
     "blmm_scan_perms_dev", "blmm_scan_perms_f32", "blmm_scan_perms_f32_dev", "blmm_lod_colmax", "blmm_lod_colmax_dev", "blmm_rotate", "blmm_null_h2_brent", "blmm_null_loglik_grid",
     "blmm_weighted_liteqtl", "blmm_liteqtl_given_h2",
+    "blmm_create_multi", "blmm_destroy_multi", "blmm_multi_ndev", "blmm_multi_last_error", "blmm_default_multi_opts",
+    "blmm_multi_shard", "blmm_bulkscan_multi", "blmm_multi_device_result",
+    "blmm_host_register", "blmm_host_unregister", "blmm_host_alloc", "blmm_host_free",
 ]
 
 BLMM_NULL_EXACT, BLMM_NULL_GRID, BLMM_ALT_GRID = 0, 1, 2
 BLMM_EIGEN, BLMM_SVD = 0, 1
 BLMM_COMPAT_ALT_COUNTER = 1
+BLMM_GATHER_NONE, BLMM_GATHER_HOST_SHARDS, BLMM_GATHER_ALLGATHER = 0, 1, 2
 
 ERR_ZERO_NORM_MSG = "Dividing by zeros: the input vector can not contain any zeros!"
 
@@ -34,11 +38,15 @@ class blmm_opts(C.Structure):
                 ("prior_sample_size", C.c_double)]
 
 
+class blmm_multi_opts(C.Structure):
+    _fields_ = [("gather_mode", C.c_int32), ("reserved", C.c_int32)]
+
+
 class blmm_status(C.Structure):
     _fields_ = [("n_neg_eig", C.c_int64), ("n_nonpos_weight", C.c_int64), ("n_zero_norm", C.c_int64),
                 ("n_nan_lod", C.c_int64), ("n_brent_maxiter", C.c_int64), ("jacobi_sweeps", C.c_int64),
                 ("jacobi_cycles", C.c_int64), ("jacobi_ticks_100mhz", C.c_int64),
-                ("lowrank_rank", C.c_int64), ("lowrank_resid", C.c_double),
+                ("lowrank_rank", C.c_int64), ("lowrank_fallback", C.c_int64), ("lowrank_resid", C.c_double),
                 ("t_eigen_ms", C.c_double), ("t_rotate_ms", C.c_double), ("t_h2_ms", C.c_double),
                 ("t_prep_ms", C.c_double), ("t_scan_ms", C.c_double), ("t_total_ms", C.c_double)]
 
@@ -103,6 +111,26 @@ def load():
     lib.blmm_null_loglik_grid.argtypes = [vp, op, vp, i64, i64, vp, i64, vp, vp, i64, vp, sp]
     lib.blmm_weighted_liteqtl.argtypes = [vp, vp, i64, i64, vp, i64, i64, vp, C.c_double, vp, sp]
     lib.blmm_liteqtl_given_h2.argtypes = [vp, vp, i64, i64, vp, i64, i64, vp, vp, vp, sp]
+    mp = C.POINTER(blmm_multi_opts)
+    lib.blmm_create_multi.argtypes = [ip, C.c_int, C.POINTER(vp)]
+    lib.blmm_destroy_multi.argtypes = [vp]
+    lib.blmm_destroy_multi.restype = None
+    lib.blmm_multi_ndev.argtypes = [vp]
+    lib.blmm_multi_last_error.argtypes = [vp]
+    lib.blmm_multi_last_error.restype = C.c_char_p
+    lib.blmm_default_multi_opts.argtypes = [mp]
+    lib.blmm_default_multi_opts.restype = None
+    lib.blmm_multi_shard.argtypes = [i64, C.c_int, C.c_int, C.POINTER(i64), C.POINTER(i64)]
+    lib.blmm_multi_shard.restype = None
+    lib.blmm_bulkscan_multi.argtypes = [vp, op, mp, vp, i64, i64, vp, i64, vp, i64, vp, vp, vp, i64, vp, vp, sp]
+    lib.blmm_multi_device_result.argtypes = [vp, C.c_int, C.POINTER(vp), C.POINTER(i64), C.POINTER(i64), C.POINTER(i64),
+                                             C.POINTER(vp)]
+    lib.blmm_host_register.argtypes = [vp, C.c_uint64]
+    lib.blmm_host_unregister.argtypes = [vp]
+    lib.blmm_host_alloc.argtypes = [C.c_uint64]
+    lib.blmm_host_alloc.restype = vp
+    lib.blmm_host_free.argtypes = [vp]
+    lib.blmm_host_free.restype = None
     for name in EXPORTS:
         getattr(lib, name)  # AttributeError if a declared symbol is not exported
     _lib = lib

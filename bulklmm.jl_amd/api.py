@@ -24,13 +24,25 @@ class BulkLMMError(Exception):
         self.code = code
 
 
+def _stream_arg(stream: Optional[int]):
+    """None -> NULL (private stream); 0 -> BLMM_STREAM_NULL (adopt the legacy default stream); else the handle."""
+    if stream is None:
+        return None
+    if int(stream) == 0:
+        return C.c_void_p(-1)  # BLMM_STREAM_NULL, include/bulklmm_hip.h
+    return C.c_void_p(int(stream))
+
+
 class Context:
     """One GPU.  Not thread-safe (include/bulklmm_hip.h)."""
 
     def __init__(self, device: int = 0, stream: Optional[int] = None):
+        """stream=None: a private non-blocking stream of the library (no ordering against the caller's streams);
+        an integer hipStream_t handle: every *_dev call enqueues there.  The handle 0 -- torch.cuda's default stream,
+        the legacy null stream -- is adopted as such (BLMM_STREAM_NULL), NOT replaced by a private stream."""
         self.lib = L.load()
         h = C.c_void_p()
-        rc = self.lib.blmm_create(int(device), C.c_void_p(stream) if stream else None, C.byref(h))
+        rc = self.lib.blmm_create(int(device), _stream_arg(stream), C.byref(h))
         if rc != 0:
             raise BulkLMMError(self.lib.blmm_err_string(rc).decode(), rc)
         self.h = h
@@ -64,11 +76,59 @@ class Context:
         return {k: float(v) for k, v in zip(names, sums)}, int(cnt.value)
 
     def set_stream(self, stream: Optional[int]):
-        self.check(self.lib.blmm_set_stream(self.h, C.c_void_p(stream) if stream else None))
+        self.check(self.lib.blmm_set_stream(self.h, _stream_arg(stream)))
 
     def synchronize(self):
         self.check(self.lib.blmm_synchronize(self.h))
 
+
+class MultiContext:
+    """Several GPUs of one node behind ONE call (blmm_create_multi): one host worker thread and one blmm_ctx per device.
+    `devices=None`: every visible device; an id may be repeated (several shards on one GPU)."""
+
+    def __init__(self, devices=None):
+        self.lib = L.load()
+        h = C.c_void_p()
+        if devices is None:
+            rc = self.lib.blmm_create_multi(None, 0, C.byref(h))
+        else:
+            ids = (C.c_int32 * len(devices))(*[int(d) for d in devices])
+            rc = self.lib.blmm_create_multi(ids, len(devices), C.byref(h))
+        if rc != 0:
+            raise BulkLMMError(self.lib.blmm_err_string(rc).decode(), rc)
+        self.h = h
+        self.ndev = int(self.lib.blmm_multi_ndev(h))
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.blmm_destroy_multi(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def check(self, rc: int):
+        if rc != 0:
+            msg = self.lib.blmm_multi_last_error(self.h).decode() or self.lib.blmm_err_string(rc).decode()
+            raise BulkLMMError(msg, rc)
+
+    def shard(self, m: int, rank: int):
+        lo, hi = C.c_int64(0), C.c_int64(0)
+        self.lib.blmm_multi_shard(int(m), int(rank), self.ndev, C.byref(lo), C.byref(hi))
+        return int(lo.value), int(hi.value)
+
+    def device_result(self, rank: int):
+        """(device pointer of L, ld, col_lo, col_hi, device pointer of h2) after a gather='none' / 'allgather' call."""
+        dL, dH = C.c_void_p(), C.c_void_p()
+        ld, lo, hi = C.c_int64(0), C.c_int64(0), C.c_int64(0)
+        self.check(self.lib.blmm_multi_device_result(self.h, int(rank), C.byref(dL), C.byref(ld), C.byref(lo), C.byref(hi), C.byref(dH)))
+        return dL.value, int(ld.value), int(lo.value), int(hi.value), dH.value
+
+
+_GATHER = {"none": L.BLMM_GATHER_NONE, "host_shards": L.BLMM_GATHER_HOST_SHARDS, "allgather": L.BLMM_GATHER_ALLGATHER}
 
 _default_ctx: Optional[Context] = None
 
@@ -175,6 +235,37 @@ def _bulkscan_call(method, Y, G, K, Covar, h2_grid, addIntercept, weights, prior
     return Lout, h2
 
 
+def host_register(a: np.ndarray):
+    """Pin the pages of an existing array (blmm_host_register): as an output it is then filled at PCIe link rate."""
+    lib = L.load()
+    if lib.blmm_host_register(a.ctypes.data_as(C.c_void_p), a.nbytes) != 0:
+        raise BulkLMMError("hipHostRegister failed", -12)
+
+
+def host_unregister(a: np.ndarray):
+    L.load().blmm_host_unregister(a.ctypes.data_as(C.c_void_p))
+
+
+def bulkscan_into(ctx: Context, method: int, Y, G, K, L_out: np.ndarray, h2_out: Optional[np.ndarray] = None, *, h2_grid=None,
+                  prior_variance: float = 1.0, prior_sample_size: float = 0.0, reml: bool = False, optim_interval: int = 1):
+    """blmm_bulkscan (host pointers) writing into caller-provided Fortran-ordered outputs -- what a Julia caller that
+    reuses its result Array does; used by bench.py for the end-to-end time."""
+    Y = _F(Y); G = _F(G); K = _F(K)
+    n, m = Y.shape
+    p = G.shape[1]
+    assert L_out.flags.f_contiguous and L_out.shape == (p, m)
+    if h2_out is None:
+        h2_out = np.empty((p, m) if method == L.BLMM_ALT_GRID else (m,), order="F")
+    grid, ngrid = None, 0
+    if method != L.BLMM_NULL_EXACT:
+        grid = np.ascontiguousarray(np.asarray(h2_grid if h2_grid is not None else [i / 10.0 for i in range(10)], dtype=np.float64))
+        ngrid = grid.shape[0]
+    o = _opts(method, reml, True, "eigen", optim_interval, prior_variance, prior_sample_size)
+    ctx.check(ctx.lib.blmm_bulkscan(ctx.h, C.byref(o), _p(Y), n, m, _p(G), p, None, 0, _p(K), None, _p(grid), ngrid,
+                                    _p(L_out), _p(h2_out), None))
+    return L_out, h2_out
+
+
 def bulkscan_null(Y, G, K, Covar=None, *, nb: int = 1, nt_blas: int = 1, addIntercept: bool = True, weights=None,
                   prior_variance: float = 1.0, prior_sample_size: float = 0.0, reml: bool = False, optim_interval: int = 1,
                   decomp_scheme: str = "eigen", ctx: Optional[Context] = None) -> BulkscanNullResult:
@@ -201,6 +292,50 @@ def bulkscan_alt_grid(Y, G, K, hsq_list, Covar=None, *, reml: bool = False, prio
                             prior_sample_size, reml, 1, decomp_scheme,
                             L.BLMM_COMPAT_ALT_COUNTER if compat_counter_quirk else 0, ctx)
     return BulkscanAltResult(Lo, h2)
+
+
+def bulkscan_multi(mctx: MultiContext, Y, G, K, Covar=None, *, method: str = "null-grid", h2_grid=None, gather: str = "host_shards",
+                   addIntercept: bool = True, weights=None, prior_variance: float = 1.0, prior_sample_size: float = 0.0,
+                   reml: bool = False, optim_interval: int = 1, decomp_scheme: str = "eigen", return_status: bool = False) -> dict:
+    """bulkscan over every GPU of `mctx` in ONE call (blmm_bulkscan_multi): the trait blocks the reference deals to its
+    threads (src/bulkscan.jl:263-309) go to the devices.  Same result fields as `bulkscan`; `gather` = "host_shards"
+    (default), "none" or "allgather" (include/bulklmm_hip.h)."""
+    if method not in _METHODS:
+        raise BulkLMMError("Unknown method `%s`; choose null-exact, null-grid or alt-grid." % method, -5)
+    if gather not in _GATHER:
+        raise BulkLMMError("gather must be one of none, host_shards, allgather")
+    Y = _F(Y); G = _F(G); K = _F(K)
+    n, m = Y.shape
+    p = G.shape[1]
+    if G.shape[0] != n or K.shape[0] != n or K.shape[1] != n:
+        raise BulkLMMError("Dimension mismatch.", -2)
+    cov, ncov = None, 0
+    if Covar is not None:
+        cov = _F(Covar)
+        if cov.shape[0] != n:
+            raise BulkLMMError("Dimension mismatch.", -2)
+        ncov = cov.shape[1]
+    else:
+        addIntercept = True
+    w = None if weights is None else np.ascontiguousarray(np.asarray(weights, dtype=np.float64).ravel())
+    meth = _METHODS[method]
+    grid, ngrid = None, 0
+    if meth != L.BLMM_NULL_EXACT:
+        grid = np.ascontiguousarray(np.asarray(h2_grid if h2_grid is not None else [i / 10.0 for i in range(10)], dtype=np.float64))
+        ngrid = grid.shape[0]
+    o = _opts(meth, reml, addIntercept, decomp_scheme, optim_interval, prior_variance, prior_sample_size)
+    mo = L.blmm_multi_opts(_GATHER[gather], 0)
+    Lout = np.empty((p, m), dtype=np.float64, order="F")
+    h2 = np.empty((p, m) if meth == L.BLMM_ALT_GRID else (m,), dtype=np.float64, order="F")
+    sts = (L.blmm_status * mctx.ndev)()
+    mctx.check(mctx.lib.blmm_bulkscan_multi(mctx.h, C.byref(o), C.byref(mo), _p(Y), n, m, _p(G), p, _p(cov), ncov, _p(K), _p(w),
+                                            _p(grid), ngrid, _p(Lout), _p(h2), sts))
+    for st in sts:
+        _raise_status(st)
+    out = {"L": Lout, ("h2_panel" if meth == L.BLMM_ALT_GRID else "h2_null_list"): h2}
+    if return_status:
+        out["status"] = list(sts)
+    return out
 
 
 def lod2log10p(lod, df: int = 1):

@@ -59,15 +59,37 @@ __global__ void k_to_rowmajor(const double* __restrict__ In, int n, int64_t ncol
   }
 }
 
+// Copies the device-side "gave up" conditions of a call into the context's pinned host word (system-scope store):
+// bit 0: the multi-workgroup weight-basis kernel timed out at its grid barrier (stat[8] < 0);
+// bit 1: the vendor eigensolver reported non-convergence (stat[11] = dsyevd's info).
+__global__ void k_note_info(const int* __restrict__ info, int64_t* __restrict__ stat) { stat[11] = *info; }
+__global__ void k_sticky(const int64_t* __restrict__ stat, int64_t* hflag) {
+  int64_t f = 0;
+  if (stat[8] < 0) f |= 1;
+  if (stat[11] != 0) f |= 2;
+  if (f) __hip_atomic_fetch_or(hflag, f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 }  // namespace blmm
 
 namespace {
+
+// A device-side failure of an EARLIER call made without a blmm_status (nothing synchronised then) surfaces here.
+int check_sticky(blmm_ctx* ctx) {
+  if (!ctx->hflag) return BLMM_OK;
+  const int64_t f = *ctx->hflag;
+  if (!f) return BLMM_OK;
+  *ctx->hflag = 0;
+  if (f & 1) return fail(ctx, BLMM_ERR_HIP, "an earlier call failed on the device: the weight-basis kernel timed out at its grid barrier (its LOD output is NaN)");
+  return fail(ctx, BLMM_ERR_HIP, "an earlier call failed on the device: the eigensolver did not converge (dsyevd info != 0)");
+}
 
 struct Pipe {
   int n = 0, c = 0, npad = 0, ldr = 0;
   int64_t m = 0, p = 0, ldy = 0, ldx = 0;
   double *Yt = nullptr, *Xt = nullptr, *Z0 = nullptr, *lam = nullptr;
   int64_t* stat = nullptr;
+  bool big = false;                // n beyond the LDS Jacobi: the call ends with k_sticky
 };
 
 struct Timer {
@@ -139,7 +161,10 @@ int finish_status(blmm_ctx* ctx, blmm_status* st, Timer* tm) {
   st->jacobi_sweeps = h[ST_JACOBI_SWEEPS];
   st->jacobi_cycles = h[6]; st->jacobi_ticks_100mhz = h[7];
   st->lowrank_rank = h[8];
+  st->lowrank_fallback = h[10];
   if (h[8] < 0) return fail(ctx, BLMM_ERR_HIP, "weight-basis kernel: a workgroup timed out at the grid barrier");
+  if (h[11] != 0) return fail(ctx, BLMM_ERR_HIP, "the eigensolver did not converge (dsyevd info = " + std::to_string((long long)h[11]) + ")");
+  if (ctx->hflag && *ctx->hflag) return check_sticky(ctx);
   { double r2; std::memcpy(&r2, &h[9], sizeof(double)); st->lowrank_resid = std::sqrt(r2 < 0 ? 0.0 : r2); }
   if (tm && tm->set && tm->set->n >= 2) {
     double t[6];
@@ -148,6 +173,17 @@ int finish_status(blmm_ctx* ctx, blmm_status* st, Timer* tm) {
     st->t_total_ms = t[5];
   }
   return BLMM_OK;
+}
+
+// Every bulkscan / scan call ends here.  Large-n calls (multi-workgroup weight basis, vendor eigensolver) first copy
+// their device-side failure conditions into the sticky host word, so that they are reported even without a status.
+int end_call(blmm_ctx* ctx, const Pipe& P, blmm_status* st, Timer* tm) {
+  if (P.big && ctx->hflag && P.stat) {
+    hipLaunchKernelGGL(k_sticky, dim3(1), dim3(1), 0, ctx->stream, P.stat, const_cast<int64_t*>(ctx->hflag));
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(ctx, BLMM_ERR_HIP, std::string("k_sticky: ") + hipGetErrorString(e));
+  }
+  return finish_status(ctx, st, tm);
 }
 
 // Eigen-decomposition for n beyond the LDS Jacobi: rocSOLVER dsyevd (the reference calls LAPACK here,
@@ -180,7 +216,9 @@ int eigen_rocsolver(blmm_ctx* ctx, double* A, int n, double* lraw, int64_t* stat
   int* info = reinterpret_cast<int*>(E + n);
   const int st = ctx->rs_dsyevd(ctx->rb_handle, /*evect_original*/ 211, /*fill_lower*/ 122, n, A, n, lraw, E, info);
   if (st != 0) return fail(ctx, BLMM_ERR_HIP, "rocsolver_dsyevd failed with status " + std::to_string(st));
-  (void)stat;
+  // dsyevd's device `info` -> stat[11] (the workspace is reused later in the call); k_sticky / finish_status report a
+  // non-converged decomposition as an error
+  hipLaunchKernelGGL(k_note_info, dim3(1), dim3(1), 0, ctx->stream, info, stat);
   return BLMM_OK;
 }
 
@@ -236,8 +274,9 @@ int prepare(blmm_ctx* ctx, const blmm_opts* o, const double* dY, int64_t n, int6
   // in a process loads the library: seconds, minutes on a cold machine).  The single-workgroup global-memory Jacobi
   // (37 ms at n = 130, 0.74 s at n = 333) is the fallback when librocsolver.so cannot be loaded, up to n = 2048.
   // BLMM_EIGEN=rocsolver|jacobi overrides the choice (the GPU tests pin "jacobi" to stay independent of the library).
-  static const char* eig_env = getenv("BLMM_EIGEN");
+  const char* eig_env = getenv("BLMM_EIGEN");
   const bool want_rs = n > jacobi_lds_max_n();
+  P.big = want_rs;
   bool used_rs = false;
   if (want_rs && !(eig_env && std::strcmp(eig_env, "jacobi") == 0) &&
       eigen_rocsolver(ctx, ptr<double>(ctx->Ks), (int)n, ptr<double>(ctx->lraw), P.stat) == BLMM_OK) {
@@ -265,8 +304,12 @@ int prepare(blmm_ctx* ctx, const blmm_opts* o, const double* dY, int64_t n, int6
     ctx->stream = main_stream;
     if (rc) return rc;
   }
-  static const char* rot_env = getenv("BLMM_ROTATE");   // "own": k_rotate for every n (A/B testing)
-  const bool blas = used_rs && !(rot_env && std::strcmp(rot_env, "own") == 0);
+  // rocBLAS picks its GEMM kernel (tile shape, split-K) from the problem shape, so a trait's rotated column -- and through
+  // the flat likelihood its h2 at the 1e-8 level -- would depend on how many OTHER traits are in the call: that breaks the
+  // sharding contract (a column block scanned alone is bit-identical, tests/test_gpu_configs.py).  The own kernels sum
+  // every output element in a fixed order; BLMM_ROTATE=blas selects rocBLAS for A/B timing only.
+  const char* rot_env = getenv("BLMM_ROTATE");
+  const bool blas = used_rs && rot_env && std::strcmp(rot_env, "blas") == 0;
   if ((rc = rotate_any(ctx, blas, ptr<double>(ctx->Rp), P.ldr, (int)n, P.npad, dY, m, P.Yt, P.ldy, P.ldy))) return rc;
   if ((rc = rotate_any(ctx, blas, ptr<double>(ctx->Rp), P.ldr, (int)n, P.npad, dG, p, P.Xt, P.ldx, P.ldx))) return rc;
   tm.mark();
@@ -302,6 +345,73 @@ ScanArgs scan_args(blmm_ctx* ctx, const Pipe& P, const double* panels, int64_t l
   a.ks = P.npad / 4; a.n = P.n; a.p = P.p; a.m = m; a.L = L; a.ldL = ldL;
   a.isx = nullptr; a.ld_isx = 0; a.bin = nullptr; a.stat = P.stat; a.logtab = ptr<double>(ctx->logtab);
   return a;
+}
+
+// ---- null-exact LOD scan in the low-rank weights form (kernels_lowrank.hip), shared by bulkscan(null-exact) and the
+// liteqtl_given_h2 seam.  lr_begin: weight basis (unless prepare() already started it) and the marker-side products on
+// the side stream; the caller may then enqueue the h2 search on the main stream; lr_finish: per-trait panels, the
+// MFMA scan, the all-trait residual guard beside it, and the full-rank re-scan of the flagged traits.
+double lr_tolerance() {
+  // relative residual |w_j - Q Q'w_j| / |w_j| above which a trait's column is recomputed from the full-length sums.
+  // BLMM_LR_TOL overrides it (tests: 0 flags every trait, so the re-scan kernel is compared with the oracle as a whole)
+  const char* e = getenv("BLMM_LR_TOL");
+  return e ? atof(e) : 1e-13;
+}
+
+int lr_begin(blmm_ctx* ctx, const Pipe& P, bool wbasis_started) {
+  int rc;
+  const int64_t ldp = P.ldy, tstride = (int64_t)P.npad * P.ldx;
+  if ((rc = ensure(ctx, ctx->lrT, sizeof(double) * (size_t)(1 + P.c) * tstride))) return rc;
+  if ((rc = ensure(ctx, ctx->lrC, sizeof(double) * (size_t)P.npad * ldp))) return rc;
+  if ((rc = ensure(ctx, ctx->lrL, sizeof(double) * (size_t)(P.c * (P.c + 1) / 2) * ldp))) return rc;
+  if ((rc = ensure(ctx, ctx->lrFlag, sizeof(int) * (size_t)(P.m > 0 ? P.m : 1)))) return rc;
+  if ((rc = ensure(ctx, ctx->panels, sizeof(double) * (size_t)P.npad * ldp))) return rc;
+  if ((rc = ensure(ctx, ctx->wbQ, sizeof(double) * (size_t)P.npad * P.n))) return rc;
+  if ((rc = ensure(ctx, ctx->wbW, sizeof(double) * (size_t)P.n * (256 + 16)))) return rc;
+  if ((rc = ensure(ctx, ctx->wbRk, sizeof(int) * 4))) return rc;
+  int* rk = ptr<int>(ctx->wbRk);
+  hipStream_t main_stream = ctx->stream;
+  BLMM_HIP(hipEventRecord(ctx->ev_fork, main_stream));            // rotated operands are ready
+  BLMM_HIP(hipStreamWaitEvent(ctx->side, ctx->ev_fork, 0));
+  ctx->stream = ctx->side;                                         // the launchers enqueue on ctx->stream
+  rc = BLMM_OK;
+  if (!wbasis_started) rc = launch_wbasis(ctx, P.lam, P.n, ptr<double>(ctx->wbW), ptr<double>(ctx->wbQ), rk, P.stat);
+  if (!rc) rc = launch_lr_tpanels(ctx, P.Xt, P.ldx, P.p, P.n, P.c, P.npad, P.Z0, ptr<double>(ctx->wbQ), rk, ptr<double>(ctx->lrT), tstride);
+  ctx->stream = main_stream;
+  if (rc) return rc;
+  BLMM_HIP(hipEventRecord(ctx->ev_join, ctx->side));
+  return BLMM_OK;
+}
+
+int lr_finish(blmm_ctx* ctx, const Pipe& P, const NullModel& nm, const double* dh2, double* dL, int64_t ldL, Timer& tm) {
+  int rc;
+  const int64_t ldp = P.ldy, tstride = (int64_t)P.npad * P.ldx, m = P.m;
+  int* rk = ptr<int>(ctx->wbRk);
+  hipStream_t main_stream = ctx->stream;
+  BLMM_HIP(hipStreamWaitEvent(main_stream, ctx->ev_join, 0));
+  if ((rc = launch_lr_panels(ctx, nm, P.Yt, P.ldy, m, P.Z0, P.lam, dh2, ptr<double>(ctx->wbQ), rk, ptr<double>(ctx->panels),
+                             ptr<double>(ctx->lrC), ptr<double>(ctx->lrL), ldp, P.stat))) return rc;
+  tm.mark();
+  // residual guard of the weight basis, every trait: side stream, beside the scan kernel; joined below
+  BLMM_HIP(hipEventRecord(ctx->ev_fork, main_stream));
+  BLMM_HIP(hipStreamWaitEvent(ctx->side, ctx->ev_fork, 0));
+  ctx->stream = ctx->side;
+  rc = launch_lr_resid(ctx, nm, m, lr_tolerance(), P.lam, dh2, ptr<double>(ctx->wbQ), rk, ptr<double>(ctx->lrC), ldp,
+                       ptr<int>(ctx->lrFlag), P.stat);
+  ctx->stream = main_stream;
+  if (rc) return rc;
+  BLMM_HIP(hipEventRecord(ctx->ev_join, ctx->side));
+  LrArgs la;
+  la.s = scan_args(ctx, P, ptr<double>(ctx->panels), ldp, dL, ldL, m);
+  la.Cp = ptr<double>(ctx->lrC); la.T = ptr<double>(ctx->lrT); la.tstride = tstride; la.Ls = ptr<double>(ctx->lrL);
+  la.rk = rk; la.c = P.c;
+  if ((rc = launch_scan_lr(ctx, la))) return rc;
+  BLMM_HIP(hipStreamWaitEvent(main_stream, ctx->ev_join, 0));
+  // flagged traits (normally none: the kernel reads the count on the device and returns): full-length sums
+  if ((rc = launch_scan_fix(ctx, nm, P.Xt, P.ldx, P.p, ptr<double>(ctx->panels), ptr<double>(ctx->lrL), ldp, P.Z0, P.lam, dh2,
+                            ptr<int>(ctx->lrFlag), dL, ldL, P.stat))) return rc;
+  tm.mark();
+  return BLMM_OK;
 }
 
 }  // namespace
@@ -344,7 +454,9 @@ int blmm_create(int device_id, void* hip_stream, blmm_ctx** out) {
   if (hipSetDevice(device_id) != hipSuccess) return BLMM_ERR_NO_DEVICE;
   blmm_ctx* ctx = new blmm_ctx();
   ctx->device = device_id;
-  if (hip_stream) {
+  if (hip_stream == BLMM_STREAM_NULL) {
+    ctx->stream = nullptr;   // the legacy default stream (handle 0)
+  } else if (hip_stream) {
     ctx->stream = reinterpret_cast<hipStream_t>(hip_stream);
   } else {
     if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { delete ctx; return BLMM_ERR_HIP; }
@@ -356,6 +468,14 @@ int blmm_create(int device_id, void* hip_stream, blmm_ctx** out) {
       hipEventCreateWithFlags(&ctx->ev_xt, hipEventDisableTiming) != hipSuccess) {
     blmm_destroy(ctx);
     return BLMM_ERR_HIP;
+  }
+  {
+    int cus = 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device_id) == hipSuccess) ctx->num_cus = cus;
+    void* hp = nullptr;
+    if (hipHostMalloc(&hp, 64, hipHostMallocMapped) != hipSuccess) { blmm_destroy(ctx); return BLMM_ERR_HIP; }
+    std::memset(hp, 0, 64);
+    ctx->hflag = reinterpret_cast<volatile int64_t*>(hp);
   }
   if (ensure(ctx, ctx->logtab, sizeof(blmm_log_table_host)) != BLMM_OK ||
       hipMemcpy(ctx->logtab.p, blmm_log_table_host, sizeof(blmm_log_table_host), hipMemcpyHostToDevice) != hipSuccess) {
@@ -374,7 +494,7 @@ void blmm_destroy(blmm_ctx* ctx) {
                     &ctx->iyy, &ctx->h2, &ctx->h2idx, &ctx->sig2, &ctx->ell, &ctx->isx, &ctx->stat, &ctx->gridd, &ctx->misc,
                     &ctx->EllTab, &ctx->inY, &ctx->inG, &ctx->inK, &ctx->inCov, &ctx->inW, &ctx->outL, &ctx->outH2,
                     &ctx->tmpA, &ctx->tmpB, &ctx->tmpC, &ctx->perm, &ctx->r0, &ctx->altbuf, &ctx->logtab, &ctx->lraw,
-                    &ctx->wbQ, &ctx->wbW, &ctx->wbRk, &ctx->lrT, &ctx->lrC, &ctx->lrL, &ctx->xf32, &ctx->pf32, &ctx->brSt, &ctx->brList};
+                    &ctx->wbQ, &ctx->wbW, &ctx->wbRk, &ctx->lrT, &ctx->lrC, &ctx->lrL, &ctx->lrFlag, &ctx->xf32, &ctx->pf32, &ctx->brSt, &ctx->brList};
   for (DevBuf* b : bufs) if (b->p) hipFree(b->p);
   for (auto& s : ctx->evsets) for (auto& e : s.e) (void)hipEventDestroy(e);
   if (ctx->rb_handle && ctx->rb_destroy) ctx->rb_destroy(ctx->rb_handle);
@@ -383,6 +503,8 @@ void blmm_destroy(blmm_ctx* ctx) {
   if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
   if (ctx->ev_xt) (void)hipEventDestroy(ctx->ev_xt);
   if (ctx->own_stream) hipStreamDestroy(ctx->stream);
+  if (ctx->hflag) (void)hipHostFree(const_cast<int64_t*>(ctx->hflag));
+  destroy_host_stage(ctx->hstage);
   delete ctx;
 }
 
@@ -392,7 +514,8 @@ int blmm_set_stream(blmm_ctx* ctx, void* hip_stream) {
   if (!ctx) return BLMM_ERR_INVALID;
   hipStreamSynchronize(ctx->stream);
   if (ctx->own_stream) { hipStreamDestroy(ctx->stream); ctx->own_stream = false; }
-  if (hip_stream) ctx->stream = reinterpret_cast<hipStream_t>(hip_stream);
+  if (hip_stream == BLMM_STREAM_NULL) ctx->stream = nullptr;
+  else if (hip_stream) ctx->stream = reinterpret_cast<hipStream_t>(hip_stream);
   else {
     if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) return fail(ctx, BLMM_ERR_HIP, "hipStreamCreate");
     ctx->own_stream = true;
@@ -423,7 +546,7 @@ int blmm_read_timings(blmm_ctx* ctx, double* sums_ms, int64_t* ncalls) {
 int blmm_synchronize(blmm_ctx* ctx) {
   if (!ctx) return BLMM_ERR_INVALID;
   BLMM_HIP(hipStreamSynchronize(ctx->stream));
-  return BLMM_OK;
+  return check_sticky(ctx);
 }
 
 void blmm_default_opts(blmm_opts* o) {
@@ -494,6 +617,7 @@ int blmm_bulkscan_dev(blmm_ctx* ctx, const blmm_opts* opts, const double* dY, in
   if (opts->method != BLMM_NULL_EXACT && opts->method != BLMM_NULL_GRID && opts->method != BLMM_ALT_GRID)
     return fail(ctx, BLMM_ERR_METHOD, "Unknown method; choose null-exact, null-grid or alt-grid.");
   BLMM_HIP(hipSetDevice(ctx->device));
+  if ((rc = check_sticky(ctx))) return rc;
   Timer tm(ctx);
   Pipe P;
   double* dgrid = nullptr;
@@ -502,14 +626,14 @@ int blmm_bulkscan_dev(blmm_ctx* ctx, const blmm_opts* opts, const double* dY, in
   }
   // null-exact runs the low-rank weights form (kernels_lowrank.hip) unless BLMM_EXACT=full (A/B testing), c = 4 (the
   // kernel would spill) or n is beyond what the basis kernel keeps in LDS
-  static const char* exact_env = getenv("BLMM_EXACT");
+  const char* exact_env = getenv("BLMM_EXACT");
   const int c_eff = (int)((ncov == 0 || !dCovar) ? 1 : ncov + (opts->add_intercept ? 1 : 0));
   const bool lowrank = opts->method == BLMM_NULL_EXACT && !(exact_env && std::strcmp(exact_env, "full") == 0) &&
                        c_eff <= 3 && n <= 6000;
   if ((rc = prepare(ctx, opts, dY, n, m, dG, p, dCovar, ncov, dK, dweights, 1, P, tm, lowrank))) return rc;
   const NullModel nm = null_model(P, opts);
   const int64_t ldp = P.ldy;
-  if (m == 0) { tm.mark(); tm.mark(); tm.mark(); return finish_status(ctx, status, &tm); }
+  if (m == 0) { tm.mark(); tm.mark(); tm.mark(); return end_call(ctx, P, status, &tm); }
   if (p == 0) {
     // no markers: only the per-trait null model (h2_null_list does not depend on G); alt-grid's h2_panel is p x m = empty
     if (opts->method == BLMM_NULL_EXACT) {
@@ -519,48 +643,17 @@ int blmm_bulkscan_dev(blmm_ctx* ctx, const blmm_opts* opts, const double* dY, in
       if ((rc = launch_loglik_grid(ctx, nm, P.Yt, P.ldy, m, P.Z0, P.lam, dgrid, (int)ngrid, nullptr, ptr<int>(ctx->h2idx), dh2_out, P.stat))) return rc;
     }
     tm.mark(); tm.mark(); tm.mark();
-    return finish_status(ctx, status, &tm);
+    return end_call(ctx, P, status, &tm);
   }
 
   if (opts->method == BLMM_NULL_EXACT) {
     if (lowrank) {
       // the basis (started in prepare) and the marker-side products (Q, Xt) run on the side stream beside the
       // per-trait Brent search
-      const int64_t tstride = (int64_t)P.npad * P.ldx;
-      if ((rc = ensure(ctx, ctx->lrT, sizeof(double) * (size_t)(1 + P.c) * tstride))) return rc;
-      if ((rc = ensure(ctx, ctx->lrC, sizeof(double) * (size_t)P.npad * ldp))) return rc;
-      if ((rc = ensure(ctx, ctx->lrL, sizeof(double) * (size_t)(P.c * (P.c + 1) / 2) * ldp))) return rc;
-      if ((rc = ensure(ctx, ctx->panels, sizeof(double) * (size_t)P.npad * ldp))) return rc;
-      int* rk = ptr<int>(ctx->wbRk);
-      hipStream_t main_stream = ctx->stream;
-      BLMM_HIP(hipEventRecord(ctx->ev_fork, main_stream));            // rotated operands are ready
-      BLMM_HIP(hipStreamWaitEvent(ctx->side, ctx->ev_fork, 0));
-      ctx->stream = ctx->side;
-      rc = launch_lr_tpanels(ctx, P.Xt, P.ldx, p, (int)n, P.c, P.npad, P.Z0, ptr<double>(ctx->wbQ), rk, ptr<double>(ctx->lrT), tstride);
-      ctx->stream = main_stream;
-      if (rc) return rc;
-      BLMM_HIP(hipEventRecord(ctx->ev_join, ctx->side));
+      if ((rc = lr_begin(ctx, P, /*wbasis_started*/ true))) return rc;
       if ((rc = launch_brent(ctx, nm, P.Yt, P.ldy, m, P.Z0, P.lam, dh2_out, nullptr, nullptr, P.stat))) return rc;
       tm.mark();
-      BLMM_HIP(hipStreamWaitEvent(main_stream, ctx->ev_join, 0));
-      if ((rc = launch_lr_panels(ctx, nm, P.Yt, P.ldy, m, P.Z0, P.lam, dh2_out, ptr<double>(ctx->wbQ), rk, ptr<double>(ctx->panels),
-                                 ptr<double>(ctx->lrC), ptr<double>(ctx->lrL), ldp, P.stat))) return rc;
-      tm.mark();
-      // residual diagnostic of the weight basis: side stream, beside the scan kernel; joined below
-      BLMM_HIP(hipEventRecord(ctx->ev_fork, main_stream));
-      BLMM_HIP(hipStreamWaitEvent(ctx->side, ctx->ev_fork, 0));
-      ctx->stream = ctx->side;
-      rc = launch_lr_resid(ctx, nm, m, P.lam, dh2_out, ptr<double>(ctx->wbQ), rk, ptr<double>(ctx->lrC), ldp, P.stat);
-      ctx->stream = main_stream;
-      if (rc) return rc;
-      BLMM_HIP(hipEventRecord(ctx->ev_join, ctx->side));
-      LrArgs la;
-      la.s = scan_args(ctx, P, ptr<double>(ctx->panels), ldp, dL_out, ldL, m);
-      la.Cp = ptr<double>(ctx->lrC); la.T = ptr<double>(ctx->lrT); la.tstride = tstride; la.Ls = ptr<double>(ctx->lrL);
-      la.rk = rk; la.c = P.c;
-      if ((rc = launch_scan_lr(ctx, la))) return rc;
-      BLMM_HIP(hipStreamWaitEvent(main_stream, ctx->ev_join, 0));
-      tm.mark();
+      if ((rc = lr_finish(ctx, P, nm, dh2_out, dL_out, ldL, tm))) return rc;
     } else {
       if ((rc = launch_brent(ctx, nm, P.Yt, P.ldy, m, P.Z0, P.lam, dh2_out, nullptr, nullptr, P.stat))) return rc;
       tm.mark();
@@ -606,7 +699,7 @@ int blmm_bulkscan_dev(blmm_ctx* ctx, const blmm_opts* opts, const double* dY, in
     if ((rc = launch_scan_alt(ctx, aa))) return rc;
     tm.mark();
   }
-  return finish_status(ctx, status, &tm);
+  return end_call(ctx, P, status, &tm);
 }
 
 int blmm_bulkscan(blmm_ctx* ctx, const blmm_opts* opts, const double* Y, int64_t n, int64_t m, const double* G, int64_t p,
@@ -642,8 +735,8 @@ int blmm_bulkscan(blmm_ctx* ctx, const blmm_opts* opts, const double* Y, int64_t
   rc = blmm_bulkscan_dev(ctx, opts, ptr<double>(ctx->inY), n, m, ptr<double>(ctx->inG), p, dCov, dCov ? ncov : 0,
                          ptr<double>(ctx->inK), dW, h2_grid, ngrid, ptr<double>(ctx->outL), p, ptr<double>(ctx->outH2), status);
   if (rc) { hipStreamSynchronize(ctx->stream); return rc; }
-  if ((size_t)p * m > 0) BLMM_HIP(hipMemcpyAsync(L_out, ctx->outL.p, sizeof(double) * (size_t)p * m, hipMemcpyDeviceToHost, ctx->stream));
-  if (h2_elems > 0) BLMM_HIP(hipMemcpyAsync(h2_out, ctx->outH2.p, sizeof(double) * h2_elems, hipMemcpyDeviceToHost, ctx->stream));
+  if ((size_t)p * m > 0 && (rc = copy_to_host(ctx, L_out, ctx->outL.p, sizeof(double) * (size_t)p * m))) return rc;
+  if (h2_elems > 0 && (rc = copy_to_host(ctx, h2_out, ctx->outH2.p, sizeof(double) * h2_elems))) return rc;
   BLMM_HIP(hipStreamSynchronize(ctx->stream));
   return BLMM_OK;
 }
@@ -661,6 +754,7 @@ static int scan_perms_impl(blmm_ctx* ctx, const blmm_opts* opts, const double* d
   if (!dy || !dG || !dK || !dscalars_out || !dlod_out || (nperms > 0 && !dLperms_out && !dLperms32_out))
     return fail(ctx, BLMM_ERR_INVALID, "scan_perms: NULL buffer");
   BLMM_HIP(hipSetDevice(ctx->device));
+  if ((rc = check_sticky(ctx))) return rc;
   Timer tm(ctx);
   Pipe P;
   if ((rc = prepare(ctx, opts, dy, n, 1, dG, p, dCovar, ncov, dK, dweights, 1, P, tm))) return rc;
@@ -698,7 +792,7 @@ static int scan_perms_impl(blmm_ctx* ctx, const blmm_opts* opts, const double* d
     }
   }
   tm.mark();
-  return finish_status(ctx, status, &tm);
+  return end_call(ctx, P, status, &tm);
 }
 
 int blmm_scan_perms_dev(blmm_ctx* ctx, const blmm_opts* opts, const double* dy, int64_t n, const double* dG, int64_t p,
@@ -763,7 +857,7 @@ static int scan_perms_host(blmm_ctx* ctx, const blmm_opts* opts, const double* y
   if (rc) { hipStreamSynchronize(ctx->stream); return rc; }
   BLMM_HIP(hipMemcpyAsync(scalars_out, ctx->outH2.p, sizeof(double) * 2, hipMemcpyDeviceToHost, ctx->stream));
   if (p > 0) BLMM_HIP(hipMemcpyAsync(lod_out, dL, sizeof(double) * p, hipMemcpyDeviceToHost, ctx->stream));
-  if (p > 0 && nperms > 0) BLMM_HIP(hipMemcpyAsync(Lperms_out, dLp, esz * (size_t)p * nperms, hipMemcpyDeviceToHost, ctx->stream));
+  if (p > 0 && nperms > 0 && (rc = copy_to_host(ctx, Lperms_out, dLp, esz * (size_t)p * nperms))) return rc;
   BLMM_HIP(hipStreamSynchronize(ctx->stream));
   return BLMM_OK;
 }
@@ -930,11 +1024,20 @@ int blmm_liteqtl_given_h2(blmm_ctx* ctx, const double* Y0, int64_t n, int64_t m,
   const NullModel nm = null_model(P, &o);
   if ((rc = ensure(ctx, ctx->h2, sizeof(double) * m))) return rc;
   BLMM_HIP(hipMemcpyAsync(ctx->h2.p, h2, sizeof(double) * m, hipMemcpyHostToDevice, ctx->stream));
-  if ((rc = ensure(ctx, ctx->panels, sizeof(double) * (size_t)(2 + P.c) * P.npad * P.ldy))) return rc;
-  if ((rc = launch_panels(ctx, nm, P.Yt, P.ldy, m, P.Z0, P.lam, ptr<double>(ctx->h2), 1, ptr<double>(ctx->panels), P.ldy, P.stat))) return rc;
   if ((rc = ensure(ctx, ctx->outL, sizeof(double) * (size_t)p * m))) return rc;
-  ScanArgs a = scan_args(ctx, P, ptr<double>(ctx->panels), P.ldy, ptr<double>(ctx->outL), p, m);
-  if ((rc = launch_scan_exact(ctx, a, P.c))) return rc;
+  // the same kernel choice as bulkscan(method = null-exact): low-rank weights form with its residual guard unless
+  // BLMM_EXACT=full, c = 4 or n beyond the basis kernel
+  const char* exact_env = getenv("BLMM_EXACT");
+  if (!(exact_env && std::strcmp(exact_env, "full") == 0) && P.c <= 3 && n <= 6000) {
+    Timer tm(ctx);
+    if ((rc = lr_begin(ctx, P, /*wbasis_started*/ false))) return rc;
+    if ((rc = lr_finish(ctx, P, nm, ptr<double>(ctx->h2), ptr<double>(ctx->outL), p, tm))) return rc;
+  } else {
+    if ((rc = ensure(ctx, ctx->panels, sizeof(double) * (size_t)(2 + P.c) * P.npad * P.ldy))) return rc;
+    if ((rc = launch_panels(ctx, nm, P.Yt, P.ldy, m, P.Z0, P.lam, ptr<double>(ctx->h2), 1, ptr<double>(ctx->panels), P.ldy, P.stat))) return rc;
+    ScanArgs a = scan_args(ctx, P, ptr<double>(ctx->panels), P.ldy, ptr<double>(ctx->outL), p, m);
+    if ((rc = launch_scan_exact(ctx, a, P.c))) return rc;
+  }
   BLMM_HIP(hipMemcpyAsync(LOD_out, ctx->outL.p, sizeof(double) * (size_t)p * m, hipMemcpyDeviceToHost, ctx->stream));
   BLMM_HIP(hipStreamSynchronize(ctx->stream));
   return finish_status(ctx, status, nullptr);

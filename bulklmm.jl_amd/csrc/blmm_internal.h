@@ -15,7 +15,7 @@ typedef double d4 __attribute__((ext_vector_type(4)));
 constexpr int CMAX = 4;          // null covariates (incl. intercept) the kernels are instantiated for
 constexpr int TILE_T = 64;       // traits per workgroup tile of the scan kernels
 constexpr int TILE_I = 128;      // markers per workgroup tile of the scan kernels
-constexpr int NSTAT = 12;        // device status counters ([6],[7]: eigensolver clocks, [8]: weight-basis rank, [9]: its residual)
+constexpr int NSTAT = 12;        // device status counters ([6],[7]: eigensolver clocks, [8]: weight-basis rank, [9]: its residual, [10]: traits re-scanned full rank)
 
 enum StatIdx { ST_NEG_EIG = 0, ST_NONPOS_W = 1, ST_ZERO_NORM = 2, ST_NAN_LOD = 3, ST_BRENT_MAXIT = 4, ST_JACOBI_SWEEPS = 5 };
 
@@ -28,6 +28,8 @@ struct DevBuf {
 
 }  // namespace blmm
 
+namespace blmm { struct HostStage; }
+
 struct blmm_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
@@ -36,7 +38,7 @@ struct blmm_ctx {
   std::string err;
   // grow-only workspace
   blmm::DevBuf Ks, V, lam, U, Zs, Z0, Rp, Yt, Xt, panels, iyy, h2, h2idx, sig2, ell, isx, stat, gridd, misc, EllTab,
-      inY, inG, inK, inCov, inW, outL, outH2, tmpA, tmpB, tmpC, perm, r0, altbuf, logtab, lraw, wbQ, wbW, wbRk, lrT, lrC, lrL, xf32, pf32, brSt, brList;
+      inY, inG, inK, inCov, inW, outL, outH2, tmpA, tmpB, tmpC, perm, r0, altbuf, logtab, lraw, wbQ, wbW, wbRk, lrT, lrC, lrL, lrFlag, xf32, pf32, brSt, brList;
   // event sets: one per timed call since the last blmm_read_timings (grown on demand, reused afterwards)
   struct EvSet { hipEvent_t e[8]; int n; };
   std::vector<EvSet> evsets;
@@ -51,6 +53,12 @@ struct blmm_ctx {
   // side stream: work that only depends on the eigenvalues / rotated markers runs beside the per-trait Brent search
   hipStream_t side = nullptr;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_xt = nullptr;
+  int num_cus = 0;                 // multiProcessorCount of the device (bounds every co-resident grid)
+  // sticky device-side abort word in pinned, device-mapped host memory: a kernel that gives up (bounded spin of the
+  // multi-workgroup weight-basis kernel) is reported by the NEXT API call / blmm_synchronize even when the failing
+  // call was made without a blmm_status (blmm_api.hip: check_sticky)
+  volatile int64_t* hflag = nullptr;
+  blmm::HostStage* hstage = nullptr;   // pinned staging ring + copy threads of the host-pointer entry points (host_path.hip)
 };
 
 namespace blmm {
@@ -65,6 +73,9 @@ int fail(blmm_ctx* ctx, int code, const std::string& msg);
   } while (0)
 
 int ensure(blmm_ctx* ctx, DevBuf& b, size_t bytes);
+// host_path.hip: device -> caller memory in stream order; returns when the bytes are in place
+int copy_to_host(blmm_ctx* ctx, void* dst, const void* dsrc, size_t bytes);
+void destroy_host_stage(HostStage* hs);
 template <typename T>
 inline T* ptr(DevBuf& b) { return reinterpret_cast<T*>(b.p); }
 
@@ -138,8 +149,11 @@ struct LrArgs {
   int c;
 };
 int launch_scan_lr(blmm_ctx* ctx, const LrArgs& la);
-int launch_lr_resid(blmm_ctx* ctx, const NullModel& nm, int64_t m, const double* lam, const double* h2, const double* Q,
-                    const int* rk, const double* Cp, int64_t ldp, int64_t* stat);
+int launch_lr_resid(blmm_ctx* ctx, const NullModel& nm, int64_t m, double tol, const double* lam, const double* h2,
+                    const double* Q, const int* rk, const double* Cp, int64_t ldp, int* flag_list, int64_t* stat);
+int launch_scan_fix(blmm_ctx* ctx, const NullModel& nm, const double* Xt, int64_t ldx, int64_t p, const double* P0,
+                    const double* Ls, int64_t ldp, const double* Z0, const double* lam, const double* h2,
+                    const int* flag_list, double* L, int64_t ldL, int64_t* stat);
 // kernels_scan_f32.hip: fp32 permutation LOD kernel and the fp64 k-major -> fp32 fragment-major conversion
 int launch_cvt_f32(blmm_ctx* ctx, const double* M, int64_t ld_in, int rows_valid, int64_t cols_valid, float* F,
                    int64_t ld_out, int kblocks);

@@ -449,7 +449,10 @@ int launch_wbasis(blmm_ctx* ctx, const double* lam, int n, double* Wk, double* Q
   int S = 0;
   for (int cand : {16, 8, 4})
     if (work + row * (size_t)cand + row * 2 <= budget) { S = cand; break; }
-  if (S && !(mw_env && std::strcmp(mw_env, "single") == 0)) {
+  // every workgroup of the multi-workgroup kernel occupies one CU (1024 threads, > 80 KB of LDS) and they meet at a grid
+  // barrier: G must not exceed the CUs of this device / partition (CPX: 32), or the surplus workgroups never become resident
+  while (S && S < 16 && 256 / S > (ctx->num_cus > 0 ? ctx->num_cus : 256) && work + row * (size_t)(2 * S) + row * 2 <= budget) S *= 2;
+  if (S && 256 / S <= (ctx->num_cus > 0 ? ctx->num_cus : 256) && !(mw_env && std::strcmp(mw_env, "single") == 0)) {
     const int G = 256 / S;
     const int qcap = (int)std::min<size_t>(WB_QCAP, (budget - work - row * S) / row);
     const size_t lds = work + row * qcap + row * S;
@@ -674,26 +677,129 @@ __global__ void __launch_bounds__(64) k_lr_panels(NullModel nm, const double* __
   }
 }
 
-// Diagnostic: relative residual |w_j - Q c_j| / |w_j| of the weight-basis expansion, evaluated directly (one wave per
-// sampled trait, every `stride`-th) and max-reduced into stat[9] (as the bits of the squared value).
-__global__ void __launch_bounds__(64) k_lr_resid(int n, int64_t m, int64_t stride, const double* __restrict__ lam,
-                                                 const double* __restrict__ h2v, const double* __restrict__ Q,
-                                                 const int* __restrict__ rk, const double* __restrict__ Cp, int64_t ldp,
-                                                 int64_t* stat) {
-  const int64_t j = (int64_t)blockIdx.x * stride;
-  if (j >= m) return;
-  const int R = rk[0], lane = threadIdx.x;
-  const double h2 = h2v[j];
-  const double delta = h2 / (1.0 - h2);
-  double rr = 0.0, ww = 0.0;
-  for (int k = lane; k < n; k += 64) {
-    const double w = fabs(1.0 / fma(delta, lam[k], 1.0));
-    double v = w;
-    for (int r = 0; r < R; ++r) v = fma(-Q[(size_t)r * n + k], Cp[(int64_t)r * ldp + j], v);
-    rr = fma(v, v, rr); ww = fma(w, w, ww);
+// Guard of the low-rank form: relative residual |w_j - Q c_j| / |w_j| of the weight-basis expansion of EVERY trait,
+// evaluated directly (one thread per trait).  The largest squared value goes to stat[9]; a trait whose squared residual
+// exceeds tol2 is appended to flag_list (count in stat[10]) and its LOD column is recomputed by k_scan_fix from the full
+// length-n sums, so no LOD leaves the library that rests on an unchecked expansion.
+__global__ void __launch_bounds__(256) k_lr_resid(int n, int64_t m, double tol2, const double* __restrict__ lam,
+                                                  const double* __restrict__ h2v, const double* __restrict__ Q,
+                                                  const int* __restrict__ rk, int qcap, const double* __restrict__ Cp,
+                                                  int64_t ldp, int* __restrict__ flag_list, int64_t* stat) {
+  // one thread per trait (coalesced reads of its coefficients Cp[r][j]); the basis rows in LDS up to qcap of them
+  extern __shared__ __attribute__((aligned(16))) double sh[];
+  double* sLam = sh;
+  double* sQ = sh + n;
+  const int R = rk[0];
+  if (R < 0) return;                       // the basis kernel gave up: the call fails as a whole (stat[8] < 0)
+  const int rl = R < qcap ? R : qcap;
+  for (int e = threadIdx.x; e < n; e += blockDim.x) sLam[e] = lam[e];
+  for (int e = threadIdx.x; e < rl * n; e += blockDim.x) sQ[e] = Q[e];
+  __syncthreads();
+  const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  double rel2 = 0.0;
+  if (j < m) {
+    const double h2 = h2v[j];
+    const double delta = h2 / (1.0 - h2);
+    double rr = 0.0, ww = 0.0;
+    constexpr int KC = 16;
+    for (int k0 = 0; k0 < n; k0 += KC) {
+      double v[KC];
+#pragma unroll
+      for (int u = 0; u < KC; ++u) {
+        const double w = (k0 + u < n) ? fabs(1.0 / fma(delta, sLam[k0 + u < n ? k0 + u : 0], 1.0)) : 0.0;
+        v[u] = w; ww = fma(w, w, ww);
+      }
+      for (int r = 0; r < R; ++r) {
+        const double c = Cp[(int64_t)r * ldp + j];
+        const double* qr = (r < rl) ? sQ + r * n : Q + (size_t)r * n;
+#pragma unroll
+        for (int u = 0; u < KC; ++u) if (k0 + u < n) v[u] = fma(-qr[k0 + u], c, v[u]);
+      }
+#pragma unroll
+      for (int u = 0; u < KC; ++u) rr = fma(v[u], v[u], rr);
+    }
+    rel2 = rr / ww;
+    if (!(rel2 >= 0.0)) rel2 = INFINITY;   // NaN counts as a failure of the expansion
+    if (!(rel2 <= tol2)) {
+      const unsigned long long slot = atomicAdd((unsigned long long*)&stat[10], 1ull);
+      flag_list[slot] = (int)j;
+    }
   }
-  rr = wave_sum(rr); ww = wave_sum(ww);
-  if (lane == 0) atomicMax((unsigned long long*)&stat[9], (unsigned long long)__double_as_longlong(rr / ww));
+  // largest squared residual of the block -> stat[9] (bit pattern of a non-negative double orders like an integer)
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) rel2 = fmax(rel2, __shfl_xor(rel2, o, 64));
+  if ((threadIdx.x & 63) == 0 && rel2 > 0.0) atomicMax((unsigned long long*)&stat[9], (unsigned long long)__double_as_longlong(rel2));
+}
+
+// Full-rank recomputation of the LOD columns of the flagged traits (univar_liteqtl, src/bulkscan_helpers.jl:138-146):
+//   num = x_i' a0_j ,  Sxx = sum_k x_ik^2 w_jk ,  s_q = sum_k x_ik z_qk w_jk ,  u = L_j^-1 s ,
+//   r^2 = num^2 / (Sxx - |u|^2) ,  LOD = -(n/2) log10(1 - r^2)
+// with plain fp64 VALU arithmetic and libm log10.  A fixed grid walks (flagged trait, 256-marker tile) pairs; it reads
+// the count on the device (no host round trip) and exits at once when nothing was flagged (the normal case).
+template <int C>
+__global__ void __launch_bounds__(256) k_scan_fix(NullModel nm, const double* __restrict__ Xt, int64_t ldx, int64_t p,
+                                                   const double* __restrict__ P0, const double* __restrict__ Ls, int64_t ldp,
+                                                   const double* __restrict__ Z0, const double* __restrict__ lam,
+                                                   const double* __restrict__ h2v, const int* __restrict__ flag_list,
+                                                   double* __restrict__ L, int64_t ldL, int64_t* stat) {
+  constexpr int KC = 256, NL = C * (C + 1) / 2;
+  __shared__ double s_a0[KC], s_w[KC], s_wz[C][KC];
+  const int64_t cnt = stat[10];
+  if (cnt <= 0) return;
+  const int n = nm.n;
+  const int64_t ntile = (p + 255) / 256;
+  const double scale = -0.5 * (double)n;
+  int nnan = 0;
+  for (int64_t item = blockIdx.x; item < cnt * ntile; item += gridDim.x) {
+    const int64_t j = flag_list[item / ntile];
+    const int64_t i = (item % ntile) * 256 + threadIdx.x;
+    const double h2 = h2v[j];
+    const double delta = h2 / (1.0 - h2);
+    double num = 0.0, sxx = 0.0, sq[C];
+#pragma unroll
+    for (int q = 0; q < C; ++q) sq[q] = 0.0;
+    for (int k0 = 0; k0 < n; k0 += KC) {
+      __syncthreads();
+      const int k = k0 + threadIdx.x;
+      if (k < n) {
+        const double w = fabs(1.0 / fma(delta, lam[k], 1.0));
+        s_a0[threadIdx.x] = P0[(int64_t)k * ldp + j];
+        s_w[threadIdx.x] = w;
+#pragma unroll
+        for (int q = 0; q < C; ++q) s_wz[q][threadIdx.x] = w * Z0[q * n + k];
+      }
+      __syncthreads();
+      if (i < p) {
+        const int kc = (n - k0 < KC) ? (n - k0) : KC;
+        for (int kk = 0; kk < kc; ++kk) {
+          const double x = Xt[(int64_t)(k0 + kk) * ldx + i];
+          num = fma(x, s_a0[kk], num);
+          sxx = fma(x * x, s_w[kk], sxx);
+#pragma unroll
+          for (int q = 0; q < C; ++q) sq[q] = fma(x, s_wz[q][kk], sq[q]);
+        }
+      }
+    }
+    if (i < p) {
+      double li[NL];
+#pragma unroll
+      for (int e = 0; e < NL; ++e) li[e] = Ls[(int64_t)e * ldp + j];
+      double xx = sxx;
+#pragma unroll
+      for (int q = 0; q < C; ++q) {
+        double u = 0.0;
+#pragma unroll
+        for (int e = 0; e <= q; ++e) u = fma(li[q * (q + 1) / 2 + e], sq[e], u);
+        xx = fma(-u, u, xx);
+      }
+      const double r2 = (num * num) / xx;
+      const double u1 = 1.0 - r2;
+      double lod = scale * log10(u1);
+      if (!(u1 > 0.0)) { lod = (u1 == 0.0) ? INFINITY : NAN; nnan += (u1 != 0.0); }
+      L[j * ldL + i] = lod;
+    }
+  }
+  if (nnan) atomicAdd((unsigned long long*)&stat[ST_NAN_LOD], (unsigned long long)nnan);
 }
 
 int launch_lr_panels(blmm_ctx* ctx, const NullModel& nm, const double* Yt, int64_t ldy, int64_t m, const double* Z0,
@@ -716,12 +822,33 @@ int launch_lr_panels(blmm_ctx* ctx, const NullModel& nm, const double* Yt, int64
   return BLMM_OK;
 }
 
-// Diagnostic only (blmm_status.lowrank_resid): the caller runs it on the side stream beside the scan kernel.
-int launch_lr_resid(blmm_ctx* ctx, const NullModel& nm, int64_t m, const double* lam, const double* h2, const double* Q,
-                    const int* rk, const double* Cp, int64_t ldp, int64_t* stat) {
-  const int64_t stride = 61;
-  hipLaunchKernelGGL(k_lr_resid, dim3((unsigned)((m + stride - 1) / stride)), dim3(64), 0, ctx->stream, nm.n, m, stride, lam, h2, Q, rk,
-                     Cp, ldp, stat);
+// The guard (all traits): the caller runs it on the side stream beside the scan kernel, then launch_scan_fix.
+int launch_lr_resid(blmm_ctx* ctx, const NullModel& nm, int64_t m, double tol, const double* lam, const double* h2,
+                    const double* Q, const int* rk, const double* Cp, int64_t ldp, int* flag_list, int64_t* stat) {
+  if (m <= 0) return BLMM_OK;
+  const int qcap = (int)std::min<size_t>((size_t)nm.n, (56 * 1024) / (sizeof(double) * (size_t)nm.n));
+  const size_t lds = sizeof(double) * ((size_t)nm.n + (size_t)qcap * nm.n);
+  if (lds > 48 * 1024)
+    BLMM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_lr_resid), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(k_lr_resid, dim3((unsigned)((m + 255) / 256)), dim3(256), lds, ctx->stream, nm.n, m, tol * tol, lam, h2, Q, rk,
+                     qcap, Cp, ldp, flag_list, stat);
+  KCHECK();
+  return BLMM_OK;
+}
+
+int launch_scan_fix(blmm_ctx* ctx, const NullModel& nm, const double* Xt, int64_t ldx, int64_t p, const double* P0,
+                    const double* Ls, int64_t ldp, const double* Z0, const double* lam, const double* h2,
+                    const int* flag_list, double* L, int64_t ldL, int64_t* stat) {
+  if (p <= 0) return BLMM_OK;
+  const unsigned grid = (unsigned)(8 * (ctx->num_cus > 0 ? ctx->num_cus : 256));
+#define FX(C) hipLaunchKernelGGL(k_scan_fix<C>, dim3(grid), dim3(256), 0, ctx->stream, nm, Xt, ldx, p, P0, Ls, ldp, Z0, lam, h2, flag_list, L, ldL, stat)
+  switch (nm.c) {
+    case 1: FX(1); break;
+    case 2: FX(2); break;
+    case 3: FX(3); break;
+    default: return fail(ctx, BLMM_ERR_UNSUPPORTED, "number of null covariates (incl. intercept) must be 1..3 in the low-rank form");
+  }
+#undef FX
   KCHECK();
   return BLMM_OK;
 }

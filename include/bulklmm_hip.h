@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define BLMM_VERSION 100 /* 0.1.0 */
+#define BLMM_VERSION 200 /* 0.2.0: blmm_status.lowrank_fallback, BLMM_STREAM_NULL, multi-GPU entry points */
 
 typedef struct blmm_ctx blmm_ctx;
 
@@ -80,14 +80,22 @@ typedef struct blmm_status {
   int64_t jacobi_cycles;   /* shader cycles / 100 MHz ticks spent inside the eigensolver (diagnostic)  */
   int64_t jacobi_ticks_100mhz;
   int64_t lowrank_rank;    /* rank R of the weight-family basis used by the null-exact kernel (kernels_lowrank.hip) */
-  double lowrank_resid;    /* largest relative residual |w_j - Q Q'w_j| / |w_j| over the traits (diagnostic)           */
+  int64_t lowrank_fallback;/* traits whose expansion residual exceeded 1e-13: their LOD columns were recomputed from
+                              the full-length sums (k_scan_fix), so every returned LOD is either guarded or exact      */
+  double lowrank_resid;    /* largest relative residual |w_j - Q Q'w_j| / |w_j| over ALL traits (before the re-scan)  */
   double t_eigen_ms, t_rotate_ms, t_h2_ms, t_prep_ms, t_scan_ms, t_total_ms;
 } blmm_status;
 
 /* ---- library / context ------------------------------------------------------------------ */
 int blmm_version(void);
 int blmm_device_count(void);
-/* Creates a context on HIP device `device_id`.  stream == NULL: the library creates its own stream. */
+/* Creates a context on HIP device `device_id`.
+ *   hip_stream == NULL             : the library creates a PRIVATE non-blocking stream; nothing the caller enqueues on
+ *                                    any other stream (the legacy default stream included) is ordered against the calls.
+ *   hip_stream == BLMM_STREAM_NULL : adopt the legacy default ("null") stream, handle 0 -- what torch.cuda's default
+ *                                    stream is.  The handle 0 itself cannot be passed because it reads as NULL.
+ *   otherwise                      : a hipStream_t of the caller; every *_dev call enqueues on it. */
+#define BLMM_STREAM_NULL ((void*)(intptr_t)-1)
 int blmm_create(int device_id, void* hip_stream, blmm_ctx** out);
 void blmm_destroy(blmm_ctx* ctx);
 const char* blmm_last_error(const blmm_ctx* ctx);
@@ -101,6 +109,16 @@ int blmm_set_timing(blmm_ctx* ctx, int on);
 int blmm_read_timings(blmm_ctx* ctx, double* sums_ms, int64_t* ncalls);
 int blmm_synchronize(blmm_ctx* ctx);
 void blmm_default_opts(blmm_opts* o); /* bulkscan() defaults: null-grid, ML, prior (1.0, 0.0), eigen */
+
+/* ---- pinned host memory for the outputs of the host-pointer entry points ------------------------------------------
+ * L is p x m doubles (2.08 GB at BXD size) and has to cross ONE PCIe link: into a pinned destination it moves at link
+ * rate in one asynchronous copy; into pageable memory the library pipelines 32 MB pieces through its own pinned ring
+ * and copies them out with a few host threads.  A Julia caller either wraps blmm_host_alloc memory (unsafe_wrap) or
+ * registers the Array it already has; both are optional. */
+int blmm_host_register(void* p, uint64_t bytes);
+int blmm_host_unregister(void* p);
+void* blmm_host_alloc(uint64_t bytes);
+void blmm_host_free(void* p);
 
 /* ---- calcKinship(G)  (src/kinship.jl:4-14) ----------------------------------------------- */
 int blmm_kinship(blmm_ctx* ctx, const double* G, int64_t n, int64_t p, double* K_out);
@@ -119,6 +137,39 @@ int blmm_bulkscan_dev(blmm_ctx* ctx, const blmm_opts* opts, const double* dY, in
                       const double* dG, int64_t p, const double* dCovar, int64_t ncov, const double* dK,
                       const double* dweights, const double* h2_grid_host, int64_t ngrid, double* dL_out,
                       int64_t ldL, double* dh2_out, blmm_status* status);
+
+/* ---- the same call over several GPUs of one node (north_star: traits shard across the GPUs) -----------------------
+ * Replaces the reference's thread blocking over contiguous trait ranges (src/bulkscan.jl:263-309): device r of R scans
+ * the column block [r*ceil(m/R), min(m, (r+1)*ceil(m/R))) (blmm_multi_shard) and owns that block of the column-major
+ * L.  One host worker thread per device; G/K/Covar/weights are replicated; no collective on the data path.
+ *   gather_mode  BLMM_GATHER_HOST_SHARDS (default): every device copies its block straight into the caller's L_out /
+ *                  h2_out over its own PCIe link -- the reference's result, L in host memory;
+ *                BLMM_GATHER_NONE: the blocks stay in HBM (blmm_multi_device_result); L_out / h2_out may be NULL
+ *                  (when given they are filled as well);
+ *                BLMM_GATHER_ALLGATHER: an RCCL all-gather over xGMI leaves the FULL p x m matrix (ld = p, columns
+ *                  padded to R*ceil(m/R)) on every device; librccl.so is loaded on first use.
+ * status: NULL or an array of blmm_multi_ndev() entries, one per device.
+ * device_ids == NULL or ndev <= 0: every visible device.  A device id may be repeated (several shards on one GPU). */
+typedef struct blmm_multi blmm_multi;
+enum blmm_gather { BLMM_GATHER_NONE = 0, BLMM_GATHER_HOST_SHARDS = 1, BLMM_GATHER_ALLGATHER = 2 };
+typedef struct blmm_multi_opts {
+  int32_t gather_mode; /* blmm_gather */
+  int32_t reserved;
+} blmm_multi_opts;
+int blmm_create_multi(const int* device_ids, int ndev, blmm_multi** out);
+void blmm_destroy_multi(blmm_multi* mc);
+int blmm_multi_ndev(const blmm_multi* mc);
+const char* blmm_multi_last_error(const blmm_multi* mc);
+void blmm_default_multi_opts(blmm_multi_opts* o);
+void blmm_multi_shard(int64_t m, int rank, int ndev, int64_t* lo, int64_t* hi);
+int blmm_bulkscan_multi(blmm_multi* mc, const blmm_opts* opts, const blmm_multi_opts* mopts, const double* Y, int64_t n,
+                        int64_t m, const double* G, int64_t p, const double* Covar, int64_t ncov, const double* K,
+                        const double* weights, const double* h2_grid, int64_t ngrid, double* L_out, double* h2_out,
+                        blmm_status* status);
+/* Device-resident result of the last blmm_bulkscan_multi with gather_mode none / allgather on device `rank`:
+ * *dL (ld *ldL) holds the columns [*col_lo, *col_hi) of L, *dh2 the matching h2 entries. */
+int blmm_multi_device_result(blmm_multi* mc, int rank, double** dL, int64_t* ldL, int64_t* col_lo, int64_t* col_hi,
+                             double** dh2);
 
 /* ---- scan(y, G, [Covar], K; permutation_test=true)  (src/scan.jl:485-557) ------------------
  * perm_idx: n x nperms int32, 0-based, column b = permutation b (r0perm[:, b+1] = r0[perm_idx[:, b]]);

@@ -8,13 +8,6 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 
-# Beyond n = 124 the library hands the eigen-decomposition to rocSOLVER, whose first use in a process loads hundreds of
-# megabytes of code objects (seconds, minutes on a cold machine).  The default GPU suite pins the in-house Jacobi so that
-# it does not depend on that; BLMM_TEST_ROCSOLVER=1 runs the same tests (and test_rocsolver_eigen_path) through rocSOLVER.
-if not os.environ.get("BLMM_TEST_ROCSOLVER"):
-    os.environ.setdefault("BLMM_EIGEN", "jacobi")
-
-
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with `-m gpu` on the GPU box)")
 

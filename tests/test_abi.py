@@ -23,13 +23,31 @@ def test_library_exports_every_declared_symbol(blmm):
     for s in syms:
         assert hasattr(lib, s), s
     assert sorted(blmm.EXPORTS) == syms
-    assert lib.blmm_version() == 100
+    assert lib.blmm_version() == 200
+
+
+def header_struct(name):
+    """[(field, ctype), ...] of `typedef struct <name> { ... } <name>;` in include/bulklmm_hip.h."""
+    txt = open(os.path.join(ROOT, "include", "bulklmm_hip.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    body = re.search(r"typedef struct %s\s*\{(.*?)\}\s*%s\s*;" % (name, name), txt, flags=re.S).group(1)
+    ctype = {"int32_t": C.c_int32, "int64_t": C.c_int64, "double": C.c_double, "uint64_t": C.c_uint64}
+    out = []
+    for decl in body.split(";"):
+        decl = decl.strip()
+        if not decl:
+            continue
+        ty, names = decl.split(None, 1)
+        out += [(nm.strip(), ctype[ty]) for nm in names.split(",")]
+    return out
 
 
 def test_struct_layouts_match_header(blmm):
+    """The ctypes mirrors are checked field by field (name, type, order) against the header the C callers compile."""
     from bulklmm_jl_amd import _lib as L
+    for name in ("blmm_opts", "blmm_status", "blmm_multi_opts"):
+        assert [(f, t) for f, t in getattr(L, name)._fields_] == header_struct(name), name
     assert C.sizeof(L.blmm_opts) == 6 * 4 + 2 * 8
-    assert C.sizeof(L.blmm_status) == 9 * 8 + 7 * 8
     o = L.blmm_opts()
     blmm.load().blmm_default_opts(C.byref(o))
     assert (o.method, o.reml, o.add_intercept, o.decomp_scheme, o.optim_interval) == (1, 0, 1, 0, 1)

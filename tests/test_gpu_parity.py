@@ -512,3 +512,40 @@ def test_lod_colmax_and_thresholds(blmm):
     thr = blmm.get_thresholds(Lm[:, 10:], [0.10, 0.05])
     peaks = Lm[:, 10:].max(axis=0)
     assert np.allclose(thr["thrs"], np.quantile(peaks, [0.90, 0.95])) and np.allclose(thr["probs"], [0.90, 0.95])
+
+
+@pytest.mark.parametrize("method", ["null-exact", "null-grid", "alt-grid"])
+def test_multi_gpu_entry_point_with_shards_on_one_device(blmm, method, monkeypatch):
+    """blmm_bulkscan_multi (the reference's thread blocking over trait ranges, src/bulkscan.jl:263-309, as devices):
+    three "devices" that are all GPU 0 scan ragged column blocks in three host threads; every gather mode returns the
+    matrix the single-context call returns, bit for bit; the device-resident modes leave the blocks / the gathered matrix
+    in HBM (checked through a device-to-host copy of the pointers blmm_multi_device_result reports)."""
+    Y, G, K, Cov = make_data(p=203, m=100, seed=9090, ncov=1)     # 100 traits over 3 shards: 34 + 34 + 32
+    grid = [i / 8.0 for i in range(8)]
+    one = blmm.bulkscan(Y, G, K, Cov, method=method, h2_grid=grid)
+    hkey = "h2_panel" if method == "alt-grid" else "h2_null_list"
+    mc = blmm.MultiContext([0, 0, 0])
+    assert mc.ndev == 3 and [mc.shard(100, r) for r in range(3)] == [(0, 34), (34, 68), (68, 100)]
+    for gather in ("host_shards", "none", "allgather"):
+        got = blmm.bulkscan_multi(mc, Y, G, K, Cov, method=method, h2_grid=grid, gather=gather)
+        assert np.array_equal(got["L"], one["L"]) and np.array_equal(got[hkey], one[hkey]), gather
+        if gather == "host_shards":
+            with pytest.raises(blmm.BulkLMMError):
+                mc.device_result(0)
+            continue
+        for r in range(3):
+            dL, ld, lo, hi, dH = mc.device_result(r)
+            assert ld == 203 and (lo, hi) == ((0, 100) if gather == "allgather" else mc.shard(100, r))
+            buf = np.empty((203, hi - lo), order="F")
+            import ctypes
+            hip = ctypes.CDLL("libamdhip64.so")
+            assert hip.hipMemcpy(buf.ctypes.data_as(ctypes.c_void_p), ctypes.c_void_p(dL), ctypes.c_size_t(buf.nbytes), 2) == 0
+            assert np.array_equal(buf, one["L"][:, lo:hi]), (gather, r)
+    mc.close()
+    # one device through RCCL itself (librccl.so is loaded with dlopen, a communicator is created, the in-place
+    # all-gather of a single rank runs): the RCCL path of gather_mode allgather cannot meet a second GPU on this box
+    monkeypatch.setenv("BLMM_ALLGATHER", "rccl")
+    mc1 = blmm.MultiContext([0])
+    got = blmm.bulkscan_multi(mc1, Y, G, K, Cov, method=method, h2_grid=grid, gather="allgather")
+    assert np.array_equal(got["L"], one["L"]) and np.array_equal(got[hkey], one[hkey])
+    mc1.close()

@@ -2,7 +2,6 @@
 the oracle with the criteria of tests/test_gpu_parity.py.  python tools/fuzz_parity.py [ncases] [seed]"""
 import sys, os, time, traceback
 sys.path.insert(0, "."); sys.path.insert(0, "tests")
-os.environ.setdefault("BLMM_EIGEN", "jacobi")
 import numpy as np
 import bulklmm_jl_amd as blmm
 import oracle.bulklmm_oracle as O
@@ -37,7 +36,17 @@ for case in range(ncases):
             got = blmm.bulkscan_null(Y, G, K, Cov, weights=w, optim_interval=oi, **kw)
             ref = O.bulkscan_null(Y, G, K, Covar=Cov, weights=w, optim_interval=oi, **kw)
             dh = np.abs(got.h2_null_list - ref.h2_null_list)
-            assert (dh > 1e-6).mean() <= 0.002, f"h2: {int((dh > 1e-6).sum())} of {m} traits differ"   # knife-edge Brent paths
+            # strict: every h2 within 1e-6 of the oracle's, EXCEPT a trait whose profile likelihood has two local maxima
+            # and Brent (a local method) ended in the other one -- it must then be a local maximum of the oracle's own
+            # likelihood (tests/test_gpu_guard.py::test_fullsize_h2_audit_all_traits measures the rate: 2 of 35,554)
+            for j in np.flatnonzero(dh > 1e-6):
+                Yw, Gw, Cw, Kw, ai = (Y, G, Cov, K, True) if w is None else O._apply_weights(Y, G, Cov if Cov is not None else np.ones((n, 0)), K, w, True)
+                Zc = np.ones((n, 1)) if Cw is None else (np.hstack([np.ones((n, 1)), Cw]) if ai else Cw)
+                y0, X0, lam0 = O.transform_rotation(Yw[:, j:j + 1], np.hstack([Zc, Gw[:, :1]]), Kw, addIntercept=False, decomp_scheme=kw["decomp_scheme"])
+                ell = lambda h: O.wls(y0, X0[:, :Zc.shape[1]], O.makeweights(h, lam0), list(prior), reml=reml).ell
+                hg = float(got.h2_null_list[j]); eg = ell(hg)
+                assert eg >= ell(min(hg + 1e-3, 1 - 1e-9)) - 1e-9 * abs(eg) and eg >= ell(max(hg - 1e-3, 0.0)) - 1e-9 * abs(eg), \
+                    f"h2[{j}]: {hg} vs {ref.h2_null_list[j]} is not a local maximum"
             okc = dh <= 1e-6
             assert np.sum((got.L[:, okc] - ref.L[:, okc]) ** 2, axis=0).max() <= 1e-7, "sum d^2"
             pin = O.bulkscan_null(Y, G, K, Covar=Cov, weights=w, h2_override=got.h2_null_list, **kw)
@@ -75,6 +84,21 @@ for case in range(ncases):
             ref = O.bulkscan_alt_grid(Y, G, K, grid, Covar=Cov, weights=w, **kw)
             assert_lod_close(got.L, ref.L, atol=1e-9)
         print("ok  ", desc, flush=True)
+    except blmm.BulkLMMError as e:
+        # an input the reference rejects (e.g. a zero-norm marker at n = 5): fine if the oracle raises the same message
+        try:
+            {"null-exact": lambda: O.bulkscan_null(Y, G, K, Covar=Cov, weights=w, optim_interval=oi, **kw),
+             "null-grid": lambda: O.bulkscan_null_grid(Y, G, K, grid, Covar=Cov, weights=w, **kw),
+             "alt-grid": lambda: O.bulkscan_alt_grid(Y, G, K, grid, Covar=Cov, weights=w, **kw),
+             "perms": lambda: O.scan(Y[:, 0], G, K, covar=Cov, permutation_test=True, nperms=4, weights=w)}[method]()
+            same = False
+        except O.BulkLMMError as oe:
+            same = str(oe) == e.msg
+        if same:
+            print("ok  ", desc, "(both sides raise:", e.msg + ")", flush=True)
+        else:
+            fails += 1
+            print("FAIL", desc, "->", repr(e)[:300], flush=True)
     except Exception as e:   # noqa: BLE001
         fails += 1
         print("FAIL", desc, "->", repr(e)[:300], flush=True)
