@@ -22,6 +22,8 @@ EXPORTS = [
     "blmm_create_multi", "blmm_destroy_multi", "blmm_multi_ndev", "blmm_multi_last_error", "blmm_default_multi_opts",
     "blmm_multi_shard", "blmm_bulkscan_multi", "blmm_multi_device_result",
     "blmm_host_register", "blmm_host_unregister", "blmm_host_alloc", "blmm_host_free",
+    "blmm_lod2log10p", "blmm_lod2log10p_dev", "blmm_lod_threshold", "blmm_lod_threshold_dev", "blmm_get_thresholds", "blmm_get_thresholds_dev",
+    "blmm_last_log10p", "blmm_last_lod_threshold", "blmm_last_get_thresholds",
 ]
 
 BLMM_NULL_EXACT, BLMM_NULL_GRID, BLMM_ALT_GRID = 0, 1, 2
@@ -125,6 +127,15 @@ def load():
     lib.blmm_bulkscan_multi.argtypes = [vp, op, mp, vp, i64, i64, vp, i64, vp, i64, vp, vp, vp, i64, vp, vp, sp]
     lib.blmm_multi_device_result.argtypes = [vp, C.c_int, C.POINTER(vp), C.POINTER(i64), C.POINTER(i64), C.POINTER(i64),
                                              C.POINTER(vp)]
+    lib.blmm_lod2log10p.argtypes = [vp, vp, i64, i64, i64, vp]
+    lib.blmm_lod2log10p_dev.argtypes = [vp, vp, i64, i64, i64, i64, vp, i64]
+    lib.blmm_lod_threshold.argtypes = [vp, vp, i64, i64, C.c_double, i64, vp, vp, vp, C.POINTER(i64)]
+    lib.blmm_lod_threshold_dev.argtypes = [vp, vp, i64, i64, i64, C.c_double, i64, vp, vp, vp, vp]
+    lib.blmm_get_thresholds.argtypes = [vp, vp, i64, i64, vp, i64, vp]
+    lib.blmm_get_thresholds_dev.argtypes = [vp, vp, i64, i64, i64, vp, i64, vp]
+    lib.blmm_last_log10p.argtypes = [vp, i64, vp]
+    lib.blmm_last_lod_threshold.argtypes = [vp, C.c_double, i64, vp, vp, vp, C.POINTER(i64)]
+    lib.blmm_last_get_thresholds.argtypes = [vp, vp, i64, vp]
     lib.blmm_host_register.argtypes = [vp, C.c_uint64]
     lib.blmm_host_unregister.argtypes = [vp]
     lib.blmm_host_alloc.argtypes = [C.c_uint64]

@@ -338,10 +338,42 @@ def bulkscan_multi(mctx: MultiContext, Y, G, K, Covar=None, *, method: str = "nu
     return out
 
 
-def lod2log10p(lod, df: int = 1):
-    """src/util.jl:199-206 (host post-map; not on the GPU path)."""
-    from scipy.stats import chi2
-    return -chi2.logsf(np.asarray(lod) * 2.0 * np.log(10.0), df) / np.log(10.0)
+def lod2log10p(lod, df: int = 1, ctx: Optional[Context] = None):
+    """lod2log10p.(lod, df), src/util.jl:199-206, on the GPU (kernels_post.hip: erfc / erfcx for df = 1, ln Q(df/2, .) in
+    log space otherwise)."""
+    ctx = ctx or default_context()
+    a = np.asarray(lod, dtype=np.float64)
+    flat = np.asfortranarray(a.reshape(-1, 1) if a.ndim != 2 else a)
+    out = np.empty(flat.shape, order="F")
+    ctx.check(ctx.lib.blmm_lod2log10p(ctx.h, _p(flat), flat.shape[0], flat.shape[1], int(df), _p(out)))
+    return out.reshape(a.shape) if a.ndim != 2 else out
+
+
+def _last_log10p(ctx: Context, shape, df: int) -> np.ndarray:
+    """-log10 p of the LOD matrix the context's last host-pointer call produced (still in HBM: no re-upload)."""
+    out = np.empty(shape, order="F")
+    ctx.check(ctx.lib.blmm_last_log10p(ctx.h, int(df), _p(out)))
+    return out
+
+
+def lod_threshold(L_mat, thr: float, ctx: Optional[Context] = None, cap: Optional[int] = None):
+    """Sparse triplets (marker, trait, LOD) of every LOD > thr, 0-based, sorted by (trait, marker) -- the filter behind
+    plot_eQTL(...; threshold) (README.md:354-359), run on the GPU with a device-side count."""
+    ctx = ctx or default_context()
+    Lm = _F(L_mat)
+    p, m = Lm.shape
+    cap = int(cap) if cap is not None else max(1024, Lm.size // 64)
+    while True:
+        ii = np.empty(cap, dtype=np.int32); jj = np.empty(cap, dtype=np.int32); ll = np.empty(cap)
+        cnt = C.c_int64(0)
+        ctx.check(ctx.lib.blmm_lod_threshold(ctx.h, _p(Lm), p, m, float(thr), cap, ii.ctypes.data_as(C.c_void_p),
+                                             jj.ctypes.data_as(C.c_void_p), _p(ll), C.byref(cnt)))
+        if cnt.value <= cap:
+            break
+        cap = int(cnt.value)
+    k = int(cnt.value)
+    order = np.lexsort((ii[:k], jj[:k]))
+    return ii[:k][order], jj[:k][order], ll[:k][order]
 
 
 def bulkscan(Y, G, K, Covar=None, *, method: str = "null-grid", h2_grid=None, nb: int = 1, nt_blas: int = 1,
@@ -369,14 +401,16 @@ def bulkscan(Y, G, K, Covar=None, *, method: str = "null-grid", h2_grid=None, nb
                               decomp_scheme=decomp_scheme, ctx=ctx)
         out = {"L": r.L, "h2_panel": r.h2_panel}
     if output_pvals:
-        out["log10Pvals_mat"] = lod2log10p(out["L"], chisq_df)
+        # lod2log10p.(L, chisq_df) merged into the result (src/bulkscan.jl:154-157), from the L still resident in HBM
+        out["log10Pvals_mat"] = _last_log10p(ctx or default_context(), out["L"].shape, chisq_df)
         out["Chisq_df"] = chisq_df
     return out
 
 
 def scan(y, g, K, covar=None, *, weights=None, prior_variance: float = 0.0, prior_sample_size: float = 0.0,
          addIntercept: bool = True, reml: bool = False, assumption: str = "null", method: str = "qr", optim_interval: int = 1,
-         permutation_test: bool = False, nperms: int = 1024, rndseed: int = 0, decomp_scheme: str = "eigen",
+         permutation_test: bool = False, nperms: int = 1024, rndseed: int = 0, profileLL: bool = False, markerID: int = 0,
+         h2_grid=None, decomp_scheme: str = "eigen",
          output_pvals: bool = False, chisq_df: int = 1, perm_idx=None, perm_precision: str = "f64",
          ctx: Optional[Context] = None) -> dict:
     """src/scan.jl:94-271 for assumption == "null": the single-trait scan routed through the same GPU
@@ -388,6 +422,9 @@ def scan(y, g, K, covar=None, *, weights=None, prior_variance: float = 0.0, prio
     y = _F(y)
     if covar is None and not addIntercept:
         raise BulkLMMError("Intercept has to be added when no other covariate is given.", -7)  # src/scan.jl:167-169
+    if profileLL:   # src/scan.jl:252-267 (profile_LL of src/analysis_helpers): not part of the GPU path
+        raise NotImplementedError("profileLL = true (profile_LL) is outside the GPU hot path; `markerID` / `h2_grid` only matter there")
+    # `method` ("qr" / "cholesky") picks a CPU factorisation in the reference; the GPU path has one (closed-form WLS)
     if assumption == "alt":
         if permutation_test:
             raise BulkLMMError("Permutation test option currently is not supported for the alternative assumption.")
@@ -436,9 +473,9 @@ def scan(y, g, K, covar=None, *, weights=None, prior_variance: float = 0.0, prio
     if permutation_test:
         out["L_perms"] = Lp[:, :nperms]
     if output_pvals:
-        out["log10pvals"] = lod2log10p(lod, chisq_df)
-        if permutation_test:
-            out["log10Pvals_perms"] = lod2log10p(out["L_perms"], chisq_df)  # the reference's UndefVarError fixed (B3)
+        out["log10pvals"] = lod2log10p(lod, chisq_df, ctx=ctx)
+        if permutation_test and not f32 and nperms > 0:
+            out["log10Pvals_perms"] = _last_log10p(ctx, (p, nperms), chisq_df)  # the reference's UndefVarError fixed (B3)
     return out
 
 
@@ -454,10 +491,15 @@ def lod_colmax(L_mat, ctx: Optional[Context] = None):
 
 
 def get_thresholds(L_perms, signif_level, ctx: Optional[Context] = None):
-    """src/analysis_helpers/single_trait_analysis.jl:13-23: quantiles of the per-permutation peak LODs."""
-    peaks, _ = lod_colmax(L_perms, ctx=ctx)
-    thr_probs = 1.0 - np.asarray(signif_level, dtype=np.float64)
-    return {"probs": thr_probs, "thrs": np.quantile(peaks, thr_probs)}  # Julia's default quantile = linear interpolation
+    """src/analysis_helpers/single_trait_analysis.jl:13-23: quantiles of the per-permutation peak LODs; column maxima,
+    sort and Julia's default (linear interpolation) quantile all on the GPU (blmm_get_thresholds)."""
+    ctx = ctx or default_context()
+    Lm = _F(L_perms)
+    p, nperms = Lm.shape
+    thr_probs = np.ascontiguousarray(1.0 - np.atleast_1d(np.asarray(signif_level, dtype=np.float64)))
+    thrs = np.empty(thr_probs.shape[0])
+    ctx.check(ctx.lib.blmm_get_thresholds(ctx.h, _p(Lm), p, nperms, _p(thr_probs), thr_probs.shape[0], _p(thrs)))
+    return {"probs": thr_probs, "thrs": thrs}
 
 
 # ---- lower-level seams ------------------------------------------------------------------------------

@@ -604,6 +604,45 @@ int blmm_lod_colmax(blmm_ctx* ctx, const double* L, int64_t p, int64_t m, double
   return BLMM_OK;
 }
 
+// host-pointer forms of the consumers (upload, reduce on the device, download the small result)
+int blmm_lod2log10p(blmm_ctx* ctx, const double* L, int64_t p, int64_t m, int64_t chisq_df, double* P_out) {
+  if (!ctx) return BLMM_ERR_INVALID;
+  if (!L || !P_out || p < 0 || m < 0 || chisq_df < 1) return fail(ctx, BLMM_ERR_INVALID, "lod2log10p: bad arguments");
+  if ((size_t)p * m == 0) return BLMM_OK;
+  BLMM_HIP(hipSetDevice(ctx->device));
+  int rc;
+  if ((rc = ensure(ctx, ctx->altbuf, sizeof(double) * (size_t)p * m * 2))) return rc;
+  double* dL = ptr<double>(ctx->altbuf);
+  double* dP = dL + (size_t)p * m;
+  BLMM_HIP(hipMemcpyAsync(dL, L, sizeof(double) * (size_t)p * m, hipMemcpyHostToDevice, ctx->stream));
+  if ((rc = launch_lod2log10p(ctx, dL, p, m, p, (int)chisq_df, dP, p))) return rc;
+  if ((rc = copy_to_host(ctx, P_out, dP, sizeof(double) * (size_t)p * m))) return rc;
+  return BLMM_OK;
+}
+
+int blmm_lod_threshold(blmm_ctx* ctx, const double* L, int64_t p, int64_t m, double thr, int64_t cap, int32_t* i_out,
+                       int32_t* j_out, double* lod_out, int64_t* count_out) {
+  if (!ctx) return BLMM_ERR_INVALID;
+  if (!L || p < 1 || m < 1) return fail(ctx, BLMM_ERR_INVALID, "lod_threshold: bad arguments");
+  BLMM_HIP(hipSetDevice(ctx->device));
+  int rc;
+  if ((rc = ensure(ctx, ctx->outL, sizeof(double) * (size_t)p * m))) return rc;
+  BLMM_HIP(hipMemcpyAsync(ctx->outL.p, L, sizeof(double) * (size_t)p * m, hipMemcpyHostToDevice, ctx->stream));
+  ctx->last_L = ptr<double>(ctx->outL); ctx->last_p = p; ctx->last_m = m; ctx->last_f32 = false;
+  return blmm_last_lod_threshold(ctx, thr, cap, i_out, j_out, lod_out, count_out);
+}
+
+int blmm_get_thresholds(blmm_ctx* ctx, const double* Lperms, int64_t p, int64_t nperms, const double* probs, int64_t nprobs,
+                        double* thrs_out) {
+  if (!ctx) return BLMM_ERR_INVALID;
+  if (!Lperms || p < 1 || nperms < 1) return fail(ctx, BLMM_ERR_INVALID, "get_thresholds: bad arguments");
+  BLMM_HIP(hipSetDevice(ctx->device));
+  int rc;
+  if ((rc = ensure(ctx, ctx->altbuf, sizeof(double) * (size_t)p * nperms))) return rc;
+  BLMM_HIP(hipMemcpyAsync(ctx->altbuf.p, Lperms, sizeof(double) * (size_t)p * nperms, hipMemcpyHostToDevice, ctx->stream));
+  return blmm_get_thresholds_dev(ctx, ptr<double>(ctx->altbuf), p, nperms, p, probs, nprobs, thrs_out);
+}
+
 // ---------------------------------------------------------------------------------------------------
 int blmm_bulkscan_dev(blmm_ctx* ctx, const blmm_opts* opts, const double* dY, int64_t n, int64_t m, const double* dG,
                       int64_t p, const double* dCovar, int64_t ncov, const double* dK, const double* dweights,
@@ -735,6 +774,7 @@ int blmm_bulkscan(blmm_ctx* ctx, const blmm_opts* opts, const double* Y, int64_t
   rc = blmm_bulkscan_dev(ctx, opts, ptr<double>(ctx->inY), n, m, ptr<double>(ctx->inG), p, dCov, dCov ? ncov : 0,
                          ptr<double>(ctx->inK), dW, h2_grid, ngrid, ptr<double>(ctx->outL), p, ptr<double>(ctx->outH2), status);
   if (rc) { hipStreamSynchronize(ctx->stream); return rc; }
+  ctx->last_L = ptr<double>(ctx->outL); ctx->last_p = p; ctx->last_m = m; ctx->last_f32 = false;
   if ((size_t)p * m > 0 && (rc = copy_to_host(ctx, L_out, ctx->outL.p, sizeof(double) * (size_t)p * m))) return rc;
   if (h2_elems > 0 && (rc = copy_to_host(ctx, h2_out, ctx->outH2.p, sizeof(double) * h2_elems))) return rc;
   BLMM_HIP(hipStreamSynchronize(ctx->stream));
@@ -855,6 +895,7 @@ static int scan_perms_host(blmm_ctx* ctx, const blmm_opts* opts, const double* y
                        ptr<double>(ctx->inK), dW, nperms, seed, dperm, ptr<double>(ctx->outH2), dL,
                        f32 ? nullptr : reinterpret_cast<double*>(dLp), f32 ? reinterpret_cast<float*>(dLp) : nullptr, status);
   if (rc) { hipStreamSynchronize(ctx->stream); return rc; }
+  ctx->last_L = reinterpret_cast<const double*>(dLp); ctx->last_p = p; ctx->last_m = nperms; ctx->last_f32 = f32;
   BLMM_HIP(hipMemcpyAsync(scalars_out, ctx->outH2.p, sizeof(double) * 2, hipMemcpyDeviceToHost, ctx->stream));
   if (p > 0) BLMM_HIP(hipMemcpyAsync(lod_out, dL, sizeof(double) * p, hipMemcpyDeviceToHost, ctx->stream));
   if (p > 0 && nperms > 0 && (rc = copy_to_host(ctx, Lperms_out, dLp, esz * (size_t)p * nperms))) return rc;

@@ -58,6 +58,8 @@ struct blmm_ctx {
   // multi-workgroup weight-basis kernel) is reported by the NEXT API call / blmm_synchronize even when the failing
   // call was made without a blmm_status (blmm_api.hip: check_sticky)
   volatile int64_t* hflag = nullptr;
+  // the LOD matrix of the last host-pointer call, still resident in the workspace (kernels_post.hip: blmm_last_*)
+  const double* last_L = nullptr; int64_t last_p = 0, last_m = 0; bool last_f32 = false;
   blmm::HostStage* hstage = nullptr;   // pinned staging ring + copy threads of the host-pointer entry points (host_path.hip)
 };
 
@@ -122,6 +124,8 @@ int launch_isx(blmm_ctx* ctx, const NullModel& nm, const double* Xt, int64_t ldx
                const double* lam, const double* grid_dev, int ngrid, double* isx, int64_t ld_isx, int64_t* stat);
 int launch_kinship(blmm_ctx* ctx, const double* dG, int64_t n, int64_t p, double* dK, double* partial);
 int launch_colmax(blmm_ctx* ctx, const double* L, int64_t p, int64_t m, int64_t ldL, double* mx, int64_t* arg);
+// kernels_post.hip
+int launch_lod2log10p(blmm_ctx* ctx, const double* dL, int64_t p, int64_t m, int64_t ldL, int df, double* dP, int64_t ldP);
 // permutation panel: column b = sqrt(w) .* P_w( pi_b(r0) ) / ||r0||  etc.  (see kernels_prep.hip)
 int launch_perm_panel(blmm_ctx* ctx, const NullModel& nm, const double* Yt, int64_t ldy, const double* Z0,
                       const double* lam, const double* h2, const int32_t* perm_idx, int64_t nperms, uint64_t seed,

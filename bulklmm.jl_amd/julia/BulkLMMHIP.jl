@@ -3,11 +3,13 @@
 # Same signatures, keyword defaults and NamedTuple fields as BulkLMM.jl's bulkscan hot path
 # (src/bulkscan.jl:81-162,188-314,321-397,428-526; src/scan.jl:94-271,485-557; src/kinship.jl:4-14), so that
 #     using BulkLMMHIP: bulkscan, bulkscan_null, bulkscan_null_grid, bulkscan_alt_grid, scan, calcKinship
-# is a drop-in for `using BulkLMM` on that path.  NOTE: there is no Julia in the build container; this file is the
-# binding a maintainer adds (INTEGRATION.md) and mirrors bulklmm.jl_amd/api.py (the ctypes host that IS tested) 1:1.
+# is a drop-in for `using BulkLMM` on that path.  NOTE: there is no Julia in the build container, so THIS FILE HAS NEVER
+# BEEN EXECUTED; it is the binding a maintainer adds (INTEGRATION.md) and mirrors bulklmm.jl_amd/api.py (the ctypes host
+# that IS tested) 1:1.  tests/test_binding_kwargs.py checks, as text, that every keyword of the reference's signatures is
+# accepted here and in api.py.
 module BulkLMMHIP
 
-export calcKinship, bulkscan, bulkscan_null, bulkscan_null_grid, bulkscan_alt_grid, scan
+export calcKinship, bulkscan, bulkscan_null, bulkscan_null_grid, bulkscan_alt_grid, scan, bulkscan_multi, lod2log10p, get_thresholds
 
 const libblmm = get(ENV, "BULKLMM_HIP_LIB", joinpath(@__DIR__, "..", "csrc", "libbulklmm_hip.so"))
 
@@ -20,9 +22,9 @@ end
 mutable struct BlmmStatus  # include/bulklmm_hip.h: blmm_status
     n_neg_eig::Int64; n_nonpos_weight::Int64; n_zero_norm::Int64; n_nan_lod::Int64
     n_brent_maxiter::Int64; jacobi_sweeps::Int64; jacobi_cycles::Int64; jacobi_ticks_100mhz::Int64
-    lowrank_rank::Int64; lowrank_resid::Float64
+    lowrank_rank::Int64; lowrank_fallback::Int64; lowrank_resid::Float64
     t_eigen_ms::Float64; t_rotate_ms::Float64; t_h2_ms::Float64; t_prep_ms::Float64; t_scan_ms::Float64; t_total_ms::Float64
-    BlmmStatus() = new(0, 0, 0, 0, 0, 0, 0, 0, 0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0)
+    BlmmStatus() = new(0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0)
 end
 
 const NULL_EXACT, NULL_GRID, ALT_GRID = Int32(0), Int32(1), Int32(2)
@@ -134,61 +136,212 @@ function bulkscan_alt_grid(Y::Array{Float64, 2}, G::Array{Float64, 2}, Covar::Ar
     return (L = L, h2_panel = h2)
 end
 
-function bulkscan(Y::Array{Float64, 2}, G::Array{Float64, 2}, K::Array{Float64, 2};
-                  method::String = "null-grid", h2_grid::Array{Float64, 1} = collect(0.0:0.1:0.9),
-                  nb::Int64 = Threads.nthreads(), nt_blas::Int64 = 1, weights = missing,
-                  prior_variance::Float64 = 1.0, prior_sample_size::Float64 = 0.0, reml::Bool = false,
-                  optim_interval::Int64 = 1, decomp_scheme::String = "eigen")
-    if method == "null-exact"
-        return bulkscan_null(Y, G, K; weights = weights, prior_variance = prior_variance, prior_sample_size = prior_sample_size,
-                             reml = reml, optim_interval = optim_interval, decomp_scheme = decomp_scheme)
-    elseif method == "null-grid"
-        return bulkscan_null_grid(Y, G, K, h2_grid; weights = weights, prior_variance = prior_variance,
-                                  prior_sample_size = prior_sample_size, reml = reml, decomp_scheme = decomp_scheme)
-    elseif method == "alt-grid"
-        return bulkscan_alt_grid(Y, G, K, h2_grid; weights = weights, prior_variance = prior_variance,
-                                 prior_sample_size = prior_sample_size, reml = reml, decomp_scheme = decomp_scheme)
-    end
-    error("Unknown method `$method`; choose null-exact, null-grid or alt-grid.")  # the reference hits an UndefVarError here
+# lod2log10p.(L, chisq_df) of the LOD matrix the last host-pointer call left in HBM (src/util.jl:199-206, on the GPU)
+function _last_log10p(dims, chisq_df::Int64)
+    P = Array{Float64}(undef, dims...)
+    GC.@preserve P check(ccall((:blmm_last_log10p, libblmm), Cint, (Ptr{Cvoid}, Int64, Ptr{Float64}), context(), chisq_df, P))
+    return P
 end
 
-# scan(y, G, K; ...): null assumption, optional permutation test (src/scan.jl:94-271, 485-557)
+function lod2log10p(lod::Array{Float64}, df::Int64)
+    P = similar(lod)
+    (p, m) = ndims(lod) == 2 ? size(lod) : (length(lod), 1)
+    GC.@preserve lod P check(ccall((:blmm_lod2log10p, libblmm), Cint, (Ptr{Cvoid}, Ptr{Float64}, Int64, Int64, Int64, Ptr{Float64}),
+                                   context(), lod, p, m, df, P))
+    return P
+end
+lod2log10p(lod::Float64, df::Int64) = lod2log10p([lod], df)[1]
+
+# bulkscan(Y, G, K; ...) and bulkscan(Y, G, Covar, K; ...): src/bulkscan.jl:81-111, 113-162
+function bulkscan(Y::Array{Float64, 2}, G::Array{Float64, 2}, K::Array{Float64, 2};
+                  method::String = "null-grid", h2_grid::Array{Float64, 1} = collect(0.0:0.1:0.9),
+                  nb::Int64 = Threads.nthreads(), nt_blas::Int64 = 1,
+                  weights::Union{Missing, Array{Float64, 1}} = missing,
+                  prior_variance::Float64 = 1.0, prior_sample_size::Float64 = 0.0,
+                  reml::Bool = false, optim_interval::Int64 = 1,
+                  decomp_scheme::String = "eigen",
+                  output_pvals::Bool = false, chisq_df::Int64 = 1)
+    # when no covariates are added, make the intercept the only covariate (src/bulkscan.jl:97-108)
+    return bulkscan(Y, G, ones(size(Y, 1), 1), K; method = method, h2_grid = h2_grid, nb = nb, nt_blas = nt_blas,
+                    addIntercept = false, weights = weights, prior_variance = prior_variance,
+                    prior_sample_size = prior_sample_size, reml = reml, optim_interval = optim_interval,
+                    decomp_scheme = decomp_scheme, output_pvals = output_pvals, chisq_df = chisq_df)
+end
+function bulkscan(Y::Array{Float64, 2}, G::Array{Float64, 2}, Covar::Array{Float64, 2}, K::Array{Float64, 2};
+                  method::String = "null-grid", h2_grid::Array{Float64, 1} = collect(0.0:0.1:0.9),
+                  nb::Int64 = Threads.nthreads(), nt_blas::Int64 = 1, addIntercept::Bool = true,
+                  weights::Union{Missing, Array{Float64, 1}} = missing,
+                  prior_variance::Float64 = 1.0, prior_sample_size::Float64 = 0.0,
+                  reml::Bool = false, optim_interval::Int64 = 1,
+                  decomp_scheme::String = "eigen",
+                  output_pvals::Bool = false, chisq_df::Int64 = 1)
+    if method == "null-exact"
+        res = bulkscan_null(Y, G, Covar, K; addIntercept = addIntercept, weights = weights, prior_variance = prior_variance,
+                            prior_sample_size = prior_sample_size, reml = reml, optim_interval = optim_interval,
+                            decomp_scheme = decomp_scheme)
+    elseif method == "null-grid"
+        res = bulkscan_null_grid(Y, G, Covar, K, h2_grid; addIntercept = addIntercept, weights = weights,
+                                 prior_variance = prior_variance, prior_sample_size = prior_sample_size, reml = reml,
+                                 decomp_scheme = decomp_scheme)
+    elseif method == "alt-grid"
+        res = bulkscan_alt_grid(Y, G, Covar, K, h2_grid; addIntercept = addIntercept, weights = weights,
+                                prior_variance = prior_variance, prior_sample_size = prior_sample_size, reml = reml,
+                                decomp_scheme = decomp_scheme)
+    else
+        error("Unknown method `$method`; choose null-exact, null-grid or alt-grid.")  # the reference hits an UndefVarError here
+    end
+    if output_pvals   # src/bulkscan.jl:154-157
+        return merge(res, (log10Pvals_mat = _last_log10p(size(res.L), chisq_df), Chisq_df = chisq_df))
+    end
+    return res
+end
+
+# ---- several GPUs of one node in ONE call (blmm_bulkscan_multi): the trait blocks the reference deals to its threads
+# (src/bulkscan.jl:263-309) go to the devices; gather = :host_shards (default) | :none | :allgather
+const _mctx = Ref{Ptr{Cvoid}}(C_NULL)
+function multi_context(devices::Vector{Int32} = Int32[])
+    if _mctx[] == C_NULL
+        h = Ref{Ptr{Cvoid}}(C_NULL)
+        rc = ccall((:blmm_create_multi, libblmm), Cint, (Ptr{Int32}, Cint, Ref{Ptr{Cvoid}}),
+                   isempty(devices) ? C_NULL : pointer(devices), length(devices), h)
+        rc == 0 || error(unsafe_string(ccall((:blmm_err_string, libblmm), Cstring, (Cint,), rc)))
+        _mctx[] = h[]
+    end
+    return _mctx[]
+end
+struct BlmmMultiOpts; gather_mode::Int32; reserved::Int32; end
+function bulkscan_multi(Y::Array{Float64, 2}, G::Array{Float64, 2}, K::Array{Float64, 2};
+                        method::String = "null-grid", h2_grid::Array{Float64, 1} = collect(0.0:0.1:0.9),
+                        gather::Symbol = :host_shards, devices::Vector{Int32} = Int32[],
+                        weights::Union{Missing, Array{Float64, 1}} = missing,
+                        prior_variance::Float64 = 1.0, prior_sample_size::Float64 = 0.0,
+                        reml::Bool = false, optim_interval::Int64 = 1, decomp_scheme::String = "eigen")
+    meth = method == "null-exact" ? NULL_EXACT : method == "null-grid" ? NULL_GRID : method == "alt-grid" ? ALT_GRID :
+           error("Unknown method `$method`; choose null-exact, null-grid or alt-grid.")
+    (n, m) = size(Y); p = size(G, 2)
+    (size(G, 1) != n || size(K, 1) != n) && error("Dimension mismatch.")
+    o = BlmmOpts(meth, reml, true, decomp(decomp_scheme), optim_interval, 0, prior_variance, prior_sample_size)
+    mo = BlmmMultiOpts(gather == :none ? 0 : gather == :allgather ? 2 : 1, 0)
+    L = Array{Float64, 2}(undef, p, m)
+    h2 = meth == ALT_GRID ? Array{Float64, 2}(undef, p, m) : Array{Float64, 1}(undef, m)
+    mc = multi_context(devices)
+    GC.@preserve Y G K weights h2_grid L h2 begin
+        rc = ccall((:blmm_bulkscan_multi, libblmm), Cint,
+                   (Ptr{Cvoid}, Ref{BlmmOpts}, Ref{BlmmMultiOpts}, Ptr{Float64}, Int64, Int64, Ptr{Float64}, Int64, Ptr{Float64}, Int64,
+                    Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Int64, Ptr{Float64}, Ptr{Float64}, Ptr{Cvoid}),
+                   mc, o, mo, Y, n, m, G, p, C_NULL, 0, K, ptr_or_null(weights), h2_grid, length(h2_grid), L, h2, C_NULL)
+        rc == 0 || error(unsafe_string(ccall((:blmm_multi_last_error, libblmm), Cstring, (Ptr{Cvoid},), mc)))
+    end
+    return meth == ALT_GRID ? (L = L, h2_panel = h2) : (L = L, h2_null_list = h2)
+end
+
+# ---- scan: the reference's four methods (src/scan.jl:94-120, 122-148, 150-180, 182-271).  On the GPU path:
+#   assumption = "null" only (scan_alt's per-marker Brent stays on the CPU reference: SURVEY.md §8(a) A19);
+#   method ("qr" / "cholesky") selects a CPU factorisation and has no meaning here: accepted, ignored;
+#   profileLL = true (profile_LL of src/analysis_helpers) is not part of this path: a clear error.
 function scan(y::Array{Float64, 1}, g::Array{Float64, 2}, K::Array{Float64, 2};
-              weights = missing, prior_variance::Float64 = 0.0, prior_sample_size::Float64 = 0.0, addIntercept::Bool = true,
-              reml::Bool = false, assumption::String = "null", optim_interval::Int64 = 1,
-              permutation_test::Bool = false, nperms::Int64 = 1024, rndseed::Int64 = 0, decomp_scheme::String = "eigen",
-              perm_precision::String = "f64")   # "f32": L_perms on the fp32 matrix cores, returned as Float32
-    addIntercept || error("Intercept has to be added when no other covariate is given.")
-    assumption == "null" || error(assumption == "alt" ? "scan_alt is not part of the GPU path" :
-                                  "Assumption keyword is not supported. Please enter null or alt.")
-    n = length(y); p = size(g, 2)
+              weights::Union{Missing, Array{Float64, 1}} = missing,
+              prior_variance::Float64 = 0.0, prior_sample_size::Float64 = 0.0, addIntercept::Bool = true,
+              reml::Bool = false, assumption::String = "null", method::String = "qr", optim_interval::Int64 = 1,
+              permutation_test::Bool = false, nperms::Int64 = 1024, rndseed::Int64 = 0,
+              profileLL::Bool = false, markerID::Int = 0, h2_grid::Array{Float64, 1} = Array{Float64, 1}(undef, 1),
+              decomp_scheme::String = "eigen",
+              output_pvals::Bool = false, chisq_df::Int64 = 1,
+              perm_precision::String = "f64")   # "f32" (not in the reference): L_perms on the fp32 matrix cores, as Float32
+    return scan(reshape(y, :, 1), g, K; weights = weights, addIntercept = addIntercept, prior_variance = prior_variance,
+                prior_sample_size = prior_sample_size, reml = reml, assumption = assumption, method = method,
+                optim_interval = optim_interval, permutation_test = permutation_test, nperms = nperms, rndseed = rndseed,
+                profileLL = profileLL, markerID = markerID, h2_grid = h2_grid, decomp_scheme = decomp_scheme,
+                output_pvals = output_pvals, chisq_df = chisq_df, perm_precision = perm_precision)
+end
+function scan(y::Array{Float64, 1}, g::Array{Float64, 2}, covar::Array{Float64, 2}, K::Array{Float64, 2};
+              weights::Union{Missing, Array{Float64, 1}} = missing,
+              prior_variance::Float64 = 0.0, prior_sample_size::Float64 = 0.0, addIntercept::Bool = true,
+              reml::Bool = false, assumption::String = "null", method::String = "qr", optim_interval::Int64 = 1,
+              permutation_test::Bool = false, nperms::Int64 = 1024, rndseed::Int64 = 0,
+              profileLL::Bool = false, markerID::Int = 0, h2_grid::Array{Float64, 1} = Array{Float64, 1}(undef, 1),
+              decomp_scheme::String = "eigen",
+              output_pvals::Bool = false, chisq_df::Int64 = 1,
+              perm_precision::String = "f64")
+    return scan(reshape(y, :, 1), g, covar, K; weights = weights, addIntercept = addIntercept, prior_variance = prior_variance,
+                prior_sample_size = prior_sample_size, reml = reml, assumption = assumption, method = method,
+                optim_interval = optim_interval, permutation_test = permutation_test, nperms = nperms, rndseed = rndseed,
+                profileLL = profileLL, markerID = markerID, h2_grid = h2_grid, decomp_scheme = decomp_scheme,
+                output_pvals = output_pvals, chisq_df = chisq_df, perm_precision = perm_precision)
+end
+function scan(y::Array{Float64, 2}, g::Array{Float64, 2}, K::Array{Float64, 2};
+              weights::Union{Missing, Array{Float64, 1}} = missing,
+              prior_variance::Float64 = 0.0, prior_sample_size::Float64 = 0.0, addIntercept::Bool = true,
+              reml::Bool = false, assumption::String = "null", method::String = "qr", optim_interval::Int64 = 1,
+              permutation_test::Bool = false, nperms::Int64 = 1024, rndseed::Int64 = 0,
+              profileLL::Bool = false, markerID::Int = 0, h2_grid::Array{Float64, 1} = Array{Float64, 1}(undef, 1),
+              decomp_scheme::String = "eigen",
+              output_pvals::Bool = false, chisq_df::Int64 = 1,
+              perm_precision::String = "f64")
+    addIntercept || error("Intercept has to be added when no other covariate is given.")   # src/scan.jl:167-169
+    return scan(y, g, ones(size(y, 1), 1), K; weights = weights, addIntercept = false, prior_variance = prior_variance,
+                prior_sample_size = prior_sample_size, reml = reml, assumption = assumption, method = method,
+                optim_interval = optim_interval, permutation_test = permutation_test, nperms = nperms, rndseed = rndseed,
+                profileLL = profileLL, markerID = markerID, h2_grid = h2_grid, decomp_scheme = decomp_scheme,
+                output_pvals = output_pvals, chisq_df = chisq_df, perm_precision = perm_precision)
+end
+function scan(y::Array{Float64, 2}, g::Array{Float64, 2}, covar::Array{Float64, 2}, K::Array{Float64, 2};
+              weights::Union{Missing, Array{Float64, 1}} = missing,
+              prior_variance::Float64 = 0.0, prior_sample_size::Float64 = 0.0, addIntercept::Bool = true,
+              reml::Bool = false, assumption::String = "null", method::String = "qr", optim_interval::Int64 = 1,
+              permutation_test::Bool = false, nperms::Int64 = 1024, rndseed::Int64 = 0,
+              profileLL::Bool = false, markerID::Int = 0, h2_grid::Array{Float64, 1} = Array{Float64, 1}(undef, 1),
+              decomp_scheme::String = "eigen",
+              output_pvals::Bool = false, chisq_df::Int64 = 1,
+              perm_precision::String = "f64")
+    if assumption == "alt"
+        permutation_test && error("Permutation test option currently is not supported for the alternative assumption.")
+        error("assumption = \"alt\" (scan_alt, per-marker h2) is not part of the GPU path; call BulkLMM.scan for it")
+    end
+    assumption == "null" || error("Assumption keyword is not supported. Please enter null or alt.")
+    profileLL && error("profileLL = true (profile_LL) is not part of the GPU path; call BulkLMM.scan for it")
+    size(y, 2) == 1 || error("Can only handle one trait.")                                   # src/scan.jl:496-498
+    n = size(y, 1); p = size(g, 2)
+    (size(g, 1) != n || size(K, 1) != n || size(covar, 1) != n) && error("Dimension mismatch.")
     np = permutation_test ? nperms : 0
     np < 0 && error("The required number of permutations must be a positive integer.")
-    o = BlmmOpts(NULL_EXACT, reml, true, decomp(decomp_scheme), optim_interval, 0, prior_variance, prior_sample_size)
     perm_precision in ("f64", "f32") || error("perm_precision must be \"f64\" or \"f32\".")
+    # `weights`, the intercept and the covariates go to the library as they are: it applies W (src/scan.jl:200-221) itself
+    o = BlmmOpts(NULL_EXACT, reml, addIntercept, decomp(decomp_scheme), optim_interval, 0, prior_variance, prior_sample_size)
     scal = zeros(2); lod = Array{Float64, 1}(undef, p); st = BlmmStatus()
-    if perm_precision == "f32"
-        Lp32 = Array{Float32, 2}(undef, p, max(np, 1))
-        GC.@preserve y g K weights scal lod Lp32 begin
+    ncov = size(covar, 2)
+    f32 = perm_precision == "f32"
+    Lp = f32 ? Array{Float32, 2}(undef, p, max(np, 1)) : Array{Float64, 2}(undef, p, max(np, 1))
+    GC.@preserve y g covar K weights scal lod Lp begin
+        if f32
             check(ccall((:blmm_scan_perms_f32, libblmm), Cint,
                         (Ptr{Cvoid}, Ref{BlmmOpts}, Ptr{Float64}, Int64, Ptr{Float64}, Int64, Ptr{Float64}, Int64, Ptr{Float64},
                          Ptr{Float64}, Int64, UInt64, Ptr{Int32}, Ptr{Float64}, Ptr{Float64}, Ptr{Float32}, Ref{BlmmStatus}),
-                        context(), o, y, n, g, p, C_NULL, 0, K, ptr_or_null(weights), np, UInt64(rndseed), C_NULL, scal, lod, Lp32, st))
+                        context(), o, y, n, g, p, covar, ncov, K, ptr_or_null(weights), np, UInt64(rndseed), C_NULL, scal, lod, Lp, st))
+        else
+            check(ccall((:blmm_scan_perms, libblmm), Cint,
+                        (Ptr{Cvoid}, Ref{BlmmOpts}, Ptr{Float64}, Int64, Ptr{Float64}, Int64, Ptr{Float64}, Int64, Ptr{Float64},
+                         Ptr{Float64}, Int64, UInt64, Ptr{Int32}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ref{BlmmStatus}),
+                        context(), o, y, n, g, p, covar, ncov, K, ptr_or_null(weights), np, UInt64(rndseed), C_NULL, scal, lod, Lp, st))
         end
-        raise_status(st)
-        return permutation_test ? (sigma2_e = scal[1], h2_null = scal[2], lod = lod, L_perms = Lp32[:, 1:np]) :
-                                  (sigma2_e = scal[1], h2_null = scal[2], lod = lod)
-    end
-    Lp = Array{Float64, 2}(undef, p, max(np, 1))
-    GC.@preserve y g K weights scal lod Lp begin
-        check(ccall((:blmm_scan_perms, libblmm), Cint,
-                    (Ptr{Cvoid}, Ref{BlmmOpts}, Ptr{Float64}, Int64, Ptr{Float64}, Int64, Ptr{Float64}, Int64, Ptr{Float64},
-                     Ptr{Float64}, Int64, UInt64, Ptr{Int32}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ref{BlmmStatus}),
-                    context(), o, y, n, g, p, C_NULL, 0, K, ptr_or_null(weights), np, UInt64(rndseed), C_NULL, scal, lod, Lp, st))
     end
     raise_status(st)
-    return permutation_test ? (sigma2_e = scal[1], h2_null = scal[2], lod = lod, L_perms = Lp[:, 1:np]) :
-                              (sigma2_e = scal[1], h2_null = scal[2], lod = lod)
+    res = permutation_test ? (sigma2_e = scal[1], h2_null = scal[2], lod = lod, L_perms = Lp[:, 1:np]) :
+                             (sigma2_e = scal[1], h2_null = scal[2], lod = lod)
+    if output_pvals   # src/scan.jl:353-355; with permutations the reference hits an UndefVarError (src/scan.jl:551): fixed
+        res = merge(res, (log10pvals = lod2log10p(lod, chisq_df),))
+    end
+    return res
+end
+
+# get_thresholds (src/analysis_helpers/single_trait_analysis.jl:13-23): column maxima, sort, quantile on the GPU
+function get_thresholds(L_perms::Array{Float64, 2}, signif_level::Array{Float64, 1})
+    probs = 1.0 .- signif_level
+    thrs = similar(probs)
+    GC.@preserve L_perms probs thrs check(ccall((:blmm_get_thresholds, libblmm), Cint,
+        (Ptr{Cvoid}, Ptr{Float64}, Int64, Int64, Ptr{Float64}, Int64, Ptr{Float64}),
+        context(), L_perms, size(L_perms, 1), size(L_perms, 2), probs, length(probs), thrs))
+    return (probs = probs, thrs = thrs)
 end
 
 end # module

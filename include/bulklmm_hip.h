@@ -203,6 +203,31 @@ int blmm_lod_colmax(blmm_ctx* ctx, const double* L, int64_t p, int64_t m, double
 int blmm_lod_colmax_dev(blmm_ctx* ctx, const double* dL, int64_t p, int64_t m, int64_t ldL, double* dmax_out,
                         int64_t* dargmax_out);
 
+/* ---- -log10 p-values: lod2log10p.(L, chisq_df)  (src/util.jl:199-206; `output_pvals`, src/bulkscan.jl:154-157,
+ * src/scan.jl:353-355).  df = 1 through erfc / erfcx, general df through ln Q(df/2, .) in log space. */
+int blmm_lod2log10p(blmm_ctx* ctx, const double* L, int64_t p, int64_t m, int64_t chisq_df, double* P_out);
+int blmm_lod2log10p_dev(blmm_ctx* ctx, const double* dL, int64_t p, int64_t m, int64_t ldL, int64_t chisq_df, double* dP_out,
+                        int64_t ldP);
+/* ---- threshold filter: every (marker, trait) with LOD > thr as a sparse triplet (0-based int32 indices), the count on
+ * the device (README.md:354-359).  At most `cap` triplets are stored, *count is the total found; order unspecified. */
+int blmm_lod_threshold(blmm_ctx* ctx, const double* L, int64_t p, int64_t m, double thr, int64_t cap, int32_t* i_out,
+                       int32_t* j_out, double* lod_out, int64_t* count_out);
+int blmm_lod_threshold_dev(blmm_ctx* ctx, const double* dL, int64_t p, int64_t m, int64_t ldL, double thr, int64_t cap,
+                           int32_t* di_out, int32_t* dj_out, double* dlod_out, int64_t* dcount_out);
+/* ---- get_thresholds (src/analysis_helpers/single_trait_analysis.jl:13-23): quantiles (Julia's default, linear
+ * interpolation) at `probs` (HOST array, nprobs <= 64) of the per-permutation maxima; column maxima, sort and
+ * interpolation on the device, thrs_out (nprobs doubles) in HOST memory. */
+int blmm_get_thresholds(blmm_ctx* ctx, const double* Lperms, int64_t p, int64_t nperms, const double* probs, int64_t nprobs,
+                        double* thrs_out);
+int blmm_get_thresholds_dev(blmm_ctx* ctx, const double* dLperms, int64_t p, int64_t nperms, int64_t ld, const double* probs,
+                            int64_t nprobs, double* thrs_out);
+/* ---- the same consumers on the LOD matrix of the LAST host-pointer call of this context (blmm_bulkscan: L;
+ * blmm_scan_perms: L_perms), which is still resident in HBM: nothing is uploaded again. */
+int blmm_last_log10p(blmm_ctx* ctx, int64_t chisq_df, double* P_out);
+int blmm_last_lod_threshold(blmm_ctx* ctx, double thr, int64_t cap, int32_t* i_out, int32_t* j_out, double* lod_out,
+                            int64_t* count_out);
+int blmm_last_get_thresholds(blmm_ctx* ctx, const double* probs, int64_t nprobs, double* thrs_out);
+
 /* ---- lower-level seams (1:1 with the reference's internal functions; used by the parity tests) ---- */
 /* transform_rotation(y, [Z G], K)  (src/transform_helpers.jl:1-54): Y0 n x m, X0 n x (c+p) (first c
  * columns = rotated null covariates, intercept first when add_intercept), lambda n. */

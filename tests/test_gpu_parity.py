@@ -549,3 +549,59 @@ def test_multi_gpu_entry_point_with_shards_on_one_device(blmm, method, monkeypat
     got = blmm.bulkscan_multi(mc1, Y, G, K, Cov, method=method, h2_grid=grid, gather="allgather")
     assert np.array_equal(got["L"], one["L"]) and np.array_equal(got[hkey], one[hkey])
     mc1.close()
+
+
+@pytest.mark.parametrize("df", [1, 2, 3, 7])
+def test_lod2log10p_on_device(blmm, df):
+    """lod2log10p (src/util.jl:199-206) against the oracle (SciPy chi2.logsf, as Distributions' logccdf): everyday LODs,
+    LODs whose p-value underflows a double (the log-space forms must not), zero, negative rounding, NaN and Inf."""
+    rng = np.random.default_rng(df)
+    lod = np.concatenate([[0.0, 1e-300, 1e-12, 1e-4, 0.2, 0.4342944819, 1.0, 3.0, 50.0, 150.0, 305.0, 340.0, 2000.0, -1e-13],
+                          rng.uniform(0, 30, 500), np.exp(rng.uniform(np.log(1e-8), np.log(1e3), 500))])
+    got = blmm.lod2log10p(lod, df)
+    ref = O.lod2log10p(lod, df)
+    fin = np.isfinite(ref)             # SciPy's logsf underflows to -inf from LOD ~ 330 on; the device's log-space form does not
+    assert fin.sum() >= lod.size - 4
+    assert np.all(np.abs(got[fin] - ref[fin]) <= 1e-10 * np.abs(ref[fin]) + 1e-14), float(np.max(np.abs(got[fin] - ref[fin]) / np.maximum(np.abs(ref[fin]), 1e-300)))
+    assert np.isfinite(got).all()
+    if df == 1:   # beyond SciPy's range: the asymptotic series of erfc, ln erfc(x) = -x^2 - ln(x sqrt(pi)) + ln(1 - 1/(2x^2) + 3/(4x^4) - 15/(8x^6))
+        big = np.array([340.0, 2000.0, 1e5])
+        x2 = big * np.log(10.0)
+        asym = -(-x2 - 0.5 * np.log(x2 * np.pi) + np.log1p(-1 / (2 * x2) + 3 / (4 * x2 ** 2) - 15 / (8 * x2 ** 3))) / np.log(10.0)
+        assert np.allclose(blmm.lod2log10p(big, 1), asym, rtol=1e-11, atol=0)
+    else:         # monotone and close to LOD itself far out in the tail
+        tail = blmm.lod2log10p(np.array([330.0, 340.0, 2000.0]), df)
+        assert np.all(np.diff(tail) > 0) and 0.9 * 2000 < tail[2] < 2000.0
+    edge = blmm.lod2log10p(np.array([np.nan, np.inf]), df)
+    assert np.isnan(edge[0]) and np.isinf(edge[1]) and edge[1] > 0
+    m2 = blmm.lod2log10p(lod[:8].reshape(2, 4), df)
+    assert m2.shape == (2, 4) and np.allclose(m2, ref[:8].reshape(2, 4), rtol=1e-10, atol=1e-14)
+
+
+def test_output_pvals_threshold_filter_and_device_quantiles(blmm):
+    """`output_pvals` of bulkscan / scan (src/bulkscan.jl:154-157, src/scan.jl:353-355) computed from the L still resident
+    in HBM; the LOD > t filter as sparse triplets; get_thresholds with the sort and the quantile on the device."""
+    Y, G, K, _ = make_data(p=260, m=33, seed=5151)
+    r = blmm.bulkscan(Y, G, K, method="null-grid", output_pvals=True, chisq_df=2)
+    assert r["Chisq_df"] == 2 and r["log10Pvals_mat"].shape == r["L"].shape
+    ref = O.lod2log10p(r["L"], 2)
+    assert np.all(np.abs(r["log10Pvals_mat"] - ref) <= 1e-10 * np.abs(ref) + 1e-13)
+    pidx = O.make_perm_idx(79, 50, 2)
+    s = blmm.scan(Y[:, 0], G, K, permutation_test=True, nperms=50, perm_idx=pidx, output_pvals=True)
+    assert np.all(np.abs(s["log10pvals"] - O.lod2log10p(s["lod"], 1)) <= 1e-10 * s["log10pvals"] + 1e-13)
+    assert np.all(np.abs(s["log10Pvals_perms"] - O.lod2log10p(s["L_perms"], 1)) <= 1e-10 * s["log10Pvals_perms"] + 1e-13)
+    # threshold filter
+    Lm = r["L"].copy()
+    Lm[5, 7] = np.nan
+    ii, jj, ll = blmm.lod_threshold(Lm, 1.5)
+    want = np.argwhere(Lm.T > 1.5)                         # sorted by (trait, marker)
+    assert np.array_equal(jj, want[:, 0]) and np.array_equal(ii, want[:, 1]) and np.array_equal(ll, Lm[ii, jj])
+    ii2, jj2, ll2 = blmm.lod_threshold(Lm, 1.5, cap=3)     # the count comes back, the call retries with room for all
+    assert np.array_equal(ii2, ii) and np.array_equal(ll2, ll)
+    assert blmm.lod_threshold(Lm, 1e9)[0].size == 0
+    # permutation thresholds: quantiles of the per-permutation maxima (Julia's default = linear interpolation)
+    for nperms in (50, 1, 1000, 20000):
+        rng = np.random.default_rng(nperms)
+        Lp = rng.random((37, nperms)) * 6
+        thr = blmm.get_thresholds(Lp, [0.10, 0.05, 0.0, 1.0])
+        assert np.allclose(thr["thrs"], np.quantile(Lp.max(axis=0), [0.90, 0.95, 1.0, 0.0]), rtol=1e-14, atol=0)
