@@ -188,3 +188,79 @@ def test_golden_fixture_reproduces():
     assert np.abs(ex.L - z["exact_L"][:, :6]).max() <= 1e-9 and np.abs(ex.h2_null_list - z["exact_h2"][:6]).max() <= 1e-9
     gr = O.bulkscan_null_grid(z["Y"], z["G"], z["K"], list(z["grid"]))
     assert np.array_equal(gr.h2_null_list, z["grid_h2"]) and np.abs(gr.L - z["grid_L"]).max() <= 1e-10
+
+
+def dense_gls_lod(Y, G, K, h2, Covar=None):
+    """An oracle that shares NOTHING with the rotation / weights algebra of the reference or of the restatement above:
+    the model of README.md:18-33 written out densely.  V = h2 K + (1 - h2) I (the error covariance up to sigma^2),
+    V = C C' (Cholesky), whiten y and [Z g_i] by C^-1, ordinary least squares with and without the marker, and the
+    likelihood-ratio statistic LOD = (n/2) log10(rss0 / rss1)."""
+    n, m = Y.shape
+    Z = np.ones((n, 1)) if Covar is None else np.hstack([np.ones((n, 1)), Covar])
+    L = np.empty((G.shape[1], m))
+    for j in range(m):
+        V = h2[j] * K + (1.0 - h2[j]) * np.eye(n)
+        C = np.linalg.cholesky(V)
+        yt = np.linalg.solve(C, Y[:, j])
+        Zt = np.linalg.solve(C, Z)
+        Gt = np.linalg.solve(C, G)
+        Q, _ = np.linalg.qr(Zt)
+        r0 = yt - Q @ (Q.T @ yt)
+        rss0 = r0 @ r0
+        Gr = Gt - Q @ (Q.T @ Gt)                      # markers with the null covariates projected out
+        num = (Gr.T @ r0) ** 2 / np.sum(Gr * Gr, axis=0)
+        L[:, j] = 0.5 * n * np.log10(rss0 / (rss0 - num))
+    return L
+
+
+@pytest.mark.parametrize("ncov", [0, 2])
+def test_oracle_equals_dense_gls_model(ncov):
+    """Pins the restatement to the MODEL (y = X b + e, V(e) = s2g K + s2e I, README.md:18-33) independently of the
+    eigen-rotation and LiteQTL weights algebra that bulkscan_null and scan_null share: same h2 in, LODs equal to 1e-8."""
+    Y, G, K, Cov = make_data(p=60, m=7, seed=606 + ncov, ncov=ncov)
+    h2 = np.array([0.0, 0.05, 0.3, 0.5, 0.77, 0.9, 0.999])
+    ref = O.bulkscan_null(Y, G, K, Covar=Cov, h2_override=h2)
+    gls = dense_gls_lod(Y, G, K, h2, Cov)
+    assert np.abs(ref.L - gls).max() <= 1e-8 * max(1.0, np.abs(gls).max())
+    # and the null log-likelihood the h2 search maximises: ell(h2) of wls on rotated data == the dense Gaussian
+    # log-likelihood with sigma^2 profiled out (same h2 ranking => same optimiser target)
+    y0, X0, lam = O.transform_rotation(Y[:, :1], G, K) if Cov is None else O.transform_rotation(Y[:, :1], np.hstack([Cov, G]), K)
+    c = 1 + ncov
+    n = Y.shape[0]
+    Z = np.ones((n, 1)) if Cov is None else np.hstack([np.ones((n, 1)), Cov])
+    ells, dense = [], []
+    for h in (0.1, 0.4, 0.8):
+        ells.append(O.wls(y0, X0[:, :c], O.makeweights(h, lam), [0.0, 0.0]).ell)
+        # V(e)/s2e = delta K + I with delta = h/(1-h): the parametrisation makeweights uses (src/lmm.jl:15-33)
+        V = (h / (1 - h)) * K + np.eye(n)
+        C = np.linalg.cholesky(V)
+        yt, Zt = np.linalg.solve(C, Y[:, 0]), np.linalg.solve(C, Z)
+        b = np.linalg.lstsq(Zt, yt, rcond=None)[0]
+        rss = np.sum((yt - Zt @ b) ** 2)
+        s2 = rss / n
+        dense.append(-0.5 * (n * np.log(s2) + 2 * np.sum(np.log(np.diag(C))) + rss / s2))
+    assert np.allclose(ells, dense, rtol=1e-10, atol=1e-9)
+
+
+BXD_PHENO = "/root/reference/data/bxdData/spleen-pheno-nomissing.csv"
+BXD_GENO = "/root/reference/data/bxdData/spleen-bxd-genoprob.csv"
+
+
+@pytest.mark.skipif(not (os.path.exists(BXD_PHENO) and os.path.exists(BXD_GENO)),
+                    reason="the BXD spleen CSVs are listed in the reference's .MISSING_LARGE_BLOBS; this KAT activates when they appear")
+def test_bxd_readme_and_lmmlite_kats():
+    """End-to-end known answers of the reference, usable the moment its two data files exist: README.md:215
+    (sigma2_e, h2) = (0.0942525841453798, 0.850587848871709) for trait 1112 and the R/lmmlite LODs of trait 7919
+    (test/run-lmmlite_R/output/result.lmmlite_{ML,REML}.csv; tolerance of test/scan_test_lmmlite.jl:27-32).
+    Loader as test/generate_test_bxdData.jl:4-14."""
+    import csv
+    ph = np.genfromtxt(BXD_PHENO, delimiter=",", skip_header=1)[:, 1:-1]
+    ge = np.genfromtxt(BXD_GENO, delimiter=",", skip_header=1)[:, 0::2]
+    K = np.round(O.calcKinship(ge), 12)
+    r = O.scan(ph[:, 1111], ge, K)
+    assert abs(r["sigma2_e"] - 0.0942525841453798) <= 1e-8 and abs(r["h2_null"] - 0.850587848871709) <= 1e-6
+    for reml, name in ((False, "ML"), (True, "REML")):
+        rows = list(csv.reader(open(f"/root/reference/test/run-lmmlite_R/output/result.lmmlite_{name}.csv")))[2:]
+        lods = np.array([float(x[4]) for x in rows])
+        got = O.scan(ph[:, 7918], ge, K, reml=reml)["lod"]
+        assert np.max((got - lods) ** 2) <= 1e-9 and np.sum((got - lods) ** 2) <= np.sqrt(1e-9)
