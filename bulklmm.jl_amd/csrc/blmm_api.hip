@@ -163,7 +163,8 @@ int finish_status(blmm_ctx* ctx, blmm_status* st, Timer* tm) {
   st->lowrank_rank = h[8];
   st->lowrank_fallback = h[10];
   if (h[8] < 0) return fail(ctx, BLMM_ERR_HIP, "weight-basis kernel: a workgroup timed out at the grid barrier");
-  if (h[11] != 0) return fail(ctx, BLMM_ERR_HIP, "the eigensolver did not converge (dsyevd info = " + std::to_string((long long)h[11]) + ")");
+  if (h[11] != 0) return fail(ctx, BLMM_ERR_HIP, "the eigensolver did not converge (code " + std::to_string((long long)h[11]) +
+                              ": > 0 dsyevd info, -7 grid barrier of the tridiagonalisation timed out, -8 QL iteration limit)");
   if (ctx->hflag && *ctx->hflag) return check_sticky(ctx);
   { double r2; std::memcpy(&r2, &h[9], sizeof(double)); st->lowrank_resid = std::sqrt(r2 < 0 ? 0.0 : r2); }
   if (tm && tm->set && tm->set->n >= 2) {
@@ -270,19 +271,27 @@ int prepare(blmm_ctx* ctx, const blmm_opts* o, const double* dY, int64_t n, int6
   tm.mark();
   if ((rc = launch_design(ctx, dK, dCovar, (int)ncov, add_int, dweights, (int)n, ptr<double>(ctx->Ks), ptr<double>(ctx->Zs)))) return rc;
   const double* evec = ptr<double>(ctx->V);
-  // n <= 124: LDS Jacobi; beyond: rocSOLVER dsyevd (2.3 ms at n = 130, 8 ms at n = 333, 14 ms at n = 500; its first use
-  // in a process loads the library: seconds, minutes on a cold machine).  The single-workgroup global-memory Jacobi
-  // (37 ms at n = 130, 0.74 s at n = 333) is the fallback when librocsolver.so cannot be loaded, up to n = 2048.
-  // BLMM_EIGEN=rocsolver|jacobi overrides the choice (the GPU tests pin "jacobi" to stay independent of the library).
+  // n <= 124: LDS Jacobi.  Beyond: the own tridiagonalisation + divide-and-conquer solver (kernels_eig.hip) up to the n
+  // its LDS-resident reduction takes (~1700 on a full MI355X); past that rocSOLVER dsyevd when librocsolver.so loads,
+  // else the single-workgroup global-memory Jacobi (slow: 0.74 s at n = 333).  BLMM_EIGEN = dc | rocsolver | jacobi
+  // overrides the choice (A/B timing and tests; "dc" also for n <= 124).
   const char* eig_env = getenv("BLMM_EIGEN");
-  const bool want_rs = n > jacobi_lds_max_n();
-  P.big = want_rs;
-  bool used_rs = false;
-  if (want_rs && !(eig_env && std::strcmp(eig_env, "jacobi") == 0) &&
+  const bool big = n > jacobi_lds_max_n();
+  P.big = big;
+  bool used_rs = false, done = false;
+  const bool want_dc = eig_env ? std::strcmp(eig_env, "dc") == 0 : big;
+  const bool want_rs = eig_env ? std::strcmp(eig_env, "rocsolver") == 0 : false;
+  if (want_dc && n >= 3) {
+    rc = launch_eig_dc(ctx, ptr<double>(ctx->Ks), (int)n, ptr<double>(ctx->lraw), ptr<double>(ctx->V), P.stat);
+    if (rc == BLMM_OK) { done = true; P.big = true; }
+    else if (rc != BLMM_ERR_UNSUPPORTED) return rc;
+  }
+  if (!done && big && (want_rs || !eig_env || std::strcmp(eig_env, "dc") == 0) &&
       eigen_rocsolver(ctx, ptr<double>(ctx->Ks), (int)n, ptr<double>(ctx->lraw), P.stat) == BLMM_OK) {
     evec = ptr<double>(ctx->Ks);  // dsyevd leaves the eigenvectors in place of K
-    used_rs = true;
-  } else {
+    used_rs = true; done = true;
+  }
+  if (!done) {
     if (n > 2048) return fail(ctx, BLMM_ERR_UNSUPPORTED, "n > 2048 needs librocsolver.so for the eigen-decomposition");
     if ((rc = launch_jacobi(ctx, ptr<double>(ctx->Ks), ptr<double>(ctx->V), (int)n, ptr<double>(ctx->lraw), P.stat))) return rc;
   }
@@ -494,7 +503,7 @@ void blmm_destroy(blmm_ctx* ctx) {
                     &ctx->iyy, &ctx->h2, &ctx->h2idx, &ctx->sig2, &ctx->ell, &ctx->isx, &ctx->stat, &ctx->gridd, &ctx->misc,
                     &ctx->EllTab, &ctx->inY, &ctx->inG, &ctx->inK, &ctx->inCov, &ctx->inW, &ctx->outL, &ctx->outH2,
                     &ctx->tmpA, &ctx->tmpB, &ctx->tmpC, &ctx->perm, &ctx->r0, &ctx->altbuf, &ctx->logtab, &ctx->lraw,
-                    &ctx->wbQ, &ctx->wbW, &ctx->wbRk, &ctx->lrT, &ctx->lrC, &ctx->lrL, &ctx->lrFlag, &ctx->xf32, &ctx->pf32, &ctx->brSt, &ctx->brList};
+                    &ctx->wbQ, &ctx->wbW, &ctx->wbRk, &ctx->lrT, &ctx->lrC, &ctx->lrL, &ctx->lrFlag, &ctx->eigW, &ctx->xf32, &ctx->pf32, &ctx->brSt, &ctx->brList};
   for (DevBuf* b : bufs) if (b->p) hipFree(b->p);
   for (auto& s : ctx->evsets) for (auto& e : s.e) (void)hipEventDestroy(e);
   if (ctx->rb_handle && ctx->rb_destroy) ctx->rb_destroy(ctx->rb_handle);

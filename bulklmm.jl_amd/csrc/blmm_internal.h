@@ -38,7 +38,7 @@ struct blmm_ctx {
   std::string err;
   // grow-only workspace
   blmm::DevBuf Ks, V, lam, U, Zs, Z0, Rp, Yt, Xt, panels, iyy, h2, h2idx, sig2, ell, isx, stat, gridd, misc, EllTab,
-      inY, inG, inK, inCov, inW, outL, outH2, tmpA, tmpB, tmpC, perm, r0, altbuf, logtab, lraw, wbQ, wbW, wbRk, lrT, lrC, lrL, lrFlag, xf32, pf32, brSt, brList;
+      inY, inG, inK, inCov, inW, outL, outH2, tmpA, tmpB, tmpC, perm, r0, altbuf, logtab, lraw, wbQ, wbW, wbRk, lrT, lrC, lrL, lrFlag, eigW, xf32, pf32, brSt, brList;
   // event sets: one per timed call since the last blmm_read_timings (grown on demand, reused afterwards)
   struct EvSet { hipEvent_t e[8]; int n; };
   std::vector<EvSet> evsets;
@@ -60,6 +60,7 @@ struct blmm_ctx {
   volatile int64_t* hflag = nullptr;
   // the LOD matrix of the last host-pointer call, still resident in the workspace (kernels_post.hip: blmm_last_*)
   const double* last_L = nullptr; int64_t last_p = 0, last_m = 0; bool last_f32 = false;
+  int eig_plan_n = -1;                 // n whose merge tree sits in eigW (kernels_eig.hip)
   blmm::HostStage* hstage = nullptr;   // pinned staging ring + copy threads of the host-pointer entry points (host_path.hip)
 };
 
@@ -93,6 +94,9 @@ int launch_design(blmm_ctx* ctx, const double* dK, const double* dCovar, int nco
 // One-sided Jacobi eigen-decomposition of the symmetric n x n matrix in A (destroyed); V gets the eigenvectors
 // (unsorted), then post_eigen sorts/derives everything the rotation needs.
 int launch_jacobi(blmm_ctx* ctx, double* A, double* V, int n, double* lraw, int64_t* stat);
+// kernels_eig.hip: tridiagonalisation + divide and conquer for n beyond the LDS Jacobi; A is not modified
+int launch_eig_dc(blmm_ctx* ctx, const double* A, int n, double* lraw, double* evec, int64_t* stat);
+int eig_dc_max_n(const blmm_ctx* ctx);
 int jacobi_lds_max_n();
 // lambda (ascending, or |lambda| descending for svd), U sorted, Z0 = U' Zs, Rp = (centered ? Q U' Wd : U' Wd)'
 int launch_post_eigen(blmm_ctx* ctx, const double* lraw, const double* V, const double* Zs, const double* dweights, int n,

@@ -1,0 +1,746 @@
+// kernels_eig.hip -- symmetric eigensolver for the kinship matrix beyond the LDS Jacobi's range (n > 124), replacing
+// LAPACK `eigen(K)` of transform_rotation (src/transform_helpers.jl:21-34) without leaving the GPU and without a vendor
+// library on the hot path (rocSOLVER dsyevd took 13 / 23 ms at n = 500 / 1000, 70-80 % of a shard's step).
+//
+//   1. k_sytrd          Householder tridiagonalisation K = H T H'.  The matrix lives in the LDS of G workgroups (rows
+//                       dealt cyclically, full symmetric storage), so a step costs ONE exchange: every workgroup
+//                       publishes its rows of p = tau A v, the owner of row k+1 publishes that row, one grid barrier,
+//                       then every workgroup forms w, updates its rows and derives the next column on its own.
+//   2. k_tql_leaves     implicit QL on leaf blocks (<= 32) of T, one wave per leaf.
+//   3. k_dc_*           Cuppen's divide and conquer up the tree: deflation (as LAPACK dlaed2), secular roots relative to
+//                       the nearer pole, Gu-Eisenstat z-hat for orthogonal vectors, the update Q <- Q W as an f64-MFMA GEMM.
+//   4. k_backtransform  U = H Z, reflectors applied to column slabs held in registers.
+//
+// tools/dc_prototype.py is the NumPy model of exactly this data flow (same conventions, same tolerances).
+// Eigenvalues come out ascending; eigenvector i is evec[i*n .. i*n+n) (what k_post_eigen expects).
+#include "blmm_internal.h"
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+
+namespace blmm {
+
+#define KCHECK()                                                                                      \
+  do {                                                                                                \
+    hipError_t e__ = hipGetLastError();                                                               \
+    if (e__ != hipSuccess) return fail(ctx, BLMM_ERR_HIP, std::string("kernel launch: ") + hipGetErrorString(e__)); \
+  } while (0)
+
+namespace {
+
+constexpr double EPS = 2.220446049250313e-16;
+constexpr int LEAF = 32;
+
+__device__ __forceinline__ double wsum(double x) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o, 64);
+  return x;
+}
+__device__ __forceinline__ double wmax(double x) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) x = fmax(x, __shfl_xor(x, o, 64));
+  return x;
+}
+__device__ __forceinline__ double wprod(double x) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) x *= __shfl_xor(x, o, 64);
+  return x;
+}
+// sum over the workgroup; every thread gets the result.  red: >= 16 doubles of LDS.  Two barriers.
+__device__ __forceinline__ double block_sum(double x, double* red) {
+  x = wsum(x);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+  __syncthreads();
+  if (lane == 0) red[wave] = x;
+  __syncthreads();
+  double s = 0.0;
+  for (int w = 0; w < nw; ++w) s += red[w];
+  return s;
+}
+__device__ __forceinline__ double block_max(double x, double* red) {
+  x = wmax(x);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+  __syncthreads();
+  if (lane == 0) red[wave] = x;
+  __syncthreads();
+  double s = red[0];
+  for (int w = 1; w < nw; ++w) s = fmax(s, red[w]);
+  return s;
+}
+
+// agent-scope (sc1) 8-byte accesses for the exchange of k_sytrd (MI355X_MICROARCH.md, inter-workgroup visibility:
+// every handed-off byte is stored and loaded with sc1, the storing waves drain before ONE lane signals)
+__device__ __forceinline__ void st_sc1(double* p, double v) {
+  __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED,
+                     __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ double ld_sc1(const double* p) {
+  return __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<const unsigned long long*>(p), __ATOMIC_RELAXED,
+                                                           __HIP_MEMORY_SCOPE_AGENT));
+}
+
+struct SytrdEx {          // global exchange area of k_sytrd
+  double* pbuf;           // [2][n]   p = tau A v, by global row
+  double* rowbuf;         // [2][n]   row k+1 of the trailing matrix before the step's update
+  unsigned int* cnt;      // arrival counter (monotonic; zeroed by the launcher)
+  int* abort;             // set when a workgroup gave up waiting
+};
+
+// ---------------------------------------------------------------------------------------------------------------------
+// 1. tridiagonalisation.  Workgroup g of G owns the rows i = g, g + G, ... (local row li = i / G), all n columns of
+// each, in LDS.  Outputs: d (n), e (n - 1), tau (n - 2), V[k*n + j] = v_k[j] for j > k (v_k[k+1] = 1).
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(512) k_sytrd(const double* __restrict__ A, int n, int nloc_max, double* __restrict__ d,
+                                                double* __restrict__ e, double* __restrict__ tau, double* __restrict__ V,
+                                                SytrdEx ex, int64_t* stat) {
+  extern __shared__ __attribute__((aligned(16))) double sh[];
+  const int G = gridDim.x, g = blockIdx.x, t = threadIdx.x, NT = blockDim.x;
+  const int lane = t & 63, wave = t >> 6, nwave = NT >> 6;
+  double* sv = sh;                  // n : current column x, then the reflector v
+  double* sw = sv + n;              // n
+  double* sp = sw + n;              // n
+  double* srow = sp + n;            // n
+  double* red = srow + n;           // 16
+  double* Al = red + 16;            // nloc_max x n
+  __shared__ int s_ok;
+  const int nloc = (n - g + G - 1) / G;
+  for (int li = 0; li < nloc; ++li) {
+    const int i = g + li * G;
+    for (int j = t; j < n; j += NT) Al[(size_t)li * n + j] = A[(size_t)j * n + i];   // symmetric: row i = column i
+  }
+  for (int j = t; j < n; j += NT) sv[j] = (j >= 1) ? A[j] : 0.0;                        // column 0, rows 1..n-1
+  double akk = A[0];
+  __syncthreads();
+  bool aborted = false;
+  for (int k = 0; k + 2 < n; ++k) {
+    const int par = k & 1;
+    // (1) Householder vector of x = sv[k+1 .. n)
+    double part = 0.0;
+    for (int j = k + 2 + t; j < n; j += NT) part = fma(sv[j], sv[j], part);
+    const double xn2 = block_sum(part, red);
+    const double alpha = sv[k + 1];
+    double beta, tk;
+    if (xn2 == 0.0) {
+      beta = alpha; tk = 0.0;
+    } else {
+      beta = -copysign(sqrt(fma(alpha, alpha, xn2)), alpha);
+      tk = (beta - alpha) / beta;
+      const double sc = 1.0 / (alpha - beta);
+      for (int j = k + 2 + t; j < n; j += NT) sv[j] *= sc;
+    }
+    __syncthreads();
+    if (t == 0) sv[k + 1] = 1.0;
+    __syncthreads();
+    if (g == k % G) {
+      for (int j = k + 1 + t; j < n; j += NT) V[(size_t)k * n + j] = sv[j];
+      if (t == 0) { d[k] = akk; e[k] = beta; tau[k] = tk; }
+    }
+    // (2) p_i = tau * sum_j A[i][j] v[j] for the owned rows i > k, one wave per row
+    const int li0 = (k + 1 > g) ? (k + 1 - g + G - 1) / G : 0;    // first local row with global index > k
+    for (int li = li0 + wave; li < nloc; li += nwave) {
+      const int i = g + li * G;
+      const double* row = Al + (size_t)li * n;
+      double acc = 0.0;
+      for (int j = k + 1 + lane; j < n; j += 64) acc = fma(row[j], sv[j], acc);
+      acc = wsum(acc) * tk;
+      if (lane == 0) { if (G > 1) st_sc1(ex.pbuf + (size_t)par * n + i, acc); else sp[i] = acc; }
+    }
+    if (G > 1) {
+      if (g == (k + 1) % G) {
+        const double* row = Al + (size_t)((k + 1) / G) * n;
+        for (int j = k + 1 + t; j < n; j += NT) st_sc1(ex.rowbuf + (size_t)par * n + j, row[j]);
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (t == 0) {
+        __hip_atomic_fetch_add(ex.cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned int target = (unsigned int)G * (unsigned int)(k + 1);
+        int ok = 0;
+        for (int spin = 0; spin < (1 << 24); ++spin) {
+          if (__hip_atomic_load(ex.cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= target) { ok = 1; break; }
+          if (__hip_atomic_load(ex.abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
+          __builtin_amdgcn_s_sleep(1);
+        }
+        if (!ok) __hip_atomic_store(ex.abort, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_ok = ok;
+      }
+      __syncthreads();
+      if (!s_ok) { aborted = true; break; }
+      for (int j = k + 1 + t; j < n; j += NT) {
+        sp[j] = ld_sc1(ex.pbuf + (size_t)par * n + j);
+        srow[j] = ld_sc1(ex.rowbuf + (size_t)par * n + j);
+      }
+    } else {
+      __syncthreads();
+      const double* row = Al + (size_t)(k + 1) * n;
+      for (int j = k + 1 + t; j < n; j += NT) srow[j] = row[j];
+    }
+    __syncthreads();
+    // (5) w = p - (tau/2)(p'v) v
+    part = 0.0;
+    for (int j = k + 1 + t; j < n; j += NT) part = fma(sp[j], sv[j], part);
+    const double pv = block_sum(part, red);
+    const double cw = 0.5 * tk * pv;
+    for (int j = k + 1 + t; j < n; j += NT) sw[j] = fma(-cw, sv[j], sp[j]);
+    __syncthreads();
+    // (6) rank-2 update of the owned rows
+    for (int li = li0 + wave; li < nloc; li += nwave) {
+      const int i = g + li * G;
+      double* row = Al + (size_t)li * n;
+      const double vi = sv[i], wi = sw[i];
+      for (int j = k + 1 + lane; j < n; j += 64) row[j] = fma(-vi, sw[j], fma(-wi, sv[j], row[j]));
+    }
+    // (7) the next column from the published (pre-update) row k+1:  x[j] = row[j] - v[k+1] w[j] - w[k+1] v[j],  v[k+1] = 1
+    const double wk1 = sw[k + 1];
+    akk = srow[k + 1] - 2.0 * wk1;
+    __syncthreads();
+    for (int j = k + 2 + t; j < n; j += NT) sv[j] = srow[j] - sw[j] - wk1 * sv[j];
+    __syncthreads();
+  }
+  if (aborted) {
+    if (g == 0 && t == 0) stat[11] = -7;   // reported as an eigensolver failure (blmm_api.hip: finish_status / k_sticky)
+    return;
+  }
+  if (g == 0 && t == 0) { d[n - 2] = akk; e[n - 2] = sv[n - 1]; }
+  if (g == (n - 1) % G && t == 0) d[n - 1] = Al[(size_t)((n - 1) / G) * n + (n - 1)];
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// 2. leaves: implicit QL with eigenvectors (EISPACK tql2) on T[lo:hi, lo:hi] with the rank-one corrections of the splits
+// taken off its two end diagonals; one wave per leaf, lane r owns row r of Z.
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(64) k_tql_leaves(const double* __restrict__ d, const double* __restrict__ e, int n,
+                                                   const int* __restrict__ bounds, double* __restrict__ lam,
+                                                   double* __restrict__ Q, int64_t* stat) {
+  __shared__ double sd[LEAF + 1], se[LEAF + 1], Z[LEAF][LEAF + 1];
+  __shared__ int sidx[LEAF];
+  const int lo = bounds[blockIdx.x], hi = bounds[blockIdx.x + 1], N = hi - lo, r = threadIdx.x;
+  if (r < N) {
+    double dv = d[lo + r];
+    if (r == 0 && lo > 0) dv -= fabs(e[lo - 1]);
+    if (r == N - 1 && hi < n) dv -= fabs(e[hi - 1]);
+    sd[r] = dv;
+    se[r] = (r < N - 1) ? e[lo + r] : 0.0;
+    for (int c = 0; c < N; ++c) Z[r][c] = (r == c) ? 1.0 : 0.0;
+  }
+  __syncthreads();
+  // the QL iteration is the same scalar sequence in every lane (d, e in LDS); only the row of Z differs
+  bool failed = false;
+  for (int l = 0; l < N && !failed; ++l) {
+    int iter = 0;
+    for (;;) {
+      int m = l;
+      for (; m < N - 1; ++m) {
+        const double dd = fabs(sd[m]) + fabs(sd[m + 1]);
+        if (fabs(se[m]) <= EPS * dd) break;
+      }
+      if (m == l) break;
+      if (++iter > 80) { failed = true; break; }
+      double gg = (sd[l + 1] - sd[l]) / (2.0 * se[l]);
+      double rr = hypot(gg, 1.0);
+      gg = sd[m] - sd[l] + se[l] / (gg + copysign(rr, gg));
+      double s = 1.0, c = 1.0, p = 0.0;
+      int i = m - 1;
+      bool under = false;
+      for (; i >= l; --i) {
+        const double f = s * se[i], b = c * se[i];
+        rr = hypot(f, gg);
+        __syncthreads();
+        if (r == 0) se[i + 1] = rr;
+        if (rr == 0.0) {
+          if (r == 0) { sd[i + 1] -= p; se[m] = 0.0; }
+          under = true;
+          __syncthreads();
+          break;
+        }
+        s = f / rr; c = gg / rr;
+        const double di1 = sd[i + 1], di = sd[i];
+        gg = di1 - p;
+        rr = (di - gg) * s + 2.0 * c * b;
+        p = s * rr;
+        __syncthreads();
+        if (r == 0) sd[i + 1] = gg + p;
+        gg = c * rr - b;
+        if (r < N) {
+          const double f2 = Z[r][i + 1], z0 = Z[r][i];
+          Z[r][i + 1] = s * z0 + c * f2;
+          Z[r][i] = c * z0 - s * f2;
+        }
+        __syncthreads();
+      }
+      if (under) continue;
+      __syncthreads();
+      if (r == 0) { sd[l] -= p; se[l] = gg; se[m] = 0.0; }
+      __syncthreads();
+    }
+  }
+  __syncthreads();
+  if (failed && r == 0) stat[11] = -8;
+  // ascending order (stable rank)
+  if (r < N) {
+    int rank = 0;
+    const double v = sd[r];
+    for (int j = 0; j < N; ++j) rank += (sd[j] < v) || (sd[j] == v && j < r);
+    sidx[rank] = r;
+  }
+  __syncthreads();
+  if (r < N) {
+    lam[lo + r] = sd[sidx[r]];
+    for (int c = 0; c < N; ++c) Q[(size_t)(lo + c) * n + lo + r] = Z[r][sidx[c]];
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// 3. divide and conquer.  Node (lo, mid, hi) joins the solved halves [lo, mid) and [mid, hi):
+//      T_node = diag(T1', T2') + |beta| u u',  beta = e[mid-1],  u = e_(mid-1) + sign(beta) e_mid.
+// Per-node scratch lives at offset lo of length-n arrays; K x K matrices on the node's diagonal block of n x n buffers.
+// ---------------------------------------------------------------------------------------------------------------------
+struct DcWs {
+  int n;
+  const double* e;          // off-diagonal of T
+  const double* lamIn; double* lamOut;
+  double* Qin; double* Qout;            // n x n, eigenvector c of a node = column c: Q[c*n + r]
+  double* Dm; double* Wt;               // n x n
+  double *dl, *zl, *zh, *defld, *lamnew, *rotc, *rots, *rho;
+  int *colidx, *deflcol, *rota, *rotb, *posn, *posd, *info;   // info[4*node + {0: K, 1: ndefl, 2: nrot}]
+  const int* nodes;         // [3*node + {lo, mid, hi}]
+};
+
+__global__ void __launch_bounds__(1024) k_dc_deflate(DcWs w) {
+  extern __shared__ __attribute__((aligned(16))) double sh[];
+  const int node = blockIdx.x, lo = w.nodes[3 * node], mid = w.nodes[3 * node + 1], hi = w.nodes[3 * node + 2];
+  const int N = hi - lo, n = w.n, t = threadIdx.x, NT = blockDim.x;
+  double* sd = sh;            // N
+  double* sz = sd + N;        // N
+  double* red = sz + N;       // 16
+  int* ord = reinterpret_cast<int*>(red + 16);   // N
+  const double beta = w.e[mid - 1];
+  const double sgn = (beta < 0.0) ? -1.0 : 1.0;
+  const double rho = 2.0 * fabs(beta);
+  for (int j = t; j < N; j += NT) {
+    sd[j] = w.lamIn[lo + j];
+    const int col = lo + j;
+    const double zr = (col < mid) ? w.Qin[(size_t)col * n + mid - 1] : sgn * w.Qin[(size_t)col * n + mid];
+    sz[j] = zr * 0.7071067811865476;
+  }
+  __syncthreads();
+  double dm = 0.0, zm = 0.0;
+  for (int j = t; j < N; j += NT) { dm = fmax(dm, fabs(sd[j])); zm = fmax(zm, fabs(sz[j])); }
+  dm = block_max(dm, red);
+  zm = block_max(zm, red);
+  const double tol = 8.0 * EPS * fmax(dm, zm);
+  for (int j = t; j < N; j += NT) {
+    const double v = sd[j];
+    int rank = 0;
+    for (int i = 0; i < N; ++i) rank += (sd[i] < v) || (sd[i] == v && i < j);
+    ord[rank] = j;
+  }
+  __syncthreads();
+  if (t == 0) {
+    int K = 0, nd = 0, nr = 0;
+    if (rho * zm <= tol) {
+      for (int s = 0; s < N; ++s) { const int j = ord[s]; w.defld[lo + nd] = sd[j]; w.deflcol[lo + nd] = lo + j; ++nd; }
+    } else {
+      int pj = -1;
+      for (int s = 0; s < N; ++s) {
+        const int nj = ord[s];
+        if (rho * fabs(sz[nj]) <= tol) { w.defld[lo + nd] = sd[nj]; w.deflcol[lo + nd] = lo + nj; ++nd; continue; }
+        if (pj < 0) { pj = nj; continue; }
+        double sn = sz[pj], cs = sz[nj];
+        const double tau = hypot(cs, sn), tt = sd[nj] - sd[pj];
+        cs /= tau; sn = -sn / tau;
+        if (fabs(tt * cs * sn) <= tol) {
+          sz[nj] = tau; sz[pj] = 0.0;
+          w.rota[lo + nr] = lo + pj; w.rotb[lo + nr] = lo + nj; w.rotc[lo + nr] = cs; w.rots[lo + nr] = sn; ++nr;
+          const double dp = sd[pj], dn = sd[nj];
+          sd[pj] = dp * cs * cs + dn * sn * sn;
+          sd[nj] = dp * sn * sn + dn * cs * cs;
+          w.defld[lo + nd] = sd[pj]; w.deflcol[lo + nd] = lo + pj; ++nd;
+          pj = nj;
+        } else {
+          w.dl[lo + K] = sd[pj]; w.zl[lo + K] = sz[pj]; w.colidx[lo + K] = lo + pj; ++K;
+          pj = nj;
+        }
+      }
+      if (pj >= 0) { w.dl[lo + K] = sd[pj]; w.zl[lo + K] = sz[pj]; w.colidx[lo + K] = lo + pj; ++K; }
+    }
+    w.info[4 * node] = K; w.info[4 * node + 1] = nd; w.info[4 * node + 2] = nr;
+    w.rho[node] = rho;
+  }
+}
+
+// Givens rotations of the close-pole deflations, applied to the node's rows of Qin in list order (rows are independent)
+__global__ void __launch_bounds__(256) k_dc_rot(DcWs w) {
+  const int node = blockIdx.x, lo = w.nodes[3 * node], hi = w.nodes[3 * node + 2], n = w.n;
+  const int nr = w.info[4 * node + 2];
+  const int r = lo + blockIdx.y * 256 + threadIdx.x;
+  if (nr == 0 || r >= hi) return;
+  for (int q = 0; q < nr; ++q) {
+    const int a = w.rota[lo + q], b = w.rotb[lo + q];
+    const double c = w.rotc[lo + q], s = w.rots[lo + q];
+    const double x = w.Qin[(size_t)a * n + r], y = w.Qin[(size_t)b * n + r];
+    w.Qin[(size_t)a * n + r] = c * x + s * y;
+    w.Qin[(size_t)b * n + r] = c * y - s * x;
+  }
+}
+
+// secular equation 1 + rho sum_j z_j^2 / (d_j - lam) = 0, root i in (d_i, d_(i+1)), one wave per root.  The root is
+// found relative to the nearer pole (the differences d_j - lam keep full relative accuracy), Newton steps safeguarded by
+// the bracket, bisection otherwise (the function is monotone between two poles: the bracket always holds the root).
+__global__ void __launch_bounds__(256) k_dc_secular(DcWs w) {
+  extern __shared__ __attribute__((aligned(16))) double sh[];
+  const int node = blockIdx.x, lo = w.nodes[3 * node], n = w.n;
+  const int K = w.info[4 * node];
+  if ((int)blockIdx.y * 4 >= K) return;
+  double* dl = sh;
+  double* z2 = sh + K;
+  for (int j = threadIdx.x; j < K; j += blockDim.x) { dl[j] = w.dl[lo + j]; const double z = w.zl[lo + j]; z2[j] = z * z; }
+  __syncthreads();
+  const int lane = threadIdx.x & 63, i = blockIdx.y * 4 + (threadIdx.x >> 6);
+  if (i >= K) return;
+  const double rho = w.rho[node];
+  int org;
+  double a, b;
+  if (i < K - 1) {
+    const double left = dl[i], mid = 0.5 * (dl[i + 1] - left);
+    double f = 0.0;
+    for (int j = lane; j < K; j += 64) f += z2[j] / ((dl[j] - left) - mid);
+    f = 1.0 + rho * wsum(f);
+    if (f > 0.0) { org = i; a = 0.0; b = mid; } else { org = i + 1; a = -mid; b = 0.0; }
+    if (f == 0.0) { org = i; a = mid; b = mid; }
+  } else {
+    double s = 0.0;
+    for (int j = lane; j < K; j += 64) s += z2[j];
+    org = K - 1; a = 0.0; b = rho * wsum(s);
+  }
+  const double dorg = dl[org];
+  double tcur = 0.5 * (a + b);
+  for (int it = 0; it < 200 && a < b; ++it) {
+    double f = 0.0, fp = 0.0;
+    for (int j = lane; j < K; j += 64) {
+      const double q = 1.0 / ((dl[j] - dorg) - tcur);
+      const double zq = z2[j] * q;
+      f += zq; fp = fma(zq, q, fp);
+    }
+    f = 1.0 + rho * wsum(f);
+    fp = rho * wsum(fp);
+    if (f == 0.0) break;
+    if (f > 0.0) b = tcur; else a = tcur;
+    double tn = tcur - f / fp;
+    if (!(a < tn && tn < b) || it > 12) tn = 0.5 * (a + b);
+    if (tn == tcur || b - a <= 2.0 * EPS * fmax(fabs(a), fabs(b))) { tcur = tn; break; }
+    tcur = tn;
+  }
+  if (lane == 0) w.lamnew[lo + i] = dorg + tcur;
+  double* drow = w.Dm + (size_t)(lo + i) * n + lo;
+  for (int j = lane; j < K; j += 64) drow[j] = (dl[j] - dorg) - tcur;
+}
+
+// Gu-Eisenstat: the z-hat for which the computed roots are the exact eigenvalues,
+//   zh_j^2 = | prod_i (d_j - lam_i) / prod_(i != j) (d_j - d_i) |,  sign from z_j.   One wave per pole j.
+__global__ void __launch_bounds__(256) k_dc_zhat(DcWs w) {
+  const int node = blockIdx.x, lo = w.nodes[3 * node], n = w.n;
+  const int K = w.info[4 * node];
+  const int lane = threadIdx.x & 63, j = blockIdx.y * 4 + (threadIdx.x >> 6);
+  if (j >= K) return;
+  const double dj = w.dl[lo + j];
+  double prod = 1.0;
+  for (int i = lane; i < K; i += 64) {
+    const double dij = w.Dm[(size_t)(lo + i) * n + lo + j];
+    prod *= (i == j) ? dij : dij / (dj - w.dl[lo + i]);
+  }
+  prod = wprod(prod);
+  if (lane == 0) w.zh[lo + j] = copysign(sqrt(fabs(prod)), w.zl[lo + j]);
+}
+
+// eigenvector of root i in the basis of the kept columns: Wt[i][j] = zh_j / (d_j - lam_i), normalised.  One wave per root.
+__global__ void __launch_bounds__(256) k_dc_wt(DcWs w) {
+  const int node = blockIdx.x, lo = w.nodes[3 * node], n = w.n;
+  const int K = w.info[4 * node];
+  const int lane = threadIdx.x & 63, i = blockIdx.y * 4 + (threadIdx.x >> 6);
+  if (i >= K) return;
+  const double* drow = w.Dm + (size_t)(lo + i) * n + lo;
+  double* wrow = w.Wt + (size_t)(lo + i) * n + lo;
+  double s = 0.0;
+  for (int j = lane; j < K; j += 64) { const double v = w.zh[lo + j] / drow[j]; wrow[j] = v; s = fma(v, v, s); }
+  s = 1.0 / sqrt(wsum(s));
+  for (int j = lane; j < K; j += 64) wrow[j] *= s;
+}
+
+// positions of the node's N eigenvalues (K new roots, then the deflated ones) in ascending order; sorted values out
+__global__ void __launch_bounds__(1024) k_dc_finalize(DcWs w) {
+  extern __shared__ __attribute__((aligned(16))) double sh[];
+  const int node = blockIdx.x, lo = w.nodes[3 * node], hi = w.nodes[3 * node + 2], N = hi - lo;
+  const int K = w.info[4 * node], t = threadIdx.x, NT = blockDim.x;
+  double* val = sh;
+  for (int j = t; j < N; j += NT) val[j] = (j < K) ? w.lamnew[lo + j] : w.defld[lo + j - K];
+  __syncthreads();
+  for (int j = t; j < N; j += NT) {
+    const double v = val[j];
+    int rank = 0;
+    for (int i = 0; i < N; ++i) rank += (val[i] < v) || (val[i] == v && i < j);
+    if (j < K) w.posn[lo + j] = lo + rank; else w.posd[lo + j - K] = lo + rank;
+    w.lamOut[lo + rank] = v;
+  }
+}
+
+__global__ void __launch_bounds__(256) k_dc_copy(DcWs w) {
+  const int node = blockIdx.x, lo = w.nodes[3 * node], hi = w.nodes[3 * node + 2], n = w.n;
+  const int nd = w.info[4 * node + 1];
+  const int r = lo + blockIdx.y * 256 + threadIdx.x;
+  if (r >= hi) return;
+  for (int q = blockIdx.z; q < nd; q += gridDim.z)
+    w.Qout[(size_t)w.posd[lo + q] * n + r] = w.Qin[(size_t)w.deflcol[lo + q] * n + r];
+}
+
+// Qout[:, posn[i]] = sum_j Wt[i][j] Qin[:, colidx[j]]  on the f64 matrix cores: D (16 roots x 16 rows of Q) per block,
+// A = Wt (root i, k = j), B = Qin' (k = j, row r).  Inside a trip of 16 k the lane group g = lane >> 4 takes
+// k = k0 + 4 g + s at MFMA step s (any fixed assignment is a valid order of the contraction): a lane reads 4 consecutive
+// Wt entries, and 16 lanes read 16 consecutive rows of one column of Qin.
+typedef double d4v __attribute__((ext_vector_type(4)));
+template <int MB, int NB>
+__global__ void __launch_bounds__(256) k_dc_gemm(DcWs w, int tiles_r) {
+  const int node = blockIdx.x, lo = w.nodes[3 * node], hi = w.nodes[3 * node + 2], n = w.n;
+  const int K = w.info[4 * node];
+  const int tile_i = blockIdx.y / tiles_r, tile_r = blockIdx.y % tiles_r;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int i0 = tile_i * (32 * MB) + (wave >> 1) * (16 * MB);     // roots
+  const int r0 = lo + tile_r * (32 * NB) + (wave & 1) * (16 * NB); // rows of Q
+  if (tile_i * (32 * MB) >= K || lo + tile_r * (32 * NB) >= hi) return;
+  const int c16 = lane & 15, g = lane >> 4;
+  d4v acc[MB][NB];
+#pragma unroll
+  for (int a = 0; a < MB; ++a)
+#pragma unroll
+    for (int b = 0; b < NB; ++b) acc[a][b] = (d4v){0, 0, 0, 0};
+  for (int k0 = 0; k0 < K; k0 += 16) {
+    double av[MB][4], bv[NB][4];
+    int col[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) { const int k = k0 + 4 * g + s; col[s] = (k < K) ? w.colidx[lo + k] : -1; }
+#pragma unroll
+    for (int a = 0; a < MB; ++a) {
+      const int i = i0 + 16 * a + c16;
+      const double* wr = w.Wt + (size_t)(lo + (i < K ? i : 0)) * n + lo;
+#pragma unroll
+      for (int s = 0; s < 4; ++s) { const int k = k0 + 4 * g + s; av[a][s] = (i < K && k < K) ? wr[k] : 0.0; }
+    }
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+      const int r = r0 + 16 * b + c16;
+#pragma unroll
+      for (int s = 0; s < 4; ++s) bv[b][s] = (col[s] >= 0 && r < hi) ? w.Qin[(size_t)col[s] * n + r] : 0.0;
+    }
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+      for (int a = 0; a < MB; ++a)
+#pragma unroll
+        for (int b = 0; b < NB; ++b) acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[a][s], bv[b][s], acc[a][b], 0, 0, 0);
+  }
+#pragma unroll
+  for (int a = 0; a < MB; ++a)
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) {
+      const int i = i0 + 16 * a + g + 4 * reg;
+      if (i >= K) continue;
+      double* dst = w.Qout + (size_t)w.posn[lo + i] * n;
+#pragma unroll
+      for (int b = 0; b < NB; ++b) {
+        const int r = r0 + 16 * b + c16;
+        if (r < hi) dst[r] = acc[a][b][reg];
+      }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// 4. back-transformation U = H_0 H_1 ... H_(n-3) Z: reflectors applied in reverse order, each wave owns CPW columns of Z
+// in registers (rows lane, lane + 64, ...); the reflector of a step is staged in LDS for the workgroup.
+// ---------------------------------------------------------------------------------------------------------------------
+template <int NR, int CPW>
+__global__ void __launch_bounds__(512) k_backtransform(const double* __restrict__ V, const double* __restrict__ tau, int n,
+                                                       double* __restrict__ Z) {
+  extern __shared__ __attribute__((aligned(16))) double sh[];   // 2 x n : double-buffered reflector
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwave = blockDim.x >> 6;
+  const int c0 = (blockIdx.x * nwave + wave) * CPW;
+  double z[CPW][NR];
+#pragma unroll
+  for (int c = 0; c < CPW; ++c)
+#pragma unroll
+    for (int q = 0; q < NR; ++q) {
+      const int r = lane + 64 * q;
+      z[c][q] = (c0 + c < n && r < n) ? Z[(size_t)(c0 + c) * n + r] : 0.0;
+    }
+  const int nref = n - 2;
+  if (nref > 0) {
+    const int k = nref - 1;
+    for (int j = k + 1 + threadIdx.x; j < n; j += blockDim.x) sh[j] = V[(size_t)k * n + j];
+  }
+  __syncthreads();
+  for (int k = nref - 1; k >= 0; --k) {
+    const double* v = sh + (size_t)((nref - 1 - k) & 1) * n;
+    double* vn = sh + (size_t)((nref - k) & 1) * n;
+    if (k > 0) for (int j = k + threadIdx.x; j < n; j += blockDim.x) vn[j] = V[(size_t)(k - 1) * n + j];   // next reflector
+    const double tk = tau[k];
+    double vr[NR];
+#pragma unroll
+    for (int q = 0; q < NR; ++q) { const int r = lane + 64 * q; vr[q] = (r > k && r < n) ? v[r] : 0.0; }
+#pragma unroll
+    for (int c = 0; c < CPW; ++c) {
+      double dot = 0.0;
+#pragma unroll
+      for (int q = 0; q < NR; ++q) dot = fma(vr[q], z[c][q], dot);
+      dot = wsum(dot) * tk;
+#pragma unroll
+      for (int q = 0; q < NR; ++q) z[c][q] = fma(-dot, vr[q], z[c][q]);
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int c = 0; c < CPW; ++c)
+#pragma unroll
+    for (int q = 0; q < NR; ++q) {
+      const int r = lane + 64 * q;
+      if (c0 + c < n && r < n) Z[(size_t)(c0 + c) * n + r] = z[c][q];
+    }
+}
+
+}  // namespace
+
+// Largest n the solver takes on this device (LDS budget of k_sytrd with one workgroup per CU).
+int eig_dc_max_n(const blmm_ctx* ctx) {
+  const int cus = ctx->num_cus > 0 ? ctx->num_cus : 256;
+  int best = 0;
+  for (int n = 128; n <= 2048; n += 8) {
+    const int nloc = (n + cus - 1) / cus;
+    const size_t lds = sizeof(double) * ((size_t)4 * n + 16 + (size_t)nloc * n) + 64;
+    if (lds <= 156 * 1024) best = n;
+  }
+  return best;
+}
+
+// Eigen-decomposition of the symmetric n x n matrix A (device, not modified): lraw ascending, evec[i*n + r].
+int launch_eig_dc(blmm_ctx* ctx, const double* A, int n, double* lraw, double* evec, int64_t* stat) {
+  if (n < 3) return fail(ctx, BLMM_ERR_UNSUPPORTED, "eig_dc: n < 3");
+  if (n > eig_dc_max_n(ctx)) return BLMM_ERR_UNSUPPORTED;
+  const size_t nn = (size_t)n * n;
+  // ---- plan: leaves and the merge tree (host) ----
+  int nl = 1;
+  while ((n + nl - 1) / nl > LEAF) nl *= 2;
+  std::vector<int> bounds(nl + 1);
+  for (int i = 0; i <= nl; ++i) bounds[i] = (int)std::llround((double)i * n / nl);
+  std::vector<std::vector<int>> levels;   // per level: flat [lo, mid, hi] triples
+  {
+    std::vector<int> cur(bounds);           // nl is a power of two: every level pairs its segments up exactly
+    while (cur.size() > 2) {
+      std::vector<int> nodes, nxt;
+      for (size_t i = 0; i + 2 < cur.size(); i += 2) {
+        nodes.push_back(cur[i]); nodes.push_back(cur[i + 1]); nodes.push_back(cur[i + 2]);
+      }
+      for (size_t i = 0; i < cur.size(); i += 2) nxt.push_back(cur[i]);
+      levels.push_back(nodes);
+      cur = nxt;
+    }
+  }
+  size_t nnodes_total = 0;
+  for (auto& l : levels) nnodes_total += l.size() / 3;
+  // ---- workspace ----
+  int rc;
+  const size_t ints = (size_t)7 * n + 4 * nnodes_total + 3 * nnodes_total + (nl + 1) + 64;
+  const size_t dbls = 5 * nn + (size_t)14 * n + nnodes_total + 64;
+  if ((rc = ensure(ctx, ctx->eigW, sizeof(double) * dbls + sizeof(int) * ints + 256))) return rc;
+  double* base = ptr<double>(ctx->eigW);
+  double* V = base; double* Qa = V + nn; double* Qb = Qa + nn; double* Dm = Qb + nn; double* Wt = Dm + nn;
+  double* vec = Wt + nn;
+  double* d = vec; double* e = d + n; double* tau = e + n; double* lamA = tau + n; double* lamB = lamA + n;
+  double* dl = lamB + n; double* zl = dl + n; double* zh = zl + n; double* defld = zh + n; double* lamnew = defld + n;
+  double* rotc = lamnew + n; double* rots = rotc + n; double* pbuf = rots + n;   // pbuf: 2n, then rowbuf below
+  double* rho = pbuf + 2 * n;   // nnodes_total (+ pad)
+  // rowbuf shares Dm (unused until the first merge)
+  double* rowbuf = Dm;
+  int* ib = reinterpret_cast<int*>(rho + nnodes_total + 8);
+  int* colidx = ib; int* deflcol = colidx + n; int* rota = deflcol + n; int* rotb = rota + n; int* posn = rotb + n;
+  int* posd = posn + n; int* sync = posd + n;          // sync: n ints reserved: [0] counter, [1] abort
+  int* info = sync + n; int* nodes_dev = info + 4 * nnodes_total; int* bounds_dev = nodes_dev + 3 * nnodes_total;
+  // plan -> device (tiny; cached per n in the context: the copy is skipped when n repeats)
+  if (ctx->eig_plan_n != n) {
+    std::vector<int> flat;
+    for (auto& l : levels) flat.insert(flat.end(), l.begin(), l.end());
+    BLMM_HIP(hipMemcpyAsync(nodes_dev, flat.data(), sizeof(int) * flat.size(), hipMemcpyHostToDevice, ctx->stream));
+    BLMM_HIP(hipMemcpyAsync(bounds_dev, bounds.data(), sizeof(int) * bounds.size(), hipMemcpyHostToDevice, ctx->stream));
+    BLMM_HIP(hipStreamSynchronize(ctx->stream));   // the host vectors die at return
+    ctx->eig_plan_n = n;
+  }
+  // ---- 1. tridiagonalisation ----
+  {
+    const int cus = ctx->num_cus > 0 ? ctx->num_cus : 256;
+    // rows per workgroup: as many as the LDS takes beside the four vectors (fewer workgroups = a cheaper barrier)
+    const size_t budget = 156 * 1024 - sizeof(double) * ((size_t)4 * n + 16) - 64;
+    int nloc = (int)(budget / (sizeof(double) * (size_t)n));
+    if (nloc < 1) return BLMM_ERR_UNSUPPORTED;
+    int G = (n + nloc - 1) / nloc;
+    if (G > cus) return BLMM_ERR_UNSUPPORTED;
+    if (const char* ge = getenv("BLMM_SYTRD_G")) { const int gv = atoi(ge); if (gv >= G && gv <= cus) G = gv; }
+    nloc = (n + G - 1) / G;
+    const size_t lds = sizeof(double) * ((size_t)4 * n + 16 + (size_t)nloc * n);
+    SytrdEx ex; ex.pbuf = pbuf; ex.rowbuf = rowbuf; ex.cnt = reinterpret_cast<unsigned int*>(sync); ex.abort = sync + 1;
+    BLMM_HIP(hipMemsetAsync(sync, 0, sizeof(int) * 4, ctx->stream));
+    BLMM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sytrd), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(k_sytrd, dim3(G), dim3(512), lds, ctx->stream, A, n, nloc, d, e, tau, V, ex, stat);
+    KCHECK();
+  }
+  // ---- 2. leaves ----
+  // a node reads the full square [lo, hi)^2 of its input Q: the blocks off the solved halves' diagonal must read as zero
+  // (block-diagonal eigenvector matrix); both ping-pong buffers, because every level leaves such blocks unwritten
+  BLMM_HIP(hipMemsetAsync(Qa, 0, sizeof(double) * 2 * nn, ctx->stream));
+  hipLaunchKernelGGL(k_tql_leaves, dim3(nl), dim3(64), 0, ctx->stream, d, e, n, bounds_dev, lamA, Qa, stat);
+  KCHECK();
+  // ---- 3. merges ----
+  DcWs w;
+  w.n = n; w.e = e; w.Dm = Dm; w.Wt = Wt; w.dl = dl; w.zl = zl; w.zh = zh; w.defld = defld; w.lamnew = lamnew;
+  w.rotc = rotc; w.rots = rots; w.colidx = colidx; w.deflcol = deflcol; w.rota = rota; w.rotb = rotb; w.posn = posn; w.posd = posd;
+  double* lamIn = lamA; double* lamOut = lamB; double* Qin = Qa; double* Qout = Qb;
+  size_t node_off = 0;
+  for (auto& lvl : levels) {
+    const int nnode = (int)(lvl.size() / 3);
+    int Nmax = 0;
+    for (int q = 0; q < nnode; ++q) Nmax = std::max(Nmax, lvl[3 * q + 2] - lvl[3 * q]);
+    w.lamIn = lamIn; w.lamOut = lamOut; w.Qin = Qin; w.Qout = Qout;
+    w.info = info + 4 * node_off; w.rho = rho + node_off; w.nodes = nodes_dev + 3 * node_off;
+    const size_t lds_defl = sizeof(double) * ((size_t)2 * Nmax + 16) + sizeof(int) * (size_t)Nmax + 16;
+    if (lds_defl > 48 * 1024) BLMM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dc_deflate), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_defl));
+    hipLaunchKernelGGL(k_dc_deflate, dim3(nnode), dim3(1024), lds_defl, ctx->stream, w);
+    hipLaunchKernelGGL(k_dc_rot, dim3(nnode, (Nmax + 255) / 256), dim3(256), 0, ctx->stream, w);
+    const size_t lds_sec = sizeof(double) * (size_t)2 * Nmax;
+    hipLaunchKernelGGL(k_dc_secular, dim3(nnode, (Nmax + 3) / 4), dim3(256), lds_sec, ctx->stream, w);
+    hipLaunchKernelGGL(k_dc_zhat, dim3(nnode, (Nmax + 3) / 4), dim3(256), 0, ctx->stream, w);
+    hipLaunchKernelGGL(k_dc_wt, dim3(nnode, (Nmax + 3) / 4), dim3(256), 0, ctx->stream, w);
+    hipLaunchKernelGGL(k_dc_finalize, dim3(nnode), dim3(1024), sizeof(double) * (size_t)Nmax, ctx->stream, w);
+    hipLaunchKernelGGL(k_dc_copy, dim3(nnode, (Nmax + 255) / 256, 16), dim3(256), 0, ctx->stream, w);
+    constexpr int MB = 2, NB = 2;
+    const int tiles_i = (Nmax + 32 * MB - 1) / (32 * MB), tiles_r = (Nmax + 32 * NB - 1) / (32 * NB);
+    hipLaunchKernelGGL((k_dc_gemm<MB, NB>), dim3(nnode, tiles_i * tiles_r), dim3(256), 0, ctx->stream, w, tiles_r);
+    KCHECK();
+    std::swap(lamIn, lamOut); std::swap(Qin, Qout);
+    node_off += nnode;
+  }
+  // ---- 4. back-transformation (in place on the final Q), results out ----
+  {
+    const size_t lds = sizeof(double) * (size_t)2 * n;
+    const int nr = (n + 63) / 64;
+#define BT(NR)                                                                                                             \
+  do {                                                                                                                     \
+    constexpr int CPW = (NR <= 8) ? 2 : 1;                                                                                 \
+    const int cols_per_wg = 8 * CPW;                                                                                       \
+    hipLaunchKernelGGL((k_backtransform<NR, CPW>), dim3((n + cols_per_wg - 1) / cols_per_wg), dim3(512), lds, ctx->stream, V, tau, n, Qin); \
+  } while (0)
+    if (nr <= 2) BT(2); else if (nr <= 4) BT(4); else if (nr <= 8) BT(8); else if (nr <= 16) BT(16); else if (nr <= 24) BT(24); else BT(32);
+#undef BT
+    KCHECK();
+  }
+  BLMM_HIP(hipMemcpyAsync(lraw, lamIn, sizeof(double) * n, hipMemcpyDeviceToDevice, ctx->stream));
+  BLMM_HIP(hipMemcpyAsync(evec, Qin, sizeof(double) * nn, hipMemcpyDeviceToDevice, ctx->stream));
+  return BLMM_OK;
+}
+
+}  // namespace blmm

@@ -605,3 +605,55 @@ def test_output_pvals_threshold_filter_and_device_quantiles(blmm):
         Lp = rng.random((37, nperms)) * 6
         thr = blmm.get_thresholds(Lp, [0.10, 0.05, 0.0, 1.0])
         assert np.allclose(thr["thrs"], np.quantile(Lp.max(axis=0), [0.90, 0.95, 1.0, 0.0]), rtol=1e-14, atol=0)
+
+
+def _kinds(n, rng):
+    G = (rng.random((n, 3 * n)) < 0.5).astype(float)
+    X = G - 0.5
+    K = 2 * X @ X.T / X.shape[1] + 0.5
+    np.fill_diagonal(K, 1.0)
+    yield "kinship", np.round(K, 12)
+    B = rng.standard_normal((n, max(n // 3, 2)))
+    yield "rank_deficient", B @ B.T / B.shape[1]
+    Qr, _ = np.linalg.qr(rng.standard_normal((n, n)))
+    lam = np.repeat([0.5, 7.0, 7.0 + 1e-10, 100.0], [n // 4, n // 4, n // 4, n - 3 * (n // 4)])
+    yield "clusters", (Qr * lam) @ Qr.T
+    yield "wilkinson", np.diag(np.abs(np.arange(n) - n // 2).astype(float)) + np.diag(np.ones(n - 1), 1) + np.diag(np.ones(n - 1), -1)
+    yield "identity", np.eye(n)
+
+
+@pytest.mark.parametrize("n", [125, 200, 333, 500, 1000])
+def test_dc_eigensolver_accuracy(blmm, n):
+    """The own eigensolver beyond the LDS Jacobi (kernels_eig.hip: LDS-resident Householder tridiagonalisation, divide
+    and conquer, back-transformation; replaces LAPACK eigen, src/transform_helpers.jl:23): orthogonality, residual and
+    eigenvalues against LAPACK on a kinship, a rank-deficient matrix (hundreds of zero eigenvalues: the deflation path),
+    tight eigenvalue clusters, Wilkinson's matrix and the identity (everything deflates)."""
+    rng = np.random.default_rng(n)
+    G = rng.random((n, 8))
+    for name, K in _kinds(n, rng):
+        K = 0.5 * (K + K.T)
+        Y0, _, lam = blmm.transform_rotation(np.eye(n), G, K)
+        U = Y0.T                                        # rotating the identity returns U'
+        sc = max(np.abs(K).max(), 1e-300)
+        assert np.all(np.diff(lam) >= 0), name
+        assert np.abs(U.T @ U - np.eye(n)).max() <= 2e-13, (name, np.abs(U.T @ U - np.eye(n)).max())
+        assert np.abs(K @ U - U * lam).max() <= 5e-13 * sc * np.sqrt(n), (name, np.abs(K @ U - U * lam).max() / sc)
+        assert np.abs(lam - np.linalg.eigvalsh(K)).max() <= 1e-12 * sc * np.sqrt(n), name
+
+
+def test_dc_eigensolver_small_n_and_end_to_end(blmm, monkeypatch):
+    """BLMM_EIGEN=dc sends n <= 124 through the same solver (single-workgroup tridiagonalisation, two merge levels);
+    bulkscan results must not depend on which eigensolver ran (LOD is invariant to the eigenbasis)."""
+    Y, G, K, _ = make_data(p=130, m=40, seed=777)
+    base = blmm.bulkscan_null(Y, G, K)
+    monkeypatch.setenv("BLMM_EIGEN", "dc")
+    for n in (5, 33, 64, 79, 124):
+        Kn = K[:n, :n] if n <= 79 else np.round(np.cov(np.random.default_rng(n).standard_normal((n, 3 * n))), 12)
+        Y0, _, lam = blmm.transform_rotation(np.eye(n), np.ones((n, 2)), Kn)
+        U = Y0.T
+        assert np.abs(U.T @ U - np.eye(n)).max() <= 1e-13 and np.abs(Kn @ U - U * lam).max() <= 1e-12 * np.abs(Kn).max() * n
+    dc = blmm.bulkscan_null(Y, G, K)
+    assert np.abs(dc.h2_null_list - base.h2_null_list).max() <= 1e-6
+    assert np.sum((dc.L - base.L) ** 2, axis=0).max() <= 1e-7
+    pin = O.bulkscan_null(Y, G, K, h2_override=dc.h2_null_list)
+    assert_lod_close(dc.L, pin.L)
