@@ -374,6 +374,7 @@ int lr_begin(blmm_ctx* ctx, const Pipe& P, bool wbasis_started) {
   if ((rc = ensure(ctx, ctx->lrC, sizeof(double) * (size_t)P.npad * ldp))) return rc;
   if ((rc = ensure(ctx, ctx->lrL, sizeof(double) * (size_t)(P.c * (P.c + 1) / 2) * ldp))) return rc;
   if ((rc = ensure(ctx, ctx->lrFlag, sizeof(int) * (size_t)(P.m > 0 ? P.m : 1)))) return rc;
+  if ((rc = ensure(ctx, ctx->lrPart, sizeof(double) * 2 * (size_t)((P.n + 63) / 64) * ldp))) return rc;
   if ((rc = ensure(ctx, ctx->panels, sizeof(double) * (size_t)P.npad * ldp))) return rc;
   if ((rc = ensure(ctx, ctx->wbQ, sizeof(double) * (size_t)P.npad * P.n))) return rc;
   if ((rc = ensure(ctx, ctx->wbW, sizeof(double) * (size_t)P.n * (256 + 16)))) return rc;
@@ -406,7 +407,7 @@ int lr_finish(blmm_ctx* ctx, const Pipe& P, const NullModel& nm, const double* d
   BLMM_HIP(hipStreamWaitEvent(ctx->side, ctx->ev_fork, 0));
   ctx->stream = ctx->side;
   rc = launch_lr_resid(ctx, nm, m, lr_tolerance(), P.lam, dh2, ptr<double>(ctx->wbQ), rk, ptr<double>(ctx->lrC), ldp,
-                       ptr<int>(ctx->lrFlag), P.stat);
+                       ptr<int>(ctx->lrFlag), ptr<double>(ctx->lrPart), P.stat);
   ctx->stream = main_stream;
   if (rc) return rc;
   BLMM_HIP(hipEventRecord(ctx->ev_join, ctx->side));
@@ -503,7 +504,7 @@ void blmm_destroy(blmm_ctx* ctx) {
                     &ctx->iyy, &ctx->h2, &ctx->h2idx, &ctx->sig2, &ctx->ell, &ctx->isx, &ctx->stat, &ctx->gridd, &ctx->misc,
                     &ctx->EllTab, &ctx->inY, &ctx->inG, &ctx->inK, &ctx->inCov, &ctx->inW, &ctx->outL, &ctx->outH2,
                     &ctx->tmpA, &ctx->tmpB, &ctx->tmpC, &ctx->perm, &ctx->r0, &ctx->altbuf, &ctx->logtab, &ctx->lraw,
-                    &ctx->wbQ, &ctx->wbW, &ctx->wbRk, &ctx->lrT, &ctx->lrC, &ctx->lrL, &ctx->lrFlag, &ctx->eigW, &ctx->xf32, &ctx->pf32, &ctx->brSt, &ctx->brList};
+                    &ctx->wbQ, &ctx->wbW, &ctx->wbRk, &ctx->lrT, &ctx->lrC, &ctx->lrL, &ctx->lrFlag, &ctx->lrPart, &ctx->eigW, &ctx->xf32, &ctx->pf32, &ctx->brSt, &ctx->brList};
   for (DevBuf* b : bufs) if (b->p) hipFree(b->p);
   for (auto& s : ctx->evsets) for (auto& e : s.e) (void)hipEventDestroy(e);
   if (ctx->rb_handle && ctx->rb_destroy) ctx->rb_destroy(ctx->rb_handle);

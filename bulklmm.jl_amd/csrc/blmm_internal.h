@@ -38,7 +38,7 @@ struct blmm_ctx {
   std::string err;
   // grow-only workspace
   blmm::DevBuf Ks, V, lam, U, Zs, Z0, Rp, Yt, Xt, panels, iyy, h2, h2idx, sig2, ell, isx, stat, gridd, misc, EllTab,
-      inY, inG, inK, inCov, inW, outL, outH2, tmpA, tmpB, tmpC, perm, r0, altbuf, logtab, lraw, wbQ, wbW, wbRk, lrT, lrC, lrL, lrFlag, eigW, xf32, pf32, brSt, brList;
+      inY, inG, inK, inCov, inW, outL, outH2, tmpA, tmpB, tmpC, perm, r0, altbuf, logtab, lraw, wbQ, wbW, wbRk, lrT, lrC, lrL, lrFlag, lrPart, eigW, xf32, pf32, brSt, brList;
   // event sets: one per timed call since the last blmm_read_timings (grown on demand, reused afterwards)
   struct EvSet { hipEvent_t e[8]; int n; };
   std::vector<EvSet> evsets;
@@ -158,7 +158,7 @@ struct LrArgs {
 };
 int launch_scan_lr(blmm_ctx* ctx, const LrArgs& la);
 int launch_lr_resid(blmm_ctx* ctx, const NullModel& nm, int64_t m, double tol, const double* lam, const double* h2,
-                    const double* Q, const int* rk, const double* Cp, int64_t ldp, int* flag_list, int64_t* stat);
+                    const double* Q, const int* rk, const double* Cp, int64_t ldp, int* flag_list, double* part, int64_t* stat);
 int launch_scan_fix(blmm_ctx* ctx, const NullModel& nm, const double* Xt, int64_t ldx, int64_t p, const double* P0,
                     const double* Ls, int64_t ldp, const double* Z0, const double* lam, const double* h2,
                     const int* flag_list, double* L, int64_t ldL, int64_t* stat);

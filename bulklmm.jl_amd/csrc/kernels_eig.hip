@@ -31,20 +31,34 @@ namespace {
 constexpr double EPS = 2.220446049250313e-16;
 constexpr int LEAF = 32;
 
+// Wave-wide reductions on the DPP path (quad_perm / row_half_mirror / row_mirror inside a row of 16 lanes, then the four
+// row totals through v_readlane): ~60 cycles for a double, against ~700 for the six ds_bpermute pairs of a __shfl_xor
+// butterfly -- these sit on the critical path of every row of k_sytrd and every reflector of k_backtransform.
+template <int CTRL>
+__device__ __forceinline__ double dpp_mov(double x) {
+  int lo = __double2loint(x), hi = __double2hiint(x);
+  lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xf, 0xf, false);
+  hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xf, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double lane_bcast(double x, int l) {
+  const int lo = __builtin_amdgcn_readlane(__double2loint(x), l), hi = __builtin_amdgcn_readlane(__double2hiint(x), l);
+  return __hiloint2double(hi, lo);
+}
 __device__ __forceinline__ double wsum(double x) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o, 64);
-  return x;
+  x += dpp_mov<0xB1>(x);    // quad_perm [1,0,3,2]
+  x += dpp_mov<0x4E>(x);    // quad_perm [2,3,0,1]
+  x += dpp_mov<0x141>(x);   // row_half_mirror
+  x += dpp_mov<0x140>(x);   // row_mirror: every lane holds its row's total
+  return (lane_bcast(x, 0) + lane_bcast(x, 16)) + (lane_bcast(x, 32) + lane_bcast(x, 48));
 }
 __device__ __forceinline__ double wmax(double x) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) x = fmax(x, __shfl_xor(x, o, 64));
-  return x;
+  x = fmax(x, dpp_mov<0xB1>(x)); x = fmax(x, dpp_mov<0x4E>(x)); x = fmax(x, dpp_mov<0x141>(x)); x = fmax(x, dpp_mov<0x140>(x));
+  return fmax(fmax(lane_bcast(x, 0), lane_bcast(x, 16)), fmax(lane_bcast(x, 32), lane_bcast(x, 48)));
 }
 __device__ __forceinline__ double wprod(double x) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) x *= __shfl_xor(x, o, 64);
-  return x;
+  x *= dpp_mov<0xB1>(x); x *= dpp_mov<0x4E>(x); x *= dpp_mov<0x141>(x); x *= dpp_mov<0x140>(x);
+  return (lane_bcast(x, 0) * lane_bcast(x, 16)) * (lane_bcast(x, 32) * lane_bcast(x, 48));
 }
 // sum over the workgroup; every thread gets the result.  red: >= 16 doubles of LDS.  Two barriers.
 __device__ __forceinline__ double block_sum(double x, double* red) {
@@ -80,15 +94,27 @@ __device__ __forceinline__ double ld_sc1(const double* p) {
 }
 
 struct SytrdEx {          // global exchange area of k_sytrd
-  double* pbuf;           // [2][n]   p = tau A v, by global row
-  double* rowbuf;         // [2][n]   row k+1 of the trailing matrix before the step's update
-  unsigned int* cnt;      // arrival counter (monotonic; zeroed by the launcher)
+  unsigned long long* gr; // [2 parities][n rows][4 granules]: {p lo, p hi, a lo, a hi}, each (tag << 32) | 32 data bits
   int* abort;             // set when a workgroup gave up waiting
 };
 
 // ---------------------------------------------------------------------------------------------------------------------
 // 1. tridiagonalisation.  Workgroup g of G owns the rows i = g, g + G, ... (local row li = i / G), all n columns of
 // each, in LDS.  Outputs: d (n), e (n - 1), tau (n - 2), V[k*n + j] = v_k[j] for j > k (v_k[k+1] = 1).
+//
+// Step k, every workgroup: Householder vector v of the current column x (known to all) -> p_i = tau (A v)_i for its rows.
+// It publishes p_i together with its own entries a_i = A[i][k+1] (by symmetry the union over the workgroups is row k+1,
+// which nobody would otherwise have in full) and gathers everybody's: ONE exchange per step.  Then all form
+// w = p - (tau/2)(p'v) v and derive the next column x = a - w - w[k+1] v on their own.
+// The rank-2 update of the rows is DEFERRED by one step and applied while the next exchange is in flight: step k's
+// products use the rows with updates <= k-2 plus the correction  - vp (wp'v) - wp (vp'v)  for the pending pair (vp, wp).
+// Four workgroup barriers per step (they cost ~500 cycles each at 512 threads: the per-step floor besides the exchange).
+// Exchange protocol: data-tagged granules (MI355X_MICROARCH.md, persistent-kernel price list: "Granule = one naturally
+// aligned 8-byte {data, tag} written by ONE sc1 store", the form that needs no ordering at all).  A double travels as two
+// granules (tag = step + 1 in the upper word, 32 data bits in the lower); the consumer spins with sc1 loads on exactly
+// the granules it needs until their tags match: no drain, no flag, no counter (64-256 atomics on one word cost 1-3 us per
+// step by themselves).  Buffers alternate by step parity (a workgroup can be at most one step ahead of the slowest: its
+// step k+1 payload needs everybody's step k payload); spins are bounded (abort word).
 // ---------------------------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(512) k_sytrd(const double* __restrict__ A, int n, int nloc_max, double* __restrict__ d,
                                                 double* __restrict__ e, double* __restrict__ tau, double* __restrict__ V,
@@ -96,113 +122,147 @@ __global__ void __launch_bounds__(512) k_sytrd(const double* __restrict__ A, int
   extern __shared__ __attribute__((aligned(16))) double sh[];
   const int G = gridDim.x, g = blockIdx.x, t = threadIdx.x, NT = blockDim.x;
   const int lane = t & 63, wave = t >> 6, nwave = NT >> 6;
-  double* sv = sh;                  // n : current column x, then the reflector v
-  double* sw = sv + n;              // n
-  double* sp = sw + n;              // n
-  double* srow = sp + n;            // n
-  double* red = srow + n;           // 16
-  double* Al = red + 16;            // nloc_max x n
-  __shared__ int s_ok;
+  double* sx = sh;                  // n : current column x (alternates with sa)
+  double* sa = sx + n;              // n : gathered column k+1, turned into the next x in place
+  double* sp = sa + n;              // n : gathered p
+  double* svc = sp + n;             // n : v of this step        (svc/swc alternate with svp/swp)
+  double* swc = svc + n;            // n : w of this step
+  double* svp = swc + n;            // n : v of the pending (previous) step
+  double* swp = svp + n;            // n : w of the pending step
+  double* red = swp + n;            // 2 parities x 4 sums x 16 waves
+  double* Al = red + 128;           // nloc_max x n
   const int nloc = (n - g + G - 1) / G;
   for (int li = 0; li < nloc; ++li) {
     const int i = g + li * G;
     for (int j = t; j < n; j += NT) Al[(size_t)li * n + j] = A[(size_t)j * n + i];   // symmetric: row i = column i
   }
-  for (int j = t; j < n; j += NT) sv[j] = (j >= 1) ? A[j] : 0.0;                        // column 0, rows 1..n-1
+  for (int j = t; j < n; j += NT) { sx[j] = (j >= 1) ? A[j] : 0.0; svp[j] = 0.0; swp[j] = 0.0; }   // column 0; no pending update yet
   double akk = A[0];
   __syncthreads();
   bool aborted = false;
+#ifdef SYTRD_PROF
+  long long pf[6] = {0, 0, 0, 0, 0, 0}, pt0 = __builtin_amdgcn_s_memtime();
+#define PSTAMP(i) do { const long long t1__ = __builtin_amdgcn_s_memtime(); pf[i] += t1__ - pt0; pt0 = t1__; } while (0)
+#else
+#define PSTAMP(i) do { } while (0)
+#endif
   for (int k = 0; k + 2 < n; ++k) {
     const int par = k & 1;
-    // (1) Householder vector of x = sv[k+1 .. n)
-    double part = 0.0;
-    for (int j = k + 2 + t; j < n; j += NT) part = fma(sv[j], sv[j], part);
-    const double xn2 = block_sum(part, red);
-    const double alpha = sv[k + 1];
-    double beta, tk;
-    if (xn2 == 0.0) {
-      beta = alpha; tk = 0.0;
-    } else {
-      beta = -copysign(sqrt(fma(alpha, alpha, xn2)), alpha);
-      tk = (beta - alpha) / beta;
-      const double sc = 1.0 / (alpha - beta);
-      for (int j = k + 2 + t; j < n; j += NT) sv[j] *= sc;
-    }
-    __syncthreads();
-    if (t == 0) sv[k + 1] = 1.0;
-    __syncthreads();
-    if (g == k % G) {
-      for (int j = k + 1 + t; j < n; j += NT) V[(size_t)k * n + j] = sv[j];
-      if (t == 0) { d[k] = akk; e[k] = beta; tau[k] = tk; }
-    }
-    // (2) p_i = tau * sum_j A[i][j] v[j] for the owned rows i > k, one wave per row
+    double* rd = red + par * 64;
+    // (1) one pass, three sums over j >= k+2:  |x|^2,  vp'x,  wp'x   (the pending pair's products with v follow from them)
+    double s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    for (int j = k + 2 + t; j < n; j += NT) { const double x = sx[j]; s1 = fma(x, x, s1); s2 = fma(svp[j], x, s2); s3 = fma(swp[j], x, s3); }
+    s1 = wsum(s1); s2 = wsum(s2); s3 = wsum(s3);
+    if (lane == 0) { rd[wave] = s1; rd[16 + wave] = s2; rd[32 + wave] = s3; }
+    __syncthreads();                                                   // barrier 1
+    s1 = 0.0; s2 = 0.0; s3 = 0.0;
+    for (int q = 0; q < nwave; ++q) { s1 += rd[q]; s2 += rd[16 + q]; s3 += rd[32 + q]; }
+    const double alpha = sx[k + 1];
+    double beta, tk, sc;
+    if (s1 == 0.0) { beta = alpha; tk = 0.0; sc = 0.0; }
+    else { beta = -copysign(sqrt(fma(alpha, alpha, s1)), alpha); tk = (beta - alpha) / beta; sc = 1.0 / (alpha - beta); }
+    const double vpk1 = svp[k + 1], wpk1 = swp[k + 1];
+    const double vpv = fma(sc, s2, vpk1), wpv = fma(sc, s3, wpk1);      // vp'v and wp'v with v = (1, sc x[k+2:])
+    PSTAMP(0);
+    // (2) owned rows i > k:  p_i = tau ((A v)_i - vp_i (wp'v) - wp_i (vp'v)),  a_i = A[i][k+1] with the pending update applied
     const int li0 = (k + 1 > g) ? (k + 1 - g + G - 1) / G : 0;    // first local row with global index > k
     for (int li = li0 + wave; li < nloc; li += nwave) {
       const int i = g + li * G;
       const double* row = Al + (size_t)li * n;
       double acc = 0.0;
-      for (int j = k + 1 + lane; j < n; j += 64) acc = fma(row[j], sv[j], acc);
-      acc = wsum(acc) * tk;
-      if (lane == 0) { if (G > 1) st_sc1(ex.pbuf + (size_t)par * n + i, acc); else sp[i] = acc; }
+      for (int j = k + 2 + lane; j < n; j += 64) acc = fma(row[j], sx[j], acc);
+      acc = wsum(acc);
+      if (lane == 0) {
+        const double vpi = svp[i], wpi = swp[i], rk1 = row[k + 1];
+        const double pi = tk * (fma(sc, acc, rk1) - vpi * wpv - wpi * vpv);
+        const double ai = rk1 - vpi * wpk1 - wpi * vpk1;
+        if (G > 1) {
+          const unsigned long long tg = (unsigned long long)(unsigned int)(k + 1) << 32;
+          const unsigned long long pb = (unsigned long long)__double_as_longlong(pi), ab = (unsigned long long)__double_as_longlong(ai);
+          unsigned long long* gq = ex.gr + ((size_t)par * n + i) * 4;
+          __hip_atomic_store(gq + 0, tg | (pb & 0xffffffffull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          __hip_atomic_store(gq + 1, tg | (pb >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          __hip_atomic_store(gq + 2, tg | (ab & 0xffffffffull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          __hip_atomic_store(gq + 3, tg | (ab >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else { sp[i] = pi; sa[i] = ai; }
+      }
     }
+    PSTAMP(1);
+    // (3) the pending rank-2 update (step k-1) of the same rows this wave just used, while the exchange is in flight
+    if (k > 0) {
+      for (int li = li0 + wave; li < nloc; li += nwave) {
+        const int i = g + li * G;
+        double* row = Al + (size_t)li * n;
+        const double vi = svp[i], wi = swp[i];
+        for (int j = k + 1 + lane; j < n; j += 64) row[j] = fma(-vi, swp[j], fma(-wi, svp[j], row[j]));
+      }
+    }
+    PSTAMP(2);
+    // (4) gather p and a of every row j > k
     if (G > 1) {
-      if (g == (k + 1) % G) {
-        const double* row = Al + (size_t)((k + 1) / G) * n;
-        for (int j = k + 1 + t; j < n; j += NT) st_sc1(ex.rowbuf + (size_t)par * n + j, row[j]);
-      }
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();
-      if (t == 0) {
-        __hip_atomic_fetch_add(ex.cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const unsigned int target = (unsigned int)G * (unsigned int)(k + 1);
-        int ok = 0;
-        for (int spin = 0; spin < (1 << 24); ++spin) {
-          if (__hip_atomic_load(ex.cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= target) { ok = 1; break; }
-          if (__hip_atomic_load(ex.abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
+      const unsigned int want = (unsigned int)(k + 1);
+      bool bad = false;
+      for (int j = k + 1 + t; j < n && !bad; j += NT) {
+        const unsigned long long* gq = ex.gr + ((size_t)par * n + j) * 4;
+        unsigned long long q0, q1, q2, q3;
+        int spin = 0;
+        for (;;) {
+          q0 = __hip_atomic_load(gq + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          q1 = __hip_atomic_load(gq + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          q2 = __hip_atomic_load(gq + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          q3 = __hip_atomic_load(gq + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if ((unsigned int)(q0 >> 32) == want && (unsigned int)(q1 >> 32) == want && (unsigned int)(q2 >> 32) == want &&
+              (unsigned int)(q3 >> 32) == want) break;
           __builtin_amdgcn_s_sleep(1);
+          if (++spin > (1 << 22) || ((spin & 1023) == 0 && __hip_atomic_load(ex.abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) { bad = true; break; }
         }
-        if (!ok) __hip_atomic_store(ex.abort, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        s_ok = ok;
+        sp[j] = __longlong_as_double((long long)((q1 << 32) | (q0 & 0xffffffffull)));
+        sa[j] = __longlong_as_double((long long)((q3 << 32) | (q2 & 0xffffffffull)));
       }
-      __syncthreads();
-      if (!s_ok) { aborted = true; break; }
-      for (int j = k + 1 + t; j < n; j += NT) {
-        sp[j] = ld_sc1(ex.pbuf + (size_t)par * n + j);
-        srow[j] = ld_sc1(ex.rowbuf + (size_t)par * n + j);
-      }
+      if (bad) __hip_atomic_store(ex.abort, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (__syncthreads_or(bad ? 1 : 0)) { aborted = true; break; }     // barrier 2
     } else {
-      __syncthreads();
-      const double* row = Al + (size_t)(k + 1) * n;
-      for (int j = k + 1 + t; j < n; j += NT) srow[j] = row[j];
+      __syncthreads();                                                   // barrier 2
     }
-    __syncthreads();
-    // (5) w = p - (tau/2)(p'v) v
-    part = 0.0;
-    for (int j = k + 1 + t; j < n; j += NT) part = fma(sp[j], sv[j], part);
-    const double pv = block_sum(part, red);
-    const double cw = 0.5 * tk * pv;
-    for (int j = k + 1 + t; j < n; j += NT) sw[j] = fma(-cw, sv[j], sp[j]);
-    __syncthreads();
-    // (6) rank-2 update of the owned rows
-    for (int li = li0 + wave; li < nloc; li += nwave) {
-      const int i = g + li * G;
-      double* row = Al + (size_t)li * n;
-      const double vi = sv[i], wi = sw[i];
-      for (int j = k + 1 + lane; j < n; j += 64) row[j] = fma(-vi, sw[j], fma(-wi, sv[j], row[j]));
+    PSTAMP(3);
+    // (5) p'v, then w = p - (tau/2)(p'v) v
+    double s4 = 0.0;
+    for (int j = k + 2 + t; j < n; j += NT) s4 = fma(sp[j], sx[j], s4);
+    s4 = wsum(s4);
+    if (lane == 0) rd[48 + wave] = s4;
+    __syncthreads();                                                     // barrier 3
+    s4 = 0.0;
+    for (int q = 0; q < nwave; ++q) s4 += rd[48 + q];
+    const double pk1 = sp[k + 1];
+    const double cw = 0.5 * tk * fma(sc, s4, pk1);
+    const double wk1 = pk1 - cw;                                         // v[k+1] = 1
+    const bool vown = (g == k % G);
+    for (int j = k + 1 + t; j < n; j += NT) {
+      const double v = (j == k + 1) ? 1.0 : sx[j] * sc;
+      const double wj = fma(-cw, v, sp[j]);
+      svc[j] = v; swc[j] = wj;
+      if (vown) V[(size_t)k * n + j] = v;
+      if (j > k + 1) sa[j] = sa[j] - wj - wk1 * v;                       // the next column, in place
     }
-    // (7) the next column from the published (pre-update) row k+1:  x[j] = row[j] - v[k+1] w[j] - w[k+1] v[j],  v[k+1] = 1
-    const double wk1 = sw[k + 1];
-    akk = srow[k + 1] - 2.0 * wk1;
-    __syncthreads();
-    for (int j = k + 2 + t; j < n; j += NT) sv[j] = srow[j] - sw[j] - wk1 * sv[j];
-    __syncthreads();
+    if (vown && t == 0) { d[k] = akk; e[k] = beta; tau[k] = tk; }
+    akk = sa[k + 1] - 2.0 * wk1;                                         // read before anyone overwrites it: sa[k+1] is not written above
+    __syncthreads();                                                     // barrier 4
+    { double* tmp = sx; sx = sa; sa = tmp; }
+    { double* tmp = svc; svc = svp; svp = tmp; tmp = swc; swc = swp; swp = tmp; }   // this step's pair is now the pending one
+    PSTAMP(4);
   }
+#ifdef SYTRD_PROF
+  if (t == 0 && (g == 0 || g == G - 1))
+    printf("sytrd prof wg %d/%d nt %d n %d: sums+householder %lld symv+publish %lld pending update %lld wait+gather %lld w/next %lld (cycles/step)\n", g, G, NT, n,
+           pf[0] / (n - 2), pf[1] / (n - 2), pf[2] / (n - 2), pf[3] / (n - 2), pf[4] / (n - 2));
+#endif
   if (aborted) {
     if (g == 0 && t == 0) stat[11] = -7;   // reported as an eigensolver failure (blmm_api.hip: finish_status / k_sticky)
     return;
   }
-  if (g == 0 && t == 0) { d[n - 2] = akk; e[n - 2] = sv[n - 1]; }
-  if (g == (n - 1) % G && t == 0) d[n - 1] = Al[(size_t)((n - 1) / G) * n + (n - 1)];
+  if (g == 0 && t == 0) { d[n - 2] = akk; e[n - 2] = sx[n - 1]; }
+  // d[n-1]: the last row still carries the pending update of the final step
+  if (g == (n - 1) % G && t == 0) d[n - 1] = Al[(size_t)((n - 1) / G) * n + (n - 1)] - 2.0 * svp[n - 1] * swp[n - 1];
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -237,28 +297,28 @@ __global__ void __launch_bounds__(64) k_tql_leaves(const double* __restrict__ d,
       if (m == l) break;
       if (++iter > 80) { failed = true; break; }
       double gg = (sd[l + 1] - sd[l]) / (2.0 * se[l]);
-      double rr = hypot(gg, 1.0);
+      double rr = sqrt(fma(gg, gg, 1.0));
       gg = sd[m] - sd[l] + se[l] / (gg + copysign(rr, gg));
       double s = 1.0, c = 1.0, p = 0.0;
       int i = m - 1;
       bool under = false;
+      // one wave: LDS accesses complete in program order, so the scalar recurrence (identical in every lane) needs no
+      // barrier; kinship-scale data keeps f^2 + g^2 far from over/underflow, so a plain sqrt replaces hypot
       for (; i >= l; --i) {
-        const double f = s * se[i], b = c * se[i];
-        rr = hypot(f, gg);
-        __syncthreads();
+        const double ei = se[i], di = sd[i], di1 = sd[i + 1];
+        const double f = s * ei, b = c * ei;
+        rr = sqrt(fma(f, f, gg * gg));
         if (r == 0) se[i + 1] = rr;
         if (rr == 0.0) {
-          if (r == 0) { sd[i + 1] -= p; se[m] = 0.0; }
+          if (r == 0) { sd[i + 1] = di1 - p; se[m] = 0.0; }
           under = true;
-          __syncthreads();
           break;
         }
-        s = f / rr; c = gg / rr;
-        const double di1 = sd[i + 1], di = sd[i];
+        const double ir = 1.0 / rr;
+        s = f * ir; c = gg * ir;
         gg = di1 - p;
         rr = (di - gg) * s + 2.0 * c * b;
         p = s * rr;
-        __syncthreads();
         if (r == 0) sd[i + 1] = gg + p;
         gg = c * rr - b;
         if (r < N) {
@@ -266,12 +326,9 @@ __global__ void __launch_bounds__(64) k_tql_leaves(const double* __restrict__ d,
           Z[r][i + 1] = s * z0 + c * f2;
           Z[r][i] = c * z0 - s * f2;
         }
-        __syncthreads();
       }
       if (under) continue;
-      __syncthreads();
       if (r == 0) { sd[l] -= p; se[l] = gg; se[m] = 0.0; }
-      __syncthreads();
     }
   }
   __syncthreads();
@@ -329,40 +386,45 @@ __global__ void __launch_bounds__(1024) k_dc_deflate(DcWs w) {
   dm = block_max(dm, red);
   zm = block_max(zm, red);
   const double tol = 8.0 * EPS * fmax(dm, zm);
+  // sorted copies (ds, zs, ord) so that the serial scan below walks consecutive LDS words
+  double* ds = red + 16 + (N + 1) / 2;   // past ord (N ints)
+  double* zs = ds + N;
   for (int j = t; j < N; j += NT) {
     const double v = sd[j];
     int rank = 0;
     for (int i = 0; i < N; ++i) rank += (sd[i] < v) || (sd[i] == v && i < j);
-    ord[rank] = j;
+    ord[rank] = j; ds[rank] = v; zs[rank] = sz[j];
   }
   __syncthreads();
   if (t == 0) {
     int K = 0, nd = 0, nr = 0;
     if (rho * zm <= tol) {
-      for (int s = 0; s < N; ++s) { const int j = ord[s]; w.defld[lo + nd] = sd[j]; w.deflcol[lo + nd] = lo + j; ++nd; }
+      for (int s = 0; s < N; ++s) { w.defld[lo + nd] = ds[s]; w.deflcol[lo + nd] = lo + ord[s]; ++nd; }
     } else {
-      int pj = -1;
+      // LAPACK dlaed2's scan in sorted order; (dp, zp, cp) = the pending candidate (value, z, column)
+      int havep = 0, cp = 0;
+      double dp = 0.0, zp = 0.0;
       for (int s = 0; s < N; ++s) {
-        const int nj = ord[s];
-        if (rho * fabs(sz[nj]) <= tol) { w.defld[lo + nd] = sd[nj]; w.deflcol[lo + nd] = lo + nj; ++nd; continue; }
-        if (pj < 0) { pj = nj; continue; }
-        double sn = sz[pj], cs = sz[nj];
-        const double tau = hypot(cs, sn), tt = sd[nj] - sd[pj];
-        cs /= tau; sn = -sn / tau;
-        if (fabs(tt * cs * sn) <= tol) {
-          sz[nj] = tau; sz[pj] = 0.0;
-          w.rota[lo + nr] = lo + pj; w.rotb[lo + nr] = lo + nj; w.rotc[lo + nr] = cs; w.rots[lo + nr] = sn; ++nr;
-          const double dp = sd[pj], dn = sd[nj];
-          sd[pj] = dp * cs * cs + dn * sn * sn;
-          sd[nj] = dp * sn * sn + dn * cs * cs;
-          w.defld[lo + nd] = sd[pj]; w.deflcol[lo + nd] = lo + pj; ++nd;
-          pj = nj;
+        const double dn = ds[s], zn = zs[s];
+        const int cn = ord[s];
+        if (rho * fabs(zn) <= tol) { w.defld[lo + nd] = dn; w.deflcol[lo + nd] = lo + cn; ++nd; continue; }
+        if (!havep) { havep = 1; dp = dn; zp = zn; cp = cn; continue; }
+        const double tt = dn - dp, tau2 = fma(zn, zn, zp * zp);
+        // |t c s| <= tol with c, s normalised by tau, tested without the division (the common case keeps both)
+        if (fabs(tt * zn * zp) <= tol * tau2) {
+          const double tau = sqrt(tau2);
+          const double cs = zn / tau, sn = -zp / tau;
+          w.rota[lo + nr] = lo + cp; w.rotb[lo + nr] = lo + cn; w.rotc[lo + nr] = cs; w.rots[lo + nr] = sn; ++nr;
+          const double dpn = dp * cs * cs + dn * sn * sn;
+          const double dnn = dp * sn * sn + dn * cs * cs;
+          w.defld[lo + nd] = dpn; w.deflcol[lo + nd] = lo + cp; ++nd;
+          dp = dnn; zp = tau; cp = cn;
         } else {
-          w.dl[lo + K] = sd[pj]; w.zl[lo + K] = sz[pj]; w.colidx[lo + K] = lo + pj; ++K;
-          pj = nj;
+          w.dl[lo + K] = dp; w.zl[lo + K] = zp; w.colidx[lo + K] = lo + cp; ++K;
+          dp = dn; zp = zn; cp = cn;
         }
       }
-      if (pj >= 0) { w.dl[lo + K] = sd[pj]; w.zl[lo + K] = sz[pj]; w.colidx[lo + K] = lo + pj; ++K; }
+      if (havep) { w.dl[lo + K] = dp; w.zl[lo + K] = zp; w.colidx[lo + K] = lo + cp; ++K; }
     }
     w.info[4 * node] = K; w.info[4 * node + 1] = nd; w.info[4 * node + 2] = nr;
     w.rho[node] = rho;
@@ -415,20 +477,43 @@ __global__ void __launch_bounds__(256) k_dc_secular(DcWs w) {
   }
   const double dorg = dl[org];
   double tcur = 0.5 * (a + b);
-  for (int it = 0; it < 200 && a < b; ++it) {
-    double f = 0.0, fp = 0.0;
+  // Bunch-Nielsen-Sorensen iteration: psi (poles left of the root) and phi (poles right of it) are each replaced by
+  // r + s / (pole - t) matching value and slope at the iterate; the root of the resulting two-pole equation (a quadratic)
+  // is the next iterate: monotone and quadratic from anywhere inside the interval.  The sign of f keeps a bracket, and a
+  // candidate outside it (rounding, or the degenerate ends) falls back to bisection.
+  const double poleL = dl[i] - dorg, poleR = (i < K - 1) ? dl[i + 1] - dorg : 0.0;
+  for (int it = 0; it < 100 && a < b; ++it) {
+    double ps = 0.0, psp = 0.0, ph = 0.0, php = 0.0;
     for (int j = lane; j < K; j += 64) {
       const double q = 1.0 / ((dl[j] - dorg) - tcur);
       const double zq = z2[j] * q;
-      f += zq; fp = fma(zq, q, fp);
+      if (j <= i) { ps += zq; psp = fma(zq, q, psp); } else { ph += zq; php = fma(zq, q, php); }
     }
-    f = 1.0 + rho * wsum(f);
-    fp = rho * wsum(fp);
+    ps = rho * wsum(ps); psp = rho * wsum(psp); ph = rho * wsum(ph); php = rho * wsum(php);
+    const double f = 1.0 + ps + ph;
     if (f == 0.0) break;
     if (f > 0.0) b = tcur; else a = tcur;
-    double tn = tcur - f / fp;
-    if (!(a < tn && tn < b) || it > 12) tn = 0.5 * (a + b);
-    if (tn == tcur || b - a <= 2.0 * EPS * fmax(fabs(a), fabs(b))) { tcur = tn; break; }
+    double tn;
+    const double dL = poleL - tcur;
+    const double sps = psp * dL * dL, rps = ps - psp * dL;
+    if (i < K - 1) {
+      const double dR = poleR - tcur;
+      const double sph = php * dR * dR, rph = ph - php * dR;
+      const double c = 1.0 + rps + rph;
+      const double a2 = c, a1 = -(c * (poleL + poleR) + sps + sph), a0 = c * poleL * poleR + sps * poleR + sph * poleL;
+      const double disc = a1 * a1 - 4.0 * a2 * a0;
+      tn = tcur;
+      if (disc >= 0.0) {
+        const double qq = -0.5 * (a1 + copysign(sqrt(disc), a1));
+        const double r1 = (a2 != 0.0) ? qq / a2 : a, r2 = (qq != 0.0) ? a0 / qq : a;
+        tn = (a < r1 && r1 < b) ? r1 : r2;
+      }
+    } else {
+      const double c = 1.0 + rps;
+      tn = poleL + sps / c;
+    }
+    if (!(a < tn && tn < b)) tn = 0.5 * (a + b);
+    if (tn == tcur || b - a <= 2.0 * EPS * fmax(fabs(a), fabs(b)) || fabs(tn - tcur) <= EPS * fabs(tn)) { tcur = tn; break; }
     tcur = tn;
   }
   if (lane == 0) w.lamnew[lo + i] = dorg + tcur;
@@ -572,15 +657,26 @@ __global__ void __launch_bounds__(512) k_backtransform(const double* __restrict_
       z[c][q] = (c0 + c < n && r < n) ? Z[(size_t)(c0 + c) * n + r] : 0.0;
     }
   const int nref = n - 2;
-  if (nref > 0) {
-    const int k = nref - 1;
-    for (int j = k + 1 + threadIdx.x; j < n; j += blockDim.x) sh[j] = V[(size_t)k * n + j];
-  }
+  // reflector k is read from global memory two iterations before its use (into registers), written to LDS one iteration
+  // before, so neither the L2 round trip nor the LDS write sits between two barriers
+  constexpr int PF = (NR * 64 + 511) / 512;     // elements per thread of one reflector (512 threads)
+  double pre[PF];
+  auto fetch = [&](int k) {
+#pragma unroll
+    for (int u = 0; u < PF; ++u) { const int j = threadIdx.x + 512 * u; pre[u] = (k >= 0 && j > k && j < n) ? V[(size_t)k * n + j] : 0.0; }
+  };
+  auto stash = [&](double* dst) {
+#pragma unroll
+    for (int u = 0; u < PF; ++u) { const int j = threadIdx.x + 512 * u; if (j < n) dst[j] = pre[u]; }
+  };
+  fetch(nref - 1); stash(sh);
+  fetch(nref - 2);
   __syncthreads();
   for (int k = nref - 1; k >= 0; --k) {
     const double* v = sh + (size_t)((nref - 1 - k) & 1) * n;
     double* vn = sh + (size_t)((nref - k) & 1) * n;
-    if (k > 0) for (int j = k + threadIdx.x; j < n; j += blockDim.x) vn[j] = V[(size_t)(k - 1) * n + j];   // next reflector
+    stash(vn);            // reflector k-1 (fetched during the previous iteration)
+    fetch(k - 2);         // reflector k-2: lands during this iteration and the next
     const double tk = tau[k];
     double vr[NR];
 #pragma unroll
@@ -613,7 +709,7 @@ int eig_dc_max_n(const blmm_ctx* ctx) {
   int best = 0;
   for (int n = 128; n <= 2048; n += 8) {
     const int nloc = (n + cus - 1) / cus;
-    const size_t lds = sizeof(double) * ((size_t)4 * n + 16 + (size_t)nloc * n) + 64;
+    const size_t lds = sizeof(double) * ((size_t)7 * n + 128 + (size_t)nloc * n) + 64;
     if (lds <= 156 * 1024) best = n;
   }
   return best;
@@ -646,7 +742,7 @@ int launch_eig_dc(blmm_ctx* ctx, const double* A, int n, double* lraw, double* e
   for (auto& l : levels) nnodes_total += l.size() / 3;
   // ---- workspace ----
   int rc;
-  const size_t ints = (size_t)7 * n + 4 * nnodes_total + 3 * nnodes_total + (nl + 1) + 64;
+  const size_t ints = (size_t)7 * n + 320 + 4 * nnodes_total + 3 * nnodes_total + (nl + 1) + 64;
   const size_t dbls = 5 * nn + (size_t)14 * n + nnodes_total + 64;
   if ((rc = ensure(ctx, ctx->eigW, sizeof(double) * dbls + sizeof(int) * ints + 256))) return rc;
   double* base = ptr<double>(ctx->eigW);
@@ -660,8 +756,8 @@ int launch_eig_dc(blmm_ctx* ctx, const double* A, int n, double* lraw, double* e
   double* rowbuf = Dm;
   int* ib = reinterpret_cast<int*>(rho + nnodes_total + 8);
   int* colidx = ib; int* deflcol = colidx + n; int* rota = deflcol + n; int* rotb = rota + n; int* posn = rotb + n;
-  int* posd = posn + n; int* sync = posd + n;          // sync: n ints reserved: [0] counter, [1] abort
-  int* info = sync + n; int* nodes_dev = info + 4 * nnodes_total; int* bounds_dev = nodes_dev + 3 * nnodes_total;
+  int* posd = posn + n; int* sync = posd + n;          // sync: n + 320 ints reserved: [0] abort, [8 .. 8+G) flags
+  int* info = sync + n + 320; int* nodes_dev = info + 4 * nnodes_total; int* bounds_dev = nodes_dev + 3 * nnodes_total;
   // plan -> device (tiny; cached per n in the context: the copy is skipped when n repeats)
   if (ctx->eig_plan_n != n) {
     std::vector<int> flat;
@@ -675,18 +771,23 @@ int launch_eig_dc(blmm_ctx* ctx, const double* A, int n, double* lraw, double* e
   {
     const int cus = ctx->num_cus > 0 ? ctx->num_cus : 256;
     // rows per workgroup: as many as the LDS takes beside the four vectors (fewer workgroups = a cheaper barrier)
-    const size_t budget = 156 * 1024 - sizeof(double) * ((size_t)4 * n + 16) - 64;
+    const size_t budget = 156 * 1024 - sizeof(double) * ((size_t)7 * n + 128) - 64;
     int nloc = (int)(budget / (sizeof(double) * (size_t)n));
     if (nloc < 1) return BLMM_ERR_UNSUPPORTED;
     int G = (n + nloc - 1) / nloc;
     if (G > cus) return BLMM_ERR_UNSUPPORTED;
+    // ~10 rows per workgroup measured best (n = 500: 3.6 ms at G = 48 against 4.0 at the LDS minimum of 16; tools/sweep_sytrd.sh)
+    if ((n + 9) / 10 > G) G = std::min(cus, (n + 9) / 10);
     if (const char* ge = getenv("BLMM_SYTRD_G")) { const int gv = atoi(ge); if (gv >= G && gv <= cus) G = gv; }
     nloc = (n + G - 1) / G;
-    const size_t lds = sizeof(double) * ((size_t)4 * n + 16 + (size_t)nloc * n);
-    SytrdEx ex; ex.pbuf = pbuf; ex.rowbuf = rowbuf; ex.cnt = reinterpret_cast<unsigned int*>(sync); ex.abort = sync + 1;
-    BLMM_HIP(hipMemsetAsync(sync, 0, sizeof(int) * 4, ctx->stream));
+    const size_t lds = sizeof(double) * ((size_t)7 * n + 128 + (size_t)nloc * n);
+    SytrdEx ex; ex.gr = reinterpret_cast<unsigned long long*>(rowbuf); ex.abort = sync;      // 8 n granules in Dm (unused until the merges)
+    BLMM_HIP(hipMemsetAsync(sync, 0, sizeof(int) * 8, ctx->stream));
+    BLMM_HIP(hipMemsetAsync(rowbuf, 0, sizeof(unsigned long long) * 8 * (size_t)n, ctx->stream));   // tags 0: nothing published
     BLMM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sytrd), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(k_sytrd, dim3(G), dim3(512), lds, ctx->stream, A, n, nloc, d, e, tau, V, ex, stat);
+    int nthr = 512;                                           // barriers at 1024 threads cost almost twice as much
+    if (const char* te = getenv("BLMM_SYTRD_NT")) { const int tv = atoi(te); if (tv == 256 || tv == 512) nthr = tv; }
+    hipLaunchKernelGGL(k_sytrd, dim3(G), dim3(nthr), lds, ctx->stream, A, n, nloc, d, e, tau, V, ex, stat);
     KCHECK();
   }
   // ---- 2. leaves ----
@@ -707,7 +808,7 @@ int launch_eig_dc(blmm_ctx* ctx, const double* A, int n, double* lraw, double* e
     for (int q = 0; q < nnode; ++q) Nmax = std::max(Nmax, lvl[3 * q + 2] - lvl[3 * q]);
     w.lamIn = lamIn; w.lamOut = lamOut; w.Qin = Qin; w.Qout = Qout;
     w.info = info + 4 * node_off; w.rho = rho + node_off; w.nodes = nodes_dev + 3 * node_off;
-    const size_t lds_defl = sizeof(double) * ((size_t)2 * Nmax + 16) + sizeof(int) * (size_t)Nmax + 16;
+    const size_t lds_defl = sizeof(double) * ((size_t)4 * Nmax + 16 + (Nmax + 1) / 2 + 2);
     if (lds_defl > 48 * 1024) BLMM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dc_deflate), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_defl));
     hipLaunchKernelGGL(k_dc_deflate, dim3(nnode), dim3(1024), lds_defl, ctx->stream, w);
     hipLaunchKernelGGL(k_dc_rot, dim3(nnode, (Nmax + 255) / 256), dim3(256), 0, ctx->stream, w);

@@ -681,48 +681,74 @@ __global__ void __launch_bounds__(64) k_lr_panels(NullModel nm, const double* __
 // evaluated directly (one thread per trait).  The largest squared value goes to stat[9]; a trait whose squared residual
 // exceeds tol2 is appended to flag_list (count in stat[10]) and its LOD column is recomputed by k_scan_fix from the full
 // length-n sums, so no LOD leaves the library that rests on an unchecked expansion.
-__global__ void __launch_bounds__(256) k_lr_resid(int n, int64_t m, double tol2, const double* __restrict__ lam,
+// Stage 1: block (x: 256 traits, y: a 64-row slice of the n individuals) -> partial sums of |w - Qc|^2 and |w|^2 of the
+// slice, one thread per trait (coalesced reads of its coefficients Cp[r][j]; the slice of the basis rows in LDS).
+// Stage 2 adds the slices in a fixed order (the flag decision must not depend on an atomic's arrival order).
+constexpr int LRR_KS = 64;
+constexpr int LRR_QC = 96;    // basis rows mirrored in LDS (48 KB); the (rare) rest is read from global memory
+__global__ void __launch_bounds__(256) k_lr_resid(int n, int64_t m, const double* __restrict__ lam,
                                                   const double* __restrict__ h2v, const double* __restrict__ Q,
-                                                  const int* __restrict__ rk, int qcap, const double* __restrict__ Cp,
-                                                  int64_t ldp, int* __restrict__ flag_list, int64_t* stat) {
-  // one thread per trait (coalesced reads of its coefficients Cp[r][j]); the basis rows in LDS up to qcap of them
+                                                  const int* __restrict__ rk, const double* __restrict__ Cp, int64_t ldp,
+                                                  double* __restrict__ part /* [nslice][2][ldp] */) {
   extern __shared__ __attribute__((aligned(16))) double sh[];
-  double* sLam = sh;
-  double* sQ = sh + n;
   const int R = rk[0];
   if (R < 0) return;                       // the basis kernel gave up: the call fails as a whole (stat[8] < 0)
-  const int rl = R < qcap ? R : qcap;
-  for (int e = threadIdx.x; e < n; e += blockDim.x) sLam[e] = lam[e];
-  for (int e = threadIdx.x; e < rl * n; e += blockDim.x) sQ[e] = Q[e];
+  const int k0 = blockIdx.y * LRR_KS, kc = (n - k0 < LRR_KS) ? (n - k0) : LRR_KS;
+  double* sLam = sh;                       // LRR_KS
+  double* sQ = sh + LRR_KS;                // R x LRR_KS
+  for (int e = threadIdx.x; e < kc; e += blockDim.x) sLam[e] = lam[k0 + e];
+  const int rl = R < LRR_QC ? R : LRR_QC;
+  for (int e = threadIdx.x; e < rl * LRR_KS; e += blockDim.x) {
+    const int r = e / LRR_KS, u = e % LRR_KS;
+    sQ[e] = (u < kc) ? Q[(size_t)r * n + k0 + u] : 0.0;
+  }
   __syncthreads();
+  const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= m) return;
+  const double h2 = h2v[j];
+  const double delta = h2 / (1.0 - h2);
+  double rr = 0.0, ww = 0.0;
+  constexpr int KC = 16;
+  for (int u0 = 0; u0 < kc; u0 += KC) {
+    double v[KC];
+#pragma unroll
+    for (int u = 0; u < KC; ++u) {
+      const double w = (u0 + u < kc) ? fabs(1.0 / fma(delta, sLam[u0 + u], 1.0)) : 0.0;
+      v[u] = w; ww = fma(w, w, ww);
+    }
+    for (int r = 0; r < rl; ++r) {
+      const double c = Cp[(int64_t)r * ldp + j];
+      const double* qr = sQ + r * LRR_KS + u0;     // zero padded beyond kc
+#pragma unroll
+      for (int u = 0; u < KC; ++u) v[u] = fma(-qr[u], c, v[u]);
+    }
+    for (int r = rl; r < R; ++r) {
+      const double c = Cp[(int64_t)r * ldp + j];
+      const double* qr = Q + (size_t)r * n + k0 + u0;
+#pragma unroll
+      for (int u = 0; u < KC; ++u) if (u0 + u < kc) v[u] = fma(-qr[u], c, v[u]);
+    }
+#pragma unroll
+    for (int u = 0; u < KC; ++u) rr = fma(v[u], v[u], rr);
+  }
+  part[((size_t)blockIdx.y * 2 + 0) * ldp + j] = rr;
+  part[((size_t)blockIdx.y * 2 + 1) * ldp + j] = ww;
+}
+
+__global__ void __launch_bounds__(256) k_lr_resid2(int nslice, int64_t m, double tol2, const double* __restrict__ part,
+                                                   int64_t ldp, const int* __restrict__ rk, int* __restrict__ flag_list,
+                                                   int64_t* stat) {
+  if (rk[0] < 0) return;
   const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   double rel2 = 0.0;
   if (j < m) {
-    const double h2 = h2v[j];
-    const double delta = h2 / (1.0 - h2);
     double rr = 0.0, ww = 0.0;
-    constexpr int KC = 16;
-    for (int k0 = 0; k0 < n; k0 += KC) {
-      double v[KC];
-#pragma unroll
-      for (int u = 0; u < KC; ++u) {
-        const double w = (k0 + u < n) ? fabs(1.0 / fma(delta, sLam[k0 + u < n ? k0 + u : 0], 1.0)) : 0.0;
-        v[u] = w; ww = fma(w, w, ww);
-      }
-      for (int r = 0; r < R; ++r) {
-        const double c = Cp[(int64_t)r * ldp + j];
-        const double* qr = (r < rl) ? sQ + r * n : Q + (size_t)r * n;
-#pragma unroll
-        for (int u = 0; u < KC; ++u) if (k0 + u < n) v[u] = fma(-qr[k0 + u], c, v[u]);
-      }
-#pragma unroll
-      for (int u = 0; u < KC; ++u) rr = fma(v[u], v[u], rr);
-    }
+    for (int s = 0; s < nslice; ++s) { rr += part[((size_t)s * 2 + 0) * ldp + j]; ww += part[((size_t)s * 2 + 1) * ldp + j]; }
     rel2 = rr / ww;
     if (!(rel2 >= 0.0)) rel2 = INFINITY;   // NaN counts as a failure of the expansion
     if (!(rel2 <= tol2)) {
       const unsigned long long slot = atomicAdd((unsigned long long*)&stat[10], 1ull);
-      flag_list[slot] = (int)j;
+      flag_list[slot] = (int)j;            // order of the list is immaterial: k_scan_fix recomputes whole columns
     }
   }
   // largest squared residual of the block -> stat[9] (bit pattern of a non-negative double orders like an integer)
@@ -824,14 +850,16 @@ int launch_lr_panels(blmm_ctx* ctx, const NullModel& nm, const double* Yt, int64
 
 // The guard (all traits): the caller runs it on the side stream beside the scan kernel, then launch_scan_fix.
 int launch_lr_resid(blmm_ctx* ctx, const NullModel& nm, int64_t m, double tol, const double* lam, const double* h2,
-                    const double* Q, const int* rk, const double* Cp, int64_t ldp, int* flag_list, int64_t* stat) {
+                    const double* Q, const int* rk, const double* Cp, int64_t ldp, int* flag_list, double* part, int64_t* stat) {
   if (m <= 0) return BLMM_OK;
-  const int qcap = (int)std::min<size_t>((size_t)nm.n, (56 * 1024) / (sizeof(double) * (size_t)nm.n));
-  const size_t lds = sizeof(double) * ((size_t)nm.n + (size_t)qcap * nm.n);
+  const int nslice = (nm.n + LRR_KS - 1) / LRR_KS;
+  const size_t lds = sizeof(double) * ((size_t)LRR_KS * (1 + (size_t)LRR_QC));
   if (lds > 48 * 1024)
     BLMM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_lr_resid), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  hipLaunchKernelGGL(k_lr_resid, dim3((unsigned)((m + 255) / 256)), dim3(256), lds, ctx->stream, nm.n, m, tol * tol, lam, h2, Q, rk,
-                     qcap, Cp, ldp, flag_list, stat);
+  hipLaunchKernelGGL(k_lr_resid, dim3((unsigned)((m + 255) / 256), (unsigned)nslice), dim3(256), lds, ctx->stream, nm.n, m, lam, h2, Q,
+                     rk, Cp, ldp, part);
+  hipLaunchKernelGGL(k_lr_resid2, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, ctx->stream, nslice, m, tol * tol, part, ldp, rk,
+                     flag_list, stat);
   KCHECK();
   return BLMM_OK;
 }

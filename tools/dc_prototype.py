@@ -71,13 +71,12 @@ def tql(d, e):
 
 
 def secular_root(i, dl, zl, rho):
-    """root i of 1 + rho sum z_j^2 / (dl_j - lam): returns (origin, tau, delta[j] = dl_j - lam)."""
-    K = len(dl)
+    """root i of 1 + rho sum z_j^2 / (dl_j - lam): returns (origin, tau, delta[j] = dl_j - lam).  Origin = the nearer pole;
+    Bunch-Nielsen-Sorensen iteration (psi / phi each matched by r + s / (pole - t)), bracket kept by the sign of f."""
+    K = len(dl); z2 = zl ** 2
     if i < K - 1:
-        lo, hi = dl[i], dl[i + 1]
-        mid = 0.5 * (hi - lo)
-        dj = dl - lo                                     # relative to the left pole
-        fmid = 1.0 + rho * np.sum(zl ** 2 / (dj - mid))
+        lo = dl[i]; mid = 0.5 * (dl[i + 1] - lo); dj = dl - lo
+        fmid = 1.0 + rho * np.sum(z2 / (dj - mid))
         if fmid > 0:
             org = i; a, b = 0.0, mid
         else:
@@ -85,24 +84,38 @@ def secular_root(i, dl, zl, rho):
         if fmid == 0:
             org = i; a = b = mid
     else:
-        org = K - 1; a, b = 0.0, rho * np.sum(zl ** 2)
-        # the last root lies in (dl[K-1], dl[K-1] + rho |z|^2]
-    dj = dl - dl[org]
-    f = lambda t: 1.0 + rho * np.sum(zl ** 2 / (dj - t))
-    fp = lambda t: rho * np.sum(zl ** 2 / (dj - t) ** 2)
+        org = K - 1; a, b = 0.0, rho * np.sum(z2)
+    dorg = dl[org]; dj = dl - dorg
+    poleL = dl[i] - dorg; poleR = dl[i + 1] - dorg if i < K - 1 else 0.0
     t = 0.5 * (a + b)
-    for it in range(200):
-        ft = f(t)
-        if ft == 0:
+    for it in range(100):
+        if not a < b:
             break
-        if ft > 0:
+        q = 1.0 / (dj - t); zq = z2 * q
+        ps = rho * np.sum(zq[:i + 1]); psp = rho * np.sum((zq * q)[:i + 1])
+        ph = rho * np.sum(zq[i + 1:]); php = rho * np.sum((zq * q)[i + 1:])
+        f = 1.0 + ps + ph
+        if f == 0:
+            break
+        if f > 0:
             b = t
         else:
             a = t
-        tn = t - ft / fp(t)
-        if not (a < tn < b) or it > 12:
+        dL = poleL - t; sps = psp * dL * dL; rps = ps - psp * dL
+        if i < K - 1:
+            dR = poleR - t; sph = php * dR * dR; rph = ph - php * dR
+            c = 1.0 + rps + rph
+            a2 = c; a1 = -(c * (poleL + poleR) + sps + sph); a0 = c * poleL * poleR + sps * poleR + sph * poleL
+            disc = a1 * a1 - 4.0 * a2 * a0; tn = t
+            if disc >= 0:
+                qq = -0.5 * (a1 + np.copysign(np.sqrt(disc), a1))
+                r1 = qq / a2 if a2 != 0 else a; r2 = a0 / qq if qq != 0 else a
+                tn = r1 if a < r1 < b else r2
+        else:
+            tn = poleL + sps / (1.0 + rps)
+        if not (a < tn < b):
             tn = 0.5 * (a + b)
-        if tn == t or b - a <= 2 * EPS * max(abs(a), abs(b)):
+        if tn == t or b - a <= 2 * EPS * max(abs(a), abs(b)) or abs(tn - t) <= EPS * abs(tn):
             t = tn
             break
         t = tn

@@ -1,0 +1,11 @@
+#!/bin/bash
+# eigen phase time vs the workgroup count / thread count of k_sytrd
+for n in 500 1000; do
+  for G in 0 24 32 48 64 96 128; do
+    for NT in 512 256; do
+      if [ $n = 500 ]; then args="--n 500 --p 20000 --m 512"; else args="--n 1000 --p 20000 --m 256 --method perms"; fi
+      r=$(BLMM_SYTRD_G=$G BLMM_SYTRD_NT=$NT python3 bench.py --no-cpu-baseline --no-host-api $args --steps 5 --warmup 2 2>/dev/null | python3 -c "import json,sys; j=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(round(j['phases_ms']['eigen'],3))")
+      echo "n=$n G=$G NT=$NT eigen_ms=$r"
+    done
+  done
+done
