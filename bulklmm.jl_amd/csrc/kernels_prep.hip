@@ -767,6 +767,108 @@ __global__ void __launch_bounds__(256) k_rotate_vec(const double* __restrict__ R
   if (wave == 0 && k < npad) Out[(int64_t)k * ldo + col] = (s_acc[0][lane] + s_acc[1][lane]) + (s_acc[2][lane] + s_acc[3][lane]);
 }
 
+// Rotation for large n (K dimension = n in the hundreds or thousands): a real GEMM.  Workgroup = 4 waves (2 x 2), tile
+// 128 rows of Out (k) x 32 NB columns; wave tile 64 x 16 NB = 4 x NB MFMA blocks.  No LDS: a 64-cycle f64 MFMA needs few operand
+// bytes, so fragments come straight from L2 -- but In is column-major (a column's n values contiguous), which makes the
+// natural fragment (16 lanes = 16 columns at ONE i) a 16-way strided gather.  The contraction order inside a trip of 32 i
+// is therefore permuted: lane group gq = lane >> 4 takes i = i0 + 8 gq + s at MFMA step s, so a lane reads 8 CONSECUTIVE
+// doubles of its column (64 bytes, four 16-byte loads) per trip, and the Rp fragment of a step is 16 consecutive doubles of
+// one row of Rp.  Any fixed assignment of i to (step, lane group) is a valid order of the sum, and it is the same for
+// every output element: a column's rotated values do not depend on what else is in the call (the sharding contract).
+// Block order: an XCD (blockIdx % 8) walks whole column tiles, all k tiles of one after the other, so In is fetched from
+// HBM once and re-read from that XCD's L2.
+typedef double d2ua __attribute__((ext_vector_type(2), aligned(8)));
+template <int NB, bool PREF>
+__global__ void __launch_bounds__(256, 2) k_rotate_big(const double* __restrict__ Rp, int ldr, int n, int npad,
+                                                       const double* __restrict__ In, int64_t ncols,
+                                                       double* __restrict__ Out, int64_t ldo, int64_t ncols_pad, int nkt,
+                                                       int64_t nct) {
+  constexpr int MB = 4;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int c16 = lane & 15, gq = lane >> 4;
+  // XCD-aware tile walk
+  const int64_t bid = blockIdx.x;
+  const int64_t xcd = bid & 7, idx = bid >> 3;
+  const int64_t ctile = (idx / nkt) * 8 + xcd;
+  const int ktile = (int)(idx % nkt);
+  if (ctile >= nct) return;
+  const int k0 = ktile * 128 + (wave >> 1) * 64;
+  const int64_t col0 = ctile * (32 * NB) + (wave & 1) * (16 * NB);
+  d4 acc[MB][NB];
+#pragma unroll
+  for (int a = 0; a < MB; ++a)
+#pragma unroll
+    for (int b = 0; b < NB; ++b) acc[a][b] = (d4){0, 0, 0, 0};
+  const double* pcol[NB];
+  bool cok[NB];
+#pragma unroll
+  for (int b = 0; b < NB; ++b) {
+    const int64_t col = col0 + 16 * b + c16;
+    cok[b] = col < ncols;
+    pcol[b] = In + (cok[b] ? col : 0) * (int64_t)n;
+  }
+  auto loadB = [&](double (&bv)[NB][8], int i0) {
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+      const int ib = i0 + 8 * gq;
+      if (cok[b] && ib + 8 <= n) {
+#pragma unroll
+        for (int h = 0; h < 4; ++h) { const d2ua v = *reinterpret_cast<const d2ua*>(pcol[b] + ib + 2 * h); bv[b][2 * h] = v[0]; bv[b][2 * h + 1] = v[1]; }
+      } else {
+#pragma unroll
+        for (int s = 0; s < 8; ++s) bv[b][s] = (cok[b] && ib + s < n) ? pcol[b][ib + s] : 0.0;
+      }
+    }
+  };
+  auto loadA = [&](double (&av)[MB], int i) {     // Rp has npad rows (zero beyond n), ldr columns
+    const double* pr = Rp + (size_t)(i < npad ? i : 0) * ldr + c16;
+#pragma unroll
+    for (int a = 0; a < MB; ++a) { const int k = k0 + 16 * a; av[a] = (i < npad && k + c16 < ldr) ? pr[k] : 0.0; }
+  };
+  double bcur[NB][8], bnext[PREF ? NB : 1][8];
+  loadB(bcur, 0);
+  for (int i0 = 0; i0 < n; i0 += 32) {
+    if constexpr (PREF) { if (i0 + 32 < n) loadB(bnext, i0 + 32); }
+    double a0[MB], a1[MB];
+    loadA(a0, i0 + 8 * gq);
+#pragma unroll
+    for (int s = 0; s < 8; s += 2) {
+      loadA(a1, i0 + 8 * gq + s + 1);
+#pragma unroll
+      for (int a = 0; a < MB; ++a)
+#pragma unroll
+        for (int b = 0; b < NB; ++b) acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[a], bcur[b][s], acc[a][b], 0, 0, 0);
+      if (s + 2 < 8) loadA(a0, i0 + 8 * gq + s + 2);
+#pragma unroll
+      for (int a = 0; a < MB; ++a)
+#pragma unroll
+        for (int b = 0; b < NB; ++b) acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[a], bcur[b][s + 1], acc[a][b], 0, 0, 0);
+    }
+    if (i0 + 32 < n) {
+      if constexpr (PREF) {
+#pragma unroll
+        for (int b = 0; b < NB; ++b)
+#pragma unroll
+          for (int s = 0; s < 8; ++s) bcur[b][s] = bnext[b][s];
+      } else {
+        loadB(bcur, i0 + 32);
+      }
+    }
+  }
+#pragma unroll
+  for (int a = 0; a < MB; ++a)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int k = k0 + 16 * a + gq + 4 * r;
+      if (k >= npad) continue;
+#pragma unroll
+      for (int b = 0; b < NB; ++b) {
+        const int64_t col = col0 + 16 * b + c16;
+        if (col < ncols_pad) Out[(int64_t)k * ldo + col] = acc[a][b][r];
+      }
+    }
+}
+
 int launch_rotate(blmm_ctx* ctx, const double* Rp, int ldr, int n, int npad, const double* In, int64_t ncols,
                   double* Out, int64_t ldo, int64_t ncols_pad) {
   if (ncols > 0 && ncols <= 4 && n > 256) {
@@ -775,6 +877,21 @@ int launch_rotate(blmm_ctx* ctx, const double* Rp, int ldr, int n, int npad, con
       hipLaunchKernelGGL(k_rotate_vec, dim3((unsigned)((npad + 63) / 64)), dim3(256), 0, ctx->stream, Rp, ldr, n, npad, In, col, Out, ldo);
     KCHECK();
     return BLMM_OK;
+  }
+  if (n > 160 && ncols >= 64 && !(getenv("BLMM_ROTATE") && std::strcmp(getenv("BLMM_ROTATE"), "small") == 0)) {
+    const int nkt = (npad + 127) / 128;
+    const char* rv = getenv("BLMM_ROTATE_TILE");   // "64": 128 x 64 tiles with the B fragments prefetched (A/B timing)
+    const bool wide = !(rv && std::strcmp(rv, "64") == 0);
+    const int64_t nct = (ncols_pad + (wide ? 127 : 63)) / (wide ? 128 : 64);
+    const int64_t nblk = ((nct + 7) / 8) * 8 * nkt;           // every XCD walks ceil(nct / 8) column tiles
+    if (nblk <= 0x7fffffffLL) {
+      if (wide) hipLaunchKernelGGL((k_rotate_big<4, false>), dim3((unsigned)nblk), dim3(256), 0, ctx->stream, Rp, ldr, n, npad, In, ncols, Out, ldo,
+                                   ncols_pad, nkt, nct);
+      else hipLaunchKernelGGL((k_rotate_big<2, true>), dim3((unsigned)nblk), dim3(256), 0, ctx->stream, Rp, ldr, n, npad, In, ncols, Out, ldo,
+                         ncols_pad, nkt, nct);
+      KCHECK();
+      return BLMM_OK;
+    }
   }
   constexpr int MBLK = 5;
   const int nrb = (npad + 15) / 16;
