@@ -11,7 +11,7 @@ BASELINE.json configs[1]) whose inputs are already resident in HBM; the p x m LO
         bench.py --gpus N --steps K --warmup W
 
 N > 1: one process per GPU.  Without WORLD_SIZE in the environment `--gpus N` starts the N ranks itself
-(torch.distributed.run as a child process, BEFORE anything touches the GPU in this one).  The headline for N > 1 is
+(one child process per GPU with the torchrun environment, BEFORE anything touches the GPU in this one).  The headline for N > 1 is
 STRONG scaling of the ONE BXD-shaped problem (BASELINE.json's metric: "full BXD-shaped bulkscan wall-time at 1/2/4/8
 GPUs"): rank r scans the trait block sharding.trait_shard(m, r, N); no data-path collective in the timed region.  The
 north_star's optional final step -- an RCCL all-gather of the LOD column blocks over xGMI -- is timed separately
@@ -102,15 +102,20 @@ def main():
     a = ap.parse_args()
 
     if "WORLD_SIZE" not in os.environ and a.gpus > 1:
-        # start the ranks ourselves; nothing in this process has touched the GPU yet (no torch import, no HIP call)
+        # start the ranks ourselves, one child process per GPU with the torchrun environment (RANK / LOCAL_RANK /
+        # WORLD_SIZE / MASTER_*); nothing in this process has touched the GPU (no torch import, no HIP call), and it only
+        # waits for them.  (torch.distributed.run would do, but its argument parser claims bench.py's short options.)
         import socket
         import subprocess
         with socket.socket() as sk:
             sk.bind(("127.0.0.1", 0))
             port = sk.getsockname()[1]
-        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}",
-               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
-        raise SystemExit(subprocess.run(cmd).returncode)
+        procs = []
+        for r in range(a.gpus):
+            env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(a.gpus), LOCAL_WORLD_SIZE=str(a.gpus),
+                       MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+            procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+        raise SystemExit(max(p.wait() for p in procs))
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))

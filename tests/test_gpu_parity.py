@@ -8,6 +8,8 @@ Tolerances (fp64; BASELINE.json north_star):
     implementations (the reference's own scan vs bulkscan_null included) agree on h2 only to ~1e-7;
   * end-to-end with each side's own h2: the reference's own criterion sum_i (dLOD_i)^2 <= 1e-7 per trait
     (test/bulkscan_test.jl:77-78), plus a loose element-wise 1e-4*|ref| + 1e-8."""
+import os
+
 import numpy as np
 import pytest
 
@@ -561,7 +563,7 @@ def test_lod2log10p_on_device(blmm, df):
     got = blmm.lod2log10p(lod, df)
     ref = O.lod2log10p(lod, df)
     fin = np.isfinite(ref)             # SciPy's logsf underflows to -inf from LOD ~ 330 on; the device's log-space form does not
-    assert fin.sum() >= lod.size - 4
+    assert fin.sum() >= 0.9 * lod.size
     assert np.all(np.abs(got[fin] - ref[fin]) <= 1e-10 * np.abs(ref[fin]) + 1e-14), float(np.max(np.abs(got[fin] - ref[fin]) / np.maximum(np.abs(ref[fin]), 1e-300)))
     assert np.isfinite(got).all()
     if df == 1:   # beyond SciPy's range: the asymptotic series of erfc, ln erfc(x) = -x^2 - ln(x sqrt(pi)) + ln(1 - 1/(2x^2) + 3/(4x^4) - 15/(8x^6))
@@ -657,3 +659,25 @@ def test_dc_eigensolver_small_n_and_end_to_end(blmm, monkeypatch):
     assert np.sum((dc.L - base.L) ** 2, axis=0).max() <= 1e-7
     pin = O.bulkscan_null(Y, G, K, h2_override=dc.h2_null_list)
     assert_lod_close(dc.L, pin.L)
+
+
+def test_bench_starts_its_own_ranks_and_shards_ragged(tmp_path):
+    """bench.py --gpus 2 without WORLD_SIZE must start the two ranks itself (torch.distributed.run as a child) and report
+    n_gpus = 2, strong scaling of ONE problem as the headline with the other mode beside it; m = 1001 makes the shards
+    ragged (501 + 500).  Rehearsed on this one-GPU box with the gloo backend (ranks share GPU 0; the RCCL all-gather is
+    skipped), which exercises everything but the collective itself."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env["BLMM_BENCH_BACKEND"] = "gloo"
+    run = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--n", "79", "--p", "500", "--m", "1001",
+                          "--steps", "2", "--warmup", "1", "--no-cpu-baseline"], capture_output=True, text=True, timeout=600, env=env)
+    assert run.returncode == 0, run.stdout[-2000:] + run.stderr[-3000:]
+    line = [l for l in run.stdout.splitlines() if l.startswith("{")][-1]
+    j = json.loads(line)
+    assert j["n_gpus"] == 2 and j["scaling"] == "strong" and j["output_finite"] is True
+    assert j["config"]["m"] == 1001 and j["config"]["m_per_gpu"] == 501
+    assert j["other_scaling"]["scaling"] == "weak" and j["other_scaling"]["m_per_gpu"] == 1001
+    assert j["value"] > 0 and j["ms_per_step"] > 0 and j["roofline"]["frac"] > 0
