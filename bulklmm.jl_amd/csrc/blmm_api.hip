@@ -281,7 +281,13 @@ int prepare(blmm_ctx* ctx, const blmm_opts* o, const double* dY, int64_t n, int6
   bool used_rs = false, done = false;
   const bool want_dc = eig_env ? std::strcmp(eig_env, "dc") == 0 : big;
   const bool want_rs = eig_env ? std::strcmp(eig_env, "rocsolver") == 0 : false;
-  if (want_dc && n >= 3) {
+  const bool want_small = eig_env && std::strcmp(eig_env, "small") == 0;    // the fused single-workgroup solver (n <= 92)
+  if (want_small && n >= 3 && n <= eig_small_max_n()) {
+    rc = launch_eig_small(ctx, ptr<double>(ctx->Ks), (int)n, ptr<double>(ctx->lraw), ptr<double>(ctx->V), P.stat);
+    if (rc == BLMM_OK) { done = true; P.big = true; }
+    else if (rc != BLMM_ERR_UNSUPPORTED) return rc;
+  }
+  if (!done && want_dc && n >= 3) {
     rc = launch_eig_dc(ctx, ptr<double>(ctx->Ks), (int)n, ptr<double>(ctx->lraw), ptr<double>(ctx->V), P.stat);
     if (rc == BLMM_OK) { done = true; P.big = true; }
     else if (rc != BLMM_ERR_UNSUPPORTED) return rc;

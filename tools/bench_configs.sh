@@ -3,7 +3,7 @@
 set -o pipefail
 OUT=${1:-gpurun_out/configs.jsonl}
 : > $OUT
-run() { echo "== $*" >&2; python3 bench.py --no-cpu-baseline "$@" 2>/dev/null | tail -n 1 >> $OUT || exit 1; }
+run() { echo "== $*" >&2; python3 bench.py --no-cpu-baseline --no-host-api "$@" 2>/dev/null | tail -n 1 >> $OUT || exit 1; }
 run                                                        # configs[1]: bulkscan_null, BXD shape
 run --method null-grid                                     # configs[3]: 16-point h2 grid, BXD shape (one GPU's view: full m)
 run --method null-grid --m 4445                            # configs[3]: one of 8 shards

@@ -1,0 +1,61 @@
+"""Condenses a tools/profile_round2.sh output directory into the tracked summaries under profiles/:
+r02_summary.json (per LOD kernel: rocprof average duration, HBM bytes per launch from the FETCH_SIZE / WRITE_SIZE passes with
+the gfx950 x2 correction on FETCH_SIZE, matrix-pipe busy fraction), the kernel-stats CSVs, the bench lines."""
+import csv
+import glob
+import json
+import os
+import re
+import shutil
+import sys
+
+out = sys.argv[1]
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+prof = os.path.join(root, "profiles")
+KERN = {"exact": "k_scan_lr", "grid": "k_scan<", "alt": "k_scan_alt", "perm32": "k_scan_f32"}
+ARGS = {"exact": "(default)", "grid": "--method null-grid", "alt": "--method alt-grid",
+        "perm32": "--method perms --perm-dtype f32 --n 1000 --p 100000 --m 1250"}
+
+
+def counter_avgs(d, kern):
+    acc = {}
+    for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+        for r in csv.DictReader(open(f)):
+            if kern in r["Kernel_Name"]:
+                acc.setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
+    return {k: sum(v) / len(v) for k, v in acc.items()}
+
+
+summary = {}
+for tag, kern in KERN.items():
+    st = glob.glob(os.path.join(out, tag, "trace", "**", "*kernel_stats.csv"), recursive=True)
+    if not st:
+        continue
+    shutil.copy(st[0], os.path.join(prof, f"r02_kernel_stats_{tag}.csv"))
+    row = next((r for r in csv.DictReader(open(st[0])) if kern in r["Name"]), None)
+    s = {"kernel": row["Name"].split("(")[0] if row else kern, "bench_args": ARGS[tag],
+         "rocprof_avg_ms": float(row["AverageNs"]) / 1e6 if row else None, "calls": int(row["Calls"]) if row else 0}
+    for c in ("FETCH_SIZE", "WRITE_SIZE", "SQ_WAVE_CYCLES"):
+        s.update({k: v for k, v in counter_avgs(os.path.join(out, tag, "pmc_" + c), kern).items()})
+    if "FETCH_SIZE" in s and "WRITE_SIZE" in s:   # rocprofv3 reports KB; FETCH_SIZE counts half of wide coalesced reads on gfx950
+        s["hbm_fetch_bytes"] = s["FETCH_SIZE"] * 1024 * 2
+        s["hbm_write_bytes"] = s["WRITE_SIZE"] * 1024
+        s["hbm_bytes_per_launch"] = s["hbm_fetch_bytes"] + s["hbm_write_bytes"]
+    if "SQ_VALU_MFMA_BUSY_CYCLES" in s and "GRBM_GUI_ACTIVE" in s:
+        s["mfma_busy_frac"] = (s["SQ_VALU_MFMA_BUSY_CYCLES"] / 1024) / (s["GRBM_GUI_ACTIVE"] / 8)   # 1024 SIMDs; GUI_ACTIVE sums 8 XCDs
+        if s["rocprof_avg_ms"]:
+            s["effective_clock_GHz"] = s["GRBM_GUI_ACTIVE"] / 8 / (s["rocprof_avg_ms"] * 1e-3) / 1e9
+    summary[tag] = s
+json.dump(summary, open(os.path.join(prof, "r02_summary.json"), "w"), indent=1)
+for name in ("bench.json", "configs.jsonl", "mb3_f64.log", "mb_f64.log"):
+    src = os.path.join(out, name)
+    if os.path.exists(src):
+        shutil.copy(src, os.path.join(prof, "r02_" + name))
+if "exact" in summary and summary["exact"].get("hbm_bytes_per_launch"):
+    e = summary["exact"]
+    json.dump({"method": "null-exact", "m": 35554, "p": 7321, "hbm_bytes_per_launch": e["hbm_bytes_per_launch"],
+               "fetch_bytes": e["hbm_fetch_bytes"], "write_bytes": e["hbm_write_bytes"], "rocprof_kernel_avg_ms": e["rocprof_avg_ms"],
+               "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) and --kernel-trace --stats, k_scan_lr<1,2,4>, "
+                         "profiles/r02_summary.json; FETCH_SIZE x2 per MI355X_MICROARCH.md (gfx950 wide coalesced reads); "
+                         "Infinity-Cache hits are counted"}, open(os.path.join(prof, "traffic_latest.json"), "w"), indent=1)
+print(json.dumps(summary, indent=1))
