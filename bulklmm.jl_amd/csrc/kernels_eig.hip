@@ -777,7 +777,7 @@ __device__ void small_merge(const SmallWs& w, int n, int lo, int mid, int hi, co
     s_info[0] = K; s_info[1] = nd; s_info[2] = nr;
   }
   __syncthreads();
-  const int K = s_info[0], nd = s_info[1], nr = s_info[2];
+  const int K = s_info[0], nr = s_info[2];
   // Givens rotations of the close-pole deflations: one thread per row of the node
   if (nr > 0 && t < N) {
     double* row = w.M2 + (lo + t) * n;
@@ -910,9 +910,16 @@ __global__ void __launch_bounds__(1024) k_eig_small(const double* __restrict__ A
     w.colidx = iq; iq += n; w.deflcol = iq; iq += n; w.rota = iq; iq += n; w.rotb = iq; iq += n; w.posn = iq; iq += n;
     w.posd = iq; iq += n; w.ord = iq; iq += n; w.srck = iq; iq += n; w.srci = iq; iq += n;
   }
+#ifdef SYTRD_PROF
+  long long qf[6] = {0, 0, 0, 0, 0, 0}, qt0 = __builtin_amdgcn_s_memtime();
+#define QSTAMP(i) do { const long long t1__ = __builtin_amdgcn_s_memtime(); qf[i] += t1__ - qt0; qt0 = t1__; } while (0)
+#else
+#define QSTAMP(i) do { } while (0)
+#endif
   for (int e0 = t; e0 < n * n; e0 += NT) { w.M1[e0] = A[e0]; w.M2[e0] = 0.0; }
   for (int j = t; j < n; j += NT) { w.svp[j] = 0.0; w.swp[j] = 0.0; }
   __syncthreads();
+  QSTAMP(0);
   // ---- 1. tridiagonalisation ----------------------------------------------------------------------------------------
   // wave 0 prepares step 0: x = column 0, its Householder vector
   auto householder = [&](int k, double akk) {   // wave 0: from sx[k+1 ..] -> sv, s_sc; reflector k -> Vg
@@ -987,6 +994,7 @@ __global__ void __launch_bounds__(1024) k_eig_small(const double* __restrict__ A
     }
     __syncthreads();
   }
+  QSTAMP(1);
   // ---- 2. leaves: implicit QL, one wave per leaf ---------------------------------------------------------------------
   int nl = 1;
   while ((n + nl - 1) / nl > 24) nl *= 2;
@@ -1055,6 +1063,7 @@ __global__ void __launch_bounds__(1024) k_eig_small(const double* __restrict__ A
     if (r < N) w.lamA[lo + r] = lv;
   }
   __syncthreads();
+  QSTAMP(2);
   // ---- 3. merges -----------------------------------------------------------------------------------------------------
   double* lamIn = w.lamA; double* lamOut = w.lamB;
   for (int width = 1; width < nl; width *= 2) {
@@ -1065,6 +1074,7 @@ __global__ void __launch_bounds__(1024) k_eig_small(const double* __restrict__ A
     { double* tmp = lamIn; lamIn = lamOut; lamOut = tmp; }
     __syncthreads();
   }
+  QSTAMP(3);
   // ---- 4. back-transformation U = H Z: reflectors back into LDS (M1), every wave owns columns of Z in registers ------
   for (int e0 = t; e0 < (n - 2) * n; e0 += NT) w.M1[e0] = Vg[e0];
   __syncthreads();
@@ -1080,6 +1090,10 @@ __global__ void __launch_bounds__(1024) k_eig_small(const double* __restrict__ A
     if (lane + 64 < n) evec[c * n + lane + 64] = z1;
   }
   for (int j = t; j < n; j += NT) lam_out[j] = lamIn[j];
+  QSTAMP(4);
+#ifdef SYTRD_PROF
+  if (t == 0) printf("eig_small prof n %d: load %lld reduction %lld leaves %lld merges %lld backtransform %lld cycles\n", n, qf[0], qf[1], qf[2], qf[3], qf[4]);
+#endif
 }
 
 }  // namespace

@@ -601,14 +601,24 @@ __global__ void __launch_bounds__(256, 2) k_scan_alt(AltArgs aa, int ntile_i, in
       for (int g = 1; g < G; ++g) l0 = fmax(l0, aa.EllTab[trait * (int64_t)G + g]);
       double* dst = a.L + trait * a.ldL + ibase;
       double* dh = aa.H2 + trait * aa.ldH + ibase;
+      double lv[NB], hv[NB];
 #pragma unroll
       for (int nb = 0; nb < NB; ++nb) {
-        if (ibase + nb < a.p) {
-          const double v = (best[mb][nb][reg] - l0) / ln10;
-          nnan += (v != v);
-          __builtin_nontemporal_store(v, dst + nb);
-          __builtin_nontemporal_store(aa.grid_dev[bidx[mb][nb][reg]], dh + nb);
-        }
+        lv[nb] = (best[mb][nb][reg] - l0) / ln10;
+        hv[nb] = aa.grid_dev[bidx[mb][nb][reg]];
+        nnan += (lv[nb] != lv[nb]) && (ibase + nb < a.p);
+      }
+      if (NB == 4 && ibase + NB <= a.p) {
+        // 16-byte stores (8-byte aligned: ld = p may be odd): four single 8-byte nontemporal stores per lane cost ~4x the
+        // HBM write traffic of the matrix (rocprofv3 WRITE_SIZE 17.6 GB against 4.16 GB algorithmic, profiles/r02_summary.json)
+        __builtin_nontemporal_store((d2u){lv[0], lv[1]}, reinterpret_cast<d2u*>(dst));
+        __builtin_nontemporal_store((d2u){lv[2], lv[3]}, reinterpret_cast<d2u*>(dst + 2));
+        __builtin_nontemporal_store((d2u){hv[0], hv[1]}, reinterpret_cast<d2u*>(dh));
+        __builtin_nontemporal_store((d2u){hv[2], hv[3]}, reinterpret_cast<d2u*>(dh + 2));
+      } else {
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+          if (ibase + nb < a.p) { dst[nb] = lv[nb]; dh[nb] = hv[nb]; }
       }
     }
   if (nnan) atomicAdd((unsigned long long*)&a.stat[ST_NAN_LOD], (unsigned long long)nnan);

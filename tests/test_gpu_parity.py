@@ -681,3 +681,23 @@ def test_bench_starts_its_own_ranks_and_shards_ragged(tmp_path):
     assert j["config"]["m"] == 1001 and j["config"]["m_per_gpu"] == 501
     assert j["other_scaling"]["scaling"] == "weak" and j["other_scaling"]["m_per_gpu"] == 1001
     assert j["value"] > 0 and j["ms_per_step"] > 0 and j["roofline"]["frac"] > 0
+
+
+@pytest.mark.parametrize("n", [3, 5, 24, 25, 47, 64, 79, 92])
+def test_fused_small_eigensolver(blmm, n, monkeypatch):
+    """BLMM_EIGEN=small: the whole decomposition (reduction, leaves, merges, back-transformation) in ONE workgroup with
+    the matrix in LDS (kernels_eig.hip: k_eig_small).  Same accuracy bar as the other solvers, same adversarial matrices."""
+    monkeypatch.setenv("BLMM_EIGEN", "small")
+    rng = np.random.default_rng(1000 + n)
+    mats = [(name, K) for name, K in _kinds(n, rng)] if n >= 8 else [("random", (lambda S: S @ S.T)(rng.standard_normal((n, n))))]
+    if n == 79:
+        mats.append(("bxd", bxd_kinship()))
+    for name, K in mats:
+        K = 0.5 * (K + K.T)
+        Y0, _, lam = blmm.transform_rotation(np.eye(n), np.ones((n, 2)), K)
+        U = Y0.T
+        sc = max(np.abs(K).max(), 1e-300)
+        assert np.all(np.diff(lam) >= 0), name
+        assert np.abs(U.T @ U - np.eye(n)).max() <= 1e-13, (name, np.abs(U.T @ U - np.eye(n)).max())
+        assert np.abs(K @ U - U * lam).max() <= 2e-13 * sc * n, (name, np.abs(K @ U - U * lam).max() / sc)
+        assert np.abs(lam - np.linalg.eigvalsh(K)).max() <= 1e-12 * sc * np.sqrt(n), name

@@ -16,4 +16,14 @@ for n in (79, 500, 1000):
         B.transform_rotation(np.eye(n)[:, :2], np.ones((n, 2)), K)
         B.transform_rotation(np.eye(n)[:, :2], np.ones((n, 2)), K)
 PY
+python3 - <<'PY'
+import numpy as np, sys, os
+sys.path.insert(0, "."); sys.path.insert(0, "tests")
+import bulklmm_jl_amd as B
+from common import bxd_kinship
+os.environ["BLMM_EIGEN"] = "small"
+K = bxd_kinship()
+for _ in range(2):
+    B.transform_rotation(np.eye(79)[:, :2], np.ones((79, 2)), K)
+PY
 cd bulklmm.jl_amd/csrc && touch kernels_eig.hip && make -j8 > /dev/null 2>&1
