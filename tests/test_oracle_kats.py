@@ -264,3 +264,18 @@ def test_bxd_readme_and_lmmlite_kats():
         lods = np.array([float(x[4]) for x in rows])
         got = O.scan(ph[:, 7918], ge, K, reml=reml)["lod"]
         assert np.max((got - lods) ** 2) <= 1e-9 and np.sum((got - lods) ** 2) <= np.sqrt(1e-9)
+
+
+@pytest.mark.skipif(__import__("shutil").which("gcc") is None, reason="no gcc")
+@pytest.mark.parametrize("ncov,reml,prior,oi", [(0, False, (1.0, 0.0), 1), (2, True, (1.0, 0.1), 1), (1, False, (0.0, 0.0), 3)])
+def test_c_openmp_restatement_equals_numpy_restatement(ncov, reml, prior, oi):
+    """oracle/bulkscan_null_ref.c (the CPU baseline bench.py times) against oracle/bulklmm_oracle.py: two independently
+    written restatements of src/bulkscan.jl:212-314 (own Jacobi eigensolver and Householder QR there, LAPACK here)."""
+    from oracle import cref
+    Y, G, K, Cov = make_data(p=90, m=12, seed=909 + ncov, ncov=ncov)
+    L, h2 = cref.bulkscan_null(Y, G, K, Cov, prior_variance=prior[0], prior_sample_size=prior[1], reml=reml, optim_interval=oi, nthreads=2)
+    ref = O.bulkscan_null(Y, G, K, Covar=Cov, prior_variance=prior[0], prior_sample_size=prior[1], reml=reml, optim_interval=oi)
+    assert np.abs(h2 - ref.h2_null_list).max() <= 1e-6
+    pin = O.bulkscan_null(Y, G, K, Covar=Cov, prior_variance=prior[0], prior_sample_size=prior[1], reml=reml, h2_override=h2)
+    assert np.abs(L - pin.L).max() <= 1e-9 * max(1.0, np.abs(pin.L).max())
+    assert np.sum((L - ref.L) ** 2, axis=0).max() <= 1e-7
