@@ -60,6 +60,15 @@ __device__ __forceinline__ double wprod(double x) {
   x *= dpp_mov<0xB1>(x); x *= dpp_mov<0x4E>(x); x *= dpp_mov<0x141>(x); x *= dpp_mov<0x140>(x);
   return (lane_bcast(x, 0) * lane_bcast(x, 16)) * (lane_bcast(x, 32) * lane_bcast(x, 48));
 }
+// 1/sqrt(h) from v_rsq_f64 (good to ~5e-8) and two Newton steps (~1 ulp), for h > 0: the QL rotations take one of these
+// instead of an IEEE sqrt followed by an IEEE division (~400 dependent cycles)
+__device__ __forceinline__ double fast_rsqrt(double h) {
+  double y = __builtin_amdgcn_rsq(h);
+  double e = fma(-h * y, y, 1.0);
+  y = fma(0.5 * y, e, y);
+  e = fma(-h * y, y, 1.0);
+  return fma(0.5 * y, e, y);
+}
 // sum over the workgroup; every thread gets the result.  red: >= 16 doubles of LDS.  Two barriers.
 __device__ __forceinline__ double block_sum(double x, double* red) {
   x = wsum(x);
@@ -139,6 +148,17 @@ __global__ void __launch_bounds__(512) k_sytrd(const double* __restrict__ A, int
   for (int j = t; j < n; j += NT) { sx[j] = (j >= 1) ? A[j] : 0.0; svp[j] = 0.0; swp[j] = 0.0; }   // column 0; no pending update yet
   double akk = A[0];
   __syncthreads();
+  // per-wave partial sums of the three reductions a step opens with, written at the END of the previous step (here: for
+  // step 0) into rdA[parity]: |x|^2, vp'x, wp'x over j >= k+2
+  double* rdA = red;            // [2][3][16]
+  double* rdB = red + 96;       // [16] partial p'x of the gather
+  {
+    double s1 = 0.0;
+    for (int j = 2 + t; j < n; j += NT) s1 = fma(sx[j], sx[j], s1);
+    s1 = wsum(s1);
+    if (lane == 0) { rdA[wave] = s1; rdA[16 + wave] = 0.0; rdA[32 + wave] = 0.0; }
+  }
+  __syncthreads();
   bool aborted = false;
 #ifdef SYTRD_PROF
   long long pf[6] = {0, 0, 0, 0, 0, 0}, pt0 = __builtin_amdgcn_s_memtime();
@@ -148,15 +168,12 @@ __global__ void __launch_bounds__(512) k_sytrd(const double* __restrict__ A, int
 #endif
   for (int k = 0; k + 2 < n; ++k) {
     const int par = k & 1;
-    double* rd = red + par * 64;
-    // (1) one pass, three sums over j >= k+2:  |x|^2,  vp'x,  wp'x   (the pending pair's products with v follow from them)
+    // (a) the step's scalars from the partial sums (every thread, redundantly: no barrier)
     double s1 = 0.0, s2 = 0.0, s3 = 0.0;
-    for (int j = k + 2 + t; j < n; j += NT) { const double x = sx[j]; s1 = fma(x, x, s1); s2 = fma(svp[j], x, s2); s3 = fma(swp[j], x, s3); }
-    s1 = wsum(s1); s2 = wsum(s2); s3 = wsum(s3);
-    if (lane == 0) { rd[wave] = s1; rd[16 + wave] = s2; rd[32 + wave] = s3; }
-    __syncthreads();                                                   // barrier 1
-    s1 = 0.0; s2 = 0.0; s3 = 0.0;
-    for (int q = 0; q < nwave; ++q) { s1 += rd[q]; s2 += rd[16 + q]; s3 += rd[32 + q]; }
+    {
+      const double* rd = rdA + par * 48;
+      for (int q = 0; q < nwave; ++q) { s1 += rd[q]; s2 += rd[16 + q]; s3 += rd[32 + q]; }
+    }
     const double alpha = sx[k + 1];
     double beta, tk, sc;
     if (s1 == 0.0) { beta = alpha; tk = 0.0; sc = 0.0; }
@@ -164,7 +181,7 @@ __global__ void __launch_bounds__(512) k_sytrd(const double* __restrict__ A, int
     const double vpk1 = svp[k + 1], wpk1 = swp[k + 1];
     const double vpv = fma(sc, s2, vpk1), wpv = fma(sc, s3, wpk1);      // vp'v and wp'v with v = (1, sc x[k+2:])
     PSTAMP(0);
-    // (2) owned rows i > k:  p_i = tau ((A v)_i - vp_i (wp'v) - wp_i (vp'v)),  a_i = A[i][k+1] with the pending update applied
+    // (b) owned rows i > k:  p_i = tau ((A v)_i - vp_i (wp'v) - wp_i (vp'v)),  a_i = A[i][k+1] with the pending update applied
     const int li0 = (k + 1 > g) ? (k + 1 - g + G - 1) / G : 0;    // first local row with global index > k
     for (int li = li0 + wave; li < nloc; li += nwave) {
       const int i = g + li * G;
@@ -188,7 +205,7 @@ __global__ void __launch_bounds__(512) k_sytrd(const double* __restrict__ A, int
       }
     }
     PSTAMP(1);
-    // (3) the pending rank-2 update (step k-1) of the same rows this wave just used, while the exchange is in flight
+    // (c) the pending rank-2 update (step k-1) of the same rows this wave just used, while the exchange is in flight
     if (k > 0) {
       for (int li = li0 + wave; li < nloc; li += nwave) {
         const int i = g + li * G;
@@ -198,10 +215,11 @@ __global__ void __launch_bounds__(512) k_sytrd(const double* __restrict__ A, int
       }
     }
     PSTAMP(2);
-    // (4) gather p and a of every row j > k
+    // (d) gather p and a of every row j > k; partial p'x on the way
+    double s4 = 0.0;
+    bool bad = false;
     if (G > 1) {
       const unsigned int want = (unsigned int)(k + 1);
-      bool bad = false;
       for (int j = k + 1 + t; j < n && !bad; j += NT) {
         const unsigned long long* gq = ex.gr + ((size_t)par * n + j) * 4;
         unsigned long long q0, q1, q2, q3;
@@ -216,44 +234,51 @@ __global__ void __launch_bounds__(512) k_sytrd(const double* __restrict__ A, int
           __builtin_amdgcn_s_sleep(1);
           if (++spin > (1 << 22) || ((spin & 1023) == 0 && __hip_atomic_load(ex.abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) { bad = true; break; }
         }
-        sp[j] = __longlong_as_double((long long)((q1 << 32) | (q0 & 0xffffffffull)));
+        const double pj = __longlong_as_double((long long)((q1 << 32) | (q0 & 0xffffffffull)));
+        sp[j] = pj;
         sa[j] = __longlong_as_double((long long)((q3 << 32) | (q2 & 0xffffffffull)));
+        if (j > k + 1) s4 = fma(pj, sx[j], s4);
       }
       if (bad) __hip_atomic_store(ex.abort, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (__syncthreads_or(bad ? 1 : 0)) { aborted = true; break; }     // barrier 2
     } else {
-      __syncthreads();                                                   // barrier 2
+      __syncthreads();     // G = 1: sp / sa were written by the row waves of this workgroup
+      for (int j = k + 2 + t; j < n; j += NT) s4 = fma(sp[j], sx[j], s4);
     }
-    PSTAMP(3);
-    // (5) p'v, then w = p - (tau/2)(p'v) v
-    double s4 = 0.0;
-    for (int j = k + 2 + t; j < n; j += NT) s4 = fma(sp[j], sx[j], s4);
     s4 = wsum(s4);
-    if (lane == 0) rd[48 + wave] = s4;
-    __syncthreads();                                                     // barrier 3
+    if (lane == 0) rdB[wave] = s4;
+    if (__syncthreads_or(bad ? 1 : 0)) { aborted = true; break; }        // barrier X
+    PSTAMP(3);
+    // (e) p'v, w = p - (tau/2)(p'v) v; (f) this step's pair, the next column in place, and the next step's three sums
     s4 = 0.0;
-    for (int q = 0; q < nwave; ++q) s4 += rd[48 + q];
+    for (int q = 0; q < nwave; ++q) s4 += rdB[q];
     const double pk1 = sp[k + 1];
     const double cw = 0.5 * tk * fma(sc, s4, pk1);
     const double wk1 = pk1 - cw;                                         // v[k+1] = 1
     const bool vown = (g == k % G);
+    double n1 = 0.0, n2 = 0.0, n3 = 0.0;
     for (int j = k + 1 + t; j < n; j += NT) {
       const double v = (j == k + 1) ? 1.0 : sx[j] * sc;
       const double wj = fma(-cw, v, sp[j]);
       svc[j] = v; swc[j] = wj;
       if (vown) V[(size_t)k * n + j] = v;
-      if (j > k + 1) sa[j] = sa[j] - wj - wk1 * v;                       // the next column, in place
+      if (j > k + 1) {
+        const double xn = sa[j] - wj - wk1 * v;                          // the next column, in place
+        sa[j] = xn;
+        if (j > k + 2) { n1 = fma(xn, xn, n1); n2 = fma(v, xn, n2); n3 = fma(wj, xn, n3); }
+      }
     }
+    n1 = wsum(n1); n2 = wsum(n2); n3 = wsum(n3);
+    if (lane == 0) { double* rn = rdA + (par ^ 1) * 48; rn[wave] = n1; rn[16 + wave] = n2; rn[32 + wave] = n3; }
     if (vown && t == 0) { d[k] = akk; e[k] = beta; tau[k] = tk; }
-    akk = sa[k + 1] - 2.0 * wk1;                                         // read before anyone overwrites it: sa[k+1] is not written above
-    __syncthreads();                                                     // barrier 4
+    akk = sa[k + 1] - 2.0 * wk1;                                         // sa[k+1] is not written above
+    __syncthreads();                                                     // barrier Y
     { double* tmp = sx; sx = sa; sa = tmp; }
     { double* tmp = svc; svc = svp; svp = tmp; tmp = swc; swc = swp; swp = tmp; }   // this step's pair is now the pending one
     PSTAMP(4);
   }
 #ifdef SYTRD_PROF
   if (t == 0 && (g == 0 || g == G - 1))
-    printf("sytrd prof wg %d/%d nt %d n %d: sums+householder %lld symv+publish %lld pending update %lld wait+gather %lld w/next %lld (cycles/step)\n", g, G, NT, n,
+    printf("sytrd prof wg %d/%d nt %d n %d: scalars %lld symv+publish %lld pending update %lld wait+gather %lld w/next/sums %lld (cycles/step)\n", g, G, NT, n,
            pf[0] / (n - 2), pf[1] / (n - 2), pf[2] / (n - 2), pf[3] / (n - 2), pf[4] / (n - 2));
 #endif
   if (aborted) {
@@ -289,11 +314,10 @@ __global__ void __launch_bounds__(64) k_tql_leaves(const double* __restrict__ d,
   for (int l = 0; l < N && !failed; ++l) {
     int iter = 0;
     for (;;) {
-      int m = l;
-      for (; m < N - 1; ++m) {
-        const double dd = fabs(sd[m]) + fabs(sd[m + 1]);
-        if (fabs(se[m]) <= EPS * dd) break;
-      }
+      // first m >= l with a negligible off-diagonal e[m] (m = N-1 if none): every lane tests its own index, one ballot
+      const bool small = (r >= N - 1) || (fabs(se[r]) <= EPS * (fabs(sd[r]) + fabs(sd[r + 1])));
+      const unsigned long long mask = __ballot(small) >> l;
+      const int m = l + (int)__builtin_ctzll(mask | (1ull << (N - 1 - l)));
       if (m == l) break;
       if (++iter > 80) { failed = true; break; }
       double gg = (sd[l + 1] - sd[l]) / (2.0 * se[l]);
@@ -303,18 +327,21 @@ __global__ void __launch_bounds__(64) k_tql_leaves(const double* __restrict__ d,
       int i = m - 1;
       bool under = false;
       // one wave: LDS accesses complete in program order, so the scalar recurrence (identical in every lane) needs no
-      // barrier; kinship-scale data keeps f^2 + g^2 far from over/underflow, so a plain sqrt replaces hypot
+      // barrier; r = sqrt(f^2 + g^2) and its reciprocal from one fast_rsqrt (kinship-scale data keeps f^2 + g^2 far
+      // from over/underflow; an exact zero takes the reference algorithm's underflow branch)
+      double ei = se[i], di = sd[i], di1 = sd[i + 1];
       for (; i >= l; --i) {
-        const double ei = se[i], di = sd[i], di1 = sd[i + 1];
         const double f = s * ei, b = c * ei;
-        rr = sqrt(fma(f, f, gg * gg));
-        if (r == 0) se[i + 1] = rr;
-        if (rr == 0.0) {
-          if (r == 0) { sd[i + 1] = di1 - p; se[m] = 0.0; }
+        const double h = fma(f, f, gg * gg);
+        const double ein = (i > l) ? se[i - 1] : 0.0, din = (i > l) ? sd[i - 1] : 0.0;   // next iteration's operands, early
+        if (h == 0.0) {
+          if (r == 0) { se[i + 1] = 0.0; sd[i + 1] = di1 - p; se[m] = 0.0; }
           under = true;
           break;
         }
-        const double ir = 1.0 / rr;
+        const double ir = fast_rsqrt(h);
+        rr = h * ir;
+        if (r == 0) se[i + 1] = rr;
         s = f * ir; c = gg * ir;
         gg = di1 - p;
         rr = (di - gg) * s + 2.0 * c * b;
@@ -326,6 +353,7 @@ __global__ void __launch_bounds__(64) k_tql_leaves(const double* __restrict__ d,
           Z[r][i + 1] = s * z0 + c * f2;
           Z[r][i] = c * z0 - s * f2;
         }
+        di1 = di; di = din; ei = ein;
       }
       if (under) continue;
       if (r == 0) { sd[l] -= p; se[l] = gg; se[m] = 0.0; }
