@@ -49,7 +49,9 @@ def cpu_baseline(Y, G, K, budget_s=15.0):
     reference is pure Julia and cannot run here); it is never on the product path."""
     from oracle import cref   # test infrastructure, used here only as the timed CPU baseline
     p = G.shape[1]
-    cores = max(1, min(cref.load().blmm_ref_max_threads(), len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)))
+    # 16 = the CPU share of a one-GPU box (more OpenMP threads than that only fight over the same cores); the reference's own
+    # published run used 16 Julia threads too (README.md:322-332)
+    cores = max(1, min(16, cref.load().blmm_ref_max_threads(), len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)))
     probe = min(Y.shape[1], 4 * cores)
     cref.bulkscan_null(Y[:, :probe], G, K, nthreads=cores)          # warm-up (thread pool, page faults)
     t0 = time.perf_counter()

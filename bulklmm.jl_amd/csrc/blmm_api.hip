@@ -9,6 +9,7 @@
 #include <limits>
 #include <dlfcn.h>
 #include <cstdlib>
+#include <mutex>
 
 using namespace blmm;
 
@@ -35,6 +36,30 @@ int ensure(blmm_ctx* ctx, DevBuf& b, size_t bytes) {
     return fail(ctx, BLMM_ERR_ALLOC, std::string("hipMalloc(") + std::to_string(want) + "): " + hipGetErrorString(e));
   }
   b.cap = want;
+  return BLMM_OK;
+}
+
+namespace {
+std::mutex g_grid_mu;
+hipEvent_t g_grid_ev[64];
+bool g_grid_has[64];
+}  // namespace
+
+int grid_kernel_begin(blmm_ctx* ctx) {
+  std::lock_guard<std::mutex> lk(g_grid_mu);
+  const int d = ctx->device & 63;
+  if (g_grid_has[d]) BLMM_HIP(hipStreamWaitEvent(ctx->stream, g_grid_ev[d], 0));
+  return BLMM_OK;
+}
+
+int grid_kernel_end(blmm_ctx* ctx) {
+  std::lock_guard<std::mutex> lk(g_grid_mu);
+  const int d = ctx->device & 63;
+  if (!g_grid_has[d]) {
+    BLMM_HIP(hipEventCreateWithFlags(&g_grid_ev[d], hipEventDisableTiming));
+    g_grid_has[d] = true;
+  }
+  BLMM_HIP(hipEventRecord(g_grid_ev[d], ctx->stream));
   return BLMM_OK;
 }
 

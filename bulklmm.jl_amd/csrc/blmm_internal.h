@@ -76,6 +76,12 @@ int fail(blmm_ctx* ctx, int code, const std::string& msg);
   } while (0)
 
 int ensure(blmm_ctx* ctx, DevBuf& b, size_t bytes);
+// Kernels whose workgroups meet at a grid barrier (k_sytrd, k_wbasis_mw) need ALL their workgroups resident at once.  Two of
+// them launched from different contexts / streams on one device could each hold part of the CUs and starve the other (their
+// bounded spins would then fail the calls).  grid_kernel_begin makes the stream wait for the previous such kernel on that
+// device, grid_kernel_end records this one: they run one after the other on the device, with no host synchronisation.
+int grid_kernel_begin(blmm_ctx* ctx);
+int grid_kernel_end(blmm_ctx* ctx);
 // host_path.hip: device -> caller memory in stream order; returns when the bytes are in place
 int copy_to_host(blmm_ctx* ctx, void* dst, const void* dsrc, size_t bytes);
 void destroy_host_stage(HostStage* hs);

@@ -685,38 +685,53 @@ __global__ void __launch_bounds__(512) k_backtransform(const double* __restrict_
       z[c][q] = (c0 + c < n && r < n) ? Z[(size_t)(c0 + c) * n + r] : 0.0;
     }
   const int nref = n - 2;
-  // reflector k is read from global memory two iterations before its use (into registers), written to LDS one iteration
-  // before, so neither the L2 round trip nor the LDS write sits between two barriers
+  // Reflectors are handled in groups of RB per barrier.  Group g = reflectors k = nref-1-RB*g ... (descending); a group is
+  // read from global memory two iterations before its use (into registers) and written to LDS one iteration before, so
+  // neither the L2 round trip nor the LDS write sits between two barriers.  LDS: 2 buffers x RB x n.
+  constexpr int RB = 4;
   constexpr int PF = (NR * 64 + 511) / 512;     // elements per thread of one reflector (512 threads)
-  double pre[PF];
-  auto fetch = [&](int k) {
+  double pre[RB][PF];
+  auto fetch = [&](int grp) {
 #pragma unroll
-    for (int u = 0; u < PF; ++u) { const int j = threadIdx.x + 512 * u; pre[u] = (k >= 0 && j > k && j < n) ? V[(size_t)k * n + j] : 0.0; }
+    for (int b = 0; b < RB; ++b) {
+      const int k = nref - 1 - RB * grp - b;
+#pragma unroll
+      for (int u = 0; u < PF; ++u) { const int j = threadIdx.x + 512 * u; pre[b][u] = (k >= 0 && j > k && j < n) ? V[(size_t)k * n + j] : 0.0; }
+    }
   };
   auto stash = [&](double* dst) {
 #pragma unroll
-    for (int u = 0; u < PF; ++u) { const int j = threadIdx.x + 512 * u; if (j < n) dst[j] = pre[u]; }
+    for (int b = 0; b < RB; ++b)
+#pragma unroll
+      for (int u = 0; u < PF; ++u) { const int j = threadIdx.x + 512 * u; if (j < n) dst[(size_t)b * n + j] = pre[b][u]; }
   };
-  fetch(nref - 1); stash(sh);
-  fetch(nref - 2);
+  const int ngrp = (nref + RB - 1) / RB;
+  fetch(0); stash(sh);
+  fetch(1);
   __syncthreads();
-  for (int k = nref - 1; k >= 0; --k) {
-    const double* v = sh + (size_t)((nref - 1 - k) & 1) * n;
-    double* vn = sh + (size_t)((nref - k) & 1) * n;
-    stash(vn);            // reflector k-1 (fetched during the previous iteration)
-    fetch(k - 2);         // reflector k-2: lands during this iteration and the next
-    const double tk = tau[k];
-    double vr[NR];
+  for (int grp = 0; grp < ngrp; ++grp) {
+    const double* vb = sh + (size_t)(grp & 1) * RB * n;
+    double* vn = sh + (size_t)((grp + 1) & 1) * RB * n;
+    stash(vn);            // group grp+1 (fetched during the previous iteration)
+    fetch(grp + 2);       // lands during this iteration and the next
 #pragma unroll
-    for (int q = 0; q < NR; ++q) { const int r = lane + 64 * q; vr[q] = (r > k && r < n) ? v[r] : 0.0; }
+    for (int b = 0; b < RB; ++b) {
+      const int k = nref - 1 - RB * grp - b;
+      if (k < 0) break;
+      const double* v = vb + (size_t)b * n;
+      const double tk = tau[k];
+      double vr[NR];
 #pragma unroll
-    for (int c = 0; c < CPW; ++c) {
-      double dot = 0.0;
+      for (int q = 0; q < NR; ++q) { const int r = lane + 64 * q; vr[q] = (r > k && r < n) ? v[r] : 0.0; }
 #pragma unroll
-      for (int q = 0; q < NR; ++q) dot = fma(vr[q], z[c][q], dot);
-      dot = wsum(dot) * tk;
+      for (int c = 0; c < CPW; ++c) {
+        double dot = 0.0;
 #pragma unroll
-      for (int q = 0; q < NR; ++q) z[c][q] = fma(-dot, vr[q], z[c][q]);
+        for (int q = 0; q < NR; ++q) dot = fma(vr[q], z[c][q], dot);
+        dot = wsum(dot) * tk;
+#pragma unroll
+        for (int q = 0; q < NR; ++q) z[c][q] = fma(-dot, vr[q], z[c][q]);
+      }
     }
     __syncthreads();
   }
@@ -1226,8 +1241,10 @@ int launch_eig_dc(blmm_ctx* ctx, const double* A, int n, double* lraw, double* e
     BLMM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sytrd), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     int nthr = 512;                                           // barriers at 1024 threads cost almost twice as much
     if (const char* te = getenv("BLMM_SYTRD_NT")) { const int tv = atoi(te); if (tv == 256 || tv == 512) nthr = tv; }
+    if (G > 1 && (rc = grid_kernel_begin(ctx))) return rc;
     hipLaunchKernelGGL(k_sytrd, dim3(G), dim3(nthr), lds, ctx->stream, A, n, nloc, d, e, tau, V, ex, stat);
     KCHECK();
+    if (G > 1 && (rc = grid_kernel_end(ctx))) return rc;
   }
   // ---- 2. leaves ----
   // a node reads the full square [lo, hi)^2 of its input Q: the blocks off the solved halves' diagonal must read as zero
@@ -1266,12 +1283,13 @@ int launch_eig_dc(blmm_ctx* ctx, const double* A, int n, double* lraw, double* e
   }
   // ---- 4. back-transformation (in place on the final Q), results out ----
   {
-    const size_t lds = sizeof(double) * (size_t)2 * n;
+    const size_t lds = sizeof(double) * (size_t)2 * 4 * n;     // 2 buffers x RB = 4 reflectors
     const int nr = (n + 63) / 64;
 #define BT(NR)                                                                                                             \
   do {                                                                                                                     \
     constexpr int CPW = (NR <= 8) ? 2 : 1;                                                                                 \
     const int cols_per_wg = 8 * CPW;                                                                                       \
+    if (lds > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_backtransform<NR, CPW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
     hipLaunchKernelGGL((k_backtransform<NR, CPW>), dim3((n + cols_per_wg - 1) / cols_per_wg), dim3(512), lds, ctx->stream, V, tau, n, Qin); \
   } while (0)
     if (nr <= 2) BT(2); else if (nr <= 4) BT(4); else if (nr <= 8) BT(8); else if (nr <= 16) BT(16); else if (nr <= 24) BT(24); else BT(32);

@@ -701,3 +701,29 @@ def test_fused_small_eigensolver(blmm, n, monkeypatch):
         assert np.abs(U.T @ U - np.eye(n)).max() <= 1e-13, (name, np.abs(U.T @ U - np.eye(n)).max())
         assert np.abs(K @ U - U * lam).max() <= 2e-13 * sc * n, (name, np.abs(K @ U - U * lam).max() / sc)
         assert np.abs(lam - np.linalg.eigvalsh(K)).max() <= 1e-12 * sc * np.sqrt(n), name
+
+
+def test_dev_entry_point_is_ordered_on_torchs_default_stream():
+    """A context created with torch's default stream (handle 0) must run ON that stream (BLMM_STREAM_NULL adopts the legacy
+    null stream; round 1 silently created a private non-blocking stream instead): work torch enqueues before and after the
+    call is ordered against it.  Runs as its own program (tests/helpers/stream_order_check.py), the way bench.py uses the
+    library: torch first, then the library."""
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    run = subprocess.run([sys.executable, os.path.join(here, "helpers", "stream_order_check.py")], capture_output=True, text=True, timeout=600)
+    assert run.returncode == 0, run.stdout[-2000:] + run.stderr[-3000:]
+    assert "stream order ok" in run.stdout
+
+
+def test_concurrent_contexts_with_grid_barrier_kernels(blmm):
+    """Three contexts on ONE device each run the tridiagonalisation (90 workgroups that meet at a grid barrier) and the
+    multi-workgroup weight basis at n = 900: 270 workgroups do not fit 256 CUs at once, so without the per-device ordering of
+    such kernels (grid_kernel_begin / _end) they could starve each other into their spin limits."""
+    Y, G, K, _ = make_data(n=900, p=70, m=33, seed=4242, bxd=False)
+    one = blmm.bulkscan(Y, G, K, method="null-exact")
+    mc = blmm.MultiContext([0, 0, 0])
+    for _ in range(3):
+        got = blmm.bulkscan_multi(mc, Y, G, K, method="null-exact", gather="host_shards")
+        assert np.array_equal(got["L"], one["L"]) and np.array_equal(got["h2_null_list"], one["h2_null_list"])
+    mc.close()
