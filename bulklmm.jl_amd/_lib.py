@@ -24,11 +24,14 @@ EXPORTS = [
     "blmm_host_register", "blmm_host_unregister", "blmm_host_alloc", "blmm_host_free",
     "blmm_lod2log10p", "blmm_lod2log10p_dev", "blmm_lod_threshold", "blmm_lod_threshold_dev", "blmm_get_thresholds", "blmm_get_thresholds_dev",
     "blmm_last_log10p", "blmm_last_lod_threshold", "blmm_last_get_thresholds",
+    "blmm_read_csv", "blmm_read_he", "blmm_table_rows", "blmm_table_cols", "blmm_table_copy", "blmm_table_free",
+    "blmm_kinship_rounded", "blmm_scan_alt", "blmm_scan_alt_dev",
 ]
 
 BLMM_NULL_EXACT, BLMM_NULL_GRID, BLMM_ALT_GRID = 0, 1, 2
 BLMM_EIGEN, BLMM_SVD = 0, 1
 BLMM_COMPAT_ALT_COUNTER = 1
+BLMM_COMPAT_ALT_TRUE_WEIGHTS = 2
 BLMM_GATHER_NONE, BLMM_GATHER_HOST_SHARDS, BLMM_GATHER_ALLGATHER = 0, 1, 2
 
 ERR_ZERO_NORM_MSG = "Dividing by zeros: the input vector can not contain any zeros!"
@@ -106,6 +109,8 @@ def load():
     lib.blmm_scan_perms_dev.argtypes = [vp, op, vp, i64, vp, i64, vp, i64, vp, vp, i64, C.c_uint64, vp, vp, vp, vp, sp]
     lib.blmm_scan_perms_f32.argtypes = [vp, op, vp, i64, vp, i64, vp, i64, vp, vp, i64, C.c_uint64, vp, vp, vp, vp, sp]
     lib.blmm_scan_perms_f32_dev.argtypes = [vp, op, vp, i64, vp, i64, vp, i64, vp, vp, i64, C.c_uint64, vp, vp, vp, vp, sp]
+    lib.blmm_scan_alt.argtypes = [vp, op, vp, i64, vp, i64, vp, i64, vp, vp, vp, vp, vp, sp]
+    lib.blmm_scan_alt_dev.argtypes = [vp, op, vp, i64, vp, i64, vp, i64, vp, vp, vp, vp, vp, sp]
     lib.blmm_lod_colmax.argtypes = [vp, vp, i64, i64, vp, vp]
     lib.blmm_lod_colmax_dev.argtypes = [vp, vp, i64, i64, i64, vp, vp]
     lib.blmm_rotate.argtypes = [vp, op, vp, i64, i64, vp, i64, vp, i64, vp, vp, vp, vp, sp]
@@ -136,6 +141,16 @@ def load():
     lib.blmm_last_log10p.argtypes = [vp, i64, vp]
     lib.blmm_last_lod_threshold.argtypes = [vp, C.c_double, i64, vp, vp, vp, C.POINTER(i64)]
     lib.blmm_last_get_thresholds.argtypes = [vp, vp, i64, vp]
+    lib.blmm_read_csv.argtypes = [C.c_char_p, i64, i64, i64, i64, C.POINTER(vp)]
+    lib.blmm_read_he.argtypes = [C.c_char_p, C.POINTER(vp)]
+    lib.blmm_table_rows.argtypes = [vp]
+    lib.blmm_table_rows.restype = i64
+    lib.blmm_table_cols.argtypes = [vp]
+    lib.blmm_table_cols.restype = i64
+    lib.blmm_table_copy.argtypes = [vp, vp]
+    lib.blmm_table_free.argtypes = [vp]
+    lib.blmm_table_free.restype = None
+    lib.blmm_kinship_rounded.argtypes = [vp, vp, i64, i64, i64, vp]
     lib.blmm_host_register.argtypes = [vp, C.c_uint64]
     lib.blmm_host_unregister.argtypes = [vp]
     lib.blmm_host_alloc.argtypes = [C.c_uint64]

@@ -186,14 +186,57 @@ class BulkscanAltResult(NamedTuple):
 _METHODS = {"null-exact": L.BLMM_NULL_EXACT, "null-grid": L.BLMM_NULL_GRID, "alt-grid": L.BLMM_ALT_GRID}
 
 
-def calcKinship(geno, ctx: Optional[Context] = None) -> np.ndarray:
-    """src/kinship.jl:4-14."""
+def calcKinship(geno, ctx: Optional[Context] = None, digits: Optional[int] = None) -> np.ndarray:
+    """src/kinship.jl:4-14.  `digits=12` gives `round.(calcKinship(geno), digits = 12)`, the README's convention
+    (README.md:176-181), rounded on the device."""
     ctx = ctx or default_context()
     G = _F(geno)
     n, p = G.shape
     K = np.empty((n, n), dtype=np.float64, order="F")
-    ctx.check(ctx.lib.blmm_kinship(ctx.h, _p(G), n, p, _p(K)))
+    if digits is None:
+        ctx.check(ctx.lib.blmm_kinship(ctx.h, _p(G), n, p, _p(K)))
+    else:
+        ctx.check(ctx.lib.blmm_kinship_rounded(ctx.h, _p(G), n, p, int(digits), _p(K)))
     return K
+
+
+def _read_table(kind: str, path: str, *args) -> np.ndarray:
+    lib = L.load()
+    h = C.c_void_p()
+    rc = lib.blmm_read_he(path.encode(), C.byref(h)) if kind == "he" else lib.blmm_read_csv(path.encode(), *args, C.byref(h))
+    if rc != 0:
+        raise BulkLMMError("could not read %s (%s)" % (path, lib.blmm_err_string(rc).decode()), rc)
+    try:
+        out = np.empty((int(lib.blmm_table_rows(h)), int(lib.blmm_table_cols(h))), order="F")
+        lib.blmm_table_copy(h, _p(out))
+    finally:
+        lib.blmm_table_free(h)
+    return out
+
+
+def readGenoProb(file: str) -> np.ndarray:
+    """src/readData.jl:41-70 (getmarkernames = getids = true): header line and id column dropped."""
+    return _read_table("csv", file, 1, 1, 1, 0)
+
+
+def readGenoProb_ExcludeComplements(file: str) -> np.ndarray:
+    """src/readData.jl:85-96: the odd (1-based) probability columns of readGenoProb."""
+    return _read_table("csv", file, 1, 1, 2, 0)
+
+
+def readBXDpheno(file: str) -> np.ndarray:
+    """src/readData.jl:159-161: readdlm(file, ','; skipstart=1)[:, 2:end-1]."""
+    return _read_table("csv", file, 1, 1, 1, 1)
+
+
+def readBXDgeno(file: str, skipstart: int = 1) -> np.ndarray:
+    """src/readData.jl:163-165: readdlm(file, ','; skipstart)[:, 2:2:end]."""
+    return _read_table("csv", file, int(skipstart), 1, 2, 0)
+
+
+def readhe(file: str) -> np.ndarray:
+    """Helium .he matrix (test/kinship_test.jl:5)."""
+    return _read_table("he", file)
 
 
 def _bulkscan_call(method, Y, G, K, Covar, h2_grid, addIntercept, weights, prior_variance, prior_sample_size, reml,
@@ -412,9 +455,10 @@ def scan(y, g, K, covar=None, *, weights=None, prior_variance: float = 0.0, prio
          permutation_test: bool = False, nperms: int = 1024, rndseed: int = 0, profileLL: bool = False, markerID: int = 0,
          h2_grid=None, decomp_scheme: str = "eigen",
          output_pvals: bool = False, chisq_df: int = 1, perm_idx=None, perm_precision: str = "f64",
-         ctx: Optional[Context] = None) -> dict:
-    """src/scan.jl:94-271 for assumption == "null": the single-trait scan routed through the same GPU
-    kernels (Brent + exact-weights LOD kernel with m = 1), and the permutation test (src/scan.jl:485-557).
+         alt_true_weights: bool = False, ctx: Optional[Context] = None) -> dict:
+    """src/scan.jl:94-271: the single-trait scan routed through the same GPU kernels (Brent + exact-weights LOD kernel with
+    m = 1), the permutation test (src/scan.jl:485-557), and assumption == "alt" (scan_alt, src/scan.jl:397-453: one Brent
+    search per marker on the device; adds `h2_each_marker`; `alt_true_weights` see BLMM_COMPAT_ALT_TRUE_WEIGHTS).
     `perm_idx` (n x nperms, 0-based) supplies the permutations; otherwise the library draws them from
     `rndseed` with its own generator (Julia's MersenneTwister stream is not reproducible).
     `perm_precision="f32"` (not in the reference; BASELINE.json configs[4]) computes L_perms on the fp32 matrix cores
@@ -425,11 +469,9 @@ def scan(y, g, K, covar=None, *, weights=None, prior_variance: float = 0.0, prio
     if profileLL:   # src/scan.jl:252-267 (profile_LL of src/analysis_helpers): not part of the GPU path
         raise NotImplementedError("profileLL = true (profile_LL) is outside the GPU hot path; `markerID` / `h2_grid` only matter there")
     # `method` ("qr" / "cholesky") picks a CPU factorisation in the reference; the GPU path has one (closed-form WLS)
-    if assumption == "alt":
-        if permutation_test:
-            raise BulkLMMError("Permutation test option currently is not supported for the alternative assumption.")
-        raise NotImplementedError("scan_alt (per-marker Brent) is outside the GPU hot path (SURVEY.md §8(a) A19)")
-    if assumption != "null":
+    if assumption == "alt" and permutation_test:
+        raise BulkLMMError("Permutation test option currently is not supported for the alternative assumption.")
+    if assumption not in ("null", "alt"):
         raise BulkLMMError("Assumption keyword is not supported. Please enter null or alt.")
     if y.shape[1] != 1:
         raise BulkLMMError("Can only handle one trait.", -6)  # src/scan.jl:496-498
@@ -463,6 +505,17 @@ def scan(y, g, K, covar=None, *, weights=None, prior_variance: float = 0.0, prio
     ctx = ctx or default_context()
     scal = np.zeros(2)
     lod = np.empty(p)
+    if assumption == "alt":
+        if alt_true_weights:
+            o.compat_flags |= L.BLMM_COMPAT_ALT_TRUE_WEIGHTS
+        h2e = np.empty(p)
+        ctx.check(ctx.lib.blmm_scan_alt(ctx.h, C.byref(o), _p(y), n, _p(G), p, _p(cov), ncov, _p(K), _p(w), _p(scal), _p(lod),
+                                        _p(h2e), C.byref(st)))
+        _raise_status(st)
+        out = {"sigma2_e": float(scal[0]), "h2_null": float(scal[1]), "h2_each_marker": h2e, "lod": lod}
+        if output_pvals:
+            out["log10pvals"] = lod2log10p(lod, chisq_df, ctx=ctx)
+        return out
     f32 = perm_precision == "f32"
     Lp = np.empty((p, max(nperms, 1)), order="F", dtype=np.float32 if f32 else np.float64)
     fn = ctx.lib.blmm_scan_perms_f32 if f32 else ctx.lib.blmm_scan_perms

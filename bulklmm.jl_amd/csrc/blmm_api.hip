@@ -621,6 +621,27 @@ int blmm_kinship(blmm_ctx* ctx, const double* G, int64_t n, int64_t p, double* K
   return BLMM_OK;
 }
 
+__global__ void k_round_digits(double* __restrict__ v, int64_t cnt, double scale) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < cnt) v[i] = rint(v[i] * scale) / scale;
+}
+
+int blmm_kinship_rounded(blmm_ctx* ctx, const double* G, int64_t n, int64_t p, int64_t digits, double* K_out) {
+  if (!ctx) return BLMM_ERR_INVALID;
+  if (!G || !K_out || n < 1 || p < 1 || digits > 300) return fail(ctx, BLMM_ERR_INVALID, "calcKinship: bad arguments");
+  BLMM_HIP(hipSetDevice(ctx->device));
+  int rc;
+  if ((rc = ensure(ctx, ctx->inG, sizeof(double) * n * p))) return rc;
+  if ((rc = ensure(ctx, ctx->inK, sizeof(double) * n * n))) return rc;
+  BLMM_HIP(hipMemcpyAsync(ctx->inG.p, G, sizeof(double) * n * p, hipMemcpyHostToDevice, ctx->stream));
+  if ((rc = blmm_kinship_dev(ctx, ptr<double>(ctx->inG), n, p, ptr<double>(ctx->inK)))) return rc;
+  if (digits >= 0)
+    hipLaunchKernelGGL(k_round_digits, dim3((unsigned)((n * n + 255) / 256)), dim3(256), 0, ctx->stream, ptr<double>(ctx->inK), n * n, std::pow(10.0, (double)digits));
+  BLMM_HIP(hipMemcpyAsync(K_out, ctx->inK.p, sizeof(double) * n * n, hipMemcpyDeviceToHost, ctx->stream));
+  BLMM_HIP(hipStreamSynchronize(ctx->stream));
+  return BLMM_OK;
+}
+
 // ---------------------------------------------------------------------------------------------------
 int blmm_lod_colmax_dev(blmm_ctx* ctx, const double* dL, int64_t p, int64_t m, int64_t ldL, double* dmax_out, int64_t* dargmax_out) {
   if (!ctx) return BLMM_ERR_INVALID;
@@ -956,6 +977,70 @@ int blmm_scan_perms_f32(blmm_ctx* ctx, const blmm_opts* opts, const double* y, i
                         const int32_t* perm_idx, double* scalars_out, double* lod_out, float* Lperms_out, blmm_status* status) {
   return scan_perms_host(ctx, opts, y, n, G, p, Covar, ncov, K, weights, nperms, seed, perm_idx, scalars_out, lod_out,
                          Lperms_out, true, status);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// scan(...; assumption = "alt") -> scan_alt (src/scan.jl:397-453): scalars [sigma2_e, h2_null], lod p, h2_each_marker p
+int blmm_scan_alt_dev(blmm_ctx* ctx, const blmm_opts* opts, const double* dy, int64_t n, const double* dG, int64_t p,
+                      const double* dCovar, int64_t ncov, const double* dK, const double* dweights, double* dscalars_out,
+                      double* dlod_out, double* dh2_each_out, blmm_status* status) {
+  if (!ctx) return BLMM_ERR_INVALID;
+  int rc = check_opts(ctx, opts);
+  if (rc) return rc;
+  if (!dy || !dG || !dK || !dscalars_out || !dlod_out || !dh2_each_out) return fail(ctx, BLMM_ERR_INVALID, "scan_alt: NULL buffer");
+  BLMM_HIP(hipSetDevice(ctx->device));
+  if ((rc = check_sticky(ctx))) return rc;
+  Timer tm(ctx);
+  Pipe P;
+  if ((rc = prepare(ctx, opts, dy, n, 1, dG, p, dCovar, ncov, dK, dweights, 1, P, tm))) return rc;
+  const NullModel nm = null_model(P, opts);
+  if (P.c + 1 >= P.n) return fail(ctx, BLMM_ERR_DIM, "Dimension mismatch.");
+  if ((rc = launch_brent(ctx, nm, P.Yt, P.ldy, 1, P.Z0, P.lam, dscalars_out + 1, dscalars_out, nullptr, P.stat))) return rc;
+  tm.mark();
+  if ((rc = launch_alt_brent(ctx, nm, P.Yt, P.ldy, P.Xt, P.ldx, p, P.Z0, P.lam, dscalars_out + 1,
+                             (opts->compat_flags & BLMM_COMPAT_ALT_TRUE_WEIGHTS) ? 1 : 0, dlod_out, dh2_each_out, P.stat))) return rc;
+  tm.mark();
+  return end_call(ctx, P, status, &tm);
+}
+
+int blmm_scan_alt(blmm_ctx* ctx, const blmm_opts* opts, const double* y, int64_t n, const double* G, int64_t p,
+                  const double* Covar, int64_t ncov, const double* K, const double* weights, double* scalars_out,
+                  double* lod_out, double* h2_each_out, blmm_status* status) {
+  if (!ctx) return BLMM_ERR_INVALID;
+  if (!opts) return fail(ctx, BLMM_ERR_INVALID, "opts is NULL");
+  if (!y || !G || !K || !scalars_out || !lod_out || !h2_each_out) return fail(ctx, BLMM_ERR_INVALID, "scan_alt: NULL buffer");
+  if (n < 1 || p < 1) return fail(ctx, BLMM_ERR_DIM, "Dimension mismatch.");
+  BLMM_HIP(hipSetDevice(ctx->device));
+  int rc;
+  if ((rc = ensure(ctx, ctx->inY, sizeof(double) * n))) return rc;
+  if ((rc = ensure(ctx, ctx->inG, sizeof(double) * n * p))) return rc;
+  if ((rc = ensure(ctx, ctx->inK, sizeof(double) * n * n))) return rc;
+  if ((rc = ensure(ctx, ctx->outL, sizeof(double) * 2 * (size_t)p))) return rc;
+  if ((rc = ensure(ctx, ctx->outH2, sizeof(double) * 2))) return rc;
+  BLMM_HIP(hipMemcpyAsync(ctx->inY.p, y, sizeof(double) * n, hipMemcpyHostToDevice, ctx->stream));
+  BLMM_HIP(hipMemcpyAsync(ctx->inG.p, G, sizeof(double) * n * p, hipMemcpyHostToDevice, ctx->stream));
+  BLMM_HIP(hipMemcpyAsync(ctx->inK.p, K, sizeof(double) * n * n, hipMemcpyHostToDevice, ctx->stream));
+  const double* dCov = nullptr; const double* dW = nullptr;
+  if (Covar && ncov > 0) {
+    if ((rc = ensure(ctx, ctx->inCov, sizeof(double) * n * ncov))) return rc;
+    BLMM_HIP(hipMemcpyAsync(ctx->inCov.p, Covar, sizeof(double) * n * ncov, hipMemcpyHostToDevice, ctx->stream));
+    dCov = ptr<double>(ctx->inCov);
+  }
+  if (weights) {
+    if ((rc = ensure(ctx, ctx->inW, sizeof(double) * n))) return rc;
+    BLMM_HIP(hipMemcpyAsync(ctx->inW.p, weights, sizeof(double) * n, hipMemcpyHostToDevice, ctx->stream));
+    dW = ptr<double>(ctx->inW);
+  }
+  double* dL = ptr<double>(ctx->outL);
+  rc = blmm_scan_alt_dev(ctx, opts, ptr<double>(ctx->inY), n, ptr<double>(ctx->inG), p, dCov, dCov ? ncov : 0,
+                         ptr<double>(ctx->inK), dW, ptr<double>(ctx->outH2), dL, dL + p, status);
+  if (rc) { hipStreamSynchronize(ctx->stream); return rc; }
+  ctx->last_L = dL; ctx->last_p = p; ctx->last_m = 1; ctx->last_f32 = false;
+  BLMM_HIP(hipMemcpyAsync(scalars_out, ctx->outH2.p, sizeof(double) * 2, hipMemcpyDeviceToHost, ctx->stream));
+  BLMM_HIP(hipMemcpyAsync(lod_out, dL, sizeof(double) * p, hipMemcpyDeviceToHost, ctx->stream));
+  BLMM_HIP(hipMemcpyAsync(h2_each_out, dL + p, sizeof(double) * p, hipMemcpyDeviceToHost, ctx->stream));
+  BLMM_HIP(hipStreamSynchronize(ctx->stream));
+  return BLMM_OK;
 }
 
 // ---------------------------------------------------------------------------------------------------

@@ -1537,6 +1537,157 @@ int launch_brent(blmm_ctx* ctx, const NullModel& nm, const double* Yt, int64_t l
   return fail(ctx, BLMM_ERR_UNSUPPORTED, "number of null covariates (incl. intercept) must be 1..4");
 }
 
+// ------------------------------------------------------------------------------------------------
+// scan_alt (src/scan.jl:397-453): one trait, the variance components re-estimated for every marker.
+//   for marker i:  X = [Z0 x_i];  out11 = fitlmm(y0, X, lambda, prior; reml, optim_interval)          (:425-428)
+//                  lod_i = (wls(y0, X, sqrt.(w(h2_i)), prior).ell - wls(y0, Z0, sqrt.(w(h2_null)), prior).ell) / ln 10   (:431-437)
+// The two closing wls calls hand wls the SQUARE ROOTS of the weights as its weights and always use ML (no `reml` keyword):
+// SQW = true restates exactly that; `true_w` (BLMM_COMPAT_ALT_TRUE_WEIGHTS) evaluates both at makeweights(h2) instead.
+// ell of y on the design [Z0 (C columns, LDS)  x (X = 1: one strided column from memory)], LPT lanes per marker; y, Z0, lambda
+// are shared by all markers and sit in LDS.
+// ------------------------------------------------------------------------------------------------
+template <int C, int X, int LPT, bool SQW>
+__device__ __forceinline__ EllOut alt_ell(double h2, const double* __restrict__ xcol, int64_t xstride, int sub, int n,
+                                          const double* __restrict__ sY, const double* __restrict__ sZ,
+                                          const double* __restrict__ sLam, double prior_a, double prior_b, int reml, int* nonpos) {
+  constexpr int D = C + X, NA = D * (D + 1) / 2;
+  const double delta = h2 / (1.0 - h2);
+  double A[NA], v[D], syy = 0.0, logsum = 0.0, prod = 1.0;
+#pragma unroll
+  for (int a = 0; a < NA; ++a) A[a] = 0.0;
+#pragma unroll
+  for (int q = 0; q < D; ++q) v[q] = 0.0;
+  int cnt = 0, bad = 0;
+  for (int k = sub; k < n; k += LPT) {
+    const double t = fma(delta, sLam[k], 1.0);
+    double w = 1.0 / t;
+    bad |= !(w > 0.0);
+    if (SQW) w = sqrt(w);
+    prod *= t;
+    if (++cnt == 8) { logsum += log(prod); prod = 1.0; cnt = 0; }
+    const double y = sY[k];
+    const double wy = w * y;
+    syy = fma(wy, y, syy);
+    double col[D];
+#pragma unroll
+    for (int q = 0; q < C; ++q) col[q] = sZ[q * n + k];
+    if (X) col[D - 1] = xcol[(int64_t)k * xstride];
+#pragma unroll
+    for (int q = 0; q < D; ++q) {
+      v[q] = fma(wy, col[q], v[q]);
+      const double wz = w * col[q];
+#pragma unroll
+      for (int r = 0; r <= q; ++r) A[q * (q + 1) / 2 + r] = fma(wz, col[r], A[q * (q + 1) / 2 + r]);
+    }
+  }
+  logsum += log(prod);
+  if (SQW) logsum *= 0.5;                       // sum ln t of the weights actually used, sqrt(w) = t^(-1/2)
+#pragma unroll
+  for (int o = 1; o < LPT; o <<= 1) {
+    syy += __shfl_xor(syy, o, LPT); logsum += __shfl_xor(logsum, o, LPT);
+#pragma unroll
+    for (int a = 0; a < NA; ++a) A[a] += __shfl_xor(A[a], o, LPT);
+#pragma unroll
+    for (int q = 0; q < D; ++q) v[q] += __shfl_xor(v[q], o, LPT);
+  }
+  if (bad && nonpos) *nonpos = 1;
+  double L[NA], t[D], logdet = 0.0, tt = 0.0;
+#pragma unroll
+  for (int q = 0; q < D; ++q) {
+#pragma unroll
+    for (int r = 0; r <= q; ++r) {
+      double s = A[q * (q + 1) / 2 + r];
+#pragma unroll
+      for (int u = 0; u < r; ++u) s = fma(-L[q * (q + 1) / 2 + u], L[r * (r + 1) / 2 + u], s);
+      if (r == q) { L[q * (q + 1) / 2 + q] = sqrt(s); logdet += log(s); }
+      else L[q * (q + 1) / 2 + r] = s / L[r * (r + 1) / 2 + r];
+    }
+    double s = v[q];
+#pragma unroll
+    for (int u = 0; u < q; ++u) s = fma(-L[q * (q + 1) / 2 + u], t[u], s);
+    t[q] = s / L[q * (q + 1) / 2 + q];
+    tt = fma(t[q], t[q], tt);
+  }
+  const double rss = syy - tt;
+  const double prior_df = prior_b > 0.0 ? prior_b + 2.0 : prior_b;
+  const double num = rss + prior_a * prior_b;
+  const double sigma2 = num / ((reml ? (double)(n - D) : (double)n) + prior_df);
+  const double ls = log(sigma2);
+  double ell = -0.5 * (((double)n + prior_b) * ls + logsum + num / sigma2);
+  if (reml) ell += 0.5 * ((double)D * ls - logdet);
+  EllOut o; o.ell = ell; o.sigma2 = sigma2; o.yy = rss;
+  return o;
+}
+
+template <int C, int LPT>
+__global__ void __launch_bounds__(256) k_alt_brent(NullModel nm, const double* __restrict__ Yt, int64_t ldy,
+                                                   const double* __restrict__ Xt, int64_t ldx, int64_t p, const double* __restrict__ Z0,
+                                                   const double* __restrict__ lam, const double* __restrict__ h2null,
+                                                   int true_w, double* __restrict__ lod, double* __restrict__ h2each,
+                                                   int64_t* stat) {
+  extern __shared__ __attribute__((aligned(16))) double sh[];
+  const int n = nm.n;
+  double* sLam = sh;            // n
+  double* sY = sh + n;          // n   (the trait: column 0 of Yt)
+  double* sZ = sh + 2 * n;      // C*n
+  for (int e = threadIdx.x; e < n; e += blockDim.x) { sLam[e] = lam[e]; sY[e] = Yt[(int64_t)e * ldy]; }
+  for (int e = threadIdx.x; e < n * C; e += blockDim.x) sZ[e] = Z0[e];
+  __syncthreads();
+  const int64_t j = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / LPT;
+  const int sub = threadIdx.x % LPT;
+  const bool valid = j < p;
+  const double* xcol = Xt + (valid ? j : 0);
+  int nonpos = 0, hit_max = 0;
+  const int nint = nm.optim_interval < 1 ? 1 : nm.optim_interval;
+  auto f = [&](double h2) { return -alt_ell<C, 1, LPT, false>(h2, xcol, ldx, sub, n, sY, sZ, sLam, nm.prior_a, nm.prior_b, nm.reml, &nonpos).ell; };
+  const double hx = brent_search(f, nint, valid, &hit_max);
+  const double h0 = *h2null;
+  double e1, e0;
+  if (true_w) {
+    e1 = alt_ell<C, 1, LPT, false>(hx, xcol, ldx, sub, n, sY, sZ, sLam, nm.prior_a, nm.prior_b, 0, nullptr).ell;
+    e0 = alt_ell<C, 0, LPT, false>(h0, xcol, ldx, sub, n, sY, sZ, sLam, nm.prior_a, nm.prior_b, 0, nullptr).ell;
+  } else {
+    e1 = alt_ell<C, 1, LPT, true>(hx, xcol, ldx, sub, n, sY, sZ, sLam, nm.prior_a, nm.prior_b, 0, nullptr).ell;
+    e0 = alt_ell<C, 0, LPT, true>(h0, xcol, ldx, sub, n, sY, sZ, sLam, nm.prior_a, nm.prior_b, 0, nullptr).ell;
+  }
+  if (valid && sub == 0) {
+    lod[j] = (e1 - e0) / log(10.0);
+    h2each[j] = hx;
+    if (hit_max) atomicAdd((unsigned long long*)&stat[ST_BRENT_MAXIT], 1ull);
+    if (nonpos) atomicAdd((unsigned long long*)&stat[ST_NONPOS_W], 1ull);
+  }
+}
+
+template <int C, int LPT>
+static int launch_alt_brent_t(blmm_ctx* ctx, const NullModel& nm, const double* Yt, int64_t ldy, const double* Xt, int64_t ldx, int64_t p,
+                              const double* Z0, const double* lam, const double* h2null, int true_w, double* lod,
+                              double* h2each, int64_t* stat) {
+  const size_t lds = sizeof(double) * (size_t)nm.n * (2 + C);
+  if (lds > 160 * 1024 - 512) return fail(ctx, BLMM_ERR_UNSUPPORTED, "scan_alt: n too large for the LDS-resident trait");
+  if (lds > 48 * 1024) BLMM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_alt_brent<C, LPT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  const int64_t threads = p * LPT;
+  hipLaunchKernelGGL((k_alt_brent<C, LPT>), dim3((unsigned)((threads + 255) / 256)), dim3(256), lds, ctx->stream, nm, Yt, ldy, Xt, ldx, p,
+                     Z0, lam, h2null, true_w, lod, h2each, stat);
+  KCHECK();
+  return BLMM_OK;
+}
+
+int launch_alt_brent(blmm_ctx* ctx, const NullModel& nm, const double* Yt, int64_t ldy, const double* Xt, int64_t ldx, int64_t p,
+                     const double* Z0, const double* lam, const double* h2null, int true_w, double* lod, double* h2each,
+                     int64_t* stat) {
+  if (p < 1) return BLMM_OK;
+#define AB(C) (nm.n <= 160 ? launch_alt_brent_t<C, 4>(ctx, nm, Yt, ldy, Xt, ldx, p, Z0, lam, h2null, true_w, lod, h2each, stat) \
+                           : launch_alt_brent_t<C, 16>(ctx, nm, Yt, ldy, Xt, ldx, p, Z0, lam, h2null, true_w, lod, h2each, stat))
+  switch (nm.c) {
+    case 1: return AB(1);
+    case 2: return AB(2);
+    case 3: return AB(3);
+    case 4: return AB(4);
+  }
+#undef AB
+  return fail(ctx, BLMM_ERR_UNSUPPORTED, "number of null covariates (incl. intercept) must be 1..4");
+}
+
 // Ell[g, j] = wls_multivar(Y0, Z0, makeweights(grid[g]), prior).Ell  (src/bulkscan_helpers.jl:267-269),
 // per-trait first arg-max (find_optim_h2, src/bulkscan_helpers.jl:204-211).
 template <int C>

@@ -294,11 +294,8 @@ function scan(y::Array{Float64, 2}, g::Array{Float64, 2}, covar::Array{Float64, 
               decomp_scheme::String = "eigen",
               output_pvals::Bool = false, chisq_df::Int64 = 1,
               perm_precision::String = "f64")
-    if assumption == "alt"
-        permutation_test && error("Permutation test option currently is not supported for the alternative assumption.")
-        error("assumption = \"alt\" (scan_alt, per-marker h2) is not part of the GPU path; call BulkLMM.scan for it")
-    end
-    assumption == "null" || error("Assumption keyword is not supported. Please enter null or alt.")
+    assumption == "alt" && permutation_test && error("Permutation test option currently is not supported for the alternative assumption.")
+    assumption in ("null", "alt") || error("Assumption keyword is not supported. Please enter null or alt.")
     profileLL && error("profileLL = true (profile_LL) is not part of the GPU path; call BulkLMM.scan for it")
     size(y, 2) == 1 || error("Can only handle one trait.")                                   # src/scan.jl:496-498
     n = size(y, 1); p = size(g, 2)
@@ -310,6 +307,16 @@ function scan(y::Array{Float64, 2}, g::Array{Float64, 2}, covar::Array{Float64, 
     o = BlmmOpts(NULL_EXACT, reml, addIntercept, decomp(decomp_scheme), optim_interval, 0, prior_variance, prior_sample_size)
     scal = zeros(2); lod = Array{Float64, 1}(undef, p); st = BlmmStatus()
     ncov = size(covar, 2)
+    if assumption == "alt"   # scan_alt (src/scan.jl:397-453): one Brent search per marker on the device
+        h2_each = Array{Float64, 1}(undef, p)
+        GC.@preserve y g covar K weights scal lod h2_each check(ccall((:blmm_scan_alt, libblmm), Cint,
+            (Ptr{Cvoid}, Ref{BlmmOpts}, Ptr{Float64}, Int64, Ptr{Float64}, Int64, Ptr{Float64}, Int64, Ptr{Float64}, Ptr{Float64},
+             Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ref{BlmmStatus}),
+            context(), o, y, n, g, p, covar, ncov, K, ptr_or_null(weights), scal, lod, h2_each, st))
+        raise_status(st)
+        res = (sigma2_e = scal[1], h2_null = scal[2], h2_each_marker = h2_each, lod = lod)
+        return output_pvals ? merge(res, (log10pvals = lod2log10p(lod, chisq_df),)) : res
+    end
     f32 = perm_precision == "f32"
     Lp = f32 ? Array{Float32, 2}(undef, p, max(np, 1)) : Array{Float64, 2}(undef, p, max(np, 1))
     GC.@preserve y g covar K weights scal lod Lp begin
@@ -342,6 +349,36 @@ function get_thresholds(L_perms::Array{Float64, 2}, signif_level::Array{Float64,
         (Ptr{Cvoid}, Ptr{Float64}, Int64, Int64, Ptr{Float64}, Int64, Ptr{Float64}),
         context(), L_perms, size(L_perms, 1), size(L_perms, 2), probs, length(probs), thrs))
     return (probs = probs, thrs = thrs)
+end
+
+# Readers (src/readData.jl:41-96, 159-165): the numeric table is parsed by the library's host code and copied into a Julia array
+check_io(rc) = rc == 0 || error("could not read the file: " * unsafe_string(ccall((:blmm_err_string, libblmm), Cstring, (Cint,), rc)))
+function read_table(open_table::Function)
+    h = Ref{Ptr{Cvoid}}(C_NULL)
+    check_io(open_table(h))
+    try
+        A = Array{Float64, 2}(undef, ccall((:blmm_table_rows, libblmm), Int64, (Ptr{Cvoid},), h[]),
+                              ccall((:blmm_table_cols, libblmm), Int64, (Ptr{Cvoid},), h[]))
+        check_io(ccall((:blmm_table_copy, libblmm), Cint, (Ptr{Cvoid}, Ptr{Float64}), h[], A))
+        return A
+    finally
+        ccall((:blmm_table_free, libblmm), Cvoid, (Ptr{Cvoid},), h[])
+    end
+end
+read_csv(file, skip, first, step, drop) = read_table(h -> ccall((:blmm_read_csv, libblmm), Cint,
+    (Cstring, Int64, Int64, Int64, Int64, Ref{Ptr{Cvoid}}), file, skip, first, step, drop, h))
+readGenoProb_ExcludeComplements(file::AbstractString) = read_csv(file, 1, 1, 2, 0)
+readBXDpheno(file::AbstractString) = read_csv(file, 1, 1, 1, 1)
+readBXDgeno(file::AbstractString; skipstart = 1) = read_csv(file, skipstart, 1, 2, 0)
+readhe(file::AbstractString) = read_table(h -> ccall((:blmm_read_he, libblmm), Cint, (Cstring, Ref{Ptr{Cvoid}}), file, h))
+
+# round.(calcKinship(G), digits = d) in one device call (README.md:176-181)
+function calcKinship(G::Array{Float64, 2}, digits::Integer)
+    n, p = size(G)
+    K = Array{Float64, 2}(undef, n, n)
+    check(ccall((:blmm_kinship_rounded, libblmm), Cint, (Ptr{Cvoid}, Ptr{Float64}, Int64, Int64, Int64, Ptr{Float64}),
+                context(), G, n, p, digits, K))
+    return K
 end
 
 end # module

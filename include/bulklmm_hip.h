@@ -54,6 +54,8 @@ enum blmm_decomp { BLMM_EIGEN = 0, BLMM_SVD = 1 };
 
 /* compat_flags bits */
 #define BLMM_COMPAT_ALT_COUNTER 1 /* B2: h2_panel indexed by an improvement counter, src/bulkscan_helpers.jl:342-343 */
+#define BLMM_COMPAT_ALT_TRUE_WEIGHTS 2 /* blmm_scan_alt: evaluate the closing log-likelihoods at makeweights(h2); the default
+                                          restates src/scan.jl:431-436, which hands wls the square roots of the weights */
 
 /* Mirrors the keyword arguments of bulkscan()/scan() 1:1 (src/bulkscan.jl:81-92, src/scan.jl:94-109).
  * `nb` and `nt_blas` (thread blocking knobs of the CPU reference) have no meaning here. */
@@ -120,9 +122,26 @@ int blmm_host_unregister(void* p);
 void* blmm_host_alloc(uint64_t bytes);
 void blmm_host_free(void* p);
 
+/* ---- readers for the file formats the reference reads (host code, no GPU needed) ----------------------------------
+ * blmm_read_csv: numeric CSV; `skip_lines` leading lines are dropped, then of every line the fields first_col, first_col +
+ * col_step, ... (0-based) up to the last `drop_last` fields are parsed: readGenoProb = (1, 1, 1, 0),
+ * readGenoProb_ExcludeComplements = (1, 1, 2, 0), readBXDpheno = (1, 1, 1, 1), readBXDgeno = (1, 1, 2, 0)
+ * (src/readData.jl:41-96, 159-165).  blmm_read_he: Helium .he (test/kinship_test.jl:5).  The table is column-major;
+ * blmm_table_copy writes it into the caller's rows x cols buffer (which may be pinned: blmm_host_alloc). */
+typedef struct blmm_table blmm_table;
+int blmm_read_csv(const char* path, int64_t skip_lines, int64_t first_col, int64_t col_step, int64_t drop_last, blmm_table** out);
+int blmm_read_he(const char* path, blmm_table** out);
+int64_t blmm_table_rows(const blmm_table* t);
+int64_t blmm_table_cols(const blmm_table* t);
+int blmm_table_copy(const blmm_table* t, double* dst);
+void blmm_table_free(blmm_table* t);
+
 /* ---- calcKinship(G)  (src/kinship.jl:4-14) ----------------------------------------------- */
 int blmm_kinship(blmm_ctx* ctx, const double* G, int64_t n, int64_t p, double* K_out);
 int blmm_kinship_dev(blmm_ctx* ctx, const double* dG, int64_t n, int64_t p, double* dK_out);
+/* round.(calcKinship(G), digits = d) on the device, the convention of README.md:176-181 and test/generate_test_bxdData.jl:14
+ * (Julia / NumPy: round(x * 10^d) / 10^d, ties to even); digits < 0: no rounding */
+int blmm_kinship_rounded(blmm_ctx* ctx, const double* G, int64_t n, int64_t p, int64_t digits, double* K_out);
 
 /* ---- bulkscan(Y, G, [Covar], K; ...)  (src/bulkscan.jl:81-162, 188-314, 321-397, 428-526) --
  * Y n x m, G n x p, Covar n x ncov (NULL/0 = none: the intercept is the only null covariate),
@@ -196,6 +215,17 @@ int blmm_scan_perms_f32_dev(blmm_ctx* ctx, const blmm_opts* opts, const double* 
                             int64_t p, const double* dCovar, int64_t ncov, const double* dK, const double* dweights,
                             int64_t nperms, uint64_t seed, const int32_t* dperm_idx, double* dscalars_out,
                             double* dlod_out, float* dLperms_out, blmm_status* status);
+
+/* ---- scan(y, G, [Z], K; assumption = "alt") -> scan_alt (src/scan.jl:397-453): the variance components are re-estimated for
+ * every marker (fitlmm on [Z g_i], src/lmm.jl:56-86, one Brent search per marker on the device).
+ * scalars_out = [sigma2_e, h2_null]; lod_out p; h2_each_out p (`h2_each_marker`).  opts->compat_flags:
+ * BLMM_COMPAT_ALT_TRUE_WEIGHTS. */
+int blmm_scan_alt(blmm_ctx* ctx, const blmm_opts* opts, const double* y, int64_t n, const double* G, int64_t p,
+                  const double* Covar, int64_t ncov, const double* K, const double* weights, double* scalars_out,
+                  double* lod_out, double* h2_each_out, blmm_status* status);
+int blmm_scan_alt_dev(blmm_ctx* ctx, const blmm_opts* opts, const double* dy, int64_t n, const double* dG, int64_t p,
+                      const double* dCovar, int64_t ncov, const double* dK, const double* dweights, double* dscalars_out,
+                      double* dlod_out, double* dh2_each_out, blmm_status* status);
 
 /* ---- on-device consumer of L: column maxima (per-trait / per-permutation peak LOD and its marker, 0-based) -------
  * The reduction behind get_thresholds (src/analysis_helpers/single_trait_analysis.jl:13-23); argmax_out may be NULL. */

@@ -43,7 +43,7 @@ __all__ = [
     "resid", "rss", "brent_optim", "gridbrent", "fitlmm", "calcKinship", "transform_rotation",
     "transform_reweight", "transform_permute", "computeR_LMM", "univar_liteqtl", "weighted_liteqtl",
     "find_optim_h2", "gridscan_by_bin", "bulkscan", "bulkscan_null", "bulkscan_null_grid",
-    "bulkscan_alt_grid", "scan", "scan_null", "scan_perms_lite", "lod2log10p", "read_he",
+    "bulkscan_alt_grid", "scan", "scan_null", "scan_alt", "scan_perms_lite", "lod2log10p", "read_he",
 ]
 
 
@@ -760,6 +760,45 @@ def scan_null(y, g, covar, K, prior, addIntercept: bool, reml: bool = False, met
     return {"sigma2_e": out00.sigma2, "h2_null": out00.h2, "lod": lod}
 
 
+def scan_alt(y, g, covar, K, prior, addIntercept: bool, reml: bool = False, method: str = "qr", optim_interval: int = 1,
+             decomp_scheme: str = "eigen", true_weights: bool = False, h2_each_override: Optional[np.ndarray] = None,
+             h2_null_override: Optional[float] = None):
+    """src/scan.jl:397-453 -- variance components re-estimated per marker.
+    The closing `wls(y0, X, sqrtw_alt, prior)` / `wls(y0, X0_covar, sqrtw_null, prior)` (:434-435) are handed the SQUARE ROOTS
+    of the weights as `w` and carry no `reml` keyword; that is restated as written.  `true_weights` (not in the reference)
+    evaluates both at makeweights(h2).  `h2_each_override` / `h2_null_override`: test hooks (skip the Brent searches)."""
+    y = _mat(y)
+    g = _mat(g)
+    covar = _mat(covar)
+    (n, p) = g.shape
+    num_of_covar = covar.shape[1] + 1 if addIntercept else covar.shape[1]
+    y0, X0, lambda0 = transform_rotation(y, np.hstack([covar, g]), K, addIntercept=addIntercept, decomp_scheme=decomp_scheme)
+    X0_covar = X0[:, :num_of_covar]
+    pve_list = np.empty(p)
+    out00 = fitlmm(y0, X0_covar, lambda0, prior, reml=reml, method=method, optim_interval=optim_interval)
+    h2_null = out00.h2 if h2_null_override is None else float(h2_null_override)
+    lod = np.zeros(p)
+    X = X0[:, :num_of_covar + 1].copy()
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        for i in range(p):
+            X[:, num_of_covar] = X0[:, num_of_covar + i]
+            if h2_each_override is None:
+                h2_alt = fitlmm(y0, X, lambda0, prior, reml=reml, method=method, optim_interval=optim_interval).h2
+            else:
+                h2_alt = float(h2_each_override[i])
+            w_null = makeweights(h2_null, lambda0)
+            w_alt = makeweights(h2_alt, lambda0)
+            if not true_weights:
+                w_null = np.sqrt(w_null)
+                w_alt = np.sqrt(w_alt)
+            wls_alt = wls(y0, X, w_alt, prior)
+            wls_null = wls(y0, X0_covar, w_null, prior)
+            lod[i] = (wls_alt.ell - wls_null.ell) / np.log(10)
+            pve_list[i] = h2_alt
+    return {"sigma2_e": out00.sigma2, "h2_null": out00.h2, "h2_each_marker": pve_list, "lod": lod}
+
+
 def scan_perms_lite(y, g, covar, K, prior_variance: float = 1.0, prior_sample_size: float = 0.0, addIntercept: bool = True,
                     method: str = "qr", optim_interval: int = 1, nperms: int = 1024, rndseed: int = 0, reml: bool = False,
                     decomp_scheme: str = "eigen", perm_idx: Optional[np.ndarray] = None, h2_override: Optional[float] = None,
@@ -797,8 +836,8 @@ def scan(y, g, K, covar=None, weights=None, prior_variance: float = 0.0, prior_s
          addIntercept: bool = True, reml: bool = False, assumption: str = "null", method: str = "qr", optim_interval: int = 1,
          permutation_test: bool = False, nperms: int = 1024, rndseed: int = 0, decomp_scheme: str = "eigen",
          output_pvals: bool = False, chisq_df: int = 1, perm_idx: Optional[np.ndarray] = None,
-         h2_override: Optional[float] = None, rotation_override=None):
-    """src/scan.jl:94-271 -- single-trait API (null assumption and permutations; `alt` is out of scope)."""
+         h2_override: Optional[float] = None, rotation_override=None, **alt_kw):
+    """src/scan.jl:94-271 -- single-trait API."""
     y = _mat(y)
     g = _mat(g)
     K = _mat(K)
@@ -823,7 +862,8 @@ def scan(y, g, K, covar=None, weights=None, prior_variance: float = 0.0, prior_s
     elif assumption == "alt":
         if permutation_test:
             raise BulkLMMError("Permutation test option currently is not supported for the alternative assumption.")
-        raise NotImplementedError("scan_alt (per-marker Brent) is outside the bulkscan hot path (SURVEY.md §8(a) A19)")
+        res = scan_alt(y, g, covar, K, [prior_variance, prior_sample_size], addIntercept, reml=reml, method=method,
+                       optim_interval=optim_interval, decomp_scheme=decomp_scheme, **alt_kw)
     else:
         raise BulkLMMError("Assumption keyword is not supported. Please enter null or alt.")
     if output_pvals:

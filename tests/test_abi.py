@@ -107,3 +107,42 @@ def test_trait_sharding_helper(blmm):
         assert all(parts[i][1] == parts[i + 1][0] for i in range(w - 1))
         sizes = [b - a for a, b in parts]
         assert max(sizes) - min(sizes) <= 1
+
+
+def test_readers_for_the_reference_file_formats(blmm, tmp_path):
+    """readGenoProb[_ExcludeComplements], readBXDpheno, readBXDgeno (src/readData.jl:41-96,159-165) and Helium .he: host
+    code behind the C ABI, no GPU needed.  Files in the shape of the BXD CSVs: quoted header, quoted id column, pheno with a
+    trailing column that is dropped, genotype probabilities in complementary column pairs."""
+    rng = np.random.default_rng(5)
+    n, pm = 7, 6
+    prob = rng.random((n, pm))
+    geno = np.empty((n, 2 * pm))
+    geno[:, 0::2] = prob
+    geno[:, 1::2] = 1.0 - prob
+    gfile = tmp_path / "geno.csv"
+    with open(gfile, "w") as f:
+        f.write(",".join(['"id"'] + [f'"m{j}_{ab}"' for j in range(pm) for ab in "BD"]) + "\n")
+        for i in range(n):
+            f.write(",".join([f'"BXD,{i}"'] + [repr(float(x)) for x in geno[i]]) + "\r\n")   # a comma inside a quoted id, CRLF
+    assert np.array_equal(blmm.readGenoProb(str(gfile)), geno)
+    assert np.array_equal(blmm.readGenoProb_ExcludeComplements(str(gfile)), prob)
+    assert np.array_equal(blmm.readBXDgeno(str(gfile)), prob)                  # [:, 2:2:end] of the raw table
+    ph = rng.standard_normal((n, 5))
+    pfile = tmp_path / "pheno.csv"
+    with open(pfile, "w") as f:
+        f.write("id,t1,t2,t3,t4,t5,extra\n")
+        for i in range(n):
+            f.write(",".join([f"s{i}"] + [repr(float(x)) for x in ph[i]] + ["0"]) + "\n")
+    assert np.array_equal(blmm.readBXDpheno(str(pfile)), ph)
+    sys_path_tests = os.path.join(ROOT, "tests")
+    import sys
+    sys.path.insert(0, sys_path_tests)
+    from common import GOLDEN, bxd_kinship
+    K = blmm.readhe(os.path.join(GOLDEN, "bxd_kinship_ref.he"))
+    assert K.shape == (79, 79) and np.array_equal(np.round(K, 12), bxd_kinship())
+    with pytest.raises(blmm.BulkLMMError):
+        blmm.readBXDpheno(str(tmp_path / "missing.csv"))
+    bad = tmp_path / "bad.csv"
+    open(bad, "w").write("id,a,b,x\ns1,1.0,2.0,0\ns2,1.0,0\n")                 # ragged
+    with pytest.raises(blmm.BulkLMMError):
+        blmm.readBXDpheno(str(bad))

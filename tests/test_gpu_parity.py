@@ -727,3 +727,80 @@ def test_concurrent_contexts_with_grid_barrier_kernels(blmm):
         got = blmm.bulkscan_multi(mc, Y, G, K, method="null-exact", gather="host_shards")
         assert np.array_equal(got["L"], one["L"]) and np.array_equal(got["h2_null_list"], one["h2_null_list"])
     mc.close()
+
+
+def test_from_files_to_lod(blmm, gpu_ctx, tmp_path):
+    ctx = gpu_ctx
+    """The reference's own usage end to end (README.md:150-200): read the pheno / geno-probability CSVs, calcKinship rounded
+    to 12 digits, bulkscan.  Files are written in the BXD layout; every stage runs through the C ABI."""
+    Y, G, _, _ = make_data(p=240, m=30, seed=91, bxd=False)
+    n, p = G.shape
+    with open(tmp_path / "geno.csv", "w") as f:
+        f.write(",".join(['"id"'] + [f'"m{j}_{ab}"' for j in range(p) for ab in "BD"]) + "\n")
+        for i in range(n):
+            f.write(",".join([f'"BXD{i}"'] + [repr(float(x)) for j in range(p) for x in (G[i, j], 1.0 - G[i, j])]) + "\n")
+    with open(tmp_path / "pheno.csv", "w") as f:
+        f.write(",".join(["id"] + [f"t{j}" for j in range(Y.shape[1])] + ["x"]) + "\n")
+        for i in range(n):
+            f.write(",".join([f"BXD{i}"] + [repr(float(x)) for x in Y[i]] + ["0"]) + "\n")
+    Yf = blmm.readBXDpheno(str(tmp_path / "pheno.csv"))
+    Gf = blmm.readGenoProb_ExcludeComplements(str(tmp_path / "geno.csv"))
+    assert np.array_equal(Yf, Y) and np.array_equal(Gf, G)
+    K = blmm.calcKinship(Gf, ctx=ctx, digits=12)
+    Kref = np.round(O.calcKinship(G), 12)
+    assert np.abs(K - Kref).max() <= 1.5e-12            # one unit in the 12th digit where the unrounded values differ by an ulp
+    assert np.array_equal(K, np.round(blmm.calcKinship(Gf, ctx=ctx), 12))     # device rounding == round.(K, digits=12)
+    got = blmm.bulkscan(Yf, Gf, K, method="null-exact", ctx=ctx)
+    ref = O.bulkscan_null(Y, G, K, h2_override=got["h2_null_list"])
+    assert_lod_close(got["L"], ref.L)
+
+
+@pytest.mark.parametrize("case", ["ml", "covar_reml_intervals", "weights", "true_weights", "n300"])
+def test_scan_alt_matches_oracle(blmm, gpu_ctx, case):
+    """scan(...; assumption = "alt") (scan_alt, src/scan.jl:397-453): one Brent search per marker on the device.  h2 of every
+    marker against the oracle's Brent (1e-6 unless the oracle's likelihood is flat there), LOD against the oracle evaluated
+    at the device's h2 (1e-6 relative), including the reference's square-rooted weights in the closing wls calls."""
+    ctx = gpu_ctx
+    kw = dict(prior_variance=1.0, prior_sample_size=0.1)
+    n, p, ncov = 79, 150, 0
+    if case == "covar_reml_intervals":
+        kw.update(reml=True, optim_interval=3)
+        ncov = 2
+    if case == "n300":
+        n, p = 300, 90
+        kw = dict(prior_variance=0.0, prior_sample_size=0.0)
+    Y, G, K, Cov = make_data(n=n, p=p, m=2, seed=311 + len(case), bxd=(n == 79), ncov=ncov)
+    y = Y[:, :1]
+    if case == "weights":
+        kw["weights"] = np.random.default_rng(3).uniform(0.5, 1.5, n)
+    gkw = dict(kw)
+    okw = dict(kw)
+    if case == "true_weights":
+        gkw["alt_true_weights"] = True
+        okw["true_weights"] = True
+    got = blmm.scan(y, G, K, Cov, assumption="alt", ctx=ctx, **gkw)
+    own = O.scan(y, G, K, covar=Cov, assumption="alt", **okw)
+    assert abs(got["h2_null"] - own["h2_null"]) <= 1e-6 and abs(got["sigma2_e"] - own["sigma2_e"]) <= 1e-6 * abs(own["sigma2_e"])
+    dh = np.abs(got["h2_each_marker"] - own["h2_each_marker"])
+    assert np.quantile(dh, 0.9) <= 1e-6, dh.max()
+    ref = O.scan(y, G, K, covar=Cov, assumption="alt", h2_each_override=got["h2_each_marker"], h2_null_override=got["h2_null"], **okw)
+    assert_lod_close(got["lod"], ref["lod"], atol=1e-9)
+    # where the searches differ by more than 1e-6 the likelihood must be flat: the LODs still agree closely
+    assert np.abs(got["lod"] - own["lod"]).max() <= 1e-6 * max(1.0, np.abs(own["lod"]).max()) + 1e-7
+    if case == "ml":
+        # the reference's own identity (test/bulkscan_test.jl:113-137): alt-grid ~ scan_alt, on a trait with h2 away from the
+        # boundary (at h2_null = 0 several markers have two-humped profiles and the local Brent search and the grid disagree,
+        # in the oracle exactly as on the device)
+        Y8 = make_data(n=n, p=p, m=8, seed=313, bxd=True)[0]
+        h8 = blmm.bulkscan_null(Y8, G, K, prior_variance=1.0, prior_sample_size=0.1, ctx=ctx).h2_null_list
+        y5 = Y8[:, [int(np.argmin(np.abs(h8 - 0.5)))]]
+        g5 = blmm.scan(y5, G, K, assumption="alt", ctx=ctx, **kw)
+        grid = [i * 0.05 for i in range(20)]
+        ag = blmm.bulkscan_alt_grid(y5, G, K, grid, prior_variance=1.0, prior_sample_size=0.1, ctx=ctx)
+        assert np.mean(np.abs(g5["h2_each_marker"] - ag.h2_panel[:, 0])) <= 0.05
+        assert np.mean((g5["lod"] - ag.L[:, 0]) ** 2) <= 0.01
+        pv = blmm.scan(y5, G, K, assumption="alt", output_pvals=True, ctx=ctx, **kw)
+        sel = pv["lod"] > 1e-3
+        assert np.allclose(pv["log10pvals"][sel], O.lod2log10p(pv["lod"][sel], 1), rtol=1e-9)
+    with pytest.raises(blmm.BulkLMMError, match="not supported for the alternative"):
+        blmm.scan(y, G, K, assumption="alt", permutation_test=True, ctx=ctx)
