@@ -51,7 +51,7 @@ class blmm_status(C.Structure):
     _fields_ = [("n_neg_eig", C.c_int64), ("n_nonpos_weight", C.c_int64), ("n_zero_norm", C.c_int64),
                 ("n_nan_lod", C.c_int64), ("n_brent_maxiter", C.c_int64), ("jacobi_sweeps", C.c_int64),
                 ("jacobi_cycles", C.c_int64), ("jacobi_ticks_100mhz", C.c_int64),
-                ("lowrank_rank", C.c_int64), ("lowrank_fallback", C.c_int64), ("lowrank_resid", C.c_double),
+                ("lowrank_rank", C.c_int64), ("lowrank_fallback", C.c_int64), ("lowrank_shared", C.c_int64), ("lowrank_resid", C.c_double),
                 ("t_eigen_ms", C.c_double), ("t_rotate_ms", C.c_double), ("t_h2_ms", C.c_double),
                 ("t_prep_ms", C.c_double), ("t_scan_ms", C.c_double), ("t_total_ms", C.c_double)]
 

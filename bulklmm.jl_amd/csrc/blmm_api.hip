@@ -187,6 +187,7 @@ int finish_status(blmm_ctx* ctx, blmm_status* st, Timer* tm) {
   st->jacobi_cycles = h[6]; st->jacobi_ticks_100mhz = h[7];
   st->lowrank_rank = h[8];
   st->lowrank_fallback = h[10];
+  st->lowrank_shared = h[12];
   if (h[8] < 0) return fail(ctx, BLMM_ERR_HIP, "weight-basis kernel: a workgroup timed out at the grid barrier");
   if (h[11] != 0) return fail(ctx, BLMM_ERR_HIP, "the eigensolver did not converge (code " + std::to_string((long long)h[11]) +
                               ": > 0 dsyevd info, -7 grid barrier of the tridiagonalisation timed out, -8 QL iteration limit)");
@@ -398,13 +399,19 @@ double lr_tolerance() {
   return e ? atof(e) : 1e-13;
 }
 
+// leading dimension of the panel arrays: the columns are the traits in k_lr_classify's order, which pads the
+// shared-weights class to a tile multiple
+int64_t lr_ldq(const Pipe& P) { return P.ldy + 128; }
+
 int lr_begin(blmm_ctx* ctx, const Pipe& P, bool wbasis_started) {
   int rc;
-  const int64_t ldp = P.ldy, tstride = (int64_t)P.npad * P.ldx;
+  const int64_t ldp = lr_ldq(P), tstride = (int64_t)P.npad * P.ldx;
+  if ((rc = ensure(ctx, ctx->lrPerm, sizeof(int) * (size_t)ldp))) return rc;
+  if ((rc = ensure(ctx, ctx->lrDen0, sizeof(double) * (size_t)P.ldx))) return rc;
   if ((rc = ensure(ctx, ctx->lrT, sizeof(double) * (size_t)(1 + P.c) * tstride))) return rc;
   if ((rc = ensure(ctx, ctx->lrC, sizeof(double) * (size_t)P.npad * ldp))) return rc;
   if ((rc = ensure(ctx, ctx->lrL, sizeof(double) * (size_t)(P.c * (P.c + 1) / 2) * ldp))) return rc;
-  if ((rc = ensure(ctx, ctx->lrFlag, sizeof(int) * (size_t)(P.m > 0 ? P.m : 1)))) return rc;
+  if ((rc = ensure(ctx, ctx->lrFlag, sizeof(int) * (size_t)ldp))) return rc;
   if ((rc = ensure(ctx, ctx->lrPart, sizeof(double) * 2 * (size_t)((P.n + 63) / 64) * ldp))) return rc;
   if ((rc = ensure(ctx, ctx->panels, sizeof(double) * (size_t)P.npad * ldp))) return rc;
   if ((rc = ensure(ctx, ctx->wbQ, sizeof(double) * (size_t)P.npad * P.n))) return rc;
@@ -418,6 +425,8 @@ int lr_begin(blmm_ctx* ctx, const Pipe& P, bool wbasis_started) {
   rc = BLMM_OK;
   if (!wbasis_started) rc = launch_wbasis(ctx, P.lam, P.n, ptr<double>(ctx->wbW), ptr<double>(ctx->wbQ), rk, P.stat);
   if (!rc) rc = launch_lr_tpanels(ctx, P.Xt, P.ldx, P.p, P.n, P.c, P.npad, P.Z0, ptr<double>(ctx->wbQ), rk, ptr<double>(ctx->lrT), tstride);
+  if (!rc) rc = launch_lr_den0(ctx, P.n, P.c, P.Xt, P.ldx, P.p, P.Z0, ptr<double>(ctx->lrDen0));
+  if (!rc && hipMemsetAsync(ctx->lrPerm.p, 0xff, sizeof(int) * (size_t)ldp, ctx->side) != hipSuccess) rc = fail(ctx, BLMM_ERR_HIP, "hipMemsetAsync failed");
   ctx->stream = main_stream;
   if (rc) return rc;
   BLMM_HIP(hipEventRecord(ctx->ev_join, ctx->side));
@@ -426,31 +435,35 @@ int lr_begin(blmm_ctx* ctx, const Pipe& P, bool wbasis_started) {
 
 int lr_finish(blmm_ctx* ctx, const Pipe& P, const NullModel& nm, const double* dh2, double* dL, int64_t ldL, Timer& tm) {
   int rc;
-  const int64_t ldp = P.ldy, tstride = (int64_t)P.npad * P.ldx, m = P.m;
+  const int64_t ldp = lr_ldq(P), tstride = (int64_t)P.npad * P.ldx, m = P.m;
   int* rk = ptr<int>(ctx->wbRk);
+  int* perm = ptr<int>(ctx->lrPerm);
   hipStream_t main_stream = ctx->stream;
+  // the shared-weights class (same tolerance as the expansion guard; BLMM_LR_SHARED=0 switches the class off: A/B testing)
+  static const bool shared_on = !(getenv("BLMM_LR_SHARED") && getenv("BLMM_LR_SHARED")[0] == '0');
   BLMM_HIP(hipStreamWaitEvent(main_stream, ctx->ev_join, 0));
-  if ((rc = launch_lr_panels(ctx, nm, P.Yt, P.ldy, m, P.Z0, P.lam, dh2, ptr<double>(ctx->wbQ), rk, ptr<double>(ctx->panels),
+  if ((rc = launch_lr_classify(ctx, P.n, m, shared_on ? lr_tolerance() : 0.0, P.lam, dh2, perm, ldp, P.stat))) return rc;
+  if ((rc = launch_lr_panels(ctx, nm, P.Yt, P.ldy, m, P.Z0, P.lam, dh2, ptr<double>(ctx->wbQ), rk, perm, ptr<double>(ctx->panels),
                              ptr<double>(ctx->lrC), ptr<double>(ctx->lrL), ldp, P.stat))) return rc;
   tm.mark();
   // residual guard of the weight basis, every trait: side stream, beside the scan kernel; joined below
   BLMM_HIP(hipEventRecord(ctx->ev_fork, main_stream));
   BLMM_HIP(hipStreamWaitEvent(ctx->side, ctx->ev_fork, 0));
   ctx->stream = ctx->side;
-  rc = launch_lr_resid(ctx, nm, m, lr_tolerance(), P.lam, dh2, ptr<double>(ctx->wbQ), rk, ptr<double>(ctx->lrC), ldp,
+  rc = launch_lr_resid(ctx, nm, m, lr_tolerance(), P.lam, dh2, ptr<double>(ctx->wbQ), rk, perm, ptr<double>(ctx->lrC), ldp,
                        ptr<int>(ctx->lrFlag), ptr<double>(ctx->lrPart), P.stat);
   ctx->stream = main_stream;
   if (rc) return rc;
   BLMM_HIP(hipEventRecord(ctx->ev_join, ctx->side));
   LrArgs la;
-  la.s = scan_args(ctx, P, ptr<double>(ctx->panels), ldp, dL, ldL, m);
+  la.s = scan_args(ctx, P, ptr<double>(ctx->panels), ldp, dL, ldL, m + 192 < ldp ? m + 192 : ldp);   // sizes the grid only: <= m/64 + 3 trait tiles are in use
   la.Cp = ptr<double>(ctx->lrC); la.T = ptr<double>(ctx->lrT); la.tstride = tstride; la.Ls = ptr<double>(ctx->lrL);
-  la.rk = rk; la.c = P.c;
+  la.rk = rk; la.c = P.c; la.perm = perm; la.nshared = P.stat + 12; la.mtraits = m; la.den0 = ptr<double>(ctx->lrDen0);
   if ((rc = launch_scan_lr(ctx, la))) return rc;
   BLMM_HIP(hipStreamWaitEvent(main_stream, ctx->ev_join, 0));
   // flagged traits (normally none: the kernel reads the count on the device and returns): full-length sums
   if ((rc = launch_scan_fix(ctx, nm, P.Xt, P.ldx, P.p, ptr<double>(ctx->panels), ptr<double>(ctx->lrL), ldp, P.Z0, P.lam, dh2,
-                            ptr<int>(ctx->lrFlag), dL, ldL, P.stat))) return rc;
+                            ptr<int>(ctx->lrFlag), perm, dL, ldL, P.stat))) return rc;
   tm.mark();
   return BLMM_OK;
 }
@@ -535,7 +548,7 @@ void blmm_destroy(blmm_ctx* ctx) {
                     &ctx->iyy, &ctx->h2, &ctx->h2idx, &ctx->sig2, &ctx->ell, &ctx->isx, &ctx->stat, &ctx->gridd, &ctx->misc,
                     &ctx->EllTab, &ctx->inY, &ctx->inG, &ctx->inK, &ctx->inCov, &ctx->inW, &ctx->outL, &ctx->outH2,
                     &ctx->tmpA, &ctx->tmpB, &ctx->tmpC, &ctx->perm, &ctx->r0, &ctx->altbuf, &ctx->logtab, &ctx->lraw,
-                    &ctx->wbQ, &ctx->wbW, &ctx->wbRk, &ctx->lrT, &ctx->lrC, &ctx->lrL, &ctx->lrFlag, &ctx->lrPart, &ctx->eigW, &ctx->xf32, &ctx->pf32, &ctx->brSt, &ctx->brList};
+                    &ctx->wbQ, &ctx->wbW, &ctx->wbRk, &ctx->lrT, &ctx->lrC, &ctx->lrL, &ctx->lrFlag, &ctx->lrPart, &ctx->lrPerm, &ctx->lrDen0, &ctx->eigW, &ctx->xf32, &ctx->pf32, &ctx->brSt, &ctx->brList};
   for (DevBuf* b : bufs) if (b->p) hipFree(b->p);
   for (auto& s : ctx->evsets) for (auto& e : s.e) (void)hipEventDestroy(e);
   if (ctx->rb_handle && ctx->rb_destroy) ctx->rb_destroy(ctx->rb_handle);

@@ -15,7 +15,7 @@ typedef double d4 __attribute__((ext_vector_type(4)));
 constexpr int CMAX = 4;          // null covariates (incl. intercept) the kernels are instantiated for
 constexpr int TILE_T = 64;       // traits per workgroup tile of the scan kernels
 constexpr int TILE_I = 128;      // markers per workgroup tile of the scan kernels
-constexpr int NSTAT = 12;        // device status counters ([6],[7]: eigensolver clocks, [8]: weight-basis rank, [9]: its residual, [10]: traits re-scanned full rank)
+constexpr int NSTAT = 14;        // device status counters ([6],[7]: eigensolver clocks, [8]: weight-basis rank, [9]: its residual, [10]: traits re-scanned full rank, [12], [13]: shared-weights traits / the others (k_lr_classify))
 
 enum StatIdx { ST_NEG_EIG = 0, ST_NONPOS_W = 1, ST_ZERO_NORM = 2, ST_NAN_LOD = 3, ST_BRENT_MAXIT = 4, ST_JACOBI_SWEEPS = 5 };
 
@@ -38,7 +38,7 @@ struct blmm_ctx {
   std::string err;
   // grow-only workspace
   blmm::DevBuf Ks, V, lam, U, Zs, Z0, Rp, Yt, Xt, panels, iyy, h2, h2idx, sig2, ell, isx, stat, gridd, misc, EllTab,
-      inY, inG, inK, inCov, inW, outL, outH2, tmpA, tmpB, tmpC, perm, r0, altbuf, logtab, lraw, wbQ, wbW, wbRk, lrT, lrC, lrL, lrFlag, lrPart, eigW, xf32, pf32, brSt, brList;
+      inY, inG, inK, inCov, inW, outL, outH2, tmpA, tmpB, tmpC, perm, r0, altbuf, logtab, lraw, wbQ, wbW, wbRk, lrT, lrC, lrL, lrFlag, lrPart, lrPerm, lrDen0, eigW, xf32, pf32, brSt, brList;
   // event sets: one per timed call since the last blmm_read_timings (grown on demand, reused afterwards)
   struct EvSet { hipEvent_t e[8]; int n; };
   std::vector<EvSet> evsets;
@@ -166,14 +166,23 @@ struct LrArgs {
   const double* T; int64_t tstride; // marker-side basis products [1+c][4*KR][ldx]
   const double* Ls;                 // packed L_j^-1 [c(c+1)/2][ldp]
   const int* rk;                    // {R, KR} on the device
+  const int* perm;                  // panel column -> trait (k_lr_classify; -1: padding)
+  const int64_t* nshared;           // device count of the shared-weights class: panel columns [0, nshared)
+  int64_t mtraits;                  // traits in all; the other class sits in columns [ldp - (mtraits - nshared), ldp)
+  const double* den0;               // the shared-weights class's denominators, per marker
   int c;
 };
 int launch_scan_lr(blmm_ctx* ctx, const LrArgs& la);
 int launch_lr_resid(blmm_ctx* ctx, const NullModel& nm, int64_t m, double tol, const double* lam, const double* h2,
-                    const double* Q, const int* rk, const double* Cp, int64_t ldp, int* flag_list, double* part, int64_t* stat);
+                    const double* Q, const int* rk, const int* perm, const double* Cp, int64_t ldp, int* flag_list,
+                    double* part, int64_t* stat);
 int launch_scan_fix(blmm_ctx* ctx, const NullModel& nm, const double* Xt, int64_t ldx, int64_t p, const double* P0,
                     const double* Ls, int64_t ldp, const double* Z0, const double* lam, const double* h2,
-                    const int* flag_list, double* L, int64_t ldL, int64_t* stat);
+                    const int* flag_list, const int* perm, double* L, int64_t ldL, int64_t* stat);
+// shared-weights class: column order of the panels (perm, info) and the per-marker denominators of the unweighted model
+int launch_lr_classify(blmm_ctx* ctx, int n, int64_t m, double tol, const double* lam, const double* h2, int* perm,
+                       int64_t ldq, int64_t* stat);
+int launch_lr_den0(blmm_ctx* ctx, int n, int c, const double* Xt, int64_t ldx, int64_t p, const double* Z0, double* den0);
 // kernels_scan_f32.hip: fp32 permutation LOD kernel and the fp64 k-major -> fp32 fragment-major conversion
 int launch_cvt_f32(blmm_ctx* ctx, const double* M, int64_t ld_in, int rows_valid, int64_t cols_valid, float* F,
                    int64_t ld_out, int kblocks);
@@ -184,8 +193,8 @@ int launch_wbasis(blmm_ctx* ctx, const double* lam, int n, double* Wk, double* Q
 int launch_lr_tpanels(blmm_ctx* ctx, const double* Xt, int64_t ldx, int64_t p, int n, int c, int npad, const double* Z0,
                       const double* Q, const int* rk, double* T, int64_t tstride);
 int launch_lr_panels(blmm_ctx* ctx, const NullModel& nm, const double* Yt, int64_t ldy, int64_t m, const double* Z0,
-                     const double* lam, const double* h2, const double* Q, const int* rk, double* P0, double* Cp,
-                     double* Ls, int64_t ldp, int64_t* stat);
+                     const double* lam, const double* h2, const double* Q, const int* rk, const int* perm, double* P0,
+                     double* Cp, double* Ls, int64_t ldp, int64_t* stat);
 int launch_scan_table(blmm_ctx* ctx, const ScanArgs& a);
 struct AltArgs {
   ScanArgs s; int ngrid; const double* EllTab; /* ngrid x m */ const double* grid_dev; double* H2; int64_t ldH; int counter_quirk;

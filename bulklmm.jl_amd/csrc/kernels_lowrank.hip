@@ -539,9 +539,9 @@ template <int C>
 __global__ void __launch_bounds__(64) k_lr_panels(NullModel nm, const double* __restrict__ Yt, int64_t ldy, int64_t m,
                                                    const double* __restrict__ Z0, const double* __restrict__ lam,
                                                    const double* __restrict__ h2v, const double* __restrict__ Q,
-                                                   const int* __restrict__ rk, int qcap, double* __restrict__ P0,
-                                                   double* __restrict__ Cp, double* __restrict__ Ls, int64_t ldp,
-                                                   int64_t* stat) {
+                                                   const int* __restrict__ rk, int qcap, const int* __restrict__ perm,
+                                                   double* __restrict__ P0, double* __restrict__ Cp,
+                                                   double* __restrict__ Ls, int64_t ldp, int64_t* stat) {
   extern __shared__ __attribute__((aligned(16))) double sh[];
   const int n = nm.n, npad = nm.npad;
   double* sLam = sh;
@@ -553,13 +553,15 @@ __global__ void __launch_bounds__(64) k_lr_panels(NullModel nm, const double* __
   for (int e = threadIdx.x; e < n * C; e += blockDim.x) sZ[e] = Z0[e];
   for (int e = threadIdx.x; e < rl * n; e += blockDim.x) sQ[e] = Q[e];
   __syncthreads();
-  const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (j >= ldp) return;
+  // column jc of the panels belongs to trait j = perm[jc] (k_lr_classify: shared-weights traits first); -1: padding
+  const int64_t jc = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (jc >= ldp) return;
   constexpr int NA = C * (C + 1) / 2;
-  if (j >= m) {  // padding columns
-    for (int k = 0; k < npad; ++k) P0[(int64_t)k * ldp + j] = 0.0;
-    for (int r = 0; r < R4; ++r) Cp[(int64_t)r * ldp + j] = 0.0;
-    for (int e = 0; e < NA; ++e) Ls[(int64_t)e * ldp + j] = 0.0;
+  const int64_t j = perm[jc];
+  if (j < 0 || j >= m) {  // padding columns
+    for (int k = 0; k < npad; ++k) P0[(int64_t)k * ldp + jc] = 0.0;
+    for (int r = 0; r < R4; ++r) Cp[(int64_t)r * ldp + jc] = 0.0;
+    for (int e = 0; e < NA; ++e) Ls[(int64_t)e * ldp + jc] = 0.0;
     return;
   }
   const double h2 = h2v[j];
@@ -647,12 +649,12 @@ __global__ void __launch_bounds__(64) k_lr_panels(NullModel nm, const double* __
           for (int q = 0; q < C; ++q) res = fma(-beta[q], sZ[q * n + k], res);
           p0 = w * res * isy;
         }
-        P0[(int64_t)k * ldp + j] = p0;
+        P0[(int64_t)k * ldp + jc] = p0;
       }
     }
   }
 #pragma unroll
-  for (int e = 0; e < NA; ++e) Ls[(int64_t)e * ldp + j] = Li[e];
+  for (int e = 0; e < NA; ++e) Ls[(int64_t)e * ldp + jc] = Li[e];
   // coefficients in the weight basis, 8 at a time (the weights are recomputed per chunk: rcp + 2 Newton steps).
   // Rows below `rl` come from the LDS copy of Q; the (rare) rest from global memory in a separate loop so that the
   // fast loop carries no global load at all.
@@ -667,7 +669,7 @@ __global__ void __launch_bounds__(64) k_lr_panels(NullModel nm, const double* __
       for (int u = 0; u < 8; ++u) c8[u] = fma(sQ[(rb + u) * n + k], w, c8[u]);
     }
 #pragma unroll
-    for (int u = 0; u < 8; ++u) Cp[(int64_t)(rb + u) * ldp + j] = c8[u];
+    for (int u = 0; u < 8; ++u) Cp[(int64_t)(rb + u) * ldp + jc] = c8[u];
   }
   for (int r = rl8; r < R4; ++r) {
     double c = 0.0;
@@ -675,7 +677,7 @@ __global__ void __launch_bounds__(64) k_lr_panels(NullModel nm, const double* __
       const double* qr = (r < rl) ? sQ + r * n : Q + (size_t)r * n;
       for (int k = 0; k < n; ++k) c = fma(qr[k], fabs(fast_rcp(fma(delta, sLam[k], 1.0))), c);
     }
-    Cp[(int64_t)r * ldp + j] = c;
+    Cp[(int64_t)r * ldp + jc] = c;
   }
 }
 
@@ -690,7 +692,8 @@ constexpr int LRR_KS = 64;
 constexpr int LRR_QC = 96;    // basis rows mirrored in LDS (48 KB); the (rare) rest is read from global memory
 __global__ void __launch_bounds__(256) k_lr_resid(int n, int64_t m, const double* __restrict__ lam,
                                                   const double* __restrict__ h2v, const double* __restrict__ Q,
-                                                  const int* __restrict__ rk, const double* __restrict__ Cp, int64_t ldp,
+                                                  const int* __restrict__ rk, const int* __restrict__ perm,
+                                                  const double* __restrict__ Cp, int64_t ldp,
                                                   double* __restrict__ part /* [nslice][2][ldp] */) {
   extern __shared__ __attribute__((aligned(16))) double sh[];
   const int R = rk[0];
@@ -705,9 +708,11 @@ __global__ void __launch_bounds__(256) k_lr_resid(int n, int64_t m, const double
     sQ[e] = (u < kc) ? Q[(size_t)r * n + k0 + u] : 0.0;
   }
   __syncthreads();
-  const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (j >= m) return;
-  const double h2 = h2v[j];
+  const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;   // panel column (permuted space); trait perm[j]
+  if (j >= ldp) return;
+  const int64_t jt = perm[j];
+  if (jt < 0 || jt >= m) return;
+  const double h2 = h2v[jt];
   const double delta = h2 / (1.0 - h2);
   double rr = 0.0, ww = 0.0;
   constexpr int KC = 16;
@@ -738,19 +743,19 @@ __global__ void __launch_bounds__(256) k_lr_resid(int n, int64_t m, const double
 }
 
 __global__ void __launch_bounds__(256) k_lr_resid2(int nslice, int64_t m, double tol2, const double* __restrict__ part,
-                                                   int64_t ldp, const int* __restrict__ rk, int* __restrict__ flag_list,
-                                                   int64_t* stat) {
+                                                   int64_t ldp, const int* __restrict__ rk, const int* __restrict__ perm,
+                                                   int* __restrict__ flag_list, int64_t* stat) {
   if (rk[0] < 0) return;
-  const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;   // panel column
   double rel2 = 0.0;
-  if (j < m) {
+  if (j < ldp && perm[j] >= 0 && perm[j] < m) {
     double rr = 0.0, ww = 0.0;
     for (int s = 0; s < nslice; ++s) { rr += part[((size_t)s * 2 + 0) * ldp + j]; ww += part[((size_t)s * 2 + 1) * ldp + j]; }
     rel2 = rr / ww;
     if (!(rel2 >= 0.0)) rel2 = INFINITY;   // NaN counts as a failure of the expansion
     if (!(rel2 <= tol2)) {
       const unsigned long long slot = atomicAdd((unsigned long long*)&stat[10], 1ull);
-      flag_list[slot] = (int)j;            // order of the list is immaterial: k_scan_fix recomputes whole columns
+      flag_list[slot] = (int)j;            // panel column; order of the list is immaterial: k_scan_fix recomputes whole columns
     }
   }
   // largest squared residual of the block -> stat[9] (bit pattern of a non-negative double orders like an integer)
@@ -769,7 +774,8 @@ __global__ void __launch_bounds__(256) k_scan_fix(NullModel nm, const double* __
                                                    const double* __restrict__ P0, const double* __restrict__ Ls, int64_t ldp,
                                                    const double* __restrict__ Z0, const double* __restrict__ lam,
                                                    const double* __restrict__ h2v, const int* __restrict__ flag_list,
-                                                   double* __restrict__ L, int64_t ldL, int64_t* stat) {
+                                                   const int* __restrict__ perm, double* __restrict__ L, int64_t ldL,
+                                                   int64_t* stat) {
   constexpr int KC = 256, NL = C * (C + 1) / 2;
   __shared__ double s_a0[KC], s_w[KC], s_wz[C][KC];
   const int64_t cnt = stat[10];
@@ -779,9 +785,10 @@ __global__ void __launch_bounds__(256) k_scan_fix(NullModel nm, const double* __
   const double scale = -0.5 * (double)n;
   int nnan = 0;
   for (int64_t item = blockIdx.x; item < cnt * ntile; item += gridDim.x) {
-    const int64_t j = flag_list[item / ntile];
+    const int64_t j = flag_list[item / ntile];      // panel column
+    const int64_t jt = perm[j];                     // its trait
     const int64_t i = (item % ntile) * 256 + threadIdx.x;
-    const double h2 = h2v[j];
+    const double h2 = h2v[jt];
     const double delta = h2 / (1.0 - h2);
     double num = 0.0, sxx = 0.0, sq[C];
 #pragma unroll
@@ -824,20 +831,154 @@ __global__ void __launch_bounds__(256) k_scan_fix(NullModel nm, const double* __
       const double u1 = 1.0 - r2;
       double lod = scale * log10(u1);
       if (!(u1 > 0.0)) { lod = (u1 == 0.0) ? INFINITY : NAN; nnan += (u1 != 0.0); }
-      L[j * ldL + i] = lod;
+      L[jt * ldL + i] = lod;
     }
   }
   if (nnan) atomicAdd((unsigned long long*)&stat[ST_NAN_LOD], (unsigned long long)nnan);
 }
 
+// ------------------------------------------------------------------------------------------------
+// Shared-weights class.  A trait whose weights are all 1 to within the tolerance of the expansion guard,
+//     |w_j - 1|_2 / |1|_2 <= delta_j sqrt(sum lambda^2 / n) <= tol          (w_jk = 1/(delta_j lambda_k + 1)),
+// needs no weight basis: its denominators Sxx - |u|^2 are the per-marker constants den0_i of the unweighted model (the
+// numerator panel still carries the trait's own weights).  On eQTL-like data that is every trait whose likelihood peaks
+// at the h2 = 0 boundary -- half of the BXD-shaped bench workload -- and k_scan_lr skips the rank-R phase for their
+// tiles.  k_lr_classify orders the panel columns: the class fills perm[] from the front, the other traits from the back
+// (perm was preset to -1 = padding; ldq - m >= 128 keeps a whole padding tile between the two), counts in stat[12] /
+// stat[13].  A workgroup owns 1024 consecutive traits and keeps their order; the order of the workgroups' ranges follows
+// the arrival of two atomics -- immaterial, every LOD is written through perm and its arithmetic does not depend on the
+// column it sits in.
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_lr_classify(int n, int64_t m, double tol, const double* __restrict__ lam,
+                                                     const double* __restrict__ h2v, int* __restrict__ perm, int64_t ldq,
+                                                     int64_t* stat) {
+  __shared__ double s_red[4];
+  __shared__ int s_cnt[4];
+  __shared__ long long s_base[2];
+  const int t = threadIdx.x;
+  double s2 = 0.0;
+  for (int k = t; k < n; k += 256) s2 = fma(lam[k], lam[k], s2);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s2 += __shfl_xor(s2, o, 64);
+  if ((t & 63) == 0) s_red[t >> 6] = s2;
+  __syncthreads();
+  const double rms = sqrt((s_red[0] + s_red[1] + s_red[2] + s_red[3]) / (double)n);
+  const double thr = (tol > 0.0) ? ((rms > 0.0) ? tol / rms : INFINITY) : 0.0;
+  const int64_t j0 = (int64_t)blockIdx.x * 1024 + 4 * t;
+  bool f[4];
+  int cnt = 0;
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    f[u] = false;
+    if (j0 + u < m) {
+      const double h2 = h2v[j0 + u];
+      f[u] = fabs(h2 / (1.0 - h2)) <= thr;      // false for NaN
+    }
+    cnt += f[u] ? 1 : 0;
+  }
+  int incl = cnt;                                // inclusive scan over the wave, then over the four waves
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const int v = __shfl_up(incl, o, 64);
+    if ((t & 63) >= o) incl += v;
+  }
+  if ((t & 63) == 63) s_cnt[t >> 6] = incl;
+  __syncthreads();
+  int before = incl - cnt;
+  for (int w = 0; w < (t >> 6); ++w) before += s_cnt[w];
+  const int total = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+  const int64_t valid = (m - (int64_t)blockIdx.x * 1024 < 1024) ? (m - (int64_t)blockIdx.x * 1024) : 1024;
+  if (t == 0) {
+    s_base[0] = (long long)atomicAdd((unsigned long long*)&stat[12], (unsigned long long)total);
+    s_base[1] = (long long)atomicAdd((unsigned long long*)&stat[13], (unsigned long long)(valid - total));
+  }
+  __syncthreads();
+  int64_t bpos = s_base[0] + before;
+  int64_t opos = s_base[1] + (4 * t - before);  // traits of the other class before this thread, in the workgroup's range
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    if (j0 + u < m) {
+      if (f[u]) perm[bpos++] = (int)(j0 + u);
+      else perm[ldq - 1 - (opos++)] = (int)(j0 + u);
+    }
+  }
+}
+
+// den0_i = Sxx - |L0^-1 s|^2 of marker i in the unweighted model: Sxx = sum_k x_ik^2, s_q = sum_k x_ik z_qk, Z0'Z0 = L0 L0'
+template <int C>
+__global__ void __launch_bounds__(256) k_lr_den0(int n, const double* __restrict__ Xt, int64_t ldx, int64_t p,
+                                                  const double* __restrict__ Z0, double* __restrict__ den0) {
+  constexpr int NA = C * (C + 1) / 2;
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= ldx) return;
+  if (i >= p) { den0[i] = 1.0; return; }
+  double A[NA], s[C], sxx = 0.0;
+#pragma unroll
+  for (int a = 0; a < NA; ++a) A[a] = 0.0;
+#pragma unroll
+  for (int q = 0; q < C; ++q) s[q] = 0.0;
+  for (int k = 0; k < n; ++k) {
+    const double x = Xt[(int64_t)k * ldx + i];
+    sxx = fma(x, x, sxx);
+#pragma unroll
+    for (int q = 0; q < C; ++q) {
+      const double zq = Z0[q * n + k];             // same address in every lane: a broadcast load
+      s[q] = fma(x, zq, s[q]);
+#pragma unroll
+      for (int r = 0; r <= q; ++r) A[q * (q + 1) / 2 + r] = fma(zq, Z0[r * n + k], A[q * (q + 1) / 2 + r]);
+    }
+  }
+  double L[NA], xx = sxx;
+#pragma unroll
+  for (int q = 0; q < C; ++q) {
+#pragma unroll
+    for (int r = 0; r <= q; ++r) {
+      double v = A[q * (q + 1) / 2 + r];
+#pragma unroll
+      for (int u = 0; u < r; ++u) v = fma(-L[q * (q + 1) / 2 + u], L[r * (r + 1) / 2 + u], v);
+      L[q * (q + 1) / 2 + r] = (r == q) ? sqrt(v) : v / L[r * (r + 1) / 2 + r];
+    }
+    double u = s[q];                               // forward substitution: u_q = (L0^-1 s)_q
+#pragma unroll
+    for (int r = 0; r < q; ++r) u = fma(-L[q * (q + 1) / 2 + r], s[r], u);
+    u /= L[q * (q + 1) / 2 + q];
+    s[q] = u;
+    xx = fma(-u, u, xx);
+  }
+  den0[i] = xx;
+}
+
+int launch_lr_classify(blmm_ctx* ctx, int n, int64_t m, double tol, const double* lam, const double* h2, int* perm,
+                       int64_t ldq, int64_t* stat) {
+  if (m > 0x7ffffff0LL) return fail(ctx, BLMM_ERR_INVALID, "too many traits for one launch");
+  if (m <= 0) return BLMM_OK;
+  hipLaunchKernelGGL(k_lr_classify, dim3((unsigned)((m + 1023) / 1024)), dim3(256), 0, ctx->stream, n, m, tol, lam, h2, perm, ldq, stat);
+  KCHECK();
+  return BLMM_OK;
+}
+
+int launch_lr_den0(blmm_ctx* ctx, int n, int c, const double* Xt, int64_t ldx, int64_t p, const double* Z0, double* den0) {
+  const unsigned blocks = (unsigned)((ldx + 255) / 256);
+#define D0(C) hipLaunchKernelGGL(k_lr_den0<C>, dim3(blocks), dim3(256), 0, ctx->stream, n, Xt, ldx, p, Z0, den0)
+  switch (c) {
+    case 1: D0(1); break;
+    case 2: D0(2); break;
+    case 3: D0(3); break;
+    default: return fail(ctx, BLMM_ERR_UNSUPPORTED, "number of null covariates (incl. intercept) must be 1..3 in the low-rank form");
+  }
+#undef D0
+  KCHECK();
+  return BLMM_OK;
+}
+
 int launch_lr_panels(blmm_ctx* ctx, const NullModel& nm, const double* Yt, int64_t ldy, int64_t m, const double* Z0,
-                     const double* lam, const double* h2, const double* Q, const int* rk, double* P0, double* Cp,
-                     double* Ls, int64_t ldp, int64_t* stat) {
+                     const double* lam, const double* h2, const double* Q, const int* rk, const int* perm, double* P0,
+                     double* Cp, double* Ls, int64_t ldp, int64_t* stat) {
   // 64 threads per block (more blocks than CUs even at m ~ 35k); basis rows in LDS up to 56 KB
   const unsigned blocks = (unsigned)((ldp + 63) / 64);
   const int qcap = (int)std::min<size_t>((size_t)nm.n, (56 * 1024) / (sizeof(double) * (size_t)nm.n));
   const size_t lds = sizeof(double) * ((size_t)nm.n * (1 + nm.c) + (size_t)qcap * nm.n);
-#define LP(C) hipLaunchKernelGGL(k_lr_panels<C>, dim3(blocks), dim3(64), lds, ctx->stream, nm, Yt, ldy, m, Z0, lam, h2, Q, rk, qcap, P0, Cp, Ls, ldp, stat)
+#define LP(C) hipLaunchKernelGGL(k_lr_panels<C>, dim3(blocks), dim3(64), lds, ctx->stream, nm, Yt, ldy, m, Z0, lam, h2, Q, rk, qcap, perm, P0, Cp, Ls, ldp, stat)
   switch (nm.c) {
     case 1: LP(1); break;
     case 2: LP(2); break;
@@ -852,26 +993,27 @@ int launch_lr_panels(blmm_ctx* ctx, const NullModel& nm, const double* Yt, int64
 
 // The guard (all traits): the caller runs it on the side stream beside the scan kernel, then launch_scan_fix.
 int launch_lr_resid(blmm_ctx* ctx, const NullModel& nm, int64_t m, double tol, const double* lam, const double* h2,
-                    const double* Q, const int* rk, const double* Cp, int64_t ldp, int* flag_list, double* part, int64_t* stat) {
+                    const double* Q, const int* rk, const int* perm, const double* Cp, int64_t ldp, int* flag_list,
+                    double* part, int64_t* stat) {
   if (m <= 0) return BLMM_OK;
   const int nslice = (nm.n + LRR_KS - 1) / LRR_KS;
   const size_t lds = sizeof(double) * ((size_t)LRR_KS * (1 + (size_t)LRR_QC));
   if (lds > 48 * 1024)
     BLMM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_lr_resid), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  hipLaunchKernelGGL(k_lr_resid, dim3((unsigned)((m + 255) / 256), (unsigned)nslice), dim3(256), lds, ctx->stream, nm.n, m, lam, h2, Q,
-                     rk, Cp, ldp, part);
-  hipLaunchKernelGGL(k_lr_resid2, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, ctx->stream, nslice, m, tol * tol, part, ldp, rk,
-                     flag_list, stat);
+  hipLaunchKernelGGL(k_lr_resid, dim3((unsigned)((ldp + 255) / 256), (unsigned)nslice), dim3(256), lds, ctx->stream, nm.n, m, lam, h2, Q,
+                     rk, perm, Cp, ldp, part);
+  hipLaunchKernelGGL(k_lr_resid2, dim3((unsigned)((ldp + 255) / 256)), dim3(256), 0, ctx->stream, nslice, m, tol * tol, part, ldp, rk,
+                     perm, flag_list, stat);
   KCHECK();
   return BLMM_OK;
 }
 
 int launch_scan_fix(blmm_ctx* ctx, const NullModel& nm, const double* Xt, int64_t ldx, int64_t p, const double* P0,
                     const double* Ls, int64_t ldp, const double* Z0, const double* lam, const double* h2,
-                    const int* flag_list, double* L, int64_t ldL, int64_t* stat) {
+                    const int* flag_list, const int* perm, double* L, int64_t ldL, int64_t* stat) {
   if (p <= 0) return BLMM_OK;
   const unsigned grid = (unsigned)(8 * (ctx->num_cus > 0 ? ctx->num_cus : 256));
-#define FX(C) hipLaunchKernelGGL(k_scan_fix<C>, dim3(grid), dim3(256), 0, ctx->stream, nm, Xt, ldx, p, P0, Ls, ldp, Z0, lam, h2, flag_list, L, ldL, stat)
+#define FX(C) hipLaunchKernelGGL(k_scan_fix<C>, dim3(grid), dim3(256), 0, ctx->stream, nm, Xt, ldx, p, P0, Ls, ldp, Z0, lam, h2, flag_list, perm, L, ldL, stat)
   switch (nm.c) {
     case 1: FX(1); break;
     case 2: FX(2); break;

@@ -8,6 +8,7 @@
 #include <cstring>
 #include <algorithm>
 #include <cstdlib>
+#include <type_traits>
 
 namespace blmm {
 
@@ -145,13 +146,16 @@ __global__ void __launch_bounds__(1024) k_jacobi_lds(const double* __restrict__ 
   constexpr int MAXB = 2;                               // blocks per thread: NP2 <= 62 -> nblk <= 1891 <= 2 x 960
   const int NW = nt - 64;                               // worker threads (the last wave is reserved for the angle lanes)
   int b_s1[MAXB], b_s2[MAXB], b_src[MAXB], b_dst[MAXB][4];
+  bool b_ok[MAXB];
 #pragma unroll
   for (int u = 0; u < MAXB; ++u) {
     const int b = (tid < NW) ? tid + u * NW : nblk;
-    b_s1[u] = -1; b_s2[u] = 0; b_src[u] = 0;
+    // a lane without a block still runs the branch-free loads and arithmetic (on slot 0 / block 0) and skips only the stores
+    b_s1[u] = 0; b_s2[u] = 0; b_src[u] = 0; b_ok[u] = false;
 #pragma unroll
     for (int w = 0; w < 4; ++w) b_dst[u][w] = 0;
     if (b < nblk) {
+      b_ok[u] = true;
       int row = (int)((sqrt(8.0 * b + 1.0) - 1.0) * 0.5);
       while (row * (row + 1) / 2 > b) --row;
       while ((row + 1) * (row + 2) / 2 <= b) ++row;
@@ -167,8 +171,10 @@ __global__ void __launch_bounds__(1024) k_jacobi_lds(const double* __restrict__ 
   const int nvit = NP2 * nr;
   const int nvthr = NW;
   const int vitem = (tid < nvthr) ? nvthr - 1 - tid : -1;
-  int v_slot = -1, v_src = 0, v_d0 = 0, v_d1 = 0;
+  int v_slot = 0, v_src = 0, v_d0 = 0, v_d1 = 0;
+  bool v_ok = false;
   if (vitem >= 0 && vitem < nvit) {
+    v_ok = true;
     v_slot = vitem / nr; const int r = vitem % nr;
     v_src = r * ld + 2 * v_slot; v_d0 = r * ld + jac_pi(2 * v_slot, NP2); v_d1 = r * ld + jac_pi(2 * v_slot + 1, NP2);
   }
@@ -212,6 +218,61 @@ __global__ void __launch_bounds__(1024) k_jacobi_lds(const double* __restrict__ 
       rel = fmax(rel, a2 * __builtin_amdgcn_rcp(pp));   // ~ (relative off-diagonal)^2; only gates the stop rule
     }
   };
+  // One round of a worker lane, branch-free up to the stores: EVERY LDS read first (the blocks' angles and entries, the V
+  // item's angle and pair), then the arithmetic, then the writes.  A and An (and the V copies) alias as far as the compiler
+  // can tell, so a read placed behind a write waits for it, and a lane with two items would walk two LDS round trips per
+  // round.  U1 / HV (wave-uniform): some lane of the wave owns a second block / a V item; lanes that own none load slot 0.
+#ifdef JAC_PROF
+  __shared__ unsigned long long s_prof[16][5];
+  bool prof = false;
+#endif
+  using TrueT = std::integral_constant<bool, true>;
+  using FalseT = std::integral_constant<bool, false>;
+  const bool w_u1 = __any(b_ok[1]) != 0, w_v = __any(v_ok) != 0;
+  auto worker_round = [&](auto U1c, auto HVc, const double* A, double* An, const double* rec, const double* Vc, double* Vn) {
+    constexpr bool U1 = decltype(U1c)::value, HV = decltype(HVc)::value;
+    constexpr int NU = U1 ? 2 : 1;
+    dpair cs1[NU], cs2[NU], x0[NU], x1[NU];
+#pragma unroll
+    for (int u = 0; u < NU; ++u) {
+      cs1[u] = *reinterpret_cast<const dpair*>(rec + 2 * b_s1[u]);
+      cs2[u] = *reinterpret_cast<const dpair*>(rec + 2 * b_s2[u]);
+      x0[u] = (dpair){A[b_src[u]], A[2 * PL + b_src[u]]};            // (b00, b10): column 2*s2
+      x1[u] = (dpair){A[PL + b_src[u]], A[3 * PL + b_src[u]]};       // (b01, b11): column 2*s2+1
+    }
+    dpair csv = (dpair){1.0, 0.0}, xy = (dpair){0.0, 0.0};
+    if constexpr (HV) {
+      csv = *reinterpret_cast<const dpair*>(rec + 2 * v_slot);
+      xy = (dpair){Vc[v_src], Vc[v_src + 1]};
+    }
+    // A: off-diagonal blocks B' = J1' B J2 written through pi.  The empty asm statements pin the arithmetic (and with it the
+    // loads) in front of the lane-conditional stores: hipcc otherwise sinks a block's loads into its `if`, behind the
+    // previous block's stores.
+    double o[NU][4];
+#pragma unroll
+    for (int u = 0; u < NU; ++u) {
+      const double c1 = cs1[u][0], sn1 = cs1[u][1], c2 = cs2[u][0], sn2 = cs2[u][1];
+      const double t00 = fma(c2, x0[u][0], -sn2 * x1[u][0]), t01 = fma(sn2, x0[u][0], c2 * x1[u][0]);
+      const double t10 = fma(c2, x0[u][1], -sn2 * x1[u][1]), t11 = fma(sn2, x0[u][1], c2 * x1[u][1]);
+      o[u][0] = fma(c1, t00, -sn1 * t10); o[u][1] = fma(c1, t01, -sn1 * t11);
+      o[u][2] = fma(sn1, t00, c1 * t10); o[u][3] = fma(sn1, t01, c1 * t11);
+      asm volatile("" : "+v"(o[u][0]), "+v"(o[u][1]), "+v"(o[u][2]), "+v"(o[u][3]));
+    }
+#ifdef JAC_PROF
+    if (prof) s_prof[tid >> 6][1] = __builtin_amdgcn_s_memtime();
+#endif
+    double v0 = 0.0, v1 = 0.0;
+    if constexpr (HV) {   // V slice: columns (2s, 2s+1) of one local row
+      v0 = fma(csv[0], xy[0], -csv[1] * xy[1]); v1 = fma(csv[1], xy[0], csv[0] * xy[1]);
+      asm volatile("" : "+v"(v0), "+v"(v1));
+    }
+#pragma unroll
+    for (int u = 0; u < NU; ++u)
+      if (b_ok[u]) { An[b_dst[u][0]] = o[u][0]; An[b_dst[u][1]] = o[u][1]; An[b_dst[u][2]] = o[u][2]; An[b_dst[u][3]] = o[u][3]; }
+    if constexpr (HV) {
+      if (v_ok) { Vn[v_d0] = v0; Vn[v_d1] = v1; }
+    }
+  };
   const double jac_stop2 = stop2;
   const bool is_angle_wave = __builtin_amdgcn_readfirstlane(tid >> 6) == (nt >> 6) - 1;
   int cur = 0, sweep = 0, dpos = N - 1;                 // dpos: where the zero pad row/col of an odd n currently sits
@@ -223,6 +284,10 @@ __global__ void __launch_bounds__(1024) k_jacobi_lds(const double* __restrict__ 
   __syncthreads();
   for (; sweep < 30; ++sweep) {
     for (int round = 0; round < N - 1; ++round) {
+#ifdef JAC_PROF
+      prof = sweep == 2 && round == 10 && blockIdx.x == 0 && (tid & 63) == 0;
+      if (prof) s_prof[tid >> 6][0] = __builtin_amdgcn_s_memtime();
+#endif
       const double* A = smem + (cur ? AO : 0);
       double* An = smem + (cur ? 0 : AO);
       const double* rec = smem + (cur ? REC1 : REC);
@@ -230,39 +295,17 @@ __global__ void __launch_bounds__(1024) k_jacobi_lds(const double* __restrict__ 
       // The angle wave and the worker waves take wave-uniform (scalar) branches: a wave must not walk the other role's
       // code with an empty exec mask (its LDS instructions would still take issue slots on the critical path).
       if (!is_angle_wave) {
-      // ---- A: off-diagonal blocks B' = J1' B J2 written through pi -------------------------------------------
-#pragma unroll
-      for (int u = 0; u < MAXB; ++u) {
-        if (b_s1[u] >= 0) {
-          const dpair cs1 = *reinterpret_cast<const dpair*>(rec + 2 * b_s1[u]);
-          const dpair cs2 = *reinterpret_cast<const dpair*>(rec + 2 * b_s2[u]);
-          const dpair x0 = (dpair){A[b_src[u]], A[2 * PL + b_src[u]]};            // (b00, b10): column 2*s2
-          const dpair x1 = (dpair){A[PL + b_src[u]], A[3 * PL + b_src[u]]};       // (b01, b11): column 2*s2+1
-          const double c1 = cs1[0], sn1 = cs1[1], c2 = cs2[0], sn2 = cs2[1];
-          const double t00 = fma(c2, x0[0], -sn2 * x1[0]), t01 = fma(sn2, x0[0], c2 * x1[0]);
-          const double t10 = fma(c2, x0[1], -sn2 * x1[1]), t11 = fma(sn2, x0[1], c2 * x1[1]);
-          An[b_dst[u][0]] = fma(c1, t00, -sn1 * t10); An[b_dst[u][1]] = fma(c1, t01, -sn1 * t11);
-          An[b_dst[u][2]] = fma(sn1, t00, c1 * t10); An[b_dst[u][3]] = fma(sn1, t01, c1 * t11);
-        }
-      }
-      // ---- V slice: columns (2s, 2s+1) of every local row -------------------------------------------------------
-      {
         const double* Vc = smem + V0 + (cur ? VO : 0);
         double* Vn = smem + V0 + (cur ? 0 : VO);
-        if (v_slot >= 0) {
-          const dpair csv = *reinterpret_cast<const dpair*>(rec + 2 * v_slot);
-          const dpair xy = (dpair){Vc[v_src], Vc[v_src + 1]};
-          Vn[v_d0] = fma(csv[0], xy[0], -csv[1] * xy[1]);
-          Vn[v_d1] = fma(csv[1], xy[0], csv[0] * xy[1]);
-        }
+        if (w_u1) { if (w_v) worker_round(TrueT{}, TrueT{}, A, An, rec, Vc, Vn); else worker_round(TrueT{}, FalseT{}, A, An, rec, Vc, Vn); }
+        else      { if (w_v) worker_round(FalseT{}, TrueT{}, A, An, rec, Vc, Vn); else worker_round(FalseT{}, FalseT{}, A, An, rec, Vc, Vn); }
         if (vitem >= 0) for (int item = vitem + nvthr; item < nvit; item += nvthr) {   // only when NP2 * rows_per exceeds the lanes left
           const int slot = item / nr, r = item % nr;
-          const dpair csv = *reinterpret_cast<const dpair*>(rec + 2 * slot);
-          const dpair xy = (dpair){Vc[r * ld + 2 * slot], Vc[r * ld + 2 * slot + 1]};
-          Vn[r * ld + jac_pi(2 * slot, NP2)] = fma(csv[0], xy[0], -csv[1] * xy[1]);
-          Vn[r * ld + jac_pi(2 * slot + 1, NP2)] = fma(csv[1], xy[0], csv[0] * xy[1]);
+          const dpair csw = *reinterpret_cast<const dpair*>(rec + 2 * slot);
+          const dpair xw = (dpair){Vc[r * ld + 2 * slot], Vc[r * ld + 2 * slot + 1]};
+          Vn[r * ld + jac_pi(2 * slot, NP2)] = fma(csw[0], xw[0], -csw[1] * xw[1]);
+          Vn[r * ld + jac_pi(2 * slot + 1, NP2)] = fma(csw[1], xw[0], csw[0] * xw[1]);
         }
-      }
       } else if (angle_lane) {
       // ---- angle lanes: own diagonal block of round r, then (c, s) of round r+1 -----------------------------------
         auto rot_diag = [&](double c, double sn, double app, double aqq, double apq, double& npp, double& nqq) {
@@ -297,7 +340,15 @@ __global__ void __launch_bounds__(1024) k_jacobi_lds(const double* __restrict__ 
       }
       dpos = jac_pi(dpos, NP2);
       cur ^= 1;
+#ifdef JAC_PROF
+      if (prof) s_prof[tid >> 6][2] = __builtin_amdgcn_s_memtime();
+      __builtin_amdgcn_s_waitcnt(0xc07f);
+      if (prof) s_prof[tid >> 6][3] = __builtin_amdgcn_s_memtime();
+#endif
       __syncthreads();
+#ifdef JAC_PROF
+      if (prof) s_prof[tid >> 6][4] = __builtin_amdgcn_s_memtime();
+#endif
     }
     // sweep verdict: the largest relative off-diagonal (squared) any pair met while its angles were derived
     if (angle_lane) { smem[REL + at] = myrel; myrel = 0.0; }
@@ -310,6 +361,15 @@ __global__ void __launch_bounds__(1024) k_jacobi_lds(const double* __restrict__ 
     // anything (tests/test_gpu_parity.py::test_eigensolver_accuracy)
     if (mx < jac_stop2) break;
   }
+#ifdef JAC_PROF
+  __syncthreads();
+  if (blockIdx.x == 0 && tid == 0) {
+    const unsigned long long b = s_prof[0][0];
+    for (int w = 0; w < (nt >> 6); ++w)
+      printf("jac wave %2d start %5lld computed %5lld issued %5lld lds-done %5lld after-barrier %5lld\n", w, (long long)(s_prof[w][0] - b),
+             (long long)(s_prof[w][1] - b), (long long)(s_prof[w][2] - b), (long long)(s_prof[w][3] - b), (long long)(s_prof[w][4] - b));
+  }
+#endif
   // positions -> compact output (skip the pad position of an odd n): eigenvalue = diagonal, eigenvector = V column
   const double* A = smem + (cur ? AO : 0);
   const double* Vc = smem + V0 + (cur ? VO : 0);

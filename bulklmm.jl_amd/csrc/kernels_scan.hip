@@ -267,25 +267,59 @@ int launch_scan_exact(blmm_ctx* ctx, const ScanArgs& a, int c) {
 //   phase 2 (R long):   Sxx  = (Q'x_i.^2)' c_j ,  s_q = (Q'(x_i.*z_q))' c_j      A = Cp panel,  B = T[0], T[1+q]
 //   epilogue:           u = L_j^-1 s ;  r^2 = num^2 / (Sxx - |u|^2) ;  LOD
 // Same tiling, fragment maps and store path as k_scan.  KR = ceil(R/4) is read from device memory (rk[1]).
+// Panel column t belongs to trait perm[t] (k_lr_classify).  The tiles at the front hold the shared-weights class
+// (weights = 1 to within the guard's tolerance): phase 2 is skipped and Sxx - |u|^2 is the per-marker constant den0_i.
 // ------------------------------------------------------------------------------------------------
+#ifdef LR_DIAG
+__device__ unsigned long long g_lr_diag[24];   // per class {sum of workgroup cycles, count}; per XCD last end tick
+#endif
 template <int C, int MB, int NB>
 __global__ void __launch_bounds__(256, 2) k_scan_lr(LrArgs la, int ntile_i, int64_t nwg) {
   const ScanArgs& a = la.s;
+#ifdef LR_DIAG
+  const unsigned long long diag_t0 = __builtin_amdgcn_s_memtime();
+#endif
   constexpr int NACC = 2 + C;
   constexpr int NL = C * (C + 1) / 2;
   __shared__ dpair s_log[BLMM_LOG_TABLE_N];
   __shared__ double s_li[NL][32 * MB];      // packed L_j^-1 of the tile's traits (read in the epilogue)
+  __shared__ int s_perm[32 * MB];           // their trait numbers (-1: padding column)
   stage_lod_table(s_log, a.logtab, -0.5 * (double)a.n);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int64_t bid = xcd_swizzle(blockIdx.x, nwg);
+  // Trait tiles in use: ns at the front (the shared-weights class, 5/8 of the matrix work of a tile of the other class) and
+  // nf from tile `fo` on.  Workgroups reach the CUs of an XCD in strict round-robin order (measured: a mix of the two
+  // classes inside one dispatch round runs at the pace of the slower class, whatever the share of the faster one), so
+  // each XCD (blockIdx % 8) is dealt a contiguous run of shared-weights work items followed by a contiguous run of the
+  // others, an eighth of either class: rounds are homogeneous, the XCDs balanced, and the items of a run follow the
+  // L2-friendly walk of tile_of.
   int64_t tile_t; int tile_i;
-  tile_of(bid, nwg / ntile_i, ntile_i, tile_t, tile_i);
+  bool shared_w;
+  {
+    constexpr int TW = 32 * MB;
+    const int64_t q = nwg >> 3;
+    if ((int64_t)blockIdx.x >= (q << 3)) return;                 // workgroup-uniform; before any barrier
+    const int64_t x = blockIdx.x & 7, local = blockIdx.x >> 3;
+    const int64_t nsh = *la.nshared;
+    const int64_t ns = (nsh + TW - 1) / TW, fo = (a.ldp - (la.mtraits - nsh)) / TW, nf = a.ldp / TW - fo;
+    const int64_t NS = ns * ntile_i, NF = nf * ntile_i;
+    const int64_t sS = (x * NS) >> 3, cS = (((x + 1) * NS) >> 3) - sS, sF = (x * NF) >> 3, cF = (((x + 1) * NF) >> 3) - sF;
+    if (local < cS) {
+      shared_w = true;
+      tile_of(sS + local, ns, ntile_i, tile_t, tile_i);
+    } else if (local - cS < cF) {
+      shared_w = false;
+      tile_of(sF + local - cS, nf, ntile_i, tile_t, tile_i);
+      tile_t += fo;
+    } else {
+      return;
+    }
+  }
   // staged here (Ls is padded to ldp, a multiple of the tile): in the epilogue these loads would sit behind the
   // stores of the previous row (possible aliasing) and expose one global-memory round trip per row
   for (int e = threadIdx.x; e < NL * 32 * MB; e += 256)
     s_li[e / (32 * MB)][e % (32 * MB)] = la.Ls[(int64_t)(e / (32 * MB)) * a.ldp + tile_t * (32 * MB) + (e % (32 * MB))];
+  if (threadIdx.x < 32 * MB) s_perm[threadIdx.x] = la.perm[tile_t * (32 * MB) + threadIdx.x];
   const int wt = wave >> 1, wi = wave & 1;
-  const int64_t t0 = tile_t * (32 * MB) + wt * (16 * MB);
   const int64_t i0 = (int64_t)tile_i * (32 * NB) + wi * (16 * NB);
   const int r = lane & 15, kk = lane >> 4;
 
@@ -339,7 +373,7 @@ __global__ void __launch_bounds__(256, 2) k_scan_lr(LrArgs la, int ntile_i, int6
           acc[1 + q][mb][nb] = __builtin_amdgcn_mfma_f64_16x16x4f64(A[mb], B[q][nb], acc[1 + q][mb][nb], 0, 0, 0);
   };
   const int K2 = a.ks / 2;
-  const int KR = la.rk[1];
+  const int KR = shared_w ? 0 : la.rk[1];
   double c0[MB], d0[1 + C][NB];
   {
     double a0[2][MB], b0[2][NB], a1[2][MB], b1[2][NB];
@@ -361,11 +395,11 @@ __global__ void __launch_bounds__(256, 2) k_scan_lr(LrArgs la, int ntile_i, int6
       __builtin_amdgcn_sched_barrier(0);
       mfma1(a0, b0);
       __builtin_amdgcn_sched_barrier(0);
-      load2(c0, d0, 0);
+      if (KR > 0) load2(c0, d0, 0);
       __builtin_amdgcn_sched_barrier(0);
       mfma1(a1, b1);
     } else {
-      load2(c0, d0, 0);
+      if (KR > 0) load2(c0, d0, 0);
       __builtin_amdgcn_sched_barrier(0);
       mfma1(a0, b0);
     }
@@ -391,13 +425,21 @@ __global__ void __launch_bounds__(256, 2) k_scan_lr(LrArgs la, int ntile_i, int6
   __syncthreads();
   const LodPoly lp = make_lod_poly(-0.5 * (double)a.n);
   const int64_t ibase = i0 + NB * r;
+  if (shared_w) {   // Sxx - |u|^2 = den0_i for every trait of the tile (the s_q accumulators stay zero)
+    double dn[NB];
+    loadv<NB>(dn, la.den0 + ibase);
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) acc[1][mb][nb] = (d4){dn[nb], dn[nb], dn[nb], dn[nb]};
+  }
   int nnan = 0;
 #pragma unroll
   for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
     for (int reg = 0; reg < 4; ++reg) {
-      const int64_t trait = t0 + MB * (kk + 4 * reg) + mb;
-      if (trait >= a.m) continue;
+      const int64_t trait = s_perm[wt * (16 * MB) + MB * (kk + 4 * reg) + mb];
+      if (trait < 0) continue;
       double li[NL];
 #pragma unroll
       for (int e = 0; e < NL; ++e) li[e] = s_li[e][wt * (16 * MB) + MB * (kk + 4 * reg) + mb];
@@ -433,18 +475,42 @@ __global__ void __launch_bounds__(256, 2) k_scan_lr(LrArgs la, int ntile_i, int6
       }
     }
   if (nnan) atomicAdd((unsigned long long*)&a.stat[ST_NAN_LOD], (unsigned long long)nnan);
+#ifdef LR_DIAG
+  if (threadIdx.x == 0) {
+    atomicAdd(&g_lr_diag[shared_w ? 0 : 2], __builtin_amdgcn_s_memtime() - diag_t0);
+    atomicAdd(&g_lr_diag[shared_w ? 1 : 3], 1ull);
+    const unsigned xcc = __builtin_amdgcn_s_getreg(6164) & 15u;   // HW_REG_XCC_ID[3:0]
+    atomicMax(&g_lr_diag[8 + (xcc & 7)], __builtin_amdgcn_s_memrealtime());
+    atomicAdd(&g_lr_diag[16 + (xcc & 7)], 1ull);
+  }
+#endif
 }
 
 template <int C, int MB>
 static int launch_scan_lr_t(blmm_ctx* ctx, const LrArgs& la) {
   constexpr int NB = 4;
   const ScanArgs& a = la.s;
-  const int64_t ntile_t = (a.m + 32 * MB - 1) / (32 * MB);
+  const int64_t ntile_t = (a.m + 32 * MB - 1) / (32 * MB);      // a.m: an upper bound of the panel columns in tiles that hold traits
   const int64_t ntile_i = (a.p + 32 * NB - 1) / (32 * NB);
-  const int64_t nwg = ntile_t * ntile_i;
-  if (nwg <= 0) return BLMM_OK;
+  if (ntile_t * ntile_i <= 0) return BLMM_OK;
+  const int64_t nwg = (ntile_t * ntile_i + 16 + 7) / 8 * 8;      // every XCD's share of either class rounds up: + 2 items each
   if (nwg > 0x7fffffffLL) return fail(ctx, BLMM_ERR_INVALID, "problem too large for one launch");
+#ifdef LR_DIAG
+  unsigned long long z[24] = {0};
+  (void)hipMemcpyToSymbol(HIP_SYMBOL(g_lr_diag), z, sizeof(z));
+  (void)hipStreamSynchronize(ctx->stream);
+#endif
   hipLaunchKernelGGL((k_scan_lr<C, MB, NB>), dim3((unsigned)nwg), dim3(256), 0, ctx->stream, la, (int)ntile_i, nwg);
+#ifdef LR_DIAG
+  (void)hipStreamSynchronize(ctx->stream);
+  (void)hipMemcpyFromSymbol(z, HIP_SYMBOL(g_lr_diag), sizeof(z));
+  unsigned long long mn = ~0ull;
+  for (int x = 0; x < 8; ++x) if (z[8 + x] && z[8 + x] < mn) mn = z[8 + x];
+  fprintf(stderr, "lr diag: shared wgs %llu avg cycles %.0f | full wgs %llu avg cycles %.0f | xcd last-end ticks(100MHz) rel:", z[1],
+          z[1] ? (double)z[0] / z[1] : 0.0, z[3], z[3] ? (double)z[2] / z[3] : 0.0);
+  for (int x = 0; x < 8; ++x) fprintf(stderr, " %llu(%llu)", z[8 + x] - mn, z[16 + x]);
+  fprintf(stderr, "\n");
+#endif
   KCHECK();
   return BLMM_OK;
 }

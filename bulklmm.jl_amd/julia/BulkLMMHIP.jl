@@ -22,9 +22,9 @@ end
 mutable struct BlmmStatus  # include/bulklmm_hip.h: blmm_status
     n_neg_eig::Int64; n_nonpos_weight::Int64; n_zero_norm::Int64; n_nan_lod::Int64
     n_brent_maxiter::Int64; jacobi_sweeps::Int64; jacobi_cycles::Int64; jacobi_ticks_100mhz::Int64
-    lowrank_rank::Int64; lowrank_fallback::Int64; lowrank_resid::Float64
+    lowrank_rank::Int64; lowrank_fallback::Int64; lowrank_shared::Int64; lowrank_resid::Float64
     t_eigen_ms::Float64; t_rotate_ms::Float64; t_h2_ms::Float64; t_prep_ms::Float64; t_scan_ms::Float64; t_total_ms::Float64
-    BlmmStatus() = new(0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0)
+    BlmmStatus() = new(0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0)
 end
 
 const NULL_EXACT, NULL_GRID, ALT_GRID = Int32(0), Int32(1), Int32(2)

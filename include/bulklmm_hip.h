@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define BLMM_VERSION 200 /* 0.2.0: blmm_status.lowrank_fallback, BLMM_STREAM_NULL, multi-GPU entry points */
+#define BLMM_VERSION 201 /* 0.2.1: blmm_status.lowrank_shared, readers, blmm_scan_alt; 200: lowrank_fallback, BLMM_STREAM_NULL, multi-GPU */
 
 typedef struct blmm_ctx blmm_ctx;
 
@@ -84,6 +84,8 @@ typedef struct blmm_status {
   int64_t lowrank_rank;    /* rank R of the weight-family basis used by the null-exact kernel (kernels_lowrank.hip) */
   int64_t lowrank_fallback;/* traits whose expansion residual exceeded 1e-13: their LOD columns were recomputed from
                               the full-length sums (k_scan_fix), so every returned LOD is either guarded or exact      */
+  int64_t lowrank_shared;  /* traits whose weights are 1 to within the same tolerance (likelihood peaks at h2 = 0): their
+                              denominators are the per-marker constants of the unweighted model, no basis needed          */
   double lowrank_resid;    /* largest relative residual |w_j - Q Q'w_j| / |w_j| over ALL traits (before the re-scan)  */
   double t_eigen_ms, t_rotate_ms, t_h2_ms, t_prep_ms, t_scan_ms, t_total_ms;
 } blmm_status;
