@@ -236,10 +236,11 @@ def main():
         return float(tmax.item()), ph, nc
 
     dt, phases, ncalls = timed(work, a.gather, a.steps, a.warmup)
-    lr_rank = lr_resid = lr_fallback = None
+    lr_rank = lr_resid = lr_fallback = lr_shared = None
     if a.method == "null-exact":   # one extra (untimed) call with a status read-back: the weight basis and its guard
         st = B.bulkscan_dev(ctx, work.dY, dG, dK, work.dL, work.dH, method=a.method, h2_grid=grid, status=True)
         lr_rank, lr_resid, lr_fallback = int(st.lowrank_rank), float(st.lowrank_resid), int(st.lowrank_fallback)
+        lr_shared = int(st.lowrank_shared)
     # sanity: the output must be finite (a fast kernel with wrong results is not a result)
     chk = torch.isfinite(work.dL[: min(64, work.m)]).all().item()
 
@@ -303,9 +304,12 @@ def main():
             # SURVEY.md §8(d)'s figure for the reference formulation is 2n(2+c) flops per test
             npad8 = -(-n // 8) * 8
             survey_flops = 2.0 * n * (2 + c) * p * m_local
+            rank_form_flops = None
             if lr_rank:
+                # traits of the shared-weights class (weights = 1 within the guard's tolerance) skip the rank-R phase
                 kr4 = 4 * (-(-lr_rank // 4))
-                flops_launch = 2.0 * (npad8 + (1 + c) * kr4) * p * m_local
+                rank_form_flops = 2.0 * (npad8 + (1 + c) * kr4) * p * m_local
+                flops_launch = 2.0 * p * (npad8 * m_local + (1 + c) * kr4 * (m_local - (lr_shared or 0)))
             else:   # BLMM_EXACT=full: the (2+c) full-length contractions
                 flops_launch = survey_flops
         elif a.method in ("null-grid", "perms"):
@@ -329,6 +333,9 @@ def main():
             roof["weight_basis_rank"] = lr_rank
             roof["weight_basis_resid"] = lr_resid
             roof["traits_rescanned_full_rank"] = lr_fallback
+            roof["traits_shared_weights"] = lr_shared
+            if rank_form_flops and scan_ms > 0:   # the same launch priced as if every trait ran the rank-R phase (the r01 / r02a form)
+                roof["frac_if_all_traits_rank_form"] = rank_form_flops / (scan_ms * 1e-3) / 1e12 / FP64_MFMA_PEAK_TFLOPS
             roof["reference_formulation_flops_per_launch"] = survey_flops   # 2n(2+c) per test, SURVEY.md §8(d)
             roof["reference_formulation_equiv_TFLOPs"] = survey_flops / (scan_ms * 1e-3) / 1e12 if scan_ms > 0 else None
             roof["note"] = ("achieved/frac count the flops the kernel EXECUTES (low-rank weights form); the same launch "

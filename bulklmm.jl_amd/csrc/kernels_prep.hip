@@ -1097,19 +1097,19 @@ struct NullRegs {
   int yo, lo;           // offsets of yp / lz in it
 };
 // Stages one trait's y into the workgroup's LDS slab: thread t owns column t of sY[NULL_NK][256].
-template <int LPT>
+template <int LPT, int NK = NULL_NK>
 __device__ __forceinline__ void stage_null_y(double* sY, const double* __restrict__ ycol, int64_t ystride, int sub, int n, bool valid) {
 #pragma unroll
-  for (int i = 0; i < NULL_NK; ++i) {
+  for (int i = 0; i < NK; ++i) {
     const int k = sub + LPT * i;
     sY[i * 256 + threadIdx.x] = (k < n && valid) ? ycol[(int64_t)k * ystride] : 0.0;
   }
 }
 // fills the LDS table of NullRegs (all threads of the workgroup; the caller synchronises)
-template <int C, int LPT>
+template <int C, int LPT, int NK = NULL_NK>
 __device__ __forceinline__ void stage_null_lz(double* lzbase, int n, const double* __restrict__ Z0, const double* __restrict__ lamv) {
-  for (int e = threadIdx.x; e < LPT * NULL_NK; e += blockDim.x) {
-    const int sub = e / NULL_NK, i = e % NULL_NK, k = sub + LPT * i;
+  for (int e = threadIdx.x; e < LPT * NK; e += blockDim.x) {
+    const int sub = e / NK, i = e % NK, k = sub + LPT * i;
     double* d = lzbase + (size_t)e * (1 + C);
     d[0] = (k < n) ? lamv[k] : 0.0;
 #pragma unroll
@@ -1117,7 +1117,7 @@ __device__ __forceinline__ void stage_null_lz(double* lzbase, int n, const doubl
   }
 }
 
-template <int C, int LPT, int UNR = BRENT_UNROLL>
+template <int C, int LPT, int UNR = BRENT_UNROLL, int NK = NULL_NK>
 __device__ __forceinline__ EllOut null_ell_reg(double h2, const NullRegs<C, LPT>& R, int n, double prior_a, double prior_b,
                                                int reml, const dpair* __restrict__ s_ln, int* nonpos) {
   constexpr int NA = C * (C + 1) / 2;
@@ -1128,7 +1128,7 @@ __device__ __forceinline__ EllOut null_ell_reg(double h2, const NullRegs<C, LPT>
 #pragma unroll
   for (int q = 0; q < C; ++q) v[q] = 0.0;
   int bad = 0;
-  static_assert(NULL_NK % 4 == 0, "weights are inverted four at a time");
+  static_assert(NK % 4 == 0, "weights are inverted four at a time");
   // w = 1/t four at a time from ONE reciprocal (of the product): 22 instruction slots per four elements instead of 40
   // (v_rcp_f64 is quarter rate); the product also feeds sum ln t = ln(prod t), kept as two partial products that stay
   // far from overflow.  Each w carries ~3 extra roundings (4e-16 relative), below the rounding of the sums it enters.
@@ -1141,7 +1141,7 @@ __device__ __forceinline__ EllOut null_ell_reg(double h2, const NullRegs<C, LPT>
   const double* lzp = R.base + lo;
   const double* yp = R.base + yo;
 #pragma unroll UNR
-  for (int i0 = 0; i0 < NULL_NK; i0 += 4) {
+  for (int i0 = 0; i0 < NK; i0 += 4) {
     double lz[4][1 + C], yv[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -1161,7 +1161,7 @@ __device__ __forceinline__ EllOut null_ell_reg(double h2, const NullRegs<C, LPT>
     const double rq = fast_rcp(q4);
     const double rab = rq * cd, rcd = rq * ab;
     const double wv[4] = {rab * t1, rab * t0, rcd * t3, rcd * t2};
-    if (i0 < NULL_NK / 2) p1 *= q4; else p2 *= q4;
+    if (i0 < NK / 2) p1 *= q4; else p2 *= q4;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const double w = wv[j];
@@ -1493,8 +1493,9 @@ __global__ void __launch_bounds__(256, BRENT_MINW) k_brent(NullModel nm, const d
   }
 }
 
-// Second kernel of the two-kernel form: finishes the traits k_brent handed over, LPT lanes per list entry.
-template <int C, int LPT>
+// Second kernel of the two-kernel form: finishes the traits k_brent handed over, LPT lanes per list entry, NK individuals
+// per lane (the state is per trait and y is re-staged, so the split may differ from k_brent's: BLMM_BRENT2_LPT).
+template <int C, int LPT, int NK = NULL_NK>
 __global__ void __launch_bounds__(256, BRENT_MINW2) k_brent2(NullModel nm, const double* __restrict__ Yt, int64_t ldy, int64_t m,
                                                 const double* __restrict__ Z0, const double* __restrict__ lam,
                                                 const double* __restrict__ logtab, double* __restrict__ h2out,
@@ -1506,19 +1507,19 @@ __global__ void __launch_bounds__(256, BRENT_MINW2) k_brent2(NullModel nm, const
   const unsigned int U = *cont.cnt;
   if ((unsigned int)blockIdx.x * TPW >= U) return;          // workgroup-uniform
   const int n = nm.n;
-  stage_null_lz<C, LPT>(sh, n, Z0, lam);
+  stage_null_lz<C, LPT, NK>(sh, n, Z0, lam);
   stage_log_table<false>(s_ln, logtab);
-  double* sY = sh + LPT * NULL_NK * (1 + C);
+  double* sY = sh + LPT * NK * (1 + C);
   const unsigned int q = (unsigned int)blockIdx.x * TPW + threadIdx.x / LPT;
   const int sub = threadIdx.x % LPT;
   const bool valid = q < U;
   const int64_t j = cont.list[valid ? q : (unsigned int)blockIdx.x * TPW];
-  stage_null_y<LPT>(sY, Yt + j, ldy, sub, n, true);
+  stage_null_y<LPT, NK>(sY, Yt + j, ldy, sub, n, true);
   __syncthreads();
   int nonpos = (int)cont.st[(int64_t)11 * m + j];
   NullRegs<C, LPT> R;
-  R.base = sh; R.lo = sub * NULL_NK * (1 + C); R.yo = LPT * NULL_NK * (1 + C) + threadIdx.x;
-  auto f = [&](double h2) { return -null_ell_reg<C, LPT, BRENT_UNROLL2>(h2, R, n, nm.prior_a, nm.prior_b, nm.reml, s_ln, &nonpos).ell; };
+  R.base = sh; R.lo = sub * NK * (1 + C); R.yo = LPT * NK * (1 + C) + threadIdx.x;
+  auto f = [&](double h2) { return -null_ell_reg<C, LPT, (NK / 4 < BRENT_UNROLL2 ? NK / 4 : BRENT_UNROLL2), NK>(h2, R, n, nm.prior_a, nm.prior_b, nm.reml, s_ln, &nonpos).ell; };
   BrentState S;
   S.xl = cont.st[j]; S.xu = cont.st[m + j]; S.x = cont.st[2 * m + j]; S.fx = cont.st[3 * m + j];
   S.step = cont.st[4 * m + j]; S.old_step = cont.st[5 * m + j]; S.ox = cont.st[6 * m + j]; S.oox = cont.st[7 * m + j];
@@ -1526,7 +1527,7 @@ __global__ void __launch_bounds__(256, BRENT_MINW2) k_brent2(NullModel nm, const
   S.done = !valid;
   const int it0 = (int)cont.st[(int64_t)10 * m + j];
   const int it2 = brent_run(f, S, 1000 - it0);
-  const EllOut fin = null_ell_reg<C, LPT, BRENT_UNROLL2>(S.x, R, n, nm.prior_a, nm.prior_b, nm.reml, s_ln, &nonpos);
+  const EllOut fin = null_ell_reg<C, LPT, (NK / 4 < BRENT_UNROLL2 ? NK / 4 : BRENT_UNROLL2), NK>(S.x, R, n, nm.prior_a, nm.prior_b, nm.reml, s_ln, &nonpos);
   if (valid && sub == 0) {
     h2out[j] = S.x;
     if (s2out) s2out[j] = fin.sigma2;
@@ -1561,11 +1562,24 @@ static int launch_brent_t(blmm_ctx* ctx, const NullModel& nm, const double* Yt, 
   KCHECK();
   if constexpr (REG) {
     if (two) {
-      if (lds > 48 * 1024)
-        BLMM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_brent2<C, LPT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-      hipLaunchKernelGGL((k_brent2<C, LPT>), dim3(blocks), dim3(256), lds, ctx->stream, nm, Yt, ldy, m, Z0, lam,
-                         ptr<double>(ctx->logtab), h2, sigma2, ell, stat, cont);
-      KCHECK();
+      // A/B testing: 8 / 16 spread a trait of the second kernel over more lanes than k_brent's 4 (measured at BXD size:
+      // h2 phase 0.250 ms at 4, 0.259 at 8, 0.372 at 16 -- the wider cross-lane sums cost more than the shorter loop saves)
+      static const int lpt2_env = getenv("BLMM_BRENT2_LPT") ? atoi(getenv("BLMM_BRENT2_LPT")) : 0;
+      auto launch2 = [&](auto kern, int lpt2, int nk2) -> int {
+        const size_t lds2 = sizeof(double) * ((size_t)lpt2 * nk2 * (1 + C) + (size_t)nk2 * 256);
+        if (lds2 > 48 * 1024)
+          BLMM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
+        const unsigned blocks2 = (unsigned)((m * lpt2 + 255) / 256);
+        hipLaunchKernelGGL(kern, dim3(blocks2), dim3(256), lds2, ctx->stream, nm, Yt, ldy, m, Z0, lam, ptr<double>(ctx->logtab), h2,
+                           sigma2, ell, stat, cont);
+        KCHECK();
+        return BLMM_OK;
+      };
+      if constexpr (LPT == 4) {
+        if (lpt2_env == 16 && nm.n <= 16 * 8) return launch2(&k_brent2<C, 16, 8>, 16, 8);
+        if (lpt2_env == 8 && nm.n <= 8 * 12) return launch2(&k_brent2<C, 8, 12>, 8, 12);
+      }
+      return launch2(&k_brent2<C, LPT, NULL_NK>, LPT, NULL_NK);
     }
   }
   return BLMM_OK;

@@ -135,3 +135,37 @@ def test_fullsize_h2_audit_all_traits(blmm, tmp_path):
     print(f"h2 audit: {bad.size} of {M} traits differ by more than 1e-6 (max |dh2| {dh.max():.3e}): {ties} ties, "
           f"{other_optimum} on the other local maximum of a bimodal profile")
     assert bad.size <= 0.0005 * M
+
+
+@pytest.mark.parametrize("ncov", [0, 1, 2])
+def test_shared_weights_class(blmm, ncov):
+    """Traits whose weights are 1 to within the guard's tolerance (h2 at the 0 boundary) take the shared-weights path of
+    k_scan_lr: no rank-R phase, per-marker denominators of the unweighted model.  Class sizes that are not tile multiples,
+    every covariate count of the low-rank form; the class size reported in blmm_status against the criterion
+    delta_j sqrt(sum lambda^2 / n) <= 1e-13 evaluated here, and the LODs against the oracle at the device's h2."""
+    Y, G, K, Cov = make_data(p=300, m=333, seed=5200 + ncov, ncov=ncov)
+    rng = np.random.default_rng(9)
+    noise = rng.permutation(333)[:150]
+    Y[:, noise] = rng.standard_normal((Y.shape[0], 150))                 # no heritable part: most of these land on h2 = 0
+    L, h2, st = blmm.api._bulkscan_call(blmm._lib.BLMM_NULL_EXACT, Y, G, K, Cov, None, True, None, 1.0, 0.0, False, 1,
+                                        "eigen", 0, None, return_status=True)
+    lam = np.linalg.eigvalsh(K)
+    want = int((h2 / (1.0 - h2) * np.sqrt((lam ** 2).sum() / lam.size) <= 1e-13).sum())
+    assert 0 < want < 333 and want % 32 != 0
+    assert st.lowrank_shared == want and st.lowrank_fallback == 0
+    pin = O.bulkscan_null(Y, G, K, Covar=Cov, h2_override=h2)
+    assert_lod_close(L, pin.L)
+    own = O.bulkscan_null(Y, G, K, Covar=Cov)
+    assert np.abs(h2 - own.h2_null_list).max() <= 1e-6
+
+
+@pytest.mark.parametrize("h2val,m", [(0.0, 130), (0.0, 64), (0.37, 130), (None, 1)])
+def test_shared_weights_class_extremes(blmm, h2val, m):
+    """All traits in the class, none, and a single trait (h2 = 0 exactly is what a grid or a caller may pass)."""
+    n, p = 79, 200
+    rng = np.random.default_rng(17 + m)
+    lam = SPECTRA["bxd_like"](n, rng)
+    Y0, X0 = rotated_problem(n, p, m, lam, 3)
+    h2 = np.full(m, 0.0 if h2val is None else h2val)
+    got = blmm.liteqtl_given_h2(Y0, X0, lam, h2)
+    assert_lod_close(got, oracle_given_h2(Y0, X0, lam, h2))
