@@ -187,7 +187,7 @@ int finish_status(blmm_ctx* ctx, blmm_status* st, Timer* tm) {
   st->jacobi_cycles = h[6]; st->jacobi_ticks_100mhz = h[7];
   st->lowrank_rank = h[8];
   st->lowrank_fallback = h[10];
-  st->lowrank_shared = h[12];
+  st->lowrank_shared = h[12] + h[14];
   if (h[8] < 0) return fail(ctx, BLMM_ERR_HIP, "weight-basis kernel: a workgroup timed out at the grid barrier");
   if (h[11] != 0) return fail(ctx, BLMM_ERR_HIP, "the eigensolver did not converge (code " + std::to_string((long long)h[11]) +
                               ": > 0 dsyevd info, -7 grid barrier of the tridiagonalisation timed out, -8 QL iteration limit)");
@@ -399,13 +399,14 @@ double lr_tolerance() {
   return e ? atof(e) : 1e-13;
 }
 
-// leading dimension of the panel arrays: the columns are the traits in k_lr_classify's order, which pads the
-// shared-weights class to a tile multiple
+// Width of one region of the panel arrays (LrRegion): k_lr_classify fills it from both ends, so it needs a whole padding
+// tile beyond the traits.  The arrays hold two regions (leading dimension 2 * lr_ldq): the second one is used when the
+// h2 search is split and its second kernel runs beside the scan of the traits the first kernel finished.
 int64_t lr_ldq(const Pipe& P) { return P.ldy + 128; }
 
 int lr_begin(blmm_ctx* ctx, const Pipe& P, bool wbasis_started) {
   int rc;
-  const int64_t ldp = lr_ldq(P), tstride = (int64_t)P.npad * P.ldx;
+  const int64_t ldp = 2 * lr_ldq(P), tstride = (int64_t)P.npad * P.ldx;
   if ((rc = ensure(ctx, ctx->lrPerm, sizeof(int) * (size_t)ldp))) return rc;
   if ((rc = ensure(ctx, ctx->lrDen0, sizeof(double) * (size_t)P.ldx))) return rc;
   if ((rc = ensure(ctx, ctx->lrT, sizeof(double) * (size_t)(1 + P.c) * tstride))) return rc;
@@ -424,46 +425,118 @@ int lr_begin(blmm_ctx* ctx, const Pipe& P, bool wbasis_started) {
   ctx->stream = ctx->side;                                         // the launchers enqueue on ctx->stream
   rc = BLMM_OK;
   if (!wbasis_started) rc = launch_wbasis(ctx, P.lam, P.n, ptr<double>(ctx->wbW), ptr<double>(ctx->wbQ), rk, P.stat);
-  if (!rc) rc = launch_lr_tpanels(ctx, P.Xt, P.ldx, P.p, P.n, P.c, P.npad, P.Z0, ptr<double>(ctx->wbQ), rk, ptr<double>(ctx->lrT), tstride);
-  if (!rc) rc = launch_lr_den0(ctx, P.n, P.c, P.Xt, P.ldx, P.p, P.Z0, ptr<double>(ctx->lrDen0));
   if (!rc && hipMemsetAsync(ctx->lrPerm.p, 0xff, sizeof(int) * (size_t)ldp, ctx->side) != hipSuccess) rc = fail(ctx, BLMM_ERR_HIP, "hipMemsetAsync failed");
+  if (!rc && hipEventRecord(ctx->ev_q, ctx->side) != hipSuccess) rc = fail(ctx, BLMM_ERR_HIP, "hipEventRecord failed");   // what the panels need
+  if (!rc) rc = launch_lr_den0(ctx, P.n, P.c, P.Xt, P.ldx, P.p, P.Z0, ptr<double>(ctx->lrDen0));
+  if (!rc) rc = launch_lr_tpanels(ctx, P.Xt, P.ldx, P.p, P.n, P.c, P.npad, P.Z0, ptr<double>(ctx->wbQ), rk, ptr<double>(ctx->lrT), tstride);
   ctx->stream = main_stream;
   if (rc) return rc;
-  BLMM_HIP(hipEventRecord(ctx->ev_join, ctx->side));
+  BLMM_HIP(hipEventRecord(ctx->ev_join, ctx->side));                // ... and what the scan needs on top
   return BLMM_OK;
 }
 
+namespace {
+// the shared-weights class uses the tolerance of the expansion guard; BLMM_LR_SHARED=0 switches the class off (A/B testing)
+double lr_shared_tol() {
+  static const bool on = !(getenv("BLMM_LR_SHARED") && getenv("BLMM_LR_SHARED")[0] == '0');
+  return on ? lr_tolerance() : 0.0;
+}
+LrArgs lr_args(blmm_ctx* ctx, const Pipe& P, const LrRegion& rg, double* dL, int64_t ldL) {
+  const int64_t ldp = 2 * lr_ldq(P);
+  LrArgs la;
+  // a.m sizes the grid only: a region holds at most m traits, in at most m/64 + 3 trait tiles
+  la.s = scan_args(ctx, P, ptr<double>(ctx->panels), ldp, dL, ldL, P.m + 192 < rg.ncol ? P.m + 192 : rg.ncol);
+  la.Cp = ptr<double>(ctx->lrC); la.T = ptr<double>(ctx->lrT); la.tstride = (int64_t)P.npad * P.ldx; la.Ls = ptr<double>(ctx->lrL);
+  la.rk = ptr<int>(ctx->wbRk); la.c = P.c; la.perm = ptr<int>(ctx->lrPerm); la.rg = rg; la.den0 = ptr<double>(ctx->lrDen0);
+  return la;
+}
+// panels of one region on the current stream
+int lr_region_panels(blmm_ctx* ctx, const Pipe& P, const NullModel& nm, const double* dh2, const LrRegion& rg) {
+  return launch_lr_panels(ctx, nm, P.Yt, P.ldy, P.m, P.Z0, P.lam, dh2, ptr<double>(ctx->wbQ), ptr<int>(ctx->wbRk), ptr<int>(ctx->lrPerm),
+                          rg, ptr<double>(ctx->panels), ptr<double>(ctx->lrC), ptr<double>(ctx->lrL), 2 * lr_ldq(P), P.stat);
+}
+int lr_region_resid(blmm_ctx* ctx, const Pipe& P, const NullModel& nm, const double* dh2, const LrRegion& rg) {
+  return launch_lr_resid(ctx, nm, P.m, lr_tolerance(), P.lam, dh2, ptr<double>(ctx->wbQ), ptr<int>(ctx->wbRk), ptr<int>(ctx->lrPerm), rg,
+                         ptr<double>(ctx->lrC), 2 * lr_ldq(P), ptr<int>(ctx->lrFlag), ptr<double>(ctx->lrPart), P.stat);
+}
+int lr_fix(blmm_ctx* ctx, const Pipe& P, const NullModel& nm, const double* dh2, double* dL, int64_t ldL) {
+  // flagged traits (normally none: the kernel reads the count on the device and returns): full-length sums
+  return launch_scan_fix(ctx, nm, P.Xt, P.ldx, P.p, ptr<double>(ctx->panels), ptr<double>(ctx->lrL), 2 * lr_ldq(P), P.Z0, P.lam, dh2,
+                         ptr<int>(ctx->lrFlag), ptr<int>(ctx->lrPerm), dL, ldL, P.stat);
+}
+}  // namespace
+
+// every trait's h2 is final: one region
 int lr_finish(blmm_ctx* ctx, const Pipe& P, const NullModel& nm, const double* dh2, double* dL, int64_t ldL, Timer& tm) {
   int rc;
-  const int64_t ldp = lr_ldq(P), tstride = (int64_t)P.npad * P.ldx, m = P.m;
-  int* rk = ptr<int>(ctx->wbRk);
-  int* perm = ptr<int>(ctx->lrPerm);
+  LrRegion rg; rg.col0 = 0; rg.ncol = lr_ldq(P); rg.counts = P.stat + 12;
   hipStream_t main_stream = ctx->stream;
-  // the shared-weights class (same tolerance as the expansion guard; BLMM_LR_SHARED=0 switches the class off: A/B testing)
-  static const bool shared_on = !(getenv("BLMM_LR_SHARED") && getenv("BLMM_LR_SHARED")[0] == '0');
   BLMM_HIP(hipStreamWaitEvent(main_stream, ctx->ev_join, 0));
-  if ((rc = launch_lr_classify(ctx, P.n, m, shared_on ? lr_tolerance() : 0.0, P.lam, dh2, perm, ldp, P.stat))) return rc;
-  if ((rc = launch_lr_panels(ctx, nm, P.Yt, P.ldy, m, P.Z0, P.lam, dh2, ptr<double>(ctx->wbQ), rk, perm, ptr<double>(ctx->panels),
-                             ptr<double>(ctx->lrC), ptr<double>(ctx->lrL), ldp, P.stat))) return rc;
+  if ((rc = launch_lr_classify(ctx, P.n, P.m, lr_shared_tol(), P.lam, dh2, nullptr, nullptr, nullptr, ptr<int>(ctx->lrPerm), rg))) return rc;
+  if ((rc = lr_region_panels(ctx, P, nm, dh2, rg))) return rc;
   tm.mark();
   // residual guard of the weight basis, every trait: side stream, beside the scan kernel; joined below
   BLMM_HIP(hipEventRecord(ctx->ev_fork, main_stream));
   BLMM_HIP(hipStreamWaitEvent(ctx->side, ctx->ev_fork, 0));
   ctx->stream = ctx->side;
-  rc = launch_lr_resid(ctx, nm, m, lr_tolerance(), P.lam, dh2, ptr<double>(ctx->wbQ), rk, perm, ptr<double>(ctx->lrC), ldp,
-                       ptr<int>(ctx->lrFlag), ptr<double>(ctx->lrPart), P.stat);
+  rc = lr_region_resid(ctx, P, nm, dh2, rg);
   ctx->stream = main_stream;
   if (rc) return rc;
   BLMM_HIP(hipEventRecord(ctx->ev_join, ctx->side));
-  LrArgs la;
-  la.s = scan_args(ctx, P, ptr<double>(ctx->panels), ldp, dL, ldL, m + 192 < ldp ? m + 192 : ldp);   // sizes the grid only: <= m/64 + 3 trait tiles are in use
-  la.Cp = ptr<double>(ctx->lrC); la.T = ptr<double>(ctx->lrT); la.tstride = tstride; la.Ls = ptr<double>(ctx->lrL);
-  la.rk = rk; la.c = P.c; la.perm = perm; la.nshared = P.stat + 12; la.mtraits = m; la.den0 = ptr<double>(ctx->lrDen0);
-  if ((rc = launch_scan_lr(ctx, la))) return rc;
+  if ((rc = launch_scan_lr(ctx, lr_args(ctx, P, rg, dL, ldL)))) return rc;
   BLMM_HIP(hipStreamWaitEvent(main_stream, ctx->ev_join, 0));
-  // flagged traits (normally none: the kernel reads the count on the device and returns): full-length sums
-  if ((rc = launch_scan_fix(ctx, nm, P.Xt, P.ldx, P.p, ptr<double>(ctx->panels), ptr<double>(ctx->lrL), ldp, P.Z0, P.lam, dh2,
-                            ptr<int>(ctx->lrFlag), perm, dL, ldL, P.stat))) return rc;
+  if ((rc = lr_fix(ctx, P, nm, dh2, dL, ldL))) return rc;
+  tm.mark();
+  return BLMM_OK;
+}
+
+// The h2 search was split (launch_brent phase 1 came back with sp.active): the traits k_brent finished (fin[j] == 1) form
+// region 0 and are scanned at once; k_brent2, the classification and the panels of its traits (region 1) run on a
+// second side stream beside that scan, and region 1 is scanned after it.
+int lr_finish_split(blmm_ctx* ctx, const Pipe& P, const NullModel& nm, double* dh2, double* dL, int64_t ldL, Timer& tm,
+                    const BrentSplit& sp) {
+  int rc;
+  const int64_t ldq = lr_ldq(P);
+  LrRegion r0, r1;
+  r0.col0 = 0; r0.ncol = ldq; r0.counts = P.stat + 12;
+  r1.col0 = ldq; r1.ncol = ldq; r1.counts = P.stat + 14;
+  hipStream_t main_stream = ctx->stream;
+  // ---- second side stream: the rest of the h2 search, then region 1's columns
+  BLMM_HIP(hipEventRecord(ctx->ev_b1, main_stream));
+  BLMM_HIP(hipStreamWaitEvent(ctx->side2, ctx->ev_b1, 0));
+  ctx->stream = ctx->side2;
+  BrentSplit sp2 = sp;
+  rc = launch_brent(ctx, nm, P.Yt, P.ldy, P.m, P.Z0, P.lam, dh2, nullptr, nullptr, P.stat, 2, &sp2);
+  if (!rc && hipStreamWaitEvent(ctx->side2, ctx->ev_q, 0) != hipSuccess) rc = fail(ctx, BLMM_ERR_HIP, "hipStreamWaitEvent failed");
+  if (!rc) rc = launch_lr_classify(ctx, P.n, P.m, lr_shared_tol(), P.lam, dh2, nullptr, sp.list, sp.cnt, ptr<int>(ctx->lrPerm), r1);
+  if (!rc) rc = lr_region_panels(ctx, P, nm, dh2, r1);
+  ctx->stream = main_stream;
+  if (rc) return rc;
+  BLMM_HIP(hipEventRecord(ctx->ev_b2, ctx->side2));
+  // ---- main stream: region 0 (the weight basis and the perm preset are ready at ev_q; the marker-side products at ev_join)
+  BLMM_HIP(hipStreamWaitEvent(main_stream, ctx->ev_q, 0));
+  if ((rc = launch_lr_classify(ctx, P.n, P.m, lr_shared_tol(), P.lam, dh2, sp.fin, nullptr, nullptr, ptr<int>(ctx->lrPerm), r0))) return rc;
+  if ((rc = lr_region_panels(ctx, P, nm, dh2, r0))) return rc;
+  tm.mark();
+  BLMM_HIP(hipStreamWaitEvent(main_stream, ctx->ev_join, 0));
+  BLMM_HIP(hipEventRecord(ctx->ev_fork, main_stream));
+  BLMM_HIP(hipStreamWaitEvent(ctx->side, ctx->ev_fork, 0));
+  ctx->stream = ctx->side;
+  rc = lr_region_resid(ctx, P, nm, dh2, r0);
+  ctx->stream = main_stream;
+  if (rc) return rc;
+  if ((rc = launch_scan_lr(ctx, lr_args(ctx, P, r0, dL, ldL)))) return rc;
+  // ---- region 1: its guard on the first side stream (behind region 0's), its scan on the main stream
+  BLMM_HIP(hipStreamWaitEvent(ctx->side, ctx->ev_b2, 0));
+  ctx->stream = ctx->side;
+  rc = lr_region_resid(ctx, P, nm, dh2, r1);
+  ctx->stream = main_stream;
+  if (rc) return rc;
+  BLMM_HIP(hipEventRecord(ctx->ev_join, ctx->side));
+  BLMM_HIP(hipStreamWaitEvent(main_stream, ctx->ev_b2, 0));
+  if ((rc = launch_scan_lr(ctx, lr_args(ctx, P, r1, dL, ldL)))) return rc;
+  BLMM_HIP(hipStreamWaitEvent(main_stream, ctx->ev_join, 0));
+  if ((rc = lr_fix(ctx, P, nm, dh2, dL, ldL))) return rc;
   tm.mark();
   return BLMM_OK;
 }
@@ -519,7 +592,11 @@ int blmm_create(int device_id, void* hip_stream, blmm_ctx** out) {
   if (hipStreamCreateWithFlags(&ctx->side, hipStreamNonBlocking) != hipSuccess ||
       hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming) != hipSuccess ||
-      hipEventCreateWithFlags(&ctx->ev_xt, hipEventDisableTiming) != hipSuccess) {
+      hipEventCreateWithFlags(&ctx->ev_xt, hipEventDisableTiming) != hipSuccess ||
+      hipStreamCreateWithFlags(&ctx->side2, hipStreamNonBlocking) != hipSuccess ||
+      hipEventCreateWithFlags(&ctx->ev_b1, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&ctx->ev_b2, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&ctx->ev_q, hipEventDisableTiming) != hipSuccess) {
     blmm_destroy(ctx);
     return BLMM_ERR_HIP;
   }
@@ -556,6 +633,10 @@ void blmm_destroy(blmm_ctx* ctx) {
   if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
   if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
   if (ctx->ev_xt) (void)hipEventDestroy(ctx->ev_xt);
+  if (ctx->ev_b1) (void)hipEventDestroy(ctx->ev_b1);
+  if (ctx->ev_b2) (void)hipEventDestroy(ctx->ev_b2);
+  if (ctx->ev_q) (void)hipEventDestroy(ctx->ev_q);
+  if (ctx->side2) { (void)hipStreamSynchronize(ctx->side2); (void)hipStreamDestroy(ctx->side2); }
   if (ctx->own_stream) hipStreamDestroy(ctx->stream);
   if (ctx->hflag) (void)hipHostFree(const_cast<int64_t*>(ctx->hflag));
   destroy_host_stage(ctx->hstage);
@@ -765,9 +846,13 @@ int blmm_bulkscan_dev(blmm_ctx* ctx, const blmm_opts* opts, const double* dY, in
       // the basis (started in prepare) and the marker-side products (Q, Xt) run on the side stream beside the
       // per-trait Brent search
       if ((rc = lr_begin(ctx, P, /*wbasis_started*/ true))) return rc;
-      if ((rc = launch_brent(ctx, nm, P.Yt, P.ldy, m, P.Z0, P.lam, dh2_out, nullptr, nullptr, P.stat))) return rc;
+      // the second kernel of a split h2 search runs beside the scan of the traits the first one finished (BLMM_LR_SPLIT=0: A/B)
+      static const bool split_on = !(getenv("BLMM_LR_SPLIT") && getenv("BLMM_LR_SPLIT")[0] == '0');
+      BrentSplit sp;
+      if ((rc = launch_brent(ctx, nm, P.Yt, P.ldy, m, P.Z0, P.lam, dh2_out, nullptr, nullptr, P.stat, split_on ? 1 : 0, &sp))) return rc;
       tm.mark();
-      if ((rc = lr_finish(ctx, P, nm, dh2_out, dL_out, ldL, tm))) return rc;
+      if (sp.active) { if ((rc = lr_finish_split(ctx, P, nm, dh2_out, dL_out, ldL, tm, sp))) return rc; }
+      else if ((rc = lr_finish(ctx, P, nm, dh2_out, dL_out, ldL, tm))) return rc;
     } else {
       if ((rc = launch_brent(ctx, nm, P.Yt, P.ldy, m, P.Z0, P.lam, dh2_out, nullptr, nullptr, P.stat))) return rc;
       tm.mark();

@@ -15,7 +15,7 @@ typedef double d4 __attribute__((ext_vector_type(4)));
 constexpr int CMAX = 4;          // null covariates (incl. intercept) the kernels are instantiated for
 constexpr int TILE_T = 64;       // traits per workgroup tile of the scan kernels
 constexpr int TILE_I = 128;      // markers per workgroup tile of the scan kernels
-constexpr int NSTAT = 14;        // device status counters ([6],[7]: eigensolver clocks, [8]: weight-basis rank, [9]: its residual, [10]: traits re-scanned full rank, [12], [13]: shared-weights traits / the others (k_lr_classify))
+constexpr int NSTAT = 16;        // device status counters ([6],[7]: eigensolver clocks, [8]: weight-basis rank, [9]: its residual, [10]: traits re-scanned full rank, [12..15]: shared-weights traits / the others of the two panel regions (k_lr_classify))
 
 enum StatIdx { ST_NEG_EIG = 0, ST_NONPOS_W = 1, ST_ZERO_NORM = 2, ST_NAN_LOD = 3, ST_BRENT_MAXIT = 4, ST_JACOBI_SWEEPS = 5 };
 
@@ -51,8 +51,8 @@ struct blmm_ctx {
   int (*rb_dgemm)(void*, int, int, int, int, int, const double*, const double*, int, const double*, int, const double*,
                   double*, int) = nullptr;
   // side stream: work that only depends on the eigenvalues / rotated markers runs beside the per-trait Brent search
-  hipStream_t side = nullptr;
-  hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_xt = nullptr;
+  hipStream_t side = nullptr, side2 = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_xt = nullptr, ev_b1 = nullptr, ev_b2 = nullptr, ev_q = nullptr;
   int num_cus = 0;                 // multiProcessorCount of the device (bounds every co-resident grid)
   // sticky device-side abort word in pinned, device-mapped host memory: a kernel that gives up (bounded spin of the
   // multi-workgroup weight-basis kernel) is reported by the NEXT API call / blmm_synchronize even when the failing
@@ -120,9 +120,19 @@ struct NullModel {
   int n, c, npad, reml, optim_interval;
   double prior_a, prior_b;
 };
-// per-trait Brent h2 (fitlmm) from centred/rotated Yt; outputs m each (sigma2/ell may be null)
+// per-trait Brent h2 (fitlmm) from centred/rotated Yt; outputs m each (sigma2/ell may be null).
+// phase 0: the whole search.  phase 1: the first kernel only -- when sp->active comes back true, the traits with
+// fin[j] == 1 are final and the other `*cnt` traits (list[]) are finished by a later phase-2 call with the same
+// arguments (possibly on another stream); when false the search is already complete.
+struct BrentSplit {
+  bool active = false;
+  const int* fin = nullptr;
+  const int* list = nullptr;
+  const unsigned int* cnt = nullptr;
+};
 int launch_brent(blmm_ctx* ctx, const NullModel& nm, const double* Yt, int64_t ldy, int64_t m, const double* Z0,
-                 const double* lam, double* h2, double* sigma2, double* ell, int64_t* stat);
+                 const double* lam, double* h2, double* sigma2, double* ell, int64_t* stat, int phase = 0,
+                 BrentSplit* sp = nullptr);
 // scan_alt: per-marker fitlmm on [Z0 x_i] and the LOD against the null model (the trait is column 0 of Yt)
 int launch_alt_brent(blmm_ctx* ctx, const NullModel& nm, const double* Yt, int64_t ldy, const double* Xt, int64_t ldx, int64_t p,
                      const double* Z0, const double* lam, const double* h2null, int true_w, double* lod, double* h2each,
@@ -160,6 +170,13 @@ struct ScanArgs {
   int64_t* stat;
 };
 int launch_scan_exact(blmm_ctx* ctx, const ScanArgs& a, int c);
+// A region of the panel arrays of the low-rank form: columns [col0, col0 + ncol), the shared-weights class at its front
+// (counts[0] traits) and the other class at its back (counts[1]); counts live on the device.
+constexpr int LR_TILE = 64;   // a multiple of every trait-tile width of k_scan_lr (32 * MB); regions are multiples of it
+struct LrRegion {
+  int64_t col0 = 0, ncol = 0;
+  int64_t* counts = nullptr;
+};
 struct LrArgs {
   ScanArgs s;                       // s.P = panel 0 only
   const double* Cp;                 // weight-basis coefficients [4*KR][ldp]
@@ -167,21 +184,20 @@ struct LrArgs {
   const double* Ls;                 // packed L_j^-1 [c(c+1)/2][ldp]
   const int* rk;                    // {R, KR} on the device
   const int* perm;                  // panel column -> trait (k_lr_classify; -1: padding)
-  const int64_t* nshared;           // device count of the shared-weights class: panel columns [0, nshared)
-  int64_t mtraits;                  // traits in all; the other class sits in columns [ldp - (mtraits - nshared), ldp)
+  LrRegion rg;                      // the region of the panel arrays this launch scans
   const double* den0;               // the shared-weights class's denominators, per marker
   int c;
 };
 int launch_scan_lr(blmm_ctx* ctx, const LrArgs& la);
 int launch_lr_resid(blmm_ctx* ctx, const NullModel& nm, int64_t m, double tol, const double* lam, const double* h2,
-                    const double* Q, const int* rk, const int* perm, const double* Cp, int64_t ldp, int* flag_list,
-                    double* part, int64_t* stat);
+                    const double* Q, const int* rk, const int* perm, const LrRegion& rg, const double* Cp, int64_t ldp,
+                    int* flag_list, double* part, int64_t* stat);
 int launch_scan_fix(blmm_ctx* ctx, const NullModel& nm, const double* Xt, int64_t ldx, int64_t p, const double* P0,
                     const double* Ls, int64_t ldp, const double* Z0, const double* lam, const double* h2,
                     const int* flag_list, const int* perm, double* L, int64_t ldL, int64_t* stat);
 // shared-weights class: column order of the panels (perm, info) and the per-marker denominators of the unweighted model
-int launch_lr_classify(blmm_ctx* ctx, int n, int64_t m, double tol, const double* lam, const double* h2, int* perm,
-                       int64_t ldq, int64_t* stat);
+int launch_lr_classify(blmm_ctx* ctx, int n, int64_t m, double tol, const double* lam, const double* h2, const int* fin,
+                       const int* list, const unsigned int* list_cnt, int* perm, const LrRegion& rg);
 int launch_lr_den0(blmm_ctx* ctx, int n, int c, const double* Xt, int64_t ldx, int64_t p, const double* Z0, double* den0);
 // kernels_scan_f32.hip: fp32 permutation LOD kernel and the fp64 k-major -> fp32 fragment-major conversion
 int launch_cvt_f32(blmm_ctx* ctx, const double* M, int64_t ld_in, int rows_valid, int64_t cols_valid, float* F,
@@ -193,8 +209,8 @@ int launch_wbasis(blmm_ctx* ctx, const double* lam, int n, double* Wk, double* Q
 int launch_lr_tpanels(blmm_ctx* ctx, const double* Xt, int64_t ldx, int64_t p, int n, int c, int npad, const double* Z0,
                       const double* Q, const int* rk, double* T, int64_t tstride);
 int launch_lr_panels(blmm_ctx* ctx, const NullModel& nm, const double* Yt, int64_t ldy, int64_t m, const double* Z0,
-                     const double* lam, const double* h2, const double* Q, const int* rk, const int* perm, double* P0,
-                     double* Cp, double* Ls, int64_t ldp, int64_t* stat);
+                     const double* lam, const double* h2, const double* Q, const int* rk, const int* perm, const LrRegion& rg,
+                     double* P0, double* Cp, double* Ls, int64_t ldp, int64_t* stat);
 int launch_scan_table(blmm_ctx* ctx, const ScanArgs& a);
 struct AltArgs {
   ScanArgs s; int ngrid; const double* EllTab; /* ngrid x m */ const double* grid_dev; double* H2; int64_t ldH; int counter_quirk;

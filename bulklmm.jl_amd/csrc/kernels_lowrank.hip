@@ -536,12 +536,13 @@ int launch_lr_tpanels(blmm_ctx* ctx, const double* Xt, int64_t ldx, int64_t p, i
 // Per trait (one thread each), from h2_j:  panel0[k][j] = w_k (y - Z0 beta_w)_k / sqrt(yy)   (as k_panels),
 // Cp[r][j] = (Q' w_j)_r for r < R (zero up to 4*KR),  Ls[e][j] = packed lower-triangular L_j^-1 (A_j = Z0'W_jZ0 = L L').
 template <int C>
-__global__ void __launch_bounds__(64) k_lr_panels(NullModel nm, const double* __restrict__ Yt, int64_t ldy, int64_t m,
+__global__ void __launch_bounds__(256) k_lr_panels(NullModel nm, const double* __restrict__ Yt, int64_t ldy, int64_t m,
                                                    const double* __restrict__ Z0, const double* __restrict__ lam,
                                                    const double* __restrict__ h2v, const double* __restrict__ Q,
                                                    const int* __restrict__ rk, int qcap, const int* __restrict__ perm,
-                                                   double* __restrict__ P0, double* __restrict__ Cp,
-                                                   double* __restrict__ Ls, int64_t ldp, int64_t* stat) {
+                                                   int64_t col0, int64_t ncol, double* __restrict__ P0,
+                                                   double* __restrict__ Cp, double* __restrict__ Ls, int64_t ldp,
+                                                   int64_t* stat) {
   extern __shared__ __attribute__((aligned(16))) double sh[];
   const int n = nm.n, npad = nm.npad;
   double* sLam = sh;
@@ -554,11 +555,14 @@ __global__ void __launch_bounds__(64) k_lr_panels(NullModel nm, const double* __
   for (int e = threadIdx.x; e < rl * n; e += blockDim.x) sQ[e] = Q[e];
   __syncthreads();
   // column jc of the panels belongs to trait j = perm[jc] (k_lr_classify: shared-weights traits first); -1: padding
-  const int64_t jc = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (jc >= ldp) return;
+  const int64_t jc = col0 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (jc >= col0 + ncol) return;
   constexpr int NA = C * (C + 1) / 2;
   const int64_t j = perm[jc];
-  if (j < 0 || j >= m) {  // padding columns
+  if (j < 0 || j >= m) {  // padding columns: zeroed where a trait tile of k_scan_lr reaches them -- a tile of the class filled
+    // from the front holds a trait in its first column, one of the class filled from the back in its last
+    const int64_t tb = jc & ~(int64_t)(LR_TILE - 1);
+    if (perm[tb] < 0 && perm[tb + LR_TILE - 1] < 0) return;
     for (int k = 0; k < npad; ++k) P0[(int64_t)k * ldp + jc] = 0.0;
     for (int r = 0; r < R4; ++r) Cp[(int64_t)r * ldp + jc] = 0.0;
     for (int e = 0; e < NA; ++e) Ls[(int64_t)e * ldp + jc] = 0.0;
@@ -692,8 +696,8 @@ constexpr int LRR_KS = 64;
 constexpr int LRR_QC = 96;    // basis rows mirrored in LDS (48 KB); the (rare) rest is read from global memory
 __global__ void __launch_bounds__(256) k_lr_resid(int n, int64_t m, const double* __restrict__ lam,
                                                   const double* __restrict__ h2v, const double* __restrict__ Q,
-                                                  const int* __restrict__ rk, const int* __restrict__ perm,
-                                                  const double* __restrict__ Cp, int64_t ldp,
+                                                  const int* __restrict__ rk, const int* __restrict__ perm, int64_t col0,
+                                                  int64_t ncol, const double* __restrict__ Cp, int64_t ldp,
                                                   double* __restrict__ part /* [nslice][2][ldp] */) {
   extern __shared__ __attribute__((aligned(16))) double sh[];
   const int R = rk[0];
@@ -708,8 +712,8 @@ __global__ void __launch_bounds__(256) k_lr_resid(int n, int64_t m, const double
     sQ[e] = (u < kc) ? Q[(size_t)r * n + k0 + u] : 0.0;
   }
   __syncthreads();
-  const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;   // panel column (permuted space); trait perm[j]
-  if (j >= ldp) return;
+  const int64_t j = col0 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;   // panel column; trait perm[j]
+  if (j >= col0 + ncol) return;
   const int64_t jt = perm[j];
   if (jt < 0 || jt >= m) return;
   const double h2 = h2v[jt];
@@ -744,11 +748,11 @@ __global__ void __launch_bounds__(256) k_lr_resid(int n, int64_t m, const double
 
 __global__ void __launch_bounds__(256) k_lr_resid2(int nslice, int64_t m, double tol2, const double* __restrict__ part,
                                                    int64_t ldp, const int* __restrict__ rk, const int* __restrict__ perm,
-                                                   int* __restrict__ flag_list, int64_t* stat) {
+                                                   int64_t col0, int64_t ncol, int* __restrict__ flag_list, int64_t* stat) {
   if (rk[0] < 0) return;
-  const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;   // panel column
+  const int64_t j = col0 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;   // panel column
   double rel2 = 0.0;
-  if (j < ldp && perm[j] >= 0 && perm[j] < m) {
+  if (j < col0 + ncol && perm[j] >= 0 && perm[j] < m) {
     double rr = 0.0, ww = 0.0;
     for (int s = 0; s < nslice; ++s) { rr += part[((size_t)s * 2 + 0) * ldp + j]; ww += part[((size_t)s * 2 + 1) * ldp + j]; }
     rel2 = rr / ww;
@@ -844,18 +848,25 @@ __global__ void __launch_bounds__(256) k_scan_fix(NullModel nm, const double* __
 // numerator panel still carries the trait's own weights).  On eQTL-like data that is every trait whose likelihood peaks
 // at the h2 = 0 boundary -- half of the BXD-shaped bench workload -- and k_scan_lr skips the rank-R phase for their
 // tiles.  k_lr_classify orders the panel columns: the class fills perm[] from the front, the other traits from the back
-// (perm was preset to -1 = padding; ldq - m >= 128 keeps a whole padding tile between the two), counts in stat[12] /
-// stat[13].  A workgroup owns 1024 consecutive traits and keeps their order; the order of the workgroups' ranges follows
+// (perm was preset to -1 = padding; ldq - m >= 128 keeps a whole padding tile between the two), counts in counts[0] /
+// counts[1].  A workgroup owns 1024 consecutive traits and keeps their order; the order of the workgroups' ranges follows
 // the arrival of two atomics -- immaterial, every LOD is written through perm and its arithmetic does not depend on the
-// column it sits in.
+// column it sits in.  The panel arrays hold two such regions (LrRegion): the traits k_brent finished, and the ones
+// k_brent2 finishes while the first region is already being scanned.
 // ------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) k_lr_classify(int n, int64_t m, double tol, const double* __restrict__ lam,
-                                                     const double* __restrict__ h2v, int* __restrict__ perm, int64_t ldq,
-                                                     int64_t* stat) {
+                                                     const double* __restrict__ h2v, const int* __restrict__ fin,
+                                                     const int* __restrict__ list, const unsigned int* __restrict__ list_cnt,
+                                                     int* __restrict__ perm, int64_t col0, int64_t ldq,
+                                                     int64_t* __restrict__ counts) {
+  // The traits of this pass: list[0 .. *list_cnt) when a list is given (the traits k_brent2 finished), otherwise every
+  // trait j < m with fin[j] == 1 (fin == nullptr: all of them).  Its panel columns are [col0, col0 + ldq).
   __shared__ double s_red[4];
   __shared__ int s_cnt[4];
   __shared__ long long s_base[2];
   const int t = threadIdx.x;
+  const int64_t E = list ? (int64_t)*list_cnt : m;
+  if ((int64_t)blockIdx.x * 1024 >= E) return;              // workgroup-uniform
   double s2 = 0.0;
   for (int k = t; k < n; k += 256) s2 = fma(lam[k], lam[k], s2);
 #pragma unroll
@@ -864,19 +875,26 @@ __global__ void __launch_bounds__(256) k_lr_classify(int n, int64_t m, double to
   __syncthreads();
   const double rms = sqrt((s_red[0] + s_red[1] + s_red[2] + s_red[3]) / (double)n);
   const double thr = (tol > 0.0) ? ((rms > 0.0) ? tol / rms : INFINITY) : 0.0;
-  const int64_t j0 = (int64_t)blockIdx.x * 1024 + 4 * t;
-  bool f[4];
-  int cnt = 0;
+  const int64_t e0 = (int64_t)blockIdx.x * 1024 + 4 * t;
+  int64_t jt[4];
+  bool inc[4], f[4];
+  int cs = 0, co = 0;
 #pragma unroll
   for (int u = 0; u < 4; ++u) {
-    f[u] = false;
-    if (j0 + u < m) {
-      const double h2 = h2v[j0 + u];
-      f[u] = fabs(h2 / (1.0 - h2)) <= thr;      // false for NaN
+    inc[u] = false; f[u] = false; jt[u] = 0;
+    if (e0 + u < E) {
+      jt[u] = list ? (int64_t)list[e0 + u] : e0 + u;
+      inc[u] = list ? true : (fin ? fin[jt[u]] == 1 : true);
+      if (inc[u]) {
+        const double h2 = h2v[jt[u]];
+        f[u] = fabs(h2 / (1.0 - h2)) <= thr;    // false for NaN
+      }
     }
-    cnt += f[u] ? 1 : 0;
+    cs += (inc[u] && f[u]) ? 1 : 0;
+    co += (inc[u] && !f[u]) ? 1 : 0;
   }
-  int incl = cnt;                                // inclusive scan over the wave, then over the four waves
+  const int mine = cs | (co << 16);             // both counts in one scan (<= 1024 each)
+  int incl = mine;
 #pragma unroll
   for (int o = 1; o < 64; o <<= 1) {
     const int v = __shfl_up(incl, o, 64);
@@ -884,22 +902,21 @@ __global__ void __launch_bounds__(256) k_lr_classify(int n, int64_t m, double to
   }
   if ((t & 63) == 63) s_cnt[t >> 6] = incl;
   __syncthreads();
-  int before = incl - cnt;
+  int before = incl - mine;
   for (int w = 0; w < (t >> 6); ++w) before += s_cnt[w];
   const int total = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
-  const int64_t valid = (m - (int64_t)blockIdx.x * 1024 < 1024) ? (m - (int64_t)blockIdx.x * 1024) : 1024;
   if (t == 0) {
-    s_base[0] = (long long)atomicAdd((unsigned long long*)&stat[12], (unsigned long long)total);
-    s_base[1] = (long long)atomicAdd((unsigned long long*)&stat[13], (unsigned long long)(valid - total));
+    s_base[0] = (long long)atomicAdd((unsigned long long*)&counts[0], (unsigned long long)(total & 0xffff));
+    s_base[1] = (long long)atomicAdd((unsigned long long*)&counts[1], (unsigned long long)(total >> 16));
   }
   __syncthreads();
-  int64_t bpos = s_base[0] + before;
-  int64_t opos = s_base[1] + (4 * t - before);  // traits of the other class before this thread, in the workgroup's range
+  int64_t bpos = s_base[0] + (before & 0xffff);
+  int64_t opos = s_base[1] + (before >> 16);
 #pragma unroll
   for (int u = 0; u < 4; ++u) {
-    if (j0 + u < m) {
-      if (f[u]) perm[bpos++] = (int)(j0 + u);
-      else perm[ldq - 1 - (opos++)] = (int)(j0 + u);
+    if (inc[u]) {
+      if (f[u]) perm[col0 + bpos++] = (int)jt[u];
+      else perm[col0 + ldq - 1 - (opos++)] = (int)jt[u];
     }
   }
 }
@@ -948,11 +965,12 @@ __global__ void __launch_bounds__(256) k_lr_den0(int n, const double* __restrict
   den0[i] = xx;
 }
 
-int launch_lr_classify(blmm_ctx* ctx, int n, int64_t m, double tol, const double* lam, const double* h2, int* perm,
-                       int64_t ldq, int64_t* stat) {
+int launch_lr_classify(blmm_ctx* ctx, int n, int64_t m, double tol, const double* lam, const double* h2, const int* fin,
+                       const int* list, const unsigned int* list_cnt, int* perm, const LrRegion& rg) {
   if (m > 0x7ffffff0LL) return fail(ctx, BLMM_ERR_INVALID, "too many traits for one launch");
   if (m <= 0) return BLMM_OK;
-  hipLaunchKernelGGL(k_lr_classify, dim3((unsigned)((m + 1023) / 1024)), dim3(256), 0, ctx->stream, n, m, tol, lam, h2, perm, ldq, stat);
+  hipLaunchKernelGGL(k_lr_classify, dim3((unsigned)((m + 1023) / 1024)), dim3(256), 0, ctx->stream, n, m, tol, lam, h2, fin, list,
+                     list_cnt, perm, rg.col0, rg.ncol, rg.counts);
   KCHECK();
   return BLMM_OK;
 }
@@ -972,13 +990,16 @@ int launch_lr_den0(blmm_ctx* ctx, int n, int c, const double* Xt, int64_t ldx, i
 }
 
 int launch_lr_panels(blmm_ctx* ctx, const NullModel& nm, const double* Yt, int64_t ldy, int64_t m, const double* Z0,
-                     const double* lam, const double* h2, const double* Q, const int* rk, const int* perm, double* P0,
-                     double* Cp, double* Ls, int64_t ldp, int64_t* stat) {
-  // 64 threads per block (more blocks than CUs even at m ~ 35k); basis rows in LDS up to 56 KB
-  const unsigned blocks = (unsigned)((ldp + 63) / 64);
+                     const double* lam, const double* h2, const double* Q, const int* rk, const int* perm, const LrRegion& rg,
+                     double* P0, double* Cp, double* Ls, int64_t ldp, int64_t* stat) {
+  // basis rows in LDS up to 56 KB, staged by every block: 64 threads per block give more blocks than CUs at m ~ 35k, 128
+  // halve the staging per trait (BLMM_LR_PANELS_NT: A/B testing)
+  static const int nt_env = getenv("BLMM_LR_PANELS_NT") ? atoi(getenv("BLMM_LR_PANELS_NT")) : 0;
+  const int nthr = (nt_env == 64 || nt_env == 128 || nt_env == 256) ? nt_env : 64;
+  const unsigned blocks = (unsigned)((rg.ncol + nthr - 1) / nthr);
   const int qcap = (int)std::min<size_t>((size_t)nm.n, (56 * 1024) / (sizeof(double) * (size_t)nm.n));
   const size_t lds = sizeof(double) * ((size_t)nm.n * (1 + nm.c) + (size_t)qcap * nm.n);
-#define LP(C) hipLaunchKernelGGL(k_lr_panels<C>, dim3(blocks), dim3(64), lds, ctx->stream, nm, Yt, ldy, m, Z0, lam, h2, Q, rk, qcap, perm, P0, Cp, Ls, ldp, stat)
+#define LP(C) hipLaunchKernelGGL(k_lr_panels<C>, dim3(blocks), dim3(nthr), lds, ctx->stream, nm, Yt, ldy, m, Z0, lam, h2, Q, rk, qcap, perm, rg.col0, rg.ncol, P0, Cp, Ls, ldp, stat)
   switch (nm.c) {
     case 1: LP(1); break;
     case 2: LP(2); break;
@@ -993,17 +1014,17 @@ int launch_lr_panels(blmm_ctx* ctx, const NullModel& nm, const double* Yt, int64
 
 // The guard (all traits): the caller runs it on the side stream beside the scan kernel, then launch_scan_fix.
 int launch_lr_resid(blmm_ctx* ctx, const NullModel& nm, int64_t m, double tol, const double* lam, const double* h2,
-                    const double* Q, const int* rk, const int* perm, const double* Cp, int64_t ldp, int* flag_list,
-                    double* part, int64_t* stat) {
+                    const double* Q, const int* rk, const int* perm, const LrRegion& rg, const double* Cp, int64_t ldp,
+                    int* flag_list, double* part, int64_t* stat) {
   if (m <= 0) return BLMM_OK;
   const int nslice = (nm.n + LRR_KS - 1) / LRR_KS;
   const size_t lds = sizeof(double) * ((size_t)LRR_KS * (1 + (size_t)LRR_QC));
   if (lds > 48 * 1024)
     BLMM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_lr_resid), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  hipLaunchKernelGGL(k_lr_resid, dim3((unsigned)((ldp + 255) / 256), (unsigned)nslice), dim3(256), lds, ctx->stream, nm.n, m, lam, h2, Q,
-                     rk, perm, Cp, ldp, part);
-  hipLaunchKernelGGL(k_lr_resid2, dim3((unsigned)((ldp + 255) / 256)), dim3(256), 0, ctx->stream, nslice, m, tol * tol, part, ldp, rk,
-                     perm, flag_list, stat);
+  hipLaunchKernelGGL(k_lr_resid, dim3((unsigned)((rg.ncol + 255) / 256), (unsigned)nslice), dim3(256), lds, ctx->stream, nm.n, m, lam, h2, Q,
+                     rk, perm, rg.col0, rg.ncol, Cp, ldp, part);
+  hipLaunchKernelGGL(k_lr_resid2, dim3((unsigned)((rg.ncol + 255) / 256)), dim3(256), 0, ctx->stream, nslice, m, tol * tol, part, ldp, rk,
+                     perm, rg.col0, rg.ncol, flag_list, stat);
   KCHECK();
   return BLMM_OK;
 }

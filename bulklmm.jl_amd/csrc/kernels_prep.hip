@@ -1360,6 +1360,7 @@ struct BrentCont {
   double* st;
   int* list;
   unsigned int* cnt;
+  int* fin;            // fin[j] = 1: trait j finished in k_brent (its h2 is final), 0: it is on the list
 };
 
 template <int C, int LPT, bool REG>
@@ -1414,6 +1415,7 @@ __global__ void __launch_bounds__(256, BRENT_MINW) k_brent(NullModel nm, const d
       fin = null_ell_reg<C, LPT>(S.x, R, n, nm.prior_a, nm.prior_b, nm.reml, s_ln, &nonpos);
       const int ts = threadIdx.x / LPT;
       if (sub == 0) {
+        if (valid && cont.fin) cont.fin[j] = S.done ? 1 : 0;
         if (valid && S.done) {
           h2out[j] = S.x;
           if (s2out) s2out[j] = fin.sigma2;
@@ -1537,29 +1539,37 @@ __global__ void __launch_bounds__(256, BRENT_MINW2) k_brent2(NullModel nm, const
   }
 }
 
+// phase 0: the whole search; 1: k_brent only (sp->active tells whether k_brent2 is pending; if not, the search is complete);
+// 2: k_brent2 (after a phase 1 with sp->active, same arguments)
 template <int C, int LPT, bool REG>
 static int launch_brent_t(blmm_ctx* ctx, const NullModel& nm, const double* Yt, int64_t ldy, int64_t m, const double* Z0,
-                          const double* lam, double* h2, double* sigma2, double* ell, int64_t* stat) {
+                          const double* lam, double* h2, double* sigma2, double* ell, int64_t* stat, int phase, BrentSplit* sp) {
   const int64_t threads = m * LPT;
   const unsigned blocks = (unsigned)((threads + 255) / 256);
   const size_t lds = REG ? sizeof(double) * ((size_t)LPT * NULL_NK * (1 + C) + (size_t)NULL_NK * 256) : sizeof(double) * (size_t)nm.n * (1 + C);
   if (lds > 48 * 1024)
     BLMM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_brent<C, LPT, REG>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  BrentCont cont{nullptr, nullptr, nullptr};
+  BrentCont cont{nullptr, nullptr, nullptr, nullptr};
   static const char* two_env = getenv("BLMM_BRENT_TWO");   // "0": keep the single-kernel form (A/B testing)
   const bool two = REG && (64 / LPT) > 1 && nm.optim_interval <= 1 && m >= 1024 && !(two_env && two_env[0] == '0');
   if (two) {
     int rc = ensure(ctx, ctx->brSt, sizeof(double) * (size_t)12 * m);
-    if (!rc) rc = ensure(ctx, ctx->brList, sizeof(int) * (size_t)m + 16);
+    if (!rc) rc = ensure(ctx, ctx->brList, sizeof(int) * 2 * (size_t)m + 16);
     if (rc) return rc;
     cont.st = ptr<double>(ctx->brSt);
     cont.cnt = ptr<unsigned int>(ctx->brList);
     cont.list = ptr<int>(ctx->brList) + 4;
-    BLMM_HIP(hipMemsetAsync(cont.cnt, 0, 16, ctx->stream));
+    cont.fin = cont.list + m;
+    if (phase != 2) BLMM_HIP(hipMemsetAsync(cont.cnt, 0, 16, ctx->stream));
   }
-  hipLaunchKernelGGL((k_brent<C, LPT, REG>), dim3(blocks), dim3(256), lds, ctx->stream, nm, Yt, ldy, m, Z0, lam,
-                     ptr<double>(ctx->logtab), h2, sigma2, ell, stat, cont);
-  KCHECK();
+  if (sp) { sp->active = two && phase == 1; sp->fin = cont.fin; sp->list = cont.list; sp->cnt = cont.cnt; }
+  if (phase != 2) {
+    hipLaunchKernelGGL((k_brent<C, LPT, REG>), dim3(blocks), dim3(256), lds, ctx->stream, nm, Yt, ldy, m, Z0, lam,
+                       ptr<double>(ctx->logtab), h2, sigma2, ell, stat, cont);
+    KCHECK();
+  }
+  if (phase == 1 && two) return BLMM_OK;
+  if (phase == 2 && !two) return BLMM_OK;
   if constexpr (REG) {
     if (two) {
       // A/B testing: 8 / 16 spread a trait of the second kernel over more lanes than k_brent's 4 (measured at BXD size:
@@ -1587,26 +1597,26 @@ static int launch_brent_t(blmm_ctx* ctx, const NullModel& nm, const double* Yt, 
 
 template <int C>
 static int launch_brent_c(blmm_ctx* ctx, const NullModel& nm, const double* Yt, int64_t ldy, int64_t m, const double* Z0,
-                          const double* lam, double* h2, double* sigma2, double* ell, int64_t* stat) {
+                          const double* lam, double* h2, double* sigma2, double* ell, int64_t* stat, int phase, BrentSplit* sp) {
   const int n = nm.n;
   static const int lpt_env = getenv("BLMM_BRENT_LPT") ? atoi(getenv("BLMM_BRENT_LPT")) : 0;
-  if (lpt_env == 8 && n <= 8 * NULL_NK) return launch_brent_t<C, 8, true>(ctx, nm, Yt, ldy, m, Z0, lam, h2, sigma2, ell, stat);
-  if (lpt_env == 16 && n <= 16 * NULL_NK) return launch_brent_t<C, 16, true>(ctx, nm, Yt, ldy, m, Z0, lam, h2, sigma2, ell, stat);
-  if (n <= 4 * NULL_NK) return launch_brent_t<C, 4, true>(ctx, nm, Yt, ldy, m, Z0, lam, h2, sigma2, ell, stat);
-  if (n <= 8 * NULL_NK) return launch_brent_t<C, 8, true>(ctx, nm, Yt, ldy, m, Z0, lam, h2, sigma2, ell, stat);
-  if (n <= 16 * NULL_NK) return launch_brent_t<C, 16, true>(ctx, nm, Yt, ldy, m, Z0, lam, h2, sigma2, ell, stat);
-  if (n <= 32 * NULL_NK) return launch_brent_t<C, 32, true>(ctx, nm, Yt, ldy, m, Z0, lam, h2, sigma2, ell, stat);
-  if (n <= 64 * NULL_NK) return launch_brent_t<C, 64, true>(ctx, nm, Yt, ldy, m, Z0, lam, h2, sigma2, ell, stat);
-  return launch_brent_t<C, BRENT_LPT, false>(ctx, nm, Yt, ldy, m, Z0, lam, h2, sigma2, ell, stat);
+  if (lpt_env == 8 && n <= 8 * NULL_NK) return launch_brent_t<C, 8, true>(ctx, nm, Yt, ldy, m, Z0, lam, h2, sigma2, ell, stat, phase, sp);
+  if (lpt_env == 16 && n <= 16 * NULL_NK) return launch_brent_t<C, 16, true>(ctx, nm, Yt, ldy, m, Z0, lam, h2, sigma2, ell, stat, phase, sp);
+  if (n <= 4 * NULL_NK) return launch_brent_t<C, 4, true>(ctx, nm, Yt, ldy, m, Z0, lam, h2, sigma2, ell, stat, phase, sp);
+  if (n <= 8 * NULL_NK) return launch_brent_t<C, 8, true>(ctx, nm, Yt, ldy, m, Z0, lam, h2, sigma2, ell, stat, phase, sp);
+  if (n <= 16 * NULL_NK) return launch_brent_t<C, 16, true>(ctx, nm, Yt, ldy, m, Z0, lam, h2, sigma2, ell, stat, phase, sp);
+  if (n <= 32 * NULL_NK) return launch_brent_t<C, 32, true>(ctx, nm, Yt, ldy, m, Z0, lam, h2, sigma2, ell, stat, phase, sp);
+  if (n <= 64 * NULL_NK) return launch_brent_t<C, 64, true>(ctx, nm, Yt, ldy, m, Z0, lam, h2, sigma2, ell, stat, phase, sp);
+  return launch_brent_t<C, BRENT_LPT, false>(ctx, nm, Yt, ldy, m, Z0, lam, h2, sigma2, ell, stat, phase, sp);
 }
 
 int launch_brent(blmm_ctx* ctx, const NullModel& nm, const double* Yt, int64_t ldy, int64_t m, const double* Z0,
-                 const double* lam, double* h2, double* sigma2, double* ell, int64_t* stat) {
+                 const double* lam, double* h2, double* sigma2, double* ell, int64_t* stat, int phase, BrentSplit* sp) {
   switch (nm.c) {
-    case 1: return launch_brent_c<1>(ctx, nm, Yt, ldy, m, Z0, lam, h2, sigma2, ell, stat);
-    case 2: return launch_brent_c<2>(ctx, nm, Yt, ldy, m, Z0, lam, h2, sigma2, ell, stat);
-    case 3: return launch_brent_c<3>(ctx, nm, Yt, ldy, m, Z0, lam, h2, sigma2, ell, stat);
-    case 4: return launch_brent_c<4>(ctx, nm, Yt, ldy, m, Z0, lam, h2, sigma2, ell, stat);
+    case 1: return launch_brent_c<1>(ctx, nm, Yt, ldy, m, Z0, lam, h2, sigma2, ell, stat, phase, sp);
+    case 2: return launch_brent_c<2>(ctx, nm, Yt, ldy, m, Z0, lam, h2, sigma2, ell, stat, phase, sp);
+    case 3: return launch_brent_c<3>(ctx, nm, Yt, ldy, m, Z0, lam, h2, sigma2, ell, stat, phase, sp);
+    case 4: return launch_brent_c<4>(ctx, nm, Yt, ldy, m, Z0, lam, h2, sigma2, ell, stat, phase, sp);
   }
   return fail(ctx, BLMM_ERR_UNSUPPORTED, "number of null covariates (incl. intercept) must be 1..4");
 }

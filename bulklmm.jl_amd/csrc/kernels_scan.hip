@@ -299,17 +299,19 @@ __global__ void __launch_bounds__(256, 2) k_scan_lr(LrArgs la, int ntile_i, int6
     const int64_t q = nwg >> 3;
     if ((int64_t)blockIdx.x >= (q << 3)) return;                 // workgroup-uniform; before any barrier
     const int64_t x = blockIdx.x & 7, local = blockIdx.x >> 3;
-    const int64_t nsh = *la.nshared;
-    const int64_t ns = (nsh + TW - 1) / TW, fo = (a.ldp - (la.mtraits - nsh)) / TW, nf = a.ldp / TW - fo;
+    const int64_t nsh = la.rg.counts[0], noth = la.rg.counts[1];
+    const int64_t tb = la.rg.col0 / TW;                          // the region's first tile (col0, ncol: multiples of 64)
+    const int64_t ns = (nsh + TW - 1) / TW, fo = (la.rg.ncol - noth) / TW, nf = la.rg.ncol / TW - fo;
     const int64_t NS = ns * ntile_i, NF = nf * ntile_i;
     const int64_t sS = (x * NS) >> 3, cS = (((x + 1) * NS) >> 3) - sS, sF = (x * NF) >> 3, cF = (((x + 1) * NF) >> 3) - sF;
     if (local < cS) {
       shared_w = true;
       tile_of(sS + local, ns, ntile_i, tile_t, tile_i);
+      tile_t += tb;
     } else if (local - cS < cF) {
       shared_w = false;
       tile_of(sF + local - cS, nf, ntile_i, tile_t, tile_i);
-      tile_t += fo;
+      tile_t += tb + fo;
     } else {
       return;
     }
