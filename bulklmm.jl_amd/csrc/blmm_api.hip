@@ -427,8 +427,8 @@ int lr_begin(blmm_ctx* ctx, const Pipe& P, bool wbasis_started) {
   if (!wbasis_started) rc = launch_wbasis(ctx, P.lam, P.n, ptr<double>(ctx->wbW), ptr<double>(ctx->wbQ), rk, P.stat);
   if (!rc && hipMemsetAsync(ctx->lrPerm.p, 0xff, sizeof(int) * (size_t)ldp, ctx->side) != hipSuccess) rc = fail(ctx, BLMM_ERR_HIP, "hipMemsetAsync failed");
   if (!rc && hipEventRecord(ctx->ev_q, ctx->side) != hipSuccess) rc = fail(ctx, BLMM_ERR_HIP, "hipEventRecord failed");   // what the panels need
-  if (!rc) rc = launch_lr_den0(ctx, P.n, P.c, P.Xt, P.ldx, P.p, P.Z0, ptr<double>(ctx->lrDen0));
-  if (!rc) rc = launch_lr_tpanels(ctx, P.Xt, P.ldx, P.p, P.n, P.c, P.npad, P.Z0, ptr<double>(ctx->wbQ), rk, ptr<double>(ctx->lrT), tstride);
+  if (!rc) rc = launch_lr_tpanels(ctx, P.Xt, P.ldx, P.p, P.n, P.c, P.npad, P.Z0, ptr<double>(ctx->wbQ), rk, ptr<double>(ctx->lrT), tstride,
+                                  ptr<double>(ctx->lrDen0));
   ctx->stream = main_stream;
   if (rc) return rc;
   BLMM_HIP(hipEventRecord(ctx->ev_join, ctx->side));                // ... and what the scan needs on top

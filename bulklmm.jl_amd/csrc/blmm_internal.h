@@ -198,7 +198,6 @@ int launch_scan_fix(blmm_ctx* ctx, const NullModel& nm, const double* Xt, int64_
 // shared-weights class: column order of the panels (perm, info) and the per-marker denominators of the unweighted model
 int launch_lr_classify(blmm_ctx* ctx, int n, int64_t m, double tol, const double* lam, const double* h2, const int* fin,
                        const int* list, const unsigned int* list_cnt, int* perm, const LrRegion& rg);
-int launch_lr_den0(blmm_ctx* ctx, int n, int c, const double* Xt, int64_t ldx, int64_t p, const double* Z0, double* den0);
 // kernels_scan_f32.hip: fp32 permutation LOD kernel and the fp64 k-major -> fp32 fragment-major conversion
 int launch_cvt_f32(blmm_ctx* ctx, const double* M, int64_t ld_in, int rows_valid, int64_t cols_valid, float* F,
                    int64_t ld_out, int kblocks);
@@ -207,7 +206,7 @@ int launch_scan_f32(blmm_ctx* ctx, const float* XF, int64_t ldxf, const float* P
 // kernels_lowrank.hip
 int launch_wbasis(blmm_ctx* ctx, const double* lam, int n, double* Wk, double* Q, int* rk, int64_t* stat);
 int launch_lr_tpanels(blmm_ctx* ctx, const double* Xt, int64_t ldx, int64_t p, int n, int c, int npad, const double* Z0,
-                      const double* Q, const int* rk, double* T, int64_t tstride);
+                      const double* Q, const int* rk, double* T, int64_t tstride, double* den0);
 int launch_lr_panels(blmm_ctx* ctx, const NullModel& nm, const double* Yt, int64_t ldy, int64_t m, const double* Z0,
                      const double* lam, const double* h2, const double* Q, const int* rk, const int* perm, const LrRegion& rg,
                      double* P0, double* Cp, double* Ls, int64_t ldp, int64_t* stat);

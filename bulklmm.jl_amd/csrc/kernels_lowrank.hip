@@ -481,15 +481,24 @@ int launch_wbasis(blmm_ctx* ctx, const double* lam, int n, double* Wk, double* Q
 
 // T[q][r][i]: q = 0: sum_k Q[r][k] x_ik^2 ; q = 1..c: sum_k Q[r][k] x_ik z_(q-1)k.   Rows r >= R (up to 4*KR) are zero.
 // grid = (ldx/256, ceil(4*KRmax/16)); the kernel reads R from rk and returns early for chunks beyond it.
+// The first chunk also leaves den0_i = Sxx - |L0^-1 s|^2 of the unweighted model (Sxx = sum_k x_ik^2, s_q = sum_k x_ik z_qk,
+// Z0'Z0 = L0 L0'): the denominators of the shared-weights class, from the same pass over Xt.
 template <int C>
 __global__ void __launch_bounds__(256) k_lr_tpanels(const double* __restrict__ Xt, int64_t ldx, int64_t p, int n,
                                                     const double* __restrict__ Z0, const double* __restrict__ Q,
-                                                    const int* __restrict__ rk, double* __restrict__ T, int64_t tstride) {
+                                                    const int* __restrict__ rk, double* __restrict__ T, int64_t tstride,
+                                                    double* __restrict__ den0) {
   const int R = rk[0], R4 = rk[1] * 4;
   const int r0 = blockIdx.y * 16;
-  if (r0 >= R4) return;
+  if (r0 >= R4 && r0 > 0) return;
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= ldx) return;
+  constexpr int NA = C * (C + 1) / 2;
+  double un[1 + C], A0[NA];                      // unweighted sums (first chunk only)
+#pragma unroll
+  for (int q = 0; q <= C; ++q) un[q] = 0.0;
+#pragma unroll
+  for (int a = 0; a < NA; ++a) A0[a] = 0.0;
   double acc[1 + C][16];
 #pragma unroll
   for (int q = 0; q <= C; ++q)
@@ -502,6 +511,14 @@ __global__ void __launch_bounds__(256) k_lr_tpanels(const double* __restrict__ X
       xv[0] = x * x;
 #pragma unroll
       for (int q = 0; q < C; ++q) xv[1 + q] = x * Z0[q * n + k];
+      if (r0 == 0) {                             // workgroup-uniform
+#pragma unroll
+        for (int q = 0; q <= C; ++q) un[q] += xv[q];
+#pragma unroll
+        for (int q = 0; q < C; ++q)
+#pragma unroll
+          for (int r = 0; r <= q; ++r) A0[q * (q + 1) / 2 + r] = fma(Z0[q * n + k], Z0[r * n + k], A0[q * (q + 1) / 2 + r]);
+      }
 #pragma unroll
       for (int t = 0; t < 16; ++t) {
         const double qv = (r0 + t < R) ? Q[(size_t)(r0 + t) * n + k] : 0.0;   // wave-uniform
@@ -515,12 +532,36 @@ __global__ void __launch_bounds__(256) k_lr_tpanels(const double* __restrict__ X
     if (r0 + t < R4)
 #pragma unroll
       for (int q = 0; q <= C; ++q) T[q * tstride + (int64_t)(r0 + t) * ldx + i] = acc[q][t];
+  if (r0 == 0) {
+    double xx = 1.0;
+    if (i < p) {
+      double L[NA];
+      xx = un[0];
+#pragma unroll
+      for (int q = 0; q < C; ++q) {
+#pragma unroll
+        for (int r = 0; r <= q; ++r) {
+          double v = A0[q * (q + 1) / 2 + r];
+#pragma unroll
+          for (int u = 0; u < r; ++u) v = fma(-L[q * (q + 1) / 2 + u], L[r * (r + 1) / 2 + u], v);
+          L[q * (q + 1) / 2 + r] = (r == q) ? sqrt(v) : v / L[r * (r + 1) / 2 + r];
+        }
+        double u = un[1 + q];                    // forward substitution: u_q = (L0^-1 s)_q
+#pragma unroll
+        for (int r = 0; r < q; ++r) u = fma(-L[q * (q + 1) / 2 + r], un[1 + r], u);
+        u /= L[q * (q + 1) / 2 + q];
+        un[1 + q] = u;
+        xx = fma(-u, u, xx);
+      }
+    }
+    den0[i] = xx;
+  }
 }
 
 int launch_lr_tpanels(blmm_ctx* ctx, const double* Xt, int64_t ldx, int64_t p, int n, int c, int npad, const double* Z0,
-                      const double* Q, const int* rk, double* T, int64_t tstride) {
+                      const double* Q, const int* rk, double* T, int64_t tstride, double* den0) {
   dim3 grid((unsigned)((ldx + 255) / 256), (unsigned)((npad + 15) / 16));
-#define TP(C) hipLaunchKernelGGL(k_lr_tpanels<C>, grid, dim3(256), 0, ctx->stream, Xt, ldx, p, n, Z0, Q, rk, T, tstride)
+#define TP(C) hipLaunchKernelGGL(k_lr_tpanels<C>, grid, dim3(256), 0, ctx->stream, Xt, ldx, p, n, Z0, Q, rk, T, tstride, den0)
   switch (c) {
     case 1: TP(1); break;
     case 2: TP(2); break;
@@ -682,6 +723,141 @@ __global__ void __launch_bounds__(256) k_lr_panels(NullModel nm, const double* _
       for (int k = 0; k < n; ++k) c = fma(qr[k], fabs(fast_rcp(fma(delta, sLam[k], 1.0))), c);
     }
     Cp[(int64_t)r * ldp + jc] = c;
+  }
+}
+
+// The same panels for larger n (> 160), LPT lanes per trait: at n = 500 a shard has a few thousand traits, and one thread
+// walking a trait's n individuals (twice, plus R dot products of length n) left the GPU at a handful of waves for 0.4 ms.
+// Lane `sub` of a trait's group owns the individuals k = sub, sub + LPT, ...; sums are butterflied over the group, the
+// small per-trait algebra is done redundantly by every lane.  Basis rows come from L2 (every group of a workgroup reads
+// the same addresses, consecutive lanes consecutive k).
+template <int C, int LPT>
+__global__ void __launch_bounds__(256) k_lr_panels_w(NullModel nm, const double* __restrict__ Yt, int64_t ldy, int64_t m,
+                                                     const double* __restrict__ Z0, const double* __restrict__ lam,
+                                                     const double* __restrict__ h2v, const double* __restrict__ Q,
+                                                     const int* __restrict__ rk, const int* __restrict__ perm, int64_t col0,
+                                                     int64_t ncol, double* __restrict__ P0, double* __restrict__ Cp,
+                                                     double* __restrict__ Ls, int64_t ldp, int64_t* stat) {
+  extern __shared__ __attribute__((aligned(16))) double sh[];
+  const int n = nm.n, npad = nm.npad;
+  double* sLam = sh;
+  double* sZ = sh + n;
+  const int R = rk[0], R4 = rk[1] * 4;
+  for (int e = threadIdx.x; e < n; e += blockDim.x) sLam[e] = lam[e];
+  for (int e = threadIdx.x; e < n * C; e += blockDim.x) sZ[e] = Z0[e];
+  __syncthreads();
+  constexpr int TPB = 256 / LPT;
+  const int sub = threadIdx.x % LPT;
+  const int64_t jc = col0 + (int64_t)blockIdx.x * TPB + threadIdx.x / LPT;
+  if (jc >= col0 + ncol) return;                 // whole lane groups leave together
+  constexpr int NA = C * (C + 1) / 2;
+  const int64_t j = perm[jc];
+  if (j < 0 || j >= m) {   // padding column (see k_lr_panels)
+    const int64_t tb = jc & ~(int64_t)(LR_TILE - 1);
+    if (perm[tb] < 0 && perm[tb + LR_TILE - 1] < 0) return;
+    for (int k = sub; k < npad; k += LPT) P0[(int64_t)k * ldp + jc] = 0.0;
+    for (int r = sub; r < R4; r += LPT) Cp[(int64_t)r * ldp + jc] = 0.0;
+    for (int e = sub; e < NA; e += LPT) Ls[(int64_t)e * ldp + jc] = 0.0;
+    return;
+  }
+  auto gsum = [](double x) {
+#pragma unroll
+    for (int o = 1; o < LPT; o <<= 1) x += __shfl_xor(x, o, LPT);
+    return x;
+  };
+  const double h2 = h2v[j];
+  const double delta = h2 / (1.0 - h2);
+  double A[NA], v[C], syy = 0.0;
+#pragma unroll
+  for (int a = 0; a < NA; ++a) A[a] = 0.0;
+#pragma unroll
+  for (int q = 0; q < C; ++q) v[q] = 0.0;
+  for (int k = sub; k < n; k += LPT) {
+    const double w = fabs(fast_rcp(fma(delta, sLam[k], 1.0)));  // sqrt.(abs.(makeweights)) squared, src/bulkscan_helpers.jl:138
+    const double y = Yt[(int64_t)k * ldy + j];
+    const double wy = w * y;
+    syy = fma(wy, y, syy);
+#pragma unroll
+    for (int q = 0; q < C; ++q) {
+      const double zq = sZ[q * n + k];
+      v[q] = fma(wy, zq, v[q]);
+      const double wz = w * zq;
+#pragma unroll
+      for (int r = 0; r <= q; ++r) A[q * (q + 1) / 2 + r] = fma(wz, sZ[r * n + k], A[q * (q + 1) / 2 + r]);
+    }
+  }
+  syy = gsum(syy);
+#pragma unroll
+  for (int a = 0; a < NA; ++a) A[a] = gsum(A[a]);
+#pragma unroll
+  for (int q = 0; q < C; ++q) v[q] = gsum(v[q]);
+  double L[NA], Li[NA], t[C], beta[C], tt = 0.0;
+#pragma unroll
+  for (int q = 0; q < C; ++q) {
+#pragma unroll
+    for (int r = 0; r <= q; ++r) {
+      double s = A[q * (q + 1) / 2 + r];
+#pragma unroll
+      for (int u = 0; u < r; ++u) s = fma(-L[q * (q + 1) / 2 + u], L[r * (r + 1) / 2 + u], s);
+      L[q * (q + 1) / 2 + r] = (r == q) ? sqrt(s) : s / L[r * (r + 1) / 2 + r];
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < C; ++q) {
+#pragma unroll
+    for (int r = 0; r <= q; ++r) {
+      double s = (r == q) ? 1.0 : 0.0;
+#pragma unroll
+      for (int u = r; u < q; ++u) s = fma(-L[q * (q + 1) / 2 + u], Li[u * (u + 1) / 2 + r], s);
+      Li[q * (q + 1) / 2 + r] = s / L[q * (q + 1) / 2 + q];
+    }
+    double s = 0.0;
+#pragma unroll
+    for (int r = 0; r <= q; ++r) s = fma(Li[q * (q + 1) / 2 + r], v[r], s);
+    t[q] = s;
+    tt = fma(s, s, tt);
+  }
+#pragma unroll
+  for (int q = 0; q < C; ++q) {
+    double s = 0.0;
+#pragma unroll
+    for (int u = q; u < C; ++u) s = fma(Li[u * (u + 1) / 2 + q], t[u], s);
+    beta[q] = s;
+  }
+  const double yy = syy - tt;
+  if (sub == 0 && !(sqrt(fabs(yy)) > 2.220446049250313e-16)) atomicAdd((unsigned long long*)&stat[ST_ZERO_NORM], 1ull);
+  const double isy = 1.0 / sqrt(yy);
+  for (int k = sub; k < npad; k += LPT) {
+    double p0 = 0.0;
+    if (k < n) {
+      const double w = fabs(fast_rcp(fma(delta, sLam[k], 1.0)));
+      double res = Yt[(int64_t)k * ldy + j];
+#pragma unroll
+      for (int q = 0; q < C; ++q) res = fma(-beta[q], sZ[q * n + k], res);
+      p0 = w * res * isy;
+    }
+    P0[(int64_t)k * ldp + jc] = p0;
+  }
+  if (sub == 0) {
+#pragma unroll
+    for (int e = 0; e < NA; ++e) Ls[(int64_t)e * ldp + jc] = Li[e];
+  }
+  // coefficients in the weight basis, 8 rows at a time over the lane's own individuals
+  for (int rb = 0; rb < R4; rb += 8) {
+    double c8[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) c8[u] = 0.0;
+    for (int k = sub; k < n; k += LPT) {
+      const double w = fabs(fast_rcp(fma(delta, sLam[k], 1.0)));
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (rb + u < R) c8[u] = fma(Q[(size_t)(rb + u) * n + k], w, c8[u]);
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const double c = gsum(c8[u]);
+      if (rb + u < R4 && sub == ((rb + u) % LPT)) Cp[(int64_t)(rb + u) * ldp + jc] = c;
+    }
   }
 }
 
@@ -921,50 +1097,6 @@ __global__ void __launch_bounds__(256) k_lr_classify(int n, int64_t m, double to
   }
 }
 
-// den0_i = Sxx - |L0^-1 s|^2 of marker i in the unweighted model: Sxx = sum_k x_ik^2, s_q = sum_k x_ik z_qk, Z0'Z0 = L0 L0'
-template <int C>
-__global__ void __launch_bounds__(256) k_lr_den0(int n, const double* __restrict__ Xt, int64_t ldx, int64_t p,
-                                                  const double* __restrict__ Z0, double* __restrict__ den0) {
-  constexpr int NA = C * (C + 1) / 2;
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= ldx) return;
-  if (i >= p) { den0[i] = 1.0; return; }
-  double A[NA], s[C], sxx = 0.0;
-#pragma unroll
-  for (int a = 0; a < NA; ++a) A[a] = 0.0;
-#pragma unroll
-  for (int q = 0; q < C; ++q) s[q] = 0.0;
-  for (int k = 0; k < n; ++k) {
-    const double x = Xt[(int64_t)k * ldx + i];
-    sxx = fma(x, x, sxx);
-#pragma unroll
-    for (int q = 0; q < C; ++q) {
-      const double zq = Z0[q * n + k];             // same address in every lane: a broadcast load
-      s[q] = fma(x, zq, s[q]);
-#pragma unroll
-      for (int r = 0; r <= q; ++r) A[q * (q + 1) / 2 + r] = fma(zq, Z0[r * n + k], A[q * (q + 1) / 2 + r]);
-    }
-  }
-  double L[NA], xx = sxx;
-#pragma unroll
-  for (int q = 0; q < C; ++q) {
-#pragma unroll
-    for (int r = 0; r <= q; ++r) {
-      double v = A[q * (q + 1) / 2 + r];
-#pragma unroll
-      for (int u = 0; u < r; ++u) v = fma(-L[q * (q + 1) / 2 + u], L[r * (r + 1) / 2 + u], v);
-      L[q * (q + 1) / 2 + r] = (r == q) ? sqrt(v) : v / L[r * (r + 1) / 2 + r];
-    }
-    double u = s[q];                               // forward substitution: u_q = (L0^-1 s)_q
-#pragma unroll
-    for (int r = 0; r < q; ++r) u = fma(-L[q * (q + 1) / 2 + r], s[r], u);
-    u /= L[q * (q + 1) / 2 + q];
-    s[q] = u;
-    xx = fma(-u, u, xx);
-  }
-  den0[i] = xx;
-}
-
 int launch_lr_classify(blmm_ctx* ctx, int n, int64_t m, double tol, const double* lam, const double* h2, const int* fin,
                        const int* list, const unsigned int* list_cnt, int* perm, const LrRegion& rg) {
   if (m > 0x7ffffff0LL) return fail(ctx, BLMM_ERR_INVALID, "too many traits for one launch");
@@ -975,25 +1107,29 @@ int launch_lr_classify(blmm_ctx* ctx, int n, int64_t m, double tol, const double
   return BLMM_OK;
 }
 
-int launch_lr_den0(blmm_ctx* ctx, int n, int c, const double* Xt, int64_t ldx, int64_t p, const double* Z0, double* den0) {
-  const unsigned blocks = (unsigned)((ldx + 255) / 256);
-#define D0(C) hipLaunchKernelGGL(k_lr_den0<C>, dim3(blocks), dim3(256), 0, ctx->stream, n, Xt, ldx, p, Z0, den0)
-  switch (c) {
-    case 1: D0(1); break;
-    case 2: D0(2); break;
-    case 3: D0(3); break;
-    default: return fail(ctx, BLMM_ERR_UNSUPPORTED, "number of null covariates (incl. intercept) must be 1..3 in the low-rank form");
-  }
-#undef D0
-  KCHECK();
-  return BLMM_OK;
-}
-
 int launch_lr_panels(blmm_ctx* ctx, const NullModel& nm, const double* Yt, int64_t ldy, int64_t m, const double* Z0,
                      const double* lam, const double* h2, const double* Q, const int* rk, const int* perm, const LrRegion& rg,
                      double* P0, double* Cp, double* Ls, int64_t ldp, int64_t* stat) {
   // basis rows in LDS up to 56 KB, staged by every block: 64 threads per block give more blocks than CUs at m ~ 35k, 128
   // halve the staging per trait (BLMM_LR_PANELS_NT: A/B testing)
+  static const char* wide_env = getenv("BLMM_LR_PANELS_WIDE");   // "0": one thread per trait at every n (A/B testing)
+  if (nm.n > 160 && !(wide_env && wide_env[0] == '0')) {
+    constexpr int LPT = 16;
+    const unsigned wblocks = (unsigned)((rg.ncol + (256 / LPT) - 1) / (256 / LPT));
+    const size_t wlds = sizeof(double) * (size_t)nm.n * (1 + nm.c);
+#define LPW(C) do { if (wlds > 48 * 1024) BLMM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_lr_panels_w<C, LPT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)wlds)); \
+    hipLaunchKernelGGL((k_lr_panels_w<C, LPT>), dim3(wblocks), dim3(256), wlds, ctx->stream, nm, Yt, ldy, m, Z0, lam, h2, Q, rk, perm, rg.col0, rg.ncol, P0, Cp, Ls, ldp, stat); } while (0)
+    switch (nm.c) {
+      case 1: LPW(1); break;
+      case 2: LPW(2); break;
+      case 3: LPW(3); break;
+      case 4: LPW(4); break;
+      default: return fail(ctx, BLMM_ERR_UNSUPPORTED, "number of null covariates (incl. intercept) must be 1..4");
+    }
+#undef LPW
+    KCHECK();
+    return BLMM_OK;
+  }
   static const int nt_env = getenv("BLMM_LR_PANELS_NT") ? atoi(getenv("BLMM_LR_PANELS_NT")) : 0;
   const int nthr = (nt_env == 64 || nt_env == 128 || nt_env == 256) ? nt_env : 64;
   const unsigned blocks = (unsigned)((rg.ncol + nthr - 1) / nthr);

@@ -32,11 +32,17 @@ for tag, kern in KERN.items():
     if not st:
         continue
     shutil.copy(st[0], os.path.join(prof, f"r02_kernel_stats_{tag}.csv"))
-    row = next((r for r in csv.DictReader(open(st[0])) if kern in r["Name"]), None)
+    rows = list(csv.DictReader(open(st[0])))
+    row = next((r for r in rows if kern in r["Name"]), None)
+    # launches of the kernel per library call: the null-exact scan runs once per panel region (two when the h2 search is
+    # split); k_design runs once per call.  Durations and counters below are PER CALL (sums over the launches of a call).
+    ncall = next((int(r["Calls"]) for r in rows if "k_design" in r["Name"]), 0)
+    per_call = (int(row["Calls"]) / ncall) if (row and ncall) else 1.0
     s = {"kernel": row["Name"].split("(")[0] if row else kern, "bench_args": ARGS[tag],
-         "rocprof_avg_ms": float(row["AverageNs"]) / 1e6 if row else None, "calls": int(row["Calls"]) if row else 0}
+         "rocprof_avg_ms": float(row["AverageNs"]) / 1e6 * per_call if row else None, "calls": int(row["Calls"]) if row else 0,
+         "launches_per_call": per_call}
     for c in ("FETCH_SIZE", "WRITE_SIZE", "SQ_WAVE_CYCLES"):
-        s.update({k: v for k, v in counter_avgs(os.path.join(out, tag, "pmc_" + c), kern).items()})
+        s.update({k: v * per_call for k, v in counter_avgs(os.path.join(out, tag, "pmc_" + c), kern).items()})
     if "FETCH_SIZE" in s and "WRITE_SIZE" in s:   # rocprofv3 reports KB; FETCH_SIZE counts half of wide coalesced reads on gfx950
         s["hbm_fetch_bytes"] = s["FETCH_SIZE"] * 1024 * 2
         s["hbm_write_bytes"] = s["WRITE_SIZE"] * 1024

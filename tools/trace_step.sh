@@ -13,7 +13,9 @@ rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 idx = [i for i, r in enumerate(rows) if "k_design" in r["Kernel_Name"]]
 i0 = idx[-2] if len(idx) > 1 else idx[-1]
 t0 = int(rows[i0]["Start_Timestamp"])
-for r in rows[i0:i0 + 26]:
-    name = r["Kernel_Name"].split("(")[0][:60]
+i1 = idx[-1] if len(idx) > 1 else len(rows)
+for r in rows[i0:i1]:
+    if int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) < 9000: continue      # < 9 us: not shown
+    name = r["Kernel_Name"].replace("(anonymous namespace)::", "").split("(")[0][:60]
     print(f'{(int(r["Start_Timestamp"]) - t0) / 1e3:9.1f} {(int(r["End_Timestamp"]) - t0) / 1e3:9.1f} us  q{r.get("Queue_Id", "?")} {name}')
 PY
