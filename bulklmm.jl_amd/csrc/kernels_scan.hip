@@ -24,6 +24,7 @@
 // L2/L1 (a 64-cycle f64 MFMA leaves the operand traffic at a few bytes/clk/CU).
 #include "blmm_internal.h"
 #include "fastmath.h"
+#include <type_traits>
 #include <cmath>
 #include <cstdlib>
 
@@ -427,55 +428,63 @@ __global__ void __launch_bounds__(256, 2) k_scan_lr(LrArgs la, int ntile_i, int6
   __syncthreads();
   const LodPoly lp = make_lod_poly(-0.5 * (double)a.n);
   const int64_t ibase = i0 + NB * r;
-  if (shared_w) {   // Sxx - |u|^2 = den0_i for every trait of the tile (the s_q accumulators stay zero)
-    double dn[NB];
-    loadv<NB>(dn, la.den0 + ibase);
+  int nnan = 0;
+  // Two instances of the epilogue behind one workgroup-uniform branch.  A shared-weights tile multiplies by the per-marker
+  // 1 / (Sxx - |u|^2) of the unweighted model (left by k_lr_tpanels): no L_j^-1, no reciprocal -- the epilogue is fp64
+  // VALU time the matrix pipe cannot overlap, and these tiles pay it in full for 5/8 of the matrix work.
+  auto epilogue = [&](auto SH) {
+    constexpr bool SHW = decltype(SH)::value;
+    double rd[NB];
+    if constexpr (SHW) loadv<NB>(rd, la.den0 + ibase);
 #pragma unroll
     for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
-      for (int nb = 0; nb < NB; ++nb) acc[1][mb][nb] = (d4){dn[nb], dn[nb], dn[nb], dn[nb]};
-  }
-  int nnan = 0;
+      for (int reg = 0; reg < 4; ++reg) {
+        const int64_t trait = s_perm[wt * (16 * MB) + MB * (kk + 4 * reg) + mb];
+        if (trait < 0) continue;
+        double li[NL];
+        if constexpr (!SHW) {
 #pragma unroll
-  for (int mb = 0; mb < MB; ++mb)
-#pragma unroll
-    for (int reg = 0; reg < 4; ++reg) {
-      const int64_t trait = s_perm[wt * (16 * MB) + MB * (kk + 4 * reg) + mb];
-      if (trait < 0) continue;
-      double li[NL];
-#pragma unroll
-      for (int e = 0; e < NL; ++e) li[e] = s_li[e][wt * (16 * MB) + MB * (kk + 4 * reg) + mb];
-      double out[NB];
-#pragma unroll
-      for (int nb = 0; nb < NB; ++nb) {
-        const double num = acc[0][mb][nb][reg];
-        double xx = acc[1][mb][nb][reg];
-#pragma unroll
-        for (int q = 0; q < C; ++q) {
-          double u = 0.0;
-#pragma unroll
-          for (int e = 0; e <= q; ++e) u = fma(li[q * (q + 1) / 2 + e], acc[2 + e][mb][nb][reg], u);
-          xx = fma(-u, u, xx);
+          for (int e = 0; e < NL; ++e) li[e] = s_li[e][wt * (16 * MB) + MB * (kk + 4 * reg) + mb];
         }
-        const double r2 = (num * num) * fast_rcp(xx);
-        const double u1 = 1.0 - r2;  // r2lod (src/bulkscan_helpers.jl:22-24): -(n/2) * log10(1.0 - r^2)
-        double lod = fast_lod(u1, s_log, lp);
-        if (__builtin_expect(!(u1 > 0.0), 0)) {
-          lod = (u1 == 0.0) ? INFINITY : NAN;
-          nnan += (u1 != 0.0) && (ibase + nb < a.p);
-        }
-        out[nb] = lod;
-      }
-      double* dst = a.L + trait * a.ldL + ibase;
-      if (ibase + NB <= a.p) {
-        __builtin_nontemporal_store((d2u){out[0], out[1]}, reinterpret_cast<d2u*>(dst));
-        __builtin_nontemporal_store((d2u){out[2], out[3]}, reinterpret_cast<d2u*>(dst + 2));
-      } else {
+        double out[NB];
 #pragma unroll
-        for (int nb = 0; nb < NB; ++nb)
-          if (ibase + nb < a.p) dst[nb] = out[nb];
+        for (int nb = 0; nb < NB; ++nb) {
+          const double num = acc[0][mb][nb][reg];
+          double r2;
+          if constexpr (SHW) {
+            r2 = (num * num) * rd[nb];
+          } else {
+            double xx = acc[1][mb][nb][reg];
+#pragma unroll
+            for (int q = 0; q < C; ++q) {
+              double u = 0.0;
+#pragma unroll
+              for (int e = 0; e <= q; ++e) u = fma(li[q * (q + 1) / 2 + e], acc[2 + e][mb][nb][reg], u);
+              xx = fma(-u, u, xx);
+            }
+            r2 = (num * num) * fast_rcp(xx);
+          }
+          const double u1 = 1.0 - r2;  // r2lod (src/bulkscan_helpers.jl:22-24): -(n/2) * log10(1.0 - r^2)
+          double lod = fast_lod(u1, s_log, lp);
+          if (__builtin_expect(!(u1 > 0.0), 0)) {
+            lod = (u1 == 0.0) ? INFINITY : NAN;
+            nnan += (u1 != 0.0) && (ibase + nb < a.p);
+          }
+          out[nb] = lod;
+        }
+        double* dst = a.L + trait * a.ldL + ibase;
+        if (ibase + NB <= a.p) {
+          __builtin_nontemporal_store((d2u){out[0], out[1]}, reinterpret_cast<d2u*>(dst));
+          __builtin_nontemporal_store((d2u){out[2], out[3]}, reinterpret_cast<d2u*>(dst + 2));
+        } else {
+#pragma unroll
+          for (int nb = 0; nb < NB; ++nb)
+            if (ibase + nb < a.p) dst[nb] = out[nb];
+        }
       }
-    }
+  };
+  if (shared_w) epilogue(std::true_type{}); else epilogue(std::false_type{});
   if (nnan) atomicAdd((unsigned long long*)&a.stat[ST_NAN_LOD], (unsigned long long)nnan);
 #ifdef LR_DIAG
   if (threadIdx.x == 0) {
