@@ -838,7 +838,10 @@ __global__ void __launch_bounds__(256) k_rotate_vec(const double* __restrict__ R
 // Block order: an XCD (blockIdx % 8) walks whole column tiles, all k tiles of one after the other, so In is fetched from
 // HBM once and re-read from that XCD's L2.
 typedef double d2ua __attribute__((ext_vector_type(2), aligned(8)));
-template <int NB, bool PREF>
+// TR: consecutive rows a lane reads of its column per trip (a trip = 4 TR rows).  TR = 8: 64-byte pieces, the next trip's
+// B fragments fetched after the trip's MFMAs (2 waves per SIMD cover each other).  TR = 4: 32-byte pieces, half the fragment
+// registers -- room to prefetch the next trip's fragments under the current trip's 64 MFMAs at NB = 4.
+template <int NB, bool PREF, int TR = 8>
 __global__ void __launch_bounds__(256, 2) k_rotate_big(const double* __restrict__ Rp, int ldr, int n, int npad,
                                                        const double* __restrict__ In, int64_t ncols,
                                                        double* __restrict__ Out, int64_t ldo, int64_t ncols_pad, int nkt,
@@ -867,16 +870,16 @@ __global__ void __launch_bounds__(256, 2) k_rotate_big(const double* __restrict_
     cok[b] = col < ncols;
     pcol[b] = In + (cok[b] ? col : 0) * (int64_t)n;
   }
-  auto loadB = [&](double (&bv)[NB][8], int i0) {
+  auto loadB = [&](double (&bv)[NB][TR], int i0) {
 #pragma unroll
     for (int b = 0; b < NB; ++b) {
-      const int ib = i0 + 8 * gq;
-      if (cok[b] && ib + 8 <= n) {
+      const int ib = i0 + TR * gq;
+      if (cok[b] && ib + TR <= n) {
 #pragma unroll
-        for (int h = 0; h < 4; ++h) { const d2ua v = *reinterpret_cast<const d2ua*>(pcol[b] + ib + 2 * h); bv[b][2 * h] = v[0]; bv[b][2 * h + 1] = v[1]; }
+        for (int h = 0; h < TR / 2; ++h) { const d2ua v = *reinterpret_cast<const d2ua*>(pcol[b] + ib + 2 * h); bv[b][2 * h] = v[0]; bv[b][2 * h + 1] = v[1]; }
       } else {
 #pragma unroll
-        for (int s = 0; s < 8; ++s) bv[b][s] = (cok[b] && ib + s < n) ? pcol[b][ib + s] : 0.0;
+        for (int s = 0; s < TR; ++s) bv[b][s] = (cok[b] && ib + s < n) ? pcol[b][ib + s] : 0.0;
       }
     }
   };
@@ -885,36 +888,86 @@ __global__ void __launch_bounds__(256, 2) k_rotate_big(const double* __restrict_
 #pragma unroll
     for (int a = 0; a < MB; ++a) { const int k = k0 + 16 * a; av[a] = (i < npad && k + c16 < ldr) ? pr[k] : 0.0; }
   };
-  double bcur[NB][8], bnext[PREF ? NB : 1][8];
-  loadB(bcur, 0);
-  for (int i0 = 0; i0 < n; i0 += 32) {
-    if constexpr (PREF) { if (i0 + 32 < n) loadB(bnext, i0 + 32); }
-    double a0[MB], a1[MB];
-    loadA(a0, i0 + 8 * gq);
+  // Full trips (i0 + 32 <= n) load through buffer descriptors with real bounds: a fragment of Rp beyond its npad rows and
+  // a column of In beyond ncols read as zero without a branch, the per-lane part of every address is one 32-bit offset
+  // fixed for the whole loop and the trip enters through the scalar offset.  (The guarded loads above cost ~270 scalar /
+  // vector instructions per 128 MFMAs, 43 of them exec-mask branches: the matrix pipe was busy 70 % of the time.)  The
+  // last, partial trip keeps the guarded loads -- a row beyond n of a column must not read the next column's values.
+  typedef unsigned int u32x4r __attribute__((ext_vector_type(4)));
+  typedef unsigned int u32x2r __attribute__((ext_vector_type(2)));
+  const uint64_t bytesA = (uint64_t)npad * (uint64_t)ldr * 8u, bytesB = (uint64_t)ncols * (uint64_t)n * 8u;
+  const bool fast = bytesA < 0xffffff00ull && bytesB < 0xffffff00ull;
+  const __amdgpu_buffer_rsrc_t srdA = __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(Rp), 0, (unsigned)(fast ? bytesA : 0), 0x00020000);
+  const __amdgpu_buffer_rsrc_t srdB = __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(In), 0, (unsigned)(fast ? bytesB : 0), 0x00020000);
+  // (the scalar offset is not part of the hardware's range check: nothing below relies on it for an out-of-range access.
+  // Rows of Rp stay below npad in a full trip; a column index beyond ldr -- rows of Out beyond npad, never stored -- is clamped)
+  uint32_t voffA[MB];
 #pragma unroll
-    for (int s = 0; s < 8; s += 2) {
-      loadA(a1, i0 + 8 * gq + s + 1);
+  for (int a = 0; a < MB; ++a) {
+    const int kc = k0 + 16 * a + c16;
+    voffA[a] = (uint32_t)((((int64_t)TR * gq) * ldr + (kc < ldr ? kc : ldr - 1)) * 8);
+  }
+  uint32_t voffB[NB];
+#pragma unroll
+  for (int b = 0; b < NB; ++b) {
+    const int64_t col = col0 + 16 * b + c16;
+    // a column beyond ncols: an offset past the end of the buffer (reads as zero); clamped so that it stays in 32 bits
+    voffB[b] = (col < ncols) ? (uint32_t)((col * (int64_t)n + TR * gq) * 8) : 0xffffff00u;
+  }
+  auto loadB_fast = [&](double (&bv)[NB][TR], int i0) {
+#pragma unroll
+    for (int b = 0; b < NB; ++b)
+#pragma unroll
+      for (int h = 0; h < TR / 2; ++h) {
+        const u32x4r v = __builtin_amdgcn_raw_buffer_load_b128(srdB, voffB[b] + 16 * h, (unsigned)i0 * 8u, 0);
+        const d2 w = __builtin_bit_cast(d2, v);
+        bv[b][2 * h] = w[0]; bv[b][2 * h + 1] = w[1];
+      }
+  };
+  auto loadA_fast = [&](double (&av)[MB], int irow) {   // irow: the trip's row i0 + s (wave-uniform); the lane adds TR gq rows
+#pragma unroll
+    for (int a = 0; a < MB; ++a) {
+      const u32x2r v = __builtin_amdgcn_raw_buffer_load_b64(srdA, voffA[a], (unsigned)irow * (unsigned)ldr * 8u, 0);
+      av[a] = __builtin_bit_cast(double, v);
+    }
+  };
+  constexpr int TRIP = 4 * TR;
+  double bcur[NB][TR], bnext[PREF ? NB : 1][TR];
+  const int nfull = fast ? (n / TRIP) * TRIP : 0;    // rows covered by full trips
+  // one trip of 32 rows: FT = a full trip through the descriptors; the B fragments of the trip are in bcur
+  auto trip = [&](auto FTc, int i0) {
+    constexpr bool FT = decltype(FTc)::value;
+    if constexpr (PREF) { if (i0 + TRIP < n) { if (i0 + TRIP < nfull) loadB_fast(bnext, i0 + TRIP); else loadB(bnext, i0 + TRIP); } }
+    double a0[MB], a1[MB];
+    if constexpr (FT) loadA_fast(a0, i0); else loadA(a0, i0 + TR * gq);
+#pragma unroll
+    for (int s = 0; s < TR; s += 2) {
+      if constexpr (FT) loadA_fast(a1, i0 + s + 1); else loadA(a1, i0 + TR * gq + s + 1);
 #pragma unroll
       for (int a = 0; a < MB; ++a)
 #pragma unroll
         for (int b = 0; b < NB; ++b) acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[a], bcur[b][s], acc[a][b], 0, 0, 0);
-      if (s + 2 < 8) loadA(a0, i0 + 8 * gq + s + 2);
+      if (s + 2 < TR) { if constexpr (FT) loadA_fast(a0, i0 + s + 2); else loadA(a0, i0 + TR * gq + s + 2); }
 #pragma unroll
       for (int a = 0; a < MB; ++a)
 #pragma unroll
         for (int b = 0; b < NB; ++b) acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[a], bcur[b][s + 1], acc[a][b], 0, 0, 0);
     }
-    if (i0 + 32 < n) {
+    if (i0 + TRIP < n) {
       if constexpr (PREF) {
 #pragma unroll
         for (int b = 0; b < NB; ++b)
 #pragma unroll
-          for (int s = 0; s < 8; ++s) bcur[b][s] = bnext[b][s];
+          for (int s = 0; s < TR; ++s) bcur[b][s] = bnext[b][s];
       } else {
-        loadB(bcur, i0 + 32);
+        if (i0 + TRIP < nfull) loadB_fast(bcur, i0 + TRIP); else loadB(bcur, i0 + TRIP);
       }
     }
-  }
+  };
+  if (nfull > 0) loadB_fast(bcur, 0); else loadB(bcur, 0);
+  int i0 = 0;
+  for (; i0 < nfull; i0 += TRIP) trip(std::true_type{}, i0);
+  for (; i0 < n; i0 += TRIP) trip(std::false_type{}, i0);
 #pragma unroll
   for (int a = 0; a < MB; ++a)
 #pragma unroll
@@ -940,12 +993,17 @@ int launch_rotate(blmm_ctx* ctx, const double* Rp, int ldr, int n, int npad, con
   }
   if (n > 160 && ncols >= 64 && !(getenv("BLMM_ROTATE") && std::strcmp(getenv("BLMM_ROTATE"), "small") == 0)) {
     const int nkt = (npad + 127) / 128;
-    const char* rv = getenv("BLMM_ROTATE_TILE");   // "64": 128 x 64 tiles with the B fragments prefetched (A/B timing)
+    // BLMM_ROTATE_TILE (A/B timing): "64": 128 x 64 tiles with the B fragments prefetched; "128p": 128 x 128 tiles, 32-byte
+    // pieces, the next trip's B fragments prefetched
+    const char* rv = getenv("BLMM_ROTATE_TILE");
     const bool wide = !(rv && std::strcmp(rv, "64") == 0);
+    const bool pref4 = rv && std::strcmp(rv, "128p") == 0;
     const int64_t nct = (ncols_pad + (wide ? 127 : 63)) / (wide ? 128 : 64);
     const int64_t nblk = ((nct + 7) / 8) * 8 * nkt;           // every XCD walks ceil(nct / 8) column tiles
     if (nblk <= 0x7fffffffLL) {
-      if (wide) hipLaunchKernelGGL((k_rotate_big<4, false>), dim3((unsigned)nblk), dim3(256), 0, ctx->stream, Rp, ldr, n, npad, In, ncols, Out, ldo,
+      if (wide && pref4) hipLaunchKernelGGL((k_rotate_big<4, true, 4>), dim3((unsigned)nblk), dim3(256), 0, ctx->stream, Rp, ldr, n, npad, In, ncols,
+                                            Out, ldo, ncols_pad, nkt, nct);
+      else if (wide) hipLaunchKernelGGL((k_rotate_big<4, false>), dim3((unsigned)nblk), dim3(256), 0, ctx->stream, Rp, ldr, n, npad, In, ncols, Out, ldo,
                                    ncols_pad, nkt, nct);
       else hipLaunchKernelGGL((k_rotate_big<2, true>), dim3((unsigned)nblk), dim3(256), 0, ctx->stream, Rp, ldr, n, npad, In, ncols, Out, ldo,
                          ncols_pad, nkt, nct);
