@@ -103,7 +103,19 @@ def main():
             env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(a.gpus), LOCAL_WORLD_SIZE=str(a.gpus),
                        MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
             procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
-        raise SystemExit(max(p.wait() for p in procs))
+        rc = 0
+        while procs:          # a rank that dies (e.g. fewer GPUs than ranks) must not leave the others waiting at the rendezvous
+            time.sleep(0.2)
+            for pr in list(procs):
+                r = pr.poll()
+                if r is None:
+                    continue
+                procs.remove(pr)
+                if r != 0:
+                    rc = rc or r
+                    for other in procs:
+                        other.terminate()          # exactly the children started above
+        raise SystemExit(rc)
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -140,6 +152,9 @@ def main():
     # devices, the collectives go through host tensors, the all-gather is skipped); the measured path is always nccl.
     backend = os.environ.get("BLMM_BENCH_BACKEND", "nccl")
     dev_index = local_rank if backend == "nccl" else local_rank % max(torch.cuda.device_count(), 1)
+    if dev_index >= torch.cuda.device_count():
+        raise SystemExit("bench.py: rank %d needs GPU %d but only %d are visible (one rank per GPU; BLMM_BENCH_BACKEND=gloo rehearses "
+                         "the control flow with ranks sharing devices)" % (rank, dev_index, torch.cuda.device_count()))
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
     if world > 1:
