@@ -726,8 +726,9 @@ __global__ void __launch_bounds__(256) k_lr_panels(NullModel nm, const double* _
   }
 }
 
-// The same panels for larger n (> 160), LPT lanes per trait: at n = 500 a shard has a few thousand traits, and one thread
-// walking a trait's n individuals (twice, plus R dot products of length n) left the GPU at a handful of waves for 0.4 ms.
+// The same panels with LPT lanes per trait (the default): one thread walking a trait's n individuals (twice, plus R dot
+// products of length n) is a long dependent chain on few waves -- 0.4 ms at n = 500 with a few thousand traits per shard,
+// 86 us on the critical path at the BXD shape.
 // Lane `sub` of a trait's group owns the individuals k = sub, sub + LPT, ...; sums are butterflied over the group, the
 // small per-trait algebra is done redundantly by every lane.  Basis rows come from L2 (every group of a workgroup reads
 // the same addresses, consecutive lanes consecutive k).
@@ -1112,8 +1113,10 @@ int launch_lr_panels(blmm_ctx* ctx, const NullModel& nm, const double* Yt, int64
                      double* P0, double* Cp, double* Ls, int64_t ldp, int64_t* stat) {
   // basis rows in LDS up to 56 KB, staged by every block: 64 threads per block give more blocks than CUs at m ~ 35k, 128
   // halve the staging per trait (BLMM_LR_PANELS_NT: A/B testing)
-  static const char* wide_env = getenv("BLMM_LR_PANELS_WIDE");   // "0": one thread per trait at every n (A/B testing)
-  if (nm.n > 160 && !(wide_env && wide_env[0] == '0')) {
+  // 16 lanes per trait at every n (BXD shape: prep 0.143 -> 0.122 ms, step -2.7 %; n = 500 shard: 0.42 -> 0.23 ms for the
+  // kernel); BLMM_LR_PANELS_WIDE=0: one thread per trait (A/B testing)
+  static const char* wide_env = getenv("BLMM_LR_PANELS_WIDE");
+  if (!(wide_env && wide_env[0] == '0')) {
     constexpr int LPT = 16;
     const unsigned wblocks = (unsigned)((rg.ncol + (256 / LPT) - 1) / (256 / LPT));
     const size_t wlds = sizeof(double) * (size_t)nm.n * (1 + nm.c);
