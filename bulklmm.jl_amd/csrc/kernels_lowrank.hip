@@ -181,6 +181,7 @@ __global__ void __launch_bounds__(1024) k_wbasis_reg(const double* __restrict__ 
   __shared__ double s_red[NS];
   __shared__ int s_arg[NS];
   __shared__ int s_neg;
+  __shared__ double s_piv_val;
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6, nwave = NT >> 6;
   const int s = t / TPS, part = t % TPS;
   if (t == 0) s_neg = 0;
@@ -209,15 +210,26 @@ __global__ void __launch_bounds__(1024) k_wbasis_reg(const double* __restrict__ 
   const double tol2 = 2e-31 * (double)n;
   int R = 0;
   for (; R < n; ++R) {
-    if (part == 0) { s_red[s] = res2; s_arg[s] = s; }
+    if (part == 0) s_red[s] = res2;
     __syncthreads();
-    for (int o = NS / 2; o > 0; o >>= 1) {     // arg-max of the residual norms (first maximum wins)
-      if (t < o && (s_red[t + o] > s_red[t] || (s_red[t + o] == s_red[t] && s_arg[t + o] < s_arg[t]))) { s_red[t] = s_red[t + o]; s_arg[t] = s_arg[t + o]; }
-      __syncthreads();
+    // arg-max of the residual norms, first maximum wins: one wave, lane l owns the samples 4l .. 4l+3, so the first maximum
+    // is the first lane holding the wave's maximum (a tree over LDS cost eight workgroup barriers per basis vector)
+    if (wave == 0) {
+      double bv = s_red[4 * lane];
+      int bi = 4 * lane;
+#pragma unroll
+      for (int u = 1; u < 4; ++u) { const double v = s_red[4 * lane + u]; if (v > bv) { bv = v; bi = 4 * lane + u; } }
+      double wm = bv;
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) wm = fmax(wm, __shfl_xor(wm, o, 64));
+      const unsigned long long who = __ballot(bv == wm);
+      const int first = who ? __ffsll((long long)who) - 1 : 0;      // who == 0: NaN residuals, the loop ends below
+      const int pi = __shfl(bi, first, 64);
+      if (lane == 0) { s_arg[0] = pi; s_piv_val = wm; }
     }
-    const double mx = s_red[0];
-    const int piv = s_arg[0];
     __syncthreads();
+    const double mx = s_piv_val;
+    const int piv = s_arg[0];
     if (!(mx > tol2)) break;
     if (s == piv) {
 #pragma unroll
