@@ -448,7 +448,23 @@ LrArgs lr_args(blmm_ctx* ctx, const Pipe& P, const LrRegion& rg, double* dL, int
   la.s = scan_args(ctx, P, ptr<double>(ctx->panels), ldp, dL, ldL, P.m + 192 < rg.ncol ? P.m + 192 : rg.ncol);
   la.Cp = ptr<double>(ctx->lrC); la.T = ptr<double>(ctx->lrT); la.tstride = (int64_t)P.npad * P.ldx; la.Ls = ptr<double>(ctx->lrL);
   la.rk = ptr<int>(ctx->wbRk); la.c = P.c; la.perm = ptr<int>(ctx->lrPerm); la.rg = rg; la.den0 = ptr<double>(ctx->lrDen0);
+  la.skip_shared = 0;
   return la;
+}
+// LOD scan of one region on the current stream: the shared-weights class through the table kernel (one bin, 4 waves per
+// SIMD), the other traits through k_scan_lr.  BLMM_LR_LEAN=0: both classes in k_scan_lr (A/B testing).
+int lr_region_scan(blmm_ctx* ctx, const Pipe& P, const LrRegion& rg, double* dL, int64_t ldL) {
+  static const bool lean = !(getenv("BLMM_LR_LEAN") && getenv("BLMM_LR_LEAN")[0] == '0');
+  LrArgs la = lr_args(ctx, P, rg, dL, ldL);
+  int rc;
+  if (lean) {
+    ScanArgs a = la.s;
+    a.isx = la.den0; a.ld_isx = P.ldx; a.bin = nullptr;
+    a.perm = la.perm; a.col0 = rg.col0; a.count = rg.counts;
+    if ((rc = launch_scan_shared(ctx, a))) return rc;
+    la.skip_shared = 1;
+  }
+  return launch_scan_lr(ctx, la);
 }
 // panels of one region on the current stream
 int lr_region_panels(blmm_ctx* ctx, const Pipe& P, const NullModel& nm, const double* dh2, const LrRegion& rg) {
@@ -483,7 +499,7 @@ int lr_finish(blmm_ctx* ctx, const Pipe& P, const NullModel& nm, const double* d
   ctx->stream = main_stream;
   if (rc) return rc;
   BLMM_HIP(hipEventRecord(ctx->ev_join, ctx->side));
-  if ((rc = launch_scan_lr(ctx, lr_args(ctx, P, rg, dL, ldL)))) return rc;
+  if ((rc = lr_region_scan(ctx, P, rg, dL, ldL))) return rc;
   BLMM_HIP(hipStreamWaitEvent(main_stream, ctx->ev_join, 0));
   if ((rc = lr_fix(ctx, P, nm, dh2, dL, ldL))) return rc;
   tm.mark();
@@ -525,7 +541,7 @@ int lr_finish_split(blmm_ctx* ctx, const Pipe& P, const NullModel& nm, double* d
   rc = lr_region_resid(ctx, P, nm, dh2, r0);
   ctx->stream = main_stream;
   if (rc) return rc;
-  if ((rc = launch_scan_lr(ctx, lr_args(ctx, P, r0, dL, ldL)))) return rc;
+  if ((rc = lr_region_scan(ctx, P, r0, dL, ldL))) return rc;
   // ---- region 1: its guard on the first side stream (behind region 0's), its scan on the main stream
   BLMM_HIP(hipStreamWaitEvent(ctx->side, ctx->ev_b2, 0));
   ctx->stream = ctx->side;
@@ -534,7 +550,7 @@ int lr_finish_split(blmm_ctx* ctx, const Pipe& P, const NullModel& nm, double* d
   if (rc) return rc;
   BLMM_HIP(hipEventRecord(ctx->ev_join, ctx->side));
   BLMM_HIP(hipStreamWaitEvent(main_stream, ctx->ev_b2, 0));
-  if ((rc = launch_scan_lr(ctx, lr_args(ctx, P, r1, dL, ldL)))) return rc;
+  if ((rc = lr_region_scan(ctx, P, r1, dL, ldL))) return rc;
   BLMM_HIP(hipStreamWaitEvent(main_stream, ctx->ev_join, 0));
   if ((rc = lr_fix(ctx, P, nm, dh2, dL, ldL))) return rc;
   tm.mark();

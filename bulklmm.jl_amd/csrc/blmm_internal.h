@@ -166,6 +166,9 @@ struct ScanArgs {
   int64_t p, m;
   double* L; int64_t ldL;
   const double* isx; int64_t ld_isx; const int* bin;  // table mode
+  // permuted-column mode of the table kernel (the shared-weights class of the low-rank form): panel column -> trait, the
+  // region's first column, and the device count of the class (columns [col0, col0 + *count))
+  const int* perm = nullptr; int64_t col0 = 0; const int64_t* count = nullptr;
   const double* logtab;                    // device copy of log_table.h
   int64_t* stat;
 };
@@ -185,7 +188,8 @@ struct LrArgs {
   const int* rk;                    // {R, KR} on the device
   const int* perm;                  // panel column -> trait (k_lr_classify; -1: padding)
   LrRegion rg;                      // the region of the panel arrays this launch scans
-  const double* den0;               // the shared-weights class's denominators, per marker
+  const double* den0;               // the shared-weights class's 1/sqrt(Sxx - |u|^2), per marker (= isx of the unweighted model)
+  int skip_shared;                  // 1: the class's tiles were scanned by launch_scan_shared
   int c;
 };
 int launch_scan_lr(blmm_ctx* ctx, const LrArgs& la);
@@ -211,6 +215,8 @@ int launch_lr_panels(blmm_ctx* ctx, const NullModel& nm, const double* Yt, int64
                      const double* lam, const double* h2, const double* Q, const int* rk, const int* perm, const LrRegion& rg,
                      double* P0, double* Cp, double* Ls, int64_t ldp, int64_t* stat);
 int launch_scan_table(blmm_ctx* ctx, const ScanArgs& a);
+// the shared-weights class of one panel region through the table kernel (isx = 1/sqrt(den0), one bin, stores through perm)
+int launch_scan_shared(blmm_ctx* ctx, const ScanArgs& a);
 struct AltArgs {
   ScanArgs s; int ngrid; const double* EllTab; /* ngrid x m */ const double* grid_dev; double* H2; int64_t ldH; int counter_quirk;
 };

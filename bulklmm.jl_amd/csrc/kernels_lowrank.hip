@@ -493,7 +493,7 @@ int launch_wbasis(blmm_ctx* ctx, const double* lam, int n, double* Wk, double* Q
 
 // T[q][r][i]: q = 0: sum_k Q[r][k] x_ik^2 ; q = 1..c: sum_k Q[r][k] x_ik z_(q-1)k.   Rows r >= R (up to 4*KR) are zero.
 // grid = (ldx/256, ceil(4*KRmax/16)); the kernel reads R from rk and returns early for chunks beyond it.
-// The first chunk also leaves den0_i = 1 / (Sxx - |L0^-1 s|^2) of the unweighted model (Sxx = sum_k x_ik^2, s_q = sum_k x_ik z_qk,
+// The first chunk also leaves den0_i = 1 / sqrt(Sxx - |L0^-1 s|^2) of the unweighted model (Sxx = sum_k x_ik^2, s_q = sum_k x_ik z_qk,
 // Z0'Z0 = L0 L0'): the denominators of the shared-weights class, from the same pass over Xt.
 template <int C>
 __global__ void __launch_bounds__(256) k_lr_tpanels(const double* __restrict__ Xt, int64_t ldx, int64_t p, int n,
@@ -566,7 +566,7 @@ __global__ void __launch_bounds__(256) k_lr_tpanels(const double* __restrict__ X
         xx = fma(-u, u, xx);
       }
     }
-    den0[i] = 1.0 / xx;          // the reciprocal: what the shared-weights epilogue multiplies by
+    den0[i] = 1.0 / sqrt(xx);    // isx of the unweighted model: what the shared-weights epilogue multiplies the numerator by
   }
 }
 

@@ -105,15 +105,33 @@ __device__ __forceinline__ void tile_of(int64_t id, int64_t ntile_t, int ntile_i
   tile_t = t_first + (rem - (int64_t)tile_i * gt);
 }
 
-template <int NX, int MB, int NB, bool TABLE, int W2>
+// PERM (table mode only): the trait tiles are the first ceil(*a.count / tile) tiles of the panel region starting at column
+// a.col0, a panel column's trait is a.perm[column] (-1: padding) -- the shared-weights class of the low-rank form, which is
+// exactly a one-bin table scan (102 VGPRs, 4 waves per SIMD, where k_scan_lr holds 2).  Every XCD takes an eighth of the items.
+template <int NX, int MB, int NB, bool TABLE, int W2, bool PERM = false>
 __global__ void __launch_bounds__(64 * W2 * W2, 2) k_scan(ScanArgs a, int ntile_i, int64_t nwg) {
   constexpr int NP = 1 + NX;  // A-side panels consumed
+  static_assert(!PERM || (TABLE && NX == 0), "permuted columns: table mode");
   __shared__ dpair s_log[BLMM_LOG_TABLE_N];
+  __shared__ int s_perm[PERM ? 16 * W2 * MB : 1];
   stage_lod_table(s_log, a.logtab, -0.5 * (double)a.n);  // read after the K loop; the barrier sits right before the epilogue
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int64_t bid = xcd_swizzle(blockIdx.x, nwg);
   int64_t tile_t; int tile_i;
-  tile_of(bid, nwg / ntile_i, ntile_i, tile_t, tile_i);
+  if constexpr (PERM) {
+    constexpr int TW = 16 * W2 * MB;
+    const int64_t q = nwg >> 3;
+    if ((int64_t)blockIdx.x >= (q << 3)) return;                 // workgroup-uniform; before any barrier
+    const int64_t x = blockIdx.x & 7, local = blockIdx.x >> 3;
+    const int64_t ns = (*a.count + TW - 1) / TW, NS = ns * ntile_i;
+    const int64_t sS = (x * NS) >> 3, cS = (((x + 1) * NS) >> 3) - sS;
+    if (local >= cS) return;
+    tile_of(sS + local, ns, ntile_i, tile_t, tile_i);
+    tile_t += a.col0 / TW;
+    if (threadIdx.x < TW) s_perm[threadIdx.x] = a.perm[tile_t * TW + threadIdx.x];
+  } else {
+    const int64_t bid = xcd_swizzle(blockIdx.x, nwg);
+    tile_of(bid, nwg / ntile_i, ntile_i, tile_t, tile_i);
+  }
   const int wt = (W2 == 2) ? (wave >> 1) : 0, wi = (W2 == 2) ? (wave & 1) : 0;
   const int64_t t0 = tile_t * (16 * W2 * MB) + wt * (16 * MB);
   const int64_t i0 = (int64_t)tile_i * (16 * W2 * NB) + wi * (16 * NB);
@@ -184,8 +202,13 @@ __global__ void __launch_bounds__(64 * W2 * W2, 2) k_scan(ScanArgs a, int ntile_
   for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
     for (int reg = 0; reg < 4; ++reg) {
-      const int64_t trait = t0 + MB * (kk + 4 * reg) + mb;
-      if (trait >= a.m) continue;
+      int64_t trait = t0 + MB * (kk + 4 * reg) + mb;
+      if constexpr (PERM) {
+        trait = s_perm[wt * (16 * MB) + MB * (kk + 4 * reg) + mb];
+        if (trait < 0) continue;
+      } else {
+        if (trait >= a.m) continue;
+      }
       // (prefetching these before the K loop costs 64 VGPRs = half the occupancy: 1.15 ms instead of 0.96 ms at BXD)
       double sc[NB];
       if constexpr (TABLE) {
@@ -303,7 +326,7 @@ __global__ void __launch_bounds__(256, 2) k_scan_lr(LrArgs la, int ntile_i, int6
     const int64_t nsh = la.rg.counts[0], noth = la.rg.counts[1];
     const int64_t tb = la.rg.col0 / TW;                          // the region's first tile (col0, ncol: multiples of 64)
     const int64_t ns = (nsh + TW - 1) / TW, fo = (la.rg.ncol - noth) / TW, nf = la.rg.ncol / TW - fo;
-    const int64_t NS = ns * ntile_i, NF = nf * ntile_i;
+    const int64_t NS = la.skip_shared ? 0 : ns * ntile_i, NF = nf * ntile_i;
     const int64_t sS = (x * NS) >> 3, cS = (((x + 1) * NS) >> 3) - sS, sF = (x * NF) >> 3, cF = (((x + 1) * NF) >> 3) - sF;
     if (local < cS) {
       shared_w = true;
@@ -430,8 +453,9 @@ __global__ void __launch_bounds__(256, 2) k_scan_lr(LrArgs la, int ntile_i, int6
   const int64_t ibase = i0 + NB * r;
   int nnan = 0;
   // Two instances of the epilogue behind one workgroup-uniform branch.  A shared-weights tile multiplies by the per-marker
-  // 1 / (Sxx - |u|^2) of the unweighted model (left by k_lr_tpanels): no L_j^-1, no reciprocal -- the epilogue is fp64
-  // VALU time the matrix pipe cannot overlap, and these tiles pay it in full for 5/8 of the matrix work.
+  // 1 / sqrt(Sxx - |u|^2) of the unweighted model (left by k_lr_tpanels): no L_j^-1, no reciprocal -- the epilogue is fp64
+  // VALU time the matrix pipe cannot overlap.  (By default these tiles go through the leaner table kernel instead:
+  // launch_scan_shared; this path serves BLMM_LR_LEAN=0.)
   auto epilogue = [&](auto SH) {
     constexpr bool SHW = decltype(SH)::value;
     double rd[NB];
@@ -453,7 +477,8 @@ __global__ void __launch_bounds__(256, 2) k_scan_lr(LrArgs la, int ntile_i, int6
           const double num = acc[0][mb][nb][reg];
           double r2;
           if constexpr (SHW) {
-            r2 = (num * num) * rd[nb];
+            const double rr = num * rd[nb];
+            r2 = rr * rr;
           } else {
             double xx = acc[1][mb][nb][reg];
 #pragma unroll
@@ -536,6 +561,18 @@ int launch_scan_lr(blmm_ctx* ctx, const LrArgs& la) {
     case 3: return launch_scan_lr_t<3, 1>(ctx, la);
   }
   return fail(ctx, BLMM_ERR_UNSUPPORTED, "number of null covariates (incl. intercept) must be 1..4");
+}
+
+int launch_scan_shared(blmm_ctx* ctx, const ScanArgs& a) {
+  constexpr int MB = 2, NB = 4, W2 = 2;
+  const int64_t ntile_t = (a.m + 16 * W2 * MB - 1) / (16 * W2 * MB);     // a.m: an upper bound of the class (sizes the grid)
+  const int64_t ntile_i = (a.p + 16 * W2 * NB - 1) / (16 * W2 * NB);
+  if (ntile_t * ntile_i <= 0) return BLMM_OK;
+  const int64_t nwg = (ntile_t * ntile_i + 8 + 7) / 8 * 8;              // every XCD's share rounds up
+  if (nwg > 0x7fffffffLL) return fail(ctx, BLMM_ERR_INVALID, "problem too large for one launch");
+  hipLaunchKernelGGL((k_scan<0, MB, NB, true, W2, true>), dim3((unsigned)nwg), dim3(64 * W2 * W2), 0, ctx->stream, a, (int)ntile_i, nwg);
+  KCHECK();
+  return BLMM_OK;
 }
 
 int launch_scan_table(blmm_ctx* ctx, const ScanArgs& a) {

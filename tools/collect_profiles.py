@@ -12,7 +12,9 @@ import sys
 out = sys.argv[1]
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 prof = os.path.join(root, "profiles")
-KERN = {"exact": "k_scan_lr", "grid": "k_scan<", "alt": "k_scan_alt", "perm32": "k_scan_f32"}
+# substrings of the kernel names that make up a configuration's LOD scan: null-exact = k_scan_lr (rank-R class) + the table
+# kernel in permuted-column mode (shared-weights class), each launched once per panel region
+KERN = {"exact": ("k_scan_lr", "k_scan<0, 2, 4, true, 2, true>"), "grid": ("k_scan<",), "alt": ("k_scan_alt",), "perm32": ("k_scan_f32",)}
 ARGS = {"exact": "(default)", "grid": "--method null-grid", "alt": "--method alt-grid",
         "perm32": "--method perms --perm-dtype f32 --n 1000 --p 100000 --m 1250"}
 
@@ -21,7 +23,7 @@ def counter_avgs(d, kern):
     acc = {}
     for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
         for r in csv.DictReader(open(f)):
-            if kern in r["Kernel_Name"]:
+            if any(k in r["Kernel_Name"] for k in kern):
                 acc.setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
     return {k: sum(v) / len(v) for k, v in acc.items()}
 
@@ -33,13 +35,15 @@ for tag, kern in KERN.items():
         continue
     shutil.copy(st[0], os.path.join(prof, f"r02_kernel_stats_{tag}.csv"))
     rows = list(csv.DictReader(open(st[0])))
-    row = next((r for r in rows if kern in r["Name"]), None)
-    # launches of the kernel per library call: the null-exact scan runs once per panel region (two when the h2 search is
+    mine = [r for r in rows if any(k in r["Name"] for k in kern)]
+    # launches per library call: the null-exact scan runs two kernels per panel region (two regions when the h2 search is
     # split); k_design runs once per call.  Durations and counters below are PER CALL (sums over the launches of a call).
     ncall = next((int(r["Calls"]) for r in rows if "k_design" in r["Name"]), 0)
-    per_call = (int(row["Calls"]) / ncall) if (row and ncall) else 1.0
-    s = {"kernel": row["Name"].split("(")[0] if row else kern, "bench_args": ARGS[tag],
-         "rocprof_avg_ms": float(row["AverageNs"]) / 1e6 * per_call if row else None, "calls": int(row["Calls"]) if row else 0,
+    nlaunch = sum(int(r["Calls"]) for r in mine)
+    per_call = (nlaunch / ncall) if (mine and ncall) else 1.0
+    tot_ns = sum(float(r["TotalDurationNs"]) for r in mine)
+    s = {"kernel": " + ".join(r["Name"].split("(")[0] for r in mine) if mine else str(kern), "bench_args": ARGS[tag],
+         "rocprof_avg_ms": (tot_ns / (ncall or nlaunch)) / 1e6 if mine else None, "calls": nlaunch,
          "launches_per_call": per_call}
     for c in ("FETCH_SIZE", "WRITE_SIZE", "SQ_WAVE_CYCLES"):
         s.update({k: v * per_call for k, v in counter_avgs(os.path.join(out, tag, "pmc_" + c), kern).items()})

@@ -21,7 +21,7 @@ prof() {  # tag, kernel regex, bench args...
     rocprofv3 --kernel-trace --pmc $ctr --kernel-include-regex "$kre" --output-format csv -d $OUT/$tag/pmc_$c1 -o p -- python3 bench.py --no-cpu-baseline --no-host-api --steps 3 --warmup 1 "$@" > $OUT/$tag.pmc_$c1.log 2>&1 || { tail -5 $OUT/$tag.pmc_$c1.log; return 1; }
   done
 }
-prof exact "k_scan_lr" || exit 1
+prof exact "k_scan_lr|k_scan<0, 2, 4, true, 2, true" || exit 1
 prof grid "k_scan<" --method null-grid || exit 1
 prof alt "k_scan_alt" --method alt-grid || exit 1
 prof perm32 "k_scan_f32" --method perms --perm-dtype f32 --n 1000 --p 100000 --m 1250 || exit 1
