@@ -18,7 +18,7 @@ for case in range(ncases):
     m = int(rng.choice([1, 2, 15, 16, 17, 63, 70, 1030]))
     ncov = int(rng.choice([0, 0, 1, 2]))
     if ncov + 2 >= n: ncov = 0
-    method = str(rng.choice(["null-exact", "null-exact", "null-grid", "alt-grid", "perms"]))
+    method = str(rng.choice(["null-exact", "null-exact", "null-grid", "alt-grid", "perms", "scan-alt"]))
     oi = int(rng.choice([1, 1, 1, 2, 3]))
     reml = bool(rng.random() < 0.25)
     svd = bool(rng.random() < 0.15)
@@ -71,6 +71,21 @@ for case in range(ncases):
                     assert_lod_close(got["L_perms"], pin["L_perms"])
             else:
                 assert np.isfinite(got["L_perms"]).all()
+        elif method == "scan-alt":
+            pp = min(p, 65)                                        # the oracle runs one Python Brent search per marker
+            true_w = bool(rng.random() < 0.3)
+            skw = dict(reml=reml, decomp_scheme="svd" if svd else "eigen", prior_variance=prior[0], prior_sample_size=prior[1],
+                       optim_interval=oi, weights=w)
+            got = blmm.scan(Y[:, :1], G[:, :pp], K, Cov, assumption="alt", alt_true_weights=true_w, **skw)
+            own = O.scan(Y[:, :1], G[:, :pp], K, covar=Cov, assumption="alt", true_weights=true_w, **skw)
+            assert abs(got["h2_null"] - own["h2_null"]) <= 1e-6
+            pin = O.scan(Y[:, :1], G[:, :pp], K, covar=Cov, assumption="alt", true_weights=true_w,
+                         h2_each_override=got["h2_each_marker"], h2_null_override=got["h2_null"], **skw)
+            assert_lod_close(got["lod"], pin["lod"], atol=1e-9)
+            # each side's own per-marker search: h2 may differ where the profile is flat or two-humped, the LOD then barely
+            dl = np.abs(got["lod"] - own["lod"])
+            if pp >= 10:      # (a handful of markers cannot carry a quantile: n = 8 with REML has flat profiles)
+                assert np.quantile(dl, 0.9) <= 1e-6 * max(1.0, np.abs(own["lod"]).max()) + 1e-7, "scan_alt LOD"
         elif method == "null-grid":
             got = blmm.bulkscan_null_grid(Y, G, K, grid, Cov, weights=w, **kw)
             ref = O.bulkscan_null_grid(Y, G, K, grid, Covar=Cov, weights=w, **kw)
@@ -90,7 +105,8 @@ for case in range(ncases):
             {"null-exact": lambda: O.bulkscan_null(Y, G, K, Covar=Cov, weights=w, optim_interval=oi, **kw),
              "null-grid": lambda: O.bulkscan_null_grid(Y, G, K, grid, Covar=Cov, weights=w, **kw),
              "alt-grid": lambda: O.bulkscan_alt_grid(Y, G, K, grid, Covar=Cov, weights=w, **kw),
-             "perms": lambda: O.scan(Y[:, 0], G, K, covar=Cov, permutation_test=True, nperms=4, weights=w)}[method]()
+             "perms": lambda: O.scan(Y[:, 0], G, K, covar=Cov, permutation_test=True, nperms=4, weights=w),
+             "scan-alt": lambda: O.scan(Y[:, :1], G[:, :min(p, 65)], K, covar=Cov, assumption="alt", weights=w)}[method]()
             same = False
         except O.BulkLMMError as oe:
             same = str(oe) == e.msg
