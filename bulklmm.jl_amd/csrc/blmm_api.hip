@@ -425,13 +425,17 @@ int lr_begin(blmm_ctx* ctx, const Pipe& P, bool wbasis_started) {
   ctx->stream = ctx->side;                                         // the launchers enqueue on ctx->stream
   rc = BLMM_OK;
   if (!wbasis_started) rc = launch_wbasis(ctx, P.lam, P.n, ptr<double>(ctx->wbW), ptr<double>(ctx->wbQ), rk, P.stat);
-  if (!rc && hipMemsetAsync(ctx->lrPerm.p, 0xff, sizeof(int) * (size_t)ldp, ctx->side) != hipSuccess) rc = fail(ctx, BLMM_ERR_HIP, "hipMemsetAsync failed");
   if (!rc && hipEventRecord(ctx->ev_q, ctx->side) != hipSuccess) rc = fail(ctx, BLMM_ERR_HIP, "hipEventRecord failed");   // what the panels need
   if (!rc) rc = launch_lr_tpanels(ctx, P.Xt, P.ldx, P.p, P.n, P.c, P.npad, P.Z0, ptr<double>(ctx->wbQ), rk, ptr<double>(ctx->lrT), tstride,
                                   ptr<double>(ctx->lrDen0));
   ctx->stream = main_stream;
   if (rc) return rc;
   BLMM_HIP(hipEventRecord(ctx->ev_join, ctx->side));                // ... and what the scan needs on top
+  // the column order's preset (-1 = padding) on the second side stream, idle until the h2 search forks: the classification
+  // needs nothing else from the side work
+  BLMM_HIP(hipStreamWaitEvent(ctx->side2, ctx->ev_fork, 0));
+  BLMM_HIP(hipMemsetAsync(ctx->lrPerm.p, 0xff, sizeof(int) * (size_t)ldp, ctx->side2));
+  BLMM_HIP(hipEventRecord(ctx->ev_m, ctx->side2));
   return BLMM_OK;
 }
 
@@ -488,6 +492,7 @@ int lr_finish(blmm_ctx* ctx, const Pipe& P, const NullModel& nm, const double* d
   LrRegion rg; rg.col0 = 0; rg.ncol = lr_ldq(P); rg.counts = P.stat + 12;
   hipStream_t main_stream = ctx->stream;
   BLMM_HIP(hipStreamWaitEvent(main_stream, ctx->ev_join, 0));
+  BLMM_HIP(hipStreamWaitEvent(main_stream, ctx->ev_m, 0));
   if ((rc = launch_lr_classify(ctx, P.n, P.m, lr_shared_tol(), P.lam, dh2, nullptr, nullptr, nullptr, ptr<int>(ctx->lrPerm), rg))) return rc;
   if ((rc = lr_region_panels(ctx, P, nm, dh2, rg))) return rc;
   tm.mark();
@@ -529,9 +534,10 @@ int lr_finish_split(blmm_ctx* ctx, const Pipe& P, const NullModel& nm, double* d
   ctx->stream = main_stream;
   if (rc) return rc;
   BLMM_HIP(hipEventRecord(ctx->ev_b2, ctx->side2));
-  // ---- main stream: region 0 (the weight basis and the perm preset are ready at ev_q; the marker-side products at ev_join)
-  BLMM_HIP(hipStreamWaitEvent(main_stream, ctx->ev_q, 0));
+  // ---- main stream: region 0 (the perm preset is ready at ev_m, the weight basis at ev_q, the marker-side products at ev_join)
+  BLMM_HIP(hipStreamWaitEvent(main_stream, ctx->ev_m, 0));
   if ((rc = launch_lr_classify(ctx, P.n, P.m, lr_shared_tol(), P.lam, dh2, sp.fin, nullptr, nullptr, ptr<int>(ctx->lrPerm), r0))) return rc;
+  BLMM_HIP(hipStreamWaitEvent(main_stream, ctx->ev_q, 0));
   if ((rc = lr_region_panels(ctx, P, nm, dh2, r0))) return rc;
   tm.mark();
   BLMM_HIP(hipStreamWaitEvent(main_stream, ctx->ev_join, 0));
@@ -612,7 +618,8 @@ int blmm_create(int device_id, void* hip_stream, blmm_ctx** out) {
       hipStreamCreateWithFlags(&ctx->side2, hipStreamNonBlocking) != hipSuccess ||
       hipEventCreateWithFlags(&ctx->ev_b1, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&ctx->ev_b2, hipEventDisableTiming) != hipSuccess ||
-      hipEventCreateWithFlags(&ctx->ev_q, hipEventDisableTiming) != hipSuccess) {
+      hipEventCreateWithFlags(&ctx->ev_q, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&ctx->ev_m, hipEventDisableTiming) != hipSuccess) {
     blmm_destroy(ctx);
     return BLMM_ERR_HIP;
   }
@@ -652,6 +659,7 @@ void blmm_destroy(blmm_ctx* ctx) {
   if (ctx->ev_b1) (void)hipEventDestroy(ctx->ev_b1);
   if (ctx->ev_b2) (void)hipEventDestroy(ctx->ev_b2);
   if (ctx->ev_q) (void)hipEventDestroy(ctx->ev_q);
+  if (ctx->ev_m) (void)hipEventDestroy(ctx->ev_m);
   if (ctx->side2) { (void)hipStreamSynchronize(ctx->side2); (void)hipStreamDestroy(ctx->side2); }
   if (ctx->own_stream) hipStreamDestroy(ctx->stream);
   if (ctx->hflag) (void)hipHostFree(const_cast<int64_t*>(ctx->hflag));

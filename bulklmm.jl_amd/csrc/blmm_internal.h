@@ -52,7 +52,7 @@ struct blmm_ctx {
                   double*, int) = nullptr;
   // side stream: work that only depends on the eigenvalues / rotated markers runs beside the per-trait Brent search
   hipStream_t side = nullptr, side2 = nullptr;
-  hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_xt = nullptr, ev_b1 = nullptr, ev_b2 = nullptr, ev_q = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_xt = nullptr, ev_b1 = nullptr, ev_b2 = nullptr, ev_q = nullptr, ev_m = nullptr;
   int num_cus = 0;                 // multiProcessorCount of the device (bounds every co-resident grid)
   // sticky device-side abort word in pinned, device-mapped host memory: a kernel that gives up (bounded spin of the
   // multi-workgroup weight-basis kernel) is reported by the NEXT API call / blmm_synchronize even when the failing

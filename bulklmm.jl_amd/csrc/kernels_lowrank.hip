@@ -495,14 +495,33 @@ int launch_wbasis(blmm_ctx* ctx, const double* lam, int n, double* Wk, double* Q
 // grid = (ldx/256, ceil(4*KRmax/16)); the kernel reads R from rk and returns early for chunks beyond it.
 // The first chunk also leaves den0_i = 1 / sqrt(Sxx - |L0^-1 s|^2) of the unweighted model (Sxx = sum_k x_ik^2, s_q = sum_k x_ik z_qk,
 // Z0'Z0 = L0 L0'): the denominators of the shared-weights class, from the same pass over Xt.
-template <int C>
+template <int C, bool STAGE>
 __global__ void __launch_bounds__(256) k_lr_tpanels(const double* __restrict__ Xt, int64_t ldx, int64_t p, int n,
                                                     const double* __restrict__ Z0, const double* __restrict__ Q,
                                                     const int* __restrict__ rk, double* __restrict__ T, int64_t tstride,
                                                     double* __restrict__ den0) {
+  // The chunk's 16 basis rows and Z0 are staged in LDS once (STAGE; beyond the LDS budget, n > ~1000, they are read from
+  // L2 -- a template parameter, not a run-time pointer choice: a pointer that may be either loses its address space and
+  // every access becomes a flat load), and a thread fetches its marker's x eight
+  // individuals at a time before using them: with the loads next to their uses every k cost an L2 round trip (94 us at the
+  // BXD shape for ~9 us of arithmetic -- on the critical path of the scan).
+  extern __shared__ __attribute__((aligned(16))) double sh[];
   const int R = rk[0], R4 = rk[1] * 4;
   const int r0 = blockIdx.y * 16;
-  if (r0 >= R4 && r0 > 0) return;
+  if (r0 >= R4 && r0 > 0) return;                // workgroup-uniform
+  if constexpr (STAGE) {
+    for (int e = threadIdx.x; e < 16 * n; e += blockDim.x) { const int t = e / n; sh[e] = (r0 + t < R) ? Q[(size_t)(r0 + t) * n + (e % n)] : 0.0; }
+    for (int e = threadIdx.x; e < C * n; e += blockDim.x) sh[16 * n + e] = Z0[e];
+    __syncthreads();
+  }
+  auto qval = [&](int t, int k) -> double {       // basis row r0 + t at individual k
+    if constexpr (STAGE) return sh[t * n + k];
+    else return (r0 + t < R) ? Q[(size_t)(r0 + t) * n + k] : 0.0;
+  };
+  auto zval = [&](int q, int k) -> double {
+    if constexpr (STAGE) return sh[16 * n + q * n + k];
+    else return Z0[q * n + k];
+  };
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= ldx) return;
   constexpr int NA = C * (C + 1) / 2;
@@ -517,25 +536,34 @@ __global__ void __launch_bounds__(256) k_lr_tpanels(const double* __restrict__ X
 #pragma unroll
     for (int t = 0; t < 16; ++t) acc[q][t] = 0.0;
   if (i < p) {
-    for (int k = 0; k < n; ++k) {
-      const double x = Xt[(int64_t)k * ldx + i];
-      double xv[1 + C];
-      xv[0] = x * x;
+    for (int k0 = 0; k0 < n; k0 += 8) {
+      double xs[8];
 #pragma unroll
-      for (int q = 0; q < C; ++q) xv[1 + q] = x * Z0[q * n + k];
-      if (r0 == 0) {                             // workgroup-uniform
+      for (int u = 0; u < 8; ++u) xs[u] = (k0 + u < n) ? Xt[(int64_t)(k0 + u) * ldx + i] : 0.0;
 #pragma unroll
-        for (int q = 0; q <= C; ++q) un[q] += xv[q];
+      for (int u = 0; u < 8; ++u) {
+        const int k = k0 + u;
+        if (k < n) {                             // workgroup-uniform
+          const double x = xs[u];
+          double xv[1 + C];
+          xv[0] = x * x;
 #pragma unroll
-        for (int q = 0; q < C; ++q)
+          for (int q = 0; q < C; ++q) xv[1 + q] = x * zval(q, k);
+          if (r0 == 0) {                         // workgroup-uniform
 #pragma unroll
-          for (int r = 0; r <= q; ++r) A0[q * (q + 1) / 2 + r] = fma(Z0[q * n + k], Z0[r * n + k], A0[q * (q + 1) / 2 + r]);
-      }
+            for (int q = 0; q <= C; ++q) un[q] += xv[q];
 #pragma unroll
-      for (int t = 0; t < 16; ++t) {
-        const double qv = (r0 + t < R) ? Q[(size_t)(r0 + t) * n + k] : 0.0;   // wave-uniform
+            for (int q = 0; q < C; ++q)
 #pragma unroll
-        for (int q = 0; q <= C; ++q) acc[q][t] = fma(qv, xv[q], acc[q][t]);
+              for (int r = 0; r <= q; ++r) A0[q * (q + 1) / 2 + r] = fma(zval(q, k), zval(r, k), A0[q * (q + 1) / 2 + r]);
+          }
+#pragma unroll
+          for (int t = 0; t < 16; ++t) {
+            const double qv = qval(t, k);          // one address per wave: a broadcast
+#pragma unroll
+            for (int q = 0; q <= C; ++q) acc[q][t] = fma(qv, xv[q], acc[q][t]);
+          }
+        }
       }
     }
   }
@@ -573,7 +601,13 @@ __global__ void __launch_bounds__(256) k_lr_tpanels(const double* __restrict__ X
 int launch_lr_tpanels(blmm_ctx* ctx, const double* Xt, int64_t ldx, int64_t p, int n, int c, int npad, const double* Z0,
                       const double* Q, const int* rk, double* T, int64_t tstride, double* den0) {
   dim3 grid((unsigned)((ldx + 255) / 256), (unsigned)((npad + 15) / 16));
-#define TP(C) hipLaunchKernelGGL(k_lr_tpanels<C>, grid, dim3(256), 0, ctx->stream, Xt, ldx, p, n, Z0, Q, rk, T, tstride, den0)
+  size_t lds = sizeof(double) * (size_t)n * (16 + c);
+  const int stage = lds <= 150 * 1024;
+  if (!stage) lds = 0;
+#define TP(C) do { if (stage) { \
+    if (lds > 48 * 1024) BLMM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_lr_tpanels<C, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+    hipLaunchKernelGGL((k_lr_tpanels<C, true>), grid, dim3(256), lds, ctx->stream, Xt, ldx, p, n, Z0, Q, rk, T, tstride, den0); \
+  } else hipLaunchKernelGGL((k_lr_tpanels<C, false>), grid, dim3(256), 0, ctx->stream, Xt, ldx, p, n, Z0, Q, rk, T, tstride, den0); } while (0)
   switch (c) {
     case 1: TP(1); break;
     case 2: TP(2); break;
@@ -748,22 +782,28 @@ template <int C, int LPT>
 __global__ void __launch_bounds__(256) k_lr_panels_w(NullModel nm, const double* __restrict__ Yt, int64_t ldy, int64_t m,
                                                      const double* __restrict__ Z0, const double* __restrict__ lam,
                                                      const double* __restrict__ h2v, const double* __restrict__ Q,
-                                                     const int* __restrict__ rk, const int* __restrict__ perm, int64_t col0,
-                                                     int64_t ncol, double* __restrict__ P0, double* __restrict__ Cp,
-                                                     double* __restrict__ Ls, int64_t ldp, int64_t* stat) {
+                                                     const int* __restrict__ rk, int qcap, const int* __restrict__ perm,
+                                                     int64_t col0, int64_t ncol, int nbatch, double* __restrict__ P0,
+                                                     double* __restrict__ Cp, double* __restrict__ Ls, int64_t ldp,
+                                                     int64_t* stat) {
   extern __shared__ __attribute__((aligned(16))) double sh[];
   const int n = nm.n, npad = nm.npad;
   double* sLam = sh;
   double* sZ = sh + n;
+  double* sQ = sZ + n * C;                     // min(R, qcap) x n : basis rows (the rest is read from L2)
   const int R = rk[0], R4 = rk[1] * 4;
+  const int rl = R < qcap ? R : qcap;
   for (int e = threadIdx.x; e < n; e += blockDim.x) sLam[e] = lam[e];
   for (int e = threadIdx.x; e < n * C; e += blockDim.x) sZ[e] = Z0[e];
+  for (int e = threadIdx.x; e < rl * n; e += blockDim.x) sQ[e] = Q[e];
   __syncthreads();
   constexpr int TPB = 256 / LPT;
   const int sub = threadIdx.x % LPT;
-  const int64_t jc = col0 + (int64_t)blockIdx.x * TPB + threadIdx.x / LPT;
-  if (jc >= col0 + ncol) return;                 // whole lane groups leave together
   constexpr int NA = C * (C + 1) / 2;
+  // A workgroup walks `nbatch` batches of TPB columns (BLMM_LR_PANELS_BATCH; default 1: fewer, longer workgroups did not
+  // help -- the kernel stays at 45-65 us for ~9 k wave-cycles of work per wave at ~5 % average wave-slot occupancy).
+  auto do_column = [&](int64_t jc) {
+  if (jc >= col0 + ncol) return;                 // whole lane groups leave together
   const int64_t j = perm[jc];
   if (j < 0 || j >= m) {   // padding column (see k_lr_panels)
     const int64_t tb = jc & ~(int64_t)(LR_TILE - 1);
@@ -785,9 +825,15 @@ __global__ void __launch_bounds__(256) k_lr_panels_w(NullModel nm, const double*
   for (int a = 0; a < NA; ++a) A[a] = 0.0;
 #pragma unroll
   for (int q = 0; q < C; ++q) v[q] = 0.0;
-  for (int k = sub; k < n; k += LPT) {
+  // the lane's y values, fetched together up front (a trait's rows are 8 bytes each in different sectors: next to their
+  // uses every one of them cost a memory round trip) and kept for the second pass when they fit (n <= YK * LPT)
+  constexpr int YK = 8;
+  const bool yreg = n <= YK * LPT;
+  double yv[YK];
+#pragma unroll
+  for (int i = 0; i < YK; ++i) { const int k = sub + LPT * i; yv[i] = (yreg && k < n) ? Yt[(int64_t)k * ldy + j] : 0.0; }
+  auto pass1 = [&](int k, double y) {
     const double w = fabs(fast_rcp(fma(delta, sLam[k], 1.0)));  // sqrt.(abs.(makeweights)) squared, src/bulkscan_helpers.jl:138
-    const double y = Yt[(int64_t)k * ldy + j];
     const double wy = w * y;
     syy = fma(wy, y, syy);
 #pragma unroll
@@ -798,6 +844,12 @@ __global__ void __launch_bounds__(256) k_lr_panels_w(NullModel nm, const double*
 #pragma unroll
       for (int r = 0; r <= q; ++r) A[q * (q + 1) / 2 + r] = fma(wz, sZ[r * n + k], A[q * (q + 1) / 2 + r]);
     }
+  };
+  if (yreg) {
+#pragma unroll
+    for (int i = 0; i < YK; ++i) { const int k = sub + LPT * i; if (k < n) pass1(k, yv[i]); }
+  } else {
+    for (int k = sub; k < n; k += LPT) pass1(k, Yt[(int64_t)k * ldy + j]);
   }
   syy = gsum(syy);
 #pragma unroll
@@ -840,16 +892,23 @@ __global__ void __launch_bounds__(256) k_lr_panels_w(NullModel nm, const double*
   const double yy = syy - tt;
   if (sub == 0 && !(sqrt(fabs(yy)) > 2.220446049250313e-16)) atomicAdd((unsigned long long*)&stat[ST_ZERO_NORM], 1ull);
   const double isy = 1.0 / sqrt(yy);
-  for (int k = sub; k < npad; k += LPT) {
+  auto pass2 = [&](int k, double y) {
     double p0 = 0.0;
     if (k < n) {
       const double w = fabs(fast_rcp(fma(delta, sLam[k], 1.0)));
-      double res = Yt[(int64_t)k * ldy + j];
+      double res = y;
 #pragma unroll
       for (int q = 0; q < C; ++q) res = fma(-beta[q], sZ[q * n + k], res);
       p0 = w * res * isy;
     }
     P0[(int64_t)k * ldp + jc] = p0;
+  };
+  if (yreg) {
+#pragma unroll
+    for (int i = 0; i < YK; ++i) { const int k = sub + LPT * i; if (k < npad) pass2(k, yv[i]); }
+    for (int k = sub + LPT * YK; k < npad; k += LPT) pass2(k, 0.0);    // padding rows beyond the registers (k >= n)
+  } else {
+    for (int k = sub; k < npad; k += LPT) pass2(k, k < n ? Yt[(int64_t)k * ldy + j] : 0.0);
   }
   if (sub == 0) {
 #pragma unroll
@@ -862,9 +921,14 @@ __global__ void __launch_bounds__(256) k_lr_panels_w(NullModel nm, const double*
     for (int u = 0; u < 8; ++u) c8[u] = 0.0;
     for (int k = sub; k < n; k += LPT) {
       const double w = fabs(fast_rcp(fma(delta, sLam[k], 1.0)));
+      if (rb + 8 <= rl) {                         // workgroup-uniform: the chunk's rows are all in LDS
 #pragma unroll
-      for (int u = 0; u < 8; ++u)
-        if (rb + u < R) c8[u] = fma(Q[(size_t)(rb + u) * n + k], w, c8[u]);
+        for (int u = 0; u < 8; ++u) c8[u] = fma(sQ[(rb + u) * n + k], w, c8[u]);
+      } else {
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+          if (rb + u < R) c8[u] = fma((rb + u < rl) ? sQ[(rb + u) * n + k] : Q[(size_t)(rb + u) * n + k], w, c8[u]);
+      }
     }
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
@@ -872,6 +936,8 @@ __global__ void __launch_bounds__(256) k_lr_panels_w(NullModel nm, const double*
       if (rb + u < R4 && sub == ((rb + u) % LPT)) Cp[(int64_t)(rb + u) * ldp + jc] = c;
     }
   }
+  };
+  for (int b = 0; b < nbatch; ++b) do_column(col0 + ((int64_t)blockIdx.x * nbatch + b) * TPB + threadIdx.x / LPT);
 }
 
 // Guard of the low-rank form: relative residual |w_j - Q c_j| / |w_j| of the weight-basis expansion of EVERY trait,
@@ -1130,10 +1196,17 @@ int launch_lr_panels(blmm_ctx* ctx, const NullModel& nm, const double* Yt, int64
   static const char* wide_env = getenv("BLMM_LR_PANELS_WIDE");
   if (!(wide_env && wide_env[0] == '0')) {
     constexpr int LPT = 16;
-    const unsigned wblocks = (unsigned)((rg.ncol + (256 / LPT) - 1) / (256 / LPT));
-    const size_t wlds = sizeof(double) * (size_t)nm.n * (1 + nm.c);
+    const int64_t wgroups = (rg.ncol + (256 / LPT) - 1) / (256 / LPT);
+    static const int nb_env = getenv("BLMM_LR_PANELS_BATCH") ? atoi(getenv("BLMM_LR_PANELS_BATCH")) : 0;
+    const int ncu = ctx->num_cus > 0 ? ctx->num_cus : 256;
+    (void)ncu;
+    const int nbatch = nb_env > 0 ? nb_env : 1;   // BXD shape, prep phase: 0.109 ms at 1, 0.106 at 2, 0.113 at 4, 0.164 at 8
+    const unsigned wblocks = (unsigned)((wgroups + nbatch - 1) / nbatch);
+    const size_t wbase = sizeof(double) * (size_t)nm.n * (1 + nm.c);
+    const int wqcap = (wbase + sizeof(double) * nm.n <= 60 * 1024) ? (int)std::min<size_t>((size_t)nm.n, (60 * 1024 - wbase) / (sizeof(double) * (size_t)nm.n)) : 0;
+    const size_t wlds = wbase + sizeof(double) * (size_t)wqcap * nm.n;
 #define LPW(C) do { if (wlds > 48 * 1024) BLMM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_lr_panels_w<C, LPT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)wlds)); \
-    hipLaunchKernelGGL((k_lr_panels_w<C, LPT>), dim3(wblocks), dim3(256), wlds, ctx->stream, nm, Yt, ldy, m, Z0, lam, h2, Q, rk, perm, rg.col0, rg.ncol, P0, Cp, Ls, ldp, stat); } while (0)
+    hipLaunchKernelGGL((k_lr_panels_w<C, LPT>), dim3(wblocks), dim3(256), wlds, ctx->stream, nm, Yt, ldy, m, Z0, lam, h2, Q, rk, wqcap, perm, rg.col0, rg.ncol, nbatch, P0, Cp, Ls, ldp, stat); } while (0)
     switch (nm.c) {
       case 1: LPW(1); break;
       case 2: LPW(2); break;
