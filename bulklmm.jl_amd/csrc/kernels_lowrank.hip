@@ -102,9 +102,11 @@ __global__ void __launch_bounds__(WB_NS * TPS) k_wbasis(const double* __restrict
     for (int pass = 0; pass < 2; ++pass) {   // classical Gram-Schmidt twice: Q stays orthonormal to rounding even for
                                               // the last, noise-dominated pivots
       for (int r = wave; r < R; r += nwave) {  // one wave per existing basis vector (LDS copy; the rest: global)
-        const double* qt = (r < qcap) ? Ql + r * n : Q + (size_t)r * n;
+        // two loops, not one pointer chosen at run time: a pointer that may be LDS or global loses its address space and
+        // every access through it becomes a flat load
         double d = 0.0;
-        for (int k = lane; k < n; k += 64) d = fma(qt[k], sq[k], d);
+        if (r < qcap) { for (int k = lane; k < n; k += 64) d = fma(Ql[r * n + k], sq[k], d); }
+        else { for (int k = lane; k < n; k += 64) d = fma(Q[(size_t)r * n + k], sq[k], d); }
         d = wave_sum(d);
         if (lane == 0) sd[r] = d;
       }
@@ -238,9 +240,11 @@ __global__ void __launch_bounds__(1024) k_wbasis_reg(const double* __restrict__ 
     __syncthreads();
     for (int pass = 0; pass < 2; ++pass) {     // classical Gram-Schmidt twice (as k_wbasis)
       for (int r = wave; r < R; r += nwave) {
-        const double* qt = (r < qcap) ? Ql + r * n : Q + (size_t)r * n;
+        // two loops, not one pointer chosen at run time: a pointer that may be LDS or global loses its address space and
+        // every access through it becomes a flat load
         double d = 0.0;
-        for (int k = lane; k < n; k += 64) d = fma(qt[k], sq[k], d);
+        if (r < qcap) { for (int k = lane; k < n; k += 64) d = fma(Ql[r * n + k], sq[k], d); }
+        else { for (int k = lane; k < n; k += 64) d = fma(Q[(size_t)r * n + k], sq[k], d); }
         d = wave_sum(d);
         if (lane == 0) sd[r] = d;
       }
@@ -385,9 +389,11 @@ __global__ void __launch_bounds__(1024) k_wbasis_mw(const double* __restrict__ l
     __syncthreads();
     for (int pass = 0; pass < 2; ++pass) {     // classical Gram-Schmidt twice (as k_wbasis)
       for (int r = wave; r < R; r += nwave) {
-        const double* qt = (r < qcap) ? Ql + (size_t)r * n : Q + (size_t)r * n;
+        // two loops, not one pointer chosen at run time: a pointer that may be LDS or global loses its address space and
+        // every access through it becomes a flat load
         double d = 0.0;
-        for (int k = lane; k < n; k += 64) d = fma(qt[k], sq[k], d);
+        if (r < qcap) { for (int k = lane; k < n; k += 64) d = fma(Ql[(size_t)r * n + k], sq[k], d); }
+        else { for (int k = lane; k < n; k += 64) d = fma(Q[(size_t)r * n + k], sq[k], d); }
         d = wave_sum(d);
         if (lane == 0) sd[r] = d;
       }
