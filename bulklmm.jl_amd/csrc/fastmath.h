@@ -89,4 +89,27 @@ __device__ __forceinline__ double fast_rcp(double x) {
   return fma(y, e, y);
 }
 
+// Sum over the aligned groups of LPT lanes (LPT a power of two <= 64); every lane of a group gets the group's total.
+// Steps inside a 16-lane row go through DPP (quad_perm, row_half_mirror, row_mirror: one v_mov_dpp pair per step, ~8
+// cycles) -- the __shfl_xor butterfly they replace is a pair of ds_bpermute per step, ~100+ cycles of LDS round trip each,
+// and was the bulk of a latency-bound evaluation's time.  Same pairing as the xor butterfly (addition commutes), so the
+// sums are bit-identical to it.
+template <int CTRL>
+__device__ __forceinline__ double blmm_dpp_mov(double x) {
+  int lo = __double2loint(x), hi = __double2hiint(x);
+  lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xf, 0xf, false);
+  hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xf, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+template <int LPT>
+__device__ __forceinline__ double group_sum(double x) {
+  if constexpr (LPT >= 2) x += blmm_dpp_mov<0xB1>(x);     // quad_perm [1,0,3,2]   = lane ^ 1
+  if constexpr (LPT >= 4) x += blmm_dpp_mov<0x4E>(x);     // quad_perm [2,3,0,1]   = lane ^ 2
+  if constexpr (LPT >= 8) x += blmm_dpp_mov<0x141>(x);    // row_half_mirror: lane i <-> 7 - i (quads hold equal sums)
+  if constexpr (LPT >= 16) x += blmm_dpp_mov<0x140>(x);   // row_mirror: lane i <-> 15 - i
+  if constexpr (LPT >= 32) x += __shfl_xor(x, 16, 64);
+  if constexpr (LPT >= 64) x += __shfl_xor(x, 32, 64);
+  return x;
+}
+
 }  // namespace blmm

@@ -11,6 +11,8 @@
 // residual, or at R = n where the form is exact by construction), so one code path serves every kinship; the
 // per-trait approximation residual is reported in blmm_status.lowrank_resid.
 #include "blmm_internal.h"
+#include <vector>
+#include <algorithm>
 #include "fastmath.h"
 #include <cmath>
 #include <cstdlib>
@@ -784,6 +786,9 @@ __global__ void __launch_bounds__(256) k_lr_panels(NullModel nm, const double* _
 // Lane `sub` of a trait's group owns the individuals k = sub, sub + LPT, ...; sums are butterflied over the group, the
 // small per-trait algebra is done redundantly by every lane.  Basis rows come from L2 (every group of a workgroup reads
 // the same addresses, consecutive lanes consecutive k).
+#ifdef PW_DIAG
+__device__ unsigned long long g_pw_diag[3 * 8192];   // per workgroup: start / after staging / end (100 MHz ticks)
+#endif
 template <int C, int LPT>
 __global__ void __launch_bounds__(256) k_lr_panels_w(NullModel nm, const double* __restrict__ Yt, int64_t ldy, int64_t m,
                                                      const double* __restrict__ Z0, const double* __restrict__ lam,
@@ -792,6 +797,9 @@ __global__ void __launch_bounds__(256) k_lr_panels_w(NullModel nm, const double*
                                                      int64_t col0, int64_t ncol, int nbatch, double* __restrict__ P0,
                                                      double* __restrict__ Cp, double* __restrict__ Ls, int64_t ldp,
                                                      int64_t* stat) {
+#ifdef PW_DIAG
+  if (threadIdx.x == 0 && blockIdx.x < 8192) g_pw_diag[3 * blockIdx.x] = __builtin_amdgcn_s_memrealtime();
+#endif
   extern __shared__ __attribute__((aligned(16))) double sh[];
   const int n = nm.n, npad = nm.npad;
   double* sLam = sh;
@@ -803,6 +811,9 @@ __global__ void __launch_bounds__(256) k_lr_panels_w(NullModel nm, const double*
   for (int e = threadIdx.x; e < n * C; e += blockDim.x) sZ[e] = Z0[e];
   for (int e = threadIdx.x; e < rl * n; e += blockDim.x) sQ[e] = Q[e];
   __syncthreads();
+#ifdef PW_DIAG
+  if (threadIdx.x == 0 && blockIdx.x < 8192) g_pw_diag[3 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();
+#endif
   constexpr int TPB = 256 / LPT;
   const int sub = threadIdx.x % LPT;
   constexpr int NA = C * (C + 1) / 2;
@@ -819,11 +830,10 @@ __global__ void __launch_bounds__(256) k_lr_panels_w(NullModel nm, const double*
     for (int e = sub; e < NA; e += LPT) Ls[(int64_t)e * ldp + jc] = 0.0;
     return;
   }
-  auto gsum = [](double x) {
-#pragma unroll
-    for (int o = 1; o < LPT; o <<= 1) x += __shfl_xor(x, o, LPT);
-    return x;
-  };
+  auto gsum = [](double x) { return group_sum<LPT>(x); };
+#ifdef PW_DIAG
+  unsigned long long pw_t[6]; pw_t[0] = __builtin_amdgcn_s_memtime();
+#endif
   const double h2 = h2v[j];
   const double delta = h2 / (1.0 - h2);
   double A[NA], v[C], syy = 0.0;
@@ -838,8 +848,12 @@ __global__ void __launch_bounds__(256) k_lr_panels_w(NullModel nm, const double*
   double yv[YK];
 #pragma unroll
   for (int i = 0; i < YK; ++i) { const int k = sub + LPT * i; yv[i] = (yreg && k < n) ? Yt[(int64_t)k * ldy + j] : 0.0; }
-  auto pass1 = [&](int k, double y) {
+  double wreg[YK];                               // the lane's weights, kept for the second pass and the coefficients (yreg)
+#pragma unroll
+  for (int i = 0; i < YK; ++i) wreg[i] = 0.0;
+  auto pass1 = [&](int k, double y, double& wkeep) {
     const double w = fabs(fast_rcp(fma(delta, sLam[k], 1.0)));  // sqrt.(abs.(makeweights)) squared, src/bulkscan_helpers.jl:138
+    wkeep = w;
     const double wy = w * y;
     syy = fma(wy, y, syy);
 #pragma unroll
@@ -853,10 +867,14 @@ __global__ void __launch_bounds__(256) k_lr_panels_w(NullModel nm, const double*
   };
   if (yreg) {
 #pragma unroll
-    for (int i = 0; i < YK; ++i) { const int k = sub + LPT * i; if (k < n) pass1(k, yv[i]); }
+    for (int i = 0; i < YK; ++i) { const int k = sub + LPT * i; if (k < n) pass1(k, yv[i], wreg[i]); }
   } else {
-    for (int k = sub; k < n; k += LPT) pass1(k, Yt[(int64_t)k * ldy + j]);
+    double wdummy;
+    for (int k = sub; k < n; k += LPT) pass1(k, Yt[(int64_t)k * ldy + j], wdummy);
   }
+#ifdef PW_DIAG
+  pw_t[1] = __builtin_amdgcn_s_memtime();
+#endif
   syy = gsum(syy);
 #pragma unroll
   for (int a = 0; a < NA; ++a) A[a] = gsum(A[a]);
@@ -895,13 +913,16 @@ __global__ void __launch_bounds__(256) k_lr_panels_w(NullModel nm, const double*
     for (int u = q; u < C; ++u) s = fma(Li[u * (u + 1) / 2 + q], t[u], s);
     beta[q] = s;
   }
+#ifdef PW_DIAG
+  pw_t[2] = __builtin_amdgcn_s_memtime();
+#endif
   const double yy = syy - tt;
   if (sub == 0 && !(sqrt(fabs(yy)) > 2.220446049250313e-16)) atomicAdd((unsigned long long*)&stat[ST_ZERO_NORM], 1ull);
   const double isy = 1.0 / sqrt(yy);
-  auto pass2 = [&](int k, double y) {
+  auto pass2 = [&](int k, double y, double wk) {   // wk < 0: recompute the weight
     double p0 = 0.0;
     if (k < n) {
-      const double w = fabs(fast_rcp(fma(delta, sLam[k], 1.0)));
+      const double w = (wk >= 0.0) ? wk : fabs(fast_rcp(fma(delta, sLam[k], 1.0)));
       double res = y;
 #pragma unroll
       for (int q = 0; q < C; ++q) res = fma(-beta[q], sZ[q * n + k], res);
@@ -911,29 +932,45 @@ __global__ void __launch_bounds__(256) k_lr_panels_w(NullModel nm, const double*
   };
   if (yreg) {
 #pragma unroll
-    for (int i = 0; i < YK; ++i) { const int k = sub + LPT * i; if (k < npad) pass2(k, yv[i]); }
-    for (int k = sub + LPT * YK; k < npad; k += LPT) pass2(k, 0.0);    // padding rows beyond the registers (k >= n)
+    for (int i = 0; i < YK; ++i) { const int k = sub + LPT * i; if (k < npad) pass2(k, yv[i], wreg[i]); }
+    for (int k = sub + LPT * YK; k < npad; k += LPT) pass2(k, 0.0, 0.0);    // padding rows beyond the registers (k >= n)
   } else {
-    for (int k = sub; k < npad; k += LPT) pass2(k, k < n ? Yt[(int64_t)k * ldy + j] : 0.0);
+    for (int k = sub; k < npad; k += LPT) pass2(k, k < n ? Yt[(int64_t)k * ldy + j] : 0.0, -1.0);
   }
+#ifdef PW_DIAG
+  pw_t[3] = __builtin_amdgcn_s_memtime();
+#endif
   if (sub == 0) {
 #pragma unroll
     for (int e = 0; e < NA; ++e) Ls[(int64_t)e * ldp + jc] = Li[e];
   }
-  // coefficients in the weight basis, 8 rows at a time over the lane's own individuals
+  // coefficients in the weight basis, 8 rows at a time over the lane's own individuals.  With the weights in registers
+  // (yreg) the loop over individuals is unrolled: its LDS reads are issued together instead of one round trip per
+  // individual, and no reciprocal is recomputed (s_memtime: this phase was 12-14 k of a wave's ~19 k cycles).
   for (int rb = 0; rb < R4; rb += 8) {
     double c8[8];
 #pragma unroll
     for (int u = 0; u < 8; ++u) c8[u] = 0.0;
-    for (int k = sub; k < n; k += LPT) {
-      const double w = fabs(fast_rcp(fma(delta, sLam[k], 1.0)));
-      if (rb + 8 <= rl) {                         // workgroup-uniform: the chunk's rows are all in LDS
+    if (yreg && rb + 8 <= rl) {                   // workgroup-uniform: weights in registers, the chunk's rows all in LDS
 #pragma unroll
-        for (int u = 0; u < 8; ++u) c8[u] = fma(sQ[(rb + u) * n + k], w, c8[u]);
-      } else {
+      for (int i = 0; i < YK; ++i) {
+        const int k = sub + LPT * i;
+        if (k < n) {
 #pragma unroll
-        for (int u = 0; u < 8; ++u)
-          if (rb + u < R) c8[u] = fma((rb + u < rl) ? sQ[(rb + u) * n + k] : Q[(size_t)(rb + u) * n + k], w, c8[u]);
+          for (int u = 0; u < 8; ++u) c8[u] = fma(sQ[(rb + u) * n + k], wreg[i], c8[u]);
+        }
+      }
+    } else {
+      for (int k = sub; k < n; k += LPT) {
+        const double w = fabs(fast_rcp(fma(delta, sLam[k], 1.0)));
+        if (rb + 8 <= rl) {                       // workgroup-uniform: the chunk's rows are all in LDS
+#pragma unroll
+          for (int u = 0; u < 8; ++u) c8[u] = fma(sQ[(rb + u) * n + k], w, c8[u]);
+        } else {
+#pragma unroll
+          for (int u = 0; u < 8; ++u)
+            if (rb + u < R) c8[u] = fma((rb + u < rl) ? sQ[(rb + u) * n + k] : Q[(size_t)(rb + u) * n + k], w, c8[u]);
+        }
       }
     }
 #pragma unroll
@@ -942,8 +979,16 @@ __global__ void __launch_bounds__(256) k_lr_panels_w(NullModel nm, const double*
       if (rb + u < R4 && sub == ((rb + u) % LPT)) Cp[(int64_t)(rb + u) * ldp + jc] = c;
     }
   }
+#ifdef PW_DIAG
+  pw_t[4] = __builtin_amdgcn_s_memtime();
+  if ((threadIdx.x & 63) == 0 && blockIdx.x % 97 == 0) printf("pw wg %d wave %d: loads+pass1 %llu  sums+chol %llu  pass2 %llu  coeffs %llu cycles\n", (int)blockIdx.x, (int)(threadIdx.x >> 6), pw_t[1] - pw_t[0], pw_t[2] - pw_t[1], pw_t[3] - pw_t[2], pw_t[4] - pw_t[3]);
+#endif
   };
   for (int b = 0; b < nbatch; ++b) do_column(col0 + ((int64_t)blockIdx.x * nbatch + b) * TPB + threadIdx.x / LPT);
+#ifdef PW_DIAG
+  __syncthreads();
+  if (threadIdx.x == 0 && blockIdx.x < 8192) g_pw_diag[3 * blockIdx.x + 2] = __builtin_amdgcn_s_memrealtime();
+#endif
 }
 
 // Guard of the low-rank form: relative residual |w_j - Q c_j| / |w_j| of the weight-basis expansion of EVERY trait,
@@ -1221,6 +1266,21 @@ int launch_lr_panels(blmm_ctx* ctx, const NullModel& nm, const double* Yt, int64
       default: return fail(ctx, BLMM_ERR_UNSUPPORTED, "number of null covariates (incl. intercept) must be 1..4");
     }
 #undef LPW
+#ifdef PW_DIAG
+    {
+      (void)hipStreamSynchronize(ctx->stream);
+      static unsigned long long z[3 * 8192];
+      (void)hipMemcpyFromSymbol(z, HIP_SYMBOL(g_pw_diag), sizeof(z));
+      const unsigned nb = wblocks < 8192 ? wblocks : 8192;
+      unsigned long long t0 = ~0ull, t1 = 0;
+      std::vector<double> st, dur, stage;
+      for (unsigned b = 0; b < nb; ++b) { if (z[3 * b] < t0) t0 = z[3 * b]; if (z[3 * b + 2] > t1) t1 = z[3 * b + 2]; }
+      for (unsigned b = 0; b < nb; ++b) { st.push_back((z[3 * b] - t0) * 0.01); stage.push_back((z[3 * b + 1] - z[3 * b]) * 0.01); dur.push_back((z[3 * b + 2] - z[3 * b]) * 0.01); }
+      std::sort(st.begin(), st.end()); std::sort(dur.begin(), dur.end()); std::sort(stage.begin(), stage.end());
+      fprintf(stderr, "panels_w diag: %u wgs, span %.1f us | start p10 %.1f p50 %.1f p90 %.1f max %.1f | staging p50 %.1f p90 %.1f | duration p10 %.1f p50 %.1f p90 %.1f max %.1f us\n",
+              nb, (t1 - t0) * 0.01, st[nb / 10], st[nb / 2], st[nb * 9 / 10], st[nb - 1], stage[nb / 2], stage[nb * 9 / 10], dur[nb / 10], dur[nb / 2], dur[nb * 9 / 10], dur[nb - 1]);
+    }
+#endif
     KCHECK();
     return BLMM_OK;
   }

@@ -1081,14 +1081,11 @@ __device__ __forceinline__ EllOut null_ell(double h2, const double* __restrict__
     }
   }
   logsum += log(prod);
+  syy = group_sum<LPT>(syy); logsum = group_sum<LPT>(logsum);
 #pragma unroll
-  for (int o = 1; o < LPT; o <<= 1) {
-    syy += __shfl_xor(syy, o, LPT); logsum += __shfl_xor(logsum, o, LPT);
+  for (int a = 0; a < NA; ++a) A[a] = group_sum<LPT>(A[a]);
 #pragma unroll
-    for (int a = 0; a < NA; ++a) A[a] += __shfl_xor(A[a], o, LPT);
-#pragma unroll
-    for (int q = 0; q < C; ++q) v[q] += __shfl_xor(v[q], o, LPT);
-  }
+  for (int q = 0; q < C; ++q) v[q] = group_sum<LPT>(v[q]);
   if (bad && nonpos) *nonpos = 1;
   // Cholesky A = L L', t = L^-1 v
   double L[NA], t[C], logdet = 0.0, tt = 0.0;
@@ -1139,11 +1136,7 @@ __device__ __forceinline__ EllOut null_ell(double h2, const double* __restrict__
 constexpr int NULL_NK = 20;
 
 template <int LPT>
-__device__ __forceinline__ double lpt_sum(double x) {
-#pragma unroll
-  for (int o = 1; o < LPT; o <<= 1) x += __shfl_xor(x, o, LPT);
-  return x;
-}
+__device__ __forceinline__ double lpt_sum(double x) { return group_sum<LPT>(x); }
 
 template <int C, int LPT>
 struct NullRegs {
@@ -1724,14 +1717,11 @@ __device__ __forceinline__ EllOut alt_ell(double h2, const double* __restrict__ 
   }
   logsum += log(prod);
   if (SQW) logsum *= 0.5;                       // sum ln t of the weights actually used, sqrt(w) = t^(-1/2)
+  syy = group_sum<LPT>(syy); logsum = group_sum<LPT>(logsum);
 #pragma unroll
-  for (int o = 1; o < LPT; o <<= 1) {
-    syy += __shfl_xor(syy, o, LPT); logsum += __shfl_xor(logsum, o, LPT);
+  for (int a = 0; a < NA; ++a) A[a] = group_sum<LPT>(A[a]);
 #pragma unroll
-    for (int a = 0; a < NA; ++a) A[a] += __shfl_xor(A[a], o, LPT);
-#pragma unroll
-    for (int q = 0; q < D; ++q) v[q] += __shfl_xor(v[q], o, LPT);
-  }
+  for (int q = 0; q < D; ++q) v[q] = group_sum<LPT>(v[q]);
   if (bad && nonpos) *nonpos = 1;
   double L[NA], t[D], logdet = 0.0, tt = 0.0;
 #pragma unroll
