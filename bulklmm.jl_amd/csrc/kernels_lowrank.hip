@@ -794,7 +794,8 @@ __global__ void __launch_bounds__(256) k_lr_panels_w(NullModel nm, const double*
                                                      const double* __restrict__ Z0, const double* __restrict__ lam,
                                                      const double* __restrict__ h2v, const double* __restrict__ Q,
                                                      const int* __restrict__ rk, int qcap, const int* __restrict__ perm,
-                                                     int64_t col0, int64_t ncol, int nbatch, double* __restrict__ P0,
+                                                     int64_t col0, int64_t ncol, const int64_t* __restrict__ counts, int nbatch,
+                                                     double* __restrict__ P0,
                                                      double* __restrict__ Cp, double* __restrict__ Ls, int64_t ldp,
                                                      int64_t* stat) {
 #ifdef PW_DIAG
@@ -944,6 +945,8 @@ __global__ void __launch_bounds__(256) k_lr_panels_w(NullModel nm, const double*
 #pragma unroll
     for (int e = 0; e < NA; ++e) Ls[(int64_t)e * ldp + jc] = Li[e];
   }
+  // A column of the shared-weights class (the front of the region) needs no coefficients: neither scan kernel reads them.
+  if (jc - col0 < counts[0]) return;
   // coefficients in the weight basis, 8 rows at a time over the lane's own individuals.  With the weights in registers
   // (yreg) the loop over individuals is unrolled: its LDS reads are issued together instead of one round trip per
   // individual, and no reciprocal is recomputed (s_memtime: this phase was 12-14 k of a wave's ~19 k cycles).
@@ -1003,7 +1006,8 @@ constexpr int LRR_QC = 96;    // basis rows mirrored in LDS (48 KB); the (rare) 
 __global__ void __launch_bounds__(256) k_lr_resid(int n, int64_t m, const double* __restrict__ lam,
                                                   const double* __restrict__ h2v, const double* __restrict__ Q,
                                                   const int* __restrict__ rk, const int* __restrict__ perm, int64_t col0,
-                                                  int64_t ncol, const double* __restrict__ Cp, int64_t ldp,
+                                                  int64_t ncol, const int64_t* __restrict__ counts,
+                                                  const double* __restrict__ Cp, int64_t ldp,
                                                   double* __restrict__ part /* [nslice][2][ldp] */) {
   extern __shared__ __attribute__((aligned(16))) double sh[];
   const int R = rk[0];
@@ -1020,6 +1024,7 @@ __global__ void __launch_bounds__(256) k_lr_resid(int n, int64_t m, const double
   __syncthreads();
   const int64_t j = col0 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;   // panel column; trait perm[j]
   if (j >= col0 + ncol) return;
+  if (j - col0 < counts[0]) return;        // shared-weights class: no expansion to check (its criterion IS the bound)
   const int64_t jt = perm[j];
   if (jt < 0 || jt >= m) return;
   const double h2 = h2v[jt];
@@ -1054,11 +1059,12 @@ __global__ void __launch_bounds__(256) k_lr_resid(int n, int64_t m, const double
 
 __global__ void __launch_bounds__(256) k_lr_resid2(int nslice, int64_t m, double tol2, const double* __restrict__ part,
                                                    int64_t ldp, const int* __restrict__ rk, const int* __restrict__ perm,
-                                                   int64_t col0, int64_t ncol, int* __restrict__ flag_list, int64_t* stat) {
+                                                   int64_t col0, int64_t ncol, const int64_t* __restrict__ counts,
+                                                   int* __restrict__ flag_list, int64_t* stat) {
   if (rk[0] < 0) return;
   const int64_t j = col0 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;   // panel column
   double rel2 = 0.0;
-  if (j < col0 + ncol && perm[j] >= 0 && perm[j] < m) {
+  if (j < col0 + ncol && j - col0 >= counts[0] && perm[j] >= 0 && perm[j] < m) {
     double rr = 0.0, ww = 0.0;
     for (int s = 0; s < nslice; ++s) { rr += part[((size_t)s * 2 + 0) * ldp + j]; ww += part[((size_t)s * 2 + 1) * ldp + j]; }
     rel2 = rr / ww;
@@ -1257,7 +1263,7 @@ int launch_lr_panels(blmm_ctx* ctx, const NullModel& nm, const double* Yt, int64
     const int wqcap = (wbase + sizeof(double) * nm.n <= 60 * 1024) ? (int)std::min<size_t>((size_t)nm.n, (60 * 1024 - wbase) / (sizeof(double) * (size_t)nm.n)) : 0;
     const size_t wlds = wbase + sizeof(double) * (size_t)wqcap * nm.n;
 #define LPW(C) do { if (wlds > 48 * 1024) BLMM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_lr_panels_w<C, LPT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)wlds)); \
-    hipLaunchKernelGGL((k_lr_panels_w<C, LPT>), dim3(wblocks), dim3(256), wlds, ctx->stream, nm, Yt, ldy, m, Z0, lam, h2, Q, rk, wqcap, perm, rg.col0, rg.ncol, nbatch, P0, Cp, Ls, ldp, stat); } while (0)
+    hipLaunchKernelGGL((k_lr_panels_w<C, LPT>), dim3(wblocks), dim3(256), wlds, ctx->stream, nm, Yt, ldy, m, Z0, lam, h2, Q, rk, wqcap, perm, rg.col0, rg.ncol, rg.counts, nbatch, P0, Cp, Ls, ldp, stat); } while (0)
     switch (nm.c) {
       case 1: LPW(1); break;
       case 2: LPW(2); break;
@@ -1312,9 +1318,9 @@ int launch_lr_resid(blmm_ctx* ctx, const NullModel& nm, int64_t m, double tol, c
   if (lds > 48 * 1024)
     BLMM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_lr_resid), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   hipLaunchKernelGGL(k_lr_resid, dim3((unsigned)((rg.ncol + 255) / 256), (unsigned)nslice), dim3(256), lds, ctx->stream, nm.n, m, lam, h2, Q,
-                     rk, perm, rg.col0, rg.ncol, Cp, ldp, part);
+                     rk, perm, rg.col0, rg.ncol, rg.counts, Cp, ldp, part);
   hipLaunchKernelGGL(k_lr_resid2, dim3((unsigned)((rg.ncol + 255) / 256)), dim3(256), 0, ctx->stream, nslice, m, tol * tol, part, ldp, rk,
-                     perm, rg.col0, rg.ncol, flag_list, stat);
+                     perm, rg.col0, rg.ncol, rg.counts, flag_list, stat);
   KCHECK();
   return BLMM_OK;
 }
