@@ -86,7 +86,8 @@ typedef struct blmm_status {
                               the full-length sums (k_scan_fix), so every returned LOD is either guarded or exact      */
   int64_t lowrank_shared;  /* traits whose weights are 1 to within the same tolerance (likelihood peaks at h2 = 0): their
                               denominators are the per-marker constants of the unweighted model, no basis needed          */
-  double lowrank_resid;    /* largest relative residual |w_j - Q Q'w_j| / |w_j| over ALL traits (before the re-scan)  */
+  double lowrank_resid;    /* largest relative residual |w_j - Q Q'w_j| / |w_j| over all traits of the rank-R class (before the
+                              re-scan); the shared-weights class is bounded by its own criterion, the same tolerance         */
   double t_eigen_ms, t_rotate_ms, t_h2_ms, t_prep_ms, t_scan_ms, t_total_ms;
 } blmm_status;
 
