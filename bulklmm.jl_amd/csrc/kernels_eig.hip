@@ -239,6 +239,9 @@ __global__ void __launch_bounds__(512) k_sytrd(const double* __restrict__ A, int
         sa[j] = __longlong_as_double((long long)((q3 << 32) | (q2 & 0xffffffffull)));
         if (j > k + 1) s4 = fma(pj, sx[j], s4);
       }
+#ifdef TQL_DIAG
+      if (bad && (t & 63) == 0) printf("sytrd wg %d/%d thread %d gave up at step %d (n %d, nloc %d)\n", g, G, t, k, n, nloc);
+#endif
       if (bad) __hip_atomic_store(ex.abort, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     } else {
       __syncthreads();     // G = 1: sp / sa were written by the row waves of this workgroup
@@ -309,13 +312,23 @@ __global__ void __launch_bounds__(64) k_tql_leaves(const double* __restrict__ d,
     for (int c = 0; c < N; ++c) Z[r][c] = (r == c) ? 1.0 : 0.0;
   }
   __syncthreads();
-  // the QL iteration is the same scalar sequence in every lane (d, e in LDS); only the row of Z differs
+  // the QL iteration is the same scalar sequence in every lane (d, e in LDS); only the row of Z differs.
+  // An off-diagonal is negligible relative to its two diagonal neighbours (LAPACK's test) OR relative to the norm of T:
+  // on a kinship with a block of (numerically) zero eigenvalues -- d = 0 +- rounding, e = rounding noise -- the first test
+  // alone never fires and the iteration burns its limit resolving noise (found by the fuzzer: K from ONE 0/1 marker,
+  // eigenvalues {0 x 123, 60, 65}).  The second test costs eps * |T| of absolute accuracy, the backward-stable bound.
+  // (the norm of the WHOLE tridiagonal matrix: on a rank-2 kinship the trailing part of T is the rounding residue of the
+  // rounding residue ..., entries of 1e-163 whose squares underflow -- negligible against |T|, not against each other)
+  double tnorm = 0.0;
+  for (int j = threadIdx.x; j < n; j += 64) tnorm = fmax(tnorm, fmax(fabs(d[j]), (j < n - 1) ? fabs(e[j]) : 0.0));
+  tnorm = wmax(tnorm);
+  const double abs_small = EPS * tnorm;
   bool failed = false;
   for (int l = 0; l < N && !failed; ++l) {
     int iter = 0;
     for (;;) {
       // first m >= l with a negligible off-diagonal e[m] (m = N-1 if none): every lane tests its own index, one ballot
-      const bool small = (r >= N - 1) || (fabs(se[r]) <= EPS * (fabs(sd[r]) + fabs(sd[r + 1])));
+      const bool small = (r >= N - 1) || (fabs(se[r]) <= EPS * (fabs(sd[r]) + fabs(sd[r + 1]))) || (fabs(se[r]) <= abs_small);
       const unsigned long long mask = __ballot(small) >> l;
       const int m = l + (int)__builtin_ctzll(mask | (1ull << (N - 1 - l)));
       if (m == l) break;
@@ -361,6 +374,12 @@ __global__ void __launch_bounds__(64) k_tql_leaves(const double* __restrict__ d,
   }
   __syncthreads();
   if (failed && r == 0) stat[11] = -8;
+#ifdef TQL_DIAG
+  if (failed && r == 0) {
+    printf("tql leaf %d [%d,%d) failed; tnorm %g\n", (int)blockIdx.x, lo, hi, tnorm);
+    for (int j = 0; j < N; ++j) printf("  j %d d %.17g e %.17g  (orig d %.17g e %.17g)\n", j, sd[j], se[j], d[lo + j], (lo + j < n - 1) ? e[lo + j] : 0.0);
+  }
+#endif
   // ascending order (stable rank)
   if (r < N) {
     int rank = 0;
@@ -1054,12 +1073,15 @@ __global__ void __launch_bounds__(1024) k_eig_small(const double* __restrict__ A
       w.M2[(lo + r) * n + lo + r] = 1.0;
     }
     double* Z = w.M2 + lo * n + lo;   // Z[r][c] = Z[r * n + c]
+    double tnorm = 0.0;                // see k_tql_leaves: negligible also relative to the norm of T
+    for (int j = 0; j < n; ++j) tnorm = fmax(tnorm, fmax(fabs(w.d[j]), (j < n - 1) ? fabs(w.e[j]) : 0.0));
+    const double abs_small = EPS * tnorm;
     bool failed = false;
     for (int l = 0; l < N && !failed; ++l) {
       int iter = 0;
       for (;;) {
         int m = l;
-        for (; m < N - 1; ++m) { const double dd = fabs(sd[m]) + fabs(sd[m + 1]); if (fabs(se[m]) <= EPS * dd) break; }
+        for (; m < N - 1; ++m) { const double dd = fabs(sd[m]) + fabs(sd[m + 1]); if (fabs(se[m]) <= EPS * dd || fabs(se[m]) <= abs_small) break; }
         if (m == l) break;
         if (++iter > 80) { failed = true; break; }
         double gg = (sd[l + 1] - sd[l]) / (2.0 * se[l]);

@@ -804,3 +804,37 @@ def test_scan_alt_matches_oracle(blmm, gpu_ctx, case):
         assert np.allclose(pv["log10pvals"][sel], O.lod2log10p(pv["lod"][sel], 1), rtol=1e-9)
     with pytest.raises(blmm.BulkLMMError, match="not supported for the alternative"):
         blmm.scan(y, G, K, assumption="alt", permutation_test=True, ctx=ctx)
+
+
+@pytest.mark.parametrize("n", [80, 124, 125, 200, 333])
+def test_eigensolvers_on_a_block_of_zero_eigenvalues(blmm, n):
+    """A kinship from ONE 0/1 marker (found by tools/fuzz_parity.py at n = 125): entries 0 / 1 only, eigenvalues {0 x (n - 2), a, b}.
+    After two Householder steps the trailing matrix is the rounding residue of the rounding residue ...: T ends in entries of
+    1e-163 whose squares underflow.  LAPACK's neighbour-relative test never declares such off-diagonals negligible (LAPACK
+    rescales T instead); the QL leaves ran into their iteration limit and the call failed with code -8.  Both device solvers
+    (LDS Jacobi up to n = 124, tridiagonalisation + divide and conquer beyond) on this spectrum, eigenvalues to 1e-12 |K|, and
+    the scan on top of it."""
+    rng = np.random.default_rng(n)
+    g = (rng.random(n) < 0.5).astype(np.float64)
+    K = O.calcKinship(g[:, None])
+    assert set(np.unique(K)) <= {0.0, 1.0}
+    Y = rng.standard_normal((n, 3))
+    G = np.hstack([g[:, None], rng.random((n, 40))])
+    ctx = blmm.Context(0)
+    y0, X0, lam = blmm.transform_rotation(Y, np.hstack([np.ones((n, 1)), G]), K, addIntercept=False, ctx=ctx)
+    ref = np.linalg.eigvalsh(K)
+    assert np.abs(np.sort(np.asarray(lam)) - ref).max() <= 1e-12 * ref.max()
+    got = blmm.bulkscan_null(Y, G[:, 1:], K, ctx=ctx)
+    pin = O.bulkscan_null(Y, G[:, 1:], K, h2_override=got.h2_null_list)
+    assert_lod_close(got.L, pin.L, rtol=1e-6, atol=1e-9)
+    ctx.close()
+
+
+def test_dc_eigensolver_fuzz_case_one_marker_kinship(blmm):
+    """The exact input of the failing fuzz case (seed 6, case 63): n = 125, K = calcKinship of one marker."""
+    Y, G, K, _ = make_data(n=125, p=1, m=2, seed=1000 + 63 + 7919 * 6, ncov=0, bxd=False)
+    ctx = blmm.Context(0)
+    _, _, lam = blmm.transform_rotation(Y, np.hstack([np.ones((125, 1)), G]), K, addIntercept=False, ctx=ctx)
+    ref = np.linalg.eigvalsh(K)
+    assert np.abs(np.sort(np.asarray(lam)) - ref).max() <= 1e-12 * max(1.0, np.abs(ref).max())
+    ctx.close()
