@@ -105,7 +105,16 @@ __device__ __forceinline__ double ld_sc1(const double* p) {
 struct SytrdEx {          // global exchange area of k_sytrd
   unsigned long long* gr; // [2 parities][n rows][4 granules]: {p lo, p hi, a lo, a hi}, each (tag << 32) | 32 data bits
   int* abort;             // set when a workgroup gave up waiting
+  const unsigned long long* anorm;   // bits of max |A_ij| (k_absmax)
 };
+
+// max |A_ij| as the bit pattern of a non-negative double (orders like an integer); *out zeroed by the launcher
+__global__ void __launch_bounds__(256) k_absmax(const double* __restrict__ A, int64_t cnt, unsigned long long* __restrict__ out) {
+  double m = 0.0;
+  for (int64_t e0 = (int64_t)blockIdx.x * 256 + threadIdx.x; e0 < cnt; e0 += (int64_t)gridDim.x * 256) m = fmax(m, fabs(A[e0]));
+  m = wmax(m);
+  if ((threadIdx.x & 63) == 0 && m > 0.0) atomicMax(out, (unsigned long long)__double_as_longlong(m));
+}
 
 // ---------------------------------------------------------------------------------------------------------------------
 // 1. tridiagonalisation.  Workgroup g of G owns the rows i = g, g + G, ... (local row li = i / G), all n columns of
@@ -160,6 +169,12 @@ __global__ void __launch_bounds__(512) k_sytrd(const double* __restrict__ A, int
   }
   __syncthreads();
   bool aborted = false;
+  // A column whose norm is negligible against |A| gets NO reflector (as an exactly zero one): with tau from a norm whose
+  // square is in the denormal range the reflector is not orthogonal -- on a rank-2 kinship the trailing matrix is the
+  // rounding residue of the rounding residue ..., 1e-163 after a few steps, and the eigenvectors of the zero cluster came
+  // out 0.19 off orthogonality (found by the fuzzer; LAPACK's dlarfg rescales such columns instead).
+  const double anorm = __longlong_as_double((long long)*ex.anorm);
+  const double s1_negl = (EPS * anorm) * (EPS * anorm);
 #ifdef SYTRD_PROF
   long long pf[6] = {0, 0, 0, 0, 0, 0}, pt0 = __builtin_amdgcn_s_memtime();
 #define PSTAMP(i) do { const long long t1__ = __builtin_amdgcn_s_memtime(); pf[i] += t1__ - pt0; pt0 = t1__; } while (0)
@@ -176,7 +191,7 @@ __global__ void __launch_bounds__(512) k_sytrd(const double* __restrict__ A, int
     }
     const double alpha = sx[k + 1];
     double beta, tk, sc;
-    if (s1 == 0.0) { beta = alpha; tk = 0.0; sc = 0.0; }
+    if (s1 <= s1_negl) { beta = alpha; tk = 0.0; sc = 0.0; }
     else { beta = -copysign(sqrt(fma(alpha, alpha, s1)), alpha); tk = (beta - alpha) / beta; sc = 1.0 / (alpha - beta); }
     const double vpk1 = svp[k + 1], wpk1 = swp[k + 1];
     const double vpv = fma(sc, s2, vpk1), wpv = fma(sc, s3, wpk1);      // vp'v and wp'v with v = (1, sc x[k+2:])
@@ -978,8 +993,11 @@ __global__ void __launch_bounds__(1024) k_eig_small(const double* __restrict__ A
 #else
 #define QSTAMP(i) do { } while (0)
 #endif
-  for (int e0 = t; e0 < n * n; e0 += NT) { w.M1[e0] = A[e0]; w.M2[e0] = 0.0; }
+  double amax = 0.0;
+  for (int e0 = t; e0 < n * n; e0 += NT) { const double a = A[e0]; w.M1[e0] = a; w.M2[e0] = 0.0; amax = fmax(amax, fabs(a)); }
   for (int j = t; j < n; j += NT) { w.svp[j] = 0.0; w.swp[j] = 0.0; }
+  amax = block_max(amax, w.red);                 // (two barriers inside)
+  const double s1_negl = (EPS * amax) * (EPS * amax);   // see k_sytrd: no reflector for a column negligible against |A|
   __syncthreads();
   QSTAMP(0);
   // ---- 1. tridiagonalisation ----------------------------------------------------------------------------------------
@@ -990,7 +1008,7 @@ __global__ void __launch_bounds__(1024) k_eig_small(const double* __restrict__ A
     s1 = wsum(s1);
     const double alpha = w.sx[k + 1];
     double beta, tk, sc;
-    if (s1 == 0.0) { beta = alpha; tk = 0.0; sc = 0.0; }
+    if (s1 <= s1_negl) { beta = alpha; tk = 0.0; sc = 0.0; }
     else { beta = -copysign(sqrt(fma(alpha, alpha, s1)), alpha); tk = (beta - alpha) / beta; sc = 1.0 / (alpha - beta); }
     for (int j = k + 1 + lane; j < n; j += 64) { const double v = (j == k + 1) ? 1.0 : w.sx[j] * sc; w.sv[j] = v; Vg[k * n + j] = v; }
     if (lane == 0) { w.d[k] = akk; w.e[k] = beta; w.tau[k] = tk; s_sc[0] = tk; }
@@ -1258,7 +1276,10 @@ int launch_eig_dc(blmm_ctx* ctx, const double* A, int n, double* lraw, double* e
     nloc = (n + G - 1) / G;
     const size_t lds = sizeof(double) * ((size_t)7 * n + 128 + (size_t)nloc * n);
     SytrdEx ex; ex.gr = reinterpret_cast<unsigned long long*>(rowbuf); ex.abort = sync;      // 8 n granules in Dm (unused until the merges)
+    ex.anorm = reinterpret_cast<const unsigned long long*>(sync + 4);                          // sync[4..5], 8-byte aligned
     BLMM_HIP(hipMemsetAsync(sync, 0, sizeof(int) * 8, ctx->stream));
+    hipLaunchKernelGGL(k_absmax, dim3((unsigned)std::min<int64_t>(256, ((int64_t)n * n + 255) / 256)), dim3(256), 0, ctx->stream, A, (int64_t)n * n,
+                       reinterpret_cast<unsigned long long*>(sync + 4));
     BLMM_HIP(hipMemsetAsync(rowbuf, 0, sizeof(unsigned long long) * 8 * (size_t)n, ctx->stream));   // tags 0: nothing published
     BLMM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sytrd), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     int nthr = 512;                                           // barriers at 1024 threads cost almost twice as much

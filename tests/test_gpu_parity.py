@@ -830,6 +830,25 @@ def test_eigensolvers_on_a_block_of_zero_eigenvalues(blmm, n):
     ctx.close()
 
 
+@pytest.mark.parametrize("seed", [35, 36, 41])
+def test_eigenvectors_of_the_zero_cluster_stay_orthogonal(blmm, seed):
+    """Same family of kinships (n = 125, one 0/1 marker; seed 35 is the fuzzer's case): eigenvalues and K = U diag U' were
+    right to 1e-14 while U'U was 0.19 off the identity INSIDE the zero-eigenvalue cluster (the residual cannot see that) --
+    Householder reflectors built from norms whose squares sat in the denormal range.  Columns negligible against |K| now get
+    no reflector.  The rotation is only an isometry -- and every LOD only right -- if U is orthogonal."""
+    n = 125
+    gk = (np.random.default_rng(seed).random((n, 3)) < 0.5).astype(np.float64)
+    K = O.calcKinship(gk[:, :1])
+    ctx = blmm.Context(0)
+    Ut, _, lam = blmm.transform_rotation(np.eye(n), np.ones((n, 2)), K, addIntercept=False, ctx=ctx)
+    U = np.asarray(Ut).T
+    lam = np.asarray(lam)
+    assert np.abs(U.T @ U - np.eye(n)).max() <= 1e-12
+    assert np.abs(K - (U * lam) @ U.T).max() <= 1e-12 * np.abs(K).max() * n
+    assert np.abs(np.sort(lam) - np.linalg.eigvalsh(K)).max() <= 1e-12 * np.abs(lam).max()
+    ctx.close()
+
+
 def test_dc_eigensolver_fuzz_case_one_marker_kinship(blmm):
     """The exact input of the failing fuzz case (seed 6, case 63): n = 125, K = calcKinship of one marker."""
     Y, G, K, _ = make_data(n=125, p=1, m=2, seed=1000 + 63 + 7919 * 6, ncov=0, bxd=False)

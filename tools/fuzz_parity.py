@@ -13,7 +13,8 @@ rng = np.random.default_rng(seed0)
 fails = 0
 t0 = time.time()
 for case in range(ncases):
-    n = int(rng.choice([5, 8, 13, 31, 47, 64, 79, 80, 93, 100, 111, 124, 125, 140]))
+    n = int(rng.choice([5, 8, 13, 31, 47, 64, 79, 80, 93, 100, 111, 124, 125, 140, 160, 200, 260]))
+    kkind = str(rng.choice(["markers", "markers", "one-marker", "few-markers", "duplicated-individuals"]))
     p = int(rng.choice([1, 2, 7, 63, 64, 65, 129, 300]))
     m = int(rng.choice([1, 2, 15, 16, 17, 63, 70, 1030]))
     ncov = int(rng.choice([0, 0, 1, 2]))
@@ -25,8 +26,9 @@ for case in range(ncases):
     use_w = bool(rng.random() < 0.2)
     prior = (1.0, 0.1) if rng.random() < 0.2 else (1.0, 0.0)
     if m > 100 and (n > 100 or method == "alt-grid"): m = 70          # keep the oracle quick
+    if n > 140: m = min(m, 17); p = min(p, 129)
     if n < 10: ncov = 0
-    desc = f"case {case}: n={n} p={p} m={m} ncov={ncov} {method} reml={reml} svd={svd} weights={use_w} prior={prior} optim_interval={oi}"
+    desc = f"case {case}: n={n} p={p} m={m} ncov={ncov} K={kkind} {method} reml={reml} svd={svd} weights={use_w} prior={prior} optim_interval={oi}"
     try:
         Y, G, K, Cov = make_data(n=n, p=p, m=m, seed=1000 + case + 7919 * seed0, ncov=ncov, bxd=(n == 79))
         # a marker that is constant over the individuals (common at n = 5 .. 13) is collinear with the intercept: its projected
@@ -35,6 +37,16 @@ for case in range(ncases):
         const = np.ptp(G, axis=0) == 0
         if const.any():
             G = G.copy(); G[:, const] = np.random.default_rng(case).random((n, int(const.sum())))
+        # degenerate kinships: the spectra that stress the eigensolvers (blocks of exactly equal / zero eigenvalues)
+        if kkind != "markers" and n >= 13:
+            gk = (np.random.default_rng(case + 5).random((n, 3)) < 0.5).astype(np.float64)
+            if kkind == "one-marker":
+                K = O.calcKinship(gk[:, :1])
+            elif kkind == "few-markers":
+                K = O.calcKinship(gk)
+            else:
+                Gd = G.copy(); Gd[n // 2:] = Gd[: n - n // 2]
+                K = np.round(O.calcKinship(Gd), 12)
         w = rng.uniform(0.5, 2.0, size=n) if use_w else None
         kw = dict(reml=reml, decomp_scheme="svd" if svd else "eigen", prior_variance=prior[0], prior_sample_size=prior[1])
         grid = [i / 10.0 for i in range(10)]
