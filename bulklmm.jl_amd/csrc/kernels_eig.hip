@@ -314,7 +314,7 @@ __global__ void __launch_bounds__(512) k_sytrd(const double* __restrict__ A, int
 // ---------------------------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(64) k_tql_leaves(const double* __restrict__ d, const double* __restrict__ e, int n,
                                                    const int* __restrict__ bounds, double* __restrict__ lam,
-                                                   double* __restrict__ Q, int64_t* stat) {
+                                                   double* __restrict__ Q, int64_t* stat, double* __restrict__ tnorm_out) {
   __shared__ double sd[LEAF + 1], se[LEAF + 1], Z[LEAF][LEAF + 1];
   __shared__ int sidx[LEAF];
   const int lo = bounds[blockIdx.x], hi = bounds[blockIdx.x + 1], N = hi - lo, r = threadIdx.x;
@@ -337,6 +337,7 @@ __global__ void __launch_bounds__(64) k_tql_leaves(const double* __restrict__ d,
   double tnorm = 0.0;
   for (int j = threadIdx.x; j < n; j += 64) tnorm = fmax(tnorm, fmax(fabs(d[j]), (j < n - 1) ? fabs(e[j]) : 0.0));
   tnorm = wmax(tnorm);
+  if (blockIdx.x == 0 && threadIdx.x == 0) *tnorm_out = tnorm;     // the merges' deflation tolerance is relative to it
   const double abs_small = EPS * tnorm;
   bool failed = false;
   for (int l = 0; l < N && !failed; ++l) {
@@ -423,6 +424,7 @@ struct DcWs {
   double *dl, *zl, *zh, *defld, *lamnew, *rotc, *rots, *rho;
   int *colidx, *deflcol, *rota, *rotb, *posn, *posd, *info;   // info[4*node + {0: K, 1: ndefl, 2: nrot}]
   const int* nodes;         // [3*node + {lo, mid, hi}]
+  const double* tnorm;      // max-norm of T (k_tql_leaves)
 };
 
 __global__ void __launch_bounds__(1024) k_dc_deflate(DcWs w) {
@@ -447,7 +449,10 @@ __global__ void __launch_bounds__(1024) k_dc_deflate(DcWs w) {
   for (int j = t; j < N; j += NT) { dm = fmax(dm, fabs(sd[j])); zm = fmax(zm, fabs(sz[j])); }
   dm = block_max(dm, red);
   zm = block_max(zm, red);
-  const double tol = 8.0 * EPS * fmax(dm, zm);
+  // dlaed2's tolerance 8 eps max(|d|, |z|) is meant for a matrix scaled to unit norm (dstedc scales T first): z has unit norm
+  // whatever the scale of T, so on the unscaled matrix the z term carries |T| (a kinship scaled by 1e-150 deflated every
+  // merge completely: found by tools/fuzz_eig.py)
+  const double tol = 8.0 * EPS * fmax(dm, zm * *w.tnorm);
   // sorted copies (ds, zs, ord) so that the serial scan below walks consecutive LDS words
   double* ds = red + 16 + (N + 1) / 2;   // past ord (N ints)
   double* zs = ds + N;
@@ -797,7 +802,7 @@ struct SmallWs {   // LDS carve-up (doubles unless noted)
 };
 
 // merge of the solved halves [lo, mid) and [mid, hi) inside the workgroup (same steps as the k_dc_* kernels)
-__device__ void small_merge(const SmallWs& w, int n, int lo, int mid, int hi, const double* lamIn, double* lamOut, int* s_info) {
+__device__ void small_merge(const SmallWs& w, int n, int lo, int mid, int hi, const double* lamIn, double* lamOut, int* s_info, double tnorm) {
   const int t = threadIdx.x, NT = blockDim.x, lane = t & 63, wave = t >> 6, nwave = NT >> 6;
   const int N = hi - lo;
   const double beta = w.e[mid - 1];
@@ -816,7 +821,7 @@ __device__ void small_merge(const SmallWs& w, int n, int lo, int mid, int hi, co
   for (int j = t; j < N; j += NT) { dm = fmax(dm, fabs(sd[j])); zm = fmax(zm, fabs(sz[j])); }
   dm = block_max(dm, w.red);
   zm = block_max(zm, w.red);
-  const double tol = 8.0 * EPS * fmax(dm, zm);
+  const double tol = 8.0 * EPS * fmax(dm, zm * tnorm);   // see k_dc_deflate
   for (int j = t; j < N; j += NT) {
     const double v = sd[j];
     int rank = 0;
@@ -1148,11 +1153,13 @@ __global__ void __launch_bounds__(1024) k_eig_small(const double* __restrict__ A
   __syncthreads();
   QSTAMP(2);
   // ---- 3. merges -----------------------------------------------------------------------------------------------------
+  double tnorm_all = 0.0;            // max-norm of T: the deflation tolerance is relative to it (k_dc_deflate)
+  for (int j = 0; j < n; ++j) tnorm_all = fmax(tnorm_all, fmax(fabs(w.d[j]), (j < n - 1) ? fabs(w.e[j]) : 0.0));
   double* lamIn = w.lamA; double* lamOut = w.lamB;
   for (int width = 1; width < nl; width *= 2) {
     for (int b0 = 0; b0 + 2 * width <= nl; b0 += 2 * width) {
       const int lo = bound(b0), mid = bound(b0 + width), hi = bound(b0 + 2 * width);
-      small_merge(w, n, lo, mid, hi, lamIn, lamOut, s_info);
+      small_merge(w, n, lo, mid, hi, lamIn, lamOut, s_info, tnorm_all);
     }
     { double* tmp = lamIn; lamIn = lamOut; lamOut = tmp; }
     __syncthreads();
@@ -1293,10 +1300,11 @@ int launch_eig_dc(blmm_ctx* ctx, const double* A, int n, double* lraw, double* e
   // a node reads the full square [lo, hi)^2 of its input Q: the blocks off the solved halves' diagonal must read as zero
   // (block-diagonal eigenvector matrix); both ping-pong buffers, because every level leaves such blocks unwritten
   BLMM_HIP(hipMemsetAsync(Qa, 0, sizeof(double) * 2 * nn, ctx->stream));
-  hipLaunchKernelGGL(k_tql_leaves, dim3(nl), dim3(64), 0, ctx->stream, d, e, n, bounds_dev, lamA, Qa, stat);
+  hipLaunchKernelGGL(k_tql_leaves, dim3(nl), dim3(64), 0, ctx->stream, d, e, n, bounds_dev, lamA, Qa, stat, rho + nnodes_total);   // |T| -> the spare doubles behind rho
   KCHECK();
   // ---- 3. merges ----
   DcWs w;
+  w.tnorm = rho + nnodes_total;
   w.n = n; w.e = e; w.Dm = Dm; w.Wt = Wt; w.dl = dl; w.zl = zl; w.zh = zh; w.defld = defld; w.lamnew = lamnew;
   w.rotc = rotc; w.rots = rots; w.colidx = colidx; w.deflcol = deflcol; w.rota = rota; w.rotb = rotb; w.posn = posn; w.posd = posd;
   double* lamIn = lamA; double* lamOut = lamB; double* Qin = Qa; double* Qout = Qb;

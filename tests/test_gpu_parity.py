@@ -857,3 +857,28 @@ def test_dc_eigensolver_fuzz_case_one_marker_kinship(blmm):
     ref = np.linalg.eigvalsh(K)
     assert np.abs(np.sort(np.asarray(lam)) - ref).max() <= 1e-12 * max(1.0, np.abs(ref).max())
     ctx.close()
+
+
+@pytest.mark.parametrize("n,kind", [(64, "clusters"), (124, "clusters"), (200, "clusters"), (79, "tiny"), (200, "tiny"), (333, "huge"),
+                                    (92, "identity"), (160, "rank1+diag")])
+def test_eigensolvers_on_clustered_and_rescaled_spectra(blmm, n, kind):
+    """tools/fuzz_eig.py's findings as fixed cases: (i) four 16-fold eigenvalues left K - U diag U' at 3e-9 |K| in the LDS
+    Jacobi -- 45-degree rotations between equal diagonal entries re-mix cross terms the sweep had already annihilated, so a
+    sweep with a large-angle rotation is never the last one; (ii) a kinship scaled by 1e-40 was deflated completely by the
+    divide-and-conquer merges -- dlaed2's tolerance assumes a matrix scaled to unit norm, the z term now carries |T|."""
+    rng = np.random.default_rng(n + len(kind))
+    Q, _ = np.linalg.qr(rng.standard_normal((n, n)))
+    lam = {"clusters": np.repeat(rng.uniform(0.1, 10.0, 4), -(-n // 4))[:n], "tiny": rng.uniform(0.1, 10.0, n) * 1e-40,
+           "huge": rng.uniform(0.1, 10.0, n) * 1e40, "identity": np.full(n, 2.5),
+           "rank1+diag": np.concatenate([[float(n)], np.full(n - 1, 0.5)])}[kind]
+    K = (Q * lam) @ Q.T
+    K = (K + K.T) / 2 if kind != "identity" else 2.5 * np.eye(n)
+    ctx = blmm.Context(0)
+    Ut, _, lam_d = blmm.transform_rotation(np.eye(n), np.ones((n, 2)), K, addIntercept=False, ctx=ctx)
+    U = np.asarray(Ut).T
+    lam_d = np.asarray(lam_d)
+    sc = np.abs(K).max()
+    assert np.abs(U.T @ U - np.eye(n)).max() <= 1e-12
+    assert np.abs(K - (U * lam_d) @ U.T).max() <= 1e-12 * n * sc
+    assert np.abs(np.sort(lam_d) - np.linalg.eigvalsh(K)).max() <= 1e-12 * sc
+    ctx.close()
