@@ -753,7 +753,7 @@ int blmm_kinship_rounded(blmm_ctx* ctx, const double* G, int64_t n, int64_t p, i
   if ((rc = ensure(ctx, ctx->inK, sizeof(double) * n * n))) return rc;
   BLMM_HIP(hipMemcpyAsync(ctx->inG.p, G, sizeof(double) * n * p, hipMemcpyHostToDevice, ctx->stream));
   if ((rc = blmm_kinship_dev(ctx, ptr<double>(ctx->inG), n, p, ptr<double>(ctx->inK)))) return rc;
-  if (digits >= 0)
+  if (digits >= 0 && digits <= 17)   // beyond 17 digits rounding a double changes nothing (and 10^digits would overflow)
     hipLaunchKernelGGL(k_round_digits, dim3((unsigned)((n * n + 255) / 256)), dim3(256), 0, ctx->stream, ptr<double>(ctx->inK), n * n, std::pow(10.0, (double)digits));
   BLMM_HIP(hipMemcpyAsync(K_out, ctx->inK.p, sizeof(double) * n * n, hipMemcpyDeviceToHost, ctx->stream));
   BLMM_HIP(hipStreamSynchronize(ctx->stream));

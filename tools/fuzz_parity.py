@@ -15,9 +15,9 @@ t0 = time.time()
 for case in range(ncases):
     n = int(rng.choice([5, 8, 13, 31, 47, 64, 79, 80, 93, 100, 111, 124, 125, 140, 160, 200, 260]))
     kkind = str(rng.choice(["markers", "markers", "one-marker", "few-markers", "duplicated-individuals"]))
-    p = int(rng.choice([1, 2, 7, 63, 64, 65, 129, 300]))
-    m = int(rng.choice([1, 2, 15, 16, 17, 63, 70, 1030]))
-    ncov = int(rng.choice([0, 0, 1, 2]))
+    p = int(rng.choice([1, 2, 7, 63, 64, 65, 127, 128, 129, 255, 256, 257, 300]))
+    m = int(rng.choice([1, 2, 15, 16, 17, 63, 64, 65, 70, 128, 129, 1030, 2100]))
+    ncov = int(rng.choice([0, 0, 1, 2, 3]))
     if ncov + 2 >= n: ncov = 0
     method = str(rng.choice(["null-exact", "null-exact", "null-grid", "alt-grid", "perms", "scan-alt"]))
     oi = int(rng.choice([1, 1, 1, 2, 3]))
@@ -26,6 +26,7 @@ for case in range(ncases):
     use_w = bool(rng.random() < 0.2)
     prior = (1.0, 0.1) if rng.random() < 0.2 else (1.0, 0.0)
     if m > 100 and (n > 100 or method == "alt-grid"): m = 70          # keep the oracle quick
+    if m > 1100 and n > 64: m = 1030
     if n > 140: m = min(m, 17); p = min(p, 129)
     if n < 10: ncov = 0
     desc = f"case {case}: n={n} p={p} m={m} ncov={ncov} K={kkind} {method} reml={reml} svd={svd} weights={use_w} prior={prior} optim_interval={oi}"
