@@ -279,3 +279,29 @@ def test_c_openmp_restatement_equals_numpy_restatement(ncov, reml, prior, oi):
     pin = O.bulkscan_null(Y, G, K, Covar=Cov, prior_variance=prior[0], prior_sample_size=prior[1], reml=reml, h2_override=h2)
     assert np.abs(L - pin.L).max() <= 1e-9 * max(1.0, np.abs(pin.L).max())
     assert np.sum((L - ref.L) ** 2, axis=0).max() <= 1e-7
+
+
+def test_oracle_scan_alt_is_the_profile_likelihood_ratio_and_restates_the_closing_calls():
+    """scan_alt (src/scan.jl:397-453) in the oracle: with `true_weights` the LOD is the ratio of the two maximised
+    log-likelihoods (fitlmm's own `ell`), per marker; as written in the reference -- the closing `wls` calls get
+    sqrt.(makeweights) as their weights -- it is the same expression with the square-rooted weights.  Both against direct
+    evaluation, so that the device's parity target is pinned to something independent of the function under test."""
+    from common import make_data
+    Y, G, K, _ = make_data(n=40, p=12, m=6, seed=77, bxd=False)
+    j = int(np.argmin(np.abs(O.bulkscan_null(Y, G, K, prior_variance=1.0, prior_sample_size=0.1).h2_null_list - 0.5)))
+    y = Y[:, [j]]
+    prior = [1.0, 0.1]
+    y0, X0, lam = O.transform_rotation(y, G, K, addIntercept=True)
+    null = O.fitlmm(y0, X0[:, :1], lam, prior)
+    a_true = O.scan(y, G, K, assumption="alt", prior_variance=1.0, prior_sample_size=0.1, true_weights=True)
+    a_ref = O.scan(y, G, K, assumption="alt", prior_variance=1.0, prior_sample_size=0.1)
+    assert abs(a_true["h2_null"] - null.h2) < 1e-12
+    for i in range(G.shape[1]):
+        Xi = X0[:, [0, 1 + i]]
+        alt = O.fitlmm(y0, Xi, lam, prior)
+        assert abs(a_true["h2_each_marker"][i] - alt.h2) < 1e-12
+        assert abs(a_true["lod"][i] - (alt.ell - null.ell) / np.log(10)) < 1e-10
+        q1 = O.wls(y0, Xi, np.sqrt(O.makeweights(alt.h2, lam)), prior).ell
+        q0 = O.wls(y0, X0[:, :1], np.sqrt(O.makeweights(null.h2, lam)), prior).ell
+        assert abs(a_ref["lod"][i] - (q1 - q0) / np.log(10)) < 1e-10
+    assert np.all(a_true["lod"] >= -1e-9)          # a likelihood ratio of nested models
