@@ -367,6 +367,7 @@ function read_table(open_table::Function)
 end
 read_csv(file, skip, first, step, drop) = read_table(h -> ccall((:blmm_read_csv, libblmm), Cint,
     (Cstring, Int64, Int64, Int64, Int64, Ref{Ptr{Cvoid}}), file, skip, first, step, drop, h))
+readGenoProb(file::AbstractString) = read_csv(file, 1, 1, 1, 0)                       # header line and id column dropped (getmarkernames = getids = true)
 readGenoProb_ExcludeComplements(file::AbstractString) = read_csv(file, 1, 1, 2, 0)
 readBXDpheno(file::AbstractString) = read_csv(file, 1, 1, 1, 1)
 readBXDgeno(file::AbstractString; skipstart = 1) = read_csv(file, skipstart, 1, 2, 0)
