@@ -277,7 +277,7 @@ int prepare(blmm_ctx* ctx, const blmm_opts* o, const double* dY, int64_t n, int6
   int add_int = o->add_intercept ? 1 : 0;
   if (ncov == 0 || !dCovar) { add_int = 1; ncov = 0; dCovar = nullptr; }  // bulkscan(Y,G,K): intercept-only null model
   const int c = (int)ncov + add_int;
-  if (c < 1 || c > CMAX) return fail(ctx, BLMM_ERR_UNSUPPORTED, "number of null covariates (incl. intercept) must be 1..4");
+  if (c < 1 || c > CMAX) return fail(ctx, BLMM_ERR_UNSUPPORTED, BLMM_C_ERR);
   if (c >= n) return fail(ctx, BLMM_ERR_DIM, "Dimension mismatch.");
   P.n = (int)n; P.c = c; P.npad = (int)round_up(n, 8); P.ldr = (int)round_up(P.npad, 16);   // K padded to 8: even K-step count
   P.m = m; P.p = p; P.ldy = round_up(m > 0 ? m : 1, 128); P.ldx = round_up(p > 0 ? p : 1, 128);
@@ -385,6 +385,7 @@ ScanArgs scan_args(blmm_ctx* ctx, const Pipe& P, const double* panels, int64_t l
   a.Xt = P.Xt; a.ldx = P.ldx; a.P = panels; a.ldp = ldp; a.pstride = (int64_t)P.npad * ldp;
   a.ks = P.npad / 4; a.n = P.n; a.p = P.p; a.m = m; a.L = L; a.ldL = ldL;
   a.isx = nullptr; a.ld_isx = 0; a.bin = nullptr; a.stat = P.stat; a.logtab = ptr<double>(ctx->logtab);
+  a.c = P.c;
   return a;
 }
 

@@ -12,7 +12,13 @@ namespace blmm {
 typedef double d2 __attribute__((ext_vector_type(2)));
 typedef double d4 __attribute__((ext_vector_type(4)));
 
-constexpr int CMAX = 4;          // null covariates (incl. intercept) the kernels are instantiated for
+constexpr int CMAX = 8;          // null covariates (incl. intercept) the kernels are instantiated for
+constexpr int CFAST = 4;         // ... with the tuned forms (LDS-resident evaluators, single-pass exact scan); beyond: the generic evaluators and a covariate-chunked scan
+#define BLMM_C_ERR "number of null covariates (incl. intercept) must be 1..8"
+// one `case C: M(C); break;` per instantiated covariate count
+#define BLMM_FOR_EACH_C(M) \
+  case 1: M(1); break; case 2: M(2); break; case 3: M(3); break; case 4: M(4); break; \
+  case 5: M(5); break; case 6: M(6); break; case 7: M(7); break; case 8: M(8); break;
 constexpr int TILE_T = 64;       // traits per workgroup tile of the scan kernels
 constexpr int TILE_I = 128;      // markers per workgroup tile of the scan kernels
 constexpr int NSTAT = 16;        // device status counters ([6],[7]: eigensolver clocks, [8]: weight-basis rank, [9]: its residual, [10]: traits re-scanned full rank, [12..15]: shared-weights traits / the others of the two panel regions (k_lr_classify))
@@ -169,6 +175,7 @@ struct ScanArgs {
   // permuted-column mode of the table kernel (the shared-weights class of the low-rank form): panel column -> trait, the
   // region's first column, and the device count of the class (columns [col0, col0 + *count))
   const int* perm = nullptr; int64_t col0 = 0; const int64_t* count = nullptr;
+  int c = 1;                               // null covariates (exact mode beyond CFAST: panels 2 + CFAST .. 1 + c are folded in chunks)
   const double* logtab;                    // device copy of log_table.h
   int64_t* stat;
 };

@@ -662,7 +662,7 @@ __global__ void __launch_bounds__(256) k_pe_cols(const double* __restrict__ V, c
   }
   const double sg = (s_v[0] < 0.0) ? -1.0 : 1.0;
   const int rank = rankof[i];
-  double zacc[CMAX] = {0.0, 0.0, 0.0, 0.0};
+  double zacc[CMAX] = {};
   for (int k = t; k < n; k += 256) {
     const double u = sg * v[k];
     U[(size_t)rank * n + k] = u;
@@ -1674,8 +1674,15 @@ int launch_brent(blmm_ctx* ctx, const NullModel& nm, const double* Yt, int64_t l
     case 2: return launch_brent_c<2>(ctx, nm, Yt, ldy, m, Z0, lam, h2, sigma2, ell, stat, phase, sp);
     case 3: return launch_brent_c<3>(ctx, nm, Yt, ldy, m, Z0, lam, h2, sigma2, ell, stat, phase, sp);
     case 4: return launch_brent_c<4>(ctx, nm, Yt, ldy, m, Z0, lam, h2, sigma2, ell, stat, phase, sp);
+    // beyond CFAST: the generic evaluator (operands re-read per evaluation, libm log / IEEE division), one instantiation each
+#define BG(C) return launch_brent_t<C, 16, false>(ctx, nm, Yt, ldy, m, Z0, lam, h2, sigma2, ell, stat, phase, sp)
+    case 5: BG(5);
+    case 6: BG(6);
+    case 7: BG(7);
+    case 8: BG(8);
+#undef BG
   }
-  return fail(ctx, BLMM_ERR_UNSUPPORTED, "number of null covariates (incl. intercept) must be 1..4");
+  return fail(ctx, BLMM_ERR_UNSUPPORTED, BLMM_C_ERR);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1821,9 +1828,15 @@ int launch_alt_brent(blmm_ctx* ctx, const NullModel& nm, const double* Yt, int64
     case 2: return AB(2);
     case 3: return AB(3);
     case 4: return AB(4);
+#define AG(C) return launch_alt_brent_t<C, 16>(ctx, nm, Yt, ldy, Xt, ldx, p, Z0, lam, h2null, true_w, lod, h2each, stat)
+    case 5: AG(5);
+    case 6: AG(6);
+    case 7: AG(7);
+    case 8: AG(8);
+#undef AG
   }
 #undef AB
-  return fail(ctx, BLMM_ERR_UNSUPPORTED, "number of null covariates (incl. intercept) must be 1..4");
+  return fail(ctx, BLMM_ERR_UNSUPPORTED, BLMM_C_ERR);
 }
 
 // Ell[g, j] = wls_multivar(Y0, Z0, makeweights(grid[g]), prior).Ell  (src/bulkscan_helpers.jl:267-269),
@@ -1937,7 +1950,8 @@ int launch_loglik_grid(blmm_ctx* ctx, const NullModel& nm, const double* Yt, int
       case 2: rc = launch_loglik_grid_c<2>(ctx, nm, Yt, ldy, m, Z0, lam, grid_dev, ngrid, EllTab, h2idx, h2, stat, &done); break;
       case 3: rc = launch_loglik_grid_c<3>(ctx, nm, Yt, ldy, m, Z0, lam, grid_dev, ngrid, EllTab, h2idx, h2, stat, &done); break;
       case 4: rc = launch_loglik_grid_c<4>(ctx, nm, Yt, ldy, m, Z0, lam, grid_dev, ngrid, EllTab, h2idx, h2, stat, &done); break;
-      default: return fail(ctx, BLMM_ERR_UNSUPPORTED, "number of null covariates (incl. intercept) must be 1..4");
+      case 5: case 6: case 7: case 8: break;   // beyond CFAST: the generic evaluator below
+      default: return fail(ctx, BLMM_ERR_UNSUPPORTED, BLMM_C_ERR);
     }
     if (rc || done) return rc;
   }
@@ -1946,11 +1960,8 @@ int launch_loglik_grid(blmm_ctx* ctx, const NullModel& nm, const double* Yt, int
   const size_t lds = sizeof(double) * (size_t)nm.n * (1 + nm.c);
 #define LG(C) hipLaunchKernelGGL(k_loglik_grid<C>, dim3(blocks), dim3(256), lds, ctx->stream, nm, Yt, ldy, m, Z0, lam, grid_dev, ngrid, EllTab, h2idx, h2, stat)
   switch (nm.c) {
-    case 1: LG(1); break;
-    case 2: LG(2); break;
-    case 3: LG(3); break;
-    case 4: LG(4); break;
-    default: return fail(ctx, BLMM_ERR_UNSUPPORTED, "number of null covariates (incl. intercept) must be 1..4");
+    BLMM_FOR_EACH_C(LG)
+    default: return fail(ctx, BLMM_ERR_UNSUPPORTED, BLMM_C_ERR);
   }
 #undef LG
   KCHECK();
@@ -2081,11 +2092,8 @@ int launch_panels(blmm_ctx* ctx, const NullModel& nm, const double* Yt, int64_t 
   const size_t lds = sizeof(double) * (size_t)nm.n * (1 + nm.c);
 #define PN(C) hipLaunchKernelGGL(k_panels<C>, dim3(blocks), dim3(256), lds, ctx->stream, nm, Yt, ldy, m, Z0, lam, h2, full, panels, ldp, stat)
   switch (nm.c) {
-    case 1: PN(1); break;
-    case 2: PN(2); break;
-    case 3: PN(3); break;
-    case 4: PN(4); break;
-    default: return fail(ctx, BLMM_ERR_UNSUPPORTED, "number of null covariates (incl. intercept) must be 1..4");
+    BLMM_FOR_EACH_C(PN)
+    default: return fail(ctx, BLMM_ERR_UNSUPPORTED, BLMM_C_ERR);
   }
 #undef PN
   KCHECK();
@@ -2171,11 +2179,8 @@ int launch_isx(blmm_ctx* ctx, const NullModel& nm, const double* Xt, int64_t ldx
   const size_t lds = sizeof(double) * (size_t)nm.n * (1 + nm.c);
 #define IX(C) hipLaunchKernelGGL(k_isx<C>, grid, dim3(256), lds, ctx->stream, nm, Xt, ldx, p, Z0, lam, grid_dev, isx, ld_isx, stat)
   switch (nm.c) {
-    case 1: IX(1); break;
-    case 2: IX(2); break;
-    case 3: IX(3); break;
-    case 4: IX(4); break;
-    default: return fail(ctx, BLMM_ERR_UNSUPPORTED, "number of null covariates (incl. intercept) must be 1..4");
+    BLMM_FOR_EACH_C(IX)
+    default: return fail(ctx, BLMM_ERR_UNSUPPORTED, BLMM_C_ERR);
   }
 #undef IX
   KCHECK();
@@ -2575,11 +2580,8 @@ int launch_perm_panel(blmm_ctx* ctx, const NullModel& nm, const double* Yt, int6
     hipLaunchKernelGGL(k_perm_fill<C>, fgrid, dim3(256), 0, ctx->stream, nm, Z0, lam, h2, pidx, ncols, orig, r0, coef, P_, ldp)
     double* P_ = panel;
     switch (nm.c) {
-      case 1: PN(1); break;
-      case 2: PN(2); break;
-      case 3: PN(3); break;
-      case 4: PN(4); break;
-      default: return fail(ctx, BLMM_ERR_UNSUPPORTED, "number of null covariates (incl. intercept) must be 1..4");
+      BLMM_FOR_EACH_C(PN)
+      default: return fail(ctx, BLMM_ERR_UNSUPPORTED, BLMM_C_ERR);
     }
 #undef PN
     KCHECK();
@@ -2591,11 +2593,8 @@ int launch_perm_panel(blmm_ctx* ctx, const NullModel& nm, const double* Yt, int6
   hipLaunchKernelGGL(k_perm_panel<C>, dim3(blocks), dim3(64), 0, ctx->stream, nm, Yt, ldy, Z0, lam, h2, perm_idx, \
                      nperms, seed, orig, panel, ldp, r0, permbuf, stat)
   switch (nm.c) {
-    case 1: PP(1); break;
-    case 2: PP(2); break;
-    case 3: PP(3); break;
-    case 4: PP(4); break;
-    default: return fail(ctx, BLMM_ERR_UNSUPPORTED, "number of null covariates (incl. intercept) must be 1..4");
+    BLMM_FOR_EACH_C(PP)
+    default: return fail(ctx, BLMM_ERR_UNSUPPORTED, BLMM_C_ERR);
   }
 #undef PP
   KCHECK();

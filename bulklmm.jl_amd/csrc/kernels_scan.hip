@@ -108,10 +108,14 @@ __device__ __forceinline__ void tile_of(int64_t id, int64_t ntile_t, int ntile_i
 // PERM (table mode only): the trait tiles are the first ceil(*a.count / tile) tiles of the panel region starting at column
 // a.col0, a panel column's trait is a.perm[column] (-1: padding) -- the shared-weights class of the low-rank form, which is
 // exactly a one-bin table scan (102 VGPRs, 4 waves per SIMD, where k_scan_lr holds 2).  Every XCD takes an eighth of the items.
-template <int NX, int MB, int NB, bool TABLE, int W2, bool PERM = false>
+// MORE (exact mode, c > CFAST): the covariate panels beyond the first CFAST are contracted CFAST at a time ahead of the main
+// loop and folded into the Sxx accumulator as -u_q^2 (an MFMA accumulates on top of whatever its accumulator holds), so the
+// register budget does not grow with c; the marker tile is re-read from L2 once per chunk.
+template <int NX, int MB, int NB, bool TABLE, int W2, bool PERM = false, bool MORE = false>
 __global__ void __launch_bounds__(64 * W2 * W2, 2) k_scan(ScanArgs a, int ntile_i, int64_t nwg) {
   constexpr int NP = 1 + NX;  // A-side panels consumed
   static_assert(!PERM || (TABLE && NX == 0), "permuted columns: table mode");
+  static_assert(!MORE || (!TABLE && NX == 1 + CFAST), "covariate chunks: exact mode with all CFAST in-loop panels");
   __shared__ dpair s_log[BLMM_LOG_TABLE_N];
   __shared__ int s_perm[PERM ? 16 * W2 * MB : 1];
   stage_lod_table(s_log, a.logtab, -0.5 * (double)a.n);  // read after the K loop; the barrier sits right before the epilogue
@@ -178,6 +182,38 @@ __global__ void __launch_bounds__(64 * W2 * W2, 2) k_scan(ScanArgs a, int ntile_
         }
       }
   };
+  if constexpr (MORE) {
+    for (int q0 = CFAST; q0 < a.c; q0 += CFAST) {
+      const int nq = (a.c - q0 < CFAST) ? a.c - q0 : CFAST;     // wave-uniform
+      for (int step = 0; step < a.ks; ++step) {
+        double A[CFAST][MB], B[NB];
+        bufload<NB>(B, make_srd(PB + step * sb), voffB);
+#pragma unroll
+        for (int q = 0; q < CFAST; ++q)
+          if (q < nq) bufload<MB>(A[q], make_srd(PA + (2 + q0 + q) * a.pstride + step * sa), voffA);
+#pragma unroll
+        for (int q = 0; q < CFAST; ++q)
+          if (q < nq) {
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+              for (int nb = 0; nb < NB; ++nb)
+                acc[2 + q][mb][nb] = __builtin_amdgcn_mfma_f64_16x16x4f64(A[q][mb], B[nb], acc[2 + q][mb][nb], 0, 0, 0);
+          }
+      }
+#pragma unroll
+      for (int q = 0; q < CFAST; ++q)
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+          for (int nb = 0; nb < NB; ++nb) {
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg)
+              acc[1][mb][nb][reg] = fma(-acc[2 + q][mb][nb][reg], acc[2 + q][mb][nb][reg], acc[1][mb][nb][reg]);
+            acc[2 + q][mb][nb] = (d4){0, 0, 0, 0};
+          }
+    }
+  }
   double a0[NP][MB], b0[NB], a1[NP][MB], b1[NB];
   load_set(a0, b0, 0);
   int ks = 0;
@@ -257,7 +293,7 @@ __global__ void __launch_bounds__(64 * W2 * W2, 2) k_scan(ScanArgs a, int ntile_
   if (nnan) atomicAdd((unsigned long long*)&a.stat[ST_NAN_LOD], (unsigned long long)nnan);
 }
 
-template <int NX, bool TABLE, int MB, int W2 = 2>
+template <int NX, bool TABLE, int MB, int W2 = 2, bool MORE = false>
 static int launch_scan_t(blmm_ctx* ctx, const ScanArgs& a) {
   constexpr int NB = 4;
   static_assert(16 * W2 * MB <= 128 && 16 * W2 * NB <= TILE_I, "tile constants (operands are padded to 128)");
@@ -266,7 +302,7 @@ static int launch_scan_t(blmm_ctx* ctx, const ScanArgs& a) {
   const int64_t nwg = ntile_t * ntile_i;
   if (nwg <= 0) return BLMM_OK;
   if (nwg > 0x7fffffffLL) return fail(ctx, BLMM_ERR_INVALID, "problem too large for one launch");
-  hipLaunchKernelGGL((k_scan<NX, MB, NB, TABLE, W2>), dim3((unsigned)nwg), dim3(64 * W2 * W2), 0, ctx->stream, a, (int)ntile_i, nwg);
+  hipLaunchKernelGGL((k_scan<NX, MB, NB, TABLE, W2, false, MORE>), dim3((unsigned)nwg), dim3(64 * W2 * W2), 0, ctx->stream, a, (int)ntile_i, nwg);
   KCHECK();
   return BLMM_OK;
 }
@@ -282,7 +318,8 @@ int launch_scan_exact(blmm_ctx* ctx, const ScanArgs& a, int c) {
     case 3: return launch_scan_t<4, false, 1>(ctx, a);
     case 4: return launch_scan_t<5, false, 1>(ctx, a);
   }
-  return fail(ctx, BLMM_ERR_UNSUPPORTED, "number of null covariates (incl. intercept) must be 1..4");
+  if (c > CFAST && c <= CMAX && a.c == c) return launch_scan_t<1 + CFAST, false, 1, 2, true>(ctx, a);
+  return fail(ctx, BLMM_ERR_UNSUPPORTED, BLMM_C_ERR);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -560,7 +597,7 @@ int launch_scan_lr(blmm_ctx* ctx, const LrArgs& la) {
     case 2: return launch_scan_lr_t<2, 1>(ctx, la);
     case 3: return launch_scan_lr_t<3, 1>(ctx, la);
   }
-  return fail(ctx, BLMM_ERR_UNSUPPORTED, "number of null covariates (incl. intercept) must be 1..4");
+  return fail(ctx, BLMM_ERR_UNSUPPORTED, BLMM_C_ERR);
 }
 
 int launch_scan_shared(blmm_ctx* ctx, const ScanArgs& a) {

@@ -882,3 +882,58 @@ def test_eigensolvers_on_clustered_and_rescaled_spectra(blmm, n, kind):
     assert np.abs(K - (U * lam_d) @ U.T).max() <= 1e-12 * n * sc
     assert np.abs(np.sort(lam_d) - np.linalg.eigvalsh(K)).max() <= 1e-12 * sc
     ctx.close()
+
+
+# ---- more null covariates than the tuned kernels hold (c = covariates + intercept) ---------------------------------------
+# c = 4 is the last single-pass exact scan (full-rank kernel: the low-rank form stops at c = 3); c = 5..8 take the generic
+# h2 evaluators and the covariate-chunked exact scan (k_scan<.., MORE>).  The reference has no cap (src/bulkscan.jl:113-124).
+@pytest.mark.parametrize("ncov", [3, 4, 6, 7])
+def test_many_covariates_every_method(blmm, ncov):
+    Y, G, K, Cov = make_data(p=197, m=37, seed=7000 + ncov, ncov=ncov)
+    n = Y.shape[0]
+    got = blmm.bulkscan_null(Y, G, K, Cov)
+    check_null_exact(got, Y, G, K, Cov)
+    rm = blmm.bulkscan_null(Y[:, :9], G, K, Cov, reml=True, optim_interval=3)
+    check_null_exact(rm, Y[:, :9], G, K, Cov, reml=True, optim_interval=3)
+    grid = [i / 10.0 for i in range(10)]
+    gg = blmm.bulkscan_null_grid(Y, G, K, grid, Cov)
+    gr = O.bulkscan_null_grid(Y, G, K, grid, Covar=Cov)
+    assert np.array_equal(gg.h2_null_list, gr.h2_null_list)
+    assert_lod_close(gg.L, gr.L)
+    ag = blmm.bulkscan_alt_grid(Y[:, :11], G, K, grid, Cov)
+    ar = O.bulkscan_alt_grid(Y[:, :11], G, K, grid, Covar=Cov)
+    assert_lod_close(ag.L, ar.L, atol=1e-9)
+    assert (ag.h2_panel != ar.h2_panel).mean() <= 1e-3
+    # scan: null, alt and the permutation test
+    y = Y[:, 0]
+    s0 = blmm.scan(y, G, K, Cov)
+    r0 = O.scan(y, G, K, covar=Cov)
+    assert abs(s0["h2_null"] - r0["h2_null"]) <= 1e-6
+    assert_lod_close(s0["lod"], r0["lod"], rtol=1e-4, atol=1e-8)
+    sa = blmm.scan(y, G[:, :40], K, Cov, assumption="alt")
+    ra = O.scan(y, G[:, :40], K, covar=Cov, assumption="alt", h2_each_override=sa["h2_each_marker"], h2_null_override=sa["h2_null"])
+    own = O.scan(y, G[:, :40], K, covar=Cov, assumption="alt")
+    assert abs(sa["h2_null"] - own["h2_null"]) <= 1e-6
+    assert_lod_close(sa["lod"], ra["lod"], rtol=1e-6, atol=1e-8)
+    assert_lod_close(sa["lod"], own["lod"], rtol=1e-4, atol=1e-6)
+    nperms = 23
+    pidx = O.make_perm_idx(n, nperms, 5)
+    sp = blmm.scan(y, G, K, Cov, permutation_test=True, nperms=nperms, perm_idx=pidx)
+    cov1 = np.hstack([np.ones((n, 1)), Cov])
+    rot = blmm.transform_rotation(Y, np.hstack([cov1, G]), K, addIntercept=False)
+    pin = O.scan(y, G, K, covar=cov1, addIntercept=False, permutation_test=True, nperms=nperms, perm_idx=pidx,
+                 h2_override=sp["h2_null"], rotation_override=rot)
+    assert_lod_close(sp["lod"], pin["lod"])
+    assert_lod_close(sp["L_perms"], pin["L_perms"])
+
+
+def test_many_covariates_larger_n_and_the_cap(blmm):
+    """n = 300 (lanes loop over the individuals in the generic evaluators; own tridiagonal eigensolver), c = 6; c = 9 fails
+    loudly with the library's message."""
+    Y, G, K, Cov = make_data(n=300, p=150, m=21, seed=7100, ncov=5, bxd=False)
+    got = blmm.bulkscan_null(Y, G, K, Cov)
+    check_null_exact(got, Y, G, K, Cov)
+    Y, G, K, Cov = make_data(p=20, m=3, seed=7101, ncov=8)
+    with pytest.raises(blmm.BulkLMMError) as e:
+        blmm.bulkscan_null(Y, G, K, Cov)
+    assert "1..8" in e.value.msg

@@ -17,7 +17,7 @@ for case in range(ncases):
     kkind = str(rng.choice(["markers", "markers", "one-marker", "few-markers", "duplicated-individuals"]))
     p = int(rng.choice([1, 2, 7, 63, 64, 65, 127, 128, 129, 255, 256, 257, 300]))
     m = int(rng.choice([1, 2, 15, 16, 17, 63, 64, 65, 70, 128, 129, 1030, 2100]))
-    ncov = int(rng.choice([0, 0, 1, 2, 3]))
+    ncov = int(rng.choice([0, 0, 1, 2, 3, 4, 5, 7]))
     if ncov + 2 >= n: ncov = 0
     method = str(rng.choice(["null-exact", "null-exact", "null-grid", "alt-grid", "perms", "scan-alt"]))
     oi = int(rng.choice([1, 1, 1, 2, 3]))
