@@ -85,6 +85,9 @@ def main():
                     help="N > 1 only; default strong (one BXD problem sharded over the ranks)")
     ap.add_argument("--no-host-api", action="store_true", help="skip the end-to-end (host pointers in, host L out) timing")
     ap.add_argument("--gather", action="store_true", help="put the RCCL all-gather of the LOD shards inside the step")
+    ap.add_argument("--ldl-align", type=int, default=1,
+                    help="leading dimension of the device LOD matrix rounded up to this many doubles (1 = dense, ld = p, the "
+                         "reference's layout and the default; 16 = every column starts on a 128-byte line)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=15.0)
     a = ap.parse_args()
@@ -191,7 +194,8 @@ def main():
                 self.dL = self.full[rank][: self.m]
             else:
                 self.full = None
-                self.dL = torch.empty((self.m, p), dtype=ldt, device=dev)
+                ldl = -(-p // a.ldl_align) * a.ldl_align
+                self.dL = torch.empty((self.m, ldl), dtype=ldt, device=dev)[:, :p]
             self.dH = torch.empty((self.m, p) if alt else (max(self.m, 1),), dtype=torch.float64, device=dev)
             if perms:
                 self.dy1 = self.dY[0].contiguous()

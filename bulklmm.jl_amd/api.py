@@ -651,7 +651,8 @@ def bulkscan_dev(ctx: Context, Y, G, K, L_out, h2_out, *, method: str = "null-ex
                  addIntercept: bool = True, prior_variance: float = 1.0, prior_sample_size: float = 0.0, reml: bool = False,
                  optim_interval: int = 1, decomp_scheme: str = "eigen", status: bool = False):
     """blmm_bulkscan_dev on torch CUDA tensors laid out column-major: pass Y as a (m, n) contiguous tensor
-    (= n x m column-major), G as (p, n), K as (n, n), L_out as (m, p) (= p x m column-major).
+    (= n x m column-major), G as (p, n), K as (n, n), L_out as (m, p) (= p x m column-major; rows may be padded: the
+    leading dimension passed on is L_out.stride(0)).
     Enqueues on the context's stream and does not synchronise unless `status` is requested."""
     m, n = Y.shape
     p = G.shape[0]
@@ -668,8 +669,15 @@ def bulkscan_dev(ctx: Context, Y, G, K, L_out, h2_out, *, method: str = "null-ex
     ctx.check(ctx.lib.blmm_bulkscan_dev(ctx.h, C.byref(o), Y.data_ptr(), n, m, G.data_ptr(), p,
                                         None if Covar is None else Covar.data_ptr(), ncov, K.data_ptr(),
                                         None if weights is None else weights.data_ptr(), _p(grid), ngrid,
-                                        L_out.data_ptr(), p, h2_out.data_ptr(), C.byref(st) if status else None))
+                                        L_out.data_ptr(), _ld(L_out, p), h2_out.data_ptr(), C.byref(st) if status else None))
     return st
+
+
+def _ld(t, p):
+    """Leading dimension of a (cols, p) tensor that holds a p x cols column-major matrix."""
+    if t.dim() != 2 or t.shape[1] != p or (p > 1 and t.stride(1) != 1) or (t.shape[0] > 1 and t.stride(0) < p):
+        raise ValueError("L_out must be a (m, p) tensor with unit stride along p")
+    return t.stride(0) if t.shape[0] > 1 else max(p, t.stride(0))
 
 
 def scan_perms_dev(ctx: Context, y, G, K, scalars_out, lod_out, Lperms_out, *, nperms: int, seed: int = 0, perm_idx=None,

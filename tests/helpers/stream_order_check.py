@@ -37,4 +37,13 @@ with torch.cuda.stream(s2):
     blmm.bulkscan_dev(ctx2, dY, dG, dK, dL, dH, method="null-exact")
     got = (dL + 0.0).cpu().numpy().T
 assert np.array_equal(got, ref.L), "side stream"
+# a padded leading dimension (every column on its own 128-byte line; bench.py --ldl-align): same values, padding untouched,
+# for every method that writes a p x m matrix
+for method in ("null-exact", "null-grid"):
+    dense = torch.empty((3000, 1500), dtype=torch.float64, device=dev)
+    blmm.bulkscan_dev(ctx, dY, dG, dK, dense, dH, method=method)
+    wide = torch.full((3000, 1504), -3.0, dtype=torch.float64, device=dev)
+    blmm.bulkscan_dev(ctx, dY, dG, dK, wide[:, :1500], dH, method=method)
+    assert torch.equal(wide[:, :1500], dense), method + ": padded ldL"
+    assert bool((wide[:, 1500:] == -3.0).all()), method + ": padding written"
 print("stream order ok")
