@@ -786,6 +786,9 @@ __global__ void __launch_bounds__(256) k_lr_panels(NullModel nm, const double* _
 // Lane `sub` of a trait's group owns the individuals k = sub, sub + LPT, ...; sums are butterflied over the group, the
 // small per-trait algebra is done redundantly by every lane.  Basis rows come from L2 (every group of a workgroup reads
 // the same addresses, consecutive lanes consecutive k).
+#ifndef PW_PRIO
+#define PW_PRIO 3
+#endif
 #ifdef PW_DIAG
 __device__ unsigned long long g_pw_diag[3 * 8192];   // per workgroup: start / after staging / end (100 MHz ticks)
 #endif
@@ -794,7 +797,7 @@ __global__ void __launch_bounds__(256) k_lr_panels_w(NullModel nm, const double*
                                                      const double* __restrict__ Z0, const double* __restrict__ lam,
                                                      const double* __restrict__ h2v, const double* __restrict__ Q,
                                                      const int* __restrict__ rk, int qcap, const int* __restrict__ perm,
-                                                     int64_t col0, int64_t ncol, const int64_t* __restrict__ counts, int nbatch,
+                                                     int64_t col0, int64_t ncol, const int64_t* __restrict__ counts, int nbatch, int hiprio,
                                                      double* __restrict__ P0,
                                                      double* __restrict__ Cp, double* __restrict__ Ls, int64_t ldp,
                                                      int64_t* stat) {
@@ -802,6 +805,9 @@ __global__ void __launch_bounds__(256) k_lr_panels_w(NullModel nm, const double*
   if (threadIdx.x == 0 && blockIdx.x < 8192) g_pw_diag[3 * blockIdx.x] = __builtin_amdgcn_s_memrealtime();
 #endif
   extern __shared__ __attribute__((aligned(16))) double sh[];
+  // On the critical path, often beside k_brent2 (second half of the h2 search, which has slack): its older waves win the
+  // oldest-first issue arbitration of a SIMD unless these waves carry a higher priority (28 us alone, 66 us beside it).
+  if (hiprio) __builtin_amdgcn_s_setprio(PW_PRIO);   // (the launch on a side stream, region 1's, runs beside the scan and keeps priority 0)
   const int n = nm.n, npad = nm.npad;
   double* sLam = sh;
   double* sZ = sh + n;
@@ -852,8 +858,9 @@ __global__ void __launch_bounds__(256) k_lr_panels_w(NullModel nm, const double*
   double wreg[YK];                               // the lane's weights, kept for the second pass and the coefficients (yreg)
 #pragma unroll
   for (int i = 0; i < YK; ++i) wreg[i] = 0.0;
-  auto pass1 = [&](int k, double y, double& wkeep) {
-    const double w = fabs(fast_rcp(fma(delta, sLam[k], 1.0)));  // sqrt.(abs.(makeweights)) squared, src/bulkscan_helpers.jl:138
+  auto pass1 = [&](int k, double y, double& wkeep, bool live = true) {
+    double w = fabs(fast_rcp(fma(delta, sLam[k], 1.0)));  // sqrt.(abs.(makeweights)) squared, src/bulkscan_helpers.jl:138
+    if (!live) w = 0.0;                            // a select: a lane past n works on a clamped element at weight zero
     wkeep = w;
     const double wy = w * y;
     syy = fma(wy, y, syy);
@@ -868,7 +875,8 @@ __global__ void __launch_bounds__(256) k_lr_panels_w(NullModel nm, const double*
   };
   if (yreg) {
 #pragma unroll
-    for (int i = 0; i < YK; ++i) { const int k = sub + LPT * i; if (k < n) pass1(k, yv[i], wreg[i]); }
+    for (int i = 0; i < YK; ++i)
+      if (LPT * i < n) { const int k = sub + LPT * i; pass1(k < n ? k : n - 1, yv[i], wreg[i], k < n); }   // wave-uniform test
   } else {
     double wdummy;
     for (int k = sub; k < n; k += LPT) pass1(k, Yt[(int64_t)k * ldy + j], wdummy);
@@ -932,8 +940,17 @@ __global__ void __launch_bounds__(256) k_lr_panels_w(NullModel nm, const double*
     P0[(int64_t)k * ldp + jc] = p0;
   };
   if (yreg) {
+    // registers: weight 0 and y = 0 past n, so the arithmetic runs branch-free on a clamped element; only the store is masked
 #pragma unroll
-    for (int i = 0; i < YK; ++i) { const int k = sub + LPT * i; if (k < npad) pass2(k, yv[i], wreg[i]); }
+    for (int i = 0; i < YK; ++i)
+      if (LPT * i < npad) {                        // wave-uniform
+        const int k = sub + LPT * i, kc = k < n ? k : n - 1;
+        double res = yv[i];
+#pragma unroll
+        for (int q = 0; q < C; ++q) res = fma(-beta[q], sZ[q * n + kc], res);
+        const double p0 = (k < n) ? wreg[i] * res * isy : 0.0;
+        if (k < npad) P0[(int64_t)k * ldp + jc] = p0;
+      }
     for (int k = sub + LPT * YK; k < npad; k += LPT) pass2(k, 0.0, 0.0);    // padding rows beyond the registers (k >= n)
   } else {
     for (int k = sub; k < npad; k += LPT) pass2(k, k < n ? Yt[(int64_t)k * ldy + j] : 0.0, -1.0);
@@ -955,12 +972,15 @@ __global__ void __launch_bounds__(256) k_lr_panels_w(NullModel nm, const double*
 #pragma unroll
     for (int u = 0; u < 8; ++u) c8[u] = 0.0;
     if (yreg && rb + 8 <= rl) {                   // workgroup-uniform: weights in registers, the chunk's rows all in LDS
+      // branch-free over the lanes (a lane past n reads a clamped element against its zero weight): inside a lane-conditional
+      // block hipcc waits for each block's LDS reads before it issues the next block's
 #pragma unroll
       for (int i = 0; i < YK; ++i) {
-        const int k = sub + LPT * i;
-        if (k < n) {
+        if (LPT * i < n) {                        // wave-uniform
+          const int k = sub + LPT * i;
+          const int kc = k < n ? k : n - 1;
 #pragma unroll
-          for (int u = 0; u < 8; ++u) c8[u] = fma(sQ[(rb + u) * n + k], wreg[i], c8[u]);
+          for (int u = 0; u < 8; ++u) c8[u] = fma(sQ[(rb + u) * n + kc], wreg[i], c8[u]);
         }
       }
     } else {
@@ -984,7 +1004,10 @@ __global__ void __launch_bounds__(256) k_lr_panels_w(NullModel nm, const double*
   }
 #ifdef PW_DIAG
   pw_t[4] = __builtin_amdgcn_s_memtime();
+#ifdef PW_DIAG_PRINT
   if ((threadIdx.x & 63) == 0 && blockIdx.x % 97 == 0) printf("pw wg %d wave %d: loads+pass1 %llu  sums+chol %llu  pass2 %llu  coeffs %llu cycles\n", (int)blockIdx.x, (int)(threadIdx.x >> 6), pw_t[1] - pw_t[0], pw_t[2] - pw_t[1], pw_t[3] - pw_t[2], pw_t[4] - pw_t[3]);
+#endif
+  (void)pw_t;
 #endif
   };
   for (int b = 0; b < nbatch; ++b) do_column(col0 + ((int64_t)blockIdx.x * nbatch + b) * TPB + threadIdx.x / LPT);
@@ -1259,11 +1282,16 @@ int launch_lr_panels(blmm_ctx* ctx, const NullModel& nm, const double* Yt, int64
     (void)ncu;
     const int nbatch = nb_env > 0 ? nb_env : 1;   // BXD shape, prep phase: 0.109 ms at 1, 0.106 at 2, 0.113 at 4, 0.164 at 8
     const unsigned wblocks = (unsigned)((wgroups + nbatch - 1) / nbatch);
+    const int hiprio = (ctx->stream != ctx->side && ctx->stream != ctx->side2) ? 1 : 0;   // main stream = critical path
     const size_t wbase = sizeof(double) * (size_t)nm.n * (1 + nm.c);
-    const int wqcap = (wbase + sizeof(double) * nm.n <= 60 * 1024) ? (int)std::min<size_t>((size_t)nm.n, (60 * 1024 - wbase) / (sizeof(double) * (size_t)nm.n)) : 0;
+    // rows of the basis mirrored in LDS: the rank is only known on the device (20-24 on kinship spectra); 32 rows keep the
+    // workgroup at 22 KB at n = 80 (7 per CU; n rows = 52 KB held it at 3), rows beyond come from L2
+    static const int qrows_env = getenv("BLMM_LR_PANELS_QROWS") ? atoi(getenv("BLMM_LR_PANELS_QROWS")) : 0;
+    const size_t qrows = qrows_env > 0 ? (size_t)qrows_env : 32;
+    const int wqcap = (wbase + sizeof(double) * nm.n <= 60 * 1024) ? (int)std::min<size_t>(std::min<size_t>((size_t)nm.n, qrows), (60 * 1024 - wbase) / (sizeof(double) * (size_t)nm.n)) : 0;
     const size_t wlds = wbase + sizeof(double) * (size_t)wqcap * nm.n;
 #define LPW(C) do { if (wlds > 48 * 1024) BLMM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_lr_panels_w<C, LPT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)wlds)); \
-    hipLaunchKernelGGL((k_lr_panels_w<C, LPT>), dim3(wblocks), dim3(256), wlds, ctx->stream, nm, Yt, ldy, m, Z0, lam, h2, Q, rk, wqcap, perm, rg.col0, rg.ncol, rg.counts, nbatch, P0, Cp, Ls, ldp, stat); } while (0)
+    hipLaunchKernelGGL((k_lr_panels_w<C, LPT>), dim3(wblocks), dim3(256), wlds, ctx->stream, nm, Yt, ldy, m, Z0, lam, h2, Q, rk, wqcap, perm, rg.col0, rg.ncol, rg.counts, nbatch, hiprio, P0, Cp, Ls, ldp, stat); } while (0)
     switch (nm.c) {
       case 1: LPW(1); break;
       case 2: LPW(2); break;

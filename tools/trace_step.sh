@@ -15,7 +15,7 @@ i0 = idx[-2] if len(idx) > 1 else idx[-1]
 t0 = int(rows[i0]["Start_Timestamp"])
 i1 = idx[-1] if len(idx) > 1 else len(rows)
 for r in rows[i0:i1]:
-    if int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) < 9000: continue      # < 9 us: not shown
+    if int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) < int(__import__("os").environ.get("TRACE_MIN_NS", "9000")): continue      # < 9 us: not shown (TRACE_MIN_NS)
     name = r["Kernel_Name"].replace("(anonymous namespace)::", "").split("(")[0][:60]
     print(f'{(int(r["Start_Timestamp"]) - t0) / 1e3:9.1f} {(int(r["End_Timestamp"]) - t0) / 1e3:9.1f} us  q{r.get("Queue_Id", "?")} {name}')
 PY
