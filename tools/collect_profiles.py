@@ -14,7 +14,7 @@ root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 prof = os.path.join(root, "profiles")
 # substrings of the kernel names that make up a configuration's LOD scan: null-exact = k_scan_lr (rank-R class) + the table
 # kernel in permuted-column mode (shared-weights class), each launched once per panel region
-KERN = {"exact": ("k_scan_lr", "k_scan<0, 2, 4, true, 2, true>"), "grid": ("k_scan<",), "alt": ("k_scan_alt",), "perm32": ("k_scan_f32",)}
+KERN = {"exact": ("k_scan_lr", "k_scan<0, 2, 4, true, 2, true"), "grid": ("k_scan<",), "alt": ("k_scan_alt",), "perm32": ("k_scan_f32",)}
 ARGS = {"exact": "(default)", "grid": "--method null-grid", "alt": "--method alt-grid",
         "perm32": "--method perms --perm-dtype f32 --n 1000 --p 100000 --m 1250"}
 
