@@ -29,7 +29,7 @@ namespace blmm {
 namespace {
 
 constexpr double EPS = 2.220446049250313e-16;
-constexpr int LEAF = 32;
+constexpr int LEAF = 32;          // largest leaf block of T (LDS arrays of k_tql_leaves); the plan aims lower at small n, see launch_eig_dc
 
 // Wave-wide reductions on the DPP path (quad_perm / row_half_mirror / row_mirror inside a row of 16 lanes, then the four
 // row totals through v_readlane): ~60 cycles for a double, against ~700 for the six ds_bpermute pairs of a __shfl_xor
@@ -359,12 +359,19 @@ __global__ void __launch_bounds__(64) k_tql_leaves(const double* __restrict__ d,
       // barrier; r = sqrt(f^2 + g^2) and its reciprocal from one fast_rsqrt (kinship-scale data keeps f^2 + g^2 far
       // from over/underflow; an exact zero takes the reference algorithm's underflow branch)
       double ei = se[i], di = sd[i], di1 = sd[i + 1];
+      // the lane's row of Z: column i + 1 is carried in a register from one rotation to the next (instead of a store -> load round trip
+      // through LDS on every step; 8 us of the kernel's 334 at n = 500: the scalar recurrence is what bounds it), column i is requested one step early like d and e
+      const int rz = r < N ? r : 0;
+      double zc = Z[rz][m], z0n = Z[rz][i];
       for (; i >= l; --i) {
         const double f = s * ei, b = c * ei;
         const double h = fma(f, f, gg * gg);
         const double ein = (i > l) ? se[i - 1] : 0.0, din = (i > l) ? sd[i - 1] : 0.0;   // next iteration's operands, early
+        const double z0 = z0n;
+        z0n = (i > l) ? Z[rz][i - 1] : 0.0;
         if (h == 0.0) {
           if (r == 0) { se[i + 1] = 0.0; sd[i + 1] = di1 - p; se[m] = 0.0; }
+          if (r < N) Z[r][i + 1] = zc;
           under = true;
           break;
         }
@@ -377,14 +384,12 @@ __global__ void __launch_bounds__(64) k_tql_leaves(const double* __restrict__ d,
         p = s * rr;
         if (r == 0) sd[i + 1] = gg + p;
         gg = c * rr - b;
-        if (r < N) {
-          const double f2 = Z[r][i + 1], z0 = Z[r][i];
-          Z[r][i + 1] = s * z0 + c * f2;
-          Z[r][i] = c * z0 - s * f2;
-        }
+        if (r < N) Z[r][i + 1] = s * z0 + c * zc;
+        zc = c * z0 - s * zc;
         di1 = di; di = din; ei = ein;
       }
       if (under) continue;
+      if (r < N) Z[r][l] = zc;
       if (r == 0) { sd[l] -= p; se[l] = gg; se[m] = 0.0; }
     }
   }
@@ -1222,8 +1227,15 @@ int launch_eig_dc(blmm_ctx* ctx, const double* A, int n, double* lraw, double* e
   if (n > eig_dc_max_n(ctx)) return BLMM_ERR_UNSUPPORTED;
   const size_t nn = (size_t)n * n;
   // ---- plan: leaves and the merge tree (host) ----
+  // leaf blocks: implicit QL on one wave is a scalar recurrence (334 us for leaves of 31, whatever n), a leaf of half the size
+  // takes about a quarter of it and costs one more merge level of tiny nodes.  The number of leaves is a power of two, so the
+  // bound decides between leaves of n/nl and n/(2 nl); tools/sweep_leaf.sh over n = 130 .. 1400: leaves of 25-31 lose to
+  // 12.5-15.6 (n = 500: eigen 3.41 -> 3.24 ms, n = 200: 1.46 -> 1.39), leaves of 16-22 win against 8-11 (n = 130: 0.96 against
+  // 1.01, n = 300: 1.97 against 1.99), n >= 700 does not care: <= 24 picks the better one everywhere (BLMM_EIG_LEAF: A/B testing)
+  static const int leaf_env = getenv("BLMM_EIG_LEAF") ? atoi(getenv("BLMM_EIG_LEAF")) : 0;
+  const int leaf = (leaf_env >= 2 && leaf_env <= LEAF) ? leaf_env : 24;
   int nl = 1;
-  while ((n + nl - 1) / nl > LEAF) nl *= 2;
+  while ((n + nl - 1) / nl > leaf) nl *= 2;
   std::vector<int> bounds(nl + 1);
   for (int i = 0; i <= nl; ++i) bounds[i] = (int)std::llround((double)i * n / nl);
   std::vector<std::vector<int>> levels;   // per level: flat [lo, mid, hi] triples
