@@ -105,15 +105,24 @@ __device__ __forceinline__ double ld_sc1(const double* p) {
 struct SytrdEx {          // global exchange area of k_sytrd
   unsigned long long* gr; // [2 parities][n rows][4 granules]: {p lo, p hi, a lo, a hi}, each (tag << 32) | 32 data bits
   int* abort;             // set when a workgroup gave up waiting
-  const unsigned long long* anorm;   // bits of max |A_ij| (k_absmax)
+  const unsigned long long* anorm;   // ABSMAX_PARTS partial maxima of |A_ij| as bit patterns (k_sytrd_prep)
 };
+constexpr int ABSMAX_PARTS = 32;
 
-// max |A_ij| as the bit pattern of a non-negative double (orders like an integer); *out zeroed by the launcher
-__global__ void __launch_bounds__(256) k_absmax(const double* __restrict__ A, int64_t cnt, unsigned long long* __restrict__ out) {
+// Everything k_sytrd needs set up, in one launch (was: memset, k_absmax with an atomic, memset -- three dependent launches
+// in front of every decomposition): block b's maximum of |A_ij| -> part[b] (bit pattern of a non-negative double; k_sytrd
+// takes the maximum of the ABSMAX_PARTS), the abort word and the exchange granules zeroed.
+__global__ void __launch_bounds__(256) k_sytrd_prep(const double* __restrict__ A, int64_t cnt, unsigned long long* __restrict__ part,
+                                                    int* __restrict__ abort8, unsigned long long* __restrict__ gr, int64_t ngr) {
+  __shared__ double s_m[4];
   double m = 0.0;
   for (int64_t e0 = (int64_t)blockIdx.x * 256 + threadIdx.x; e0 < cnt; e0 += (int64_t)gridDim.x * 256) m = fmax(m, fabs(A[e0]));
   m = wmax(m);
-  if ((threadIdx.x & 63) == 0 && m > 0.0) atomicMax(out, (unsigned long long)__double_as_longlong(m));
+  if ((threadIdx.x & 63) == 0) s_m[threadIdx.x >> 6] = m;
+  for (int64_t e0 = (int64_t)blockIdx.x * 256 + threadIdx.x; e0 < ngr; e0 += (int64_t)gridDim.x * 256) gr[e0] = 0ull;
+  if (blockIdx.x == 0 && threadIdx.x < 8) abort8[threadIdx.x] = 0;
+  __syncthreads();
+  if (threadIdx.x == 0) part[blockIdx.x] = (unsigned long long)__double_as_longlong(fmax(fmax(s_m[0], s_m[1]), fmax(s_m[2], s_m[3])));
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -173,7 +182,8 @@ __global__ void __launch_bounds__(512) k_sytrd(const double* __restrict__ A, int
   // square is in the denormal range the reflector is not orthogonal -- on a rank-2 kinship the trailing matrix is the
   // rounding residue of the rounding residue ..., 1e-163 after a few steps, and the eigenvectors of the zero cluster came
   // out 0.19 off orthogonality (found by the fuzzer; LAPACK's dlarfg rescales such columns instead).
-  const double anorm = __longlong_as_double((long long)*ex.anorm);
+  double anorm = 0.0;
+  for (int b = 0; b < ABSMAX_PARTS; ++b) anorm = fmax(anorm, __longlong_as_double((long long)ex.anorm[b]));
   const double s1_negl = (EPS * anorm) * (EPS * anorm);
 #ifdef SYTRD_PROF
   long long pf[6] = {0, 0, 0, 0, 0, 0}, pt0 = __builtin_amdgcn_s_memtime();
@@ -468,6 +478,58 @@ __global__ void __launch_bounds__(1024) k_dc_deflate(DcWs w) {
     ord[rank] = j; ds[rank] = v; zs[rank] = sz[j];
   }
   __syncthreads();
+  // Fast path, all threads: without a close pair of poles among the entries that survive the z test, dlaed2's scan keeps
+  // exactly those entries, in sorted order, and deflates the others in sorted order -- two stream compactions.  One thread
+  // walking the list costs ~360 cycles per entry (75 of the kernel's 97 us at N = 500); the serial scan below stays for
+  // the merges that do rotate (clustered spectra), where its order of operations is LAPACK's.
+  __shared__ int s_wcnt[2][16], s_any;
+  int* cidx = reinterpret_cast<int*>(sd);          // surviving entries in sorted order (sd / sz are free after the sort)
+  if (t == 0) s_any = 0;
+  if (rho * zm > tol && N <= 2 * NT) {
+    const int lane = t & 63, wv = t >> 6, nwv = NT >> 6;
+    int keep[2], pre[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int sI = t + h * NT;
+      keep[h] = (sI < N) && !(rho * fabs(zs[sI < N ? sI : 0]) <= tol);
+      const unsigned long long bal = __ballot(keep[h]);
+      pre[h] = __popcll(bal & ((1ull << lane) - 1ull));
+      if (lane == 0) s_wcnt[h][wv] = __popcll(bal);
+    }
+    __syncthreads();
+    int base[2] = {0, 0}, tot0 = 0, tot1 = 0;
+    for (int q = 0; q < nwv; ++q) { if (q < wv) { base[0] += s_wcnt[0][q]; base[1] += s_wcnt[1][q]; } tot0 += s_wcnt[0][q]; tot1 += s_wcnt[1][q]; }
+    base[1] += tot0;
+    const int K = tot0 + tot1;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) if (keep[h]) cidx[base[h] + pre[h]] = t + h * NT;
+    __syncthreads();
+    int pass = 0;
+    for (int k = 1 + t; k < K; k += NT) {
+      const int a = cidx[k - 1], b = cidx[k];
+      const double tt = ds[b] - ds[a], zn = zs[b], zp = zs[a];
+      pass |= fabs(tt * zn * zp) <= tol * fma(zn, zn, zp * zp);
+    }
+    if (pass) s_any = 1;
+    __syncthreads();
+    if (!s_any) {
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int sI = t + h * NT;
+        if (sI >= N) continue;
+        if (keep[h]) {
+          const int k = base[h] + pre[h];
+          w.dl[lo + k] = ds[sI]; w.zl[lo + k] = zs[sI]; w.colidx[lo + k] = lo + ord[sI];
+        } else {
+          const int q = sI - (base[h] + pre[h]);       // deflated entries before it = entries before it - kept before it
+          w.defld[lo + q] = ds[sI]; w.deflcol[lo + q] = lo + ord[sI];
+        }
+      }
+      if (t == 0) { w.info[4 * node] = K; w.info[4 * node + 1] = N - K; w.info[4 * node + 2] = 0; w.rho[node] = rho; }
+      return;
+    }
+  }
+  __syncthreads();
   if (t == 0) {
     int K = 0, nd = 0, nr = 0;
     if (rho * zm <= tol) {
@@ -476,9 +538,14 @@ __global__ void __launch_bounds__(1024) k_dc_deflate(DcWs w) {
       // LAPACK dlaed2's scan in sorted order; (dp, zp, cp) = the pending candidate (value, z, column)
       int havep = 0, cp = 0;
       double dp = 0.0, zp = 0.0;
+      // the next entry is requested before the current one is worked on (every path of the body ends in a branch; read at
+      // the top of the loop, each iteration began with an LDS round trip)
+      double dnx = ds[0], znx = zs[0];
+      int cnx = ord[0];
       for (int s = 0; s < N; ++s) {
-        const double dn = ds[s], zn = zs[s];
-        const int cn = ord[s];
+        const double dn = dnx, zn = znx;
+        const int cn = cnx;
+        if (s + 1 < N) { dnx = ds[s + 1]; znx = zs[s + 1]; cnx = ord[s + 1]; }
         if (rho * fabs(zn) <= tol) { w.defld[lo + nd] = dn; w.deflcol[lo + nd] = lo + cn; ++nd; continue; }
         if (!havep) { havep = 1; dp = dn; zp = zn; cp = cn; continue; }
         const double tt = dn - dp, tau2 = fma(zn, zn, zp * zp);
@@ -1255,7 +1322,7 @@ int launch_eig_dc(blmm_ctx* ctx, const double* A, int n, double* lraw, double* e
   for (auto& l : levels) nnodes_total += l.size() / 3;
   // ---- workspace ----
   int rc;
-  const size_t ints = (size_t)7 * n + 320 + 4 * nnodes_total + 3 * nnodes_total + (nl + 1) + 64;
+  const size_t ints = (size_t)7 * n + 320 + 2 * ABSMAX_PARTS + 2 + 4 * nnodes_total + 3 * nnodes_total + (nl + 1) + 64;
   const size_t dbls = 5 * nn + (size_t)14 * n + nnodes_total + 64;
   if ((rc = ensure(ctx, ctx->eigW, sizeof(double) * dbls + sizeof(int) * ints + 256))) return rc;
   double* base = ptr<double>(ctx->eigW);
@@ -1269,8 +1336,8 @@ int launch_eig_dc(blmm_ctx* ctx, const double* A, int n, double* lraw, double* e
   double* rowbuf = Dm;
   int* ib = reinterpret_cast<int*>(rho + nnodes_total + 8);
   int* colidx = ib; int* deflcol = colidx + n; int* rota = deflcol + n; int* rotb = rota + n; int* posn = rotb + n;
-  int* posd = posn + n; int* sync = posd + n;          // sync: n + 320 ints reserved: [0] abort, [8 .. 8+G) flags
-  int* info = sync + n + 320; int* nodes_dev = info + 4 * nnodes_total; int* bounds_dev = nodes_dev + 3 * nnodes_total;
+  int* posd = posn + n; int* sync = posd + n;          // sync: n + 320 + 2 ABSMAX_PARTS ints reserved: [0] abort, [8 .. 8+G) flags, [n + 320 ..) partial maxima of |A|
+  int* info = sync + n + 320 + 2 * ABSMAX_PARTS + 2; int* nodes_dev = info + 4 * nnodes_total; int* bounds_dev = nodes_dev + 3 * nnodes_total;
   // plan -> device (tiny; cached per n in the context: the copy is skipped when n repeats)
   if (ctx->eig_plan_n != n) {
     std::vector<int> flat;
@@ -1295,11 +1362,10 @@ int launch_eig_dc(blmm_ctx* ctx, const double* A, int n, double* lraw, double* e
     nloc = (n + G - 1) / G;
     const size_t lds = sizeof(double) * ((size_t)7 * n + 128 + (size_t)nloc * n);
     SytrdEx ex; ex.gr = reinterpret_cast<unsigned long long*>(rowbuf); ex.abort = sync;      // 8 n granules in Dm (unused until the merges)
-    ex.anorm = reinterpret_cast<const unsigned long long*>(sync + 4);                          // sync[4..5], 8-byte aligned
-    BLMM_HIP(hipMemsetAsync(sync, 0, sizeof(int) * 8, ctx->stream));
-    hipLaunchKernelGGL(k_absmax, dim3((unsigned)std::min<int64_t>(256, ((int64_t)n * n + 255) / 256)), dim3(256), 0, ctx->stream, A, (int64_t)n * n,
-                       reinterpret_cast<unsigned long long*>(sync + 4));
-    BLMM_HIP(hipMemsetAsync(rowbuf, 0, sizeof(unsigned long long) * 8 * (size_t)n, ctx->stream));   // tags 0: nothing published
+    unsigned long long* parts = reinterpret_cast<unsigned long long*>(sync + ((n + 320 + 1) & ~1));   // 8-byte aligned (sync is)
+    ex.anorm = parts;
+    hipLaunchKernelGGL(k_sytrd_prep, dim3(ABSMAX_PARTS), dim3(256), 0, ctx->stream, A, (int64_t)n * n, parts, sync,
+                       reinterpret_cast<unsigned long long*>(rowbuf), (int64_t)8 * n);           // tags 0: nothing published
     BLMM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sytrd), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     int nthr = 512;                                           // barriers at 1024 threads cost almost twice as much
     if (const char* te = getenv("BLMM_SYTRD_NT")) { const int tv = atoi(te); if (tv == 256 || tv == 512) nthr = tv; }

@@ -625,16 +625,26 @@ __global__ void __launch_bounds__(1024) k_post_eigen(const double* __restrict__ 
 // (1) rank of every eigenvalue (ascending; svd: |lambda| descending; ties by index) -> lam[rank], rankof[i]
 __global__ void __launch_bounds__(256) k_pe_rank(const double* __restrict__ lraw_in, int n, int decomp, double* __restrict__ lam,
                                                  int* __restrict__ rankof, int64_t* stat) {
+  // the values every thread compares against go through LDS, 256 at a time (read straight from memory the loop was one
+  // dependent scalar load per iteration: 55 us at n = 500, 109 us at n = 1000)
+  __shared__ double s_l[256];
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
   const bool svd = decomp == BLMM_SVD;
-  const double li = svd ? fabs(lraw_in[i]) : lraw_in[i];
+  const double li = (i < n) ? (svd ? fabs(lraw_in[i]) : lraw_in[i]) : 0.0;
   int rank = 0;
-  for (int j = 0; j < n; ++j) {
-    const double lj = svd ? fabs(lraw_in[j]) : lraw_in[j];
-    if (svd) rank += (lj > li) || (lj == li && j < i);
-    else rank += (lj < li) || (lj == li && j < i);
+  for (int j0 = 0; j0 < n; j0 += 256) {
+    const int jn = (n - j0 < 256) ? n - j0 : 256;
+    __syncthreads();
+    if ((int)threadIdx.x < jn) { const double v = lraw_in[j0 + threadIdx.x]; s_l[threadIdx.x] = svd ? fabs(v) : v; }
+    __syncthreads();
+    for (int u = 0; u < jn; ++u) {
+      const double lj = s_l[u];
+      const int j = j0 + u;
+      if (svd) rank += (lj > li) || (lj == li && j < i);
+      else rank += (lj < li) || (lj == li && j < i);
+    }
   }
+  if (i >= n) return;
   lam[rank] = li;
   rankof[i] = rank;
   if (li < -1e-7) atomicAdd((unsigned long long*)&stat[ST_NEG_EIG], 1ull);
