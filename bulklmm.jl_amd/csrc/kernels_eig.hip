@@ -588,6 +588,9 @@ __global__ void __launch_bounds__(256) k_dc_rot(DcWs w) {
 // secular equation 1 + rho sum_j z_j^2 / (d_j - lam) = 0, root i in (d_i, d_(i+1)), one wave per root.  The root is
 // found relative to the nearer pole (the differences d_j - lam keep full relative accuracy), Newton steps safeguarded by
 // the bracket, bisection otherwise (the function is monotone between two poles: the bracket always holds the root).
+#ifdef SEC_DIAG
+__device__ unsigned int g_sec_hist[64];   // iterations per root (diagnostic build; read by launch_eig_dc)
+#endif
 __global__ void __launch_bounds__(256) k_dc_secular(DcWs w) {
   extern __shared__ __attribute__((aligned(16))) double sh[];
   const int node = blockIdx.x, lo = w.nodes[3 * node], n = w.n;
@@ -621,7 +624,13 @@ __global__ void __launch_bounds__(256) k_dc_secular(DcWs w) {
   // is the next iterate: monotone and quadratic from anywhere inside the interval.  The sign of f keeps a bracket, and a
   // candidate outside it (rounding, or the degenerate ends) falls back to bisection.
   const double poleL = dl[i] - dorg, poleR = (i < K - 1) ? dl[i + 1] - dorg : 0.0;
+#ifdef SEC_DIAG
+  int sec_it = 0;
+#endif
   for (int it = 0; it < 100 && a < b; ++it) {
+#ifdef SEC_DIAG
+    sec_it = it + 1;
+#endif
     double ps = 0.0, psp = 0.0, ph = 0.0, php = 0.0;
     for (int j = lane; j < K; j += 64) {
       const double q = 1.0 / ((dl[j] - dorg) - tcur);
@@ -630,7 +639,10 @@ __global__ void __launch_bounds__(256) k_dc_secular(DcWs w) {
     }
     ps = rho * wsum(ps); psp = rho * wsum(psp); ph = rho * wsum(ph); php = rho * wsum(php);
     const double f = 1.0 + ps + ph;
-    if (f == 0.0) break;
+    // LAPACK dlaed4's test: |f| within the rounding error of its own evaluation (here in units of f = rho w: the sum of the
+    // terms' magnitudes ph - ps, the constant, and the slope times the offset).  Without it one root in ten went on bisecting
+    // on the noise of the sign of f for 25-54 iterations (4-8 otherwise), and the slowest root is the kernel's duration.
+    if (fabs(f) <= EPS * (16.0 * (ph - ps) + 2.0 + 3.0 * fabs(tcur) * (psp + php))) break;
     if (f > 0.0) b = tcur; else a = tcur;
     double tn;
     const double dL = poleL - tcur;
@@ -655,6 +667,9 @@ __global__ void __launch_bounds__(256) k_dc_secular(DcWs w) {
     if (tn == tcur || b - a <= 2.0 * EPS * fmax(fabs(a), fabs(b)) || fabs(tn - tcur) <= EPS * fabs(tn)) { tcur = tn; break; }
     tcur = tn;
   }
+#ifdef SEC_DIAG
+  if (lane == 0) atomicAdd(&g_sec_hist[sec_it < 63 ? sec_it : 63], 1u);
+#endif
   if (lane == 0) w.lamnew[lo + i] = dorg + tcur;
   double* drow = w.Dm + (size_t)(lo + i) * n + lo;
   for (int j = lane; j < K; j += 64) drow[j] = (dl[j] - dorg) - tcur;
@@ -1407,6 +1422,18 @@ int launch_eig_dc(blmm_ctx* ctx, const double* A, int n, double* lraw, double* e
     const int tiles_i = (Nmax + 32 * MB - 1) / (32 * MB), tiles_r = (Nmax + 32 * NB - 1) / (32 * NB);
     hipLaunchKernelGGL((k_dc_gemm<MB, NB>), dim3(nnode, tiles_i * tiles_r), dim3(256), 0, ctx->stream, w, tiles_r);
     KCHECK();
+#ifdef SEC_DIAG
+    {
+      (void)hipStreamSynchronize(ctx->stream);
+      unsigned int h[64];
+      (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_sec_hist), sizeof(h));
+      fprintf(stderr, "secular diag: level of %d nodes (N <= %d): iterations per root:", nnode, Nmax);
+      for (int q = 0; q < 64; ++q) if (h[q]) fprintf(stderr, " %d:%u", q, h[q]);
+      fprintf(stderr, "\n");
+      unsigned int z[64] = {0};
+      (void)hipMemcpyToSymbol(HIP_SYMBOL(g_sec_hist), z, sizeof(z));
+    }
+#endif
     std::swap(lamIn, lamOut); std::swap(Qin, Qout);
     node_off += nnode;
   }
