@@ -1309,13 +1309,12 @@ int launch_eig_dc(blmm_ctx* ctx, const double* A, int n, double* lraw, double* e
   if (n > eig_dc_max_n(ctx)) return BLMM_ERR_UNSUPPORTED;
   const size_t nn = (size_t)n * n;
   // ---- plan: leaves and the merge tree (host) ----
-  // leaf blocks: implicit QL on one wave is a scalar recurrence (334 us for leaves of 31, whatever n), a leaf of half the size
-  // takes about a quarter of it and costs one more merge level of tiny nodes.  The number of leaves is a power of two, so the
-  // bound decides between leaves of n/nl and n/(2 nl); tools/sweep_leaf.sh over n = 130 .. 1400: leaves of 25-31 lose to
-  // 12.5-15.6 (n = 500: eigen 3.41 -> 3.24 ms, n = 200: 1.46 -> 1.39), leaves of 16-22 win against 8-11 (n = 130: 0.96 against
-  // 1.01, n = 300: 1.97 against 1.99), n >= 700 does not care: <= 24 picks the better one everywhere (BLMM_EIG_LEAF: A/B testing)
+  // leaf blocks: implicit QL on one wave is a scalar recurrence (334 us for leaves of 31 rows, 102 us at 16, whatever n), while
+  // a merge level of tiny nodes costs ~50 us since the secular solver stops on LAPACK's test.  The number of leaves is a power
+  // of two; tools/sweep_leaf.sh over n = 130 .. 1400 with bounds 6 .. 32: leaves of 6-12 rows are best or tied everywhere
+  // (n = 500: eigen 2.83 ms at <= 12, 2.86 at <= 24, 3.02 at <= 32; n = 300: 1.74 / 1.78 / 1.77) (BLMM_EIG_LEAF: A/B testing)
   static const int leaf_env = getenv("BLMM_EIG_LEAF") ? atoi(getenv("BLMM_EIG_LEAF")) : 0;
-  const int leaf = (leaf_env >= 2 && leaf_env <= LEAF) ? leaf_env : 24;
+  const int leaf = (leaf_env >= 2 && leaf_env <= LEAF) ? leaf_env : 12;
   int nl = 1;
   while ((n + nl - 1) / nl > leaf) nl *= 2;
   std::vector<int> bounds(nl + 1);
