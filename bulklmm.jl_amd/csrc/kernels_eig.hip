@@ -571,10 +571,10 @@ __global__ void __launch_bounds__(1024) k_dc_deflate(DcWs w) {
 }
 
 // Givens rotations of the close-pole deflations, applied to the node's rows of Qin in list order (rows are independent)
-__global__ void __launch_bounds__(256) k_dc_rot(DcWs w) {
+__device__ __forceinline__ void dc_rot(const DcWs& w, int by) {
   const int node = blockIdx.x, lo = w.nodes[3 * node], hi = w.nodes[3 * node + 2], n = w.n;
   const int nr = w.info[4 * node + 2];
-  const int r = lo + blockIdx.y * 256 + threadIdx.x;
+  const int r = lo + by * 256 + threadIdx.x;
   if (nr == 0 || r >= hi) return;
   for (int q = 0; q < nr; ++q) {
     const int a = w.rota[lo + q], b = w.rotb[lo + q];
@@ -591,16 +591,15 @@ __global__ void __launch_bounds__(256) k_dc_rot(DcWs w) {
 #ifdef SEC_DIAG
 __device__ unsigned int g_sec_hist[64];   // iterations per root (diagnostic build; read by launch_eig_dc)
 #endif
-__global__ void __launch_bounds__(256) k_dc_secular(DcWs w) {
-  extern __shared__ __attribute__((aligned(16))) double sh[];
+__device__ __forceinline__ void dc_secular(const DcWs& w, int by, double* sh) {
   const int node = blockIdx.x, lo = w.nodes[3 * node], n = w.n;
   const int K = w.info[4 * node];
-  if ((int)blockIdx.y * 4 >= K) return;
+  if ((int)by * 4 >= K) return;
   double* dl = sh;
   double* z2 = sh + K;
   for (int j = threadIdx.x; j < K; j += blockDim.x) { dl[j] = w.dl[lo + j]; const double z = w.zl[lo + j]; z2[j] = z * z; }
   __syncthreads();
-  const int lane = threadIdx.x & 63, i = blockIdx.y * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63, i = by * 4 + (threadIdx.x >> 6);
   if (i >= K) return;
   const double rho = w.rho[node];
   int org;
@@ -677,10 +676,10 @@ __global__ void __launch_bounds__(256) k_dc_secular(DcWs w) {
 
 // Gu-Eisenstat: the z-hat for which the computed roots are the exact eigenvalues,
 //   zh_j^2 = | prod_i (d_j - lam_i) / prod_(i != j) (d_j - d_i) |,  sign from z_j.   One wave per pole j.
-__global__ void __launch_bounds__(256) k_dc_zhat(DcWs w) {
+__device__ __forceinline__ void dc_zhat(const DcWs& w, int by) {
   const int node = blockIdx.x, lo = w.nodes[3 * node], n = w.n;
   const int K = w.info[4 * node];
-  const int lane = threadIdx.x & 63, j = blockIdx.y * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63, j = by * 4 + (threadIdx.x >> 6);
   if (j >= K) return;
   const double dj = w.dl[lo + j];
   double prod = 1.0;
@@ -693,10 +692,10 @@ __global__ void __launch_bounds__(256) k_dc_zhat(DcWs w) {
 }
 
 // eigenvector of root i in the basis of the kept columns: Wt[i][j] = zh_j / (d_j - lam_i), normalised.  One wave per root.
-__global__ void __launch_bounds__(256) k_dc_wt(DcWs w) {
+__device__ __forceinline__ void dc_wt(const DcWs& w, int by) {
   const int node = blockIdx.x, lo = w.nodes[3 * node], n = w.n;
   const int K = w.info[4 * node];
-  const int lane = threadIdx.x & 63, i = blockIdx.y * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63, i = by * 4 + (threadIdx.x >> 6);
   if (i >= K) return;
   const double* drow = w.Dm + (size_t)(lo + i) * n + lo;
   double* wrow = w.Wt + (size_t)(lo + i) * n + lo;
@@ -707,29 +706,50 @@ __global__ void __launch_bounds__(256) k_dc_wt(DcWs w) {
 }
 
 // positions of the node's N eigenvalues (K new roots, then the deflated ones) in ascending order; sorted values out
-__global__ void __launch_bounds__(1024) k_dc_finalize(DcWs w) {
-  extern __shared__ __attribute__((aligned(16))) double sh[];
+__device__ __forceinline__ void dc_finalize(const DcWs& w, int by, double* sh) {
+  // block `by` of a node ranks the entries [256 by, 256 by + 256) against all N values (staged in LDS by every block)
   const int node = blockIdx.x, lo = w.nodes[3 * node], hi = w.nodes[3 * node + 2], N = hi - lo;
   const int K = w.info[4 * node], t = threadIdx.x, NT = blockDim.x;
+  if (by * 256 >= N) return;                                   // workgroup-uniform
   double* val = sh;
   for (int j = t; j < N; j += NT) val[j] = (j < K) ? w.lamnew[lo + j] : w.defld[lo + j - K];
   __syncthreads();
-  for (int j = t; j < N; j += NT) {
-    const double v = val[j];
-    int rank = 0;
-    for (int i = 0; i < N; ++i) rank += (val[i] < v) || (val[i] == v && i < j);
-    if (j < K) w.posn[lo + j] = lo + rank; else w.posd[lo + j - K] = lo + rank;
-    w.lamOut[lo + rank] = v;
-  }
+  const int j = by * 256 + t;
+  if (j >= N) return;
+  const double v = val[j];
+  int rank = 0;
+  for (int i = 0; i < N; ++i) rank += (val[i] < v) || (val[i] == v && i < j);
+  if (j < K) w.posn[lo + j] = lo + rank; else w.posd[lo + j - K] = lo + rank;
+  w.lamOut[lo + rank] = v;
 }
 
-__global__ void __launch_bounds__(256) k_dc_copy(DcWs w) {
+__device__ __forceinline__ void dc_copy(const DcWs& w, int by, int bz, int nz) {
   const int node = blockIdx.x, lo = w.nodes[3 * node], hi = w.nodes[3 * node + 2], n = w.n;
   const int nd = w.info[4 * node + 1];
-  const int r = lo + blockIdx.y * 256 + threadIdx.x;
+  const int r = lo + by * 256 + threadIdx.x;
   if (r >= hi) return;
-  for (int q = blockIdx.z; q < nd; q += gridDim.z)
+  for (int q = bz; q < nd; q += nz)
     w.Qout[(size_t)w.posd[lo + q] * n + r] = w.Qin[(size_t)w.deflcol[lo + q] * n + r];
+}
+
+// The merge's small steps, three launches instead of six (a launch is ~4.7 us, six levels of them per decomposition): blocks
+// past the first kernel's range do the work of an independent second one.
+//   secular roots  |  Givens rotations of the deflated pairs on Qin (read again only by the copy and the GEMM)
+//   z-hat          |  ranks of the new and the deflated eigenvalues (needs the roots, not z-hat)
+//   eigenvectors   |  deflated columns to their places (needs the ranks)
+constexpr int DC_COPY_Z = 16;
+__global__ void __launch_bounds__(256) k_dc_secular_rot(DcWs w, int nsec) {
+  extern __shared__ __attribute__((aligned(16))) double sh[];
+  if ((int)blockIdx.y < nsec) dc_secular(w, (int)blockIdx.y, sh); else dc_rot(w, (int)blockIdx.y - nsec);
+}
+__global__ void __launch_bounds__(256) k_dc_zhat_fin(DcWs w, int nz) {
+  extern __shared__ __attribute__((aligned(16))) double sh[];
+  if ((int)blockIdx.y < nz) dc_zhat(w, (int)blockIdx.y); else dc_finalize(w, (int)blockIdx.y - nz, sh);
+}
+__global__ void __launch_bounds__(256) k_dc_wt_copy(DcWs w, int nw) {
+  if ((int)blockIdx.y < nw) { dc_wt(w, (int)blockIdx.y); return; }
+  const int c = (int)blockIdx.y - nw;
+  dc_copy(w, c / DC_COPY_Z, c % DC_COPY_Z, DC_COPY_Z);
 }
 
 // Qout[:, posn[i]] = sum_j Wt[i][j] Qin[:, colidx[j]]  on the f64 matrix cores: D (16 roots x 16 rows of Q) per block,
@@ -1410,13 +1430,11 @@ int launch_eig_dc(blmm_ctx* ctx, const double* A, int n, double* lraw, double* e
     const size_t lds_defl = sizeof(double) * ((size_t)4 * Nmax + 16 + (Nmax + 1) / 2 + 2);
     if (lds_defl > 48 * 1024) BLMM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dc_deflate), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_defl));
     hipLaunchKernelGGL(k_dc_deflate, dim3(nnode), dim3(1024), lds_defl, ctx->stream, w);
-    hipLaunchKernelGGL(k_dc_rot, dim3(nnode, (Nmax + 255) / 256), dim3(256), 0, ctx->stream, w);
+    const int nq4 = (Nmax + 3) / 4, nb256 = (Nmax + 255) / 256;
     const size_t lds_sec = sizeof(double) * (size_t)2 * Nmax;
-    hipLaunchKernelGGL(k_dc_secular, dim3(nnode, (Nmax + 3) / 4), dim3(256), lds_sec, ctx->stream, w);
-    hipLaunchKernelGGL(k_dc_zhat, dim3(nnode, (Nmax + 3) / 4), dim3(256), 0, ctx->stream, w);
-    hipLaunchKernelGGL(k_dc_wt, dim3(nnode, (Nmax + 3) / 4), dim3(256), 0, ctx->stream, w);
-    hipLaunchKernelGGL(k_dc_finalize, dim3(nnode), dim3(1024), sizeof(double) * (size_t)Nmax, ctx->stream, w);
-    hipLaunchKernelGGL(k_dc_copy, dim3(nnode, (Nmax + 255) / 256, 16), dim3(256), 0, ctx->stream, w);
+    hipLaunchKernelGGL(k_dc_secular_rot, dim3(nnode, nq4 + nb256), dim3(256), lds_sec, ctx->stream, w, nq4);
+    hipLaunchKernelGGL(k_dc_zhat_fin, dim3(nnode, nq4 + nb256), dim3(256), sizeof(double) * (size_t)Nmax, ctx->stream, w, nq4);
+    hipLaunchKernelGGL(k_dc_wt_copy, dim3(nnode, nq4 + nb256 * DC_COPY_Z), dim3(256), 0, ctx->stream, w, nq4);
     constexpr int MB = 2, NB = 2;
     const int tiles_i = (Nmax + 32 * MB - 1) / (32 * MB), tiles_r = (Nmax + 32 * NB - 1) / (32 * NB);
     hipLaunchKernelGGL((k_dc_gemm<MB, NB>), dim3(nnode, tiles_i * tiles_r), dim3(256), 0, ctx->stream, w, tiles_r);
