@@ -1391,8 +1391,9 @@ int launch_eig_dc(blmm_ctx* ctx, const double* A, int n, double* lraw, double* e
     int G = (n + nloc - 1) / nloc;
     if (G > cus) return BLMM_ERR_UNSUPPORTED;
     // ~10 rows per workgroup measured best (n = 500: 3.6 ms at G = 48 against 4.0 at the LDS minimum of 16; tools/sweep_sytrd.sh)
+    const int Gmin = G;
     if ((n + 9) / 10 > G) G = std::min(cus, (n + 9) / 10);
-    if (const char* ge = getenv("BLMM_SYTRD_G")) { const int gv = atoi(ge); if (gv >= G && gv <= cus) G = gv; }
+    if (const char* ge = getenv("BLMM_SYTRD_G")) { const int gv = atoi(ge); if (gv >= Gmin && gv <= cus) G = gv; }
     nloc = (n + G - 1) / G;
     const size_t lds = sizeof(double) * ((size_t)7 * n + 128 + (size_t)nloc * n);
     SytrdEx ex; ex.gr = reinterpret_cast<unsigned long long*>(rowbuf); ex.abort = sync;      // 8 n granules in Dm (unused until the merges)
