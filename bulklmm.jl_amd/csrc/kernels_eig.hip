@@ -440,6 +440,7 @@ struct DcWs {
   int *colidx, *deflcol, *rota, *rotb, *posn, *posd, *info;   // info[4*node + {0: K, 1: ndefl, 2: nrot}]
   const int* nodes;         // [3*node + {lo, mid, hi}]
   const double* tnorm;      // max-norm of T (k_tql_leaves)
+  int serial_deflate;       // 1: always take dlaed2's serial scan (BLMM_DC_DEFLATE=serial; tests compare it with the parallel path)
 };
 
 __global__ void __launch_bounds__(1024) k_dc_deflate(DcWs w) {
@@ -485,7 +486,7 @@ __global__ void __launch_bounds__(1024) k_dc_deflate(DcWs w) {
   __shared__ int s_wcnt[2][16], s_any;
   int* cidx = reinterpret_cast<int*>(sd);          // surviving entries in sorted order (sd / sz are free after the sort)
   if (t == 0) s_any = 0;
-  if (rho * zm > tol && N <= 2 * NT) {
+  if (rho * zm > tol && N <= 2 * NT && !w.serial_deflate) {
     const int lane = t & 63, wv = t >> 6, nwv = NT >> 6;
     int keep[2], pre[2];
 #pragma unroll
@@ -1418,6 +1419,7 @@ int launch_eig_dc(blmm_ctx* ctx, const double* A, int n, double* lraw, double* e
   // ---- 3. merges ----
   DcWs w;
   w.tnorm = rho + nnodes_total;
+  { const char* de = getenv("BLMM_DC_DEFLATE"); w.serial_deflate = (de && de[0] == 's') ? 1 : 0; }   // read per call: a test flips it
   w.n = n; w.e = e; w.Dm = Dm; w.Wt = Wt; w.dl = dl; w.zl = zl; w.zh = zh; w.defld = defld; w.lamnew = lamnew;
   w.rotc = rotc; w.rots = rots; w.colidx = colidx; w.deflcol = deflcol; w.rota = rota; w.rotb = rotb; w.posn = posn; w.posd = posd;
   double* lamIn = lamA; double* lamOut = lamB; double* Qin = Qa; double* Qout = Qb;

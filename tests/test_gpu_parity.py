@@ -13,7 +13,7 @@ import os
 import numpy as np
 import pytest
 
-from common import assert_lod_close, make_data, bxd_kinship, make_geno
+from common import assert_lod_close, make_data, bxd_kinship, make_geno, kinship_of
 from oracle import bulklmm_oracle as O
 
 pytestmark = pytest.mark.gpu
@@ -937,3 +937,22 @@ def test_many_covariates_larger_n_and_the_cap(blmm):
     with pytest.raises(blmm.BulkLMMError) as e:
         blmm.bulkscan_null(Y, G, K, Cov)
     assert "1..8" in e.value.msg
+
+
+@pytest.mark.parametrize("n", [130, 333, 700])
+def test_dc_parallel_deflation_equals_the_serial_scan(blmm, n, monkeypatch):
+    """k_dc_deflate's all-thread path (two stream compactions when no pair of poles is close) must leave exactly the lists
+    dlaed2's serial scan leaves: eigenvalues and eigenvectors bit for bit, on a kinship (the z test deflates little) and on
+    a rank-deficient matrix (it deflates hundreds of entries per merge)."""
+    rng = np.random.default_rng(900 + n)
+    A = rng.random((n, 40))
+    mats = {"kinship": kinship_of(make_geno(n, 3 * n, rng)) if n < 400 else np.cov(rng.standard_normal((n, 2 * n))),
+            "rank-deficient": A @ A.T / 40.0}
+    for name, K in mats.items():
+        K = 0.5 * (K + K.T)
+        monkeypatch.delenv("BLMM_DC_DEFLATE", raising=False)
+        Y0, _, lam = blmm.transform_rotation(np.eye(n), np.ones((n, 2)), K)
+        monkeypatch.setenv("BLMM_DC_DEFLATE", "serial")
+        Y0s, _, lams = blmm.transform_rotation(np.eye(n), np.ones((n, 2)), K)
+        assert np.array_equal(lam, lams), name
+        assert np.array_equal(Y0, Y0s), name
