@@ -817,8 +817,8 @@ __global__ void __launch_bounds__(256) k_dc_gemm(DcWs w, int tiles_r) {
 // 4. back-transformation U = H_0 H_1 ... H_(n-3) Z: reflectors applied in reverse order, each wave owns CPW columns of Z
 // in registers (rows lane, lane + 64, ...); the reflector of a step is staged in LDS for the workgroup.
 // ---------------------------------------------------------------------------------------------------------------------
-template <int NR, int CPW>
-__global__ void __launch_bounds__(512) k_backtransform(const double* __restrict__ V, const double* __restrict__ tau, int n,
+template <int NR, int CPW, int NT>
+__global__ void __launch_bounds__(NT) k_backtransform(const double* __restrict__ V, const double* __restrict__ tau, int n,
                                                        double* __restrict__ Z) {
   extern __shared__ __attribute__((aligned(16))) double sh[];   // 2 x n : double-buffered reflector
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwave = blockDim.x >> 6;
@@ -836,29 +836,34 @@ __global__ void __launch_bounds__(512) k_backtransform(const double* __restrict_
   // read from global memory two iterations before its use (into registers) and written to LDS one iteration before, so
   // neither the L2 round trip nor the LDS write sits between two barriers.  LDS: 2 buffers x RB x n.
   constexpr int RB = 4;
-  constexpr int PF = (NR * 64 + 511) / 512;     // elements per thread of one reflector (512 threads)
+  constexpr int PF = (NR * 64 + NT - 1) / NT;     // elements per thread of one reflector (NT threads)
   double pre[RB][PF];
+  double pret = 0.0;              // tau of reflector threadIdx.x of the group (threads < RB): staged with the vectors, a
+                                  // scalar load of tau[k] next to its use put an L2 round trip into every reflector's chain
+  const size_t bufsz = (size_t)RB * n + RB;
   auto fetch = [&](int grp) {
 #pragma unroll
     for (int b = 0; b < RB; ++b) {
       const int k = nref - 1 - RB * grp - b;
 #pragma unroll
-      for (int u = 0; u < PF; ++u) { const int j = threadIdx.x + 512 * u; pre[b][u] = (k >= 0 && j > k && j < n) ? V[(size_t)k * n + j] : 0.0; }
+      for (int u = 0; u < PF; ++u) { const int j = threadIdx.x + NT * u; pre[b][u] = (k >= 0 && j > k && j < n) ? V[(size_t)k * n + j] : 0.0; }
     }
+    if (threadIdx.x < RB) { const int k = nref - 1 - RB * grp - (int)threadIdx.x; pret = (k >= 0) ? tau[k] : 0.0; }
   };
   auto stash = [&](double* dst) {
 #pragma unroll
     for (int b = 0; b < RB; ++b)
 #pragma unroll
-      for (int u = 0; u < PF; ++u) { const int j = threadIdx.x + 512 * u; if (j < n) dst[(size_t)b * n + j] = pre[b][u]; }
+      for (int u = 0; u < PF; ++u) { const int j = threadIdx.x + NT * u; if (j < n) dst[(size_t)b * n + j] = pre[b][u]; }
+    if (threadIdx.x < RB) dst[(size_t)RB * n + threadIdx.x] = pret;
   };
   const int ngrp = (nref + RB - 1) / RB;
   fetch(0); stash(sh);
   fetch(1);
   __syncthreads();
   for (int grp = 0; grp < ngrp; ++grp) {
-    const double* vb = sh + (size_t)(grp & 1) * RB * n;
-    double* vn = sh + (size_t)((grp + 1) & 1) * RB * n;
+    const double* vb = sh + (size_t)(grp & 1) * bufsz;
+    double* vn = sh + (size_t)((grp + 1) & 1) * bufsz;
     stash(vn);            // group grp+1 (fetched during the previous iteration)
     fetch(grp + 2);       // lands during this iteration and the next
 #pragma unroll
@@ -866,7 +871,7 @@ __global__ void __launch_bounds__(512) k_backtransform(const double* __restrict_
       const int k = nref - 1 - RB * grp - b;
       if (k < 0) break;
       const double* v = vb + (size_t)b * n;
-      const double tk = tau[k];
+      const double tk = vb[(size_t)RB * n + b];
       double vr[NR];
 #pragma unroll
       for (int q = 0; q < NR; ++q) { const int r = lane + 64 * q; vr[q] = (r > k && r < n) ? v[r] : 0.0; }
@@ -1459,14 +1464,23 @@ int launch_eig_dc(blmm_ctx* ctx, const double* A, int n, double* lraw, double* e
   }
   // ---- 4. back-transformation (in place on the final Q), results out ----
   {
-    const size_t lds = sizeof(double) * (size_t)2 * 4 * n;     // 2 buffers x RB = 4 reflectors
+    const size_t lds = sizeof(double) * (size_t)2 * (4 * n + 4);     // 2 buffers x (RB = 4 reflectors + their tau)
     const int nr = (n + 63) / 64;
+    static const bool bt_wide = getenv("BLMM_BT_WIDE") && getenv("BLMM_BT_WIDE")[0] == '1';
 #define BT(NR)                                                                                                             \
   do {                                                                                                                     \
-    constexpr int CPW = (NR <= 8) ? 2 : 1;                                                                                 \
-    const int cols_per_wg = 8 * CPW;                                                                                       \
-    if (lds > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_backtransform<NR, CPW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-    hipLaunchKernelGGL((k_backtransform<NR, CPW>), dim3((n + cols_per_wg - 1) / cols_per_wg), dim3(512), lds, ctx->stream, V, tau, n, Qin); \
+    /* one column per wave, four waves per workgroup: the kernel is VALU-issue bound per SIMD (~110 instructions per        \
+       reflector and column), so the columns are spread over as many CUs as there are (n = 500: 125 workgroups instead of   \
+       32 of eight two-column waves: 302 -> 228 us; n = 200: 95 -> 59; n = 1000: 721 -> 739; BLMM_BT_WIDE=1: the old shape) */  \
+    constexpr int CPWW = (NR <= 8) ? 2 : 1;                                                                                \
+    if (bt_wide) {                                                                                                         \
+      const int cols_per_wg = 8 * CPWW;                                                                                    \
+      if (lds > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_backtransform<NR, CPWW, 512>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+      hipLaunchKernelGGL((k_backtransform<NR, CPWW, 512>), dim3((n + cols_per_wg - 1) / cols_per_wg), dim3(512), lds, ctx->stream, V, tau, n, Qin); \
+    } else {                                                                                                               \
+      if (lds > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_backtransform<NR, 1, 256>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+      hipLaunchKernelGGL((k_backtransform<NR, 1, 256>), dim3((n + 3) / 4), dim3(256), lds, ctx->stream, V, tau, n, Qin);   \
+    }                                                                                                                      \
   } while (0)
     if (nr <= 2) BT(2); else if (nr <= 4) BT(4); else if (nr <= 8) BT(8); else if (nr <= 16) BT(16); else if (nr <= 24) BT(24); else BT(32);
 #undef BT
