@@ -1012,8 +1012,10 @@ int launch_rotate(blmm_ctx* ctx, const double* Rp, int ldr, int n, int npad, con
     // BLMM_ROTATE_TILE (A/B timing): "64": 128 x 64 tiles with the B fragments prefetched; "128p": 128 x 128 tiles, 32-byte
     // pieces, the next trip's B fragments prefetched
     const char* rv = getenv("BLMM_ROTATE_TILE");
-    const bool wide = !(rv && std::strcmp(rv, "64") == 0);
-    const bool pref4 = rv && std::strcmp(rv, "128p") == 0;
+    const bool wide = !(rv && std::strcmp(rv, "64") == 0);     // "128": the plain 128 x 128 form at every n
+    // default: the prefetching form from n = 900 (n = 1000, p = 1e5: 3.75 against 3.87 ms, 53.4 TF; n = 700: 1.32 against 1.31;
+    // n = 500: 0.78 against 0.75); the choice depends on n only, so a column's bits do not depend on the call's width
+    const bool pref4 = rv ? std::strcmp(rv, "128p") == 0 : (n >= 900);
     const int64_t nct = (ncols_pad + (wide ? 127 : 63)) / (wide ? 128 : 64);
     const int64_t nblk = ((nct + 7) / 8) * 8 * nkt;           // every XCD walks ceil(nct / 8) column tiles
     if (nblk <= 0x7fffffffLL) {
