@@ -213,7 +213,7 @@ def dense_gls_lod(Y, G, K, h2, Covar=None):
     return L
 
 
-@pytest.mark.parametrize("ncov", [0, 2])
+@pytest.mark.parametrize("ncov", [0, 2, 7])   # 7: the oracle that pins the c = 5..8 kernels is itself pinned to the model
 def test_oracle_equals_dense_gls_model(ncov):
     """Pins the restatement to the MODEL (y = X b + e, V(e) = s2g K + s2e I, README.md:18-33) independently of the
     eigen-rotation and LiteQTL weights algebra that bulkscan_null and scan_null share: same h2 in, LODs equal to 1e-8."""
