@@ -32,6 +32,7 @@ BLMM_NULL_EXACT, BLMM_NULL_GRID, BLMM_ALT_GRID = 0, 1, 2
 BLMM_EIGEN, BLMM_SVD = 0, 1
 BLMM_COMPAT_ALT_COUNTER = 1
 BLMM_COMPAT_ALT_TRUE_WEIGHTS = 2
+BLMM_FLAG_H2_AUDIT = 4
 BLMM_GATHER_NONE, BLMM_GATHER_HOST_SHARDS, BLMM_GATHER_ALLGATHER = 0, 1, 2
 
 ERR_ZERO_NORM_MSG = "Dividing by zeros: the input vector can not contain any zeros!"
@@ -53,7 +54,8 @@ class blmm_status(C.Structure):
                 ("jacobi_cycles", C.c_int64), ("jacobi_ticks_100mhz", C.c_int64),
                 ("lowrank_rank", C.c_int64), ("lowrank_fallback", C.c_int64), ("lowrank_shared", C.c_int64), ("lowrank_resid", C.c_double),
                 ("t_eigen_ms", C.c_double), ("t_rotate_ms", C.c_double), ("t_h2_ms", C.c_double),
-                ("t_prep_ms", C.c_double), ("t_scan_ms", C.c_double), ("t_total_ms", C.c_double)]
+                ("t_prep_ms", C.c_double), ("t_scan_ms", C.c_double), ("t_total_ms", C.c_double),
+                ("n_h2_boundary", C.c_int64), ("n_h2_multimodal", C.c_int64), ("n_illcond_rescan", C.c_int64)]
 
 
 def build(force: bool = False) -> str:

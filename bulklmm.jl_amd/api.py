@@ -361,6 +361,8 @@ def bulkscan_multi(mctx: MultiContext, Y, G, K, Covar=None, *, method: str = "nu
     else:
         addIntercept = True
     w = None if weights is None else np.ascontiguousarray(np.asarray(weights, dtype=np.float64).ravel())
+    if w is not None and w.shape[0] != n:
+        raise BulkLMMError("Dimension mismatch.", -2)
     meth = _METHODS[method]
     grid, ngrid = None, 0
     if meth != L.BLMM_NULL_EXACT:
@@ -485,10 +487,14 @@ def scan(y, g, K, covar=None, *, weights=None, prior_variance: float = 0.0, prio
     ncov = 0
     if covar is not None:
         cov = _F(covar)
+        if cov.shape[0] != n:
+            raise BulkLMMError("Dimension mismatch.", -2)
         ncov = cov.shape[1]
     else:
         addIntercept = True
     w = None if weights is None else np.ascontiguousarray(np.asarray(weights, dtype=np.float64).ravel())
+    if w is not None and w.shape[0] != n:
+        raise BulkLMMError("Dimension mismatch.", -2)
     o = _opts(L.BLMM_NULL_EXACT, reml, addIntercept, decomp_scheme, optim_interval, prior_variance, prior_sample_size)
     st = L.blmm_status()
     if not permutation_test:

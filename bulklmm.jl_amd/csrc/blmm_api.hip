@@ -21,6 +21,9 @@ int fail(blmm_ctx* ctx, int code, const std::string& msg) {
 }
 
 int ensure(blmm_ctx* ctx, DevBuf& b, size_t bytes) {
+  // whoever asks for the output buffer is about to overwrite (or reallocate) it: the blmm_last_* consumers must not see the
+  // previous call's matrix through it.  The entry points set last_L again once their own result is in place.
+  if (&b == &ctx->outL) ctx->last_L = nullptr;
   if (bytes == 0) bytes = 8;
   if (b.cap >= bytes) return BLMM_OK;
   if (b.p) {
@@ -40,28 +43,29 @@ int ensure(blmm_ctx* ctx, DevBuf& b, size_t bytes) {
 }
 
 namespace {
-std::mutex g_grid_mu;
+std::mutex g_grid_mu[64];           // one per device: held across wait -> launch -> record (GridKernelGuard)
 hipEvent_t g_grid_ev[64];
 bool g_grid_has[64];
 }  // namespace
 
-int grid_kernel_begin(blmm_ctx* ctx) {
-  std::lock_guard<std::mutex> lk(g_grid_mu);
-  const int d = ctx->device & 63;
-  if (g_grid_has[d]) BLMM_HIP(hipStreamWaitEvent(ctx->stream, g_grid_ev[d], 0));
+GridKernelGuard::GridKernelGuard(blmm_ctx* c) : ctx(c), dev(c->device & 63) {
+  g_grid_mu[dev].lock();
+  if (g_grid_has[dev] && hipStreamWaitEvent(ctx->stream, g_grid_ev[dev], 0) != hipSuccess)
+    rc = fail(ctx, BLMM_ERR_HIP, "hipStreamWaitEvent (grid-kernel order) failed");
+}
+
+int GridKernelGuard::record() {
+  if (!g_grid_has[dev]) {
+    if (hipEventCreateWithFlags(&g_grid_ev[dev], hipEventDisableTiming) != hipSuccess)
+      return fail(ctx, BLMM_ERR_HIP, "hipEventCreate (grid-kernel order) failed");
+    g_grid_has[dev] = true;
+  }
+  if (hipEventRecord(g_grid_ev[dev], ctx->stream) != hipSuccess)
+    return fail(ctx, BLMM_ERR_HIP, "hipEventRecord (grid-kernel order) failed");
   return BLMM_OK;
 }
 
-int grid_kernel_end(blmm_ctx* ctx) {
-  std::lock_guard<std::mutex> lk(g_grid_mu);
-  const int d = ctx->device & 63;
-  if (!g_grid_has[d]) {
-    BLMM_HIP(hipEventCreateWithFlags(&g_grid_ev[d], hipEventDisableTiming));
-    g_grid_has[d] = true;
-  }
-  BLMM_HIP(hipEventRecord(g_grid_ev[d], ctx->stream));
-  return BLMM_OK;
-}
+GridKernelGuard::~GridKernelGuard() { g_grid_mu[dev].unlock(); }
 
 __global__ void k_fill(double* p, int64_t n, double v) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -167,6 +171,7 @@ int reset_stat(blmm_ctx* ctx, int64_t** stat) {
   int rc = ensure(ctx, ctx->stat, sizeof(int64_t) * NSTAT);
   if (rc) return rc;
   *stat = ptr<int64_t>(ctx->stat);
+  ctx->audit_ran = false;
   BLMM_HIP(hipMemsetAsync(*stat, 0, sizeof(int64_t) * NSTAT, ctx->stream));
   return BLMM_OK;
 }
@@ -188,6 +193,9 @@ int finish_status(blmm_ctx* ctx, blmm_status* st, Timer* tm) {
   st->lowrank_rank = h[8];
   st->lowrank_fallback = h[10];
   st->lowrank_shared = h[12] + h[14];
+  st->n_h2_boundary = h[ST_H2_BOUNDARY];
+  st->n_h2_multimodal = ctx->audit_ran ? h[ST_H2_MULTIMODAL] : -1;
+  st->n_illcond_rescan = h[ST_ILLCOND];
   if (h[8] < 0) return fail(ctx, BLMM_ERR_HIP, "weight-basis kernel: a workgroup timed out at the grid barrier");
   if (h[11] != 0) return fail(ctx, BLMM_ERR_HIP, "the eigensolver did not converge (code " + std::to_string((long long)h[11]) +
                               ": > 0 dsyevd info, -7 grid barrier of the tridiagonalisation timed out, -8 QL iteration limit)");
@@ -487,6 +495,17 @@ int lr_fix(blmm_ctx* ctx, const Pipe& P, const NullModel& nm, const double* dh2,
 }
 }  // namespace
 
+// Conditioning guard (kernels_dyn.hip): traits whose weighted null design is nearly collinear (several covariates, h2 -> 1)
+// get their LOD columns recomputed with an orthogonalised projection; a no-op for c = 1.  Runs on the current stream after
+// the scan kernels that wrote dL.
+int illcond_rescan(blmm_ctx* ctx, const Pipe& P, const NullModel& nm, int64_t m, const double* dh2, double* dL, int64_t ldL) {
+  if (P.c < 2 || m <= 0 || P.p <= 0) return BLMM_OK;
+  int rc = ensure(ctx, ctx->illList, sizeof(int) * (size_t)m);
+  if (rc) return rc;
+  if ((rc = launch_illcond_flag(ctx, nm, m, P.Z0, P.lam, dh2, ptr<int>(ctx->illList), P.stat))) return rc;
+  return launch_scan_qr(ctx, nm, P.Yt, P.ldy, P.Xt, P.ldx, P.p, P.Z0, P.lam, dh2, ptr<int>(ctx->illList), dL, ldL, P.stat);
+}
+
 // every trait's h2 is final: one region
 int lr_finish(blmm_ctx* ctx, const Pipe& P, const NullModel& nm, const double* dh2, double* dL, int64_t ldL, Timer& tm) {
   int rc;
@@ -508,6 +527,7 @@ int lr_finish(blmm_ctx* ctx, const Pipe& P, const NullModel& nm, const double* d
   if ((rc = lr_region_scan(ctx, P, rg, dL, ldL))) return rc;
   BLMM_HIP(hipStreamWaitEvent(main_stream, ctx->ev_join, 0));
   if ((rc = lr_fix(ctx, P, nm, dh2, dL, ldL))) return rc;
+  if ((rc = illcond_rescan(ctx, P, nm, P.m, dh2, dL, ldL))) return rc;
   tm.mark();
   return BLMM_OK;
 }
@@ -560,6 +580,7 @@ int lr_finish_split(blmm_ctx* ctx, const Pipe& P, const NullModel& nm, double* d
   if ((rc = lr_region_scan(ctx, P, r1, dL, ldL))) return rc;
   BLMM_HIP(hipStreamWaitEvent(main_stream, ctx->ev_join, 0));
   if ((rc = lr_fix(ctx, P, nm, dh2, dL, ldL))) return rc;
+  if ((rc = illcond_rescan(ctx, P, nm, P.m, dh2, dL, ldL))) return rc;
   tm.mark();
   return BLMM_OK;
 }
@@ -649,7 +670,7 @@ void blmm_destroy(blmm_ctx* ctx) {
                     &ctx->iyy, &ctx->h2, &ctx->h2idx, &ctx->sig2, &ctx->ell, &ctx->isx, &ctx->stat, &ctx->gridd, &ctx->misc,
                     &ctx->EllTab, &ctx->inY, &ctx->inG, &ctx->inK, &ctx->inCov, &ctx->inW, &ctx->outL, &ctx->outH2,
                     &ctx->tmpA, &ctx->tmpB, &ctx->tmpC, &ctx->perm, &ctx->r0, &ctx->altbuf, &ctx->logtab, &ctx->lraw,
-                    &ctx->wbQ, &ctx->wbW, &ctx->wbRk, &ctx->lrT, &ctx->lrC, &ctx->lrL, &ctx->lrFlag, &ctx->lrPart, &ctx->lrPerm, &ctx->lrDen0, &ctx->eigW, &ctx->xf32, &ctx->pf32, &ctx->brSt, &ctx->brList};
+                    &ctx->wbQ, &ctx->wbW, &ctx->wbRk, &ctx->lrT, &ctx->lrC, &ctx->lrL, &ctx->lrFlag, &ctx->lrPart, &ctx->lrPerm, &ctx->lrDen0, &ctx->eigW, &ctx->xf32, &ctx->pf32, &ctx->brSt, &ctx->brList, &ctx->illList, &ctx->qrSlab};
   for (DevBuf* b : bufs) if (b->p) hipFree(b->p);
   for (auto& s : ctx->evsets) for (auto& e : s.e) (void)hipEventDestroy(e);
   if (ctx->rb_handle && ctx->rb_destroy) ctx->rb_destroy(ctx->rb_handle);
@@ -778,6 +799,7 @@ int blmm_lod_colmax(blmm_ctx* ctx, const double* L, int64_t p, int64_t m, double
   if ((rc = ensure(ctx, ctx->tmpA, sizeof(double) * (size_t)(m > 0 ? m : 1)))) return rc;
   if ((rc = ensure(ctx, ctx->tmpB, sizeof(int64_t) * (size_t)(m > 0 ? m : 1)))) return rc;
   BLMM_HIP(hipMemcpyAsync(ctx->outL.p, L, sizeof(double) * (size_t)p * m, hipMemcpyHostToDevice, ctx->stream));
+  if (m > 0) { ctx->last_L = ptr<double>(ctx->outL); ctx->last_p = p; ctx->last_m = m; ctx->last_f32 = false; }
   if ((rc = launch_colmax(ctx, ptr<double>(ctx->outL), p, m, p, ptr<double>(ctx->tmpA), ptr<int64_t>(ctx->tmpB)))) return rc;
   BLMM_HIP(hipMemcpyAsync(max_out, ctx->tmpA.p, sizeof(double) * (size_t)m, hipMemcpyDeviceToHost, ctx->stream));
   if (argmax_out) BLMM_HIP(hipMemcpyAsync(argmax_out, ctx->tmpB.p, sizeof(int64_t) * (size_t)m, hipMemcpyDeviceToHost, ctx->stream));
@@ -886,7 +908,19 @@ int blmm_bulkscan_dev(blmm_ctx* ctx, const blmm_opts* opts, const double* dY, in
       tm.mark();
       ScanArgs a = scan_args(ctx, P, ptr<double>(ctx->panels), ldp, dL_out, ldL, m);
       if ((rc = launch_scan_exact(ctx, a, P.c))) return rc;
+      if ((rc = illcond_rescan(ctx, P, nm, m, dh2_out, dL_out, ldL))) return rc;
       tm.mark();
+    }
+    if (opts->compat_flags & BLMM_FLAG_H2_AUDIT) {
+      // opt-in diagnostic: the profile log-likelihood of every trait on the grid 0, 1/16, .., 15/16 -> n_h2_multimodal
+      double gridh[16];
+      for (int g = 0; g < 16; ++g) gridh[g] = g / 16.0;
+      double* dg = nullptr;
+      if ((rc = grid_to_device(ctx, gridh, 16, &dg))) return rc;
+      if ((rc = ensure(ctx, ctx->EllTab, sizeof(double) * (size_t)16 * m))) return rc;
+      if ((rc = launch_loglik_grid(ctx, nm, P.Yt, P.ldy, m, P.Z0, P.lam, dg, 16, ptr<double>(ctx->EllTab), nullptr, nullptr, P.stat))) return rc;
+      if ((rc = launch_h2_audit(ctx, ptr<double>(ctx->EllTab), 16, m, P.stat))) return rc;
+      ctx->audit_ran = true;
     }
   } else if (opts->method == BLMM_NULL_GRID) {
     if ((rc = ensure(ctx, ctx->h2idx, sizeof(int) * (size_t)m))) return rc;
@@ -963,7 +997,7 @@ int blmm_bulkscan(blmm_ctx* ctx, const blmm_opts* opts, const double* Y, int64_t
   if ((size_t)p * m > 0 && (rc = copy_to_host(ctx, L_out, ctx->outL.p, sizeof(double) * (size_t)p * m))) return rc;
   if (h2_elems > 0 && (rc = copy_to_host(ctx, h2_out, ctx->outH2.p, sizeof(double) * h2_elems))) return rc;
   BLMM_HIP(hipStreamSynchronize(ctx->stream));
-  return BLMM_OK;
+  return check_sticky(ctx);   // a device-side failure of THIS call (no status passed): reported now, not by the next call
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -1001,6 +1035,8 @@ static int scan_perms_impl(blmm_ctx* ctx, const blmm_opts* opts, const double* d
     ScanArgs a = scan_args(ctx, P, pan0, ldp0, dlod_out, p, 1);
     a.isx = ptr<double>(ctx->isx); a.ld_isx = P.ldx;
     if ((rc = launch_scan_table(ctx, a))) return rc;
+    // the trait's own LOD vector (scan_null's result) gets the conditioning guard; the permutation matrix keeps the Cholesky form
+    if ((rc = illcond_rescan(ctx, P, nm, 1, dscalars_out + 1, dlod_out, p))) return rc;
     if (nperms > 0 && dLperms32_out) {
       // fp32 path: fp32 fragment-major copies of the rotated markers and of the permutation panel, fp32 MFMA, fp32 L
       const int64_t ldxf = round_up(p, 256), ldpf = ldp1;
@@ -1085,7 +1121,7 @@ static int scan_perms_host(blmm_ctx* ctx, const blmm_opts* opts, const double* y
   if (p > 0) BLMM_HIP(hipMemcpyAsync(lod_out, dL, sizeof(double) * p, hipMemcpyDeviceToHost, ctx->stream));
   if (p > 0 && nperms > 0 && (rc = copy_to_host(ctx, Lperms_out, dLp, esz * (size_t)p * nperms))) return rc;
   BLMM_HIP(hipStreamSynchronize(ctx->stream));
-  return BLMM_OK;
+  return check_sticky(ctx);
 }
 
 int blmm_scan_perms(blmm_ctx* ctx, const blmm_opts* opts, const double* y, int64_t n, const double* G, int64_t p,
@@ -1163,7 +1199,7 @@ int blmm_scan_alt(blmm_ctx* ctx, const blmm_opts* opts, const double* y, int64_t
   BLMM_HIP(hipMemcpyAsync(lod_out, dL, sizeof(double) * p, hipMemcpyDeviceToHost, ctx->stream));
   BLMM_HIP(hipMemcpyAsync(h2_each_out, dL + p, sizeof(double) * p, hipMemcpyDeviceToHost, ctx->stream));
   BLMM_HIP(hipStreamSynchronize(ctx->stream));
-  return BLMM_OK;
+  return check_sticky(ctx);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -1327,6 +1363,7 @@ int blmm_liteqtl_given_h2(blmm_ctx* ctx, const double* Y0, int64_t n, int64_t m,
     if ((rc = launch_panels(ctx, nm, P.Yt, P.ldy, m, P.Z0, P.lam, ptr<double>(ctx->h2), 1, ptr<double>(ctx->panels), P.ldy, P.stat))) return rc;
     ScanArgs a = scan_args(ctx, P, ptr<double>(ctx->panels), P.ldy, ptr<double>(ctx->outL), p, m);
     if ((rc = launch_scan_exact(ctx, a, P.c))) return rc;
+    if ((rc = illcond_rescan(ctx, P, nm, m, ptr<double>(ctx->h2), ptr<double>(ctx->outL), p))) return rc;
   }
   BLMM_HIP(hipMemcpyAsync(LOD_out, ctx->outL.p, sizeof(double) * (size_t)p * m, hipMemcpyDeviceToHost, ctx->stream));
   BLMM_HIP(hipStreamSynchronize(ctx->stream));

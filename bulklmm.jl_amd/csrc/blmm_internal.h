@@ -21,9 +21,10 @@ constexpr int CFAST = 4;         // ... with the tuned forms (LDS-resident evalu
   case 5: M(5); break; case 6: M(6); break; case 7: M(7); break; case 8: M(8); break;
 constexpr int TILE_T = 64;       // traits per workgroup tile of the scan kernels
 constexpr int TILE_I = 128;      // markers per workgroup tile of the scan kernels
-constexpr int NSTAT = 16;        // device status counters ([6],[7]: eigensolver clocks, [8]: weight-basis rank, [9]: its residual, [10]: traits re-scanned full rank, [12..15]: shared-weights traits / the others of the two panel regions (k_lr_classify))
+constexpr int NSTAT = 24;        // device status counters ([6],[7]: eigensolver clocks, [8]: weight-basis rank, [9]: its residual, [10]: traits re-scanned full rank, [11]: eigensolver abort code, [12..15]: shared-weights traits / the others of the two panel regions (k_lr_classify), [16..18]: StatIdx below)
 
-enum StatIdx { ST_NEG_EIG = 0, ST_NONPOS_W = 1, ST_ZERO_NORM = 2, ST_NAN_LOD = 3, ST_BRENT_MAXIT = 4, ST_JACOBI_SWEEPS = 5 };
+enum StatIdx { ST_NEG_EIG = 0, ST_NONPOS_W = 1, ST_ZERO_NORM = 2, ST_NAN_LOD = 3, ST_BRENT_MAXIT = 4, ST_JACOBI_SWEEPS = 5,
+               ST_H2_BOUNDARY = 16, ST_H2_MULTIMODAL = 17, ST_ILLCOND = 18 };
 
 inline int64_t round_up(int64_t x, int64_t q) { return (x + q - 1) / q * q; }
 
@@ -44,7 +45,7 @@ struct blmm_ctx {
   std::string err;
   // grow-only workspace
   blmm::DevBuf Ks, V, lam, U, Zs, Z0, Rp, Yt, Xt, panels, iyy, h2, h2idx, sig2, ell, isx, stat, gridd, misc, EllTab,
-      inY, inG, inK, inCov, inW, outL, outH2, tmpA, tmpB, tmpC, perm, r0, altbuf, logtab, lraw, wbQ, wbW, wbRk, lrT, lrC, lrL, lrFlag, lrPart, lrPerm, lrDen0, eigW, xf32, pf32, brSt, brList;
+      inY, inG, inK, inCov, inW, outL, outH2, tmpA, tmpB, tmpC, perm, r0, altbuf, logtab, lraw, wbQ, wbW, wbRk, lrT, lrC, lrL, lrFlag, lrPart, lrPerm, lrDen0, eigW, xf32, pf32, brSt, brList, illList, qrSlab;
   // event sets: one per timed call since the last blmm_read_timings (grown on demand, reused afterwards)
   struct EvSet { hipEvent_t e[8]; int n; };
   std::vector<EvSet> evsets;
@@ -66,6 +67,7 @@ struct blmm_ctx {
   volatile int64_t* hflag = nullptr;
   // the LOD matrix of the last host-pointer call, still resident in the workspace (kernels_post.hip: blmm_last_*)
   const double* last_L = nullptr; int64_t last_p = 0, last_m = 0; bool last_f32 = false;
+  bool audit_ran = false;              // the current call ran the BLMM_FLAG_H2_AUDIT pass (finish_status: n_h2_multimodal, else -1)
   int eig_plan_n = -1;                 // n whose merge tree sits in eigW (kernels_eig.hip)
   blmm::HostStage* hstage = nullptr;   // pinned staging ring + copy threads of the host-pointer entry points (host_path.hip)
 };
@@ -84,10 +86,20 @@ int fail(blmm_ctx* ctx, int code, const std::string& msg);
 int ensure(blmm_ctx* ctx, DevBuf& b, size_t bytes);
 // Kernels whose workgroups meet at a grid barrier (k_sytrd, k_wbasis_mw) need ALL their workgroups resident at once.  Two of
 // them launched from different contexts / streams on one device could each hold part of the CUs and starve the other (their
-// bounded spins would then fail the calls).  grid_kernel_begin makes the stream wait for the previous such kernel on that
-// device, grid_kernel_end records this one: they run one after the other on the device, with no host synchronisation.
-int grid_kernel_begin(blmm_ctx* ctx);
-int grid_kernel_end(blmm_ctx* ctx);
+// bounded spins would then fail the calls).  A GridKernelGuard makes the stream wait for the previous such kernel on that
+// device and, after the launch, record() marks this one: they run one after the other on the device, with no host
+// synchronisation.  The guard holds the device's mutex from the wait to its destruction, so that wait -> launch -> record is
+// one step against the other contexts' threads (blmm_bulkscan_multi with repeated device ids drives several contexts of one
+// device from different threads; with begin / end as two separately locked calls both could pass the wait before either
+// recorded).
+struct GridKernelGuard {
+  blmm_ctx* ctx; int dev; int rc = 0;
+  explicit GridKernelGuard(blmm_ctx* c);
+  int record();
+  ~GridKernelGuard();
+  GridKernelGuard(const GridKernelGuard&) = delete;
+  GridKernelGuard& operator=(const GridKernelGuard&) = delete;
+};
 // host_path.hip: device -> caller memory in stream order; returns when the bytes are in place
 int copy_to_host(blmm_ctx* ctx, void* dst, const void* dsrc, size_t bytes);
 void destroy_host_stage(HostStage* hs);
@@ -147,6 +159,8 @@ int launch_alt_brent(blmm_ctx* ctx, const NullModel& nm, const double* Yt, int64
 int launch_loglik_grid(blmm_ctx* ctx, const NullModel& nm, const double* Yt, int64_t ldy, int64_t m, const double* Z0,
                        const double* lam, const double* grid_dev, int ngrid, double* EllTab, int* h2idx, double* h2,
                        int64_t* stat);
+// BLMM_FLAG_H2_AUDIT: counts the traits whose grid profile (EllTab, ngrid x m) has two or more local maxima
+int launch_h2_audit(blmm_ctx* ctx, const double* EllTab, int ngrid, int64_t m, int64_t* stat);
 // A-side panels for the scan kernels from per-trait h2: panel 0 = w.*resid/sqrt(yy); if full: panel 1 = w,
 // panels 2..1+c = w .* (Z0 Linv')_q.  panels: [np][npad][ldp]
 int launch_panels(blmm_ctx* ctx, const NullModel& nm, const double* Yt, int64_t ldy, int64_t m, const double* Z0,
@@ -214,6 +228,11 @@ int launch_cvt_f32(blmm_ctx* ctx, const double* M, int64_t ld_in, int rows_valid
                    int64_t ld_out, int kblocks);
 int launch_scan_f32(blmm_ctx* ctx, const float* XF, int64_t ldxf, const float* PF, int64_t ldpf, int npad, int n,
                     int64_t p, int64_t m, const double* isx, float* L, int64_t ldL, int64_t* stat);
+// kernels_dyn.hip: conditioning guard of the null-exact scan (c >= 2) and the QR-grade re-scan of the flagged traits
+int launch_illcond_flag(blmm_ctx* ctx, const NullModel& nm, int64_t m, const double* Z0, const double* lam, const double* h2,
+                        int* list, int64_t* stat);
+int launch_scan_qr(blmm_ctx* ctx, const NullModel& nm, const double* Yt, int64_t ldy, const double* Xt, int64_t ldx, int64_t p,
+                   const double* Z0, const double* lam, const double* h2, const int* list, double* L, int64_t ldL, int64_t* stat);
 // kernels_lowrank.hip
 int launch_wbasis(blmm_ctx* ctx, const double* lam, int n, double* Wk, double* Q, int* rk, int64_t* stat);
 int launch_lr_tpanels(blmm_ctx* ctx, const double* Xt, int64_t ldx, int64_t p, int n, int c, int npad, const double* Z0,

@@ -62,6 +62,15 @@ struct blmm_multi {
 
 namespace {
 
+// The multi-device entry points visit every device from the CALLER's thread (context creation, the all-gather loops, the
+// copy-out); the caller's current HIP device is put back on every exit path, so a torch caller keeps allocating and
+// launching where it was.
+struct DeviceRestore {
+  int d = -1;
+  DeviceRestore() { if (hipGetDevice(&d) != hipSuccess) d = -1; }
+  ~DeviceRestore() { if (d >= 0) (void)hipSetDevice(d); }
+};
+
 int mfail(blmm_multi* mc, int code, const std::string& msg) {
   if (mc) mc->err = msg;
   return code;
@@ -164,6 +173,7 @@ int blmm_create_multi(const int* device_ids, int ndev, blmm_multi** out) {
   if (avail <= 0) return BLMM_ERR_NO_DEVICE;
   if (ndev <= 0) ndev = avail;            // ndev <= 0: every visible device
   if (ndev > 64) return BLMM_ERR_INVALID;
+  DeviceRestore keep_device;
   blmm_multi* mc = new blmm_multi();
   mc->ndev = ndev;
   mc->dY.resize(ndev); mc->dG.resize(ndev); mc->dK.resize(ndev); mc->dCov.resize(ndev); mc->dW.resize(ndev);
@@ -187,6 +197,7 @@ int blmm_create_multi(const int* device_ids, int ndev, blmm_multi** out) {
 
 void blmm_destroy_multi(blmm_multi* mc) {
   if (!mc) return;
+  DeviceRestore keep_device;
   for (Worker* w : mc->wk) {
     { std::lock_guard<std::mutex> lk(w->mu); w->quit = true; }
     w->cv.notify_all();
@@ -227,6 +238,7 @@ int blmm_bulkscan_multi(blmm_multi* mc, const blmm_opts* opts, const blmm_multi_
   if (!Y || !G || !K) return mfail(mc, BLMM_ERR_INVALID, "bulkscan: NULL buffer");
   if (gather == BLMM_GATHER_HOST_SHARDS && (!L_out || !h2_out)) return mfail(mc, BLMM_ERR_INVALID, "bulkscan: NULL output buffer");
   if (n < 1 || m < 0 || p < 0) return mfail(mc, BLMM_ERR_DIM, "Dimension mismatch.");
+  DeviceRestore keep_device;
   const int R = mc->ndev;
   const bool alt = opts->method == BLMM_ALT_GRID;
   const int64_t blk = (m + R - 1) / R;          // columns per device; the last shard may be shorter (or empty)
@@ -280,8 +292,9 @@ int blmm_bulkscan_multi(blmm_multi* mc, const blmm_opts* opts, const blmm_multi_
     e = blmm_bulkscan_dev(ctx, opts, ptr<double>(mc->dY[r]), n, mr, ptr<double>(mc->dG[r]), p, dCov, dCov ? ncov : 0,
                           ptr<double>(mc->dK[r]), dW, h2_grid, ngrid, dL, p > 0 ? p : 1, dH, status ? status + r : nullptr);
     if (e) { (void)hipStreamSynchronize(ctx->stream); return e; }
-    BLMM_HIP(hipStreamSynchronize(ctx->stream));   // the host inputs may be released; the blocks are complete
-    return BLMM_OK;
+    // the host inputs may be released; the blocks are complete; a device-side failure of this call made without a status
+    // (grid-barrier timeout, eigensolver abort) is reported by this call
+    return blmm_synchronize(ctx);
   });
   if (rc) return rc;
   mc->last_m = m; mc->last_p = p; mc->last_block = blk; mc->last_gather = gather; mc->last_method = opts->method;

@@ -112,4 +112,14 @@ __device__ __forceinline__ double group_sum(double x) {
   return x;
 }
 
+// Adds the number of lanes of the wave with `flag` set to *cnt: one atomic per wave (every lane of the wave must call it).
+__device__ __forceinline__ void wave_count(int64_t* cnt, bool flag) {
+  const unsigned long long b = __ballot(flag);
+  if (b != 0ull && (int)(threadIdx.x & 63) == __ffsll((long long)b) - 1)
+    atomicAdd((unsigned long long*)cnt, (unsigned long long)__popcll(b));
+}
+
+// h2 estimates on a boundary of [0, 1] (blmm_status.n_h2_boundary)
+__device__ __forceinline__ bool h2_on_boundary(double h2) { return h2 <= 1e-6 || h2 >= 1.0 - 1e-6; }
+
 }  // namespace blmm

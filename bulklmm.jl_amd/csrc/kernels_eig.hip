@@ -1410,10 +1410,16 @@ int launch_eig_dc(blmm_ctx* ctx, const double* A, int n, double* lraw, double* e
     BLMM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sytrd), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     int nthr = 512;                                           // barriers at 1024 threads cost almost twice as much
     if (const char* te = getenv("BLMM_SYTRD_NT")) { const int tv = atoi(te); if (tv == 256 || tv == 512) nthr = tv; }
-    if (G > 1 && (rc = grid_kernel_begin(ctx))) return rc;
-    hipLaunchKernelGGL(k_sytrd, dim3(G), dim3(nthr), lds, ctx->stream, A, n, nloc, d, e, tau, V, ex, stat);
-    KCHECK();
-    if (G > 1 && (rc = grid_kernel_end(ctx))) return rc;
+    if (G > 1) {
+      GridKernelGuard gk(ctx);
+      if (gk.rc) return gk.rc;
+      hipLaunchKernelGGL(k_sytrd, dim3(G), dim3(nthr), lds, ctx->stream, A, n, nloc, d, e, tau, V, ex, stat);
+      KCHECK();
+      if ((rc = gk.record())) return rc;
+    } else {
+      hipLaunchKernelGGL(k_sytrd, dim3(G), dim3(nthr), lds, ctx->stream, A, n, nloc, d, e, tau, V, ex, stat);
+      KCHECK();
+    }
   }
   // ---- 2. leaves ----
   // a node reads the full square [lo, hi)^2 of its input Q: the blocks off the solved halves' diagonal must read as zero

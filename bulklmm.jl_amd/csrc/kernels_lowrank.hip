@@ -481,11 +481,11 @@ int launch_wbasis(blmm_ctx* ctx, const double* lam, int n, double* Wk, double* Q
     x.val = Wk; x.col = Wk + 2 * G; x.cnt = reinterpret_cast<unsigned int*>(Wk + 2 * G + (size_t)2 * G * n);
     BLMM_HIP(hipMemsetAsync(x.cnt, 0, sizeof(unsigned int) * 2, ctx->stream));
     BLMM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wbasis_mw), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    { const int rcg = grid_kernel_begin(ctx); if (rcg) return rcg; }
+    GridKernelGuard gk(ctx);
+    if (gk.rc) return gk.rc;
     hipLaunchKernelGGL(k_wbasis_mw, dim3(G), dim3(1024), lds, ctx->stream, lam, n, S, qcap, Q, rk, stat, x);
     KCHECK();
-    { const int rcg = grid_kernel_end(ctx); if (rcg) return rcg; }
-    return BLMM_OK;
+    return gk.record();
   }
   {
     // sample columns in global memory (L2-resident), one workgroup: slow (~0.1 ms per basis vector) but has no

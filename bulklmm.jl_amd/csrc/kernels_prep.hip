@@ -1483,6 +1483,7 @@ __global__ void __launch_bounds__(256, BRENT_MINW) k_brent(NullModel nm, const d
       const int it1 = brent_run(f, S, BRENT_PHASE1);
       fin = null_ell_reg<C, LPT>(S.x, R, n, nm.prior_a, nm.prior_b, nm.reml, s_ln, &nonpos);
       const int ts = threadIdx.x / LPT;
+      wave_count(&stat[ST_H2_BOUNDARY], sub == 0 && valid && S.done && h2_on_boundary(S.x));
       if (sub == 0) {
         if (valid && cont.fin) cont.fin[j] = S.done ? 1 : 0;
         if (valid && S.done) {
@@ -1534,6 +1535,7 @@ __global__ void __launch_bounds__(256, BRENT_MINW) k_brent(NullModel nm, const d
       const int it0 = s_bit[src];
       const int it2 = brent_run(f, S, 1000 - it0);
       fin = null_ell_reg<C, LPT>(S.x, R, n, nm.prior_a, nm.prior_b, nm.reml, s_ln, &nonpos);
+      wave_count(&stat[ST_H2_BOUNDARY], valid2 && sub == 0 && h2_on_boundary(S.x));
       if (valid2 && sub == 0) {
         h2out[j2] = S.x;
         if (s2out) s2out[j2] = fin.sigma2;
@@ -1555,6 +1557,7 @@ __global__ void __launch_bounds__(256, BRENT_MINW) k_brent(NullModel nm, const d
     best_x = brent_search(f, nint, valid, &hit_max);
     fin = null_ell<C, LPT>(best_x, ycol, ldy, sub, n, sZ, sLam, nm.prior_a, nm.prior_b, nm.reml, &nonpos);
   }
+  wave_count(&stat[ST_H2_BOUNDARY], valid && sub == 0 && h2_on_boundary(best_x));
   if (valid && sub == 0) {
     h2out[j] = best_x;
     if (s2out) s2out[j] = fin.sigma2;
@@ -1599,6 +1602,7 @@ __global__ void __launch_bounds__(256, BRENT_MINW2) k_brent2(NullModel nm, const
   const int it0 = (int)cont.st[(int64_t)10 * m + j];
   const int it2 = brent_run(f, S, 1000 - it0);
   const EllOut fin = null_ell_reg<C, LPT, (NK / 4 < BRENT_UNROLL2 ? NK / 4 : BRENT_UNROLL2), NK>(S.x, R, n, nm.prior_a, nm.prior_b, nm.reml, s_ln, &nonpos);
+  wave_count(&stat[ST_H2_BOUNDARY], valid && sub == 0 && h2_on_boundary(S.x));
   if (valid && sub == 0) {
     h2out[j] = S.x;
     if (s2out) s2out[j] = fin.sigma2;
@@ -1976,6 +1980,32 @@ int launch_loglik_grid(blmm_ctx* ctx, const NullModel& nm, const double* Yt, int
     default: return fail(ctx, BLMM_ERR_UNSUPPORTED, BLMM_C_ERR);
   }
 #undef LG
+  KCHECK();
+  return BLMM_OK;
+}
+
+// BLMM_FLAG_H2_AUDIT: local maxima of every trait's profile log-likelihood on a grid (EllTab: ngrid x m from
+// launch_loglik_grid).  Grid point g is a local maximum when it exceeds both neighbours by more than 1e-9 |Ell| (the end
+// points have one neighbour); two or more -> the trait is counted in stat[ST_H2_MULTIMODAL]: a local optimiser (Brent,
+// src/gridbrent.jl:9-24) may end in either one.
+__global__ void __launch_bounds__(256) k_h2_audit(const double* __restrict__ EllTab, int ngrid, int64_t m, int64_t* stat) {
+  const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  int nmax = 0;
+  if (j < m && ngrid >= 2) {
+    const double* e = EllTab + j * (int64_t)ngrid;
+    for (int g = 0; g < ngrid; ++g) {
+      const double v = e[g], slack = 1e-9 * fabs(v);
+      const bool up = (g == 0) || v > e[g - 1] + slack;
+      const bool dn = (g == ngrid - 1) || v > e[g + 1] + slack;
+      nmax += (up && dn) ? 1 : 0;
+    }
+  }
+  wave_count(&stat[ST_H2_MULTIMODAL], nmax >= 2);
+}
+
+int launch_h2_audit(blmm_ctx* ctx, const double* EllTab, int ngrid, int64_t m, int64_t* stat) {
+  if (m <= 0) return BLMM_OK;
+  hipLaunchKernelGGL(k_h2_audit, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, ctx->stream, EllTab, ngrid, m, stat);
   KCHECK();
   return BLMM_OK;
 }

@@ -10,12 +10,15 @@ from typing import Tuple
 
 
 def trait_shard(m: int, rank: int, world: int) -> Tuple[int, int]:
-    """Contiguous, balanced (first `m % world` ranks get one more) column range of rank `rank`."""
+    """Column range of rank `rank`: blocks of ceil(m / world) columns, the last ranks may be short or empty --
+    [r*ceil(m/R), min(m, (r+1)*ceil(m/R))), SURVEY.md §8(e).  The SAME partition as the C ABI's blmm_multi_shard
+    (bulklmm.jl_amd/csrc/blmm_multi.hip; tests/test_abi.py checks the two against each other): fixed-size blocks are
+    what lets the all-gather run in place on the full-size (padded) matrix."""
     if world < 1 or not (0 <= rank < world):
         raise ValueError("bad rank/world")
-    base, rem = divmod(m, world)
-    lo = rank * base + min(rank, rem)
-    return lo, lo + base + (1 if rank < rem else 0)
+    blk = -(-m // world)
+    lo = min(m, rank * blk)
+    return lo, min(m, lo + blk)
 
 
 def shard_sizes(m: int, world: int):

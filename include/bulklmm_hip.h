@@ -28,7 +28,8 @@
 extern "C" {
 #endif
 
-#define BLMM_VERSION 201 /* 0.2.1: blmm_status.lowrank_shared, readers, blmm_scan_alt; 200: lowrank_fallback, BLMM_STREAM_NULL, multi-GPU */
+#define BLMM_VERSION 202 /* 0.2.2: blmm_status.n_h2_boundary / n_h2_multimodal / n_illcond_rescan (appended), BLMM_FLAG_H2_AUDIT;
+                            201: lowrank_shared, readers, blmm_scan_alt; 200: lowrank_fallback, BLMM_STREAM_NULL, multi-GPU */
 
 typedef struct blmm_ctx blmm_ctx;
 
@@ -56,6 +57,14 @@ enum blmm_decomp { BLMM_EIGEN = 0, BLMM_SVD = 1 };
 #define BLMM_COMPAT_ALT_COUNTER 1 /* B2: h2_panel indexed by an improvement counter, src/bulkscan_helpers.jl:342-343 */
 #define BLMM_COMPAT_ALT_TRUE_WEIGHTS 2 /* blmm_scan_alt: evaluate the closing log-likelihoods at makeweights(h2); the default
                                           restates src/scan.jl:431-436, which hands wls the square roots of the weights */
+/* Not a compat switch but carried in the same word: null-exact only, opt-in diagnostic.  After the h2 search the profile
+ * log-likelihood of EVERY trait is evaluated on the 16-point grid 0, 1/16, .., 15/16 and blmm_status.n_h2_multimodal counts
+ * the traits whose grid profile has two or more local maxima.  Brent (src/gridbrent.jl:9-24, one run over [0, 1] when
+ * optim_interval = 1) is a LOCAL method: on such a trait rounding-level differences decide which maximum a run ends in --
+ * for the reference's arithmetic as much as for this library's -- so these are the traits whose h2 (and LOD column) may
+ * legitimately differ between two correct implementations; raising optim_interval resolves them.  Costs one grid
+ * log-likelihood pass (~0.06 ms at BXD size). */
+#define BLMM_FLAG_H2_AUDIT 4
 
 /* Mirrors the keyword arguments of bulkscan()/scan() 1:1 (src/bulkscan.jl:81-92, src/scan.jl:94-109).
  * `nb` and `nt_blas` (thread blocking knobs of the CPU reference) have no meaning here. */
@@ -89,6 +98,14 @@ typedef struct blmm_status {
   double lowrank_resid;    /* largest relative residual |w_j - Q Q'w_j| / |w_j| over all traits of the rank-R class (before the
                               re-scan); the shared-weights class is bounded by its own criterion, the same tolerance         */
   double t_eigen_ms, t_rotate_ms, t_h2_ms, t_prep_ms, t_scan_ms, t_total_ms;
+  int64_t n_h2_boundary;   /* null-exact / scan: traits whose h2 estimate sits on a boundary of [0, 1] (<= 1e-6 or >= 1 - 1e-6):
+                              the likelihood is one-sided there and x_tol shrinks with x, so these are the long Brent runs  */
+  int64_t n_h2_multimodal; /* BLMM_FLAG_H2_AUDIT: traits whose profile log-likelihood has >= 2 local maxima on the 16-point
+                              grid (optimiser-sensitive: see the flag); -1 when the audit was not requested                  */
+  int64_t n_illcond_rescan;/* traits whose weighted null design sqrt(w) .* Z0 is ill conditioned (Cholesky pivot ratio of
+                              Z0'WZ0 above 1e4, i.e. cond(sqrt(W) Z0) > 100: h2 -> 1 with several covariates): their LOD
+                              columns were recomputed with an orthogonalised (MGS2, QR-grade) projection, as the
+                              reference's `resid` does by Householder QR (src/wls.jl:221-241)                               */
 } blmm_status;
 
 /* ---- library / context ------------------------------------------------------------------ */

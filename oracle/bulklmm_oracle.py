@@ -648,8 +648,10 @@ def bulkscan_null_grid(Y, G, K, grid_list, Covar=None, addIntercept: bool = True
 
 def bulkscan_alt_grid(Y, G, K, hsq_list, Covar=None, addIntercept: bool = True, weights=None,
                       prior_variance: float = 1.0, prior_sample_size: float = 0.0, reml: bool = False,
-                      decomp_scheme: str = "eigen", compat_counter_quirk: bool = False) -> BulkscanAltResult:
+                      decomp_scheme: str = "eigen", compat_counter_quirk: bool = False, return_tables: bool = False):
     """src/bulkscan.jl:428-526 (alt-grid) with `tmax!` (src/bulkscan_helpers.jl:330-350).
+    `return_tables` (test hook, not in the reference): also return the stack logL1[g, i, j] of every grid point, so that a
+    test can tell a genuine arg-max disagreement from a tie decided at rounding level.
 
     Deviations, both flagged in SURVEY.md Appendix B: (B1) `num_of_covar` is passed for every grid point
     (the reference omits it at src/bulkscan.jl:510, which makes c>1 fail with a dimension error);
@@ -686,8 +688,11 @@ def bulkscan_alt_grid(Y, G, K, hsq_list, Covar=None, addIntercept: bool = True, 
     logL0_all[0, :] = logL0
     h2_panel = np.ones((p, m)) * hsq_list[0]
     counter = np.ones((p, m), dtype=np.int64)
+    tables = [logL1.copy()] if return_tables else None
     for k, h in enumerate(hsq_list[1:], start=1):
         logL1_k, logL0_k = one(h)
+        if return_tables:
+            tables.append(logL1_k)
         logL0_all[k, :] = logL0_k
         better = logL1 < logL1_k
         logL1 = np.where(better, logL1_k, logL1)
@@ -698,6 +703,8 @@ def bulkscan_alt_grid(Y, G, K, hsq_list, Covar=None, addIntercept: bool = True, 
             h2_panel = np.where(better, h, h2_panel)
     logL0_opt = np.max(logL0_all, axis=0, keepdims=True)
     L = (logL1 - logL0_opt) / ln10
+    if return_tables:
+        return BulkscanAltResult(L, h2_panel), np.stack(tables)
     return BulkscanAltResult(L, h2_panel)
 
 

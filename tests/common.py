@@ -71,3 +71,26 @@ def assert_lod_close(got, ref, rtol=RTOL, atol=ATOL, what="LOD"):
         raise AssertionError(f"{what}: {int(bad.sum())}/{bad.size} outside |d| <= {rtol}*|ref| + {atol}; "
                              f"worst at {i}: got {got[i]!r} ref {ref[i]!r} |d| {err[i]:.3e}; max rel "
                              f"{np.nanmax(err / np.maximum(np.abs(ref), 1e-300)):.3e}")
+
+
+def assert_h2_panel_ties_only(got_panel, ref_panel, logL1, grid, quirk=False, rel=1e-12, what="h2_panel"):
+    """alt-grid: wherever the arg-max grid value differs from the oracle's, the two candidates must be TIED in the oracle's
+    own logL1 table (logL1[g, i, j], O.bulkscan_alt_grid(..., return_tables=True)) to `rel` relative -- tmax!'s strict `<`
+    (src/bulkscan_helpers.jl:330-350) then decides at rounding level, on either side.  With the improvement-counter quirk
+    (B2) the panel value depends on every comparison of the running maximum: a mismatch needs a near-tie somewhere along
+    the grid.  Returns the number of (tie-explained) mismatches."""
+    grid = np.asarray(grid, dtype=np.float64)
+    bad = np.argwhere(got_panel != ref_panel)
+    for i, j in bad:
+        col = logL1[:, i, j]
+        scale = max(1.0, float(np.abs(col).max()))
+        if quirk:
+            run = np.maximum.accumulate(col)
+            gaps = np.abs(col[1:] - run[:-1])
+            assert gaps.min() <= rel * scale, f"{what}[{i},{j}]: counter differs without a near-tie (min gap {gaps.min():.3e})"
+        else:
+            gg = int(np.flatnonzero(grid == got_panel[i, j])[0])
+            gr = int(np.flatnonzero(grid == ref_panel[i, j])[0])
+            assert abs(col[gg] - col[gr]) <= rel * scale, \
+                f"{what}[{i},{j}]: {got_panel[i, j]} vs {ref_panel[i, j]}: logL1 {col[gg]!r} vs {col[gr]!r} is not a tie"
+    return len(bad)

@@ -23,7 +23,7 @@ def test_library_exports_every_declared_symbol(blmm):
     for s in syms:
         assert hasattr(lib, s), s
     assert sorted(blmm.EXPORTS) == syms
-    assert lib.blmm_version() == 201
+    assert lib.blmm_version() == 202
 
 
 def header_struct(name):
@@ -101,12 +101,22 @@ def test_host_mirror_argument_checks(blmm):
 
 
 def test_trait_sharding_helper(blmm):
-    for m, w in [(35554, 8), (10, 3), (7, 8), (0, 2)]:
+    """ONE partition everywhere (blocks of ceil(m/R)): the torch.distributed host path (sharding.trait_shard,
+    bench.py) and the C ABI's multi-GPU entry point (blmm_multi_shard) must agree."""
+    import ctypes as C
+    lib = blmm.load()
+    for m, w in [(35554, 8), (10, 3), (7, 8), (0, 2), (20000, 8), (1, 1), (4096, 5)]:
         parts = [blmm.trait_shard(m, r, w) for r in range(w)]
         assert parts[0][0] == 0 and parts[-1][1] == m
         assert all(parts[i][1] == parts[i + 1][0] for i in range(w - 1))
-        sizes = [b - a for a, b in parts]
-        assert max(sizes) - min(sizes) <= 1
+        blk = -(-m // w)
+        assert all(b - a in (blk, max(0, m - r * blk)) or b == a for r, (a, b) in enumerate(parts))
+        assert blmm.shard_sizes(m, w) == [b - a for a, b in parts]
+        for r in range(w):
+            lo, hi = C.c_int64(-1), C.c_int64(-1)
+            lib.blmm_multi_shard(m, r, w, C.byref(lo), C.byref(hi))
+            assert (lo.value, hi.value) == parts[r], (m, w, r)
+    assert [b - a for a, b in (blmm.trait_shard(35554, r, 8) for r in range(8))] == [4445] * 7 + [4439]
 
 
 def test_readers_for_the_reference_file_formats(blmm, tmp_path):

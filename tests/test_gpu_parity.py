@@ -13,18 +13,26 @@ import os
 import numpy as np
 import pytest
 
-from common import assert_lod_close, make_data, bxd_kinship, make_geno, kinship_of
+from common import assert_lod_close, assert_h2_panel_ties_only, make_data, bxd_kinship, make_geno, kinship_of
 from oracle import bulklmm_oracle as O
 
 pytestmark = pytest.mark.gpu
 
 
 def check_null_exact(got, Y, G, K, Cov=None, **kw):
-    """h2 parity, end-to-end parity (reference's own criterion) and strict LOD parity at the GPU's h2."""
+    """h2 parity, end-to-end parity (reference's own criterion) and strict LOD parity at the GPU's h2.  End to end -- each
+    side with its OWN h2 estimate -- the north-star bound 1e-6 relative is asserted for every trait whose two estimates agree
+    to 1e-8 (Brent stops at x_tol = sqrt(eps) |x| + eps on a likelihood that is flat to rounding over ~1e-7 around its
+    maximum: two correct searches agree on h2 only to ~1e-7, and d LOD / d h2 is O(LOD)); the other traits get the
+    reference's own criterion sum d^2 <= 1e-7 (test/bulkscan_test.jl:77-78) and 1e-4."""
     ref = O.bulkscan_null(Y, G, K, Covar=Cov, **kw)
-    assert np.abs(got.h2_null_list - ref.h2_null_list).max() <= 1e-6
+    dh = np.abs(got.h2_null_list - ref.h2_null_list)
+    assert dh.max() <= 1e-6
     assert np.sum((got.L - ref.L) ** 2, axis=0).max() <= 1e-7
     assert_lod_close(got.L, ref.L, rtol=1e-4, atol=1e-8, what="LOD (own h2 each side)")
+    close = dh <= 1e-8
+    if close.any():
+        assert_lod_close(got.L[:, close], ref.L[:, close], rtol=1e-6, atol=1e-9, what="LOD (own h2 each side, |dh2| <= 1e-8)")
     pinned = O.bulkscan_null(Y, G, K, Covar=Cov, h2_override=got.h2_null_list, **kw)
     assert_lod_close(got.L, pinned.L, what="LOD (oracle at the GPU h2)")
 
@@ -185,14 +193,15 @@ def test_bulkscan_alt_grid_matches_oracle(blmm, ncov):
     Y, G, K, Cov = make_data(p=200, m=33, seed=61 + ncov, ncov=ncov)
     grid = [i / 10.0 for i in range(10)]
     got = blmm.bulkscan_alt_grid(Y, G, K, grid, Cov)
-    ref = O.bulkscan_alt_grid(Y, G, K, grid, Covar=Cov)
+    ref, tab = O.bulkscan_alt_grid(Y, G, K, grid, Covar=Cov, return_tables=True)
     assert_lod_close(got.L, ref.L, atol=1e-9)
-    # ties between grid points are decided at rounding level: allow them where the two log-likelihoods coincide
-    diff = got.h2_panel != ref.h2_panel
-    assert diff.mean() <= 1e-3
+    # the arg-max grid value: equal, or a tie in the oracle's own logL1 table (strict `<` decides those at rounding level)
+    nt = assert_h2_panel_ties_only(got.h2_panel, ref.h2_panel, tab, grid)
+    assert nt <= 1e-3 * ref.h2_panel.size
     qk = blmm.bulkscan_alt_grid(Y, G, K, grid, Cov, compat_counter_quirk=True)
     rq = O.bulkscan_alt_grid(Y, G, K, grid, Covar=Cov, compat_counter_quirk=True)
-    assert (qk.h2_panel != rq.h2_panel).mean() <= 1e-3
+    nq = assert_h2_panel_ties_only(qk.h2_panel, rq.h2_panel, tab, grid, quirk=True)
+    assert nq <= 1e-3 * rq.h2_panel.size
     assert_lod_close(qk.L, rq.L, atol=1e-9)
 
 
@@ -415,7 +424,8 @@ def test_golden_fixture(blmm):
     assert_lod_close(gr.L, z["grid_L"])
     al = blmm.bulkscan_alt_grid(Y, G, K, grid)
     assert_lod_close(al.L, z["alt_L"], atol=1e-9)
-    assert (al.h2_panel != z["alt_h2"]).mean() <= 1e-3
+    _, tab = O.bulkscan_alt_grid(Y, G, K, grid, return_tables=True)
+    assert assert_h2_panel_ties_only(al.h2_panel, z["alt_h2"], tab, grid) <= 1e-3 * al.h2_panel.size
 
 
 @pytest.mark.parametrize("n", [130, 333])
@@ -717,16 +727,23 @@ def test_dev_entry_point_is_ordered_on_torchs_default_stream():
 
 
 def test_concurrent_contexts_with_grid_barrier_kernels(blmm):
-    """Three contexts on ONE device each run the tridiagonalisation (90 workgroups that meet at a grid barrier) and the
-    multi-workgroup weight basis at n = 900: 270 workgroups do not fit 256 CUs at once, so without the per-device ordering of
-    such kernels (grid_kernel_begin / _end) they could starve each other into their spin limits."""
-    Y, G, K, _ = make_data(n=900, p=70, m=33, seed=4242, bxd=False)
+    """Four contexts on ONE device, driven from four host threads, each run the tridiagonalisation (100 workgroups that meet
+    at a grid barrier) and the multi-workgroup weight basis at n = 1000: 400 workgroups do not fit 256 CUs at once, so without
+    the per-device ordering of such kernels they starve each other into their spin limits (the call then fails with
+    BLMM_ERR_HIP and a NaN matrix).  The ordering is one step -- wait for the previous such kernel, launch, record -- under a
+    per-device mutex (GridKernelGuard): with the wait and the record as two separately locked calls (round 2) two threads
+    could both pass the wait before either had recorded."""
+    Y, G, K, _ = make_data(n=1000, p=70, m=44, seed=4242, bxd=False)
     one = blmm.bulkscan(Y, G, K, method="null-exact")
-    mc = blmm.MultiContext([0, 0, 0])
-    for _ in range(3):
-        got = blmm.bulkscan_multi(mc, Y, G, K, method="null-exact", gather="host_shards")
-        assert np.array_equal(got["L"], one["L"]) and np.array_equal(got["h2_null_list"], one["h2_null_list"])
-    mc.close()
+    assert np.isfinite(one["L"]).all()
+    for devs in ([0, 0, 0, 0], [0, 0, 0]):
+        mc = blmm.MultiContext(devs)
+        for _ in range(4):
+            got = blmm.bulkscan_multi(mc, Y, G, K, method="null-exact", gather="host_shards")
+            assert np.array_equal(got["L"], one["L"]) and np.array_equal(got["h2_null_list"], one["h2_null_list"])
+        got = blmm.bulkscan_multi(mc, Y, G, K, method="null-exact", gather="none")      # the device-resident path reports through
+        assert np.array_equal(got["L"], one["L"])                                       # blmm_synchronize: no status, no silent NaN
+        mc.close()
 
 
 def test_from_files_to_lod(blmm, gpu_ctx, tmp_path):
@@ -901,9 +918,9 @@ def test_many_covariates_every_method(blmm, ncov):
     assert np.array_equal(gg.h2_null_list, gr.h2_null_list)
     assert_lod_close(gg.L, gr.L)
     ag = blmm.bulkscan_alt_grid(Y[:, :11], G, K, grid, Cov)
-    ar = O.bulkscan_alt_grid(Y[:, :11], G, K, grid, Covar=Cov)
+    ar, atab = O.bulkscan_alt_grid(Y[:, :11], G, K, grid, Covar=Cov, return_tables=True)
     assert_lod_close(ag.L, ar.L, atol=1e-9)
-    assert (ag.h2_panel != ar.h2_panel).mean() <= 1e-3
+    assert assert_h2_panel_ties_only(ag.h2_panel, ar.h2_panel, atab, grid) <= 1e-3 * ar.h2_panel.size
     # scan: null, alt and the permutation test
     y = Y[:, 0]
     s0 = blmm.scan(y, G, K, Cov)
@@ -956,3 +973,80 @@ def test_dc_parallel_deflation_equals_the_serial_scan(blmm, n, monkeypatch):
         Y0s, _, lams = blmm.transform_rotation(np.eye(n), np.ones((n, 2)), K)
         assert np.array_equal(lam, lams), name
         assert np.array_equal(Y0, Y0s), name
+
+
+# ---- conditioning guard of the null-exact scan (kernels_dyn.hip) ---------------------------------------------------------
+def _fuzz_case(n, p, m, ncov, case, seed0):
+    """The data of one case of tools/fuzz_parity.py (K from the markers)."""
+    Y, G, K, Cov = make_data(n=n, p=p, m=m, seed=1000 + case + 7919 * seed0, ncov=ncov, bxd=False)
+    const = np.ptp(G, axis=0) == 0
+    if const.any():
+        G = G.copy(); G[:, const] = np.random.default_rng(case).random((n, int(const.sum())))
+    return Y, G, K, Cov
+
+
+def _null_exact_with_status(blmm, Y, G, K, Cov, **kw):
+    return blmm.api._bulkscan_call(blmm._lib.BLMM_NULL_EXACT, Y, G, K, Cov, None, True, kw.get("weights"), 1.0, 0.0,
+                                   kw.get("reml", False), kw.get("optim_interval", 1), "eigen", 0, None, return_status=True)
+
+
+def test_illconditioned_weighted_covariates_at_the_h2_one_boundary(blmm):
+    """Case 237 of seed 201 of tools/fuzz_parity.py (round 2: LOD 2.8e-6 off, the only miss in 3,200 cases): n = 13, 8 null
+    covariates, three traits whose h2 estimate sits at the h2 -> 1 boundary -- weights 2e-9 .. 1, the weighted covariates
+    have condition 2e4.  The Cholesky form of the projection carries cond^2 eps; the reference's `resid` is a Householder QR
+    (src/wls.jl:221-241, cond eps).  The conditioning guard must put those traits on its list and the re-scan must meet the
+    standard 1e-6."""
+    Y, G, K, Cov = _fuzz_case(13, 63, 15, 7, 237, 201)
+    L, h2, st = _null_exact_with_status(blmm, Y, G, K, Cov)
+    edge = h2 > 1.0 - 1e-6
+    assert edge.any() and st.n_h2_boundary >= edge.sum()
+    assert st.n_illcond_rescan >= edge.sum()
+    pin = O.bulkscan_null(Y, G, K, Covar=Cov, h2_override=h2)
+    assert_lod_close(L, pin.L)
+    ref = O.bulkscan_null(Y, G, K, Covar=Cov)
+    assert np.abs(h2 - ref.h2_null_list).max() <= 1e-6
+
+
+@pytest.mark.parametrize("ncov,n", [(1, 79), (2, 79), (7, 79), (3, 200), (5, 300)])
+def test_qr_grade_rescan_equals_oracle_when_every_trait_is_flagged(blmm, ncov, n, monkeypatch):
+    """BLMM_ILLCOND_RHO=2 puts EVERY trait on the guard's list (the pivot shares are <= 1): the orthogonalised re-scan kernel
+    (k_scan_qr) is then compared with the oracle as a whole, for the low-rank path (c = 2, 3), the full-rank path (c = 8, 6)
+    and beyond the LDS Jacobi (n = 200, 300)."""
+    Y, G, K, Cov = make_data(n=n, p=333, m=70, seed=9100 + ncov, ncov=ncov, bxd=(n == 79))
+    monkeypatch.setenv("BLMM_ILLCOND_RHO", "2")
+    L, h2, st = _null_exact_with_status(blmm, Y, G, K, Cov)
+    assert st.n_illcond_rescan == Y.shape[1]
+    pin = O.bulkscan_null(Y, G, K, Covar=Cov, h2_override=h2)
+    assert_lod_close(L, pin.L)
+    monkeypatch.setenv("BLMM_ILLCOND_RHO", "0")        # guard off: the Cholesky form alone (well conditioned here)
+    L0, h20, st0 = _null_exact_with_status(blmm, Y, G, K, Cov)
+    assert st0.n_illcond_rescan == 0 and np.array_equal(h2, h20)
+    assert_lod_close(L0, pin.L)
+    monkeypatch.delenv("BLMM_ILLCOND_RHO")
+    y = Y[:, 0]
+    monkeypatch.setenv("BLMM_ILLCOND_RHO", "2")
+    s = blmm.scan(y, G, K, Cov)                        # scan(): the trait's own LOD vector takes the guard too
+    r = O.bulkscan_null(Y[:, :1], G, K, Covar=Cov, h2_override=[s["h2_null"]])
+    assert_lod_close(s["lod"], r.L[:, 0])
+
+
+def test_h2_boundary_counter_and_profile_audit(blmm):
+    """blmm_status.n_h2_boundary counts the estimates on a boundary of [0, 1]; BLMM_FLAG_H2_AUDIT evaluates every trait's
+    profile on the 16-point grid and counts those with two or more local maxima -- the traits on which a local optimiser
+    (src/gridbrent.jl:9-24) may legitimately end in either maximum (2 of 35,554 at BXD size)."""
+    Y, G, K, _ = make_data(p=64, m=2048, seed=20241)
+    L, h2, st = _null_exact_with_status(blmm, Y, G, K, None)
+    assert st.n_h2_boundary == int(((h2 <= 1e-6) | (h2 >= 1 - 1e-6)).sum()) and st.n_h2_boundary > 0
+    assert st.n_h2_multimodal == -1                     # not requested
+    La, h2a, sta = blmm.api._bulkscan_call(blmm._lib.BLMM_NULL_EXACT, Y, G, K, None, None, True, None, 1.0, 0.0, False, 1, "eigen",
+                                           blmm._lib.BLMM_FLAG_H2_AUDIT, None, return_status=True)
+    assert np.array_equal(La, L) and np.array_equal(h2a, h2)
+    Y0, X0, lam = O.transform_rotation(Y, G, K)
+    grid = np.arange(16) / 16.0
+    Ell = np.vstack([O.wls_multivar(Y0, X0[:, :1], O.makeweights(h, lam), [1.0, 0.0]).Ell for h in grid])
+    slack = 1e-9 * np.abs(Ell)
+    up = np.vstack([np.ones((1, Ell.shape[1]), bool), Ell[1:] > Ell[:-1] + slack[1:]])
+    dn = np.vstack([Ell[:-1] > Ell[1:] + slack[:-1], np.ones((1, Ell.shape[1]), bool)])
+    multi = ((up & dn).sum(axis=0) >= 2)
+    # near-ties against the slack may fall on either side: the device evaluates Ell with its own rounding
+    assert abs(sta.n_h2_multimodal - int(multi.sum())) <= 2, (sta.n_h2_multimodal, int(multi.sum()))
