@@ -392,8 +392,9 @@ ScanArgs scan_args(blmm_ctx* ctx, const Pipe& P, const double* panels, int64_t l
   ScanArgs a;
   a.Xt = P.Xt; a.ldx = P.ldx; a.P = panels; a.ldp = ldp; a.pstride = (int64_t)P.npad * ldp;
   a.ks = P.npad / 4; a.n = P.n; a.p = P.p; a.m = m; a.L = L; a.ldL = ldL;
-  a.isx = nullptr; a.ld_isx = 0; a.bin = nullptr; a.stat = P.stat; a.logtab = ptr<double>(ctx->logtab);
+  a.isx = nullptr; a.ld_isx = 0; a.bin = nullptr; a.stat = P.stat; a.logtab = ptr<double>(ctx->logtab); a.lodtab = ptr<double>(ctx->lodtab);
   a.c = P.c;
+  lod_poly5_host(-0.5 * (double)P.n, a.lodc);
   return a;
 }
 
@@ -654,7 +655,9 @@ int blmm_create(int device_id, void* hip_stream, blmm_ctx** out) {
     ctx->hflag = reinterpret_cast<volatile int64_t*>(hp);
   }
   if (ensure(ctx, ctx->logtab, sizeof(blmm_log_table_host)) != BLMM_OK ||
-      hipMemcpy(ctx->logtab.p, blmm_log_table_host, sizeof(blmm_log_table_host), hipMemcpyHostToDevice) != hipSuccess) {
+      hipMemcpy(ctx->logtab.p, blmm_log_table_host, sizeof(blmm_log_table_host), hipMemcpyHostToDevice) != hipSuccess ||
+      ensure(ctx, ctx->lodtab, sizeof(blmm_lod_table_host)) != BLMM_OK ||
+      hipMemcpy(ctx->lodtab.p, blmm_lod_table_host, sizeof(blmm_lod_table_host), hipMemcpyHostToDevice) != hipSuccess) {
     blmm_destroy(ctx);
     return BLMM_ERR_HIP;
   }
@@ -670,7 +673,7 @@ void blmm_destroy(blmm_ctx* ctx) {
                     &ctx->iyy, &ctx->h2, &ctx->h2idx, &ctx->sig2, &ctx->ell, &ctx->isx, &ctx->stat, &ctx->gridd, &ctx->misc,
                     &ctx->EllTab, &ctx->inY, &ctx->inG, &ctx->inK, &ctx->inCov, &ctx->inW, &ctx->outL, &ctx->outH2,
                     &ctx->tmpA, &ctx->tmpB, &ctx->tmpC, &ctx->perm, &ctx->r0, &ctx->altbuf, &ctx->logtab, &ctx->lraw,
-                    &ctx->wbQ, &ctx->wbW, &ctx->wbRk, &ctx->lrT, &ctx->lrC, &ctx->lrL, &ctx->lrFlag, &ctx->lrPart, &ctx->lrPerm, &ctx->lrDen0, &ctx->eigW, &ctx->xf32, &ctx->pf32, &ctx->brSt, &ctx->brList, &ctx->illList, &ctx->qrSlab};
+                    &ctx->wbQ, &ctx->wbW, &ctx->wbRk, &ctx->lrT, &ctx->lrC, &ctx->lrL, &ctx->lrFlag, &ctx->lrPart, &ctx->lrPerm, &ctx->lrDen0, &ctx->eigW, &ctx->xf32, &ctx->pf32, &ctx->brSt, &ctx->brList, &ctx->illList, &ctx->qrSlab, &ctx->lodtab};
   for (DevBuf* b : bufs) if (b->p) hipFree(b->p);
   for (auto& s : ctx->evsets) for (auto& e : s.e) (void)hipEventDestroy(e);
   if (ctx->rb_handle && ctx->rb_destroy) ctx->rb_destroy(ctx->rb_handle);
@@ -952,6 +955,7 @@ int blmm_bulkscan_dev(blmm_ctx* ctx, const blmm_opts* opts, const double* dY, in
     AltArgs aa;
     aa.s = scan_args(ctx, P, ptr<double>(ctx->panels), ldp, dL_out, ldL, m);
     aa.s.isx = ptr<double>(ctx->isx); aa.s.ld_isx = P.ldx;
+    lod_poly5_host(-0.5 * (double)P.n * 2.302585092994046, aa.s.lodc);   // ln10 * LOD = -(n/2) ln(1 - r^2)
     aa.ngrid = (int)ngrid; aa.EllTab = ptr<double>(ctx->EllTab); aa.grid_dev = dgrid; aa.H2 = dh2_out; aa.ldH = p;
     aa.counter_quirk = (opts->compat_flags & BLMM_COMPAT_ALT_COUNTER) ? 1 : 0;
     if ((rc = launch_scan_alt(ctx, aa))) return rc;

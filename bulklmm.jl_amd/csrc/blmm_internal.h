@@ -45,7 +45,7 @@ struct blmm_ctx {
   std::string err;
   // grow-only workspace
   blmm::DevBuf Ks, V, lam, U, Zs, Z0, Rp, Yt, Xt, panels, iyy, h2, h2idx, sig2, ell, isx, stat, gridd, misc, EllTab,
-      inY, inG, inK, inCov, inW, outL, outH2, tmpA, tmpB, tmpC, perm, r0, altbuf, logtab, lraw, wbQ, wbW, wbRk, lrT, lrC, lrL, lrFlag, lrPart, lrPerm, lrDen0, eigW, xf32, pf32, brSt, brList, illList, qrSlab;
+      inY, inG, inK, inCov, inW, outL, outH2, tmpA, tmpB, tmpC, perm, r0, altbuf, logtab, lraw, wbQ, wbW, wbRk, lrT, lrC, lrL, lrFlag, lrPart, lrPerm, lrDen0, eigW, xf32, pf32, brSt, brList, illList, qrSlab, lodtab;
   // event sets: one per timed call since the last blmm_read_timings (grown on demand, reused afterwards)
   struct EvSet { hipEvent_t e[8]; int n; };
   std::vector<EvSet> evsets;
@@ -191,6 +191,10 @@ struct ScanArgs {
   const int* perm = nullptr; int64_t col0 = 0; const int64_t* count = nullptr;
   int c = 1;                               // null covariates (exact mode beyond CFAST: panels 2 + CFAST .. 1 + c are folded in chunks)
   const double* logtab;                    // device copy of log_table.h
+  const double* lodtab;                    // ... of its directly indexed LOD table (fastmath.h: fast_lod5)
+  double lodc[6];                          // {scale = -n/2, c1..c5}: the LOD polynomial of fast_lod5, computed on the host so that
+                                           // the kernels hold it in SGPRs (gfx950 has no scalar fp64 arithmetic: derived in the
+                                           // kernel the five coefficients cost 10 VGPRs in kernels at the register limit)
   int64_t* stat;
 };
 int launch_scan_exact(blmm_ctx* ctx, const ScanArgs& a, int c);
@@ -244,7 +248,8 @@ int launch_scan_table(blmm_ctx* ctx, const ScanArgs& a);
 // the shared-weights class of one panel region through the table kernel (isx = 1/sqrt(den0), one bin, stores through perm)
 int launch_scan_shared(blmm_ctx* ctx, const ScanArgs& a);
 struct AltArgs {
-  ScanArgs s; int ngrid; const double* EllTab; /* ngrid x m */ const double* grid_dev; double* H2; int64_t ldH; int counter_quirk;
+  ScanArgs s;            // s.lodc: scale = -(n/2) ln 10 here (the kernel folds ln10 * LOD + Ell)
+  int ngrid; const double* EllTab; /* ngrid x m */ const double* grid_dev; double* H2; int64_t ldH; int counter_quirk;
 };
 int launch_scan_alt(blmm_ctx* ctx, const AltArgs& a);
 

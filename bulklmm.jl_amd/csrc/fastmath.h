@@ -80,6 +80,89 @@ __device__ __forceinline__ double fast_lod(double x, const dpair* __restrict__ l
   return fma(r, p, fma((double)k, P.k2, e[1]));
 }
 
+// ---- LOD through the DIRECTLY indexed table (log_table.h: blmm_lod_table_host; tools/gen_log_table.py) ----------------
+// The argument of the LOD map is u = 1 - r^2 in (0, 1], almost always in [2^-4, 1] (u < 2^-4 is a LOD beyond ~1.2 n / 2): over
+// those four octaves the table is indexed by the high word of u alone -- no exponent extraction, no mantissa re-assembly, no
+// int -> double conversion, and |r| <= 2^-10 leaves a degree-5 polynomial: 6 fp64 and 4 integer instructions per output where
+// fast_lod has 11 + 7 (every fp64 VALU instruction of an epilogue is paid in matrix-pipe time, see the file header).
+// Relative error <= ~2e-16 on [2^-4, 1] including u -> 1 (the last entry has c = 1: r = u - 1 exactly); lod_fast_ok(u) tells
+// whether u is in the table's range, lod_slow() serves the rest (u < 2^-4, u <= 0, NaN) with the reference's own operations.
+struct LodPoly5 { double c1, c2, c3, c4, c5; };
+// host side: {scale, c1..c5} for ScanArgs::lodc
+inline void lod_poly5_host(double scale, double (&out)[6]) {
+  const double s = scale * BLMM_INV_LN10;
+  out[0] = scale; out[1] = s; out[2] = -s * 0.5; out[3] = s * (1.0 / 3.0); out[4] = -s * 0.25; out[5] = s * (1.0 / 5.0);
+}
+__device__ __forceinline__ LodPoly5 lod_poly5_of(const double (&c)[6]) { return LodPoly5{c[1], c[2], c[3], c[4], c[5]}; }
+__device__ __forceinline__ LodPoly5 make_lod_poly5(double scale) {
+  const double s = scale * BLMM_INV_LN10;
+  LodPoly5 p;
+  p.c1 = s; p.c2 = -s * 0.5; p.c3 = s * (1.0 / 3.0); p.c4 = -s * 0.25; p.c5 = s * (1.0 / 5.0);
+  return p;
+}
+// Staging of the table into LDS (NT threads per workgroup), split in two so that the loads can be issued at the top of a kernel
+// and their results written out only after other loads are in flight: lds[i] = {invc_i, scale * log10(c_i)}.
+template <int NT>
+struct LodStage { dpair v[(BLMM_LOD_TABLE_N + NT - 1) / NT]; };
+template <int NT>
+__device__ __forceinline__ void lod_stage_load(LodStage<NT>& st, const double* __restrict__ gtab) {
+  constexpr int PER = (BLMM_LOD_TABLE_N + NT - 1) / NT;
+  const dpair* g = reinterpret_cast<const dpair*>(gtab);
+#pragma unroll
+  for (int u = 0; u < PER; ++u) {
+    const int i = (int)threadIdx.x + NT * u;
+    st.v[u] = g[i < BLMM_LOD_TABLE_N ? i : BLMM_LOD_TABLE_N - 1];
+  }
+}
+template <int NT>
+__device__ __forceinline__ void lod_stage_store(const LodStage<NT>& st, dpair* lds, double scale) {
+  constexpr int PER = (BLMM_LOD_TABLE_N + NT - 1) / NT;
+#pragma unroll
+  for (int u = 0; u < PER; ++u) {
+    const int i = (int)threadIdx.x + NT * u;
+    if (i < BLMM_LOD_TABLE_N) lds[i] = (dpair){st.v[u][0], scale * st.v[u][1]};
+  }
+}
+__device__ __forceinline__ bool lod_fast_ok(double u) {
+  return (uint32_t)__double2hiint(u) - BLMM_LOD_HI0 <= 0x3ff00000u - BLMM_LOD_HI0;   // 2^-4 <= u <= 1 (false for NaN, u <= 0)
+}
+__device__ __forceinline__ double fast_lod5(double u, const dpair* __restrict__ lds, const LodPoly5& P) {
+  uint32_t off = (((uint32_t)__double2hiint(u) + (0x400u - BLMM_LOD_HI0)) >> 7) & 0xfff0u;   // 16 * ((hi - HI0 + 2^10) >> 11)
+  off = off < 16u * (BLMM_LOD_TABLE_N - 1) ? off : 16u * (BLMM_LOD_TABLE_N - 1);             // out-of-range u: any entry (lod_slow replaces the value)
+  const dpair e = *reinterpret_cast<const dpair*>(reinterpret_cast<const char*>(lds) + off);
+  const double r = fma(u, e[0], -1.0);
+  double p = P.c5;
+  p = fma(p, r, P.c4);
+  p = fma(p, r, P.c3);
+  p = fma(p, r, P.c2);
+  p = fma(p, r, P.c1);
+  return fma(r, p, e[1]);
+}
+// r2lod outside the table's range (src/bulkscan_helpers.jl:22-24: scale * log10(u)).  0 < u < 2^-4 is brought into the table by
+// an exact power of 16: scale log10(u) = fast_lod5(u 16^sh) - sh (4 scale log10 2), u 16^sh in [2^-4, 1) -- no libm call (its
+// log10 is ~200 instructions and ~40 registers at every call site of kernels that sit at the register limit).  u = 0 -> +Inf;
+// u < 0 (r^2 > 1: DomainError in Julia) or NaN -> NaN, counted in *nnan when `counted`.
+__device__ __forceinline__ double lod_out_of_range(double u, const dpair* __restrict__ lds, const LodPoly5& P, double scale,
+                                                   bool counted, int* nnan) {
+  if (u > 0.0) {
+    const int e = __builtin_amdgcn_frexp_exp(u);          // u = m 2^e, m in [0.5, 1); here e <= -4
+    const int sh = (-e) >> 2;                             // e + 4 sh in (-4, 0]
+    const double us = __builtin_amdgcn_ldexp(u, 4 * sh);   // exact, subnormal u included
+    return fma(-(double)sh, scale * (4.0 * BLMM_LOG10_2), fast_lod5(us, lds, P));
+  }
+  if (u == 0.0) return INFINITY;
+  *nnan += counted ? 1 : 0;
+  return NAN;
+}
+
+// 1/x to ~20 ulp (2.2e-15 relative, tools/mb4_rcp.hip): v_rcp_f64 seed (4.6e-8) + ONE Newton step.  Used where the quotient
+// feeds 1 - r^2 of a LOD: its error there is far below the rounding of the subtraction.
+__device__ __forceinline__ double fast_rcp1(double x) {
+  const double y = __builtin_amdgcn_rcp(x);
+  const double e = fma(-x, y, 1.0);
+  return fma(y, e, y);
+}
+
 // 1/x to ~1 ulp: v_rcp_f64 seed + two Newton steps (x finite, non-zero, normal)
 __device__ __forceinline__ double fast_rcp(double x) {
   double y = __builtin_amdgcn_rcp(x);

@@ -16,7 +16,7 @@
 // Operand layout (both row-major "k-major", produced by k_rotate / k_panels):
 //   Xt[k][i]  markers,  ld = ldx (padded to the tile);     P[q][k][j]  A-side panels, ld = ldp.
 // MFMA roles: A (16 rows) = traits, B (16 cols) = markers, so that D's 16 lanes of a register hold 16
-// marker slots of ONE trait column of L.  Marker <-> (block nb, col c) is permuted to ibase + NB*c + nb and
+// marker slots of ONE trait column of L.  Marker <-> (block nb, col c) is permuted to i0 + NB*c + nb (mslot below) and
 // trait <-> (block mb, row r) to tbase + MB*r + mb, so every lane owns NB consecutive markers (vector
 // loads of Xt, 32-byte stores of L; 16 lanes = 512 contiguous bytes of one L column) and MB consecutive
 // traits (vector loads of the panels).
@@ -85,6 +85,41 @@ __device__ __forceinline__ void bufload(double (&dst)[N], __amdgpu_buffer_rsrc_t
 // 8-byte-aligned 16-byte vector (columns of L start at arbitrary multiples of 8 bytes: ld = p is odd for BXD)
 typedef double d2u __attribute__((ext_vector_type(2), aligned(8)));
 
+// ---- marker slots of a lane ----------------------------------------------------------------------------------------------
+// A wave's 16 NB markers; MFMA block nb, column c (= lane & 15): column c owns the NB CONSECUTIVE markers i0 + NB c + nb (32
+// contiguous bytes of Xt and of an L column for NB = 4, in two 16-byte instructions).  Measured and not adopted (round 3): the
+// split map i0 + 32 (nb >> 1) + 2 c + (nb & 1), with which one 16-byte access per lane covers 256 contiguous bytes per 16 lanes
+// (every 128-byte line written whole by ONE store instruction): null-exact scan 1.28-1.29 ms against 1.22-1.26, null-grid 0.93
+// against 0.91-0.92 -- a lane's two accesses to the same 64-byte sector are worth more than dense quarter-waves.
+template <int NB>
+__device__ __forceinline__ int mslot(int c, int nb) { return NB * c + nb; }
+template <int NB>
+__device__ __forceinline__ uint32_t mvoff(int c) { return (uint32_t)(NB * c * 8); }   // byte offset of the lane's first slot
+template <int NB>
+__device__ __forceinline__ void bufload_m(double (&dst)[NB], __amdgpu_buffer_rsrc_t srd, uint32_t voff) { bufload<NB>(dst, srd, voff); }
+// per-marker values (marker norms): p points at the wave's first marker
+template <int NB>
+__device__ __forceinline__ void loadv_m(double (&dst)[NB], const double* __restrict__ p, int c) { loadv<NB>(dst, p + NB * c); }
+// a lane's NB results of one trait column: col points at L[i0, trait], i0 the wave's first marker, `valid` = p - i0 markers exist
+template <int NB>
+__device__ __forceinline__ void store_m(double* __restrict__ col, int c, const double (&out)[NB], int64_t valid) {
+  double* dst = col + NB * c;
+  if (NB * c + NB <= valid) {
+    if constexpr (NB == 4) {
+      __builtin_nontemporal_store((d2u){out[0], out[1]}, reinterpret_cast<d2u*>(dst));
+      __builtin_nontemporal_store((d2u){out[2], out[3]}, reinterpret_cast<d2u*>(dst + 2));
+    } else if constexpr (NB == 2) {
+      __builtin_nontemporal_store((d2u){out[0], out[1]}, reinterpret_cast<d2u*>(dst));
+    } else {
+      __builtin_nontemporal_store(out[0], dst);
+    }
+  } else {
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb)
+      if (NB * c + nb < valid) dst[nb] = out[nb];
+  }
+}
+
 __device__ __forceinline__ int64_t xcd_swizzle(int64_t bid, int64_t nwg) {
   // Workgroups are dealt round-robin over the 8 XCDs (bid % 8).  Give each XCD a contiguous range of tiles
   // so the A-side panels of a trait tile stay in ONE XCD's L2 (speed only; any placement is correct).
@@ -105,6 +140,17 @@ __device__ __forceinline__ void tile_of(int64_t id, int64_t ntile_t, int ntile_i
   tile_t = t_first + (rem - (int64_t)tile_i * gt);
 }
 
+// the same walk in 32-bit arithmetic (launchers bound the workgroup count by 2^31): a 64-bit division is ~100 scalar
+// instructions, and the walk has two of them at the head of every workgroup
+__device__ __forceinline__ void tile_of32(uint32_t id, uint32_t ntile_t, uint32_t ntile_i, uint32_t& tile_t, uint32_t& tile_i) {
+  const uint32_t per_group = (uint32_t)GT * ntile_i;
+  const uint32_t g = id / per_group, rem = id - g * per_group;
+  const uint32_t t_first = g * GT;
+  const uint32_t gt = (ntile_t - t_first < (uint32_t)GT) ? (ntile_t - t_first) : (uint32_t)GT;  // last group may be short
+  tile_i = rem / gt;
+  tile_t = t_first + (rem - tile_i * gt);
+}
+
 // PERM (table mode only): the trait tiles are the first ceil(*a.count / tile) tiles of the panel region starting at column
 // a.col0, a panel column's trait is a.perm[column] (-1: padding) -- the shared-weights class of the low-rank form, which is
 // exactly a one-bin table scan (102 VGPRs, 4 waves per SIMD, where k_scan_lr holds 2).  Every XCD takes an eighth of the items.
@@ -114,46 +160,64 @@ __device__ __forceinline__ void tile_of(int64_t id, int64_t ntile_t, int ntile_i
 template <int NX, int MB, int NB, bool TABLE, int W2, bool PERM = false, bool MORE = false>
 __global__ void __launch_bounds__(64 * W2 * W2, 2) k_scan(ScanArgs a, int ntile_i, int64_t nwg) {
   constexpr int NP = 1 + NX;  // A-side panels consumed
+  constexpr int NT = 64 * W2 * W2;
   static_assert(!PERM || (TABLE && NX == 0), "permuted columns: table mode");
   static_assert(!MORE || (!TABLE && NX == 1 + CFAST), "covariate chunks: exact mode with all CFAST in-loop panels");
-  __shared__ dpair s_log[BLMM_LOG_TABLE_N];
+  __shared__ dpair s_lod[BLMM_LOD_TABLE_N];
   __shared__ int s_perm[PERM ? 16 * W2 * MB : 1];
-  stage_lod_table(s_log, a.logtab, -0.5 * (double)a.n);  // read after the K loop; the barrier sits right before the epilogue
+  // the LOD table (read after the K loop; the barrier sits right before the epilogue): its loads go out first and are written
+  // to LDS once the tile arithmetic is done and the first fragment loads are in flight -- one exposed round trip per workgroup
+  // instead of two or three.  (64-thread workgroups, an A/B variant, would need 33 entries per thread: plain copy loop.)
+  LodStage<NT> lst;
+  if constexpr (NT >= 256) lod_stage_load<NT>(lst, a.lodtab);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  int64_t tile_t; int tile_i;
+  uint32_t tile_t, tile_i;                  // 32-bit tile arithmetic: the launchers bound nwg by 2^31
+  int perm_st = -1;
   if constexpr (PERM) {
     constexpr int TW = 16 * W2 * MB;
-    const int64_t q = nwg >> 3;
-    if ((int64_t)blockIdx.x >= (q << 3)) return;                 // workgroup-uniform; before any barrier
-    const int64_t x = blockIdx.x & 7, local = blockIdx.x >> 3;
-    const int64_t ns = (*a.count + TW - 1) / TW, NS = ns * ntile_i;
-    const int64_t sS = (x * NS) >> 3, cS = (((x + 1) * NS) >> 3) - sS;
+    const uint32_t q = (uint32_t)(nwg >> 3);
+    if (blockIdx.x >= (q << 3)) return;                          // workgroup-uniform; before any barrier
+    const uint32_t x = blockIdx.x & 7, local = blockIdx.x >> 3;
+    const uint32_t ns = ((uint32_t)*a.count + TW - 1) / TW;
+    const uint64_t NS = (uint64_t)ns * (uint32_t)ntile_i;
+    const uint32_t sS = (uint32_t)((x * NS) >> 3), cS = (uint32_t)(((x + 1) * NS) >> 3) - sS;
     if (local >= cS) return;
-    tile_of(sS + local, ns, ntile_i, tile_t, tile_i);
-    tile_t += a.col0 / TW;
-    if (threadIdx.x < TW) s_perm[threadIdx.x] = a.perm[tile_t * TW + threadIdx.x];
+    tile_of32(sS + local, ns, (uint32_t)ntile_i, tile_t, tile_i);
+    tile_t += (uint32_t)(a.col0 / TW);
+    if (threadIdx.x < TW) perm_st = a.perm[(int64_t)tile_t * TW + threadIdx.x];
   } else {
-    const int64_t bid = xcd_swizzle(blockIdx.x, nwg);
-    tile_of(bid, nwg / ntile_i, ntile_i, tile_t, tile_i);
+    const uint32_t bid = (uint32_t)xcd_swizzle(blockIdx.x, nwg);
+    tile_of32(bid, (uint32_t)nwg / (uint32_t)ntile_i, (uint32_t)ntile_i, tile_t, tile_i);
   }
   const int wt = (W2 == 2) ? (wave >> 1) : 0, wi = (W2 == 2) ? (wave & 1) : 0;
-  const int64_t t0 = tile_t * (16 * W2 * MB) + wt * (16 * MB);
+  const int64_t t0 = (int64_t)tile_t * (16 * W2 * MB) + wt * (16 * MB);
   const int64_t i0 = (int64_t)tile_i * (16 * W2 * NB) + wi * (16 * NB);
   const int r = lane & 15, kk = lane >> 4;
 
   d4 acc[NP][MB][NB];
+  auto stage_and_zero = [&]() {
+    if constexpr (NT >= 256) {
+      lod_stage_store<NT>(lst, s_lod, a.lodc[0]);
+    } else {
+      for (int i = threadIdx.x; i < BLMM_LOD_TABLE_N; i += NT)
+        s_lod[i] = (dpair){a.lodtab[2 * i], a.lodc[0] * a.lodtab[2 * i + 1]};
+    }
+    if constexpr (PERM) {
+      if (threadIdx.x < 16 * W2 * MB) s_perm[threadIdx.x] = perm_st;
+    }
 #pragma unroll
-  for (int q = 0; q < NP; ++q)
+    for (int q = 0; q < NP; ++q)
 #pragma unroll
-    for (int mb = 0; mb < MB; ++mb)
+      for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
-      for (int nb = 0; nb < NB; ++nb) acc[q][mb][nb] = (d4){0, 0, 0, 0};
+        for (int nb = 0; nb < NB; ++nb) acc[q][mb][nb] = (d4){0, 0, 0, 0};
+  };
 
   // uniform tile bases (blockIdx-derived) for the descriptors; per-lane byte offsets (wave, lane) in voffset
-  const double* PA = a.P + tile_t * (16 * W2 * MB);
+  const double* PA = a.P + (int64_t)tile_t * (16 * W2 * MB);
   const double* PB = a.Xt + (int64_t)tile_i * (16 * W2 * NB);
   const uint32_t voffA = (uint32_t)(((int64_t)kk * a.ldp + wt * (16 * MB) + MB * r) * 8);
-  const uint32_t voffB = (uint32_t)(((int64_t)kk * a.ldx + wi * (16 * NB) + NB * r) * 8);
+  const uint32_t voffB = (uint32_t)(((int64_t)kk * a.ldx + wi * (16 * NB)) * 8) + mvoff<NB>(r);
   const int64_t sa = 4 * a.ldp, sb = 4 * a.ldx;
 
   // K loop, two fragment sets: the loads of step ks+1 are issued before the MFMAs of step ks and are only waited
@@ -161,7 +225,7 @@ __global__ void __launch_bounds__(64 * W2 * W2, 2) k_scan(ScanArgs a, int ntile_
   auto load_set = [&](double (&A)[NP][MB], double (&B)[NB], int step) {
 #pragma unroll
     for (int q = 0; q < NP; ++q) bufload<MB>(A[q], make_srd(PA + q * a.pstride + step * sa), voffA);
-    bufload<NB>(B, make_srd(PB + step * sb), voffB);
+    bufload_m<NB>(B, make_srd(PB + step * sb), voffB);
   };
   auto mfma_set = [&](const double (&A)[NP][MB], const double (&B)[NB]) {
     double b2[NB];
@@ -183,11 +247,12 @@ __global__ void __launch_bounds__(64 * W2 * W2, 2) k_scan(ScanArgs a, int ntile_
       }
   };
   if constexpr (MORE) {
+    stage_and_zero();
     for (int q0 = CFAST; q0 < a.c; q0 += CFAST) {
       const int nq = (a.c - q0 < CFAST) ? a.c - q0 : CFAST;     // wave-uniform
       for (int step = 0; step < a.ks; ++step) {
         double A[CFAST][MB], B[NB];
-        bufload<NB>(B, make_srd(PB + step * sb), voffB);
+        bufload_m<NB>(B, make_srd(PB + step * sb), voffB);
 #pragma unroll
         for (int q = 0; q < CFAST; ++q)
           if (q < nq) bufload<MB>(A[q], make_srd(PA + (2 + q0 + q) * a.pstride + step * sa), voffA);
@@ -216,6 +281,11 @@ __global__ void __launch_bounds__(64 * W2 * W2, 2) k_scan(ScanArgs a, int ntile_
   }
   double a0[NP][MB], b0[NB], a1[NP][MB], b1[NB];
   load_set(a0, b0, 0);
+  if constexpr (!MORE) {
+    __builtin_amdgcn_sched_barrier(0);
+    stage_and_zero();       // under the first fragments' round trip
+    __builtin_amdgcn_sched_barrier(0);
+  }
   int ks = 0;
   for (; ks + 2 <= a.ks; ks += 2) {
     load_set(a1, b1, ks + 1);
@@ -231,8 +301,8 @@ __global__ void __launch_bounds__(64 * W2 * W2, 2) k_scan(ScanArgs a, int ntile_
 
   // ---- epilogue: projection, normalisation, r -> LOD, 32-byte stores ---------------------------------
   __syncthreads();
-  const LodPoly lp = make_lod_poly(-0.5 * (double)a.n);
-  const int64_t ibase = i0 + NB * r;
+  const double scale = a.lodc[0];
+  const LodPoly5 lp = lod_poly5_of(a.lodc);
   int nnan = 0;
 #pragma unroll
   for (int mb = 0; mb < MB; ++mb)
@@ -249,9 +319,11 @@ __global__ void __launch_bounds__(64 * W2 * W2, 2) k_scan(ScanArgs a, int ntile_
       double sc[NB];
       if constexpr (TABLE) {
         const int64_t b = a.bin ? (int64_t)a.bin[trait] : 0;
-        loadv<NB>(sc, a.isx + b * a.ld_isx + ibase);
+        loadv_m<NB>(sc, a.isx + b * a.ld_isx + i0, r);
       }
-      double out[NB];
+      // the NB outputs of a row are independent chains; u outside the LOD table's range (LOD beyond ~1.2 n / 2, r^2 >= 1 --
+      // +Inf / DomainError in Julia, NaN here --, NaN) is rare and handled per ROW behind one branch
+      double uv[NB], out[NB];
 #pragma unroll
       for (int nb = 0; nb < NB; ++nb) {
         const double num = acc[0][mb][nb][reg];
@@ -263,32 +335,19 @@ __global__ void __launch_bounds__(64 * W2 * W2, 2) k_scan(ScanArgs a, int ntile_
           double xx = acc[1][mb][nb][reg];
 #pragma unroll
           for (int q = 2; q < NP; ++q) xx = fma(-acc[q][mb][nb][reg], acc[q][mb][nb][reg], xx);
-          r2 = (num * num) * fast_rcp(xx);
+          r2 = (num * num) * fast_rcp1(xx);
         }
-        // r2lod (src/bulkscan_helpers.jl:22-24): -(n/2) * log10(1.0 - r^2), same operation order
-        const double u = 1.0 - r2;
-        double lod = fast_lod(u, s_log, lp);
-        if (__builtin_expect(!(u > 0.0), 0)) {  // r^2 = 1 -> +Inf; r^2 > 1 -> DomainError in Julia, NaN here
-          lod = (u == 0.0) ? INFINITY : NAN;
-          nnan += (u != 0.0) && (ibase + nb < a.p);
-        }
-        out[nb] = lod;
+        uv[nb] = 1.0 - r2;   // r2lod (src/bulkscan_helpers.jl:22-24): -(n/2) * log10(1.0 - r^2), same operation order
       }
-      double* dst = a.L + trait * a.ldL + ibase;
-      if (ibase + NB <= a.p) {
-        if constexpr (NB == 4) {
-          __builtin_nontemporal_store((d2u){out[0], out[1]}, reinterpret_cast<d2u*>(dst));
-          __builtin_nontemporal_store((d2u){out[2], out[3]}, reinterpret_cast<d2u*>(dst + 2));
-        } else if constexpr (NB == 2) {
-          __builtin_nontemporal_store((d2u){out[0], out[1]}, reinterpret_cast<d2u*>(dst));
-        } else {
-          __builtin_nontemporal_store(out[0], dst);
-        }
-      } else {
+      bool ok = true;
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) { out[nb] = fast_lod5(uv[nb], s_lod, lp); ok = ok && lod_fast_ok(uv[nb]); }
+      if (__builtin_expect(!ok, 0)) {
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb)
-          if (ibase + nb < a.p) dst[nb] = out[nb];
+          if (!lod_fast_ok(uv[nb])) out[nb] = lod_out_of_range(uv[nb], s_lod, lp, scale, i0 + mslot<NB>(r, nb) < a.p, &nnan);
       }
+      store_m<NB>(a.L + trait * a.ldL + i0, r, out, a.p - i0);
     }
   if (nnan) atomicAdd((unsigned long long*)&a.stat[ST_NAN_LOD], (unsigned long long)nnan);
 }
@@ -334,82 +393,105 @@ int launch_scan_exact(blmm_ctx* ctx, const ScanArgs& a, int c) {
 #ifdef LR_DIAG
 __device__ unsigned long long g_lr_diag[24];   // per class {sum of workgroup cycles, count}; per XCD last end tick
 #endif
+#ifdef LR_PHASE
+// per class (0: shared-weights tiles, 1: rank-R tiles) sums over the waves of {K loops, barrier wait, epilogue} cycles and the count
+__device__ unsigned long long g_lr_phase[8];
+#endif
 template <int C, int MB, int NB>
 __global__ void __launch_bounds__(256, 2) k_scan_lr(LrArgs la, int ntile_i, int64_t nwg) {
   const ScanArgs& a = la.s;
 #ifdef LR_DIAG
   const unsigned long long diag_t0 = __builtin_amdgcn_s_memtime();
 #endif
+#ifdef LR_PHASE
+  const unsigned long long ph_t0 = __builtin_amdgcn_s_memtime();
+#endif
   constexpr int NACC = 2 + C;
   constexpr int NL = C * (C + 1) / 2;
-  __shared__ dpair s_log[BLMM_LOG_TABLE_N];
-  __shared__ double s_li[NL][32 * MB];      // packed L_j^-1 of the tile's traits (read in the epilogue)
-  __shared__ int s_perm[32 * MB];           // their trait numbers (-1: padding column)
-  stage_lod_table(s_log, a.logtab, -0.5 * (double)a.n);
+  constexpr int TW = 32 * MB;
+  __shared__ dpair s_lod[BLMM_LOD_TABLE_N];
+  __shared__ double s_li[NL][TW];           // packed L_j^-1 of the tile's traits (read in the epilogue)
+  __shared__ int s_perm[TW];                // their trait numbers (-1: padding column)
+  // The LOD table's loads go out first: nothing below depends on them until the LDS stores in front of the K loops, so their
+  // round trip runs under the tile arithmetic and the first fragment loads (round 2 staged the table, then L^-1 / perm, then
+  // fetched the first fragments: three exposed round trips at the head of every workgroup).
+  LodStage<256> lst;
+  lod_stage_load<256>(lst, a.lodtab);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   // Trait tiles in use: ns at the front (the shared-weights class, 5/8 of the matrix work of a tile of the other class) and
   // nf from tile `fo` on.  Workgroups reach the CUs of an XCD in strict round-robin order (measured: a mix of the two
   // classes inside one dispatch round runs at the pace of the slower class, whatever the share of the faster one), so
   // each XCD (blockIdx % 8) is dealt a contiguous run of shared-weights work items followed by a contiguous run of the
   // others, an eighth of either class: rounds are homogeneous, the XCDs balanced, and the items of a run follow the
-  // L2-friendly walk of tile_of.
-  int64_t tile_t; int tile_i;
+  // L2-friendly walk of tile_of.  (32-bit tile arithmetic: the launcher bounds nwg by 2^31; 64-bit divisions cost ~800 scalar
+  // instructions at the head of every workgroup.)
+  uint32_t tile_t; uint32_t tile_i;
   bool shared_w;
   {
-    constexpr int TW = 32 * MB;
-    const int64_t q = nwg >> 3;
-    if ((int64_t)blockIdx.x >= (q << 3)) return;                 // workgroup-uniform; before any barrier
-    const int64_t x = blockIdx.x & 7, local = blockIdx.x >> 3;
-    const int64_t nsh = la.rg.counts[0], noth = la.rg.counts[1];
-    const int64_t tb = la.rg.col0 / TW;                          // the region's first tile (col0, ncol: multiples of 64)
-    const int64_t ns = (nsh + TW - 1) / TW, fo = (la.rg.ncol - noth) / TW, nf = la.rg.ncol / TW - fo;
-    const int64_t NS = la.skip_shared ? 0 : ns * ntile_i, NF = nf * ntile_i;
-    const int64_t sS = (x * NS) >> 3, cS = (((x + 1) * NS) >> 3) - sS, sF = (x * NF) >> 3, cF = (((x + 1) * NF) >> 3) - sF;
+    const uint32_t q = (uint32_t)(nwg >> 3);
+    if (blockIdx.x >= (q << 3)) return;                          // workgroup-uniform; before any barrier
+    const uint32_t x = blockIdx.x & 7, local = blockIdx.x >> 3;
+    const uint32_t nsh = (uint32_t)la.rg.counts[0], noth = (uint32_t)la.rg.counts[1];
+    const uint32_t tb = (uint32_t)(la.rg.col0 / TW);             // the region's first tile (col0, ncol: multiples of 64)
+    const uint32_t ncolt = (uint32_t)(la.rg.ncol / TW);
+    const uint32_t ns = (nsh + TW - 1) / TW, fo = ((uint32_t)la.rg.ncol - noth) / TW, nf = ncolt - fo;
+    const uint64_t NS = la.skip_shared ? 0 : (uint64_t)ns * (uint32_t)ntile_i, NF = (uint64_t)nf * (uint32_t)ntile_i;
+    const uint32_t sS = (uint32_t)((x * NS) >> 3), cS = (uint32_t)(((x + 1) * NS) >> 3) - sS;
+    const uint32_t sF = (uint32_t)((x * NF) >> 3), cF = (uint32_t)(((x + 1) * NF) >> 3) - sF;
     if (local < cS) {
       shared_w = true;
-      tile_of(sS + local, ns, ntile_i, tile_t, tile_i);
+      tile_of32(sS + local, ns, (uint32_t)ntile_i, tile_t, tile_i);
       tile_t += tb;
     } else if (local - cS < cF) {
       shared_w = false;
-      tile_of(sF + local - cS, nf, ntile_i, tile_t, tile_i);
+      tile_of32(sF + local - cS, nf, (uint32_t)ntile_i, tile_t, tile_i);
       tile_t += tb + fo;
     } else {
       return;
     }
   }
-  // staged here (Ls is padded to ldp, a multiple of the tile): in the epilogue these loads would sit behind the
-  // stores of the previous row (possible aliasing) and expose one global-memory round trip per row
-  for (int e = threadIdx.x; e < NL * 32 * MB; e += 256)
-    s_li[e / (32 * MB)][e % (32 * MB)] = la.Ls[(int64_t)(e / (32 * MB)) * a.ldp + tile_t * (32 * MB) + (e % (32 * MB))];
-  if (threadIdx.x < 32 * MB) s_perm[threadIdx.x] = la.perm[tile_t * (32 * MB) + threadIdx.x];
+  // L^-1 and the trait numbers of the tile (Ls is padded to ldp, a multiple of the tile): fetched here, stored to LDS in front
+  // of the K loops -- in the epilogue these loads would sit behind the stores of the previous row (possible aliasing)
+  static_assert(NL * TW <= 2 * 256, "L^-1 staging: two elements per thread");
+  double li_st[2]; int perm_st = -1;
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const int e = (int)threadIdx.x + 256 * u;
+    li_st[u] = (e < NL * TW) ? la.Ls[(int64_t)(e / TW) * a.ldp + (int64_t)tile_t * TW + (e % TW)] : 0.0;
+  }
+  if (threadIdx.x < TW) perm_st = la.perm[(int64_t)tile_t * TW + threadIdx.x];
   const int wt = wave >> 1, wi = wave & 1;
   const int64_t i0 = (int64_t)tile_i * (32 * NB) + wi * (16 * NB);
   const int r = lane & 15, kk = lane >> 4;
 
-  d4 acc[NACC][MB][NB];
-#pragma unroll
-  for (int q = 0; q < NACC; ++q)
-#pragma unroll
-    for (int mb = 0; mb < MB; ++mb)
-#pragma unroll
-      for (int nb = 0; nb < NB; ++nb) acc[q][mb][nb] = (d4){0, 0, 0, 0};
-
-  const double* PA = a.P + tile_t * (32 * MB);
+  const double* PA = a.P + (int64_t)tile_t * TW;
   const double* PB = a.Xt + (int64_t)tile_i * (32 * NB);
-  const double* PC = la.Cp + tile_t * (32 * MB);
+  const double* PC = la.Cp + (int64_t)tile_t * TW;
   const double* PT = la.T + (int64_t)tile_i * (32 * NB);
   const uint32_t voffA = (uint32_t)(((int64_t)kk * a.ldp + wt * (16 * MB) + MB * r) * 8);
-  const uint32_t voffB = (uint32_t)(((int64_t)kk * a.ldx + wi * (16 * NB) + NB * r) * 8);
+  const uint32_t voffB = (uint32_t)(((int64_t)kk * a.ldx + wi * (16 * NB)) * 8) + mvoff<NB>(r);
   const int64_t sa = 4 * a.ldp, sb = 4 * a.ldx;
+
+  d4 acc[NACC][MB][NB];
 
   // ---- phase 1: num, two K steps per fragment set (a.ks is even: the K dimension is padded to 8);
   //      phase 2: Sxx and s_q over the weight basis.  The first fragment set of phase 2 is fetched under the last
   //      MFMAs of phase 1, so the only exposed load latency of a tile is its very first set.
   auto load1 = [&](double (&A)[2][MB], double (&B)[2][NB], int step2) {
+#ifdef LR_NOLOAD    // diagnostic: the matrix pipe alone (operands from registers)
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+#pragma unroll
+      for (int u = 0; u < MB; ++u) { A[h][u] = (double)(lane + step2 + u); asm volatile("" : "+v"(A[h][u])); }
+#pragma unroll
+      for (int u = 0; u < NB; ++u) { B[h][u] = (double)(lane - step2 + u); asm volatile("" : "+v"(B[h][u])); }
+    }
+    return;
+#endif
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
       bufload<MB>(A[h], make_srd(PA + (int64_t)(2 * step2 + h) * sa), voffA);
-      bufload<NB>(B[h], make_srd(PB + (int64_t)(2 * step2 + h) * sb), voffB);
+      bufload_m<NB>(B[h], make_srd(PB + (int64_t)(2 * step2 + h) * sb), voffB);
     }
   };
   auto mfma1 = [&](const double (&A)[2][MB], const double (&B)[2][NB]) {
@@ -422,9 +504,18 @@ __global__ void __launch_bounds__(256, 2) k_scan_lr(LrArgs la, int ntile_i, int6
           acc[0][mb][nb] = __builtin_amdgcn_mfma_f64_16x16x4f64(A[h][mb], B[h][nb], acc[0][mb][nb], 0, 0, 0);
   };
   auto load2 = [&](double (&A)[MB], double (&B)[1 + C][NB], int step) {
+#ifdef LR_NOLOAD
+#pragma unroll
+    for (int u = 0; u < MB; ++u) { A[u] = (double)(lane + step + u); asm volatile("" : "+v"(A[u])); }
+#pragma unroll
+    for (int q = 0; q <= C; ++q)
+#pragma unroll
+      for (int u = 0; u < NB; ++u) { B[q][u] = (double)(lane - step + u + q); asm volatile("" : "+v"(B[q][u])); }
+    return;
+#endif
     bufload<MB>(A, make_srd(PC + (int64_t)step * sa), voffA);
 #pragma unroll
-    for (int q = 0; q <= C; ++q) bufload<NB>(B[q], make_srd(PT + q * la.tstride + (int64_t)step * sb), voffB);
+    for (int q = 0; q <= C; ++q) bufload_m<NB>(B[q], make_srd(PT + q * la.tstride + (int64_t)step * sb), voffB);
   };
   auto mfma2 = [&](const double (&A)[MB], const double (&B)[1 + C][NB]) {
 #pragma unroll
@@ -441,6 +532,22 @@ __global__ void __launch_bounds__(256, 2) k_scan_lr(LrArgs la, int ntile_i, int6
   {
     double a0[2][MB], b0[2][NB], a1[2][MB], b1[2][NB];
     load1(a0, b0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    // the staged tables go to LDS while the first fragments are on their way (read after the barrier in front of the epilogue)
+    lod_stage_store<256>(lst, s_lod, a.lodc[0]);
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int e = (int)threadIdx.x + 256 * u;
+      if (e < NL * TW) s_li[e / TW][e % TW] = li_st[u];
+    }
+    if (threadIdx.x < TW) s_perm[threadIdx.x] = perm_st;
+#pragma unroll
+    for (int q = 0; q < NACC; ++q)
+#pragma unroll
+      for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) acc[q][mb][nb] = (d4){0, 0, 0, 0};
+    __builtin_amdgcn_sched_barrier(0);
     int s2 = 0;
     while (s2 + 2 < K2) {   // a following pair exists
       load1(a1, b1, s2 + 1);
@@ -485,18 +592,30 @@ __global__ void __launch_bounds__(256, 2) k_scan_lr(LrArgs la, int ntile_i, int6
   }
 
   // ---- epilogue ---------------------------------------------------------------------------------------------
+#ifdef LR_PHASE
+  __builtin_amdgcn_sched_barrier(0);
+  const unsigned long long ph_t2 = __builtin_amdgcn_s_memtime();
+  __builtin_amdgcn_sched_barrier(0);
+#endif
   __syncthreads();
-  const LodPoly lp = make_lod_poly(-0.5 * (double)a.n);
-  const int64_t ibase = i0 + NB * r;
+#ifdef LR_PHASE
+  __builtin_amdgcn_sched_barrier(0);
+  const unsigned long long ph_t3 = __builtin_amdgcn_s_memtime();
+  __builtin_amdgcn_sched_barrier(0);
+#endif
+  const double scale = a.lodc[0];
+  const LodPoly5 lp = lod_poly5_of(a.lodc);
   int nnan = 0;
   // Two instances of the epilogue behind one workgroup-uniform branch.  A shared-weights tile multiplies by the per-marker
   // 1 / sqrt(Sxx - |u|^2) of the unweighted model (left by k_lr_tpanels): no L_j^-1, no reciprocal -- the epilogue is fp64
   // VALU time the matrix pipe cannot overlap.  (By default these tiles go through the leaner table kernel instead:
   // launch_scan_shared; this path serves BLMM_LR_LEAN=0.)
+  // The NB outputs of a row are NB independent chains; u outside the LOD table's range (LOD beyond ~1.2 n / 2, r^2 >= 1, NaN)
+  // is rare and handled per ROW behind one branch.
   auto epilogue = [&](auto SH) {
     constexpr bool SHW = decltype(SH)::value;
     double rd[NB];
-    if constexpr (SHW) loadv<NB>(rd, la.den0 + ibase);
+    if constexpr (SHW) loadv_m<NB>(rd, la.den0 + i0, r);
 #pragma unroll
     for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
@@ -508,7 +627,7 @@ __global__ void __launch_bounds__(256, 2) k_scan_lr(LrArgs la, int ntile_i, int6
 #pragma unroll
           for (int e = 0; e < NL; ++e) li[e] = s_li[e][wt * (16 * MB) + MB * (kk + 4 * reg) + mb];
         }
-        double out[NB];
+        double uv[NB], out[NB];
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) {
           const double num = acc[0][mb][nb][reg];
@@ -525,29 +644,41 @@ __global__ void __launch_bounds__(256, 2) k_scan_lr(LrArgs la, int ntile_i, int6
               for (int e = 0; e <= q; ++e) u = fma(li[q * (q + 1) / 2 + e], acc[2 + e][mb][nb][reg], u);
               xx = fma(-u, u, xx);
             }
-            r2 = (num * num) * fast_rcp(xx);
+            r2 = (num * num) * fast_rcp1(xx);
           }
-          const double u1 = 1.0 - r2;  // r2lod (src/bulkscan_helpers.jl:22-24): -(n/2) * log10(1.0 - r^2)
-          double lod = fast_lod(u1, s_log, lp);
-          if (__builtin_expect(!(u1 > 0.0), 0)) {
-            lod = (u1 == 0.0) ? INFINITY : NAN;
-            nnan += (u1 != 0.0) && (ibase + nb < a.p);
-          }
-          out[nb] = lod;
+          uv[nb] = 1.0 - r2;   // r2lod (src/bulkscan_helpers.jl:22-24): -(n/2) * log10(1.0 - r^2)
         }
-        double* dst = a.L + trait * a.ldL + ibase;
-        if (ibase + NB <= a.p) {
-          __builtin_nontemporal_store((d2u){out[0], out[1]}, reinterpret_cast<d2u*>(dst));
-          __builtin_nontemporal_store((d2u){out[2], out[3]}, reinterpret_cast<d2u*>(dst + 2));
-        } else {
+        bool ok = true;
+#ifdef LR_NOEPI     // diagnostic: the K loops and the stores alone
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) out[nb] = acc[0][mb][nb][reg] + acc[1][mb][nb][reg] + acc[2][mb][nb][reg];
+#else
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) { out[nb] = fast_lod5(uv[nb], s_lod, lp); ok = ok && lod_fast_ok(uv[nb]); }
+        if (__builtin_expect(!ok, 0)) {
 #pragma unroll
           for (int nb = 0; nb < NB; ++nb)
-            if (ibase + nb < a.p) dst[nb] = out[nb];
+            if (!lod_fast_ok(uv[nb])) out[nb] = lod_out_of_range(uv[nb], s_lod, lp, scale, i0 + mslot<NB>(r, nb) < a.p, &nnan);
         }
+#endif
+#ifdef LR_NOSTORE   // diagnostic: everything but the stream of stores
+        if (out[0] + out[1] + out[2] + out[3] != 1.2345e-300) continue;
+#endif
+        store_m<NB>(a.L + trait * a.ldL + i0, r, out, a.p - i0);
       }
   };
   if (shared_w) epilogue(std::true_type{}); else epilogue(std::false_type{});
   if (nnan) atomicAdd((unsigned long long*)&a.stat[ST_NAN_LOD], (unsigned long long)nnan);
+#ifdef LR_PHASE
+  {
+    __builtin_amdgcn_sched_barrier(0);
+    const unsigned long long ph_t4 = __builtin_amdgcn_s_memtime();
+    if (lane == 0) {
+      unsigned long long* z = g_lr_phase + (shared_w ? 0 : 4);
+      atomicAdd(&z[0], ph_t2 - ph_t0); atomicAdd(&z[1], ph_t3 - ph_t2); atomicAdd(&z[2], ph_t4 - ph_t3); atomicAdd(&z[3], 1ull);
+    }
+  }
+#endif
 #ifdef LR_DIAG
   if (threadIdx.x == 0) {
     atomicAdd(&g_lr_diag[shared_w ? 0 : 2], __builtin_amdgcn_s_memtime() - diag_t0);
@@ -573,7 +704,20 @@ static int launch_scan_lr_t(blmm_ctx* ctx, const LrArgs& la) {
   (void)hipMemcpyToSymbol(HIP_SYMBOL(g_lr_diag), z, sizeof(z));
   (void)hipStreamSynchronize(ctx->stream);
 #endif
+#ifdef LR_PHASE
+  unsigned long long zp[8] = {0};
+  (void)hipMemcpyToSymbol(HIP_SYMBOL(g_lr_phase), zp, sizeof(zp));
+  (void)hipStreamSynchronize(ctx->stream);
+#endif
   hipLaunchKernelGGL((k_scan_lr<C, MB, NB>), dim3((unsigned)nwg), dim3(256), 0, ctx->stream, la, (int)ntile_i, nwg);
+#ifdef LR_PHASE
+  (void)hipStreamSynchronize(ctx->stream);
+  (void)hipMemcpyFromSymbol(zp, HIP_SYMBOL(g_lr_phase), sizeof(zp));
+  for (int cls = 0; cls < 2; ++cls)
+    if (zp[4 * cls + 3])
+      fprintf(stderr, "lr phase: %s tiles: %llu waves, avg cycles K loops %.0f | barrier wait %.0f | epilogue %.0f\n", cls ? "rank-R" : "shared",
+              zp[4 * cls + 3], (double)zp[4 * cls] / zp[4 * cls + 3], (double)zp[4 * cls + 1] / zp[4 * cls + 3], (double)zp[4 * cls + 2] / zp[4 * cls + 3]);
+#endif
 #ifdef LR_DIAG
   (void)hipStreamSynchronize(ctx->stream);
   (void)hipMemcpyFromSymbol(z, HIP_SYMBOL(g_lr_diag), sizeof(z));
@@ -626,21 +770,27 @@ int launch_scan_table(blmm_ctx* ctx, const ScanArgs& a) {
 // Panels: P[g][k][j] = panel 0 under h2 = grid[g].
 // ------------------------------------------------------------------------------------------------
 template <int MB, int NB>
-__global__ void __launch_bounds__(256, 2) k_scan_alt(AltArgs aa, int ntile_i, int64_t nwg) {
+__global__ void __launch_bounds__(256, 3) k_scan_alt(AltArgs aa, int ntile_i, int64_t nwg) {
   const ScanArgs& a = aa.s;
-  __shared__ dpair s_log[BLMM_LOG_TABLE_N];
-  stage_lod_table(s_log, a.logtab, -0.5 * (double)a.n);   // scale folded into the table: fast_lod returns -(n/2) log10(u)
+  __shared__ dpair s_lod[BLMM_LOD_TABLE_N];
+  const double ln10 = 2.302585092994046;  // log(10)
+  // the table carries -(n/2) ln c: fast_lod5 then returns ln10 * LOD = -(n/2) ln(u) directly (one multiply less per grid
+  // point and test than ln10 * (-(n/2) log10 u))
+  const double scale = a.lodc[0];
+  {
+    LodStage<256> lst;
+    lod_stage_load<256>(lst, a.lodtab);
+    lod_stage_store<256>(lst, s_lod, scale);
+  }
   __syncthreads();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int64_t bid = xcd_swizzle(blockIdx.x, nwg);
-  int64_t tile_t; int tile_i;
-  tile_of(bid, nwg / ntile_i, ntile_i, tile_t, tile_i);
-  const int64_t t0 = tile_t * (32 * MB) + (wave >> 1) * (16 * MB);
+  const uint32_t bid = (uint32_t)xcd_swizzle(blockIdx.x, nwg);
+  uint32_t tile_t, tile_i;
+  tile_of32(bid, (uint32_t)nwg / (uint32_t)ntile_i, (uint32_t)ntile_i, tile_t, tile_i);
+  const int64_t t0 = (int64_t)tile_t * (32 * MB) + (wave >> 1) * (16 * MB);
   const int64_t i0 = (int64_t)tile_i * (32 * NB) + (wave & 1) * (16 * NB);
   const int r = lane & 15, kk = lane >> 4;
-  const LodPoly lp = make_lod_poly(-0.5 * (double)a.n);
-  const double ln10 = 2.302585092994046;  // log(10)
-  const int64_t ibase = i0 + NB * r;
+  const LodPoly5 lp = lod_poly5_of(a.lodc);
 
   double best[MB][NB][4];
   int bidx[MB][NB][4];
@@ -656,16 +806,16 @@ __global__ void __launch_bounds__(256, 2) k_scan_alt(AltArgs aa, int ntile_i, in
 
   // one flat loop over (grid point g, K step ks) with the same two-fragment-set prefetch as k_scan; the prefetch
   // runs across grid points, the running-max epilogue fires after the last K step of every g
-  const double* PA = a.P + tile_t * (32 * MB);
+  const double* PA = a.P + (int64_t)tile_t * (32 * MB);
   const double* PB = a.Xt + (int64_t)tile_i * (32 * NB);
   const uint32_t voffA = (uint32_t)(((int64_t)kk * a.ldp + (wave >> 1) * (16 * MB) + MB * r) * 8);
-  const uint32_t voffB = (uint32_t)(((int64_t)kk * a.ldx + (wave & 1) * (16 * NB) + NB * r) * 8);
+  const uint32_t voffB = (uint32_t)(((int64_t)kk * a.ldx + (wave & 1) * (16 * NB)) * 8) + mvoff<NB>(r);
   const int64_t sa = 4 * a.ldp, sb = 4 * a.ldx;
   const int KS = a.ks, G = aa.ngrid;
   int gl = 0, kl = 0;  // load cursor
   auto load_next = [&](double (&A)[MB], double (&B)[NB]) {
     bufload<MB>(A, make_srd(PA + (int64_t)gl * a.pstride + kl * sa), voffA);
-    bufload<NB>(B, make_srd(PB + kl * sb), voffB);
+    bufload_m<NB>(B, make_srd(PB + kl * sb), voffB);
     if (++kl == KS) { kl = 0; if (gl + 1 < G) ++gl; else kl = KS - 1; }   // clamp at the very end (harmless re-load)
   };
   auto mfma_set = [&](const double (&A)[MB], const double (&B)[NB]) {
@@ -679,7 +829,7 @@ __global__ void __launch_bounds__(256, 2) k_scan_alt(AltArgs aa, int ntile_i, in
   // at the START of g's K loop: at fold time they used to cost one exposed global round trip per grid point
   double sc[NB], ellv[MB][4];
   auto fold_fetch = [&](int g) {
-    loadv<NB>(sc, a.isx + (int64_t)g * a.ld_isx + ibase);
+    loadv_m<NB>(sc, a.isx + (int64_t)g * a.ld_isx + i0, r);
 #pragma unroll
     for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
@@ -694,13 +844,23 @@ __global__ void __launch_bounds__(256, 2) k_scan_alt(AltArgs aa, int ntile_i, in
 #pragma unroll
       for (int reg = 0; reg < 4; ++reg) {
         const double ell = ellv[mb][reg];
+        double uv[NB], lv[NB];
+        bool ok = true;
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) {
           const double rr = acc[mb][nb][reg] * sc[nb];
-          const double u = 1.0 - rr * rr;
-          double lod = fast_lod(u, s_log, lp);
-          if (!(u > 0.0)) lod = (u == 0.0) ? INFINITY : NAN;
-          const double l1 = fma(lod, ln10, ell);
+          uv[nb] = 1.0 - rr * rr;
+          lv[nb] = fast_lod5(uv[nb], s_lod, lp);
+          ok = ok && lod_fast_ok(uv[nb]);
+        }
+        if (__builtin_expect(!ok, 0)) {   // rare: LOD beyond ~1.2 n / 2, r^2 >= 1 (+Inf / NaN), NaN
+#pragma unroll
+          for (int nb = 0; nb < NB; ++nb)
+            if (!lod_fast_ok(uv[nb])) { int dummy = 0; lv[nb] = lod_out_of_range(uv[nb], s_lod, lp, scale, false, &dummy); }
+        }
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+          const double l1 = lv[nb] + ell;
           const bool first = g == 0;
           const bool better = best[mb][nb][reg] < l1;
           if (first || better) best[mb][nb][reg] = l1;
@@ -750,27 +910,16 @@ __global__ void __launch_bounds__(256, 2) k_scan_alt(AltArgs aa, int ntile_i, in
       if (trait >= a.m) continue;
       double l0 = aa.EllTab[trait * (int64_t)G];
       for (int g = 1; g < G; ++g) l0 = fmax(l0, aa.EllTab[trait * (int64_t)G + g]);
-      double* dst = a.L + trait * a.ldL + ibase;
-      double* dh = aa.H2 + trait * aa.ldH + ibase;
       double lv[NB], hv[NB];
 #pragma unroll
       for (int nb = 0; nb < NB; ++nb) {
         lv[nb] = (best[mb][nb][reg] - l0) / ln10;
         hv[nb] = aa.grid_dev[bidx[mb][nb][reg]];
-        nnan += (lv[nb] != lv[nb]) && (ibase + nb < a.p);
+        nnan += (lv[nb] != lv[nb]) && (i0 + mslot<NB>(r, nb) < a.p);
       }
-      if (NB == 4 && ibase + NB <= a.p) {
-        // 16-byte stores (8-byte aligned: ld = p may be odd): four single 8-byte nontemporal stores per lane cost ~4x the
-        // HBM write traffic of the matrix (rocprofv3 WRITE_SIZE 17.6 GB against 4.16 GB algorithmic, profiles/r02_summary.json)
-        __builtin_nontemporal_store((d2u){lv[0], lv[1]}, reinterpret_cast<d2u*>(dst));
-        __builtin_nontemporal_store((d2u){lv[2], lv[3]}, reinterpret_cast<d2u*>(dst + 2));
-        __builtin_nontemporal_store((d2u){hv[0], hv[1]}, reinterpret_cast<d2u*>(dh));
-        __builtin_nontemporal_store((d2u){hv[2], hv[3]}, reinterpret_cast<d2u*>(dh + 2));
-      } else {
-#pragma unroll
-        for (int nb = 0; nb < NB; ++nb)
-          if (ibase + nb < a.p) { dst[nb] = lv[nb]; dh[nb] = hv[nb]; }
-      }
+      // 16-byte stores (8-byte aligned: ld = p may be odd), whole 128-byte lines per instruction (store_m)
+      store_m<NB>(a.L + trait * a.ldL + i0, r, lv, a.p - i0);
+      store_m<NB>(aa.H2 + trait * aa.ldH + i0, r, hv, a.p - i0);
     }
   if (nnan) atomicAdd((unsigned long long*)&a.stat[ST_NAN_LOD], (unsigned long long)nnan);
 }
