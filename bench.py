@@ -66,6 +66,24 @@ def cpu_baseline(Y, G, K, budget_s=15.0):
                       f"first {sample} of {Y.shape[1]} traits x {p} markers, {cores} threads, {dt:.1f} s"}
 
 
+def workload_name(a, n, p, m_total, m_local, f32, world):
+    """Names the configuration actually run: method, shape, dtype and the BASELINE.json config it corresponds to (if any)."""
+    dt = "fp32 permutation matrix (null model fp64)" if f32 else "fp64"
+    shape = (n, p, m_total)
+    if a.method == "null-exact" and shape == (79, 7321, 35554):
+        which = "BASELINE.json configs[1]: bulkscan_null, BXD shape"
+    elif a.method in ("null-grid", "alt-grid") and shape == (79, 7321, 35554):
+        which = "BASELINE.json configs[3]: 16-point h2 grid, BXD shape (" + ("primary" if a.method == "null-grid" else "secondary") + " method)"
+    elif a.method in ("null-exact", "null-grid") and (n, p) == (500, 50000):
+        which = f"BASELINE.json configs[2]: synthetic large eQTL ({m_total} of its 20000 traits" + (", one of 8 shards" if m_total == 2500 else "") + ")"
+    elif a.method == "perms" and (n, p) == (1000, 100000):
+        which = f"BASELINE.json configs[4]: single-trait permutation test ({m_total} of its 10000 permutations" + (", one of 8 shards" if m_total == 1250 else "") + ")"
+    else:
+        which = "no BASELINE.json config has this method and shape"
+    unit = "permutations" if a.method == "perms" else "traits"
+    return (f"method={a.method} n={n} p={p} m={m_total} {dt}, {which}; {m_local} {unit} on rank 0 of {world}")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -255,6 +273,18 @@ def main():
         return float(tmax.item()), ph, nc
 
     dt, phases, ncalls = timed(work, a.gather, a.steps, a.warmup)
+    # The headline workload's h2 = 0 share (about half of the synthetic traits end at the boundary and take the cheaper
+    # shared-weights class) is a property of the DATA: one more timed loop with the class switched off (every trait through the
+    # rank-R form, BLMM_LR_SHARED=0, read per call by the library) says what the step costs without it.
+    all_rank = None
+    if a.method == "null-exact" and world == 1 and a.streams == 1 and not os.environ.get("BLMM_LR_SHARED"):
+        os.environ["BLMM_LR_SHARED"] = "0"
+        try:
+            dt_r, ph_r, nc_r = timed(work, False, max(a.steps // 2, 3), 1)
+            all_rank = {"ms_per_step": dt_r / max(a.steps // 2, 3) * 1e3, "scan_ms": ph_r["scan"] / max(nc_r, 1)}
+        finally:
+            del os.environ["BLMM_LR_SHARED"]
+        work.scan(); torch.cuda.synchronize()      # leave the default path's result in the outputs
     lr_rank = lr_resid = lr_fallback = lr_shared = None
     if a.method == "null-exact":   # one extra (untimed) call with a status read-back: the weight basis and its guard
         st = B.bulkscan_dev(ctx, work.dY, dG, dK, work.dL, work.dH, method=a.method, h2_grid=grid, status=True)
@@ -359,13 +389,22 @@ def main():
             roof["reference_formulation_equiv_TFLOPs"] = survey_flops / (scan_ms * 1e-3) / 1e12 if scan_ms > 0 else None
             roof["note"] = ("achieved/frac count the flops the kernel EXECUTES (low-rank weights form); the same launch "
                             "delivers the reference formulation's 2n(2+c) flops/test at reference_formulation_equiv_TFLOPs")
+        if all_rank:
+            roof["ms_per_step_all_rank_form"] = all_rank["ms_per_step"]
+            roof["scan_ms_all_rank_form"] = all_rank["scan_ms"]
+            if rank_form_flops and all_rank["scan_ms"] > 0:
+                roof["frac_all_rank_form_measured"] = rank_form_flops / (all_rank["scan_ms"] * 1e-3) / 1e12 / FP64_MFMA_PEAK_TFLOPS
+        # HBM traffic comes from PMC counters, which need their own rocprofv3 passes (tools/collect_profiles.py writes
+        # profiles/traffic_latest.json): it is NOT measured by this run -- `traffic_measured_in_this_run` says so -- and is only
+        # quoted when that profile was taken on the same method and shape
+        roof["traffic_measured_in_this_run"] = False
         tp = os.path.join(ROOT, "profiles", "traffic_latest.json")
         if os.path.exists(tp):
             try:
                 tj = json.load(open(tp))
-                if tj.get("method") == a.method and tj.get("m") == m_local and tj.get("p") == p:
+                if tj.get("method") == a.method and tj.get("m") == m_local and tj.get("p") == p and tj.get("n", n) == n:
                     roof["traffic"] = tj.get("hbm_bytes_per_launch")
-                    roof["traffic_source"] = tj.get("source")
+                    roof["traffic_source"] = "from profiles/traffic_latest.json (" + str(tj.get("round", "?")) + "): " + str(tj.get("source"))
                     if tj.get("rocprof_kernel_avg_ms"):
                         roof["kernel_ms_rocprof"] = tj["rocprof_kernel_avg_ms"]
                         roof["frac_rocprof"] = flops_launch / (tj["rocprof_kernel_avg_ms"] * 1e-3) / 1e12 / roof["peak"]
@@ -375,8 +414,7 @@ def main():
             "metric": "trait x marker LOD tests/sec", "value": tests / (dt / a.steps), "unit": "tests/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms_step, "higher_is_better": True,
             "scaling": a.scaling, "vs_baseline": None, "dtype": "f32" if f32 else "f64", "data": "synthetic",
-            "config": {"workload": f"bulkscan_null-shaped: method={a.method} n={n} p={p} m={m_total} fp64 "
-                                   f"(BASELINE.json configs[1]; {m_local} traits on rank 0)",
+            "config": {"workload": workload_name(a, n, p, m_total, m_local, f32, world),
                        "n": n, "p": p, "m": m_total, "m_per_gpu": m_local, "method": a.method,
                        "parallelism": f"traits sharded over {world} GPU(s)", "gather_in_step": bool(a.gather),
                        "streams": max(a.streams, 1)},

@@ -452,8 +452,9 @@ int lr_begin(blmm_ctx* ctx, const Pipe& P, bool wbasis_started) {
 namespace {
 // the shared-weights class uses the tolerance of the expansion guard; BLMM_LR_SHARED=0 switches the class off (A/B testing)
 double lr_shared_tol() {
-  static const bool on = !(getenv("BLMM_LR_SHARED") && getenv("BLMM_LR_SHARED")[0] == '0');
-  return on ? lr_tolerance() : 0.0;
+  // read per call (not cached): bench.py times the same process with and without the class (ms_per_step_all_rank_form)
+  const char* e = getenv("BLMM_LR_SHARED");
+  return !(e && e[0] == '0') ? lr_tolerance() : 0.0;
 }
 LrArgs lr_args(blmm_ctx* ctx, const Pipe& P, const LrRegion& rg, double* dL, int64_t ldL) {
   const int64_t ldp = 2 * lr_ldq(P);

@@ -1,5 +1,5 @@
-"""Condenses a tools/profile_round2.sh output directory into the tracked summaries under profiles/:
-r02_summary.json (per LOD kernel: rocprof average duration, HBM bytes per launch from the FETCH_SIZE / WRITE_SIZE passes with
+"""Condenses a tools/profile_round.sh output directory into the tracked summaries under profiles/ (python3
+tools/collect_profiles.py gpurun_out/r03 r03): <round>_summary.json (per LOD kernel: rocprof average duration, HBM bytes per launch from the FETCH_SIZE / WRITE_SIZE passes with
 the gfx950 x2 correction on FETCH_SIZE, matrix-pipe busy fraction), the kernel-stats CSVs, the bench lines."""
 import csv
 import glob
@@ -10,6 +10,7 @@ import shutil
 import sys
 
 out = sys.argv[1]
+RND = sys.argv[2] if len(sys.argv) > 2 else "r03"
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 prof = os.path.join(root, "profiles")
 # substrings of the kernel names that make up a configuration's LOD scan: null-exact = k_scan_lr (rank-R class) + the table
@@ -33,7 +34,7 @@ for tag, kern in KERN.items():
     st = glob.glob(os.path.join(out, tag, "trace", "**", "*kernel_stats.csv"), recursive=True)
     if not st:
         continue
-    shutil.copy(st[0], os.path.join(prof, f"r02_kernel_stats_{tag}.csv"))
+    shutil.copy(st[0], os.path.join(prof, f"{RND}_kernel_stats_{tag}.csv"))
     rows = list(csv.DictReader(open(st[0])))
     mine = [r for r in rows if any(k in r["Name"] for k in kern)]
     # launches per library call: the null-exact scan runs two kernels per panel region (two regions when the h2 search is
@@ -56,17 +57,17 @@ for tag, kern in KERN.items():
         if s["rocprof_avg_ms"]:
             s["effective_clock_GHz"] = s["GRBM_GUI_ACTIVE"] / 8 / (s["rocprof_avg_ms"] * 1e-3) / 1e9
     summary[tag] = s
-json.dump(summary, open(os.path.join(prof, "r02_summary.json"), "w"), indent=1)
-for name in ("bench.json", "configs.jsonl", "mb3_f64.log", "mb_f64.log"):
+json.dump(summary, open(os.path.join(prof, RND + "_summary.json"), "w"), indent=1)
+for name in ("bench.json", "configs.jsonl", "mb3_f64.log", "mb_f64.log", "mb4_rcp.log", "mb_lod.log"):
     src = os.path.join(out, name)
     if os.path.exists(src):
-        shutil.copy(src, os.path.join(prof, "r02_" + name))
+        shutil.copy(src, os.path.join(prof, RND + "_" + name))
 if "exact" in summary and summary["exact"].get("hbm_bytes_per_launch"):
     e = summary["exact"]
-    json.dump({"method": "null-exact", "m": 35554, "p": 7321, "hbm_bytes_per_launch": e["hbm_bytes_per_launch"],
+    json.dump({"method": "null-exact", "n": 79, "m": 35554, "p": 7321, "round": RND, "hbm_bytes_per_launch": e["hbm_bytes_per_launch"],
                "fetch_bytes": e["hbm_fetch_bytes"], "write_bytes": e["hbm_write_bytes"], "rocprof_kernel_avg_ms": e["rocprof_avg_ms"],
                "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) and --kernel-trace --stats, per call = k_scan_lr<1,2,4> + "
                          "k_scan<0,2,4,table,perm> over both panel regions, "
-                         "profiles/r02_summary.json; FETCH_SIZE x2 per MI355X_MICROARCH.md (gfx950 wide coalesced reads); "
+                         "profiles/" + RND + "_summary.json; FETCH_SIZE x2 per MI355X_MICROARCH.md (gfx950 wide coalesced reads); "
                          "Infinity-Cache hits are counted"}, open(os.path.join(prof, "traffic_latest.json"), "w"), indent=1)
 print(json.dumps(summary, indent=1))

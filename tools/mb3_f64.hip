@@ -44,8 +44,11 @@ void run(const char* name, int cus, int wps, int iters, double* out, unsigned lo
   for (int w = 0; w < grid * 4; w++) { cyc.push_back((double)h[2 * w]); mhz.push_back((double)h[2 * w] / (double)h[2 * w + 1] * 100.0); }
   std::sort(cyc.begin(), cyc.end()); std::sort(mhz.begin(), mhz.end());
   double nm = (double)grid * 4 * iters * NACC;
-  printf("%-26s nacc %d waves/SIMD %d: %.3f ms  %.1f TF  cycles/mfma/wave %.1f  (per SIMD %.1f)  clock %.0f MHz\n", name, NACC, wps, best,
-         nm * 2048 / best / 1e9, cyc[cyc.size() / 2] / (iters * NACC), cyc[cyc.size() / 2] / (iters * NACC) / wps, mhz[mhz.size() / 2]);
+  // per SIMD: from the THROUGHPUT (1024 SIMDs at the measured clock), not from the launch's waves-per-SIMD figure -- with 4 waves
+  // per SIMD requested the hardware may run two workgroups after one another (round 2 printed 32.0 there, against its own TF column)
+  const double tf = nm * 2048 / best / 1e9;
+  printf("%-26s nacc %d waves/SIMD %d: %.3f ms  %.1f TF  cycles/mfma/wave %.1f  (per SIMD, from the throughput: %.1f)  clock %.0f MHz\n", name, NACC, wps, best,
+         tf, cyc[cyc.size() / 2] / (iters * NACC), 2048.0 * 1024.0 * mhz[mhz.size() / 2] * 1e6 / (tf * 1e12), mhz[mhz.size() / 2]);
 }
 
 int main() {

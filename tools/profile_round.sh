@@ -1,19 +1,31 @@
 #!/bin/bash
-# Runs on the GPU box (via gpurun): default bench, rocprofv3 kernel-trace stats and the HBM PMC passes for the
-# dominant kernel.  Outputs under gpurun_out/<tag>/; copy the summaries into profiles/ afterwards.
+# Evidence run of a round (on the GPU box via gpurun; ROUND=r03 by default): microbenchmarks, the default bench line, kernel-trace stats and the HBM /
+# SQ counter passes for every LOD kernel at its BASELINE shape.  Outputs under gpurun_out/$ROUND/; tools/collect_profiles.py
+# turns them into the tracked summaries under profiles/.
 set -o pipefail
-TAG=${1:-r01}
-OUT=gpurun_out/$TAG
+ROUND=${ROUND:-r03}
+OUT=gpurun_out/$ROUND
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-echo "== bench (default flags)"; python3 bench.py > $OUT/bench.json 2> $OUT/bench.err || { tail -5 $OUT/bench.err; exit 1; }
-cat $OUT/bench.json
-echo "== kernel trace + stats"
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o trace -- python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline > $OUT/trace.log 2>&1 || { tail -5 $OUT/trace.log; exit 1; }
-echo "== pmc FETCH_SIZE"
-rocprofv3 --kernel-trace --pmc FETCH_SIZE --kernel-include-regex "k_scan" --output-format csv -d $OUT/pmc_fetch -o fetch -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline > $OUT/pmc_fetch.log 2>&1 || { tail -5 $OUT/pmc_fetch.log; exit 1; }
-echo "== pmc WRITE_SIZE"
-rocprofv3 --kernel-trace --pmc WRITE_SIZE --kernel-include-regex "k_scan" --output-format csv -d $OUT/pmc_write -o write -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline > $OUT/pmc_write.log 2>&1 || { tail -5 $OUT/pmc_write.log; exit 1; }
-echo "== pmc SQ"
-rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE --kernel-include-regex "k_scan" --output-format csv -d $OUT/pmc_sq -o sq -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline > $OUT/pmc_sq.log 2>&1 || { tail -5 $OUT/pmc_sq.log; exit 1; }
-ls -R $OUT | head -40
+echo "== microbenchmarks"
+for mb in mb3_f64 mb_f64 mb4_rcp mb_lod; do
+  /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 -I bulklmm.jl_amd/csrc tools/$mb.hip -o /tmp/$mb 2> $OUT/$mb.build.log && /tmp/$mb > $OUT/$mb.log 2>&1 || { echo "$mb failed"; tail -3 $OUT/$mb.build.log $OUT/$mb.log; }
+done
+echo "== default bench"; python3 bench.py > $OUT/bench.json 2> $OUT/bench.err || { tail -5 $OUT/bench.err; exit 1; }
+prof() {  # tag, kernel regex, bench args...
+  local tag=$1 kre=$2; shift 2
+  echo "== $tag: kernel trace"
+  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/$tag/trace -o t -- python3 bench.py --no-cpu-baseline --no-host-api --steps 5 --warmup 1 "$@" > $OUT/$tag.trace.log 2>&1 || { tail -5 $OUT/$tag.trace.log; return 1; }
+  for ctr in FETCH_SIZE WRITE_SIZE "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE"; do
+    local c1=${ctr%% *}
+    echo "== $tag: pmc $c1"
+    rocprofv3 --kernel-trace --pmc $ctr --kernel-include-regex "$kre" --output-format csv -d $OUT/$tag/pmc_$c1 -o p -- python3 bench.py --no-cpu-baseline --no-host-api --steps 3 --warmup 1 "$@" > $OUT/$tag.pmc_$c1.log 2>&1 || { tail -5 $OUT/$tag.pmc_$c1.log; return 1; }
+  done
+}
+prof exact "k_scan_lr|k_scan<0, 2, 4, true, 2, true" || exit 1
+prof grid "k_scan<" --method null-grid || exit 1
+prof alt "k_scan_alt" --method alt-grid || exit 1
+prof perm32 "k_scan_f32" --method perms --perm-dtype f32 --n 1000 --p 100000 --m 1250 || exit 1
+echo "== every configuration"
+bash tools/bench_configs.sh $OUT/configs.jsonl
+python3 tools/collect_profiles.py $OUT $ROUND
