@@ -7,7 +7,6 @@
 #include <cmath>
 #include <cstring>
 #include <limits>
-#include <dlfcn.h>
 #include <cstdlib>
 #include <mutex>
 
@@ -90,12 +89,11 @@ __global__ void k_to_rowmajor(const double* __restrict__ In, int n, int64_t ncol
 
 // Copies the device-side "gave up" conditions of a call into the context's pinned host word (system-scope store):
 // bit 0: the multi-workgroup weight-basis kernel timed out at its grid barrier (stat[8] < 0);
-// bit 1: the vendor eigensolver reported non-convergence (stat[11] = dsyevd's info).
-__global__ void k_note_info(const int* __restrict__ info, int64_t* __restrict__ stat) { stat[11] = *info; }
+// bit 1: the eigensolver gave up (stat[11]: -7 grid barrier of the tridiagonalisation timed out, -8 QL iteration limit).
 __global__ void k_sticky(const int64_t* __restrict__ stat, int64_t* hflag) {
   int64_t f = 0;
   if (stat[8] < 0) f |= 1;
-  if (stat[11] != 0) f |= 2;
+  if (stat[11] != 0) { f |= 2; hflag[1] = stat[11]; }      // the code itself: -7 / -8, the own solver's aborts
   if (f) __hip_atomic_fetch_or(hflag, f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
@@ -109,8 +107,10 @@ int check_sticky(blmm_ctx* ctx) {
   const int64_t f = *ctx->hflag;
   if (!f) return BLMM_OK;
   *ctx->hflag = 0;
-  if (f & 1) return fail(ctx, BLMM_ERR_HIP, "an earlier call failed on the device: the weight-basis kernel timed out at its grid barrier (its LOD output is NaN)");
-  return fail(ctx, BLMM_ERR_HIP, "an earlier call failed on the device: the eigensolver did not converge (dsyevd info != 0)");
+  if (f & 1) return fail(ctx, BLMM_ERR_HIP, "a call failed on the device: the weight-basis kernel timed out at its grid barrier (its LOD output is NaN)");
+  const long long code = (long long)ctx->hflag[1];
+  return fail(ctx, BLMM_ERR_HIP, "a call failed on the device: the eigensolver did not converge (code " + std::to_string(code) +
+                                 ": -7 grid barrier of the tridiagonalisation timed out, -8 QL iteration limit)");
 }
 
 struct Pipe {
@@ -198,7 +198,7 @@ int finish_status(blmm_ctx* ctx, blmm_status* st, Timer* tm) {
   st->n_illcond_rescan = h[ST_ILLCOND];
   if (h[8] < 0) return fail(ctx, BLMM_ERR_HIP, "weight-basis kernel: a workgroup timed out at the grid barrier");
   if (h[11] != 0) return fail(ctx, BLMM_ERR_HIP, "the eigensolver did not converge (code " + std::to_string((long long)h[11]) +
-                              ": > 0 dsyevd info, -7 grid barrier of the tridiagonalisation timed out, -8 QL iteration limit)");
+                              ": -7 grid barrier of the tridiagonalisation timed out, -8 QL iteration limit)");
   if (ctx->hflag && *ctx->hflag) return check_sticky(ctx);
   { double r2; std::memcpy(&r2, &h[9], sizeof(double)); st->lowrank_resid = std::sqrt(r2 < 0 ? 0.0 : r2); }
   if (tm && tm->set && tm->set->n >= 2) {
@@ -221,67 +221,13 @@ int end_call(blmm_ctx* ctx, const Pipe& P, blmm_status* st, Timer* tm) {
   return finish_status(ctx, st, tm);
 }
 
-// Eigen-decomposition for n beyond the LDS Jacobi: rocSOLVER dsyevd (the reference calls LAPACK here,
-// src/transform_helpers.jl:23); loaded lazily so that the common small-n path carries no rocBLAS start-up cost.
-// On return A holds the eigenvectors (columns) and lraw the eigenvalues.
-int eigen_rocsolver(blmm_ctx* ctx, double* A, int n, double* lraw, int64_t* stat) {
-  if (!ctx->rs_tried) {
-    ctx->rs_tried = true;
-    ctx->rb_lib = dlopen("librocblas.so", RTLD_NOW | RTLD_GLOBAL);
-    if (!ctx->rb_lib) ctx->rb_lib = dlopen("/opt/rocm/lib/librocblas.so", RTLD_NOW | RTLD_GLOBAL);
-    ctx->rs_lib = dlopen("librocsolver.so", RTLD_NOW | RTLD_GLOBAL);
-    if (!ctx->rs_lib) ctx->rs_lib = dlopen("/opt/rocm/lib/librocsolver.so", RTLD_NOW | RTLD_GLOBAL);
-    if (ctx->rb_lib && ctx->rs_lib) {
-      auto create = reinterpret_cast<int (*)(void**)>(dlsym(ctx->rb_lib, "rocblas_create_handle"));
-      ctx->rb_destroy = reinterpret_cast<int (*)(void*)>(dlsym(ctx->rb_lib, "rocblas_destroy_handle"));
-      ctx->rb_set_stream = reinterpret_cast<int (*)(void*, hipStream_t)>(dlsym(ctx->rb_lib, "rocblas_set_stream"));
-      ctx->rs_dsyevd = reinterpret_cast<int (*)(void*, int, int, int, double*, int, double*, double*, int*)>(dlsym(ctx->rs_lib, "rocsolver_dsyevd"));
-      ctx->rb_dgemm = reinterpret_cast<int (*)(void*, int, int, int, int, int, const double*, const double*, int, const double*, int,
-                                               const double*, double*, int)>(dlsym(ctx->rb_lib, "rocblas_dgemm"));
-      if (create && ctx->rb_destroy && ctx->rb_set_stream && ctx->rs_dsyevd) {
-        if (create(&ctx->rb_handle) != 0) ctx->rb_handle = nullptr;
-      }
-    }
-  }
-  if (!ctx->rb_handle || !ctx->rs_dsyevd) return BLMM_ERR_UNSUPPORTED;
-  int rc = ensure(ctx, ctx->tmpB, sizeof(double) * (size_t)n + 64);
-  if (rc) return rc;
-  if (ctx->rb_set_stream(ctx->rb_handle, ctx->stream) != 0) return fail(ctx, BLMM_ERR_HIP, "rocblas_set_stream failed");
-  double* E = ptr<double>(ctx->tmpB);
-  int* info = reinterpret_cast<int*>(E + n);
-  const int st = ctx->rs_dsyevd(ctx->rb_handle, /*evect_original*/ 211, /*fill_lower*/ 122, n, A, n, lraw, E, info);
-  if (st != 0) return fail(ctx, BLMM_ERR_HIP, "rocsolver_dsyevd failed with status " + std::to_string(st));
-  // dsyevd's device `info` -> stat[11] (the workspace is reused later in the call); k_sticky / finish_status report a
-  // non-converged decomposition as an error
-  hipLaunchKernelGGL(k_note_info, dim3(1), dim3(1), 0, ctx->stream, info, stat);
-  return BLMM_OK;
-}
-
-// Out (k-major, npad x ldo) = R * In for large n: a plain GEMM, handed to rocBLAS when it is loaded anyway (n beyond
-// the Jacobi range, where rocSOLVER did the eigen-decomposition); k_rotate otherwise.  In column-major terms
-// Out' (ncols x npad, ld = ldo) = In' (n x ncols, ld = n)' * R' with R = Rp viewed column-major (npad x n, ld = ldr).
-int rotate_any(blmm_ctx* ctx, bool use_blas, const double* Rp, int ldr, int n, int npad, const double* In, int64_t ncols,
-               double* Out, int64_t ldo, int64_t ncols_pad) {
-  if (use_blas && ctx->rb_handle && ctx->rb_dgemm && ncols >= 256 && ncols < 0x7fffffffLL && ldo < 0x7fffffffLL) {
-    if (ncols_pad > ncols)   // the pad columns of every row must read as zero
-      BLMM_HIP(hipMemset2DAsync(Out + ncols, sizeof(double) * ldo, 0, sizeof(double) * (ncols_pad - ncols), npad, ctx->stream));
-    const double one = 1.0, zero = 0.0;
-    if (ctx->rb_set_stream(ctx->rb_handle, ctx->stream) != 0) return fail(ctx, BLMM_ERR_HIP, "rocblas_set_stream failed");
-    const int st = ctx->rb_dgemm(ctx->rb_handle, /*transpose*/ 112, /*transpose*/ 112, (int)ncols, npad, n, &one, In, n, Rp, ldr,
-                                 &zero, Out, (int)ldo);
-    if (st != 0) return fail(ctx, BLMM_ERR_HIP, "rocblas_dgemm failed with status " + std::to_string(st));
-    return BLMM_OK;
-  }
-  return launch_rotate(ctx, Rp, ldr, n, npad, In, ncols, Out, ldo, ncols_pad);
-}
-
 // design -> eigen -> rotation of Y and G.  centered = 1: the rotation also removes the unweighted projection
 // on the null covariates (kernels_prep.hip:k_post_eigen).
 int prepare(blmm_ctx* ctx, const blmm_opts* o, const double* dY, int64_t n, int64_t m, const double* dG, int64_t p,
             const double* dCovar, int64_t ncov, const double* dK, const double* dweights, int centered, Pipe& P, Timer& tm,
             bool early_wbasis = false) {
   if (n < 1 || m < 0 || p < 0 || ncov < 0) return fail(ctx, BLMM_ERR_DIM, "Dimension mismatch.");
-  if (n > 46000) return fail(ctx, BLMM_ERR_UNSUPPORTED, "n too large");
+  if (n > 2048) return fail(ctx, BLMM_ERR_UNSUPPORTED, "more than 2048 individuals: the device eigensolver (tridiagonalisation + divide and conquer) stops at n = 2048");
   int add_int = o->add_intercept ? 1 : 0;
   if (ncov == 0 || !dCovar) { add_int = 1; ncov = 0; dCovar = nullptr; }  // bulkscan(Y,G,K): intercept-only null model
   const int c = (int)ncov + add_int;
@@ -305,16 +251,16 @@ int prepare(blmm_ctx* ctx, const blmm_opts* o, const double* dY, int64_t n, int6
   tm.mark();
   if ((rc = launch_design(ctx, dK, dCovar, (int)ncov, add_int, dweights, (int)n, ptr<double>(ctx->Ks), ptr<double>(ctx->Zs)))) return rc;
   const double* evec = ptr<double>(ctx->V);
-  // n <= 124: LDS Jacobi.  Beyond: the own tridiagonalisation + divide-and-conquer solver (kernels_eig.hip) up to the n
-  // its LDS-resident reduction takes (~1700 on a full MI355X); past that rocSOLVER dsyevd when librocsolver.so loads,
-  // else the single-workgroup global-memory Jacobi (slow: 0.74 s at n = 333).  BLMM_EIGEN = dc | rocsolver | jacobi
-  // overrides the choice (A/B timing and tests; "dc" also for n <= 124).
+  // n <= 124: LDS Jacobi.  Beyond: the own tridiagonalisation + divide-and-conquer solver (kernels_eig.hip) up to n = 2048 (its
+  // reduction keeps the matrix in LDS up to ~1450 and in L2-resident global memory beyond).  No vendor library: rocSOLVER's first
+  // use in a process takes MINUTES on this image (code-object load) and its path could not be part of the default test run.
+  // BLMM_EIGEN = dc | small | jacobi overrides the choice (A/B timing and tests; "dc" also for n <= 124; "jacobi" beyond 124 is the
+  // single-workgroup global-memory Jacobi: 0.74 s at n = 333).
   const char* eig_env = getenv("BLMM_EIGEN");
   const bool big = n > jacobi_lds_max_n();
   P.big = big;
-  bool used_rs = false, done = false;
+  bool done = false;
   const bool want_dc = eig_env ? std::strcmp(eig_env, "dc") == 0 : big;
-  const bool want_rs = eig_env ? std::strcmp(eig_env, "rocsolver") == 0 : false;
   const bool want_small = eig_env && std::strcmp(eig_env, "small") == 0;    // the fused single-workgroup solver (n <= 92)
   if (want_small && n >= 3 && n <= eig_small_max_n()) {
     rc = launch_eig_small(ctx, ptr<double>(ctx->Ks), (int)n, ptr<double>(ctx->lraw), ptr<double>(ctx->V), P.stat);
@@ -326,13 +272,7 @@ int prepare(blmm_ctx* ctx, const blmm_opts* o, const double* dY, int64_t n, int6
     if (rc == BLMM_OK) { done = true; P.big = true; }
     else if (rc != BLMM_ERR_UNSUPPORTED) return rc;
   }
-  if (!done && big && (want_rs || !eig_env || std::strcmp(eig_env, "dc") == 0) &&
-      eigen_rocsolver(ctx, ptr<double>(ctx->Ks), (int)n, ptr<double>(ctx->lraw), P.stat) == BLMM_OK) {
-    evec = ptr<double>(ctx->Ks);  // dsyevd leaves the eigenvectors in place of K
-    used_rs = true; done = true;
-  }
   if (!done) {
-    if (n > 2048) return fail(ctx, BLMM_ERR_UNSUPPORTED, "n > 2048 needs librocsolver.so for the eigen-decomposition");
     if ((rc = launch_jacobi(ctx, ptr<double>(ctx->Ks), ptr<double>(ctx->V), (int)n, ptr<double>(ctx->lraw), P.stat))) return rc;
   }
   if ((rc = launch_post_eigen(ctx, ptr<double>(ctx->lraw), evec, ptr<double>(ctx->Zs), dweights, (int)n, c,
@@ -353,14 +293,11 @@ int prepare(blmm_ctx* ctx, const blmm_opts* o, const double* dY, int64_t n, int6
     ctx->stream = main_stream;
     if (rc) return rc;
   }
-  // rocBLAS picks its GEMM kernel (tile shape, split-K) from the problem shape, so a trait's rotated column -- and through
-  // the flat likelihood its h2 at the 1e-8 level -- would depend on how many OTHER traits are in the call: that breaks the
-  // sharding contract (a column block scanned alone is bit-identical, tests/test_gpu_configs.py).  The own kernels sum
-  // every output element in a fixed order; BLMM_ROTATE=blas selects rocBLAS for A/B timing only.
-  const char* rot_env = getenv("BLMM_ROTATE");
-  const bool blas = used_rs && rot_env && std::strcmp(rot_env, "blas") == 0;
-  if ((rc = rotate_any(ctx, blas, ptr<double>(ctx->Rp), P.ldr, (int)n, P.npad, dY, m, P.Yt, P.ldy, P.ldy))) return rc;
-  if ((rc = rotate_any(ctx, blas, ptr<double>(ctx->Rp), P.ldr, (int)n, P.npad, dG, p, P.Xt, P.ldx, P.ldx))) return rc;
+  // The own rotation kernels sum every output element in a fixed order, so a trait's rotated column does not depend on how many
+  // OTHER traits are in the call (the sharding contract: a column block scanned alone is bit-identical, tests/test_gpu_configs.py;
+  // a vendor GEMM picks its kernel -- tile shape, split-K -- from the problem shape and broke exactly that in round 1).
+  if ((rc = launch_rotate(ctx, ptr<double>(ctx->Rp), P.ldr, (int)n, P.npad, dY, m, P.Yt, P.ldy, P.ldy))) return rc;
+  if ((rc = launch_rotate(ctx, ptr<double>(ctx->Rp), P.ldr, (int)n, P.npad, dG, p, P.Xt, P.ldx, P.ldx))) return rc;
   tm.mark();
   return BLMM_OK;
 }
@@ -677,7 +614,6 @@ void blmm_destroy(blmm_ctx* ctx) {
                     &ctx->wbQ, &ctx->wbW, &ctx->wbRk, &ctx->lrT, &ctx->lrC, &ctx->lrL, &ctx->lrFlag, &ctx->lrPart, &ctx->lrPerm, &ctx->lrDen0, &ctx->eigW, &ctx->xf32, &ctx->pf32, &ctx->brSt, &ctx->brList, &ctx->illList, &ctx->qrSlab, &ctx->lodtab};
   for (DevBuf* b : bufs) if (b->p) hipFree(b->p);
   for (auto& s : ctx->evsets) for (auto& e : s.e) (void)hipEventDestroy(e);
-  if (ctx->rb_handle && ctx->rb_destroy) ctx->rb_destroy(ctx->rb_handle);
   if (ctx->side) { (void)hipStreamSynchronize(ctx->side); (void)hipStreamDestroy(ctx->side); }
   if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
   if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);

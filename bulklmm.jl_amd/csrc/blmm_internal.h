@@ -50,13 +50,6 @@ struct blmm_ctx {
   struct EvSet { hipEvent_t e[8]; int n; };
   std::vector<EvSet> evsets;
   size_t ev_used = 0;
-  // rocSOLVER (dlopen'ed lazily; only used for the eigen-decomposition when n exceeds the LDS Jacobi's range)
-  void* rs_lib = nullptr; void* rb_lib = nullptr; void* rb_handle = nullptr; bool rs_tried = false;
-  int (*rb_destroy)(void*) = nullptr;
-  int (*rb_set_stream)(void*, hipStream_t) = nullptr;
-  int (*rs_dsyevd)(void*, int, int, int, double*, int, double*, double*, int*) = nullptr;
-  int (*rb_dgemm)(void*, int, int, int, int, int, const double*, const double*, int, const double*, int, const double*,
-                  double*, int) = nullptr;
   // side stream: work that only depends on the eigenvalues / rotated markers runs beside the per-trait Brent search
   hipStream_t side = nullptr, side2 = nullptr;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_xt = nullptr, ev_b1 = nullptr, ev_b2 = nullptr, ev_q = nullptr, ev_m = nullptr;

@@ -143,9 +143,14 @@ __global__ void __launch_bounds__(256) k_sytrd_prep(const double* __restrict__ A
 // step by themselves).  Buffers alternate by step parity (a workgroup can be at most one step ahead of the slowest: its
 // step k+1 payload needs everybody's step k payload); spins are bounded (abort word).
 // ---------------------------------------------------------------------------------------------------------------------
+// GLB: the workgroup's rows live in a slab of global memory (Aw: L2-resident, a workgroup only ever touches its own rows) instead
+// of LDS -- n beyond the LDS budget (~1450 on a full MI355X) up to the 2048 the rest of the solver takes.  Same algorithm, same
+// exchange; a step then re-reads the workgroup's rows from L2 (n = 2000, 10 rows: 160 KB per step).  A row is written by one
+// wave (the deferred update) and read by another a step later, with workgroup barriers in between.
+template <bool GLB>
 __global__ void __launch_bounds__(512) k_sytrd(const double* __restrict__ A, int n, int nloc_max, double* __restrict__ d,
                                                 double* __restrict__ e, double* __restrict__ tau, double* __restrict__ V,
-                                                SytrdEx ex, int64_t* stat) {
+                                                SytrdEx ex, int64_t* stat, double* Aw) {
   extern __shared__ __attribute__((aligned(16))) double sh[];
   const int G = gridDim.x, g = blockIdx.x, t = threadIdx.x, NT = blockDim.x;
   const int lane = t & 63, wave = t >> 6, nwave = NT >> 6;
@@ -157,7 +162,7 @@ __global__ void __launch_bounds__(512) k_sytrd(const double* __restrict__ A, int
   double* svp = swc + n;            // n : v of the pending (previous) step
   double* swp = svp + n;            // n : w of the pending step
   double* red = swp + n;            // 2 parities x 4 sums x 16 waves
-  double* Al = red + 128;           // nloc_max x n
+  double* Al = GLB ? Aw + (size_t)g * nloc_max * n : red + 128;   // nloc_max x n
   const int nloc = (n - g + G - 1) / G;
   for (int li = 0; li < nloc; ++li) {
     const int i = g + li * G;
@@ -1301,17 +1306,9 @@ __global__ void __launch_bounds__(1024) k_eig_small(const double* __restrict__ A
 
 }  // namespace
 
-// Largest n the solver takes on this device (LDS budget of k_sytrd with one workgroup per CU).
-int eig_dc_max_n(const blmm_ctx* ctx) {
-  const int cus = ctx->num_cus > 0 ? ctx->num_cus : 256;
-  int best = 0;
-  for (int n = 128; n <= 2048; n += 8) {
-    const int nloc = (n + cus - 1) / cus;
-    const size_t lds = sizeof(double) * ((size_t)7 * n + 128 + (size_t)nloc * n) + 64;
-    if (lds <= 156 * 1024) best = n;
-  }
-  return best;
-}
+// Largest n the solver takes: the back-transformation holds a column in 32 registers per lane of a wave (n <= 2048), and the
+// seven vectors of k_sytrd fit the LDS up to there; its rows move to global memory where the LDS budget ends (~1450).
+int eig_dc_max_n(const blmm_ctx*) { return 2048; }
 
 int eig_small_max_n() { return EIGS_NMAX; }
 
@@ -1390,34 +1387,42 @@ int launch_eig_dc(blmm_ctx* ctx, const double* A, int n, double* lraw, double* e
   // ---- 1. tridiagonalisation ----
   {
     const int cus = ctx->num_cus > 0 ? ctx->num_cus : 256;
-    // rows per workgroup: as many as the LDS takes beside the four vectors (fewer workgroups = a cheaper barrier)
+    // rows per workgroup: as many as the LDS takes beside the seven vectors (fewer workgroups = a cheaper barrier)
+    if (sizeof(double) * ((size_t)7 * n + 128) + 64 > 156 * 1024) return BLMM_ERR_UNSUPPORTED;
     const size_t budget = 156 * 1024 - sizeof(double) * ((size_t)7 * n + 128) - 64;
     int nloc = (int)(budget / (sizeof(double) * (size_t)n));
-    if (nloc < 1) return BLMM_ERR_UNSUPPORTED;
-    int G = (n + nloc - 1) / nloc;
-    if (G > cus) return BLMM_ERR_UNSUPPORTED;
+    int G = nloc >= 1 ? (n + nloc - 1) / nloc : cus + 1;
+    // the rows of a workgroup in global memory when the LDS cannot hold them with one workgroup per CU (BLMM_SYTRD_GLB=1: always)
+    const bool glb = G > cus || (getenv("BLMM_SYTRD_GLB") && getenv("BLMM_SYTRD_GLB")[0] == '1');
+    if (glb) G = 1;
     // ~10 rows per workgroup measured best (n = 500: 3.6 ms at G = 48 against 4.0 at the LDS minimum of 16; tools/sweep_sytrd.sh)
     const int Gmin = G;
     if ((n + 9) / 10 > G) G = std::min(cus, (n + 9) / 10);
     if (const char* ge = getenv("BLMM_SYTRD_G")) { const int gv = atoi(ge); if (gv >= Gmin && gv <= cus) G = gv; }
     nloc = (n + G - 1) / G;
-    const size_t lds = sizeof(double) * ((size_t)7 * n + 128 + (size_t)nloc * n);
+    const size_t lds = sizeof(double) * ((size_t)7 * n + 128 + (glb ? 0 : (size_t)nloc * n));
+    double* Aw = Qa;                          // G * nloc * n <= n^2 + G n doubles: the two Q buffers are unused until the leaves
     SytrdEx ex; ex.gr = reinterpret_cast<unsigned long long*>(rowbuf); ex.abort = sync;      // 8 n granules in Dm (unused until the merges)
     unsigned long long* parts = reinterpret_cast<unsigned long long*>(sync + ((n + 320 + 1) & ~1));   // 8-byte aligned (sync is)
     ex.anorm = parts;
     hipLaunchKernelGGL(k_sytrd_prep, dim3(ABSMAX_PARTS), dim3(256), 0, ctx->stream, A, (int64_t)n * n, parts, sync,
                        reinterpret_cast<unsigned long long*>(rowbuf), (int64_t)8 * n);           // tags 0: nothing published
-    BLMM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sytrd), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    BLMM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sytrd<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    BLMM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sytrd<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     int nthr = 512;                                           // barriers at 1024 threads cost almost twice as much
     if (const char* te = getenv("BLMM_SYTRD_NT")) { const int tv = atoi(te); if (tv == 256 || tv == 512) nthr = tv; }
+    auto launch = [&]() {
+      if (glb) hipLaunchKernelGGL(k_sytrd<true>, dim3(G), dim3(nthr), lds, ctx->stream, A, n, nloc, d, e, tau, V, ex, stat, Aw);
+      else hipLaunchKernelGGL(k_sytrd<false>, dim3(G), dim3(nthr), lds, ctx->stream, A, n, nloc, d, e, tau, V, ex, stat, Aw);
+    };
     if (G > 1) {
       GridKernelGuard gk(ctx);
       if (gk.rc) return gk.rc;
-      hipLaunchKernelGGL(k_sytrd, dim3(G), dim3(nthr), lds, ctx->stream, A, n, nloc, d, e, tau, V, ex, stat);
+      launch();
       KCHECK();
       if ((rc = gk.record())) return rc;
     } else {
-      hipLaunchKernelGGL(k_sytrd, dim3(G), dim3(nthr), lds, ctx->stream, A, n, nloc, d, e, tau, V, ex, stat);
+      launch();
       KCHECK();
     }
   }

@@ -430,7 +430,7 @@ def test_golden_fixture(blmm):
 
 @pytest.mark.parametrize("n", [130, 333])
 def test_larger_sample_sizes(blmm, n):
-    """n > 124: eigensolver outside the LDS Jacobi (global-memory Jacobi here, rocSOLVER with BLMM_TEST_ROCSOLVER=1), the
+    """n > 124: eigensolver outside the LDS Jacobi (the own tridiagonalisation + divide-and-conquer solver), the
     multi-workgroup weight basis and the wider lanes-per-trait Brent variants."""
     Y, G, K, _ = make_data(n=n, p=150, m=21, seed=500 + n, bxd=False)
     got = blmm.bulkscan_null(Y, G, K)
@@ -442,17 +442,36 @@ def test_larger_sample_sizes(blmm, n):
     assert_lod_close(gg.L, gr.L)
 
 
-@pytest.mark.skipif(not __import__("os").environ.get("BLMM_TEST_ROCSOLVER"),
-                    reason="rocSOLVER's first use in a process takes minutes on this image; set BLMM_TEST_ROCSOLVER=1")
-def test_rocsolver_eigen_path(blmm):
-    """n > 124 takes rocSOLVER dsyevd for the kinship eigen-decomposition (and rocBLAS dgemm for the rotation)."""
-    Y, G, K, _ = make_data(n=500, p=300, m=9, seed=77, bxd=False)   # p >= 256: the marker rotation goes through rocBLAS dgemm
+def test_own_eigensolver_up_to_2048_and_no_vendor_fallback(blmm, monkeypatch):
+    """Every n the library takes runs on its own eigensolver (round 2 fell back to rocSOLVER dsyevd beyond n ~ 1450: a vendor
+    path behind the default ABI whose first use takes minutes on this image and that no default test could reach).  Beyond
+    the LDS budget of the tridiagonalisation its rows live in L2-resident global memory (k_sytrd<GLB>): bit-identical to the
+    LDS form where both apply (forced with BLMM_SYTRD_GLB=1 at n = 300 and 700), accurate at n = 1500 and 2048, and
+    n = 2049 fails loudly."""
+    for n in (300, 700):
+        rng = np.random.default_rng(n)
+        K = kinship_of(make_geno(n, 2 * n, rng))
+        monkeypatch.delenv("BLMM_SYTRD_GLB", raising=False)
+        Y0, _, lam = blmm.transform_rotation(np.eye(n), np.ones((n, 2)), K)
+        monkeypatch.setenv("BLMM_SYTRD_GLB", "1")
+        Y0g, _, lamg = blmm.transform_rotation(np.eye(n), np.ones((n, 2)), K)
+        monkeypatch.delenv("BLMM_SYTRD_GLB")
+        assert np.array_equal(lam, lamg) and np.array_equal(Y0, Y0g), n
+    for n in (1500, 2048):
+        rng = np.random.default_rng(n)
+        K = kinship_of(make_geno(n, 800, rng))          # rank-deficient at n = 1500, 2048: a block of equal eigenvalues too
+        Y0, _, lam = blmm.transform_rotation(np.eye(n), np.ones((n, 2)), K)
+        U = Y0.T
+        assert np.abs(U.T @ U - np.eye(n)).max() <= 5e-12, n
+        assert np.abs((U * lam) @ U.T - K).max() <= 5e-13 * np.abs(K).max() * n, n
+        assert np.abs(np.sort(lam) - np.linalg.eigvalsh(K)).max() <= 1e-11 * np.abs(lam).max(), n
+    Y, G, K, _ = make_data(n=1500, p=130, m=5, seed=78, bxd=False)
     got = blmm.bulkscan_null(Y, G, K)
     check_null_exact(got, Y, G, K)
-    # n = 1100: the multi-workgroup weight basis with 8 sample columns per workgroup (32 workgroups), 64 lanes per trait
-    Y, G, K, _ = make_data(n=1100, p=260, m=5, seed=78, bxd=False)
-    got = blmm.bulkscan_null(Y, G, K)
-    check_null_exact(got, Y, G, K)
+    n = 2049
+    with pytest.raises(blmm.BulkLMMError) as e:
+        blmm.transform_rotation(np.eye(n)[:, :2], np.ones((n, 2)), np.eye(n))
+    assert "2048" in e.value.msg
 
 
 @pytest.mark.parametrize("n,bxd", [(79, True), (64, False), (93, False), (124, False), (130, False)])
