@@ -5,11 +5,14 @@
 #     using BulkLMMHIP: bulkscan, bulkscan_null, bulkscan_null_grid, bulkscan_alt_grid, scan, calcKinship
 # is a drop-in for `using BulkLMM` on that path.  NOTE: there is no Julia in the build container, so THIS FILE HAS NEVER
 # BEEN EXECUTED; it is the binding a maintainer adds (INTEGRATION.md) and mirrors bulklmm.jl_amd/api.py (the ctypes host
-# that IS tested) 1:1.  tests/test_binding_kwargs.py checks, as text, that every keyword of the reference's signatures is
-# accepted here and in api.py.
+# that IS tested) 1:1.  What can be checked without Julia is checked as TEXT by tests/test_binding_kwargs.py: every keyword of
+# the reference's signatures is accepted here and in api.py; the fields of BlmmOpts / BlmmStatus / BlmmMultiOpts (names, types,
+# order, and through them offsets and sizes, against `offsetof` / `sizeof` printed by a C program compiled from the header);
+# every `ccall`'s symbol, return type and argument tuple (arity and types) against the prototype in include/bulklmm_hip.h.
 module BulkLMMHIP
 
-export calcKinship, bulkscan, bulkscan_null, bulkscan_null_grid, bulkscan_alt_grid, scan, bulkscan_multi, lod2log10p, get_thresholds
+export calcKinship, bulkscan, bulkscan_null, bulkscan_null_grid, bulkscan_alt_grid, scan, bulkscan_multi, lod2log10p, get_thresholds,
+       lod_threshold, lod_colmax, pinned_matrix, host_register, host_unregister
 
 const libblmm = get(ENV, "BULKLMM_HIP_LIB", joinpath(@__DIR__, "..", "csrc", "libbulklmm_hip.so"))
 
@@ -24,7 +27,8 @@ mutable struct BlmmStatus  # include/bulklmm_hip.h: blmm_status
     n_brent_maxiter::Int64; jacobi_sweeps::Int64; jacobi_cycles::Int64; jacobi_ticks_100mhz::Int64
     lowrank_rank::Int64; lowrank_fallback::Int64; lowrank_shared::Int64; lowrank_resid::Float64
     t_eigen_ms::Float64; t_rotate_ms::Float64; t_h2_ms::Float64; t_prep_ms::Float64; t_scan_ms::Float64; t_total_ms::Float64
-    BlmmStatus() = new(0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0)
+    n_h2_boundary::Int64; n_h2_multimodal::Int64; n_illcond_rescan::Int64
+    BlmmStatus() = new(0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0, 0, 0)
 end
 
 const NULL_EXACT, NULL_GRID, ALT_GRID = Int32(0), Int32(1), Int32(2)
@@ -42,7 +46,7 @@ end
 
 check(rc) = rc == 0 || error(unsafe_string(ccall((:blmm_last_error, libblmm), Cstring, (Ptr{Cvoid},), context())))
 
-function raise_status(st::BlmmStatus)
+function raise_status(st)   # BlmmStatus, or one element of the per-device Vector of bulkscan_multi
     st.n_neg_eig > 0 && @warn "Negative eigenvalues exist. The kinship matrix supplied may not be SPD."   # src/transform_helpers.jl:29
     st.n_nonpos_weight > 0 && @warn "Some weights are not positive."                                      # src/wls.jl:36
     st.n_zero_norm > 0 && error("Dividing by zeros: the input vector can not contain any zeros!")         # src/util.jl:70
@@ -63,7 +67,9 @@ function _bulkscan(method::Int32, Y::Array{Float64, 2}, G::Array{Float64, 2}, Co
                    addIntercept::Bool, weights, prior_variance::Float64, prior_sample_size::Float64, reml::Bool,
                    optim_interval::Int64, decomp_scheme::String)
     (n, m) = size(Y); p = size(G, 2)
-    (size(G, 1) != n || size(K, 1) != n) && error("Dimension mismatch.")
+    (size(G, 1) != n || size(K, 1) != n || size(K, 2) != n) && error("Dimension mismatch.")   # src/transform_helpers.jl:9-11
+    (Covar !== nothing && size(Covar, 1) != n) && error("Dimension mismatch.")
+    (weights !== missing && length(weights) != n) && error("Dimension mismatch.")
     ncov = Covar === nothing ? 0 : size(Covar, 2)
     o = BlmmOpts(method, reml, Covar === nothing ? true : addIntercept, decomp(decomp_scheme), optim_interval, 0,
                  prior_variance, prior_sample_size)
@@ -199,13 +205,19 @@ end
 # ---- several GPUs of one node in ONE call (blmm_bulkscan_multi): the trait blocks the reference deals to its threads
 # (src/bulkscan.jl:263-309) go to the devices; gather = :host_shards (default) | :none | :allgather
 const _mctx = Ref{Ptr{Cvoid}}(C_NULL)
+const _mctx_devices = Ref{Vector{Int32}}(Int32[])
 function multi_context(devices::Vector{Int32} = Int32[])
+    if _mctx[] != C_NULL && _mctx_devices[] != devices      # a different device list: a new context (the old one is released)
+        ccall((:blmm_destroy_multi, libblmm), Cvoid, (Ptr{Cvoid},), _mctx[])
+        _mctx[] = C_NULL
+    end
     if _mctx[] == C_NULL
         h = Ref{Ptr{Cvoid}}(C_NULL)
-        rc = ccall((:blmm_create_multi, libblmm), Cint, (Ptr{Int32}, Cint, Ref{Ptr{Cvoid}}),
-                   isempty(devices) ? C_NULL : pointer(devices), length(devices), h)
+        rc = GC.@preserve devices ccall((:blmm_create_multi, libblmm), Cint, (Ptr{Int32}, Cint, Ref{Ptr{Cvoid}}),
+                                        isempty(devices) ? Ptr{Int32}(C_NULL) : pointer(devices), length(devices), h)
         rc == 0 || error(unsafe_string(ccall((:blmm_err_string, libblmm), Cstring, (Cint,), rc)))
         _mctx[] = h[]
+        _mctx_devices[] = copy(devices)
     end
     return _mctx[]
 end
@@ -219,24 +231,32 @@ function bulkscan_multi(Y::Array{Float64, 2}, G::Array{Float64, 2}, K::Array{Flo
     meth = method == "null-exact" ? NULL_EXACT : method == "null-grid" ? NULL_GRID : method == "alt-grid" ? ALT_GRID :
            error("Unknown method `$method`; choose null-exact, null-grid or alt-grid.")
     (n, m) = size(Y); p = size(G, 2)
-    (size(G, 1) != n || size(K, 1) != n) && error("Dimension mismatch.")
+    (size(G, 1) != n || size(K, 1) != n || size(K, 2) != n) && error("Dimension mismatch.")
+    (weights !== missing && length(weights) != n) && error("Dimension mismatch.")
     o = BlmmOpts(meth, reml, true, decomp(decomp_scheme), optim_interval, 0, prior_variance, prior_sample_size)
     mo = BlmmMultiOpts(gather == :none ? 0 : gather == :allgather ? 2 : 1, 0)
     L = Array{Float64, 2}(undef, p, m)
     h2 = meth == ALT_GRID ? Array{Float64, 2}(undef, p, m) : Array{Float64, 1}(undef, m)
     mc = multi_context(devices)
-    GC.@preserve Y G K weights h2_grid L h2 begin
+    ndev = ccall((:blmm_multi_ndev, libblmm), Cint, (Ptr{Cvoid},), mc)
+    sts = [BlmmStatus() for _ in 1:ndev]                 # one status per device: the warnings / errors of every shard are raised
+    stbuf = Vector{UInt8}(undef, ndev * sizeof(BlmmStatus))
+    GC.@preserve Y G K weights h2_grid L h2 stbuf begin
         rc = ccall((:blmm_bulkscan_multi, libblmm), Cint,
                    (Ptr{Cvoid}, Ref{BlmmOpts}, Ref{BlmmMultiOpts}, Ptr{Float64}, Int64, Int64, Ptr{Float64}, Int64, Ptr{Float64}, Int64,
                     Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Int64, Ptr{Float64}, Ptr{Float64}, Ptr{Cvoid}),
-                   mc, o, mo, Y, n, m, G, p, C_NULL, 0, K, ptr_or_null(weights), h2_grid, length(h2_grid), L, h2, C_NULL)
+                   mc, o, mo, Y, n, m, G, p, C_NULL, 0, K, ptr_or_null(weights), h2_grid, length(h2_grid), L, h2, pointer(stbuf))
         rc == 0 || error(unsafe_string(ccall((:blmm_multi_last_error, libblmm), Cstring, (Ptr{Cvoid},), mc)))
+        for r in 1:ndev
+            sts[r] = unsafe_load(Ptr{BlmmStatus}(pointer(stbuf)) , r)
+        end
     end
+    foreach(raise_status, sts)
     return meth == ALT_GRID ? (L = L, h2_panel = h2) : (L = L, h2_null_list = h2)
 end
 
 # ---- scan: the reference's four methods (src/scan.jl:94-120, 122-148, 150-180, 182-271).  On the GPU path:
-#   assumption = "null" only (scan_alt's per-marker Brent stays on the CPU reference: SURVEY.md §8(a) A19);
+#   assumption = "null" and "alt" (scan_alt, src/scan.jl:397-453: one Brent search per marker on the device, blmm_scan_alt);
 #   method ("qr" / "cholesky") selects a CPU factorisation and has no meaning here: accepted, ignored;
 #   profileLL = true (profile_LL of src/analysis_helpers) is not part of this path: a clear error.
 function scan(y::Array{Float64, 1}, g::Array{Float64, 2}, K::Array{Float64, 2};
@@ -299,7 +319,8 @@ function scan(y::Array{Float64, 2}, g::Array{Float64, 2}, covar::Array{Float64, 
     profileLL && error("profileLL = true (profile_LL) is not part of the GPU path; call BulkLMM.scan for it")
     size(y, 2) == 1 || error("Can only handle one trait.")                                   # src/scan.jl:496-498
     n = size(y, 1); p = size(g, 2)
-    (size(g, 1) != n || size(K, 1) != n || size(covar, 1) != n) && error("Dimension mismatch.")
+    (size(g, 1) != n || size(K, 1) != n || size(K, 2) != n || size(covar, 1) != n) && error("Dimension mismatch.")
+    (weights !== missing && length(weights) != n) && error("Dimension mismatch.")
     np = permutation_test ? nperms : 0
     np < 0 && error("The required number of permutations must be a positive integer.")
     perm_precision in ("f64", "f32") || error("perm_precision must be \"f64\" or \"f32\".")
@@ -350,6 +371,46 @@ function get_thresholds(L_perms::Array{Float64, 2}, signif_level::Array{Float64,
         context(), L_perms, size(L_perms, 1), size(L_perms, 2), probs, length(probs), thrs))
     return (probs = probs, thrs = thrs)
 end
+
+# ---- on-device consumers of L (README.md:246-255, 354-359) -------------------------------------------------------------
+# (marker, trait, LOD) of every LOD > thr, 1-based like findall(L .> thr): the filter behind plot_eQTL(...; threshold)
+function lod_threshold(L::Array{Float64, 2}, thr::Float64; cap::Int64 = max(1024, length(L) ÷ 64))
+    (p, m) = size(L)
+    while true
+        ii = Vector{Int32}(undef, cap); jj = Vector{Int32}(undef, cap); ll = Vector{Float64}(undef, cap)
+        cnt = Ref{Int64}(0)
+        GC.@preserve L ii jj ll check(ccall((:blmm_lod_threshold, libblmm), Cint,
+            (Ptr{Cvoid}, Ptr{Float64}, Int64, Int64, Float64, Int64, Ptr{Int32}, Ptr{Int32}, Ptr{Float64}, Ref{Int64}),
+            context(), L, p, m, thr, cap, ii, jj, ll, cnt))
+        if cnt[] <= cap
+            k = cnt[]
+            ord = sortperm(collect(zip(jj[1:k], ii[1:k])))
+            return (marker = Int.(ii[1:k][ord]) .+ 1, trait = Int.(jj[1:k][ord]) .+ 1, lod = ll[1:k][ord])
+        end
+        cap = cnt[]
+    end
+end
+# per-column maximum of an LOD matrix and the (1-based) marker where it sits
+function lod_colmax(L::Array{Float64, 2})
+    (p, m) = size(L)
+    mx = Vector{Float64}(undef, m); arg = Vector{Int64}(undef, m)
+    GC.@preserve L mx arg check(ccall((:blmm_lod_colmax, libblmm), Cint,
+        (Ptr{Cvoid}, Ptr{Float64}, Int64, Int64, Ptr{Float64}, Ptr{Int64}), context(), L, p, m, mx, arg))
+    return (max = mx, argmax = arg .+ 1)
+end
+
+# ---- pinned host memory for the outputs: L (2.08 GB at BXD size) then crosses the PCIe link in one asynchronous copy at link rate
+# (42 ms against 52 ms into pageable memory).  pinned_matrix wraps blmm_host_alloc memory (released by the finalizer);
+# host_register pins the pages of an Array the caller already has.
+function pinned_matrix(p::Integer, m::Integer)
+    ptr = ccall((:blmm_host_alloc, libblmm), Ptr{Cvoid}, (UInt64,), UInt64(8 * p * m))
+    ptr == C_NULL && error("blmm_host_alloc failed")
+    A = unsafe_wrap(Array, Ptr{Float64}(ptr), (Int(p), Int(m)); own = false)
+    finalizer(_ -> ccall((:blmm_host_free, libblmm), Cvoid, (Ptr{Cvoid},), ptr), A)
+    return A
+end
+host_register(A::Array{Float64}) = (ccall((:blmm_host_register, libblmm), Cint, (Ptr{Cvoid}, UInt64), A, UInt64(sizeof(A))) == 0 || error("hipHostRegister failed"); A)
+host_unregister(A::Array{Float64}) = (ccall((:blmm_host_unregister, libblmm), Cint, (Ptr{Cvoid},), A); nothing)
 
 # Readers (src/readData.jl:41-96, 159-165): the numeric table is parsed by the library's host code and copied into a Julia array
 check_io(rc) = rc == 0 || error("could not read the file: " * unsafe_string(ccall((:blmm_err_string, libblmm), Cstring, (Cint,), rc)))
