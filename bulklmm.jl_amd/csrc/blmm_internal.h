@@ -12,10 +12,11 @@ namespace blmm {
 typedef double d2 __attribute__((ext_vector_type(2)));
 typedef double d4 __attribute__((ext_vector_type(4)));
 
-constexpr int CMAX = 8;          // null covariates (incl. intercept) the kernels are instantiated for
+constexpr int CMAX = 32;         // null covariates (incl. intercept) the library takes: 1 .. CTPL through kernels that are templates over c,
+constexpr int CTPL = 8;          // CTPL + 1 .. CMAX through the run-time-c kernels of kernels_dyn.hip (the reference has no cap: src/wls.jl:27-60)
 constexpr int CFAST = 4;         // ... with the tuned forms (LDS-resident evaluators, single-pass exact scan); beyond: the generic evaluators and a covariate-chunked scan
-#define BLMM_C_ERR "number of null covariates (incl. intercept) must be 1..8"
-// one `case C: M(C); break;` per instantiated covariate count
+#define BLMM_C_ERR "number of null covariates (incl. intercept) must be 1..32"
+// one `case C: M(C); break;` per instantiated covariate count (1 .. CTPL)
 #define BLMM_FOR_EACH_C(M) \
   case 1: M(1); break; case 2: M(2); break; case 3: M(3); break; case 4: M(4); break; \
   case 5: M(5); break; case 6: M(6); break; case 7: M(7); break; case 8: M(8); break;
@@ -45,7 +46,7 @@ struct blmm_ctx {
   std::string err;
   // grow-only workspace
   blmm::DevBuf Ks, V, lam, U, Zs, Z0, Rp, Yt, Xt, panels, iyy, h2, h2idx, sig2, ell, isx, stat, gridd, misc, EllTab,
-      inY, inG, inK, inCov, inW, outL, outH2, tmpA, tmpB, tmpC, perm, r0, altbuf, logtab, lraw, wbQ, wbW, wbRk, lrT, lrC, lrL, lrFlag, lrPart, lrPerm, lrDen0, eigW, xf32, pf32, brSt, brList, illList, qrSlab, lodtab;
+      inY, inG, inK, inCov, inW, outL, outH2, tmpA, tmpB, tmpC, perm, r0, altbuf, logtab, lraw, wbQ, wbW, wbRk, lrT, lrC, lrL, lrFlag, lrPart, lrPerm, lrDen0, eigW, xf32, pf32, brSt, brList, illList, qrSlab, lodtab, dynFac;
   // event sets: one per timed call since the last blmm_read_timings (grown on demand, reused afterwards)
   struct EvSet { hipEvent_t e[8]; int n; };
   std::vector<EvSet> evsets;
@@ -225,6 +226,18 @@ int launch_cvt_f32(blmm_ctx* ctx, const double* M, int64_t ld_in, int rows_valid
                    int64_t ld_out, int kblocks);
 int launch_scan_f32(blmm_ctx* ctx, const float* XF, int64_t ldxf, const float* PF, int64_t ldpf, int npad, int n,
                     int64_t p, int64_t m, const double* isx, float* L, int64_t ldL, int64_t* stat);
+// kernels_dyn.hip: run-time covariate counts (c = CTPL + 1 .. CMAX): the counterparts of launch_brent / launch_loglik_grid /
+// launch_panels / launch_isx / launch_perm_panel, which route there
+int launch_dyn_brent(blmm_ctx* ctx, const NullModel& nm, const double* Yt, int64_t ldy, int64_t m, const double* Z0, const double* lam,
+                     double* h2, double* sigma2, double* ell, int64_t* stat);
+int launch_dyn_loglik_grid(blmm_ctx* ctx, const NullModel& nm, const double* Yt, int64_t ldy, int64_t m, const double* Z0,
+                           const double* lam, const double* grid_dev, int ngrid, double* EllTab, int* h2idx, double* h2, int64_t* stat);
+int launch_dyn_panels(blmm_ctx* ctx, const NullModel& nm, const double* Yt, int64_t ldy, int64_t m, const double* Z0, const double* lam,
+                      const double* h2, int full, double* panels, int64_t ldp, int64_t* stat);
+int launch_dyn_isx(blmm_ctx* ctx, const NullModel& nm, const double* Xt, int64_t ldx, int64_t p, const double* Z0, const double* lam,
+                   const double* grid_dev, int ngrid, double* isx, int64_t ld_isx, int64_t* stat);
+int launch_dyn_perm(blmm_ctx* ctx, const NullModel& nm, const double* Yt, int64_t ldy, const double* Z0, const double* lam, const double* h2,
+                    const int32_t* perm, int64_t ncols, int orig, double* r0, double* panel, int64_t ldp, int64_t* stat);
 // kernels_dyn.hip: conditioning guard of the null-exact scan (c >= 2) and the QR-grade re-scan of the flagged traits
 int launch_illcond_flag(blmm_ctx* ctx, const NullModel& nm, int64_t m, const double* Z0, const double* lam, const double* h2,
                         int* list, int64_t* stat);

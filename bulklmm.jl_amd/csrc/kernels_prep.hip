@@ -582,7 +582,7 @@ __global__ void __launch_bounds__(1024) k_post_eigen(const double* __restrict__ 
   __syncthreads();
   if (tid == 0) {
     // Gram = Z0'Z0, inverse by Gauss-Jordan (c <= CMAX)
-    double G[CMAX][2 * CMAX];
+    __shared__ double G[CMAX][2 * CMAX];        // (LDS: 16 KB at CMAX = 32 -- as a local array it would be scratch memory of every thread)
     for (int a = 0; a < c; ++a)
       for (int b = 0; b < c; ++b) {
         double s = 0;
@@ -700,7 +700,7 @@ __global__ void __launch_bounds__(256) k_pe_bq(const double* __restrict__ Z0, co
   }
   __syncthreads();
   if (t == 0) {
-    double G[CMAX][2 * CMAX];
+    __shared__ double G[CMAX][2 * CMAX];        // (LDS: 16 KB at CMAX = 32 -- as a local array it would be scratch memory of every thread)
     for (int a = 0; a < c; ++a)
       for (int b = 0; b < c; ++b) {
         const int ab = a * c + b;
@@ -1685,6 +1685,10 @@ static int launch_brent_c(blmm_ctx* ctx, const NullModel& nm, const double* Yt, 
 
 int launch_brent(blmm_ctx* ctx, const NullModel& nm, const double* Yt, int64_t ldy, int64_t m, const double* Z0,
                  const double* lam, double* h2, double* sigma2, double* ell, int64_t* stat, int phase, BrentSplit* sp) {
+  if (nm.c > CTPL && nm.c <= CMAX) {       // run-time covariate count: one kernel, never split
+    if (sp) sp->active = false;
+    return phase == 2 ? BLMM_OK : launch_dyn_brent(ctx, nm, Yt, ldy, m, Z0, lam, h2, sigma2, ell, stat);
+  }
   switch (nm.c) {
     case 1: return launch_brent_c<1>(ctx, nm, Yt, ldy, m, Z0, lam, h2, sigma2, ell, stat, phase, sp);
     case 2: return launch_brent_c<2>(ctx, nm, Yt, ldy, m, Z0, lam, h2, sigma2, ell, stat, phase, sp);
@@ -1852,7 +1856,7 @@ int launch_alt_brent(blmm_ctx* ctx, const NullModel& nm, const double* Yt, int64
 #undef AG
   }
 #undef AB
-  return fail(ctx, BLMM_ERR_UNSUPPORTED, BLMM_C_ERR);
+  return fail(ctx, BLMM_ERR_UNSUPPORTED, "scan(...; assumption = \"alt\"): at most 8 null covariates (incl. intercept) -- the per-marker search has no run-time-c form");
 }
 
 // Ell[g, j] = wls_multivar(Y0, Z0, makeweights(grid[g]), prior).Ell  (src/bulkscan_helpers.jl:267-269),
@@ -1957,6 +1961,7 @@ static int launch_loglik_grid_c(blmm_ctx* ctx, const NullModel& nm, const double
 int launch_loglik_grid(blmm_ctx* ctx, const NullModel& nm, const double* Yt, int64_t ldy, int64_t m, const double* Z0,
                        const double* lam, const double* grid_dev, int ngrid, double* EllTab, int* h2idx, double* h2,
                        int64_t* stat) {
+  if (nm.c > CTPL && nm.c <= CMAX) return launch_dyn_loglik_grid(ctx, nm, Yt, ldy, m, Z0, lam, grid_dev, ngrid, EllTab, h2idx, h2, stat);
   static const char* gen_env = getenv("BLMM_LOGLIK_GENERIC");   // "1": the generic evaluator for every n (A/B testing)
   if (!(gen_env && gen_env[0] == '1')) {
     bool done = false;
@@ -2130,6 +2135,7 @@ __global__ void __launch_bounds__(256) k_panels(NullModel nm, const double* __re
 
 int launch_panels(blmm_ctx* ctx, const NullModel& nm, const double* Yt, int64_t ldy, int64_t m, const double* Z0,
                   const double* lam, const double* h2, int full, double* panels, int64_t ldp, int64_t* stat) {
+  if (nm.c > CTPL && nm.c <= CMAX) return launch_dyn_panels(ctx, nm, Yt, ldy, m, Z0, lam, h2, full, panels, ldp, stat);
   const unsigned blocks = (unsigned)((ldp + 255) / 256);
   const size_t lds = sizeof(double) * (size_t)nm.n * (1 + nm.c);
 #define PN(C) hipLaunchKernelGGL(k_panels<C>, dim3(blocks), dim3(256), lds, ctx->stream, nm, Yt, ldy, m, Z0, lam, h2, full, panels, ldp, stat)
@@ -2217,6 +2223,7 @@ __global__ void __launch_bounds__(256) k_isx(NullModel nm, const double* __restr
 
 int launch_isx(blmm_ctx* ctx, const NullModel& nm, const double* Xt, int64_t ldx, int64_t p, const double* Z0,
                const double* lam, const double* grid_dev, int ngrid, double* isx, int64_t ld_isx, int64_t* stat) {
+  if (nm.c > CTPL && nm.c <= CMAX) return launch_dyn_isx(ctx, nm, Xt, ldx, p, Z0, lam, grid_dev, ngrid, isx, ld_isx, stat);
   dim3 grid((unsigned)((ld_isx + 255) / 256), (unsigned)ngrid);
   const size_t lds = sizeof(double) * (size_t)nm.n * (1 + nm.c);
 #define IX(C) hipLaunchKernelGGL(k_isx<C>, grid, dim3(256), lds, ctx->stream, nm, Xt, ldx, p, Z0, lam, grid_dev, isx, ld_isx, stat)
@@ -2597,6 +2604,22 @@ int launch_perm_panel(blmm_ctx* ctx, const NullModel& nm, const double* Yt, int6
     permbuf = ptr<int32_t>(ctx->perm);
   }
   double* r0 = ptr<double>(ctx->r0);
+  if (nm.c > CTPL && nm.c <= CMAX) {
+    // run-time covariate count (kernels_dyn.hip): permutations from the same generator (k_perm_gen), one wave per column
+    if (nm.n > 65535) return fail(ctx, BLMM_ERR_UNSUPPORTED, "permutation test: n > 65535");
+    const int64_t ncols = orig ? 1 : nperms;
+    const int32_t* pidx = perm_idx;
+    if (!orig && !perm_idx && nperms > 0) {
+      int cols = (int)std::min<size_t>(64, (150 * 1024) / (sizeof(unsigned short) * (size_t)nm.n));
+      if (cols < 1) cols = 1;
+      const size_t lds = sizeof(unsigned short) * (size_t)nm.n * cols;
+      BLMM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_perm_gen), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      hipLaunchKernelGGL(k_perm_gen, dim3((unsigned)((nperms + cols - 1) / cols)), dim3(64), lds, ctx->stream, nm.n, nperms, seed, cols, permbuf);
+      KCHECK();
+      pidx = permbuf;
+    }
+    return launch_dyn_perm(ctx, nm, Yt, ldy, Z0, lam, h2, pidx, ncols, orig, r0, panel, ldp, stat);
+  }
   // large n: the multi-kernel form (BLMM_PERM_PATH=old|new forces one; read per call so that a test can compare them)
   const char* path_env = getenv("BLMM_PERM_PATH");
   const bool newpath = path_env ? std::strcmp(path_env, "new") == 0 : nm.n > 256;

@@ -370,8 +370,7 @@ int launch_scan_exact(blmm_ctx* ctx, const ScanArgs& a, int c) {
   switch (c) {
     // accumulators per lane: (2 + c) * MB * 4 blocks * 8 VGPRs; MB = 1 beyond c = 1 keeps 2 waves/SIMD spill-free
     case 1: {
-      static const int w1 = getenv("BLMM_SCAN_W1") ? atoi(getenv("BLMM_SCAN_W1")) : 0;
-      return w1 ? launch_scan_t<2, false, 2, 1>(ctx, a) : launch_scan_t<2, false, 2, 2>(ctx, a);
+      return launch_scan_t<2, false, 2, 2>(ctx, a);
     }
     case 2: return launch_scan_t<3, false, 1>(ctx, a);
     case 3: return launch_scan_t<4, false, 1>(ctx, a);

@@ -963,16 +963,58 @@ def test_many_covariates_every_method(blmm, ncov):
     assert_lod_close(sp["L_perms"], pin["L_perms"])
 
 
-def test_many_covariates_larger_n_and_the_cap(blmm):
-    """n = 300 (lanes loop over the individuals in the generic evaluators; own tridiagonal eigensolver), c = 6; c = 9 fails
-    loudly with the library's message."""
+def test_many_covariates_larger_n(blmm):
+    """n = 300 (lanes loop over the individuals in the generic evaluators; own tridiagonal eigensolver), c = 6."""
     Y, G, K, Cov = make_data(n=300, p=150, m=21, seed=7100, ncov=5, bxd=False)
     got = blmm.bulkscan_null(Y, G, K, Cov)
     check_null_exact(got, Y, G, K, Cov)
-    Y, G, K, Cov = make_data(p=20, m=3, seed=7101, ncov=8)
+
+
+@pytest.mark.parametrize("ncov,n", [(8, 79), (11, 79), (31, 79), (13, 200)])
+def test_runtime_covariate_counts_every_method(blmm, ncov, n):
+    """The reference has no cap on the null covariates (src/wls.jl:27-60, src/bulkscan_helpers.jl:187-193); beyond the 8 the
+    template kernels are instantiated for, c = 9 .. 32 runs through the run-time-c kernels of kernels_dyn.hip (normal
+    equations, Cholesky factor and its inverse in LDS) feeding the SAME scan kernels: null-exact (covariate-chunked exact scan),
+    null-grid, alt-grid, scan() with the permutation test, REML and sub-intervals; c = 33 fails loudly."""
+    Y, G, K, Cov = make_data(n=n, p=197, m=23, seed=7200 + ncov, ncov=ncov, bxd=(n == 79))
+    got = blmm.bulkscan_null(Y, G, K, Cov)
+    check_null_exact(got, Y, G, K, Cov)
+    rm = blmm.bulkscan_null(Y[:, :5], G, K, Cov, reml=True, optim_interval=3)
+    check_null_exact(rm, Y[:, :5], G, K, Cov, reml=True, optim_interval=3)
+    grid = [i / 10.0 for i in range(10)]
+    gg = blmm.bulkscan_null_grid(Y, G, K, grid, Cov, prior_variance=1.0, prior_sample_size=0.1)
+    gr = O.bulkscan_null_grid(Y, G, K, grid, Covar=Cov, prior_variance=1.0, prior_sample_size=0.1)
+    assert np.array_equal(gg.h2_null_list, gr.h2_null_list)
+    assert_lod_close(gg.L, gr.L)
+    ag = blmm.bulkscan_alt_grid(Y[:, :7], G, K, grid, Cov)
+    ar, atab = O.bulkscan_alt_grid(Y[:, :7], G, K, grid, Covar=Cov, return_tables=True)
+    assert_lod_close(ag.L, ar.L, atol=1e-9)
+    assert assert_h2_panel_ties_only(ag.h2_panel, ar.h2_panel, atab, grid) <= 1e-3 * ar.h2_panel.size
+    y = Y[:, 0]
+    nperms = 19
+    pidx = O.make_perm_idx(n, nperms, 5)
+    sp = blmm.scan(y, G, K, Cov, permutation_test=True, nperms=nperms, perm_idx=pidx)
+    cov1 = np.hstack([np.ones((n, 1)), Cov])
+    rot = blmm.transform_rotation(Y, np.hstack([cov1, G]), K, addIntercept=False)
+    pin = O.scan(y, G, K, covar=cov1, addIntercept=False, permutation_test=True, nperms=nperms, perm_idx=pidx,
+                 h2_override=sp["h2_null"], rotation_override=rot)
+    own = O.scan(y, G, K, covar=Cov)
+    assert abs(sp["h2_null"] - own["h2_null"]) <= 1e-6 and abs(sp["sigma2_e"] - own["sigma2_e"]) <= 1e-6 * own["sigma2_e"]
+    assert_lod_close(sp["lod"], pin["lod"])
+    assert_lod_close(sp["L_perms"], pin["L_perms"])
+    own_rng = blmm.scan(y, G, K, Cov, permutation_test=True, nperms=5, rndseed=3)       # the library's own generator
+    assert own_rng["L_perms"].shape == (G.shape[1], 5) and np.isfinite(own_rng["L_perms"]).all()
+
+
+def test_covariate_cap_is_32_and_fails_loudly(blmm):
+    Y, G, K, Cov = make_data(p=20, m=3, seed=7101, ncov=32)
     with pytest.raises(blmm.BulkLMMError) as e:
         blmm.bulkscan_null(Y, G, K, Cov)
-    assert "1..8" in e.value.msg
+    assert "1..32" in e.value.msg
+    Y, G, K, Cov = make_data(p=20, m=3, seed=7102, ncov=9)
+    with pytest.raises(blmm.BulkLMMError) as e:
+        blmm.scan(Y[:, 0], G, K, Cov, assumption="alt")
+    assert "at most 8" in e.value.msg
 
 
 @pytest.mark.parametrize("n", [130, 333, 700])
