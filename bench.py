@@ -219,11 +219,27 @@ def main():
                 self.dy1 = self.dY[0].contiguous()
                 self.dsc = torch.empty(2, dtype=torch.float64, device=dev)
                 self.dlod = torch.empty(p, dtype=torch.float64, device=dev)
+            # N > 1 and n >= 256: the marker rotation is SHARDED over the ranks (blmm_prepare_dev / blmm_rotate_block_dev, an
+            # all-gather of the k-major blocks over xGMI, blmm_bulkscan_prerotated_dev) instead of repeated by every rank; at
+            # n = 79 the whole rotation is 15 us and the replicated form is the faster one.  This all-gather is a data-path
+            # collective INSIDE the step.
+            self.shard_rot = shard_rotation and not perms
+            if self.shard_rot:
+                self.bc = -(-p // world)
+                rows = -(-n // 8) * 8
+                self.gx = torch.zeros((world, rows, -(-self.bc // 128) * 128), dtype=torch.float64, device=dev)
+                self.gblk = dG[rank * self.bc: min(p, (rank + 1) * self.bc)]
 
         def scan(self, c=None, L=None, H=None):
             c = c or ctx; L = self.dL if L is None else L; H = self.dH if H is None else H
             if perms:
                 B.scan_perms_dev(c, self.dy1, dG, dK, self.dsc, self.dlod, L, nperms=self.m, seed=1 + rank)
+            elif self.shard_rot:
+                B.prepare_dev(c, dK)
+                if self.gblk.shape[0] > 0:
+                    B.rotate_block_dev(c, self.gblk, self.gx[rank])
+                dist.all_gather_into_tensor(self.gx.view(-1), self.gx[rank].reshape(-1))
+                B.bulkscan_prerotated_dev(c, self.dY, self.gx, p, self.bc, L, H, method=a.method, h2_grid=grid)
             else:
                 B.bulkscan_dev(c, self.dY, dG, dK, L, H, method=a.method, h2_grid=grid)
 
@@ -231,6 +247,7 @@ def main():
             if self.full is not None and backend == "nccl":
                 dist.all_gather_into_tensor(self.full.view(-1), self.full[rank].reshape(-1))
 
+    shard_rotation = world > 1 and backend == "nccl" and n >= 256 and a.streams == 1
     work = Work(Y, mx if a.scaling == "strong" else a.m)
 
     # --streams S > 1: S independent contexts (own stream, own workspace, own outputs); step i runs on context i % S
@@ -416,7 +433,8 @@ def main():
             "scaling": a.scaling, "vs_baseline": None, "dtype": "f32" if f32 else "f64", "data": "synthetic",
             "config": {"workload": workload_name(a, n, p, m_total, m_local, f32, world),
                        "n": n, "p": p, "m": m_total, "m_per_gpu": m_local, "method": a.method,
-                       "parallelism": f"traits sharded over {world} GPU(s)", "gather_in_step": bool(a.gather),
+                       "parallelism": f"traits sharded over {world} GPU(s)" + ("; marker rotation sharded, rotated blocks all-gathered over xGMI inside the step" if shard_rotation and not perms else ""),
+                       "gather_in_step": bool(a.gather),
                        "streams": max(a.streams, 1)},
             "phases_ms": {k: v / max(ncalls, 1) for k, v in phases.items()},
             "allgather_ms": ag_ms, "gathered_ms_per_step": gathered_ms, "other_scaling": weak, "output_finite": bool(chk),

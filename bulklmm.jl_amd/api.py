@@ -679,6 +679,51 @@ def bulkscan_dev(ctx: Context, Y, G, K, L_out, h2_out, *, method: str = "null-ex
     return st
 
 
+def prepare_dev(ctx: Context, K, *, Covar=None, weights=None, addIntercept: bool = True, decomp_scheme: str = "eigen", status: bool = False):
+    """blmm_prepare_dev on torch CUDA tensors (K (n, n); Covar (ncov, n) = n x ncov column-major): design, eigen-decomposition and
+    rotation matrix; the context then serves rotate_block_dev / bulkscan_prerotated_dev (one process per GPU: the marker
+    rotation is sharded over the ranks, include/bulklmm_hip.h)."""
+    n = K.shape[0]
+    ncov = 0 if Covar is None else Covar.shape[0]
+    if Covar is None:
+        addIntercept = True
+    o = _opts(L.BLMM_NULL_EXACT, False, addIntercept, decomp_scheme)
+    st = L.blmm_status() if status else None
+    ctx.check(ctx.lib.blmm_prepare_dev(ctx.h, C.byref(o), n, None if Covar is None else Covar.data_ptr(), ncov, K.data_ptr(),
+                                       None if weights is None else weights.data_ptr(), C.byref(st) if status else None))
+    return st
+
+
+def rotated_rows(ctx: Context) -> int:
+    return int(ctx.lib.blmm_rotated_rows(ctx.h))
+
+
+def rotate_block_dev(ctx: Context, G_block, Xt_block):
+    """blmm_rotate_block_dev: G_block (pb, n) contiguous (= n x pb column-major) -> Xt_block (rows, ld) contiguous, k-major."""
+    pb = G_block.shape[0]
+    ctx.check(ctx.lib.blmm_rotate_block_dev(ctx.h, G_block.data_ptr(), pb, Xt_block.data_ptr(), Xt_block.stride(0)))
+
+
+def bulkscan_prerotated_dev(ctx: Context, Y, Xt_blocks, p: int, block_cols: int, L_out, h2_out, *, method: str = "null-exact", h2_grid=None,
+                            prior_variance: float = 1.0, prior_sample_size: float = 0.0, reml: bool = False, optim_interval: int = 1,
+                            status: bool = False):
+    """blmm_bulkscan_prerotated_dev: Y (m, n); Xt_blocks (nblocks, rows, block_ld) contiguous -- the all-gathered output of
+    rotate_block_dev, block b = markers [b block_cols, min(p, (b+1) block_cols)); L_out (m, p) [ld = stride(0)]."""
+    m = Y.shape[0]
+    grid, ngrid = None, 0
+    if method != "null-exact":
+        grid = np.ascontiguousarray(np.asarray(h2_grid if h2_grid is not None else [i / 10.0 for i in range(10)], dtype=np.float64))
+        ngrid = grid.shape[0]
+    o = _opts(_METHODS[method], reml, True, "eigen", optim_interval, prior_variance, prior_sample_size)
+    st = L.blmm_status() if status else None
+    nb, rows, bld = Xt_blocks.shape
+    assert Xt_blocks.is_contiguous() and rows == rotated_rows(ctx)
+    ctx.check(ctx.lib.blmm_bulkscan_prerotated_dev(ctx.h, C.byref(o), Y.data_ptr(), m, int(p), Xt_blocks.data_ptr(), nb, int(block_cols), bld,
+                                                   _p(grid), ngrid, L_out.data_ptr(), _ld(L_out, int(p)), h2_out.data_ptr(),
+                                                   C.byref(st) if status else None))
+    return st
+
+
 def _ld(t, p):
     """Leading dimension of a (cols, p) tensor that holds a p x cols column-major matrix."""
     if t.dim() != 2 or t.shape[1] != p or (p > 1 and t.stride(1) != 1) or (t.shape[0] > 1 and t.stride(0) < p):

@@ -113,14 +113,6 @@ int check_sticky(blmm_ctx* ctx) {
                                  ": -7 grid barrier of the tridiagonalisation timed out, -8 QL iteration limit)");
 }
 
-struct Pipe {
-  int n = 0, c = 0, npad = 0, ldr = 0;
-  int64_t m = 0, p = 0, ldy = 0, ldx = 0;
-  double *Yt = nullptr, *Xt = nullptr, *Z0 = nullptr, *lam = nullptr;
-  int64_t* stat = nullptr;
-  bool big = false;                // n beyond the LDS Jacobi: the call ends with k_sticky
-};
-
 struct Timer {
   blmm_ctx* ctx; blmm_ctx::EvSet* set = nullptr;
   explicit Timer(blmm_ctx* c) : ctx(c) {
@@ -221,12 +213,11 @@ int end_call(blmm_ctx* ctx, const Pipe& P, blmm_status* st, Timer* tm) {
   return finish_status(ctx, st, tm);
 }
 
-// design -> eigen -> rotation of Y and G.  centered = 1: the rotation also removes the unweighted projection
-// on the null covariates (kernels_prep.hip:k_post_eigen).
-int prepare(blmm_ctx* ctx, const blmm_opts* o, const double* dY, int64_t n, int64_t m, const double* dG, int64_t p,
-            const double* dCovar, int64_t ncov, const double* dK, const double* dweights, int centered, Pipe& P, Timer& tm,
-            bool early_wbasis = false) {
-  if (n < 1 || m < 0 || p < 0 || ncov < 0) return fail(ctx, BLMM_ERR_DIM, "Dimension mismatch.");
+// design -> eigen (prepare_eigen) -> rotation of Y and G (prepare_rotate).  centered = 1: the rotation also removes the
+// unweighted projection on the null covariates (kernels_prep.hip:k_post_eigen).
+int prepare_eigen(blmm_ctx* ctx, const blmm_opts* o, int64_t n, const double* dCovar, int64_t ncov, const double* dK,
+                  const double* dweights, int centered, Pipe& P, Timer& tm) {
+  if (n < 1 || ncov < 0) return fail(ctx, BLMM_ERR_DIM, "Dimension mismatch.");
   if (n > 2048) return fail(ctx, BLMM_ERR_UNSUPPORTED, "more than 2048 individuals: the device eigensolver (tridiagonalisation + divide and conquer) stops at n = 2048");
   int add_int = o->add_intercept ? 1 : 0;
   if (ncov == 0 || !dCovar) { add_int = 1; ncov = 0; dCovar = nullptr; }  // bulkscan(Y,G,K): intercept-only null model
@@ -234,7 +225,6 @@ int prepare(blmm_ctx* ctx, const blmm_opts* o, const double* dY, int64_t n, int6
   if (c < 1 || c > CMAX) return fail(ctx, BLMM_ERR_UNSUPPORTED, BLMM_C_ERR);
   if (c >= n) return fail(ctx, BLMM_ERR_DIM, "Dimension mismatch.");
   P.n = (int)n; P.c = c; P.npad = (int)round_up(n, 8); P.ldr = (int)round_up(P.npad, 16);   // K padded to 8: even K-step count
-  P.m = m; P.p = p; P.ldy = round_up(m > 0 ? m : 1, 128); P.ldx = round_up(p > 0 ? p : 1, 128);
   int rc;
   if ((rc = ensure(ctx, ctx->Ks, sizeof(double) * n * n))) return rc;
   if ((rc = ensure(ctx, ctx->V, sizeof(double) * (n * n + 4 * n + 16)))) return rc;
@@ -244,10 +234,8 @@ int prepare(blmm_ctx* ctx, const blmm_opts* o, const double* dY, int64_t n, int6
   if ((rc = ensure(ctx, ctx->Zs, sizeof(double) * n * c))) return rc;
   if ((rc = ensure(ctx, ctx->Z0, sizeof(double) * n * c))) return rc;
   if ((rc = ensure(ctx, ctx->Rp, sizeof(double) * (size_t)P.npad * P.ldr))) return rc;
-  if ((rc = ensure(ctx, ctx->Yt, sizeof(double) * (size_t)P.npad * P.ldy))) return rc;
-  if ((rc = ensure(ctx, ctx->Xt, sizeof(double) * (size_t)P.npad * P.ldx))) return rc;
   if ((rc = reset_stat(ctx, &P.stat))) return rc;
-  P.Yt = ptr<double>(ctx->Yt); P.Xt = ptr<double>(ctx->Xt); P.Z0 = ptr<double>(ctx->Z0); P.lam = ptr<double>(ctx->lam);
+  P.Z0 = ptr<double>(ctx->Z0); P.lam = ptr<double>(ctx->lam);
   tm.mark();
   if ((rc = launch_design(ctx, dK, dCovar, (int)ncov, add_int, dweights, (int)n, ptr<double>(ctx->Ks), ptr<double>(ctx->Zs)))) return rc;
   const double* evec = ptr<double>(ctx->V);
@@ -279,25 +267,56 @@ int prepare(blmm_ctx* ctx, const blmm_opts* o, const double* dY, int64_t n, int6
                               P.npad, P.ldr, o->decomp_scheme, centered, P.lam, ptr<double>(ctx->U), P.Z0,
                               ptr<double>(ctx->Rp), P.stat))) return rc;
   tm.mark();
-  if (early_wbasis && m > 0 && p > 0) {
-    // null-exact, low-rank weights form: the basis of the weight family needs only the sorted eigenvalues, so it
-    // starts on the side stream here, beside the rotation and the Brent search (joined before k_lr_panels)
-    if ((rc = ensure(ctx, ctx->wbQ, sizeof(double) * (size_t)P.npad * n))) return rc;
-    if ((rc = ensure(ctx, ctx->wbW, sizeof(double) * (size_t)n * (256 + 16)))) return rc;
-    if ((rc = ensure(ctx, ctx->wbRk, sizeof(int) * 4))) return rc;
-    hipStream_t main_stream = ctx->stream;
-    BLMM_HIP(hipEventRecord(ctx->ev_xt, main_stream));
-    BLMM_HIP(hipStreamWaitEvent(ctx->side, ctx->ev_xt, 0));
-    ctx->stream = ctx->side;                                           // the launchers enqueue on ctx->stream
-    rc = launch_wbasis(ctx, P.lam, (int)n, ptr<double>(ctx->wbW), ptr<double>(ctx->wbQ), ptr<int>(ctx->wbRk), P.stat);
-    ctx->stream = main_stream;
-    if (rc) return rc;
-  }
-  // The own rotation kernels sum every output element in a fixed order, so a trait's rotated column does not depend on how many
-  // OTHER traits are in the call (the sharding contract: a column block scanned alone is bit-identical, tests/test_gpu_configs.py;
-  // a vendor GEMM picks its kernel -- tile shape, split-K -- from the problem shape and broke exactly that in round 1).
-  if ((rc = launch_rotate(ctx, ptr<double>(ctx->Rp), P.ldr, (int)n, P.npad, dY, m, P.Yt, P.ldy, P.ldy))) return rc;
-  if ((rc = launch_rotate(ctx, ptr<double>(ctx->Rp), P.ldr, (int)n, P.npad, dG, p, P.Xt, P.ldx, P.ldx))) return rc;
+  return BLMM_OK;
+}
+
+// null-exact, low-rank weights form: the basis of the weight family needs only the sorted eigenvalues, so it starts on the side
+// stream right behind the eigen-decomposition, beside the rotation and the Brent search (joined before k_lr_panels)
+int start_wbasis(blmm_ctx* ctx, const Pipe& P) {
+  int rc;
+  const int64_t n = P.n;
+  if ((rc = ensure(ctx, ctx->wbQ, sizeof(double) * (size_t)P.npad * n))) return rc;
+  if ((rc = ensure(ctx, ctx->wbW, sizeof(double) * (size_t)n * (256 + 16)))) return rc;
+  if ((rc = ensure(ctx, ctx->wbRk, sizeof(int) * 4))) return rc;
+  hipStream_t main_stream = ctx->stream;
+  BLMM_HIP(hipEventRecord(ctx->ev_xt, main_stream));
+  BLMM_HIP(hipStreamWaitEvent(ctx->side, ctx->ev_xt, 0));
+  ctx->stream = ctx->side;                                           // the launchers enqueue on ctx->stream
+  rc = launch_wbasis(ctx, P.lam, (int)n, ptr<double>(ctx->wbW), ptr<double>(ctx->wbQ), ptr<int>(ctx->wbRk), P.stat);
+  ctx->stream = main_stream;
+  return rc;
+}
+
+// The own rotation kernels sum every output element in a fixed order, so a trait's (or marker's) rotated column does not depend on
+// how many OTHER columns are in the call (the sharding contract: a column block scanned alone is bit-identical,
+// tests/test_gpu_configs.py; a vendor GEMM picks its kernel -- tile shape, split-K -- from the problem shape and broke exactly
+// that in round 1).
+int rotate_traits(blmm_ctx* ctx, Pipe& P, const double* dY, int64_t m) {
+  if (m < 0) return fail(ctx, BLMM_ERR_DIM, "Dimension mismatch.");
+  P.m = m; P.ldy = round_up(m > 0 ? m : 1, 128);
+  int rc = ensure(ctx, ctx->Yt, sizeof(double) * (size_t)P.npad * P.ldy);
+  if (rc) return rc;
+  P.Yt = ptr<double>(ctx->Yt);
+  return launch_rotate(ctx, ptr<double>(ctx->Rp), P.ldr, P.n, P.npad, dY, m, P.Yt, P.ldy, P.ldy);
+}
+int rotate_markers(blmm_ctx* ctx, Pipe& P, const double* dG, int64_t p) {
+  if (p < 0) return fail(ctx, BLMM_ERR_DIM, "Dimension mismatch.");
+  P.p = p; P.ldx = round_up(p > 0 ? p : 1, 128);
+  int rc = ensure(ctx, ctx->Xt, sizeof(double) * (size_t)P.npad * P.ldx);
+  if (rc) return rc;
+  P.Xt = ptr<double>(ctx->Xt);
+  return launch_rotate(ctx, ptr<double>(ctx->Rp), P.ldr, P.n, P.npad, dG, p, P.Xt, P.ldx, P.ldx);
+}
+
+int prepare(blmm_ctx* ctx, const blmm_opts* o, const double* dY, int64_t n, int64_t m, const double* dG, int64_t p,
+            const double* dCovar, int64_t ncov, const double* dK, const double* dweights, int centered, Pipe& P, Timer& tm,
+            bool early_wbasis = false) {
+  if (m < 0 || p < 0) return fail(ctx, BLMM_ERR_DIM, "Dimension mismatch.");
+  int rc = prepare_eigen(ctx, o, n, dCovar, ncov, dK, dweights, centered, P, tm);
+  if (rc) return rc;
+  if (early_wbasis && m > 0 && p > 0 && (rc = start_wbasis(ctx, P))) return rc;
+  if ((rc = rotate_traits(ctx, P, dY, m))) return rc;
+  if ((rc = rotate_markers(ctx, P, dG, p))) return rc;
   tm.mark();
   return BLMM_OK;
 }
@@ -787,32 +806,12 @@ int blmm_get_thresholds(blmm_ctx* ctx, const double* Lperms, int64_t p, int64_t 
 }
 
 // ---------------------------------------------------------------------------------------------------
-int blmm_bulkscan_dev(blmm_ctx* ctx, const blmm_opts* opts, const double* dY, int64_t n, int64_t m, const double* dG,
-                      int64_t p, const double* dCovar, int64_t ncov, const double* dK, const double* dweights,
-                      const double* h2_grid_host, int64_t ngrid, double* dL_out, int64_t ldL, double* dh2_out,
-                      blmm_status* status) {
-  if (!ctx) return BLMM_ERR_INVALID;
-  int rc = check_opts(ctx, opts);
-  if (rc) return rc;
-  if (!dY || !dG || !dK || !dL_out || !dh2_out) return fail(ctx, BLMM_ERR_INVALID, "bulkscan: NULL buffer");
-  if (ldL < p) return fail(ctx, BLMM_ERR_INVALID, "bulkscan: ldL < p");
-  if (opts->method != BLMM_NULL_EXACT && opts->method != BLMM_NULL_GRID && opts->method != BLMM_ALT_GRID)
-    return fail(ctx, BLMM_ERR_METHOD, "Unknown method; choose null-exact, null-grid or alt-grid.");
-  BLMM_HIP(hipSetDevice(ctx->device));
-  if ((rc = check_sticky(ctx))) return rc;
-  Timer tm(ctx);
-  Pipe P;
-  double* dgrid = nullptr;
-  if (opts->method != BLMM_NULL_EXACT) {
-    if ((rc = grid_to_device(ctx, h2_grid_host, ngrid, &dgrid))) return rc;
-  }
-  // null-exact runs the low-rank weights form (kernels_lowrank.hip) unless BLMM_EXACT=full (A/B testing), c = 4 (the
-  // kernel would spill) or n is beyond what the basis kernel keeps in LDS
-  const char* exact_env = getenv("BLMM_EXACT");
-  const int c_eff = (int)((ncov == 0 || !dCovar) ? 1 : ncov + (opts->add_intercept ? 1 : 0));
-  const bool lowrank = opts->method == BLMM_NULL_EXACT && !(exact_env && std::strcmp(exact_env, "full") == 0) &&
-                       c_eff <= 3 && n <= 6000;
-  if ((rc = prepare(ctx, opts, dY, n, m, dG, p, dCovar, ncov, dK, dweights, 1, P, tm, lowrank))) return rc;
+// Everything behind the rotations: the h2 search / grid log-likelihoods, the panels and the LOD kernels of one method, then the
+// status.  Shared by blmm_bulkscan_dev and blmm_bulkscan_prerotated_dev.
+static int scan_pipeline(blmm_ctx* ctx, const blmm_opts* opts, Pipe& P, Timer& tm, bool lowrank, bool wbasis_started, double* dgrid,
+                         const double* h2_grid_host, int64_t ngrid, double* dL_out, int64_t ldL, double* dh2_out, blmm_status* status) {
+  int rc;
+  const int64_t m = P.m, p = P.p;
   const NullModel nm = null_model(P, opts);
   const int64_t ldp = P.ldy;
   if (m == 0) { tm.mark(); tm.mark(); tm.mark(); return end_call(ctx, P, status, &tm); }
@@ -832,7 +831,7 @@ int blmm_bulkscan_dev(blmm_ctx* ctx, const blmm_opts* opts, const double* dY, in
     if (lowrank) {
       // the basis (started in prepare) and the marker-side products (Q, Xt) run on the side stream beside the
       // per-trait Brent search
-      if ((rc = lr_begin(ctx, P, /*wbasis_started*/ true))) return rc;
+      if ((rc = lr_begin(ctx, P, wbasis_started))) return rc;
       // the second kernel of a split h2 search runs beside the scan of the traits the first one finished (BLMM_LR_SPLIT=0: A/B)
       static const bool split_on = !(getenv("BLMM_LR_SPLIT") && getenv("BLMM_LR_SPLIT")[0] == '0');
       BrentSplit sp;
@@ -899,6 +898,120 @@ int blmm_bulkscan_dev(blmm_ctx* ctx, const blmm_opts* opts, const double* dY, in
     tm.mark();
   }
   return end_call(ctx, P, status, &tm);
+}
+
+int blmm_bulkscan_dev(blmm_ctx* ctx, const blmm_opts* opts, const double* dY, int64_t n, int64_t m, const double* dG,
+                      int64_t p, const double* dCovar, int64_t ncov, const double* dK, const double* dweights,
+                      const double* h2_grid_host, int64_t ngrid, double* dL_out, int64_t ldL, double* dh2_out,
+                      blmm_status* status) {
+  if (!ctx) return BLMM_ERR_INVALID;
+  int rc = check_opts(ctx, opts);
+  if (rc) return rc;
+  if (!dY || !dG || !dK || !dL_out || !dh2_out) return fail(ctx, BLMM_ERR_INVALID, "bulkscan: NULL buffer");
+  if (ldL < p) return fail(ctx, BLMM_ERR_INVALID, "bulkscan: ldL < p");
+  if (opts->method != BLMM_NULL_EXACT && opts->method != BLMM_NULL_GRID && opts->method != BLMM_ALT_GRID)
+    return fail(ctx, BLMM_ERR_METHOD, "Unknown method; choose null-exact, null-grid or alt-grid.");
+  BLMM_HIP(hipSetDevice(ctx->device));
+  if ((rc = check_sticky(ctx))) return rc;
+  Timer tm(ctx);
+  Pipe P;
+  double* dgrid = nullptr;
+  if (opts->method != BLMM_NULL_EXACT) {
+    if ((rc = grid_to_device(ctx, h2_grid_host, ngrid, &dgrid))) return rc;
+  }
+  // null-exact runs the low-rank weights form (kernels_lowrank.hip) unless BLMM_EXACT=full (A/B testing), c = 4 (the
+  // kernel would spill) or n is beyond what the basis kernel keeps in LDS
+  const char* exact_env = getenv("BLMM_EXACT");
+  const int c_eff = (int)((ncov == 0 || !dCovar) ? 1 : ncov + (opts->add_intercept ? 1 : 0));
+  const bool lowrank = opts->method == BLMM_NULL_EXACT && !(exact_env && std::strcmp(exact_env, "full") == 0) &&
+                       c_eff <= 3 && n <= 6000;
+  if ((rc = prepare(ctx, opts, dY, n, m, dG, p, dCovar, ncov, dK, dweights, 1, P, tm, lowrank))) return rc;
+  return scan_pipeline(ctx, opts, P, tm, lowrank, /*wbasis_started*/ lowrank && m > 0 && p > 0, dgrid, h2_grid_host, ngrid, dL_out, ldL, dh2_out, status);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// One process per GPU (torch.distributed / MPI hosts): the pipeline in three calls, so that the marker rotation -- replicated
+// work when every rank runs blmm_bulkscan_dev on the full G -- is SHARDED.  At n >= 500 it is 10-25 % of a rank's step
+// (configs[4]: 3.8 ms of 16.5), against ~0.7 ms for an all-gather of the rotated blocks over xGMI; the eigen-decomposition stays
+// replicated (broadcasting U would synchronise all devices in the middle of the call).
+//   blmm_prepare_dev               design, eigen, post-eigen: the context then holds U, lambda, Z0 and the rotation matrix
+//   blmm_rotate_block_dev          rank r rotates ITS column block of G into a k-major block (rows = blmm_rotated_rows())
+//   [the host all-gathers the blocks: RCCL ncclAllGather / torch.distributed.all_gather_into_tensor]
+//   blmm_bulkscan_prerotated_dev   assembles Xt from the gathered blocks, rotates this rank's traits, runs the method
+// A marker's rotated column is the same bits whichever rank and block shape produced it (fixed summation order), so the result
+// equals blmm_bulkscan_dev's bit for bit (tests/test_gpu_configs.py).
+int blmm_prepare_dev(blmm_ctx* ctx, const blmm_opts* opts, int64_t n, const double* dCovar, int64_t ncov, const double* dK,
+                     const double* dweights, blmm_status* status) {
+  if (!ctx) return BLMM_ERR_INVALID;
+  int rc = check_opts(ctx, opts);
+  if (rc) return rc;
+  if (!dK) return fail(ctx, BLMM_ERR_INVALID, "prepare: NULL buffer");
+  BLMM_HIP(hipSetDevice(ctx->device));
+  if ((rc = check_sticky(ctx))) return rc;
+  ctx->prep_valid = false;
+  Timer tm(ctx);
+  Pipe P;
+  if ((rc = prepare_eigen(ctx, opts, n, dCovar, ncov, dK, dweights, 1, P, tm))) return rc;
+  ctx->prep = P;
+  ctx->prep_valid = true;
+  return end_call(ctx, P, status, &tm);
+}
+
+int64_t blmm_rotated_rows(const blmm_ctx* ctx) { return (ctx && ctx->prep_valid) ? ctx->prep.npad : 0; }
+
+int blmm_rotate_block_dev(blmm_ctx* ctx, const double* dG_block, int64_t pb, double* dXt_block, int64_t ld) {
+  if (!ctx) return BLMM_ERR_INVALID;
+  if (!ctx->prep_valid) return fail(ctx, BLMM_ERR_INVALID, "rotate_block: blmm_prepare_dev has not run on this context");
+  if (!dG_block || !dXt_block || pb < 0 || ld < pb) return fail(ctx, BLMM_ERR_INVALID, "rotate_block: bad arguments");
+  BLMM_HIP(hipSetDevice(ctx->device));
+  const Pipe& P = ctx->prep;
+  return launch_rotate(ctx, ptr<double>(ctx->Rp), P.ldr, P.n, P.npad, dG_block, pb, dXt_block, ld, ld);
+}
+
+int blmm_bulkscan_prerotated_dev(blmm_ctx* ctx, const blmm_opts* opts, const double* dY, int64_t m, int64_t p,
+                                 const double* dXt_blocks, int64_t nblocks, int64_t block_cols, int64_t block_ld,
+                                 const double* h2_grid_host, int64_t ngrid, double* dL_out, int64_t ldL, double* dh2_out,
+                                 blmm_status* status) {
+  if (!ctx) return BLMM_ERR_INVALID;
+  int rc = check_opts(ctx, opts);
+  if (rc) return rc;
+  if (!ctx->prep_valid) return fail(ctx, BLMM_ERR_INVALID, "bulkscan_prerotated: blmm_prepare_dev has not run on this context");
+  if (!dY || !dXt_blocks || !dL_out || !dh2_out) return fail(ctx, BLMM_ERR_INVALID, "bulkscan: NULL buffer");
+  if (m < 0 || p < 0 || nblocks < 1 || block_cols < 1 || block_ld < block_cols || nblocks * block_cols < p)
+    return fail(ctx, BLMM_ERR_DIM, "Dimension mismatch.");
+  if (ldL < p) return fail(ctx, BLMM_ERR_INVALID, "bulkscan: ldL < p");
+  if (opts->method != BLMM_NULL_EXACT && opts->method != BLMM_NULL_GRID && opts->method != BLMM_ALT_GRID)
+    return fail(ctx, BLMM_ERR_METHOD, "Unknown method; choose null-exact, null-grid or alt-grid.");
+  BLMM_HIP(hipSetDevice(ctx->device));
+  if ((rc = check_sticky(ctx))) return rc;
+  Timer tm(ctx);
+  Pipe P = ctx->prep;
+  double* dgrid = nullptr;
+  if (opts->method != BLMM_NULL_EXACT) {
+    if ((rc = grid_to_device(ctx, h2_grid_host, ngrid, &dgrid))) return rc;
+  }
+  // the counters of this scan start from zero except what the eigen-decomposition left (negative eigenvalues, its clocks)
+  BLMM_HIP(hipMemsetAsync(P.stat + 1, 0, sizeof(int64_t) * 4, ctx->stream));
+  BLMM_HIP(hipMemsetAsync(P.stat + 8, 0, sizeof(int64_t) * (NSTAT - 8), ctx->stream));
+  ctx->audit_ran = false;
+  tm.mark(); tm.mark();
+  const char* exact_env = getenv("BLMM_EXACT");
+  const bool lowrank = opts->method == BLMM_NULL_EXACT && !(exact_env && std::strcmp(exact_env, "full") == 0) && P.c <= 3;
+  if (lowrank && m > 0 && p > 0 && (rc = start_wbasis(ctx, P))) return rc;
+  if ((rc = rotate_traits(ctx, P, dY, m))) return rc;
+  // Xt (k-major, npad x ldx) from the gathered blocks [nblocks][npad][block_ld]: block b holds the columns [b block_cols, ..)
+  P.p = p; P.ldx = round_up(p > 0 ? p : 1, 128);
+  if ((rc = ensure(ctx, ctx->Xt, sizeof(double) * (size_t)P.npad * P.ldx))) return rc;
+  P.Xt = ptr<double>(ctx->Xt);
+  if (P.ldx > p) BLMM_HIP(hipMemset2DAsync(P.Xt + p, sizeof(double) * P.ldx, 0, sizeof(double) * (P.ldx - p), P.npad, ctx->stream));
+  for (int64_t b = 0; b < nblocks; ++b) {
+    const int64_t lo = b * block_cols, hi = (lo + block_cols < p) ? lo + block_cols : p;
+    if (hi <= lo) break;
+    BLMM_HIP(hipMemcpy2DAsync(P.Xt + lo, sizeof(double) * P.ldx, dXt_blocks + (size_t)b * P.npad * block_ld, sizeof(double) * block_ld,
+                              sizeof(double) * (hi - lo), P.npad, hipMemcpyDeviceToDevice, ctx->stream));
+  }
+  tm.mark();
+  return scan_pipeline(ctx, opts, P, tm, lowrank, lowrank && m > 0 && p > 0, dgrid, h2_grid_host, ngrid, dL_out, ldL, dh2_out, status);
 }
 
 int blmm_bulkscan(blmm_ctx* ctx, const blmm_opts* opts, const double* Y, int64_t n, int64_t m, const double* G, int64_t p,

@@ -34,6 +34,15 @@ struct DevBuf {
   size_t cap = 0;
 };
 
+// What the stages of a call hand to one another: shapes, the rotated operands and the null model's rotated covariates.
+struct Pipe {
+  int n = 0, c = 0, npad = 0, ldr = 0;
+  int64_t m = 0, p = 0, ldy = 0, ldx = 0;
+  double *Yt = nullptr, *Xt = nullptr, *Z0 = nullptr, *lam = nullptr;
+  int64_t* stat = nullptr;
+  bool big = false;                // n beyond the LDS Jacobi: the call ends with k_sticky
+};
+
 }  // namespace blmm
 
 namespace blmm { struct HostStage; }
@@ -61,6 +70,7 @@ struct blmm_ctx {
   volatile int64_t* hflag = nullptr;
   // the LOD matrix of the last host-pointer call, still resident in the workspace (kernels_post.hip: blmm_last_*)
   const double* last_L = nullptr; int64_t last_p = 0, last_m = 0; bool last_f32 = false;
+  blmm::Pipe prep; bool prep_valid = false;   // state left by blmm_prepare_dev for blmm_rotate_block_dev / blmm_bulkscan_prerotated_dev
   bool audit_ran = false;              // the current call ran the BLMM_FLAG_H2_AUDIT pass (finish_status: n_h2_multimodal, else -1)
   int eig_plan_n = -1;                 // n whose merge tree sits in eigW (kernels_eig.hip)
   blmm::HostStage* hstage = nullptr;   // pinned staging ring + copy threads of the host-pointer entry points (host_path.hip)

@@ -177,6 +177,25 @@ int blmm_bulkscan_dev(blmm_ctx* ctx, const blmm_opts* opts, const double* dY, in
                       const double* dweights, const double* h2_grid_host, int64_t ngrid, double* dL_out,
                       int64_t ldL, double* dh2_out, blmm_status* status);
 
+/* ---- the pipeline in three calls, for hosts that run ONE PROCESS PER GPU (torch.distributed, MPI; bench.py --gpus N):
+ * blmm_bulkscan_dev on every rank repeats the rotation of the whole G (10-25 % of a rank's step at n >= 500).  Instead every
+ * rank prepares (design, eigen-decomposition, rotation matrix: replicated, as the reference's transform_rotation is one call,
+ * src/transform_helpers.jl:21-34), rotates ITS column block of G, the host all-gathers the k-major blocks (RCCL over xGMI), and
+ * the scan takes the gathered blocks.  Bit-identical to blmm_bulkscan_dev.
+ *   blmm_prepare_dev              K n x n, Covar n x ncov (NULL/0: intercept only), weights n (NULL: missing)
+ *   blmm_rotated_rows             rows of a rotated block (n rounded up to 8); 0 before blmm_prepare_dev
+ *   blmm_rotate_block_dev         dG_block n x pb (column-major) -> dXt_block rows x ld (k-major: row k contiguous), ld >= pb
+ *   blmm_bulkscan_prerotated_dev  dXt_blocks = nblocks consecutive blocks of rows x block_ld doubles, block b = the markers
+ *                                 [b block_cols, min(p, (b+1) block_cols)); dY n x m = this rank's traits; outputs as blmm_bulkscan_dev */
+int blmm_prepare_dev(blmm_ctx* ctx, const blmm_opts* opts, int64_t n, const double* dCovar, int64_t ncov, const double* dK,
+                     const double* dweights, blmm_status* status);
+int64_t blmm_rotated_rows(const blmm_ctx* ctx);
+int blmm_rotate_block_dev(blmm_ctx* ctx, const double* dG_block, int64_t pb, double* dXt_block, int64_t ld);
+int blmm_bulkscan_prerotated_dev(blmm_ctx* ctx, const blmm_opts* opts, const double* dY, int64_t m, int64_t p,
+                                 const double* dXt_blocks, int64_t nblocks, int64_t block_cols, int64_t block_ld,
+                                 const double* h2_grid_host, int64_t ngrid, double* dL_out, int64_t ldL, double* dh2_out,
+                                 blmm_status* status);
+
 /* ---- the same call over several GPUs of one node (north_star: traits shard across the GPUs) -----------------------
  * Replaces the reference's thread blocking over contiguous trait ranges (src/bulkscan.jl:263-309): device r of R scans
  * the column block [r*ceil(m/R), min(m, (r+1)*ceil(m/R))) (blmm_multi_shard) and owns that block of the column-major
