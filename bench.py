@@ -107,6 +107,8 @@ def main():
                     help="leading dimension of the device LOD matrix rounded up to this many doubles (1 = dense, ld = p, the "
                          "reference's layout and the default; 16 = every column starts on a 128-byte line)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-all-rank-form", action="store_true",
+                    help="skip the extra timed loop with every trait in the rank-R form (profiling runs: its launches would be averaged into the kernel statistics)")
     ap.add_argument("--cpu-budget", type=float, default=15.0)
     a = ap.parse_args()
 
@@ -294,7 +296,7 @@ def main():
     # shared-weights class) is a property of the DATA: one more timed loop with the class switched off (every trait through the
     # rank-R form, BLMM_LR_SHARED=0, read per call by the library) says what the step costs without it.
     all_rank = None
-    if a.method == "null-exact" and world == 1 and a.streams == 1 and not os.environ.get("BLMM_LR_SHARED"):
+    if a.method == "null-exact" and world == 1 and a.streams == 1 and not a.no_all_rank_form and not os.environ.get("BLMM_LR_SHARED"):
         os.environ["BLMM_LR_SHARED"] = "0"
         try:
             dt_r, ph_r, nc_r = timed(work, False, max(a.steps // 2, 3), 1)

@@ -426,6 +426,9 @@ LrArgs lr_args(blmm_ctx* ctx, const Pipe& P, const LrRegion& rg, double* dL, int
 // SIMD), the other traits through k_scan_lr.  BLMM_LR_LEAN=0: both classes in k_scan_lr (A/B testing).
 int lr_region_scan(blmm_ctx* ctx, const Pipe& P, const LrRegion& rg, double* dL, int64_t ldL) {
   static const bool lean = !(getenv("BLMM_LR_LEAN") && getenv("BLMM_LR_LEAN")[0] == '0');
+  // diagnostic: the scan kernels alone on the chip (their rocprofv3 durations are then free of the side streams' kernels)
+  static const bool serial = getenv("BLMM_LR_SERIAL") && getenv("BLMM_LR_SERIAL")[0] == '1';
+  if (serial) { (void)hipStreamSynchronize(ctx->side); (void)hipStreamSynchronize(ctx->side2); (void)hipStreamSynchronize(ctx->stream); }
   LrArgs la = lr_args(ctx, P, rg, dL, ldL);
   int rc;
   if (lean) {

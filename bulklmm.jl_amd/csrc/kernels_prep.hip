@@ -756,7 +756,12 @@ int launch_post_eigen(blmm_ctx* ctx, const double* lraw, const double* V, const 
   int rc = ensure(ctx, ctx->misc, sizeof(double) * ((size_t)n + (size_t)c * n + 64));
   if (rc) return rc;
   const size_t lds = sizeof(double) * ((size_t)2 * n * n + (size_t)3 * n * c + n);
-  if (lds <= 150 * 1024) {
+  // the kernel's static LDS (the CMAX-sized Gauss-Jordan work arrays) counts against the 160 KB of the CU as well
+  static const size_t lds_static = [] {
+    hipFuncAttributes fa;
+    return hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(&k_post_eigen<true>)) == hipSuccess ? (size_t)fa.sharedSizeBytes : (size_t)32768;
+  }();
+  if (lds + lds_static <= 158 * 1024) {
     BLMM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_post_eigen<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(k_post_eigen<true>, dim3(1), dim3(1024), lds, ctx->stream, lraw, V, Zs, dweights, n, c, npad, ldr, decomp,
                        centered, lam, U, Z0, Rp, ptr<double>(ctx->misc), stat);

@@ -131,6 +131,7 @@ __device__ __forceinline__ int64_t xcd_swizzle(int64_t bid, int64_t nwg) {
 // the trait tile the fast one.  The GT trait tiles' A-side panels (GT x ~120 KB) stay in the 4 MB L2 while each
 // 80 KB marker tile of Xt is fetched once per group instead of once per trait tile (HBM/MALL fetch / ~GT).
 constexpr int GT = 16;
+
 __device__ __forceinline__ void tile_of(int64_t id, int64_t ntile_t, int ntile_i, int64_t& tile_t, int& tile_i) {
   const int64_t per_group = (int64_t)GT * ntile_i;
   const int64_t g = id / per_group, rem = id - g * per_group;

@@ -15,11 +15,11 @@ echo "== default bench"; python3 bench.py > $OUT/bench.json 2> $OUT/bench.err ||
 prof() {  # tag, kernel regex, bench args...
   local tag=$1 kre=$2; shift 2
   echo "== $tag: kernel trace"
-  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/$tag/trace -o t -- python3 bench.py --no-cpu-baseline --no-host-api --steps 5 --warmup 1 "$@" > $OUT/$tag.trace.log 2>&1 || { tail -5 $OUT/$tag.trace.log; return 1; }
+  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/$tag/trace -o t -- python3 bench.py --no-cpu-baseline --no-host-api --no-all-rank-form --steps 5 --warmup 1 "$@" > $OUT/$tag.trace.log 2>&1 || { tail -5 $OUT/$tag.trace.log; return 1; }
   for ctr in FETCH_SIZE WRITE_SIZE "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE"; do
     local c1=${ctr%% *}
     echo "== $tag: pmc $c1"
-    rocprofv3 --kernel-trace --pmc $ctr --kernel-include-regex "$kre" --output-format csv -d $OUT/$tag/pmc_$c1 -o p -- python3 bench.py --no-cpu-baseline --no-host-api --steps 3 --warmup 1 "$@" > $OUT/$tag.pmc_$c1.log 2>&1 || { tail -5 $OUT/$tag.pmc_$c1.log; return 1; }
+    rocprofv3 --kernel-trace --pmc $ctr --kernel-include-regex "$kre" --output-format csv -d $OUT/$tag/pmc_$c1 -o p -- python3 bench.py --no-cpu-baseline --no-host-api --no-all-rank-form --steps 3 --warmup 1 "$@" > $OUT/$tag.pmc_$c1.log 2>&1 || { tail -5 $OUT/$tag.pmc_$c1.log; return 1; }
   done
 }
 prof exact "k_scan_lr|k_scan<0, 2, 4, true, 2, true" || exit 1
