@@ -8,6 +8,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "log_table.h"
+#include "pval_table.h"
 
 namespace blmm {
 
@@ -153,6 +154,62 @@ __device__ __forceinline__ double lod_out_of_range(double u, const dpair* __rest
   if (u == 0.0) return INFINITY;
   *nnan += counted ? 1 : 0;
   return NAN;
+}
+
+// ---- -log10 p of a LOD score, one degree of freedom, inside a scan epilogue (`output_pvals`, src/bulkscan.jl:154-157;
+// lod2log10p, src/util.jl:199-206 with chisq_df = 1) --------------------------------------------------------------------------
+//   -log10 erfc(x) = LOD + x w(x),  x = sqrt(LOD ln 10),  w(x) = -log10(erfcx(x)) / x
+// w: bucketed degree-7 polynomials (pval_table.h, tools/gen_pval_table.py: 4.3e-15 relative on the whole range); both terms are
+// non-negative.  LOD <= 0 -> 0 (the reference's logccdf of a non-positive statistic), NaN -> NaN, +Inf -> +Inf; LOD < 1e-290
+// (p = 1 - 1e-145) -> 0.  ~20 fp64 operations + four 16-byte LDS reads per value, against ~150 of the erfc / erfcx / log route
+// of kernels_post.hip (which stays the general-df path).
+template <int NT>
+struct PvStage { dpair v[(BLMM_PV_TABLE_N * 4 + NT - 1) / NT]; };
+template <int NT>
+__device__ __forceinline__ void pv_stage_load(PvStage<NT>& st, const double* __restrict__ gtab) {
+  constexpr int PER = (BLMM_PV_TABLE_N * 4 + NT - 1) / NT;
+  const dpair* g = reinterpret_cast<const dpair*>(gtab);
+#pragma unroll
+  for (int u = 0; u < PER; ++u) {
+    const int i = (int)threadIdx.x + NT * u;
+    st.v[u] = g[i < BLMM_PV_TABLE_N * 4 ? i : BLMM_PV_TABLE_N * 4 - 1];
+  }
+}
+template <int NT>
+__device__ __forceinline__ void pv_stage_store(const PvStage<NT>& st, dpair* lds) {
+  constexpr int PER = (BLMM_PV_TABLE_N * 4 + NT - 1) / NT;
+#pragma unroll
+  for (int u = 0; u < PER; ++u) {
+    const int i = (int)threadIdx.x + NT * u;
+    if (i < BLMM_PV_TABLE_N * 4) lds[i] = st.v[u];
+  }
+}
+__device__ __forceinline__ double fast_log10p1(double lod, const dpair* __restrict__ pv) {
+  const double t = lod * 2.302585092994046;
+  if (!(t >= 1e-290)) return (t == t) ? 0.0 : t;         // <= 0, underflowing, NaN
+  // sqrt: v_rsq_f64 seed, two Newton steps on x = t y
+  const double y = __builtin_amdgcn_rsq(t);
+  const double h = 0.5 * y;
+  double x = t * y;
+  x = fma(fma(-x, x, t), h, x);
+  x = fma(fma(-x, x, t), h, x);
+  if (!(x < 16384.0)) return lod;                         // beyond the table (LOD >= 1.2e8, +Inf): x w(x) < 1e-8 LOD
+  const uint32_t hi = (uint32_t)__double2hiint(x);
+  const bool first = hi < BLMM_PV_HI0;                    // x < 2^-12: bucket 0, polynomial in x itself
+  const uint32_t b = first ? 0u : 1u + ((hi - BLMM_PV_HI0) >> BLMM_PV_SHIFT);
+  const double c = first ? 0.0 : __hiloint2double((int)((hi & ~((1u << BLMM_PV_SHIFT) - 1u)) | (1u << (BLMM_PV_SHIFT - 1))), 0);
+  const double s = x - c;
+  const dpair* e = pv + 4 * b;
+  const dpair c01 = e[0], c23 = e[1], c45 = e[2], c67 = e[3];
+  double w = c67[1];
+  w = fma(w, s, c67[0]);
+  w = fma(w, s, c45[1]);
+  w = fma(w, s, c45[0]);
+  w = fma(w, s, c23[1]);
+  w = fma(w, s, c23[0]);
+  w = fma(w, s, c01[1]);
+  w = fma(w, s, c01[0]);
+  return fma(x, w, lod);
 }
 
 // 1/x to ~20 ulp (2.2e-15 relative, tools/mb4_rcp.hip): v_rcp_f64 seed (4.6e-8) + ONE Newton step.  Used where the quotient
