@@ -81,7 +81,8 @@ def workload_name(a, n, p, m_total, m_local, f32, world):
     else:
         which = "no BASELINE.json config has this method and shape"
     unit = "permutations" if a.method == "perms" else "traits"
-    return (f"method={a.method} n={n} p={p} m={m_total} {dt}, {which}; {m_local} {unit} on rank 0 of {world}")
+    pv = " + output_pvals (-log10 p matrix written by the same step)" if getattr(a, "pvals", False) and a.method != "perms" else ""
+    return (f"method={a.method} n={n} p={p} m={m_total} {dt}{pv}, {which}; {m_local} {unit} on rank 0 of {world}")
 
 
 def main():
@@ -107,6 +108,9 @@ def main():
                     help="leading dimension of the device LOD matrix rounded up to this many doubles (1 = dense, ld = p, the "
                          "reference's layout and the default; 16 = every column starts on a 128-byte line)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--pvals", action="store_true",
+                    help="`output_pvals = true`: the step also produces the -log10 p matrix (blmm_set_log10p_output; BLMM_PVAL_FUSED=0 "
+                         "in the environment runs it as the column pass over the finished L instead of from the scan epilogues)")
     ap.add_argument("--no-all-rank-form", action="store_true",
                     help="skip the extra timed loop with every trait in the rank-R form (profiling runs: its launches would be averaged into the kernel statistics)")
     ap.add_argument("--cpu-budget", type=float, default=15.0)
@@ -217,6 +221,7 @@ def main():
                 ldl = -(-p // a.ldl_align) * a.ldl_align
                 self.dL = torch.empty((self.m, ldl), dtype=ldt, device=dev)[:, :p]
             self.dH = torch.empty((self.m, p) if alt else (max(self.m, 1),), dtype=torch.float64, device=dev)
+            self.dP = torch.empty((self.m, p), dtype=torch.float64, device=dev) if a.pvals and not perms else None
             if perms:
                 self.dy1 = self.dY[0].contiguous()
                 self.dsc = torch.empty(2, dtype=torch.float64, device=dev)
@@ -243,7 +248,7 @@ def main():
                 dist.all_gather_into_tensor(self.gx.view(-1), self.gx[rank].reshape(-1))
                 B.bulkscan_prerotated_dev(c, self.dY, self.gx, p, self.bc, L, H, method=a.method, h2_grid=grid)
             else:
-                B.bulkscan_dev(c, self.dY, dG, dK, L, H, method=a.method, h2_grid=grid)
+                B.bulkscan_dev(c, self.dY, dG, dK, L, H, method=a.method, h2_grid=grid, log10p_out=self.dP)
 
         def gather(self):
             if self.full is not None and backend == "nccl":

@@ -23,7 +23,7 @@ EXPORTS = [
     "blmm_multi_shard", "blmm_bulkscan_multi", "blmm_multi_device_result",
     "blmm_host_register", "blmm_host_unregister", "blmm_host_alloc", "blmm_host_free",
     "blmm_lod2log10p", "blmm_lod2log10p_dev", "blmm_lod_threshold", "blmm_lod_threshold_dev", "blmm_get_thresholds", "blmm_get_thresholds_dev",
-    "blmm_last_log10p", "blmm_last_lod_threshold", "blmm_last_get_thresholds",
+    "blmm_last_log10p", "blmm_last_lod_threshold", "blmm_last_get_thresholds", "blmm_set_log10p_output",
     "blmm_read_csv", "blmm_read_he", "blmm_table_rows", "blmm_table_cols", "blmm_table_copy", "blmm_table_free",
     "blmm_kinship_rounded", "blmm_scan_alt", "blmm_scan_alt_dev",
     "blmm_prepare_dev", "blmm_rotated_rows", "blmm_rotate_block_dev", "blmm_bulkscan_prerotated_dev",
@@ -147,6 +147,7 @@ def load():
     lib.blmm_get_thresholds.argtypes = [vp, vp, i64, i64, vp, i64, vp]
     lib.blmm_get_thresholds_dev.argtypes = [vp, vp, i64, i64, i64, vp, i64, vp]
     lib.blmm_last_log10p.argtypes = [vp, i64, vp]
+    lib.blmm_set_log10p_output.argtypes = [vp, vp, i64, i64]
     lib.blmm_last_lod_threshold.argtypes = [vp, C.c_double, i64, vp, vp, vp, C.POINTER(i64)]
     lib.blmm_last_get_thresholds.argtypes = [vp, vp, i64, vp]
     lib.blmm_read_csv.argtypes = [C.c_char_p, i64, i64, i64, i64, C.POINTER(vp)]

@@ -430,6 +430,11 @@ def bulkscan(Y, G, K, Covar=None, *, method: str = "null-grid", h2_grid=None, nb
         h2_grid = [i / 10.0 for i in range(10)]  # collect(0.0:0.1:0.9)
     if method not in _METHODS:
         raise BulkLMMError("Unknown method `%s`; choose null-exact, null-grid or alt-grid." % method, -5)
+    if output_pvals:
+        # lod2log10p.(L, chisq_df) merged into the result (src/bulkscan.jl:154-157): asked for BEFORE the scan, so that the
+        # scan kernels write it from their epilogues (chisq_df = 1, null-* methods) into a buffer of the context
+        c_ = ctx or default_context()
+        c_.check(c_.lib.blmm_set_log10p_output(c_.h, None, 0, int(chisq_df)))
     if method == "null-exact":
         r = bulkscan_null(Y, G, K, Covar, addIntercept=addIntercept, weights=weights, prior_variance=prior_variance,
                           prior_sample_size=prior_sample_size, reml=reml, optim_interval=optim_interval,
@@ -446,7 +451,6 @@ def bulkscan(Y, G, K, Covar=None, *, method: str = "null-grid", h2_grid=None, nb
                               decomp_scheme=decomp_scheme, ctx=ctx)
         out = {"L": r.L, "h2_panel": r.h2_panel}
     if output_pvals:
-        # lod2log10p.(L, chisq_df) merged into the result (src/bulkscan.jl:154-157), from the L still resident in HBM
         out["log10Pvals_mat"] = _last_log10p(ctx or default_context(), out["L"].shape, chisq_df)
         out["Chisq_df"] = chisq_df
     return out
@@ -655,13 +659,16 @@ def liteqtl_given_h2(Y0, X0, lambda0, h2, *, num_of_covar: int = 1, ctx: Optiona
 
 def bulkscan_dev(ctx: Context, Y, G, K, L_out, h2_out, *, method: str = "null-exact", h2_grid=None, Covar=None, weights=None,
                  addIntercept: bool = True, prior_variance: float = 1.0, prior_sample_size: float = 0.0, reml: bool = False,
-                 optim_interval: int = 1, decomp_scheme: str = "eigen", status: bool = False):
+                 optim_interval: int = 1, decomp_scheme: str = "eigen", status: bool = False, log10p_out=None, chisq_df: int = 1):
     """blmm_bulkscan_dev on torch CUDA tensors laid out column-major: pass Y as a (m, n) contiguous tensor
     (= n x m column-major), G as (p, n), K as (n, n), L_out as (m, p) (= p x m column-major; rows may be padded: the
-    leading dimension passed on is L_out.stride(0)).
+    leading dimension passed on is L_out.stride(0)).  `log10p_out` (same layout as L_out): `output_pvals` inside the scan
+    (blmm_set_log10p_output).
     Enqueues on the context's stream and does not synchronise unless `status` is requested."""
     m, n = Y.shape
     p = G.shape[0]
+    if log10p_out is not None:
+        ctx.check(ctx.lib.blmm_set_log10p_output(ctx.h, log10p_out.data_ptr(), _ld(log10p_out, p), int(chisq_df)))
     grid = None
     ngrid = 0
     if method != "null-exact":

@@ -23,6 +23,7 @@ int ensure(blmm_ctx* ctx, DevBuf& b, size_t bytes) {
   // whoever asks for the output buffer is about to overwrite (or reallocate) it: the blmm_last_* consumers must not see the
   // previous call's matrix through it.  The entry points set last_L again once their own result is in place.
   if (&b == &ctx->outL) ctx->last_L = nullptr;
+  if (&b == &ctx->outL || &b == &ctx->outP) ctx->last_P = nullptr;
   if (bytes == 0) bytes = 8;
   if (b.cap >= bytes) return BLMM_OK;
   if (b.p) {
@@ -349,6 +350,7 @@ ScanArgs scan_args(blmm_ctx* ctx, const Pipe& P, const double* panels, int64_t l
   a.Xt = P.Xt; a.ldx = P.ldx; a.P = panels; a.ldp = ldp; a.pstride = (int64_t)P.npad * ldp;
   a.ks = P.npad / 4; a.n = P.n; a.p = P.p; a.m = m; a.L = L; a.ldL = ldL;
   a.isx = nullptr; a.ld_isx = 0; a.bin = nullptr; a.stat = P.stat; a.logtab = ptr<double>(ctx->logtab); a.lodtab = ptr<double>(ctx->lodtab);
+  a.Pv = ctx->pv_cur; a.ldPv = ctx->pv_cur_ld; a.pvtab = ptr<double>(ctx->pvtab);
   a.c = P.c;
   lod_poly5_host(-0.5 * (double)P.n, a.lodc);
   return a;
@@ -617,7 +619,9 @@ int blmm_create(int device_id, void* hip_stream, blmm_ctx** out) {
   if (ensure(ctx, ctx->logtab, sizeof(blmm_log_table_host)) != BLMM_OK ||
       hipMemcpy(ctx->logtab.p, blmm_log_table_host, sizeof(blmm_log_table_host), hipMemcpyHostToDevice) != hipSuccess ||
       ensure(ctx, ctx->lodtab, sizeof(blmm_lod_table_host)) != BLMM_OK ||
-      hipMemcpy(ctx->lodtab.p, blmm_lod_table_host, sizeof(blmm_lod_table_host), hipMemcpyHostToDevice) != hipSuccess) {
+      hipMemcpy(ctx->lodtab.p, blmm_lod_table_host, sizeof(blmm_lod_table_host), hipMemcpyHostToDevice) != hipSuccess ||
+      ensure(ctx, ctx->pvtab, sizeof(blmm_pv_table_host)) != BLMM_OK ||
+      hipMemcpy(ctx->pvtab.p, blmm_pv_table_host, sizeof(blmm_pv_table_host), hipMemcpyHostToDevice) != hipSuccess) {
     blmm_destroy(ctx);
     return BLMM_ERR_HIP;
   }
@@ -633,7 +637,7 @@ void blmm_destroy(blmm_ctx* ctx) {
                     &ctx->iyy, &ctx->h2, &ctx->h2idx, &ctx->sig2, &ctx->ell, &ctx->isx, &ctx->stat, &ctx->gridd, &ctx->misc,
                     &ctx->EllTab, &ctx->inY, &ctx->inG, &ctx->inK, &ctx->inCov, &ctx->inW, &ctx->outL, &ctx->outH2,
                     &ctx->tmpA, &ctx->tmpB, &ctx->tmpC, &ctx->perm, &ctx->r0, &ctx->altbuf, &ctx->logtab, &ctx->lraw,
-                    &ctx->wbQ, &ctx->wbW, &ctx->wbRk, &ctx->lrT, &ctx->lrC, &ctx->lrL, &ctx->lrFlag, &ctx->lrPart, &ctx->lrPerm, &ctx->lrDen0, &ctx->eigW, &ctx->xf32, &ctx->pf32, &ctx->brSt, &ctx->brList, &ctx->illList, &ctx->qrSlab, &ctx->lodtab, &ctx->dynFac};
+                    &ctx->wbQ, &ctx->wbW, &ctx->wbRk, &ctx->lrT, &ctx->lrC, &ctx->lrL, &ctx->lrFlag, &ctx->lrPart, &ctx->lrPerm, &ctx->lrDen0, &ctx->eigW, &ctx->xf32, &ctx->pf32, &ctx->brSt, &ctx->brList, &ctx->illList, &ctx->qrSlab, &ctx->lodtab, &ctx->dynFac, &ctx->pvtab, &ctx->outP};
   for (DevBuf* b : bufs) if (b->p) hipFree(b->p);
   for (auto& s : ctx->evsets) for (auto& e : s.e) (void)hipEventDestroy(e);
   if (ctx->side) { (void)hipStreamSynchronize(ctx->side); (void)hipStreamDestroy(ctx->side); }
@@ -811,12 +815,48 @@ int blmm_get_thresholds(blmm_ctx* ctx, const double* Lperms, int64_t p, int64_t 
 // ---------------------------------------------------------------------------------------------------
 // Everything behind the rotations: the h2 search / grid log-likelihoods, the panels and the LOD kernels of one method, then the
 // status.  Shared by blmm_bulkscan_dev and blmm_bulkscan_prerotated_dev.
+// `output_pvals` inside the scan (blmm_set_log10p_output): resolves the armed request for THIS call.  One degree of freedom and a
+// null-* method: the scan kernels write -log10 p from their epilogues (ScanArgs::Pv, set through ctx->pv_cur while they run);
+// otherwise (alt-grid: the LOD is only final after the last grid point; other degrees of freedom: incomplete gamma function)
+// the column pass of kernels_post.hip runs over the finished L, still inside the call.
+namespace {
+struct PvCall {
+  blmm_ctx* ctx; double* P = nullptr; int64_t ld = 0, df = 1; bool fused = false, owned = false;
+  explicit PvCall(blmm_ctx* c) : ctx(c) {}
+  ~PvCall() { ctx->pv_cur = nullptr; ctx->pv_cur_ld = 0; }
+  int begin(const Pipe& Pp, const blmm_opts* o) {
+    if (!ctx->pv_armed) return BLMM_OK;
+    ctx->pv_armed = false;
+    if (Pp.p <= 0 || Pp.m <= 0) return BLMM_OK;
+    df = ctx->pv_df; P = ctx->pv_out; ld = ctx->pv_ld;
+    if (P && ld < Pp.p) { P = nullptr; return fail(ctx, BLMM_ERR_INVALID, "log10p output: ldP < p"); }
+    if (!P) {
+      int rc = ensure(ctx, ctx->outP, sizeof(double) * (size_t)Pp.p * (size_t)Pp.m);
+      if (rc) return rc;
+      P = ptr<double>(ctx->outP); ld = Pp.p; owned = true;
+    }
+    fused = df == 1 && o->method != BLMM_ALT_GRID && !(getenv("BLMM_PVAL_FUSED") && getenv("BLMM_PVAL_FUSED")[0] == '0');
+    if (fused) { ctx->pv_cur = P; ctx->pv_cur_ld = ld; }
+    return BLMM_OK;
+  }
+  int finish(const Pipe& Pp, const double* dL, int64_t ldL) {
+    ctx->pv_cur = nullptr; ctx->pv_cur_ld = 0;
+    if (!P) return BLMM_OK;
+    if (!fused) { int rc = launch_lod2log10p(ctx, dL, Pp.p, Pp.m, ldL, (int)df, P, ld); if (rc) return rc; }
+    if (owned) { ctx->last_P = P; ctx->last_P_ld = ld; ctx->last_P_df = df; }
+    return BLMM_OK;
+  }
+};
+}  // namespace
+
 static int scan_pipeline(blmm_ctx* ctx, const blmm_opts* opts, Pipe& P, Timer& tm, bool lowrank, bool wbasis_started, double* dgrid,
                          const double* h2_grid_host, int64_t ngrid, double* dL_out, int64_t ldL, double* dh2_out, blmm_status* status) {
   int rc;
   const int64_t m = P.m, p = P.p;
   const NullModel nm = null_model(P, opts);
   const int64_t ldp = P.ldy;
+  PvCall pvc(ctx);
+  if ((rc = pvc.begin(P, opts))) return rc;
   if (m == 0) { tm.mark(); tm.mark(); tm.mark(); return end_call(ctx, P, status, &tm); }
   if (p == 0) {
     // no markers: only the per-trait null model (h2_null_list does not depend on G); alt-grid's h2_panel is p x m = empty
@@ -900,7 +940,16 @@ static int scan_pipeline(blmm_ctx* ctx, const blmm_opts* opts, Pipe& P, Timer& t
     if ((rc = launch_scan_alt(ctx, aa))) return rc;
     tm.mark();
   }
+  if ((rc = pvc.finish(P, dL_out, ldL))) return rc;
   return end_call(ctx, P, status, &tm);
+}
+
+int blmm_set_log10p_output(blmm_ctx* ctx, double* dP_out, int64_t ldP, int64_t chisq_df) {
+  if (!ctx) return BLMM_ERR_INVALID;
+  if (chisq_df < 0 || chisq_df > 1000000 || (dP_out && ldP < 1)) return fail(ctx, BLMM_ERR_INVALID, "set_log10p_output: bad arguments");
+  ctx->pv_armed = chisq_df > 0;
+  ctx->pv_out = dP_out; ctx->pv_ld = ldP; ctx->pv_df = chisq_df > 0 ? chisq_df : 1;
+  return BLMM_OK;
 }
 
 int blmm_bulkscan_dev(blmm_ctx* ctx, const blmm_opts* opts, const double* dY, int64_t n, int64_t m, const double* dG,

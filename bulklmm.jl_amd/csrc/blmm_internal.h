@@ -55,7 +55,7 @@ struct blmm_ctx {
   std::string err;
   // grow-only workspace
   blmm::DevBuf Ks, V, lam, U, Zs, Z0, Rp, Yt, Xt, panels, iyy, h2, h2idx, sig2, ell, isx, stat, gridd, misc, EllTab,
-      inY, inG, inK, inCov, inW, outL, outH2, tmpA, tmpB, tmpC, perm, r0, altbuf, logtab, lraw, wbQ, wbW, wbRk, lrT, lrC, lrL, lrFlag, lrPart, lrPerm, lrDen0, eigW, xf32, pf32, brSt, brList, illList, qrSlab, lodtab, dynFac;
+      inY, inG, inK, inCov, inW, outL, outH2, tmpA, tmpB, tmpC, perm, r0, altbuf, logtab, lraw, wbQ, wbW, wbRk, lrT, lrC, lrL, lrFlag, lrPart, lrPerm, lrDen0, eigW, xf32, pf32, brSt, brList, illList, qrSlab, lodtab, dynFac, pvtab, outP;
   // event sets: one per timed call since the last blmm_read_timings (grown on demand, reused afterwards)
   struct EvSet { hipEvent_t e[8]; int n; };
   std::vector<EvSet> evsets;
@@ -70,6 +70,11 @@ struct blmm_ctx {
   volatile int64_t* hflag = nullptr;
   // the LOD matrix of the last host-pointer call, still resident in the workspace (kernels_post.hip: blmm_last_*)
   const double* last_L = nullptr; int64_t last_p = 0, last_m = 0; bool last_f32 = false;
+  // blmm_set_log10p_output: the next bulkscan call also writes -log10 p (pv_out == nullptr: into outP, dense); pv_cur is set
+  // while that call's scan kernels run (blmm_api.hip: scan_args).  last_P: the matrix that call left (blmm_last_log10p).
+  bool pv_armed = false; double* pv_out = nullptr; int64_t pv_ld = 0, pv_df = 1;
+  double* pv_cur = nullptr; int64_t pv_cur_ld = 0;
+  const double* last_P = nullptr; int64_t last_P_ld = 0, last_P_df = 0;
   blmm::Pipe prep; bool prep_valid = false;   // state left by blmm_prepare_dev for blmm_rotate_block_dev / blmm_bulkscan_prerotated_dev
   bool audit_ran = false;              // the current call ran the BLMM_FLAG_H2_AUDIT pass (finish_status: n_h2_multimodal, else -1)
   int eig_plan_n = -1;                 // n whose merge tree sits in eigW (kernels_eig.hip)
@@ -200,6 +205,10 @@ struct ScanArgs {
                                            // the kernels hold it in SGPRs (gfx950 has no scalar fp64 arithmetic: derived in the
                                            // kernel the five coefficients cost 10 VGPRs in kernels at the register limit)
   int64_t* stat;
+  // optional second output of the epilogue: -log10 p, one degree of freedom (blmm_set_log10p_output); pvtab = device copy of
+  // pval_table.h.  Kernels without the fused form (alt-grid, fp32 permutations, the rare per-trait re-scans) leave Pv to a
+  // column pass over the finished L (launch_lod2log10p / launch_pv_list).
+  double* Pv = nullptr; int64_t ldPv = 0; const double* pvtab = nullptr;
 };
 int launch_scan_exact(blmm_ctx* ctx, const ScanArgs& a, int c);
 // A region of the panel arrays of the low-rank form: columns [col0, col0 + ncol), the shared-weights class at its front

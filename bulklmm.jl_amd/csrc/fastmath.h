@@ -164,24 +164,24 @@ __device__ __forceinline__ double lod_out_of_range(double u, const dpair* __rest
 // (p = 1 - 1e-145) -> 0.  ~20 fp64 operations + four 16-byte LDS reads per value, against ~150 of the erfc / erfcx / log route
 // of kernels_post.hip (which stays the general-df path).
 template <int NT>
-struct PvStage { dpair v[(BLMM_PV_TABLE_N * 4 + NT - 1) / NT]; };
+struct PvStage { dpair v[(BLMM_PV_TABLE_N * (BLMM_PV_STRIDE / 2) + NT - 1) / NT]; };
 template <int NT>
 __device__ __forceinline__ void pv_stage_load(PvStage<NT>& st, const double* __restrict__ gtab) {
-  constexpr int PER = (BLMM_PV_TABLE_N * 4 + NT - 1) / NT;
+  constexpr int PER = (BLMM_PV_TABLE_N * (BLMM_PV_STRIDE / 2) + NT - 1) / NT;
   const dpair* g = reinterpret_cast<const dpair*>(gtab);
 #pragma unroll
   for (int u = 0; u < PER; ++u) {
     const int i = (int)threadIdx.x + NT * u;
-    st.v[u] = g[i < BLMM_PV_TABLE_N * 4 ? i : BLMM_PV_TABLE_N * 4 - 1];
+    st.v[u] = g[i < BLMM_PV_TABLE_N * (BLMM_PV_STRIDE / 2) ? i : BLMM_PV_TABLE_N * (BLMM_PV_STRIDE / 2) - 1];
   }
 }
 template <int NT>
 __device__ __forceinline__ void pv_stage_store(const PvStage<NT>& st, dpair* lds) {
-  constexpr int PER = (BLMM_PV_TABLE_N * 4 + NT - 1) / NT;
+  constexpr int PER = (BLMM_PV_TABLE_N * (BLMM_PV_STRIDE / 2) + NT - 1) / NT;
 #pragma unroll
   for (int u = 0; u < PER; ++u) {
     const int i = (int)threadIdx.x + NT * u;
-    if (i < BLMM_PV_TABLE_N * 4) lds[i] = st.v[u];
+    if (i < BLMM_PV_TABLE_N * (BLMM_PV_STRIDE / 2)) lds[i] = st.v[u];
   }
 }
 __device__ __forceinline__ double fast_log10p1(double lod, const dpair* __restrict__ pv) {
@@ -199,7 +199,7 @@ __device__ __forceinline__ double fast_log10p1(double lod, const dpair* __restri
   const uint32_t b = first ? 0u : 1u + ((hi - BLMM_PV_HI0) >> BLMM_PV_SHIFT);
   const double c = first ? 0.0 : __hiloint2double((int)((hi & ~((1u << BLMM_PV_SHIFT) - 1u)) | (1u << (BLMM_PV_SHIFT - 1))), 0);
   const double s = x - c;
-  const dpair* e = pv + 4 * b;
+  const dpair* e = pv + (BLMM_PV_STRIDE / 2) * b;
   const dpair c01 = e[0], c23 = e[1], c45 = e[2], c67 = e[3];
   double w = c67[1];
   w = fma(w, s, c67[0]);

@@ -126,7 +126,8 @@ __global__ void __launch_bounds__(256) k_scan_qr(int n, int c, const double* __r
                                                  const double* __restrict__ Xt, int64_t ldx, int64_t p,
                                                  const double* __restrict__ Z0, const double* __restrict__ lam,
                                                  const double* __restrict__ h2v, const int* __restrict__ list,
-                                                 double* slab, double* __restrict__ L, int64_t ldL, int64_t* stat) {
+                                                 double* slab, double* __restrict__ L, int64_t ldL, int64_t* stat,
+                                                 double* __restrict__ Pv, int64_t ldPv, const double* __restrict__ pvtab) {
   extern __shared__ __attribute__((aligned(16))) double sh[];
   __shared__ double s_red[4 * 8];
   const int64_t cnt = stat[ST_ILLCOND];
@@ -206,6 +207,7 @@ __global__ void __launch_bounds__(256) k_scan_qr(int n, int c, const double* __r
       double lod = scale * log10(u1);
       if (!(u1 > 0.0)) lod = (u1 == 0.0) ? INFINITY : NAN;
       L[j * ldL + i] = lod;
+      if (Pv) Pv[j * ldPv + i] = fast_log10p1(lod, reinterpret_cast<const dpair*>(pvtab));   // the fused `output_pvals` column
     }
   }
 }
@@ -802,10 +804,10 @@ int launch_scan_qr(blmm_ctx* ctx, const NullModel& nm, const double* Yt, int64_t
   }
   if (nm.c <= 8) {
     if (lds > 48 * 1024) BLMM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_scan_qr<8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(k_scan_qr<8>, dim3(grid), dim3(256), lds, ctx->stream, nm.n, nm.c, Yt, ldy, Xt, ldx, p, Z0, lam, h2, list, slab, L, ldL, stat);
+    hipLaunchKernelGGL(k_scan_qr<8>, dim3(grid), dim3(256), lds, ctx->stream, nm.n, nm.c, Yt, ldy, Xt, ldx, p, Z0, lam, h2, list, slab, L, ldL, stat, ctx->pv_cur, ctx->pv_cur_ld, ptr<double>(ctx->pvtab));
   } else {
     if (lds > 48 * 1024) BLMM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_scan_qr<32>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(k_scan_qr<32>, dim3(grid), dim3(256), lds, ctx->stream, nm.n, nm.c, Yt, ldy, Xt, ldx, p, Z0, lam, h2, list, slab, L, ldL, stat);
+    hipLaunchKernelGGL(k_scan_qr<32>, dim3(grid), dim3(256), lds, ctx->stream, nm.n, nm.c, Yt, ldy, Xt, ldx, p, Z0, lam, h2, list, slab, L, ldL, stat, ctx->pv_cur, ctx->pv_cur_ld, ptr<double>(ctx->pvtab));
   }
   KCHECK();
   return BLMM_OK;

@@ -1114,7 +1114,8 @@ __global__ void __launch_bounds__(256) k_scan_fix(NullModel nm, const double* __
                                                    const double* __restrict__ Z0, const double* __restrict__ lam,
                                                    const double* __restrict__ h2v, const int* __restrict__ flag_list,
                                                    const int* __restrict__ perm, double* __restrict__ L, int64_t ldL,
-                                                   int64_t* stat) {
+                                                   int64_t* stat, double* __restrict__ Pv, int64_t ldPv,
+                                                   const double* __restrict__ pvtab) {
   constexpr int KC = 256, NL = C * (C + 1) / 2;
   __shared__ double s_a0[KC], s_w[KC], s_wz[C][KC];
   const int64_t cnt = stat[10];
@@ -1171,6 +1172,7 @@ __global__ void __launch_bounds__(256) k_scan_fix(NullModel nm, const double* __
       double lod = scale * log10(u1);
       if (!(u1 > 0.0)) { lod = (u1 == 0.0) ? INFINITY : NAN; nnan += (u1 != 0.0); }
       L[jt * ldL + i] = lod;
+      if (Pv) Pv[jt * ldPv + i] = fast_log10p1(lod, reinterpret_cast<const dpair*>(pvtab));   // the fused `output_pvals` column
     }
   }
   if (nnan) atomicAdd((unsigned long long*)&stat[ST_NAN_LOD], (unsigned long long)nnan);
@@ -1358,7 +1360,7 @@ int launch_scan_fix(blmm_ctx* ctx, const NullModel& nm, const double* Xt, int64_
                     const int* flag_list, const int* perm, double* L, int64_t ldL, int64_t* stat) {
   if (p <= 0) return BLMM_OK;
   const unsigned grid = (unsigned)(8 * (ctx->num_cus > 0 ? ctx->num_cus : 256));
-#define FX(C) hipLaunchKernelGGL(k_scan_fix<C>, dim3(grid), dim3(256), 0, ctx->stream, nm, Xt, ldx, p, P0, Ls, ldp, Z0, lam, h2, flag_list, perm, L, ldL, stat)
+#define FX(C) hipLaunchKernelGGL(k_scan_fix<C>, dim3(grid), dim3(256), 0, ctx->stream, nm, Xt, ldx, p, P0, Ls, ldp, Z0, lam, h2, flag_list, perm, L, ldL, stat, ctx->pv_cur, ctx->pv_cur_ld, ptr<double>(ctx->pvtab))
   switch (nm.c) {
     case 1: FX(1); break;
     case 2: FX(2); break;

@@ -5,7 +5,9 @@
 //   * permutation thresholds    quantiles of the per-permutation maxima, get_thresholds,
 //                               src/analysis_helpers/single_trait_analysis.jl:13-23
 #include "blmm_internal.h"
+#include "fastmath.h"
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 
 namespace blmm {
@@ -68,8 +70,29 @@ __global__ void __launch_bounds__(256) k_lod2log10p(const double* __restrict__ L
   for (int64_t j = blockIdx.y; j < m; j += gridDim.y) P[j * ldP + i] = lod_to_log10p(L[j * ldL + i], df);
 }
 
+// One degree of freedom (the default of `output_pvals`): the bucketed-polynomial form of fastmath.h (table in LDS), ~20 fp64
+// operations per value -- the pass is bound by its 16 B/value of HBM traffic, where the erfc / erfcx / log route above costs ~150.
+__global__ void __launch_bounds__(256) k_lod2log10p1(const double* __restrict__ L, int64_t p, int64_t m, int64_t ldL,
+                                                     const double* __restrict__ pvtab, double* __restrict__ P, int64_t ldP) {
+  __shared__ dpair s_pv[BLMM_PV_TABLE_N * (BLMM_PV_STRIDE / 2)];
+  const dpair* g = reinterpret_cast<const dpair*>(pvtab);
+  for (int i = threadIdx.x; i < BLMM_PV_TABLE_N * (BLMM_PV_STRIDE / 2); i += 256) s_pv[i] = g[i];
+  __syncthreads();
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= p) return;
+  for (int64_t j = blockIdx.y; j < m; j += gridDim.y) P[j * ldP + i] = fast_log10p1(L[j * ldL + i], s_pv);
+}
+
 int launch_lod2log10p(blmm_ctx* ctx, const double* dL, int64_t p, int64_t m, int64_t ldL, int df, double* dP, int64_t ldP) {
   if (p <= 0 || m <= 0) return BLMM_OK;
+  static const bool exact_route = getenv("BLMM_PVAL_LIBM") && getenv("BLMM_PVAL_LIBM")[0] == '1';   // A/B: erfc / erfcx / log for df = 1 too
+  if (df == 1 && ctx->pvtab.p && !exact_route) {
+    // few, long columns walks: the table is staged once per workgroup
+    dim3 grid1((unsigned)((p + 255) / 256), (unsigned)(m < 64 ? m : 64));
+    hipLaunchKernelGGL(k_lod2log10p1, grid1, dim3(256), 0, ctx->stream, dL, p, m, ldL, ptr<double>(ctx->pvtab), dP, ldP);
+    KCHECK();
+    return BLMM_OK;
+  }
   dim3 grid((unsigned)((p + 255) / 256), (unsigned)(m < 4096 ? m : 4096));
   hipLaunchKernelGGL(k_lod2log10p, grid, dim3(256), 0, ctx->stream, dL, p, m, ldL, df, dP, ldP);
   KCHECK();
@@ -240,6 +263,12 @@ int blmm_last_log10p(blmm_ctx* ctx, int64_t chisq_df, double* P_out) {
   BLMM_HIP(hipSetDevice(ctx->device));
   const int64_t p = ctx->last_p, m = ctx->last_m;
   int rc;
+  if (ctx->last_P && ctx->last_P_df == chisq_df && ctx->last_P_ld == p) {
+    // the call that left L also wrote -log10 p (blmm_set_log10p_output with a library-owned buffer): nothing to compute
+    if ((rc = copy_to_host(ctx, P_out, const_cast<double*>(ctx->last_P), sizeof(double) * (size_t)p * m))) return rc;
+    BLMM_HIP(hipStreamSynchronize(ctx->stream));
+    return BLMM_OK;
+  }
   if ((rc = ensure(ctx, ctx->altbuf, sizeof(double) * (size_t)(p > 0 ? p : 1) * (size_t)(m > 0 ? m : 1)))) return rc;
   if ((rc = launch_lod2log10p(ctx, ctx->last_L, p, m, p, (int)chisq_df, ptr<double>(ctx->altbuf), p))) return rc;
   if ((rc = copy_to_host(ctx, P_out, ctx->altbuf.p, sizeof(double) * (size_t)p * m))) return rc;

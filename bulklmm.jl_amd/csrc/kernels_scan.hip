@@ -158,7 +158,7 @@ __device__ __forceinline__ void tile_of32(uint32_t id, uint32_t ntile_t, uint32_
 // MORE (exact mode, c > CFAST): the covariate panels beyond the first CFAST are contracted CFAST at a time ahead of the main
 // loop and folded into the Sxx accumulator as -u_q^2 (an MFMA accumulates on top of whatever its accumulator holds), so the
 // register budget does not grow with c; the marker tile is re-read from L2 once per chunk.
-template <int NX, int MB, int NB, bool TABLE, int W2, bool PERM = false, bool MORE = false>
+template <int NX, int MB, int NB, bool TABLE, int W2, bool PERM = false, bool MORE = false, bool PV = false>
 __global__ void __launch_bounds__(64 * W2 * W2, 2) k_scan(ScanArgs a, int ntile_i, int64_t nwg) {
   constexpr int NP = 1 + NX;  // A-side panels consumed
   constexpr int NT = 64 * W2 * W2;
@@ -166,6 +166,9 @@ __global__ void __launch_bounds__(64 * W2 * W2, 2) k_scan(ScanArgs a, int ntile_
   static_assert(!MORE || (!TABLE && NX == 1 + CFAST), "covariate chunks: exact mode with all CFAST in-loop panels");
   __shared__ dpair s_lod[BLMM_LOD_TABLE_N];
   __shared__ int s_perm[PERM ? 16 * W2 * MB : 1];
+  // PV: -log10 p (one degree of freedom) as a second output of the epilogue (`output_pvals`, src/bulkscan.jl:154-157) -- the LOD
+  // never travels to HBM and back for it (fastmath.h: fast_log10p1)
+  __shared__ dpair s_pv[PV ? BLMM_PV_TABLE_N * (BLMM_PV_STRIDE / 2) : 1];
   // the LOD table (read after the K loop; the barrier sits right before the epilogue): its loads go out first and are written
   // to LDS once the tile arithmetic is done and the first fragment loads are in flight -- one exposed round trip per workgroup
   // instead of two or three.  (64-thread workgroups, an A/B variant, would need 33 entries per thread: plain copy loop.)
@@ -205,6 +208,10 @@ __global__ void __launch_bounds__(64 * W2 * W2, 2) k_scan(ScanArgs a, int ntile_
     }
     if constexpr (PERM) {
       if (threadIdx.x < 16 * W2 * MB) s_perm[threadIdx.x] = perm_st;
+    }
+    if constexpr (PV) {
+      const dpair* g = reinterpret_cast<const dpair*>(a.pvtab);
+      for (int i = threadIdx.x; i < BLMM_PV_TABLE_N * (BLMM_PV_STRIDE / 2); i += NT) s_pv[i] = g[i];
     }
 #pragma unroll
     for (int q = 0; q < NP; ++q)
@@ -349,6 +356,12 @@ __global__ void __launch_bounds__(64 * W2 * W2, 2) k_scan(ScanArgs a, int ntile_
           if (!lod_fast_ok(uv[nb])) out[nb] = lod_out_of_range(uv[nb], s_lod, lp, scale, i0 + mslot<NB>(r, nb) < a.p, &nnan);
       }
       store_m<NB>(a.L + trait * a.ldL + i0, r, out, a.p - i0);
+      if constexpr (PV) {
+        double pv[NB];
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) pv[nb] = fast_log10p1(out[nb], s_pv);
+        store_m<NB>(a.Pv + trait * a.ldPv + i0, r, pv, a.p - i0);
+      }
     }
   if (nnan) atomicAdd((unsigned long long*)&a.stat[ST_NAN_LOD], (unsigned long long)nnan);
 }
@@ -362,7 +375,10 @@ static int launch_scan_t(blmm_ctx* ctx, const ScanArgs& a) {
   const int64_t nwg = ntile_t * ntile_i;
   if (nwg <= 0) return BLMM_OK;
   if (nwg > 0x7fffffffLL) return fail(ctx, BLMM_ERR_INVALID, "problem too large for one launch");
-  hipLaunchKernelGGL((k_scan<NX, MB, NB, TABLE, W2, false, MORE>), dim3((unsigned)nwg), dim3(64 * W2 * W2), 0, ctx->stream, a, (int)ntile_i, nwg);
+  if (a.Pv)
+    hipLaunchKernelGGL((k_scan<NX, MB, NB, TABLE, W2, false, MORE, true>), dim3((unsigned)nwg), dim3(64 * W2 * W2), 0, ctx->stream, a, (int)ntile_i, nwg);
+  else
+    hipLaunchKernelGGL((k_scan<NX, MB, NB, TABLE, W2, false, MORE>), dim3((unsigned)nwg), dim3(64 * W2 * W2), 0, ctx->stream, a, (int)ntile_i, nwg);
   KCHECK();
   return BLMM_OK;
 }
@@ -397,7 +413,7 @@ __device__ unsigned long long g_lr_diag[24];   // per class {sum of workgroup cy
 // per class (0: shared-weights tiles, 1: rank-R tiles) sums over the waves of {K loops, barrier wait, epilogue} cycles and the count
 __device__ unsigned long long g_lr_phase[8];
 #endif
-template <int C, int MB, int NB>
+template <int C, int MB, int NB, bool PV = false>
 __global__ void __launch_bounds__(256, 2) k_scan_lr(LrArgs la, int ntile_i, int64_t nwg) {
   const ScanArgs& a = la.s;
 #ifdef LR_DIAG
@@ -412,6 +428,7 @@ __global__ void __launch_bounds__(256, 2) k_scan_lr(LrArgs la, int ntile_i, int6
   __shared__ dpair s_lod[BLMM_LOD_TABLE_N];
   __shared__ double s_li[NL][TW];           // packed L_j^-1 of the tile's traits (read in the epilogue)
   __shared__ int s_perm[TW];                // their trait numbers (-1: padding column)
+  __shared__ dpair s_pv[PV ? BLMM_PV_TABLE_N * (BLMM_PV_STRIDE / 2) : 1];   // PV: -log10 p as a second output (see k_scan)
   // The LOD table's loads go out first: nothing below depends on them until the LDS stores in front of the K loops, so their
   // round trip runs under the tile arithmetic and the first fragment loads (round 2 staged the table, then L^-1 / perm, then
   // fetched the first fragments: three exposed round trips at the head of every workgroup).
@@ -541,6 +558,10 @@ __global__ void __launch_bounds__(256, 2) k_scan_lr(LrArgs la, int ntile_i, int6
       if (e < NL * TW) s_li[e / TW][e % TW] = li_st[u];
     }
     if (threadIdx.x < TW) s_perm[threadIdx.x] = perm_st;
+    if constexpr (PV) {
+      const dpair* g = reinterpret_cast<const dpair*>(a.pvtab);
+      for (int i = threadIdx.x; i < BLMM_PV_TABLE_N * (BLMM_PV_STRIDE / 2); i += 256) s_pv[i] = g[i];
+    }
 #pragma unroll
     for (int q = 0; q < NACC; ++q)
 #pragma unroll
@@ -665,6 +686,12 @@ __global__ void __launch_bounds__(256, 2) k_scan_lr(LrArgs la, int ntile_i, int6
         if (out[0] + out[1] + out[2] + out[3] != 1.2345e-300) continue;
 #endif
         store_m<NB>(a.L + trait * a.ldL + i0, r, out, a.p - i0);
+        if constexpr (PV) {
+          double pv[NB];
+#pragma unroll
+          for (int nb = 0; nb < NB; ++nb) pv[nb] = fast_log10p1(out[nb], s_pv);
+          store_m<NB>(a.Pv + trait * a.ldPv + i0, r, pv, a.p - i0);
+        }
       }
   };
   if (shared_w) epilogue(std::true_type{}); else epilogue(std::false_type{});
@@ -709,7 +736,10 @@ static int launch_scan_lr_t(blmm_ctx* ctx, const LrArgs& la) {
   (void)hipMemcpyToSymbol(HIP_SYMBOL(g_lr_phase), zp, sizeof(zp));
   (void)hipStreamSynchronize(ctx->stream);
 #endif
-  hipLaunchKernelGGL((k_scan_lr<C, MB, NB>), dim3((unsigned)nwg), dim3(256), 0, ctx->stream, la, (int)ntile_i, nwg);
+  if (a.Pv)
+    hipLaunchKernelGGL((k_scan_lr<C, MB, NB, true>), dim3((unsigned)nwg), dim3(256), 0, ctx->stream, la, (int)ntile_i, nwg);
+  else
+    hipLaunchKernelGGL((k_scan_lr<C, MB, NB>), dim3((unsigned)nwg), dim3(256), 0, ctx->stream, la, (int)ntile_i, nwg);
 #ifdef LR_PHASE
   (void)hipStreamSynchronize(ctx->stream);
   (void)hipMemcpyFromSymbol(zp, HIP_SYMBOL(g_lr_phase), sizeof(zp));
@@ -751,7 +781,10 @@ int launch_scan_shared(blmm_ctx* ctx, const ScanArgs& a) {
   if (ntile_t * ntile_i <= 0) return BLMM_OK;
   const int64_t nwg = (ntile_t * ntile_i + 8 + 7) / 8 * 8;              // every XCD's share rounds up
   if (nwg > 0x7fffffffLL) return fail(ctx, BLMM_ERR_INVALID, "problem too large for one launch");
-  hipLaunchKernelGGL((k_scan<0, MB, NB, true, W2, true>), dim3((unsigned)nwg), dim3(64 * W2 * W2), 0, ctx->stream, a, (int)ntile_i, nwg);
+  if (a.Pv)
+    hipLaunchKernelGGL((k_scan<0, MB, NB, true, W2, true, false, true>), dim3((unsigned)nwg), dim3(64 * W2 * W2), 0, ctx->stream, a, (int)ntile_i, nwg);
+  else
+    hipLaunchKernelGGL((k_scan<0, MB, NB, true, W2, true>), dim3((unsigned)nwg), dim3(64 * W2 * W2), 0, ctx->stream, a, (int)ntile_i, nwg);
   KCHECK();
   return BLMM_OK;
 }

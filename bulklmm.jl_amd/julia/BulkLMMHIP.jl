@@ -181,6 +181,12 @@ function bulkscan(Y::Array{Float64, 2}, G::Array{Float64, 2}, Covar::Array{Float
                   reml::Bool = false, optim_interval::Int64 = 1,
                   decomp_scheme::String = "eigen",
                   output_pvals::Bool = false, chisq_df::Int64 = 1)
+    # `output_pvals`: asked for before the scan, so that the scan kernels write -log10 p from their epilogues (chisq_df = 1,
+    # null-* methods; otherwise the column pass runs inside the call) into a buffer of the context that _last_log10p hands out
+    if output_pvals && method in ("null-exact", "null-grid", "alt-grid")
+        check(ccall((:blmm_set_log10p_output, libblmm), Cint, (Ptr{Cvoid}, Ptr{Float64}, Int64, Int64),
+                    context(), Ptr{Float64}(C_NULL), Int64(0), chisq_df))
+    end
     if method == "null-exact"
         res = bulkscan_null(Y, G, Covar, K; addIntercept = addIntercept, weights = weights, prior_variance = prior_variance,
                             prior_sample_size = prior_sample_size, reml = reml, optim_interval = optim_interval,

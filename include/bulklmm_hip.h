@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define BLMM_VERSION 202 /* 0.2.2: blmm_status.n_h2_boundary / n_h2_multimodal / n_illcond_rescan (appended), BLMM_FLAG_H2_AUDIT;
+#define BLMM_VERSION 203 /* 0.2.2: blmm_status.n_h2_boundary / n_h2_multimodal / n_illcond_rescan (appended), BLMM_FLAG_H2_AUDIT;
                             201: lowrank_shared, readers, blmm_scan_alt; 200: lowrank_fallback, BLMM_STREAM_NULL, multi-GPU */
 
 typedef struct blmm_ctx blmm_ctx;
@@ -273,10 +273,18 @@ int blmm_lod_colmax_dev(blmm_ctx* ctx, const double* dL, int64_t p, int64_t m, i
                         int64_t* dargmax_out);
 
 /* ---- -log10 p-values: lod2log10p.(L, chisq_df)  (src/util.jl:199-206; `output_pvals`, src/bulkscan.jl:154-157,
- * src/scan.jl:353-355).  df = 1 through erfc / erfcx, general df through ln Q(df/2, .) in log space. */
+ * src/scan.jl:353-355).  df = 1: LOD + x w(x), x = sqrt(LOD ln 10), w = -log10(erfcx(x)) / x from bucketed polynomials
+ * (4e-15 relative; BLMM_PVAL_LIBM=1: erfc / erfcx / log instead); general df through ln Q(df/2, .) in log space. */
 int blmm_lod2log10p(blmm_ctx* ctx, const double* L, int64_t p, int64_t m, int64_t chisq_df, double* P_out);
 int blmm_lod2log10p_dev(blmm_ctx* ctx, const double* dL, int64_t p, int64_t m, int64_t ldL, int64_t chisq_df, double* dP_out,
                         int64_t ldP);
+/* `output_pvals = true` of bulkscan (src/bulkscan.jl:154-157) INSIDE the scan: the next blmm_bulkscan / blmm_bulkscan_dev /
+ * blmm_bulkscan_prerotated_dev call of this context also writes -log10 p, p x m with leading dimension ldP, into the DEVICE
+ * buffer dP_out -- or, dP_out == NULL, into a buffer of the context that blmm_last_log10p then hands out without computing
+ * anything.  chisq_df = 1 with a null-* method: a second output of the scan kernels' epilogues (the LOD matrix is not read
+ * back from HBM for it); alt-grid or another chisq_df: the column pass above, run inside the call.  One-shot: the request is
+ * consumed by that call; chisq_df = 0 withdraws it. */
+int blmm_set_log10p_output(blmm_ctx* ctx, double* dP_out, int64_t ldP, int64_t chisq_df);
 /* ---- threshold filter: every (marker, trait) with LOD > thr as a sparse triplet (0-based int32 indices), the count on
  * the device (README.md:354-359).  At most `cap` triplets are stored, *count is the total found; order unspecified. */
 int blmm_lod_threshold(blmm_ctx* ctx, const double* L, int64_t p, int64_t m, double thr, int64_t cap, int32_t* i_out,

@@ -189,7 +189,7 @@ def test_every_ccall_matches_its_prototype():
     need = {"blmm_create", "blmm_kinship", "blmm_kinship_rounded", "blmm_bulkscan", "blmm_bulkscan_multi", "blmm_scan_perms",
             "blmm_scan_perms_f32", "blmm_scan_alt", "blmm_lod2log10p", "blmm_last_log10p", "blmm_get_thresholds", "blmm_lod_threshold",
             "blmm_lod_colmax", "blmm_host_alloc", "blmm_host_free", "blmm_host_register", "blmm_host_unregister", "blmm_read_csv",
-            "blmm_read_he", "blmm_create_multi", "blmm_destroy_multi", "blmm_multi_ndev"}
+            "blmm_read_he", "blmm_create_multi", "blmm_destroy_multi", "blmm_multi_ndev", "blmm_set_log10p_output"}
     assert need <= seen, sorted(need - seen)
 
 

@@ -1111,3 +1111,48 @@ def test_h2_boundary_counter_and_profile_audit(blmm):
     multi = ((up & dn).sum(axis=0) >= 2)
     # near-ties against the slack may fall on either side: the device evaluates Ell with its own rounding
     assert abs(sta.n_h2_multimodal - int(multi.sum())) <= 2, (sta.n_h2_multimodal, int(multi.sum()))
+
+
+@pytest.mark.parametrize("route", ["lowrank-c1", "lowrank-c3", "exact-c5", "exact-c11", "null-grid", "alt-grid", "df3", "fix-rescan", "qr-rescan"])
+def test_output_pvals_written_by_the_scan(blmm, route, monkeypatch):
+    """`output_pvals = true` (src/bulkscan.jl:154-157) asked for before the scan: with one degree of freedom and a null-* method
+    every kernel that writes a LOD column writes -log10 p beside it (k_scan_lr, the table kernel of the shared-weights class and
+    of null-grid, the exact kernel for c >= 4, the per-trait re-scans of the two guards); alt-grid and other degrees of freedom
+    run the column pass inside the call.  Either way the matrix equals lod2log10p.(L, df) of the L the same call returned --
+    against the library's own column pass to rounding, against the oracle (SciPy chi2.logsf) to 1e-10."""
+    ncov = {"lowrank-c3": 2, "exact-c5": 4, "exact-c11": 10, "qr-rescan": 2}.get(route, 0)
+    Y, G, K, Cov = make_data(p=333, m=150, seed=7300 + ncov, ncov=ncov)
+    method = route if route in ("null-grid", "alt-grid") else "null-exact"
+    df = 3 if route == "df3" else 1
+    if route == "fix-rescan":
+        monkeypatch.setenv("BLMM_LR_TOL", "0")          # every trait through k_scan_fix
+    if route == "qr-rescan":
+        monkeypatch.setenv("BLMM_ILLCOND_RHO", "2")     # every trait through k_scan_qr
+    r = blmm.bulkscan(Y, G, K, Cov, method=method, output_pvals=True, chisq_df=df)
+    P, L = r["log10Pvals_mat"], r["L"]
+    assert P.shape == L.shape == (333, 150) and r["Chisq_df"] == df
+    own = blmm.lod2log10p(L, df)
+    assert np.all(np.abs(P - own) <= 1e-14 * np.abs(own) + 1e-300), float(np.max(np.abs(P - own)))
+    ref = O.lod2log10p(L, df)
+    fin = np.isfinite(ref)
+    assert fin.all() and np.all(np.abs(P - ref) <= 1e-10 * np.abs(ref) + 1e-14)
+    # and the scan's own output is what it is without the second output
+    monkeypatch.setenv("BLMM_PVAL_FUSED", "0")
+    r0 = blmm.bulkscan(Y, G, K, Cov, method=method, output_pvals=True, chisq_df=df)
+    assert np.array_equal(r0["L"], L) and np.all(np.abs(r0["log10Pvals_mat"] - P) <= 1e-14 * np.abs(P) + 1e-300)
+
+
+def test_output_pvals_request_is_one_shot(blmm):
+    """blmm_set_log10p_output is consumed by exactly one bulkscan call, can be withdrawn, and checks its arguments."""
+    import ctypes as C
+    lib = blmm.load()
+    Y, G, K, _ = make_data(p=300, m=40, seed=7400)
+    ctx = blmm.Context(0)
+    r1 = blmm.bulkscan(Y, G, K, method="null-exact", output_pvals=True, ctx=ctx)
+    r2 = blmm.bulkscan(Y, G, K, method="null-exact", ctx=ctx)              # the request does not carry over
+    assert "log10Pvals_mat" not in r2 and np.array_equal(r1["L"], r2["L"])
+    assert lib.blmm_set_log10p_output(ctx.h, None, 0, -1) != 0
+    assert lib.blmm_set_log10p_output(ctx.h, None, 0, 1) == 0 and lib.blmm_set_log10p_output(ctx.h, None, 0, 0) == 0   # withdrawn
+    r3 = blmm.bulkscan(Y, G, K, method="null-exact", ctx=ctx)
+    assert np.array_equal(r3["L"], r1["L"])
+    ctx.close()
