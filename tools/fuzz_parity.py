@@ -17,9 +17,11 @@ for case in range(ncases):
     kkind = str(rng.choice(["markers", "markers", "one-marker", "few-markers", "duplicated-individuals"]))
     p = int(rng.choice([1, 2, 7, 63, 64, 65, 127, 128, 129, 255, 256, 257, 300]))
     m = int(rng.choice([1, 2, 15, 16, 17, 63, 64, 65, 70, 128, 129, 1030, 2100]))
-    ncov = int(rng.choice([0, 0, 1, 2, 3, 4, 5, 7]))
+    ncov = int(rng.choice([0, 0, 1, 2, 3, 4, 5, 7, 8, 11, 19, 31]))      # beyond 7: the run-time-c kernels (kernels_dyn.hip)
     if ncov + 2 >= n: ncov = 0
     method = str(rng.choice(["null-exact", "null-exact", "null-grid", "alt-grid", "perms", "scan-alt"]))
+    if ncov > 7 and method == "scan-alt": ncov = 7                      # scan_alt: at most 8 covariates incl. the intercept
+    if ncov > 7 and n < 3 * ncov: ncov = 7                              # keep the null design comfortably full rank
     oi = int(rng.choice([1, 1, 1, 2, 3]))
     reml = bool(rng.random() < 0.25)
     svd = bool(rng.random() < 0.15)
@@ -72,6 +74,10 @@ for case in range(ncases):
             # strict for every trait: the h2 -> 1 boundary traits with badly conditioned weighted covariates (case 237 of seed
             # 201: n = 13, 8 null covariates, cond 2e4) are re-scanned with an orthogonalised projection (kernels_dyn.hip)
             assert_lod_close(got.L, pin.L)
+            if case % 3 == 0:       # `output_pvals` written by the scan itself (low-rank, exact, dyn and re-scan kernels alike)
+                rp = blmm.bulkscan(Y, G, K, Cov, method="null-exact", weights=w, optim_interval=oi, output_pvals=True, **kw)
+                refp = O.lod2log10p(rp["L"], 1)
+                assert np.array_equal(rp["L"], got.L) and np.all(np.abs(rp["log10Pvals_mat"] - refp) <= 1e-10 * np.abs(refp) + 1e-14), "output_pvals"
         elif method == "perms":
             nperms = int(rng.choice([1, 5, 64, 130]))
             pidx = O.make_perm_idx(n, nperms, case)
