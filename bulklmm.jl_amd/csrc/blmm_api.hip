@@ -262,6 +262,14 @@ int prepare_eigen(blmm_ctx* ctx, const blmm_opts* o, int64_t n, const double* dC
     else if (rc != BLMM_ERR_UNSUPPORTED) return rc;
   }
   if (!done) {
+    // n <= 124: the fast path first (tridiagonalisation, Sturm multi-section, twisted factorisation; kernels_eig.hip: k_eigf_*).
+    // It checks its own result on the device; the Jacobi behind it is a no-op when the checks passed and the whole solver when
+    // they did not (numerically repeated eigenvalues).  BLMM_EIGEN=jacobi: the Jacobi alone (A/B timing, tests).
+    const bool want_fast = !(eig_env && std::strcmp(eig_env, "jacobi") == 0) && n >= 3 && n <= eig_fast_max_n();
+    if (want_fast) {
+      rc = launch_eig_fast(ctx, ptr<double>(ctx->Ks), (int)n, ptr<double>(ctx->lraw), ptr<double>(ctx->V), P.stat);
+      if (rc != BLMM_OK && rc != BLMM_ERR_UNSUPPORTED) return rc;
+    }
     if ((rc = launch_jacobi(ctx, ptr<double>(ctx->Ks), ptr<double>(ctx->V), (int)n, ptr<double>(ctx->lraw), P.stat))) return rc;
   }
   if ((rc = launch_post_eigen(ctx, ptr<double>(ctx->lraw), evec, ptr<double>(ctx->Zs), dweights, (int)n, c,

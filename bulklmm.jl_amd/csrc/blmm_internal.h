@@ -25,7 +25,8 @@ constexpr int TILE_I = 128;      // markers per workgroup tile of the scan kerne
 constexpr int NSTAT = 24;        // device status counters ([6],[7]: eigensolver clocks, [8]: weight-basis rank, [9]: its residual, [10]: traits re-scanned full rank, [11]: eigensolver abort code, [12..15]: shared-weights traits / the others of the two panel regions (k_lr_classify), [16..18]: StatIdx below)
 
 enum StatIdx { ST_NEG_EIG = 0, ST_NONPOS_W = 1, ST_ZERO_NORM = 2, ST_NAN_LOD = 3, ST_BRENT_MAXIT = 4, ST_JACOBI_SWEEPS = 5,
-               ST_H2_BOUNDARY = 16, ST_H2_MULTIMODAL = 17, ST_ILLCOND = 18 };
+               ST_H2_BOUNDARY = 16, ST_H2_MULTIMODAL = 17, ST_ILLCOND = 18,
+               ST_EIG_FAST = 19 /* 1: the fast eigen path ran */, ST_EIG_BAD = 20 /* its largest check / bound, bits of a double: accepted up to 1.0 */ };
 
 inline int64_t round_up(int64_t x, int64_t q) { return (x + q - 1) / q * q; }
 
@@ -130,6 +131,8 @@ int launch_jacobi(blmm_ctx* ctx, double* A, double* V, int n, double* lraw, int6
 // kernels_eig.hip: tridiagonalisation + divide and conquer for n beyond the LDS Jacobi; A is not modified
 int launch_eig_dc(blmm_ctx* ctx, const double* A, int n, double* lraw, double* evec, int64_t* stat);
 int eig_dc_max_n(const blmm_ctx* ctx);
+int launch_eig_fast(blmm_ctx* ctx, const double* A, int n, double* lraw, double* evec, int64_t* stat);
+int eig_fast_max_n();
 int launch_eig_small(blmm_ctx* ctx, const double* A, int n, double* lraw, double* evec, int64_t* stat);
 int eig_small_max_n();
 int jacobi_lds_max_n();

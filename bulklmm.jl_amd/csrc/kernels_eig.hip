@@ -818,24 +818,69 @@ __global__ void __launch_bounds__(256) k_dc_gemm(DcWs w, int tiles_r) {
     }
 }
 
+// "badness" of a check as a monotone bit pattern: v / bound, NaN or negative counted as +Inf
+__device__ __forceinline__ void eigf_note(int64_t* stat, double v, double bound) {
+  const double q = (v >= 0.0 && bound > 0.0) ? v / bound : ((v == 0.0) ? 0.0 : INFINITY);
+  atomicMax(reinterpret_cast<unsigned long long*>(&stat[ST_EIG_BAD]), (unsigned long long)__double_as_longlong(q));
+}
+
 // ---------------------------------------------------------------------------------------------------------------------
 // 4. back-transformation U = H_0 H_1 ... H_(n-3) Z: reflectors applied in reverse order, each wave owns CPW columns of Z
 // in registers (rows lane, lane + 64, ...); the reflector of a step is staged in LDS for the workgroup.
 // ---------------------------------------------------------------------------------------------------------------------
 template <int NR, int CPW, int NT>
 __global__ void __launch_bounds__(NT) k_backtransform(const double* __restrict__ V, const double* __restrict__ tau, int n,
-                                                       double* __restrict__ Z) {
+                                                       double* __restrict__ Z, const double* __restrict__ Zt_chk,
+                                                       const double* __restrict__ Zc_chk, int64_t* __restrict__ stat_chk) {
   extern __shared__ __attribute__((aligned(16))) double sh[];   // 2 x n : double-buffered reflector
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwave = blockDim.x >> 6;
   const int c0 = (blockIdx.x * nwave + wave) * CPW;
+  // Behind k_eigf_pairs (NR = 2, CPW = 1, n <= 128): the wave's column a of Z comes from the PRISTINE copies the pairs kernel
+  // left (Zc column-major, Zt row-major; the result goes to Z).  Row a of E = Z'Z - I first -- its largest entry / 3e-8 ->
+  // stat[ST_EIG_BAD] --, then the symmetric first-order correction z_a <- z_a - (1/2) sum_b E_ab z_b: every workgroup corrects
+  // from the same uncorrected Z, together Z (I - E / 2), orthogonal to ~|E|^2.  On kinships |E| is ~4e-14 and the correction only
+  // takes the vectors from there to rounding level; it is what lets near-repeated eigenvalues through (|E| up to 3e-8).
   double z[CPW][NR];
-#pragma unroll
-  for (int c = 0; c < CPW; ++c)
-#pragma unroll
-    for (int q = 0; q < NR; ++q) {
-      const int r = lane + 64 * q;
-      z[c][q] = (c0 + c < n && r < n) ? Z[(size_t)(c0 + c) * n + r] : 0.0;
+  if (Zt_chk) {
+    const int a = c0;
+    double e0 = 0.0, e1 = 0.0;
+    if (a < n) {
+      double acc0 = 0.0, acc1 = 0.0;
+#pragma unroll 8
+      for (int i = 0; i < n; ++i) {               // (unrolled: the loads of eight rows in flight together, L2 round trips)
+        const double za = Zt_chk[(size_t)i * n + a];
+        acc0 = fma(za, (lane < n) ? Zt_chk[(size_t)i * n + lane] : 0.0, acc0);
+        acc1 = fma(za, (lane + 64 < n) ? Zt_chk[(size_t)i * n + lane + 64] : 0.0, acc1);
+      }
+      e0 = (lane < n) ? acc0 - ((lane == a) ? 1.0 : 0.0) : 0.0;
+      e1 = (lane + 64 < n) ? acc1 - ((lane + 64 == a) ? 1.0 : 0.0) : 0.0;
+      double bad = fmax(fabs(e0), fabs(e1));
+      if (!(acc0 == acc0) || !(acc1 == acc1)) bad = INFINITY;
+      bad = wmax(bad);
+      if (lane == 0) eigf_note(stat_chk, bad, 3e-8);
     }
+    double z0 = (a < n && lane < n) ? Zc_chk[(size_t)a * n + lane] : 0.0, z1 = (a < n && lane + 64 < n) ? Zc_chk[(size_t)a * n + lane + 64] : 0.0;
+    if (a < n) {
+      double c0v = 0.0, c1v = 0.0;
+#pragma unroll 8
+      for (int b = 0; b < n; ++b) {
+        const double eab = lane_bcast((b < 64) ? e0 : e1, b & 63);     // (b is wave-uniform)
+        c0v = fma(eab, (lane < n) ? Zc_chk[(size_t)b * n + lane] : 0.0, c0v);
+        c1v = fma(eab, (lane + 64 < n) ? Zc_chk[(size_t)b * n + lane + 64] : 0.0, c1v);
+      }
+      z0 = fma(-0.5, c0v, z0); z1 = fma(-0.5, c1v, z1);
+    }
+    z[0][0] = z0;
+    if constexpr (NR > 1) z[0][1] = z1;
+  } else {
+#pragma unroll
+    for (int c = 0; c < CPW; ++c)
+#pragma unroll
+      for (int q = 0; q < NR; ++q) {
+        const int r = lane + 64 * q;
+        z[c][q] = (c0 + c < n && r < n) ? Z[(size_t)(c0 + c) * n + r] : 0.0;
+      }
+  }
   const int nref = n - 2;
   // Reflectors are handled in groups of RB per barrier.  Group g = reflectors k = nref-1-RB*g ... (descending); a group is
   // read from global memory two iterations before its use (into registers) and written to LDS one iteration before, so
@@ -1091,38 +1136,19 @@ __device__ void small_merge(const SmallWs& w, int n, int lo, int mid, int hi, co
   __syncthreads();
 }
 
-__global__ void __launch_bounds__(1024) k_eig_small(const double* __restrict__ A, int n, double* __restrict__ lam_out,
-                                                    double* __restrict__ evec, double* __restrict__ Vg, int64_t* stat) {
-  extern __shared__ __attribute__((aligned(16))) double sh[];
-  const int t = threadIdx.x, NT = blockDim.x, lane = t & 63, wave = t >> 6, nwave = NT >> 6;
-  __shared__ int s_info[4];
-  __shared__ double s_sc[4];   // {tau, sc, akk, beta} of the current step
-  SmallWs w;
-  {
-    double* q = sh;
-    w.M1 = q; q += n * n; w.M2 = q; q += n * n;
-    w.sx = q; q += n; w.sv = q; q += n; w.sw = q; q += n; w.svp = q; q += n; w.swp = q; q += n;
-    w.part = q; q += 8 * 128;
-    w.d = q; q += n; w.e = q; q += n; w.tau = q; q += n; w.lamA = q; q += n; w.lamB = q; q += n;
-    w.dl = q; q += n; w.zl = q; q += n; w.zh = q; q += n; w.defld = q; q += n; w.lamnew = q; q += n;
-    w.rotc = q; q += n; w.rots = q; q += n; w.ds = q; q += n; w.zs = q; q += n; w.red = q; q += 16;
-    int* iq = reinterpret_cast<int*>(q);
-    w.colidx = iq; iq += n; w.deflcol = iq; iq += n; w.rota = iq; iq += n; w.rotb = iq; iq += n; w.posn = iq; iq += n;
-    w.posd = iq; iq += n; w.ord = iq; iq += n; w.srck = iq; iq += n; w.srci = iq; iq += n;
-  }
-#ifdef SYTRD_PROF
-  long long qf[6] = {0, 0, 0, 0, 0, 0}, qt0 = __builtin_amdgcn_s_memtime();
-#define QSTAMP(i) do { const long long t1__ = __builtin_amdgcn_s_memtime(); qf[i] += t1__ - qt0; qt0 = t1__; } while (0)
-#else
-#define QSTAMP(i) do { } while (0)
-#endif
+// Householder tridiagonalisation of the n x n matrix A inside ONE workgroup (n <= EIGS_NMAX), shared by k_eig_small and
+// k_eig_fast: A is copied to w.M1 (LDS, full symmetric storage; w.M2 zeroed), on return w.d / w.e / w.tau hold the diagonal, the
+// off-diagonal and the reflector scalars of T = H' A H and Vg[k * n + j] the reflector vectors (v[k + 1] = 1).  Column form of the
+// matrix-vector product (thread (j, rs) sums A[i][j] v[i] over its row subset: no cross-lane reduction), the rank-2 update of the
+// previous step applied in the same pass; wave 0 does the O(n) vector work of a step while the others wait: two barriers per step.
+__device__ void small_sytrd(const SmallWs& w, const double* __restrict__ A, int n, double* __restrict__ Vg, double* s_sc) {
+  const int t = threadIdx.x, NT = blockDim.x, lane = t & 63, wave = t >> 6;
   double amax = 0.0;
-  for (int e0 = t; e0 < n * n; e0 += NT) { const double a = A[e0]; w.M1[e0] = a; w.M2[e0] = 0.0; amax = fmax(amax, fabs(a)); }
+  for (int e0 = t; e0 < n * n; e0 += NT) { const double a = A[e0]; w.M1[e0] = a; if (w.M2) w.M2[e0] = 0.0; amax = fmax(amax, fabs(a)); }
   for (int j = t; j < n; j += NT) { w.svp[j] = 0.0; w.swp[j] = 0.0; }
   amax = block_max(amax, w.red);                 // (two barriers inside)
   const double s1_negl = (EPS * amax) * (EPS * amax);   // see k_sytrd: no reflector for a column negligible against |A|
   __syncthreads();
-  QSTAMP(0);
   // ---- 1. tridiagonalisation ----------------------------------------------------------------------------------------
   // wave 0 prepares step 0: x = column 0, its Householder vector
   auto householder = [&](int k, double akk) {   // wave 0: from sx[k+1 ..] -> sv, s_sc; reflector k -> Vg
@@ -1197,6 +1223,34 @@ __global__ void __launch_bounds__(1024) k_eig_small(const double* __restrict__ A
     }
     __syncthreads();
   }
+}
+
+__global__ void __launch_bounds__(1024) k_eig_small(const double* __restrict__ A, int n, double* __restrict__ lam_out,
+                                                    double* __restrict__ evec, double* __restrict__ Vg, int64_t* stat) {
+  extern __shared__ __attribute__((aligned(16))) double sh[];
+  const int t = threadIdx.x, NT = blockDim.x, lane = t & 63, wave = t >> 6, nwave = NT >> 6;
+  __shared__ int s_info[4];
+  __shared__ double s_sc[4];   // {tau, sc, akk, beta} of the current step
+  SmallWs w;
+  {
+    double* q = sh;
+    w.M1 = q; q += n * n; w.M2 = q; q += n * n;
+    w.sx = q; q += n; w.sv = q; q += n; w.sw = q; q += n; w.svp = q; q += n; w.swp = q; q += n;
+    w.part = q; q += 8 * 128;
+    w.d = q; q += n; w.e = q; q += n; w.tau = q; q += n; w.lamA = q; q += n; w.lamB = q; q += n;
+    w.dl = q; q += n; w.zl = q; q += n; w.zh = q; q += n; w.defld = q; q += n; w.lamnew = q; q += n;
+    w.rotc = q; q += n; w.rots = q; q += n; w.ds = q; q += n; w.zs = q; q += n; w.red = q; q += 16;
+    int* iq = reinterpret_cast<int*>(q);
+    w.colidx = iq; iq += n; w.deflcol = iq; iq += n; w.rota = iq; iq += n; w.rotb = iq; iq += n; w.posn = iq; iq += n;
+    w.posd = iq; iq += n; w.ord = iq; iq += n; w.srck = iq; iq += n; w.srci = iq; iq += n;
+  }
+#ifdef SYTRD_PROF
+  long long qf[6] = {0, 0, 0, 0, 0, 0}, qt0 = __builtin_amdgcn_s_memtime();
+#define QSTAMP(i) do { const long long t1__ = __builtin_amdgcn_s_memtime(); qf[i] += t1__ - qt0; qt0 = t1__; } while (0)
+#else
+#define QSTAMP(i) do { } while (0)
+#endif
+  small_sytrd(w, A, n, Vg, s_sc);
   QSTAMP(1);
   // ---- 2. leaves: implicit QL, one wave per leaf ---------------------------------------------------------------------
   int nl = 1;
@@ -1304,6 +1358,209 @@ __global__ void __launch_bounds__(1024) k_eig_small(const double* __restrict__ A
 #endif
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// 6. n <= 124, the FAST path (round 3), three launches:
+//   k_eigf_reduce (one workgroup)  Householder tridiagonalisation in LDS (small_sytrd); T cleaned of negligible off-diagonals,
+//                                  a copy scaled into [-1, 1], its Gershgorin interval -> a small global workspace
+//   k_eigf_pairs  (n workgroups)   workgroup k: eigenvalue k by multi-section on Sturm counts (512 points per round, 7-8 rounds
+//                                  down to the grid of doubles), then ITS eigenvector of T by the twisted factorisation -- no
+//                                  iteration, no orthogonalisation --, and the residual of the pair
+//   k_backtransform (checked form) first the orthogonality of the wave's column against all others and the symmetric first-order
+//                                  correction Z (I - (Z'Z - I) / 2) (from the copies the pairs kernel left), then U = H Z
+// Every step past the reduction is parallel over the eigenpairs, the one sequential dimension being the n of a Sturm count or of
+// a factorisation (a few thousand cycles), against the Jacobi's 9 x 79 dependent rounds on one CU.  The twisted vectors are as
+// good as the eigenvalues are separated: on full-rank kinships (BXD: smallest relative gap 4e-5) they come out orthogonal to
+// 4e-14.  Numerically repeated eigenvalues (rank-deficient K, duplicated individuals, identity, Wilkinson pairs) give parallel
+// vectors: the checks see it -- stat[ST_EIG_BAD] holds max(|z_a' z_b - delta_ab| / 3e-8, |T z - lambda z| / (2e-14 |T|)) as
+// the bit pattern of a double -- and the Jacobi launched behind the three kernels, a no-op otherwise, does the whole job.
+// ---------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ double quot_fast(double num, double den) {   // num / den, ~2 ulp; den = +-Inf -> 0
+  const double y = __builtin_amdgcn_rcp(den);
+  const double q = num * y;
+  const double r = fma(-den, q, num);
+  const double t = fma(r, y, q);
+  return (fabs(den) == INFINITY) ? 0.0 : t;
+}
+// Number of eigenvalues of the (scaled) tridiagonal matrix below x0 / x1: sign changes of the leading principal minors
+//   p_0 = 1, p_1 = d_0 - x, p_(i+1) = (d_i - x) p_i - e_(i-1)^2 p_(i-1)
+// (a vanishing p takes the sign opposite to its predecessor's).  Three fp64 operations per step where the quotient form of
+// LAPACK's dlaebz needs a division; the pair (p_(i-1), p_i) is rescaled by a power of two every 8 steps, and the matrix is
+// scaled to |d_i - x| <= 2 by the caller, so nothing overflows; ds, es2 in LDS (broadcast reads).
+__device__ __forceinline__ void sturm2(const double* __restrict__ ds, const double* __restrict__ es2, int n, double x0, double x1,
+                                       int& c0, int& c1) {
+  // (p, q) = two consecutive minors, the NEWER one alternating between the two registers (no moves); a minor that vanishes
+  // exactly needs no care unless the off-diagonal in front of it vanishes too (a decoupled block: the recurrence would stay at
+  // zero), which the rescaling block looks at every 8 steps -- counts that are off for a few steps on such matrices only cost
+  // the fast path its check (repeated eigenvalues: the Jacobi's job anyway)
+  double p0 = 1.0, p1 = 1.0, q0 = ds[0] - x0, q1 = ds[0] - x1;
+  unsigned s0 = (unsigned)__double2hiint(q0) >> 31, s1 = (unsigned)__double2hiint(q1) >> 31;
+  int i = 1;
+  for (; i + 1 < n; i += 2) {
+    const double da = ds[i], ea = es2[i - 1], db = ds[i + 1], eb = es2[i];
+    p0 = fma(da - x0, q0, -ea * p0); p1 = fma(da - x1, q1, -ea * p1);
+    s0 += (unsigned)(__double2hiint(p0) ^ __double2hiint(q0)) >> 31;
+    s1 += (unsigned)(__double2hiint(p1) ^ __double2hiint(q1)) >> 31;
+    q0 = fma(db - x0, p0, -eb * q0); q1 = fma(db - x1, p1, -eb * q1);
+    s0 += (unsigned)(__double2hiint(q0) ^ __double2hiint(p0)) >> 31;
+    s1 += (unsigned)(__double2hiint(q1) ^ __double2hiint(p1)) >> 31;
+    if ((i & 7) == 7) {
+      if (q0 == 0.0) q0 = -1e-100 * p0;
+      if (q1 == 0.0) q1 = -1e-100 * p1;
+      const int e0 = __builtin_amdgcn_frexp_exp(fmax(fabs(p0), fabs(q0))), e1 = __builtin_amdgcn_frexp_exp(fmax(fabs(p1), fabs(q1)));
+      p0 = __builtin_amdgcn_ldexp(p0, -e0); q0 = __builtin_amdgcn_ldexp(q0, -e0);
+      p1 = __builtin_amdgcn_ldexp(p1, -e1); q1 = __builtin_amdgcn_ldexp(q1, -e1);
+    }
+  }
+  if (i < n) {
+    const double da = ds[i], ea = es2[i - 1];
+    p0 = fma(da - x0, q0, -ea * p0); p1 = fma(da - x1, q1, -ea * p1);
+    s0 += (unsigned)(__double2hiint(p0) ^ __double2hiint(q0)) >> 31;
+    s1 += (unsigned)(__double2hiint(p1) ^ __double2hiint(q1)) >> 31;
+  }
+  c0 = (int)s0; c1 = (int)s1;
+}
+// global workspace behind the reflectors: tau | d | e | ds | es2 | {|T|, scale, lo, hi, ...} | Zt (n x n, row-major = transposed Z) |
+// Zc (n x n, column-major: eigenvector k of T in Zc[k * n ..])
+struct EigfWs { double *tau, *d, *e, *ds, *es2, *par, *Zt, *Zc; };
+__host__ __device__ inline EigfWs eigf_ws(double* base, int n) {
+  EigfWs q;
+  q.tau = base; q.d = base + n; q.e = base + 2 * n; q.ds = base + 3 * n; q.es2 = base + 4 * n; q.par = base + 5 * n; q.Zt = base + 5 * n + 8; q.Zc = q.Zt + (size_t)n * n;
+  return q;
+}
+
+__global__ void __launch_bounds__(1024) k_eigf_reduce(const double* __restrict__ A, int n, double* __restrict__ Vg, double* __restrict__ wsb,
+                                                      int64_t* stat) {
+  extern __shared__ __attribute__((aligned(16))) double sh[];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  __shared__ double s_sc[4];
+  SmallWs w = {};
+  {
+    double* q = sh;
+    w.M1 = q; q += n * n;
+    w.sx = q; q += n; w.sv = q; q += n; w.svp = q; q += n; w.swp = q; q += n;
+    w.part = q; q += 8 * 128;
+    w.d = q; q += n; w.e = q; q += n; w.tau = q; q += n; w.red = q; q += 16;
+  }
+  small_sytrd(w, A, n, Vg, s_sc);
+  const EigfWs g = eigf_ws(wsb, n);
+  if (wave == 0) {
+    double tn = 0.0;
+    for (int j = lane; j < n; j += 64) { tn = fmax(tn, fabs(w.d[j])); if (j < n - 1) tn = fmax(tn, fabs(w.e[j])); }
+    tn = wmax(tn);
+    for (int j = lane; j < n; j += 64) {
+      double ej = (j < n - 1) ? w.e[j] : 0.0;
+      if (fabs(ej) <= EPS * tn) ej = 0.0;        // negligible against |T|: the blocks decouple exactly
+      w.e[j] = ej;
+    }
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_wave_barrier();
+    double gl = INFINITY, gu = -INFINITY;
+    for (int j = lane; j < n; j += 64) {
+      const double rad = ((j > 0) ? fabs(w.e[j - 1]) : 0.0) + fabs(w.e[j]);
+      gl = fmin(gl, w.d[j] - rad); gu = fmax(gu, w.d[j] + rad);
+    }
+    gl = -wmax(-gl); gu = wmax(gu);
+    // the Sturm counts work on T / bn (entries and arguments within [-1, 1]); bn = 0: T = 0, every eigenvalue 0
+    const double bn = fmax(fabs(gl), fabs(gu));
+    const double sinv = (bn > 0.0) ? 1.0 / bn : 0.0;
+    for (int j = lane; j < n; j += 64) {
+      const double es = w.e[j] * sinv;
+      g.d[j] = w.d[j]; g.e[j] = w.e[j]; g.ds[j] = w.d[j] * sinv; g.es2[j] = es * es; g.tau[j] = (j < n - 2) ? w.tau[j] : 0.0;
+    }
+    if (lane == 0) { g.par[0] = tn; g.par[1] = bn; g.par[2] = gl * sinv - 4.0 * EPS * n; g.par[3] = gu * sinv + 4.0 * EPS * n; stat[ST_EIG_FAST] = 1; }
+  }
+}
+
+__global__ void __launch_bounds__(256) k_eigf_pairs(int n, const double* __restrict__ wsb, double* __restrict__ lam_out,
+                                                    int64_t* stat) {
+  __shared__ double sd[128], se[128], sds[128], ses2[128], sDp[128], sDm[128];
+  __shared__ double s_red[8];
+  __shared__ int s_cnt[2][4];
+  __shared__ int s_r;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6, k = blockIdx.x;
+  const EigfWs g = eigf_ws(const_cast<double*>(wsb), n);
+  if (t < n) { sd[t] = g.d[t]; se[t] = g.e[t]; sds[t] = g.ds[t]; ses2[t] = g.es2[t]; }
+  const double tn = g.par[0], bscale = g.par[1];
+  double lo = g.par[2], hi = g.par[3];
+  __syncthreads();
+  // ---- eigenvalue k: 512 interior points per round (two per thread) ------------------------------------------------------
+  for (int round = 0; round < 8; ++round) {          // 513^7 > 2^63
+    const double wd = hi - lo;
+    const double x0 = lo + wd * ((2 * t + 1) * (1.0 / 513.0)), x1 = lo + wd * ((2 * t + 2) * (1.0 / 513.0));
+    int c0, c1;
+    sturm2(sds, ses2, n, x0, x1, c0, c1);
+    const int mle = (int)wsum((double)((c0 <= k) + (c1 <= k)));       // points with at most k eigenvalues below them
+    if (lane == 0) s_cnt[round & 1][wave] = mle;
+    __syncthreads();
+    const int tot = s_cnt[round & 1][0] + s_cnt[round & 1][1] + s_cnt[round & 1][2] + s_cnt[round & 1][3];
+    const double nlo = (tot == 0) ? lo : lo + wd * (tot * (1.0 / 513.0));
+    const double nhi = (tot == 512) ? hi : lo + wd * ((tot + 1) * (1.0 / 513.0));
+    lo = nlo; hi = nhi;
+    if (!(hi - lo > 4.0 * EPS * fmax(fabs(lo), fabs(hi)))) break;     // to 2 ulp of the midpoint; workgroup-uniform
+  }
+  const double l = (0.5 * (lo + hi)) * bscale;
+  // ---- its eigenvector of T: twisted factorisation; thread 0 runs the forward factor D+, thread 64 the backward D- ---------
+  const double tiny = fmax(EPS * EPS * tn, 1e-300);
+  if (t == 0) {
+    double dp = sd[0] - l;
+    for (int i = 0; i < n - 1; ++i) {
+      if (fabs(dp) < tiny) dp = copysign(tiny, dp);
+      sDp[i] = dp;
+      dp = (sd[i + 1] - l) - quot_fast(se[i] * se[i], dp);
+    }
+    if (fabs(dp) < tiny) dp = copysign(tiny, dp);
+    sDp[n - 1] = dp;
+  } else if (t == 64) {
+    double dm = sd[n - 1] - l;
+    for (int i = n - 1; i >= 1; --i) {
+      if (fabs(dm) < tiny) dm = copysign(tiny, dm);
+      sDm[i] = dm;
+      dm = (sd[i - 1] - l) - quot_fast(se[i - 1] * se[i - 1], dm);
+    }
+    if (fabs(dm) < tiny) dm = copysign(tiny, dm);
+    sDm[0] = dm;
+  }
+  __syncthreads();
+  if (t == 0) {     // twist index r = argmin |gamma_i|, gamma_i = D+_i + D-_i - (d_i - lambda)
+    double gbest = INFINITY; int r = 0;
+    for (int i = 0; i < n; ++i) { const double gam = fabs(sDp[i] + sDm[i] - (sd[i] - l)); if (gam < gbest) { gbest = gam; r = i; } }
+    s_r = r;
+  }
+  __syncthreads();
+  const int r = s_r;
+  // z_r = 1, upwards through D+ (thread 0), downwards through D- (thread 64); the entries overwrite the factor they came from
+  if (t == 0) {
+    double z = 1.0, nrm = 1.0;
+    for (int i = r - 1; i >= 0; --i) { z = -quot_fast(se[i], sDp[i]) * z; sDp[i] = z; nrm = fma(z, z, nrm); }
+    sDp[r] = 1.0;
+    s_red[0] = nrm;
+  } else if (t == 64) {
+    double z = 1.0, nrm = 0.0;
+    for (int i = r; i < n - 1; ++i) { z = -quot_fast(se[i], sDm[i + 1]) * z; sDm[i + 1] = z; nrm = fma(z, z, nrm); }
+    s_red[1] = nrm;
+  }
+  __syncthreads();
+  const double inv = fast_rsqrt(s_red[0] + s_red[1]);
+  double res = 0.0;
+  if (t < n) {
+    auto zat = [&](int i) { return ((i <= r) ? sDp[i] : sDm[i]) * inv; };
+    const double zi = zat(t);
+    g.Zc[(size_t)k * n + t] = zi;
+    g.Zt[(size_t)t * n + k] = zi;
+    double rr = (sd[t] - l) * zi;
+    if (t > 0) rr = fma(se[t - 1], zat(t - 1), rr);
+    if (t < n - 1) rr = fma(se[t], zat(t + 1), rr);
+    res = fabs(rr);
+    if (!(rr == rr)) res = INFINITY;
+  }
+  if (t == 0) lam_out[k] = l;
+  if (wave < 2) {
+    res = wmax(res);
+    if (lane == 0) eigf_note(stat, res, 2e-14 * tn);
+  }
+}
+
 }  // namespace
 
 // Largest n the solver takes: the back-transformation holds a column in 32 registers per lane of a wave (n <= 2048), and the
@@ -1321,6 +1578,31 @@ int launch_eig_small(blmm_ctx* ctx, const double* A, int n, double* lraw, double
   if (lds > 160 * 1024) return BLMM_ERR_UNSUPPORTED;
   BLMM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_eig_small), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   hipLaunchKernelGGL(k_eig_small, dim3(1), dim3(1024), lds, ctx->stream, A, n, lraw, evec, ptr<double>(ctx->eigW), stat);
+  KCHECK();
+  ctx->eig_plan_n = -1;    // the workspace was reused: a cached merge tree of the multi-workgroup solver is gone
+  return BLMM_OK;
+}
+
+// The fast path for 3 <= n <= 124 (k_eigf_reduce, k_eigf_pairs, k_backtransform with the orthogonality check).  The device decides
+// whether the result stands (stat[ST_EIG_FAST] = 1: it ran; stat[ST_EIG_BAD]: largest check / bound as the bits of a double, accepted
+// up to 1.0); the caller launches the Jacobi behind it, which returns at once when it does.
+int eig_fast_max_n() { return 124; }
+int launch_eig_fast(blmm_ctx* ctx, const double* A, int n, double* lraw, double* evec, int64_t* stat) {
+  if (n < 3 || n > eig_fast_max_n()) return BLMM_ERR_UNSUPPORTED;
+  int rc;
+  if ((rc = ensure(ctx, ctx->eigW, sizeof(double) * ((size_t)3 * n * n + (size_t)5 * n + 8) + 256))) return rc;
+  const size_t lds = sizeof(double) * ((size_t)n * n + (size_t)7 * n + 8 * 128 + 16) + 64;
+  if (lds > 158 * 1024) return BLMM_ERR_UNSUPPORTED;
+  double* Vg = ptr<double>(ctx->eigW);
+  double* wsb = Vg + (size_t)n * n;
+  const EigfWs g = eigf_ws(wsb, n);
+  BLMM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_eigf_reduce), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(k_eigf_reduce, dim3(1), dim3(1024), lds, ctx->stream, A, n, Vg, wsb, stat);
+  KCHECK();
+  hipLaunchKernelGGL(k_eigf_pairs, dim3(n), dim3(256), 0, ctx->stream, n, (const double*)wsb, lraw, stat);
+  KCHECK();
+  const size_t lds_bt = sizeof(double) * (size_t)2 * (4 * n + 4);
+  hipLaunchKernelGGL((k_backtransform<2, 1, 256>), dim3((n + 3) / 4), dim3(256), lds_bt, ctx->stream, Vg, g.tau, n, evec, (const double*)g.Zt, (const double*)g.Zc, stat);
   KCHECK();
   ctx->eig_plan_n = -1;    // the workspace was reused: a cached merge tree of the multi-workgroup solver is gone
   return BLMM_OK;
@@ -1487,10 +1769,10 @@ int launch_eig_dc(blmm_ctx* ctx, const double* A, int n, double* lraw, double* e
     if (bt_wide) {                                                                                                         \
       const int cols_per_wg = 8 * CPWW;                                                                                    \
       if (lds > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_backtransform<NR, CPWW, 512>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-      hipLaunchKernelGGL((k_backtransform<NR, CPWW, 512>), dim3((n + cols_per_wg - 1) / cols_per_wg), dim3(512), lds, ctx->stream, V, tau, n, Qin); \
+      hipLaunchKernelGGL((k_backtransform<NR, CPWW, 512>), dim3((n + cols_per_wg - 1) / cols_per_wg), dim3(512), lds, ctx->stream, V, tau, n, Qin, (const double*)nullptr, (const double*)nullptr, (int64_t*)nullptr); \
     } else {                                                                                                               \
       if (lds > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_backtransform<NR, 1, 256>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-      hipLaunchKernelGGL((k_backtransform<NR, 1, 256>), dim3((n + 3) / 4), dim3(256), lds, ctx->stream, V, tau, n, Qin);   \
+      hipLaunchKernelGGL((k_backtransform<NR, 1, 256>), dim3((n + 3) / 4), dim3(256), lds, ctx->stream, V, tau, n, Qin, (const double*)nullptr, (const double*)nullptr, (int64_t*)nullptr);   \
     }                                                                                                                      \
   } while (0)
     if (nr <= 2) BT(2); else if (nr <= 4) BT(4); else if (nr <= 8) BT(8); else if (nr <= 16) BT(16); else if (nr <= 24) BT(24); else BT(32);

@@ -105,6 +105,8 @@ __global__ void __launch_bounds__(1024) k_jacobi_lds(const double* __restrict__ 
                                                      double* __restrict__ lraw, int64_t* stat, double stop2) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   __shared__ double s_anorm;
+  // the fast path (kernels_eig.hip: k_eigf_*) ran ahead of this launch and its checks passed: nothing to do (workgroup-uniform)
+  if (stat[ST_EIG_FAST] == 1 && __longlong_as_double((long long)stat[ST_EIG_BAD]) <= 1.0) return;
   const int tid = threadIdx.x, nt = blockDim.x;
   const unsigned long long dbg_t0 = __builtin_amdgcn_s_memtime(), dbg_r0 = __builtin_amdgcn_s_memrealtime();
   const int N = n + (n & 1), NP2 = N / 2, ld = N + 1;       // ld: leading dimension of the V slices (odd)

@@ -1156,3 +1156,42 @@ def test_output_pvals_request_is_one_shot(blmm):
     r3 = blmm.bulkscan(Y, G, K, method="null-exact", ctx=ctx)
     assert np.array_equal(r3["L"], r1["L"])
     ctx.close()
+
+
+def test_fast_eigen_path_is_taken_on_kinships_and_falls_back_on_repeated_eigenvalues(blmm):
+    """n <= 124: tridiagonalisation + Sturm multi-section + twisted factorisation (kernels_eig.hip: k_eigf_*) with a device-side
+    check of its own result; the LDS Jacobi behind it runs only when the check fails.  `jacobi_sweeps` in the status says
+    which one produced the decomposition: 0 for full-rank kinships (BXD, random markers with p >> n), > 0 where eigenvalues
+    repeat (duplicated individuals, a kinship of rank 3) -- and the decomposition is accurate either way.  BLMM_EIGEN=jacobi
+    keeps the Jacobi alone."""
+    import os
+    for n, kind, want_fast in [(79, "bxd", True), (64, "markers", True), (124, "markers", True), (16, "markers", True), (3, "markers", None),
+                               (79, "dup", False), (92, "few", False), (40, "identity", False)]:
+        Y, G, K, _ = make_data(n=n, p=5 * n, m=3, seed=4100 + n, bxd=(kind == "bxd"))     # p >> n: a full-rank kinship
+        rng = np.random.default_rng(n)
+        if kind == "dup":
+            Gd = (rng.random((n, 4 * n)) < 0.5).astype(np.float64); Gd[n // 2:] = Gd[: n - n // 2]
+            K = np.round(O.calcKinship(Gd), 12)
+        elif kind == "few":
+            K = O.calcKinship((rng.random((n, 3)) < 0.5).astype(np.float64))
+        elif kind == "identity":
+            K = 2.5 * np.eye(n)
+        import warnings
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            _, _, st = _null_exact_with_status(blmm, Y, G, K, None)
+            Y0, _, lam = blmm.transform_rotation(np.eye(n), G, K)
+        if want_fast is not None:
+            assert (st.jacobi_sweeps == 0) == want_fast, (n, kind, st.jacobi_sweeps)
+        U = Y0.T
+        sc = max(np.abs(K).max(), 1e-300)
+        assert np.abs(U.T @ U - np.eye(n)).max() <= 2e-13, (n, kind)
+        assert np.abs((U * lam) @ U.T - K).max() <= 5e-13 * sc * np.sqrt(n), (n, kind)
+        assert np.abs(np.sort(lam) - np.linalg.eigvalsh(K)).max() <= 1e-12 * sc, (n, kind)
+    os.environ["BLMM_EIGEN"] = "jacobi"
+    try:
+        Y, G, K, _ = make_data(n=79, p=60, m=3, seed=4179)
+        _, _, st = _null_exact_with_status(blmm, Y, G, K, None)
+        assert st.jacobi_sweeps > 0
+    finally:
+        del os.environ["BLMM_EIGEN"]
