@@ -830,43 +830,44 @@ __device__ __forceinline__ void eigf_note(int64_t* stat, double v, double bound)
 // ---------------------------------------------------------------------------------------------------------------------
 template <int NR, int CPW, int NT>
 __global__ void __launch_bounds__(NT) k_backtransform(const double* __restrict__ V, const double* __restrict__ tau, int n,
-                                                       double* __restrict__ Z, const double* __restrict__ Zt_chk,
-                                                       const double* __restrict__ Zc_chk, int64_t* __restrict__ stat_chk) {
+                                                       double* __restrict__ Z, const double* __restrict__ Zc_chk,
+                                                       int64_t* __restrict__ stat_chk) {
   extern __shared__ __attribute__((aligned(16))) double sh[];   // 2 x n : double-buffered reflector
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwave = blockDim.x >> 6;
   const int c0 = (blockIdx.x * nwave + wave) * CPW;
-  // Behind k_eigf_pairs (NR = 2, CPW = 1, n <= 128): the wave's column a of Z comes from the PRISTINE copies the pairs kernel
-  // left (Zc column-major, Zt row-major; the result goes to Z).  Row a of E = Z'Z - I first -- its largest entry / 3e-8 ->
+  // Behind k_eigf_pairs (NR = 2, CPW = 1, n <= 128): the whole uncorrected Z (Zc_chk, column-major, written by workgroups on
+  // every XCD: a dependent chain of reads from it would pay the cross-XCD round trip each time -- 52 us for this kernel, 35 with
+  // the staging) is copied into LDS with one batch of loads.  Row a of E = Z'Z - I first -- its largest entry / 3e-8 ->
   // stat[ST_EIG_BAD] --, then the symmetric first-order correction z_a <- z_a - (1/2) sum_b E_ab z_b: every workgroup corrects
   // from the same uncorrected Z, together Z (I - E / 2), orthogonal to ~|E|^2.  On kinships |E| is ~4e-14 and the correction only
   // takes the vectors from there to rounding level; it is what lets near-repeated eigenvalues through (|E| up to 3e-8).
   double z[CPW][NR];
-  if (Zt_chk) {
+  if (Zc_chk) {
+    double* Zs = sh + 2 * (4 * (size_t)n + 4);        // behind the two reflector buffers; odd column stride: lane <-> column reads
+    const int lz = n | 1;                             // spread over the banks (n = 64 with stride 64: one bank for all lanes)
+    for (int e = threadIdx.x; e < n * n; e += NT) { const int cb = e / n; Zs[cb * lz + (e - cb * n)] = Zc_chk[e]; }
+    __syncthreads();
     const int a = c0;
-    double e0 = 0.0, e1 = 0.0;
+    double e0 = 0.0, e1 = 0.0, z0 = 0.0, z1 = 0.0;
     if (a < n) {
       double acc0 = 0.0, acc1 = 0.0;
-#pragma unroll 8
-      for (int i = 0; i < n; ++i) {               // (unrolled: the loads of eight rows in flight together, L2 round trips)
-        const double za = Zt_chk[(size_t)i * n + a];
-        acc0 = fma(za, (lane < n) ? Zt_chk[(size_t)i * n + lane] : 0.0, acc0);
-        acc1 = fma(za, (lane + 64 < n) ? Zt_chk[(size_t)i * n + lane + 64] : 0.0, acc1);
-      }
+      const double* za = Zs + (size_t)a * lz;
+      const double* zb0 = Zs + (size_t)((lane < n) ? lane : 0) * lz;
+      const double* zb1 = Zs + (size_t)((lane + 64 < n) ? lane + 64 : 0) * lz;
+      for (int i = 0; i < n; ++i) { const double v = za[i]; acc0 = fma(v, zb0[i], acc0); acc1 = fma(v, zb1[i], acc1); }
       e0 = (lane < n) ? acc0 - ((lane == a) ? 1.0 : 0.0) : 0.0;
       e1 = (lane + 64 < n) ? acc1 - ((lane + 64 == a) ? 1.0 : 0.0) : 0.0;
       double bad = fmax(fabs(e0), fabs(e1));
-      if (!(acc0 == acc0) || !(acc1 == acc1)) bad = INFINITY;
+      if (!(e0 == e0) || !(e1 == e1)) bad = INFINITY;
       bad = wmax(bad);
       if (lane == 0) eigf_note(stat_chk, bad, 3e-8);
-    }
-    double z0 = (a < n && lane < n) ? Zc_chk[(size_t)a * n + lane] : 0.0, z1 = (a < n && lane + 64 < n) ? Zc_chk[(size_t)a * n + lane + 64] : 0.0;
-    if (a < n) {
+      z0 = (lane < n) ? za[lane] : 0.0; z1 = (lane + 64 < n) ? za[lane + 64] : 0.0;
       double c0v = 0.0, c1v = 0.0;
-#pragma unroll 8
       for (int b = 0; b < n; ++b) {
         const double eab = lane_bcast((b < 64) ? e0 : e1, b & 63);     // (b is wave-uniform)
-        c0v = fma(eab, (lane < n) ? Zc_chk[(size_t)b * n + lane] : 0.0, c0v);
-        c1v = fma(eab, (lane + 64 < n) ? Zc_chk[(size_t)b * n + lane + 64] : 0.0, c1v);
+        const double* zb = Zs + (size_t)b * lz;
+        c0v = fma(eab, (lane < n) ? zb[lane] : 0.0, c0v);
+        c1v = fma(eab, (lane + 64 < n) ? zb[lane + 64] : 0.0, c1v);
       }
       z0 = fma(-0.5, c0v, z0); z1 = fma(-0.5, c1v, z1);
     }
@@ -1202,19 +1203,44 @@ __device__ void small_sytrd(const SmallWs& w, const double* __restrict__ A, int 
 #pragma unroll
       for (int h = 0; h < 2; ++h) { wj[h] = fma(-cw, vj[h], pj[h]); }
       const double wk1 = lane_bcast(wj[(k + 1) >> 6], (k + 1) & 63);
-      double akk = 0.0;
+      // the next column x (rows k+2 ..) stays in registers for its reflector (lane <-> row as everywhere in this wave; sx only
+      // serves the last step): no LDS round trip, one reciprocal square root and one reciprocal instead of an IEEE square root
+      // and two IEEE divisions on the critical path of every step (149 -> 141 us at n = 79)
+      double akk = 0.0, xj[2] = {0.0, 0.0};
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
         const int j = lane + 64 * h;
         if (j > k && j < n) {
           w.svp[j] = vj[h]; w.swp[j] = wj[h];
           const double a = w.M1[(k + 1) * n + j];
-          if (j == k + 1) akk = a - 2.0 * wk1; else w.sx[j] = a - wj[h] - wk1 * vj[h];
+          if (j == k + 1) akk = a - 2.0 * wk1; else { xj[h] = a - wj[h] - wk1 * vj[h]; w.sx[j] = xj[h]; }
         }
       }
       akk = lane_bcast(akk, (k + 1) & 63);   // held by the lane that owns j = k+1 ... in half h = (k+1) >> 6
       if (k + 3 < n) {
-        householder(k + 1, akk);
+        const int k1 = k + 1;
+        const double alpha = lane_bcast(xj[(k1 + 1) >> 6], (k1 + 1) & 63);
+        double s1 = 0.0;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) { const int j = lane + 64 * h; if (j > k1 + 1 && j < n) s1 = fma(xj[h], xj[h], s1); }
+        s1 = wsum(s1);
+        double beta, tk1, sc;
+        if (s1 <= s1_negl) { beta = alpha; tk1 = 0.0; sc = 0.0; }
+        else {
+          const double hh = fma(alpha, alpha, s1), rs = fast_rsqrt(hh), nrm = hh * rs;
+          beta = -copysign(nrm, alpha);
+          tk1 = fma(fabs(alpha), rs, 1.0);                          // (beta - alpha) / beta
+          double y = __builtin_amdgcn_rcp(fabs(alpha) + nrm);       // 1 / (alpha - beta) = sign(alpha) / (|alpha| + |x|)
+          y = fma(y, fma(-(fabs(alpha) + nrm), y, 1.0), y);
+          y = fma(y, fma(-(fabs(alpha) + nrm), y, 1.0), y);
+          sc = copysign(y, alpha);
+        }
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const int j = lane + 64 * h;
+          if (j > k1 && j < n) { const double v = (j == k1 + 1) ? 1.0 : xj[h] * sc; w.sv[j] = v; Vg[k1 * n + j] = v; }
+        }
+        if (lane == 0) { w.d[k1] = akk; w.e[k1] = beta; w.tau[k1] = tk1; s_sc[0] = tk1; }
       } else if (lane == 0) {
         // the reduction ends: last two diagonal entries and the last off-diagonal one
         w.d[n - 2] = akk; w.e[n - 2] = w.sx[n - 1];
@@ -1367,7 +1393,7 @@ __global__ void __launch_bounds__(1024) k_eig_small(const double* __restrict__ A
 //                                  down to the grid of doubles), then ITS eigenvector of T by the twisted factorisation -- no
 //                                  iteration, no orthogonalisation --, and the residual of the pair
 //   k_backtransform (checked form) first the orthogonality of the wave's column against all others and the symmetric first-order
-//                                  correction Z (I - (Z'Z - I) / 2) (from the copies the pairs kernel left), then U = H Z
+//                                  correction Z (I - (Z'Z - I) / 2) (Z staged in LDS), then U = H Z
 // Every step past the reduction is parallel over the eigenpairs, the one sequential dimension being the n of a Sturm count or of
 // a factorisation (a few thousand cycles), against the Jacobi's 9 x 79 dependent rounds on one CU.  The twisted vectors are as
 // good as the eigenvalues are separated: on full-rank kinships (BXD: smallest relative gap 4e-5) they come out orthogonal to
@@ -1420,12 +1446,12 @@ __device__ __forceinline__ void sturm2(const double* __restrict__ ds, const doub
   }
   c0 = (int)s0; c1 = (int)s1;
 }
-// global workspace behind the reflectors: tau | d | e | ds | es2 | {|T|, scale, lo, hi, ...} | Zt (n x n, row-major = transposed Z) |
-// Zc (n x n, column-major: eigenvector k of T in Zc[k * n ..])
-struct EigfWs { double *tau, *d, *e, *ds, *es2, *par, *Zt, *Zc; };
+// global workspace behind the reflectors: tau | d | e | ds | es2 | {|T|, scale, lo, hi, ...} | Zc (n x n, column-major: eigenvector
+// k of T in Zc[k * n ..])
+struct EigfWs { double *tau, *d, *e, *ds, *es2, *par, *Zc; };
 __host__ __device__ inline EigfWs eigf_ws(double* base, int n) {
   EigfWs q;
-  q.tau = base; q.d = base + n; q.e = base + 2 * n; q.ds = base + 3 * n; q.es2 = base + 4 * n; q.par = base + 5 * n; q.Zt = base + 5 * n + 8; q.Zc = q.Zt + (size_t)n * n;
+  q.tau = base; q.d = base + n; q.e = base + 2 * n; q.ds = base + 3 * n; q.es2 = base + 4 * n; q.par = base + 5 * n; q.Zc = base + 5 * n + 8;
   return q;
 }
 
@@ -1547,7 +1573,6 @@ __global__ void __launch_bounds__(256) k_eigf_pairs(int n, const double* __restr
     auto zat = [&](int i) { return ((i <= r) ? sDp[i] : sDm[i]) * inv; };
     const double zi = zat(t);
     g.Zc[(size_t)k * n + t] = zi;
-    g.Zt[(size_t)t * n + k] = zi;
     double rr = (sd[t] - l) * zi;
     if (t > 0) rr = fma(se[t - 1], zat(t - 1), rr);
     if (t < n - 1) rr = fma(se[t], zat(t + 1), rr);
@@ -1590,7 +1615,7 @@ int eig_fast_max_n() { return 124; }
 int launch_eig_fast(blmm_ctx* ctx, const double* A, int n, double* lraw, double* evec, int64_t* stat) {
   if (n < 3 || n > eig_fast_max_n()) return BLMM_ERR_UNSUPPORTED;
   int rc;
-  if ((rc = ensure(ctx, ctx->eigW, sizeof(double) * ((size_t)3 * n * n + (size_t)5 * n + 8) + 256))) return rc;
+  if ((rc = ensure(ctx, ctx->eigW, sizeof(double) * ((size_t)2 * n * n + (size_t)5 * n + 8) + 256))) return rc;
   const size_t lds = sizeof(double) * ((size_t)n * n + (size_t)7 * n + 8 * 128 + 16) + 64;
   if (lds > 158 * 1024) return BLMM_ERR_UNSUPPORTED;
   double* Vg = ptr<double>(ctx->eigW);
@@ -1601,8 +1626,9 @@ int launch_eig_fast(blmm_ctx* ctx, const double* A, int n, double* lraw, double*
   KCHECK();
   hipLaunchKernelGGL(k_eigf_pairs, dim3(n), dim3(256), 0, ctx->stream, n, (const double*)wsb, lraw, stat);
   KCHECK();
-  const size_t lds_bt = sizeof(double) * (size_t)2 * (4 * n + 4);
-  hipLaunchKernelGGL((k_backtransform<2, 1, 256>), dim3((n + 3) / 4), dim3(256), lds_bt, ctx->stream, Vg, g.tau, n, evec, (const double*)g.Zt, (const double*)g.Zc, stat);
+  const size_t lds_bt = sizeof(double) * ((size_t)2 * (4 * n + 4) + (size_t)n * (n | 1));   // reflector buffers + the staged Z
+  BLMM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_backtransform<2, 1, 256>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bt));
+  hipLaunchKernelGGL((k_backtransform<2, 1, 256>), dim3((n + 3) / 4), dim3(256), lds_bt, ctx->stream, Vg, g.tau, n, evec, (const double*)g.Zc, stat);
   KCHECK();
   ctx->eig_plan_n = -1;    // the workspace was reused: a cached merge tree of the multi-workgroup solver is gone
   return BLMM_OK;
@@ -1769,10 +1795,10 @@ int launch_eig_dc(blmm_ctx* ctx, const double* A, int n, double* lraw, double* e
     if (bt_wide) {                                                                                                         \
       const int cols_per_wg = 8 * CPWW;                                                                                    \
       if (lds > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_backtransform<NR, CPWW, 512>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-      hipLaunchKernelGGL((k_backtransform<NR, CPWW, 512>), dim3((n + cols_per_wg - 1) / cols_per_wg), dim3(512), lds, ctx->stream, V, tau, n, Qin, (const double*)nullptr, (const double*)nullptr, (int64_t*)nullptr); \
+      hipLaunchKernelGGL((k_backtransform<NR, CPWW, 512>), dim3((n + cols_per_wg - 1) / cols_per_wg), dim3(512), lds, ctx->stream, V, tau, n, Qin, (const double*)nullptr, (int64_t*)nullptr); \
     } else {                                                                                                               \
       if (lds > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_backtransform<NR, 1, 256>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-      hipLaunchKernelGGL((k_backtransform<NR, 1, 256>), dim3((n + 3) / 4), dim3(256), lds, ctx->stream, V, tau, n, Qin, (const double*)nullptr, (const double*)nullptr, (int64_t*)nullptr);   \
+      hipLaunchKernelGGL((k_backtransform<NR, 1, 256>), dim3((n + 3) / 4), dim3(256), lds, ctx->stream, V, tau, n, Qin, (const double*)nullptr, (int64_t*)nullptr);   \
     }                                                                                                                      \
   } while (0)
     if (nr <= 2) BT(2); else if (nr <= 4) BT(4); else if (nr <= 8) BT(8); else if (nr <= 16) BT(16); else if (nr <= 24) BT(24); else BT(32);
