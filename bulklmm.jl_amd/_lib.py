@@ -25,7 +25,7 @@ EXPORTS = [
     "blmm_lod2log10p", "blmm_lod2log10p_dev", "blmm_lod_threshold", "blmm_lod_threshold_dev", "blmm_get_thresholds", "blmm_get_thresholds_dev",
     "blmm_last_log10p", "blmm_last_lod_threshold", "blmm_last_get_thresholds", "blmm_set_log10p_output",
     "blmm_read_csv", "blmm_read_he", "blmm_table_rows", "blmm_table_cols", "blmm_table_copy", "blmm_table_free",
-    "blmm_kinship_rounded", "blmm_scan_alt", "blmm_scan_alt_dev",
+    "blmm_kinship_rounded", "blmm_scan_alt", "blmm_scan_alt_dev", "blmm_bulkscan_alt_exact", "blmm_bulkscan_alt_exact_dev",
     "blmm_prepare_dev", "blmm_rotated_rows", "blmm_rotate_block_dev", "blmm_bulkscan_prerotated_dev",
 ]
 
@@ -114,6 +114,8 @@ def load():
     lib.blmm_scan_perms_f32_dev.argtypes = [vp, op, vp, i64, vp, i64, vp, i64, vp, vp, i64, C.c_uint64, vp, vp, vp, vp, sp]
     lib.blmm_scan_alt.argtypes = [vp, op, vp, i64, vp, i64, vp, i64, vp, vp, vp, vp, vp, sp]
     lib.blmm_scan_alt_dev.argtypes = [vp, op, vp, i64, vp, i64, vp, i64, vp, vp, vp, vp, vp, sp]
+    lib.blmm_bulkscan_alt_exact.argtypes = [vp, C.POINTER(blmm_opts), vp, i64, i64, vp, i64, vp, i64, vp, vp, vp, vp, vp, vp, C.POINTER(blmm_status)]
+    lib.blmm_bulkscan_alt_exact_dev.argtypes = [vp, C.POINTER(blmm_opts), vp, i64, i64, vp, i64, vp, i64, vp, vp, vp, i64, vp, i64, vp, vp, C.POINTER(blmm_status)]
     lib.blmm_prepare_dev.argtypes = [vp, op, i64, vp, i64, vp, vp, sp]
     lib.blmm_rotated_rows.argtypes = [vp]
     lib.blmm_rotated_rows.restype = i64

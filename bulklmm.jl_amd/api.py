@@ -337,6 +337,44 @@ def bulkscan_alt_grid(Y, G, K, hsq_list, Covar=None, *, reml: bool = False, prio
     return BulkscanAltResult(Lo, h2)
 
 
+def bulkscan_alt_exact(Y, G, K, Covar=None, *, reml: bool = False, prior_variance: float = 0.0, prior_sample_size: float = 0.0,
+                       weights=None, addIntercept: bool = True, optim_interval: int = 1, decomp_scheme: str = "eigen",
+                       alt_true_weights: bool = False, ctx: Optional[Context] = None) -> dict:
+    """The bulk form of `scan(...; assumption = "alt")` (scan_alt, src/scan.jl:397-453; SURVEY.md N3 -- the reference itself only
+    has the single-trait function and the grid approximation bulkscan_alt_grid): for every (trait, marker) the exact
+    heritability under the alternative, one Brent search per test on the device.  Returns L (p x m), h2_panel (p x m),
+    h2_null_list (m), sigma2_e (m); column j equals scan(Y[:, j], ...; assumption = "alt") bit for bit.  Defaults are
+    scan's (prior 0 / 0), not bulkscan's."""
+    Y = _F(Y); G = _F(G); K = _F(K)
+    n, m = Y.shape
+    p = G.shape[1]
+    if G.shape[0] != n or K.shape[0] != n or K.shape[1] != n:
+        raise BulkLMMError("Dimension mismatch.", -2)
+    if Covar is None and not addIntercept:
+        raise BulkLMMError("Intercept has to be added when no other covariate is given.", -7)
+    cov, ncov = None, 0
+    if Covar is not None:
+        cov = _F(Covar)
+        if cov.shape[0] != n:
+            raise BulkLMMError("Dimension mismatch.", -2)
+        ncov = cov.shape[1]
+    else:
+        addIntercept = True
+    w = None if weights is None else np.ascontiguousarray(np.asarray(weights, dtype=np.float64).ravel())
+    if w is not None and w.shape[0] != n:
+        raise BulkLMMError("Dimension mismatch.", -2)
+    o = _opts(L.BLMM_NULL_EXACT, reml, addIntercept, decomp_scheme, optim_interval, prior_variance, prior_sample_size)
+    if alt_true_weights:
+        o.compat_flags |= L.BLMM_COMPAT_ALT_TRUE_WEIGHTS
+    st = L.blmm_status()
+    ctx = ctx or default_context()
+    Lo = np.empty((p, m), order="F"); H = np.empty((p, m), order="F"); h2 = np.empty(m); s2 = np.empty(m)
+    ctx.check(ctx.lib.blmm_bulkscan_alt_exact(ctx.h, C.byref(o), _p(Y), n, m, _p(G), p, _p(cov), ncov, _p(K), _p(w), _p(Lo), _p(H),
+                                              _p(h2), _p(s2), C.byref(st)))
+    _raise_status(st)
+    return {"L": Lo, "h2_panel": H, "h2_null_list": h2, "sigma2_e": s2}
+
+
 def bulkscan_multi(mctx: MultiContext, Y, G, K, Covar=None, *, method: str = "null-grid", h2_grid=None, gather: str = "host_shards",
                    addIntercept: bool = True, weights=None, prior_variance: float = 1.0, prior_sample_size: float = 0.0,
                    reml: bool = False, optim_interval: int = 1, decomp_scheme: str = "eigen", return_status: bool = False) -> dict:

@@ -166,7 +166,7 @@ int launch_brent(blmm_ctx* ctx, const NullModel& nm, const double* Yt, int64_t l
 // scan_alt: per-marker fitlmm on [Z0 x_i] and the LOD against the null model (the trait is column 0 of Yt)
 int launch_alt_brent(blmm_ctx* ctx, const NullModel& nm, const double* Yt, int64_t ldy, const double* Xt, int64_t ldx, int64_t p,
                      const double* Z0, const double* lam, const double* h2null, int true_w, double* lod, double* h2each,
-                     int64_t* stat);
+                     int64_t* stat, int64_t m = 1, int64_t ldL = 0, int64_t ldH = 0);
 // Ell[g, j] for every grid point and first-argmax; EllTab (ngrid x m, ld = ngrid) may be null
 int launch_loglik_grid(blmm_ctx* ctx, const NullModel& nm, const double* Yt, int64_t ldy, int64_t m, const double* Z0,
                        const double* lam, const double* grid_dev, int ngrid, double* EllTab, int* h2idx, double* h2,

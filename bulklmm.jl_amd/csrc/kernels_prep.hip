@@ -1796,13 +1796,16 @@ __global__ void __launch_bounds__(256) k_alt_brent(NullModel nm, const double* _
                                                    const double* __restrict__ Xt, int64_t ldx, int64_t p, const double* __restrict__ Z0,
                                                    const double* __restrict__ lam, const double* __restrict__ h2null,
                                                    int true_w, double* __restrict__ lod, double* __restrict__ h2each,
-                                                   int64_t* stat) {
+                                                   int64_t* stat, int64_t trait0, int64_t ldL, int64_t ldH) {
   extern __shared__ __attribute__((aligned(16))) double sh[];
   const int n = nm.n;
+  // blockIdx.y: the trait (bulk form, blmm_bulkscan_alt_exact: trait0 + blockIdx.y; outputs are columns of p x m matrices)
+  const int64_t tr = trait0 + blockIdx.y;
+  lod += tr * ldL; h2each += tr * ldH;
   double* sLam = sh;            // n
-  double* sY = sh + n;          // n   (the trait: column 0 of Yt)
+  double* sY = sh + n;          // n   (the trait: column tr of Yt)
   double* sZ = sh + 2 * n;      // C*n
-  for (int e = threadIdx.x; e < n; e += blockDim.x) { sLam[e] = lam[e]; sY[e] = Yt[(int64_t)e * ldy]; }
+  for (int e = threadIdx.x; e < n; e += blockDim.x) { sLam[e] = lam[e]; sY[e] = Yt[(int64_t)e * ldy + tr]; }
   for (int e = threadIdx.x; e < n * C; e += blockDim.x) sZ[e] = Z0[e];
   __syncthreads();
   const int64_t j = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / LPT;
@@ -1813,7 +1816,7 @@ __global__ void __launch_bounds__(256) k_alt_brent(NullModel nm, const double* _
   const int nint = nm.optim_interval < 1 ? 1 : nm.optim_interval;
   auto f = [&](double h2) { return -alt_ell<C, 1, LPT, false>(h2, xcol, ldx, sub, n, sY, sZ, sLam, nm.prior_a, nm.prior_b, nm.reml, &nonpos).ell; };
   const double hx = brent_search(f, nint, valid, &hit_max);
-  const double h0 = *h2null;
+  const double h0 = h2null[tr];
   double e1, e0;
   if (true_w) {
     e1 = alt_ell<C, 1, LPT, false>(hx, xcol, ldx, sub, n, sY, sZ, sLam, nm.prior_a, nm.prior_b, 0, nullptr).ell;
@@ -1833,29 +1836,32 @@ __global__ void __launch_bounds__(256) k_alt_brent(NullModel nm, const double* _
 template <int C, int LPT>
 static int launch_alt_brent_t(blmm_ctx* ctx, const NullModel& nm, const double* Yt, int64_t ldy, const double* Xt, int64_t ldx, int64_t p,
                               const double* Z0, const double* lam, const double* h2null, int true_w, double* lod,
-                              double* h2each, int64_t* stat) {
+                              double* h2each, int64_t* stat, int64_t m, int64_t ldL, int64_t ldH) {
   const size_t lds = sizeof(double) * (size_t)nm.n * (2 + C);
   if (lds > 160 * 1024 - 512) return fail(ctx, BLMM_ERR_UNSUPPORTED, "scan_alt: n too large for the LDS-resident trait");
   if (lds > 48 * 1024) BLMM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_alt_brent<C, LPT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   const int64_t threads = p * LPT;
-  hipLaunchKernelGGL((k_alt_brent<C, LPT>), dim3((unsigned)((threads + 255) / 256)), dim3(256), lds, ctx->stream, nm, Yt, ldy, Xt, ldx, p,
-                     Z0, lam, h2null, true_w, lod, h2each, stat);
-  KCHECK();
+  for (int64_t t0 = 0; t0 < m; t0 += 65535) {       // gridDim.y <= 65535
+    const int64_t mt = (m - t0 < 65535) ? m - t0 : 65535;
+    hipLaunchKernelGGL((k_alt_brent<C, LPT>), dim3((unsigned)((threads + 255) / 256), (unsigned)mt), dim3(256), lds, ctx->stream, nm, Yt, ldy, Xt, ldx, p,
+                       Z0, lam, h2null, true_w, lod, h2each, stat, t0, ldL, ldH);
+    KCHECK();
+  }
   return BLMM_OK;
 }
 
 int launch_alt_brent(blmm_ctx* ctx, const NullModel& nm, const double* Yt, int64_t ldy, const double* Xt, int64_t ldx, int64_t p,
                      const double* Z0, const double* lam, const double* h2null, int true_w, double* lod, double* h2each,
-                     int64_t* stat) {
-  if (p < 1) return BLMM_OK;
-#define AB(C) (nm.n <= 160 ? launch_alt_brent_t<C, 4>(ctx, nm, Yt, ldy, Xt, ldx, p, Z0, lam, h2null, true_w, lod, h2each, stat) \
-                           : launch_alt_brent_t<C, 16>(ctx, nm, Yt, ldy, Xt, ldx, p, Z0, lam, h2null, true_w, lod, h2each, stat))
+                     int64_t* stat, int64_t m, int64_t ldL, int64_t ldH) {
+  if (p < 1 || m < 1) return BLMM_OK;
+#define AB(C) (nm.n <= 160 ? launch_alt_brent_t<C, 4>(ctx, nm, Yt, ldy, Xt, ldx, p, Z0, lam, h2null, true_w, lod, h2each, stat, m, ldL, ldH) \
+                           : launch_alt_brent_t<C, 16>(ctx, nm, Yt, ldy, Xt, ldx, p, Z0, lam, h2null, true_w, lod, h2each, stat, m, ldL, ldH))
   switch (nm.c) {
     case 1: return AB(1);
     case 2: return AB(2);
     case 3: return AB(3);
     case 4: return AB(4);
-#define AG(C) return launch_alt_brent_t<C, 16>(ctx, nm, Yt, ldy, Xt, ldx, p, Z0, lam, h2null, true_w, lod, h2each, stat)
+#define AG(C) return launch_alt_brent_t<C, 16>(ctx, nm, Yt, ldy, Xt, ldx, p, Z0, lam, h2null, true_w, lod, h2each, stat, m, ldL, ldH)
     case 5: AG(5);
     case 6: AG(6);
     case 7: AG(7);

@@ -11,7 +11,7 @@
 # every `ccall`'s symbol, return type and argument tuple (arity and types) against the prototype in include/bulklmm_hip.h.
 module BulkLMMHIP
 
-export calcKinship, bulkscan, bulkscan_null, bulkscan_null_grid, bulkscan_alt_grid, scan, bulkscan_multi, lod2log10p, get_thresholds,
+export calcKinship, bulkscan, bulkscan_null, bulkscan_null_grid, bulkscan_alt_grid, bulkscan_alt_exact, scan, bulkscan_multi, lod2log10p, get_thresholds,
        lod_threshold, lod_colmax, pinned_matrix, host_register, host_unregister
 
 const libblmm = get(ENV, "BULKLMM_HIP_LIB", joinpath(@__DIR__, "..", "csrc", "libbulklmm_hip.so"))
@@ -207,6 +207,28 @@ function bulkscan(Y::Array{Float64, 2}, G::Array{Float64, 2}, Covar::Array{Float
     end
     return res
 end
+
+# ---- the bulk form of scan(...; assumption = "alt") (scan_alt, src/scan.jl:397-453; not in the reference, which has the
+# single-trait function and the grid approximation bulkscan_alt_grid): the exact heritability of EVERY (trait, marker) test
+function bulkscan_alt_exact(Y::Array{Float64, 2}, G::Array{Float64, 2}, Covar::Array{Float64, 2}, K::Array{Float64, 2};
+                            addIntercept::Bool = true, weights::Union{Missing, Array{Float64, 1}} = missing,
+                            prior_variance::Float64 = 0.0, prior_sample_size::Float64 = 0.0, reml::Bool = false,
+                            optim_interval::Int64 = 1, decomp_scheme::String = "eigen")
+    n = size(Y, 1); m = size(Y, 2); p = size(G, 2)
+    (size(G, 1) != n || size(K, 1) != n || size(K, 2) != n || size(Covar, 1) != n) && error("Dimension mismatch.")
+    (weights !== missing && length(weights) != n) && error("Dimension mismatch.")
+    o = BlmmOpts(NULL_EXACT, reml, addIntercept, decomp(decomp_scheme), optim_interval, 0, prior_variance, prior_sample_size)
+    L = Array{Float64, 2}(undef, p, m); H = Array{Float64, 2}(undef, p, m)
+    h2 = Array{Float64, 1}(undef, m); s2 = Array{Float64, 1}(undef, m); st = BlmmStatus()
+    GC.@preserve Y G Covar K weights L H h2 s2 check(ccall((:blmm_bulkscan_alt_exact, libblmm), Cint,
+        (Ptr{Cvoid}, Ref{BlmmOpts}, Ptr{Float64}, Int64, Int64, Ptr{Float64}, Int64, Ptr{Float64}, Int64, Ptr{Float64}, Ptr{Float64},
+         Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ref{BlmmStatus}),
+        context(), o, Y, n, m, G, p, Covar, size(Covar, 2), K, ptr_or_null(weights), L, H, h2, s2, st))
+    raise_status(st)
+    return (L = L, h2_panel = H, h2_null_list = h2, sigma2_e = s2)
+end
+bulkscan_alt_exact(Y::Array{Float64, 2}, G::Array{Float64, 2}, K::Array{Float64, 2}; kwargs...) =
+    bulkscan_alt_exact(Y, G, ones(size(Y, 1), 1), K; addIntercept = false, kwargs...)
 
 # ---- several GPUs of one node in ONE call (blmm_bulkscan_multi): the trait blocks the reference deals to its threads
 # (src/bulkscan.jl:263-309) go to the devices; gather = :host_shards (default) | :none | :allgather

@@ -1195,3 +1195,26 @@ def test_fast_eigen_path_is_taken_on_kinships_and_falls_back_on_repeated_eigenva
         assert st.jacobi_sweeps > 0
     finally:
         del os.environ["BLMM_EIGEN"]
+
+
+@pytest.mark.parametrize("ncov,reml,oi", [(0, False, 1), (2, True, 3)])
+def test_bulkscan_alt_exact_is_scan_alt_on_every_trait(blmm, ncov, reml, oi):
+    """The bulk form of scan(...; assumption = "alt") (second half; the reference has the single-trait scan_alt,
+    src/scan.jl:397-453, and the grid approximation): every column equals the single-trait entry point bit for bit (same kernel,
+    the trait on blockIdx.y), the LOD equals the oracle's scan_alt at the device's per-test h2 to 1e-6 and, with the oracle's own
+    searches, on 90 % of the markers (where the two searches differ the profile is flat or two-humped, as for scan_alt)."""
+    Y, G, K, Cov = make_data(n=60, p=45, m=5, seed=6100 + ncov, ncov=ncov, bxd=False)
+    kw = dict(reml=reml, optim_interval=oi)
+    r = blmm.bulkscan_alt_exact(Y, G, K, Cov, **kw)
+    assert r["L"].shape == (45, 5) and r["h2_panel"].shape == (45, 5) and r["h2_null_list"].shape == (5,)
+    for j in range(5):
+        s = blmm.scan(Y[:, j], G, K, Cov, assumption="alt", **kw)
+        assert np.array_equal(s["lod"], r["L"][:, j]) and np.array_equal(s["h2_each_marker"], r["h2_panel"][:, j])
+        assert s["h2_null"] == r["h2_null_list"][j] and s["sigma2_e"] == r["sigma2_e"][j]
+    j = 2
+    pin = O.scan(Y[:, j:j + 1], G, K, covar=Cov, assumption="alt", h2_each_override=r["h2_panel"][:, j],
+                 h2_null_override=r["h2_null_list"][j], **kw)
+    assert_lod_close(r["L"][:, j], pin["lod"], atol=1e-9)
+    own = O.scan(Y[:, j:j + 1], G, K, covar=Cov, assumption="alt", **kw)
+    assert abs(own["h2_null"] - r["h2_null_list"][j]) <= 1e-6
+    assert np.quantile(np.abs(own["lod"] - r["L"][:, j]), 0.9) <= 1e-6 * max(1.0, np.abs(own["lod"]).max()) + 1e-7
