@@ -207,7 +207,17 @@ __global__ void __launch_bounds__(512) k_sytrd(const double* __restrict__ A, int
     const double alpha = sx[k + 1];
     double beta, tk, sc;
     if (s1 <= s1_negl) { beta = alpha; tk = 0.0; sc = 0.0; }
-    else { beta = -copysign(sqrt(fma(alpha, alpha, s1)), alpha); tk = (beta - alpha) / beta; sc = 1.0 / (alpha - beta); }
+    else {
+      // one v_rsq_f64 + Newton and one v_rcp_f64 + Newton where an IEEE square root and two IEEE divisions stood on the critical
+      // path of every step (as in small_sytrd): tau = (beta - alpha) / beta = 1 + |alpha| / |x|, 1 / (alpha - beta) = sign(alpha) / (|alpha| + |x|)
+      const double hh = fma(alpha, alpha, s1), rs = fast_rsqrt(hh), nrm = hh * rs;
+      beta = -copysign(nrm, alpha);
+      tk = fma(fabs(alpha), rs, 1.0);
+      double y = __builtin_amdgcn_rcp(fabs(alpha) + nrm);
+      y = fma(y, fma(-(fabs(alpha) + nrm), y, 1.0), y);
+      y = fma(y, fma(-(fabs(alpha) + nrm), y, 1.0), y);
+      sc = copysign(y, alpha);
+    }
     const double vpk1 = svp[k + 1], wpk1 = swp[k + 1];
     const double vpv = fma(sc, s2, vpk1), wpv = fma(sc, s3, wpk1);      // vp'v and wp'v with v = (1, sc x[k+2:])
     PSTAMP(0);
