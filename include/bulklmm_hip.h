@@ -87,7 +87,7 @@ typedef struct blmm_status {
   int64_t n_zero_norm;     /* |column norm| <= eps          -> error,   src/util.jl:47-71              */
   int64_t n_nan_lod;       /* r^2 > 1 (DomainError in the reference, NaN here), src/bulkscan_helpers.jl:23 */
   int64_t n_brent_maxiter; /* traits whose Brent search hit 1000 iterations                            */
-  int64_t jacobi_sweeps;   /* sweeps used by the device eigensolver                                   */
+  int64_t jacobi_sweeps;   /* sweeps of the LDS Jacobi; 0: n <= 124 and the fast path's result stood, or n > 124 */
   int64_t jacobi_cycles;   /* shader cycles / 100 MHz ticks spent inside the eigensolver (diagnostic)  */
   int64_t jacobi_ticks_100mhz;
   int64_t lowrank_rank;    /* rank R of the weight-family basis used by the null-exact kernel (kernels_lowrank.hip) */
