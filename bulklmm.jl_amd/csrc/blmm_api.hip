@@ -243,19 +243,13 @@ int prepare_eigen(blmm_ctx* ctx, const blmm_opts* o, int64_t n, const double* dC
   // n <= 124: LDS Jacobi.  Beyond: the own tridiagonalisation + divide-and-conquer solver (kernels_eig.hip) up to n = 2048 (its
   // reduction keeps the matrix in LDS up to ~1450 and in L2-resident global memory beyond).  No vendor library: rocSOLVER's first
   // use in a process takes MINUTES on this image (code-object load) and its path could not be part of the default test run.
-  // BLMM_EIGEN = dc | small | jacobi overrides the choice (A/B timing and tests; "dc" also for n <= 124; "jacobi" beyond 124 is the
+  // BLMM_EIGEN = dc | jacobi overrides the choice (A/B timing and tests; "dc" also for n <= 124; "jacobi" beyond 124 is the
   // single-workgroup global-memory Jacobi: 0.74 s at n = 333).
   const char* eig_env = getenv("BLMM_EIGEN");
   const bool big = n > jacobi_lds_max_n();
   P.big = big;
   bool done = false;
   const bool want_dc = eig_env ? std::strcmp(eig_env, "dc") == 0 : big;
-  const bool want_small = eig_env && std::strcmp(eig_env, "small") == 0;    // the fused single-workgroup solver (n <= 92)
-  if (want_small && n >= 3 && n <= eig_small_max_n()) {
-    rc = launch_eig_small(ctx, ptr<double>(ctx->Ks), (int)n, ptr<double>(ctx->lraw), ptr<double>(ctx->V), P.stat);
-    if (rc == BLMM_OK) { done = true; P.big = true; }
-    else if (rc != BLMM_ERR_UNSUPPORTED) return rc;
-  }
   if (!done && want_dc && n >= 3) {
     rc = launch_eig_dc(ctx, ptr<double>(ctx->Ks), (int)n, ptr<double>(ctx->lraw), ptr<double>(ctx->V), P.stat);
     if (rc == BLMM_OK) { done = true; P.big = true; }

@@ -133,8 +133,6 @@ int launch_eig_dc(blmm_ctx* ctx, const double* A, int n, double* lraw, double* e
 int eig_dc_max_n(const blmm_ctx* ctx);
 int launch_eig_fast(blmm_ctx* ctx, const double* A, int n, double* lraw, double* evec, int64_t* stat);
 int eig_fast_max_n();
-int launch_eig_small(blmm_ctx* ctx, const double* A, int n, double* lraw, double* evec, int64_t* stat);
-int eig_small_max_n();
 int jacobi_lds_max_n();
 // lambda (ascending, or |lambda| descending for svd), U sorted, Z0 = U' Zs, Rp = (centered ? Q U' Wd : U' Wd)'
 int launch_post_eigen(blmm_ctx* ctx, const double* lraw, const double* V, const double* Zs, const double* dweights, int n,

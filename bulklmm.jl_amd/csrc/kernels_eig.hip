@@ -959,196 +959,17 @@ __global__ void __launch_bounds__(NT) k_backtransform(const double* __restrict__
 
 
 // ---------------------------------------------------------------------------------------------------------------------
-// 5. small n (<= EIGS_NMAX): the WHOLE decomposition in one workgroup and one launch -- tridiagonalisation, leaves, the
-// merge tree and the back-transformation, matrix and eigenvectors resident in LDS.  This is the BXD case (n = 79), where
-// the eigen-decomposition is a serial front of the call that sharding traits over GPUs does not shorten.
-//   M1 (n x n): K during the reduction (full symmetric storage), then the secular differences / merge weights;
-//   M2 (n x n): the eigenvector blocks Q[row][col] (row-major), merged in place row by row.
-// Reduction: column form of the matrix-vector product (thread (j, rs) sums A[i][j] v[i] over its row subset: no
-// cross-lane reduction), the rank-2 update of the previous step applied in the same pass; wave 0 does the O(n) vector work
-// of a step while the others wait: two barriers per step.
+// 5. n <= 124: the tridiagonalisation inside ONE workgroup, matrix resident in LDS (the BXD case, n = 79, where the
+// eigen-decomposition is a serial front of the call that sharding traits over GPUs does not shorten).  Round 2 continued in the
+// same workgroup with QL leaves, the merge tree and the back-transformation (`k_eig_small`: 0.89 ms, slower than the Jacobi);
+// round 3 keeps only the reduction and hands T to the parallel fast path of section 6.
 // ---------------------------------------------------------------------------------------------------------------------
-constexpr int EIGS_NMAX = 92;
-
-struct SmallWs {   // LDS carve-up (doubles unless noted)
-  double *M1, *M2, *sx, *sv, *sw, *svp, *swp, *part, *d, *e, *tau, *lamA, *lamB, *dl, *zl, *zh, *defld, *lamnew, *rotc, *rots, *ds, *zs, *red;
-  int *colidx, *deflcol, *rota, *rotb, *posn, *posd, *ord, *srck, *srci;
+struct SmallWs {   // LDS carve-up of the reduction (doubles); M2 optional (zeroed when given)
+  double *M1, *M2, *sx, *sv, *svp, *swp, *part, *d, *e, *tau, *red;
 };
 
-// merge of the solved halves [lo, mid) and [mid, hi) inside the workgroup (same steps as the k_dc_* kernels)
-__device__ void small_merge(const SmallWs& w, int n, int lo, int mid, int hi, const double* lamIn, double* lamOut, int* s_info, double tnorm) {
-  const int t = threadIdx.x, NT = blockDim.x, lane = t & 63, wave = t >> 6, nwave = NT >> 6;
-  const int N = hi - lo;
-  const double beta = w.e[mid - 1];
-  const double sgn = (beta < 0.0) ? -1.0 : 1.0;
-  const double rho = 2.0 * fabs(beta);
-  double* sd = w.sx;   // scratch vectors of the reduction are free now
-  double* sz = w.sv;
-  for (int j = t; j < N; j += NT) {
-    sd[j] = lamIn[lo + j];
-    const int col = lo + j;
-    const double zr = (col < mid) ? w.M2[(mid - 1) * n + col] : sgn * w.M2[mid * n + col];
-    sz[j] = zr * 0.7071067811865476;
-  }
-  __syncthreads();
-  double dm = 0.0, zm = 0.0;
-  for (int j = t; j < N; j += NT) { dm = fmax(dm, fabs(sd[j])); zm = fmax(zm, fabs(sz[j])); }
-  dm = block_max(dm, w.red);
-  zm = block_max(zm, w.red);
-  const double tol = 8.0 * EPS * fmax(dm, zm * tnorm);   // see k_dc_deflate
-  for (int j = t; j < N; j += NT) {
-    const double v = sd[j];
-    int rank = 0;
-    for (int i = 0; i < N; ++i) rank += (sd[i] < v) || (sd[i] == v && i < j);
-    w.ord[rank] = j; w.ds[rank] = v; w.zs[rank] = sz[j];
-  }
-  __syncthreads();
-  if (t == 0) {
-    int K = 0, nd = 0, nr = 0;
-    if (rho * zm <= tol) {
-      for (int s = 0; s < N; ++s) { w.defld[nd] = w.ds[s]; w.deflcol[nd] = lo + w.ord[s]; ++nd; }
-    } else {
-      int havep = 0, cp = 0;
-      double dp = 0.0, zp = 0.0;
-      for (int s = 0; s < N; ++s) {
-        const double dn = w.ds[s], zn = w.zs[s];
-        const int cn = w.ord[s];
-        if (rho * fabs(zn) <= tol) { w.defld[nd] = dn; w.deflcol[nd] = lo + cn; ++nd; continue; }
-        if (!havep) { havep = 1; dp = dn; zp = zn; cp = cn; continue; }
-        const double tt = dn - dp, tau2 = fma(zn, zn, zp * zp);
-        if (fabs(tt * zn * zp) <= tol * tau2) {
-          const double tau = sqrt(tau2);
-          const double cs = zn / tau, sn = -zp / tau;
-          w.rota[nr] = lo + cp; w.rotb[nr] = lo + cn; w.rotc[nr] = cs; w.rots[nr] = sn; ++nr;
-          const double dpn = dp * cs * cs + dn * sn * sn, dnn = dp * sn * sn + dn * cs * cs;
-          w.defld[nd] = dpn; w.deflcol[nd] = lo + cp; ++nd;
-          dp = dnn; zp = tau; cp = cn;
-        } else {
-          w.dl[K] = dp; w.zl[K] = zp; w.colidx[K] = lo + cp; ++K;
-          dp = dn; zp = zn; cp = cn;
-        }
-      }
-      if (havep) { w.dl[K] = dp; w.zl[K] = zp; w.colidx[K] = lo + cp; ++K; }
-    }
-    s_info[0] = K; s_info[1] = nd; s_info[2] = nr;
-  }
-  __syncthreads();
-  const int K = s_info[0], nr = s_info[2];
-  // Givens rotations of the close-pole deflations: one thread per row of the node
-  if (nr > 0 && t < N) {
-    double* row = w.M2 + (lo + t) * n;
-    for (int q = 0; q < nr; ++q) {
-      const int a = w.rota[q], b = w.rotb[q];
-      const double c = w.rotc[q], sn = w.rots[q];
-      const double x = row[a], y = row[b];
-      row[a] = c * x + sn * y; row[b] = c * y - sn * x;
-    }
-  }
-  // secular roots: one wave per root (as k_dc_secular); differences into M1[i][j]
-  for (int i = wave; i < K; i += nwave) {
-    int org;
-    double a, b;
-    if (i < K - 1) {
-      const double left = w.dl[i], midp = 0.5 * (w.dl[i + 1] - left);
-      double f = 0.0;
-      for (int j = lane; j < K; j += 64) { const double z = w.zl[j]; f += z * z / ((w.dl[j] - left) - midp); }
-      f = 1.0 + rho * wsum(f);
-      if (f > 0.0) { org = i; a = 0.0; b = midp; } else { org = i + 1; a = -midp; b = 0.0; }
-      if (f == 0.0) { org = i; a = midp; b = midp; }
-    } else {
-      double s2 = 0.0;
-      for (int j = lane; j < K; j += 64) { const double z = w.zl[j]; s2 = fma(z, z, s2); }
-      org = K - 1; a = 0.0; b = rho * wsum(s2);
-    }
-    const double dorg = w.dl[org];
-    double tcur = 0.5 * (a + b);
-    const double poleL = w.dl[i] - dorg, poleR = (i < K - 1) ? w.dl[i + 1] - dorg : 0.0;
-    for (int it = 0; it < 100 && a < b; ++it) {
-      double ps = 0.0, psp = 0.0, ph = 0.0, php = 0.0;
-      for (int j = lane; j < K; j += 64) {
-        const double z = w.zl[j];
-        const double q = 1.0 / ((w.dl[j] - dorg) - tcur);
-        const double zq = z * z * q;
-        if (j <= i) { ps += zq; psp = fma(zq, q, psp); } else { ph += zq; php = fma(zq, q, php); }
-      }
-      ps = rho * wsum(ps); psp = rho * wsum(psp); ph = rho * wsum(ph); php = rho * wsum(php);
-      const double f = 1.0 + ps + ph;
-      if (f == 0.0) break;
-      if (f > 0.0) b = tcur; else a = tcur;
-      double tn;
-      const double dL = poleL - tcur;
-      const double sps = psp * dL * dL, rps = ps - psp * dL;
-      if (i < K - 1) {
-        const double dR = poleR - tcur;
-        const double sph = php * dR * dR, rph = ph - php * dR;
-        const double c = 1.0 + rps + rph;
-        const double a2 = c, a1 = -(c * (poleL + poleR) + sps + sph), a0 = c * poleL * poleR + sps * poleR + sph * poleL;
-        const double disc = a1 * a1 - 4.0 * a2 * a0;
-        tn = tcur;
-        if (disc >= 0.0) {
-          const double qq = -0.5 * (a1 + copysign(sqrt(disc), a1));
-          const double r1 = (a2 != 0.0) ? qq / a2 : a, r2 = (qq != 0.0) ? a0 / qq : a;
-          tn = (a < r1 && r1 < b) ? r1 : r2;
-        }
-      } else {
-        tn = poleL + sps / (1.0 + rps);
-      }
-      if (!(a < tn && tn < b)) tn = 0.5 * (a + b);
-      if (tn == tcur || b - a <= 2.0 * EPS * fmax(fabs(a), fabs(b)) || fabs(tn - tcur) <= EPS * fabs(tn)) { tcur = tn; break; }
-      tcur = tn;
-    }
-    if (lane == 0) w.lamnew[i] = dorg + tcur;
-    for (int j = lane; j < K; j += 64) w.M1[i * n + j] = (w.dl[j] - dorg) - tcur;
-  }
-  __syncthreads();
-  // z-hat (one wave per pole), then the normalised weights in place (one wave per root)
-  for (int j = wave; j < K; j += nwave) {
-    const double dj = w.dl[j];
-    double prod = 1.0;
-    for (int i = lane; i < K; i += 64) { const double dij = w.M1[i * n + j]; prod *= (i == j) ? dij : dij / (dj - w.dl[i]); }
-    prod = wprod(prod);
-    if (lane == 0) w.zh[j] = copysign(sqrt(fabs(prod)), w.zl[j]);
-  }
-  __syncthreads();
-  for (int i = wave; i < K; i += nwave) {
-    double* wr = w.M1 + i * n;
-    double s2 = 0.0;
-    for (int j = lane; j < K; j += 64) { const double v = w.zh[j] / wr[j]; wr[j] = v; s2 = fma(v, v, s2); }
-    s2 = 1.0 / sqrt(wsum(s2));
-    for (int j = lane; j < K; j += 64) wr[j] *= s2;
-  }
-  // positions in ascending order and, per output column, where it comes from
-  if (t < N) {
-    const double v = (t < K) ? w.lamnew[t] : w.defld[t - K];
-    int rank = 0;
-    for (int i = 0; i < N; ++i) { const double u = (i < K) ? w.lamnew[i] : w.defld[i - K]; rank += (u < v) || (u == v && i < t); }
-    lamOut[lo + rank] = v;
-    w.srck[rank] = (t < K) ? 1 : 0;
-    w.srci[rank] = (t < K) ? t : w.deflcol[t - K];
-  }
-  __syncthreads();
-  // Q <- Q W row by row, in place: a wave reads everything it needs of its row before it writes (program order of one wave)
-  for (int r = wave; r < N; r += nwave) {
-    double* row = w.M2 + (lo + r) * n;
-    double outv[2];
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      const int c = lane + 64 * h;
-      double acc = 0.0;
-      if (c < N) {
-        if (w.srck[c]) { const double* wr = w.M1 + w.srci[c] * n; for (int j = 0; j < K; ++j) acc = fma(wr[j], row[w.colidx[j]], acc); }
-        else acc = row[w.srci[c]];
-      }
-      outv[h] = acc;
-    }
-#pragma unroll
-    for (int h = 0; h < 2; ++h) { const int c = lane + 64 * h; if (c < N) row[lo + c] = outv[h]; }
-  }
-  __syncthreads();
-}
-
-// Householder tridiagonalisation of the n x n matrix A inside ONE workgroup (n <= EIGS_NMAX), shared by k_eig_small and
-// k_eig_fast: A is copied to w.M1 (LDS, full symmetric storage; w.M2 zeroed), on return w.d / w.e / w.tau hold the diagonal, the
+// Householder tridiagonalisation of the n x n matrix A inside ONE workgroup of 1024 threads (n <= 128; k_eigf_reduce): A is
+// copied to w.M1 (LDS, full symmetric storage), on return w.d / w.e / w.tau hold the diagonal, the
 // off-diagonal and the reflector scalars of T = H' A H and Vg[k * n + j] the reflector vectors (v[k + 1] = 1).  Column form of the
 // matrix-vector product (thread (j, rs) sums A[i][j] v[i] over its row subset: no cross-lane reduction), the rank-2 update of the
 // previous step applied in the same pass; wave 0 does the O(n) vector work of a step while the others wait: two barriers per step.
@@ -1260,140 +1081,6 @@ __device__ void small_sytrd(const SmallWs& w, const double* __restrict__ A, int 
     __syncthreads();
   }
 }
-
-__global__ void __launch_bounds__(1024) k_eig_small(const double* __restrict__ A, int n, double* __restrict__ lam_out,
-                                                    double* __restrict__ evec, double* __restrict__ Vg, int64_t* stat) {
-  extern __shared__ __attribute__((aligned(16))) double sh[];
-  const int t = threadIdx.x, NT = blockDim.x, lane = t & 63, wave = t >> 6, nwave = NT >> 6;
-  __shared__ int s_info[4];
-  __shared__ double s_sc[4];   // {tau, sc, akk, beta} of the current step
-  SmallWs w;
-  {
-    double* q = sh;
-    w.M1 = q; q += n * n; w.M2 = q; q += n * n;
-    w.sx = q; q += n; w.sv = q; q += n; w.sw = q; q += n; w.svp = q; q += n; w.swp = q; q += n;
-    w.part = q; q += 8 * 128;
-    w.d = q; q += n; w.e = q; q += n; w.tau = q; q += n; w.lamA = q; q += n; w.lamB = q; q += n;
-    w.dl = q; q += n; w.zl = q; q += n; w.zh = q; q += n; w.defld = q; q += n; w.lamnew = q; q += n;
-    w.rotc = q; q += n; w.rots = q; q += n; w.ds = q; q += n; w.zs = q; q += n; w.red = q; q += 16;
-    int* iq = reinterpret_cast<int*>(q);
-    w.colidx = iq; iq += n; w.deflcol = iq; iq += n; w.rota = iq; iq += n; w.rotb = iq; iq += n; w.posn = iq; iq += n;
-    w.posd = iq; iq += n; w.ord = iq; iq += n; w.srck = iq; iq += n; w.srci = iq; iq += n;
-  }
-#ifdef SYTRD_PROF
-  long long qf[6] = {0, 0, 0, 0, 0, 0}, qt0 = __builtin_amdgcn_s_memtime();
-#define QSTAMP(i) do { const long long t1__ = __builtin_amdgcn_s_memtime(); qf[i] += t1__ - qt0; qt0 = t1__; } while (0)
-#else
-#define QSTAMP(i) do { } while (0)
-#endif
-  small_sytrd(w, A, n, Vg, s_sc);
-  QSTAMP(1);
-  // ---- 2. leaves: implicit QL, one wave per leaf ---------------------------------------------------------------------
-  int nl = 1;
-  while ((n + nl - 1) / nl > 24) nl *= 2;
-  auto bound = [&](int i) { return (int)(((long long)i * n + nl / 2) / nl); };
-  if (wave < nl) {
-    const int lo = bound(wave), hi = bound(wave + 1), N = hi - lo, r = lane;
-    double* sd = w.lamB + lo;     // scratch: the leaf's diagonal / off-diagonal
-    double* se = w.dl + lo;
-    if (r < N) {
-      double dv = w.d[lo + r];
-      if (r == 0 && lo > 0) dv -= fabs(w.e[lo - 1]);
-      if (r == N - 1 && hi < n) dv -= fabs(w.e[hi - 1]);
-      sd[r] = dv; se[r] = (r < N - 1) ? w.e[lo + r] : 0.0;
-      w.M2[(lo + r) * n + lo + r] = 1.0;
-    }
-    double* Z = w.M2 + lo * n + lo;   // Z[r][c] = Z[r * n + c]
-    double tnorm = 0.0;                // see k_tql_leaves: negligible also relative to the norm of T
-    for (int j = 0; j < n; ++j) tnorm = fmax(tnorm, fmax(fabs(w.d[j]), (j < n - 1) ? fabs(w.e[j]) : 0.0));
-    const double abs_small = EPS * tnorm;
-    bool failed = false;
-    for (int l = 0; l < N && !failed; ++l) {
-      int iter = 0;
-      for (;;) {
-        int m = l;
-        for (; m < N - 1; ++m) { const double dd = fabs(sd[m]) + fabs(sd[m + 1]); if (fabs(se[m]) <= EPS * dd || fabs(se[m]) <= abs_small) break; }
-        if (m == l) break;
-        if (++iter > 80) { failed = true; break; }
-        double gg = (sd[l + 1] - sd[l]) / (2.0 * se[l]);
-        double rr = sqrt(fma(gg, gg, 1.0));
-        gg = sd[m] - sd[l] + se[l] / (gg + copysign(rr, gg));
-        double s = 1.0, c = 1.0, p = 0.0;
-        int i = m - 1;
-        bool under = false;
-        for (; i >= l; --i) {
-          const double ei = se[i], di = sd[i], di1 = sd[i + 1];
-          const double f = s * ei, b = c * ei;
-          rr = sqrt(fma(f, f, gg * gg));
-          if (r == 0) se[i + 1] = rr;
-          if (rr == 0.0) { if (r == 0) { sd[i + 1] = di1 - p; se[m] = 0.0; } under = true; break; }
-          const double ir = 1.0 / rr;
-          s = f * ir; c = gg * ir;
-          gg = di1 - p;
-          rr = (di - gg) * s + 2.0 * c * b;
-          p = s * rr;
-          if (r == 0) sd[i + 1] = gg + p;
-          gg = c * rr - b;
-          if (r < N) { const double f2 = Z[r * n + i + 1], z0 = Z[r * n + i]; Z[r * n + i + 1] = s * z0 + c * f2; Z[r * n + i] = c * z0 - s * f2; }
-        }
-        if (under) continue;
-        if (r == 0) { sd[l] -= p; se[l] = gg; se[m] = 0.0; }
-      }
-    }
-    if (failed && r == 0) stat[11] = -8;
-    // ascending order: permute the leaf's columns through registers (one wave: reads complete before the writes)
-    int src = 0;
-    double lv = 0.0;
-    if (r < N) {
-      int rank = 0;
-      const double v = sd[r];
-      for (int j = 0; j < N; ++j) rank += (sd[j] < v) || (sd[j] == v && j < r);
-      w.ord[lo + rank] = r;
-    }
-    if (r < N) { src = w.ord[lo + r]; lv = sd[src]; }
-    double zrow[24];
-#pragma unroll
-    for (int c = 0; c < 24; ++c) zrow[c] = (r < N && c < N) ? Z[r * n + w.ord[lo + c]] : 0.0;
-#pragma unroll
-    for (int c = 0; c < 24; ++c) if (r < N && c < N) Z[r * n + c] = zrow[c];
-    if (r < N) w.lamA[lo + r] = lv;
-  }
-  __syncthreads();
-  QSTAMP(2);
-  // ---- 3. merges -----------------------------------------------------------------------------------------------------
-  double tnorm_all = 0.0;            // max-norm of T: the deflation tolerance is relative to it (k_dc_deflate)
-  for (int j = 0; j < n; ++j) tnorm_all = fmax(tnorm_all, fmax(fabs(w.d[j]), (j < n - 1) ? fabs(w.e[j]) : 0.0));
-  double* lamIn = w.lamA; double* lamOut = w.lamB;
-  for (int width = 1; width < nl; width *= 2) {
-    for (int b0 = 0; b0 + 2 * width <= nl; b0 += 2 * width) {
-      const int lo = bound(b0), mid = bound(b0 + width), hi = bound(b0 + 2 * width);
-      small_merge(w, n, lo, mid, hi, lamIn, lamOut, s_info, tnorm_all);
-    }
-    { double* tmp = lamIn; lamIn = lamOut; lamOut = tmp; }
-    __syncthreads();
-  }
-  QSTAMP(3);
-  // ---- 4. back-transformation U = H Z: reflectors back into LDS (M1), every wave owns columns of Z in registers ------
-  for (int e0 = t; e0 < (n - 2) * n; e0 += NT) w.M1[e0] = Vg[e0];
-  __syncthreads();
-  for (int c = wave; c < n; c += nwave) {
-    double z0 = (lane < n) ? w.M2[lane * n + c] : 0.0, z1 = (lane + 64 < n) ? w.M2[(lane + 64) * n + c] : 0.0;
-    for (int k = n - 3; k >= 0; --k) {
-      const double* v = w.M1 + k * n;
-      const double v0 = (lane > k && lane < n) ? v[lane] : 0.0, v1 = (lane + 64 > k && lane + 64 < n) ? v[lane + 64] : 0.0;
-      const double dot = wsum(fma(v0, z0, v1 * z1)) * w.tau[k];
-      z0 = fma(-dot, v0, z0); z1 = fma(-dot, v1, z1);
-    }
-    if (lane < n) evec[c * n + lane] = z0;
-    if (lane + 64 < n) evec[c * n + lane + 64] = z1;
-  }
-  for (int j = t; j < n; j += NT) lam_out[j] = lamIn[j];
-  QSTAMP(4);
-#ifdef SYTRD_PROF
-  if (t == 0) printf("eig_small prof n %d: load %lld reduction %lld leaves %lld merges %lld backtransform %lld cycles\n", n, qf[0], qf[1], qf[2], qf[3], qf[4]);
-#endif
-}
-
 
 // ---------------------------------------------------------------------------------------------------------------------
 // 6. n <= 124, the FAST path (round 3), three launches:
@@ -1601,22 +1288,6 @@ __global__ void __launch_bounds__(256) k_eigf_pairs(int n, const double* __restr
 // Largest n the solver takes: the back-transformation holds a column in 32 registers per lane of a wave (n <= 2048), and the
 // seven vectors of k_sytrd fit the LDS up to there; its rows move to global memory where the LDS budget ends (~1450).
 int eig_dc_max_n(const blmm_ctx*) { return 2048; }
-
-int eig_small_max_n() { return EIGS_NMAX; }
-
-// n <= EIGS_NMAX: the fused single-workgroup solver
-int launch_eig_small(blmm_ctx* ctx, const double* A, int n, double* lraw, double* evec, int64_t* stat) {
-  if (n < 3 || n > EIGS_NMAX) return BLMM_ERR_UNSUPPORTED;
-  int rc;
-  if ((rc = ensure(ctx, ctx->eigW, sizeof(double) * (size_t)n * n + 256))) return rc;
-  const size_t lds = sizeof(double) * ((size_t)2 * n * n + (size_t)19 * n + 8 * 128 + 16) + sizeof(int) * (size_t)9 * n + 64;
-  if (lds > 160 * 1024) return BLMM_ERR_UNSUPPORTED;
-  BLMM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_eig_small), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  hipLaunchKernelGGL(k_eig_small, dim3(1), dim3(1024), lds, ctx->stream, A, n, lraw, evec, ptr<double>(ctx->eigW), stat);
-  KCHECK();
-  ctx->eig_plan_n = -1;    // the workspace was reused: a cached merge tree of the multi-workgroup solver is gone
-  return BLMM_OK;
-}
 
 // The fast path for 3 <= n <= 124 (k_eigf_reduce, k_eigf_pairs, k_backtransform with the orthogonality check).  The device decides
 // whether the result stands (stat[ST_EIG_FAST] = 1: it ran; stat[ST_EIG_BAD]: largest check / bound as the bits of a double, accepted

@@ -21,7 +21,6 @@ import numpy as np, sys, os
 sys.path.insert(0, "."); sys.path.insert(0, "tests")
 import bulklmm_jl_amd as B
 from common import bxd_kinship
-os.environ["BLMM_EIGEN"] = "small"
 K = bxd_kinship()
 for _ in range(2):
     B.transform_rotation(np.eye(79)[:, :2], np.ones((79, 2)), K)
