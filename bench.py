@@ -230,7 +230,7 @@ def main():
             # all-gather of the k-major blocks over xGMI, blmm_bulkscan_prerotated_dev) instead of repeated by every rank; at
             # n = 79 the whole rotation is 15 us and the replicated form is the faster one.  This all-gather is a data-path
             # collective INSIDE the step.
-            self.shard_rot = shard_rotation and not perms
+            self.shard_rot = shard_rotation
             if self.shard_rot:
                 self.bc = -(-p // world)
                 rows = -(-n // 8) * 8
@@ -239,14 +239,17 @@ def main():
 
         def scan(self, c=None, L=None, H=None):
             c = c or ctx; L = self.dL if L is None else L; H = self.dH if H is None else H
-            if perms:
-                B.scan_perms_dev(c, self.dy1, dG, dK, self.dsc, self.dlod, L, nperms=self.m, seed=1 + rank)
-            elif self.shard_rot:
+            if self.shard_rot:
                 B.prepare_dev(c, dK)
                 if self.gblk.shape[0] > 0:
                     B.rotate_block_dev(c, self.gblk, self.gx[rank])
                 dist.all_gather_into_tensor(self.gx.view(-1), self.gx[rank].reshape(-1))
-                B.bulkscan_prerotated_dev(c, self.dY, self.gx, p, self.bc, L, H, method=a.method, h2_grid=grid)
+                if perms:
+                    B.scan_perms_prerotated_dev(c, self.dy1, self.gx, p, self.bc, self.dsc, self.dlod, L, nperms=self.m, seed=1 + rank)
+                else:
+                    B.bulkscan_prerotated_dev(c, self.dY, self.gx, p, self.bc, L, H, method=a.method, h2_grid=grid)
+            elif perms:
+                B.scan_perms_dev(c, self.dy1, dG, dK, self.dsc, self.dlod, L, nperms=self.m, seed=1 + rank)
             else:
                 B.bulkscan_dev(c, self.dY, dG, dK, L, H, method=a.method, h2_grid=grid, log10p_out=self.dP)
 
@@ -440,7 +443,7 @@ def main():
             "scaling": a.scaling, "vs_baseline": None, "dtype": "f32" if f32 else "f64", "data": "synthetic",
             "config": {"workload": workload_name(a, n, p, m_total, m_local, f32, world),
                        "n": n, "p": p, "m": m_total, "m_per_gpu": m_local, "method": a.method,
-                       "parallelism": f"traits sharded over {world} GPU(s)" + ("; marker rotation sharded, rotated blocks all-gathered over xGMI inside the step" if shard_rotation and not perms else ""),
+                       "parallelism": f"traits sharded over {world} GPU(s)" + ("; marker rotation sharded, rotated blocks all-gathered over xGMI inside the step" if shard_rotation else ""),
                        "gather_in_step": bool(a.gather),
                        "streams": max(a.streams, 1)},
             "phases_ms": {k: v / max(ncalls, 1) for k, v in phases.items()},

@@ -26,7 +26,7 @@ EXPORTS = [
     "blmm_last_log10p", "blmm_last_lod_threshold", "blmm_last_get_thresholds", "blmm_set_log10p_output",
     "blmm_read_csv", "blmm_read_he", "blmm_table_rows", "blmm_table_cols", "blmm_table_copy", "blmm_table_free",
     "blmm_kinship_rounded", "blmm_scan_alt", "blmm_scan_alt_dev", "blmm_bulkscan_alt_exact", "blmm_bulkscan_alt_exact_dev",
-    "blmm_prepare_dev", "blmm_rotated_rows", "blmm_rotate_block_dev", "blmm_bulkscan_prerotated_dev",
+    "blmm_prepare_dev", "blmm_rotated_rows", "blmm_rotate_block_dev", "blmm_bulkscan_prerotated_dev", "blmm_scan_perms_prerotated_dev",
 ]
 
 BLMM_NULL_EXACT, BLMM_NULL_GRID, BLMM_ALT_GRID = 0, 1, 2
@@ -121,6 +121,7 @@ def load():
     lib.blmm_rotated_rows.restype = i64
     lib.blmm_rotate_block_dev.argtypes = [vp, vp, i64, vp, i64]
     lib.blmm_bulkscan_prerotated_dev.argtypes = [vp, op, vp, i64, i64, vp, i64, i64, i64, vp, i64, vp, i64, vp, sp]
+    lib.blmm_scan_perms_prerotated_dev.argtypes = [vp, op, vp, i64, vp, i64, i64, i64, i64, C.c_uint64, vp, vp, vp, vp, vp, sp]
     lib.blmm_lod_colmax.argtypes = [vp, vp, i64, i64, vp, vp]
     lib.blmm_lod_colmax_dev.argtypes = [vp, vp, i64, i64, i64, vp, vp]
     lib.blmm_rotate.argtypes = [vp, op, vp, i64, i64, vp, i64, vp, i64, vp, vp, vp, vp, sp]

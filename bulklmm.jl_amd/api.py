@@ -776,6 +776,26 @@ def _ld(t, p):
     return t.stride(0) if t.shape[0] > 1 else max(p, t.stride(0))
 
 
+def scan_perms_prerotated_dev(ctx: Context, y, Xt_blocks, p: int, block_cols: int, scalars_out, lod_out, Lperms_out, *, nperms: int,
+                              seed: int = 0, perm_idx=None, prior_variance: float = 0.0, prior_sample_size: float = 0.0,
+                              reml: bool = False, optim_interval: int = 1, status: bool = False):
+    """blmm_scan_perms_prerotated_dev (after prepare_dev on this context): the permutation test on the gathered rotated marker
+    blocks Xt_blocks (nblocks, rows, block_ld); y (n,), scalars_out (2,), lod_out (p,), Lperms_out (nperms, p) float64 or float32
+    (fp32 matrix cores), perm_idx (nperms, n) int32 or None (the library's generator with `seed`)."""
+    import torch
+    o = _opts(L.BLMM_NULL_EXACT, reml, True, "eigen", optim_interval, prior_variance, prior_sample_size)
+    st = L.blmm_status() if status else None
+    nb, rows, bld = Xt_blocks.shape
+    assert Xt_blocks.is_contiguous() and rows == rotated_rows(ctx)
+    f32 = Lperms_out is not None and Lperms_out.dtype == torch.float32
+    ctx.check(ctx.lib.blmm_scan_perms_prerotated_dev(ctx.h, C.byref(o), y.data_ptr(), int(p), Xt_blocks.data_ptr(), nb, int(block_cols), bld,
+                                                     int(nperms), C.c_uint64(int(seed)), None if perm_idx is None else perm_idx.data_ptr(),
+                                                     scalars_out.data_ptr(), lod_out.data_ptr(),
+                                                     None if (f32 or Lperms_out is None) else Lperms_out.data_ptr(),
+                                                     Lperms_out.data_ptr() if f32 else None, C.byref(st) if status else None))
+    return st
+
+
 def scan_perms_dev(ctx: Context, y, G, K, scalars_out, lod_out, Lperms_out, *, nperms: int, seed: int = 0, perm_idx=None,
                    Covar=None, weights=None, addIntercept: bool = True, prior_variance: float = 0.0,
                    prior_sample_size: float = 0.0, reml: bool = False, optim_interval: int = 1,

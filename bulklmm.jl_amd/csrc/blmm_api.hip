@@ -1022,6 +1022,23 @@ int blmm_rotate_block_dev(blmm_ctx* ctx, const double* dG_block, int64_t pb, dou
   return launch_rotate(ctx, ptr<double>(ctx->Rp), P.ldr, P.n, P.npad, dG_block, pb, dXt_block, ld, ld);
 }
 
+// Xt (k-major, npad x ldx) from the gathered blocks [nblocks][npad][block_ld]: block b holds the columns [b block_cols, ..)
+static int assemble_prerotated(blmm_ctx* ctx, Pipe& P, int64_t p, const double* dXt_blocks, int64_t nblocks, int64_t block_cols,
+                               int64_t block_ld) {
+  int rc;
+  P.p = p; P.ldx = round_up(p > 0 ? p : 1, 128);
+  if ((rc = ensure(ctx, ctx->Xt, sizeof(double) * (size_t)P.npad * P.ldx))) return rc;
+  P.Xt = ptr<double>(ctx->Xt);
+  if (P.ldx > p) BLMM_HIP(hipMemset2DAsync(P.Xt + p, sizeof(double) * P.ldx, 0, sizeof(double) * (P.ldx - p), P.npad, ctx->stream));
+  for (int64_t b = 0; b < nblocks; ++b) {
+    const int64_t lo = b * block_cols, hi = (lo + block_cols < p) ? lo + block_cols : p;
+    if (hi <= lo) break;
+    BLMM_HIP(hipMemcpy2DAsync(P.Xt + lo, sizeof(double) * P.ldx, dXt_blocks + (size_t)b * P.npad * block_ld, sizeof(double) * block_ld,
+                              sizeof(double) * (hi - lo), P.npad, hipMemcpyDeviceToDevice, ctx->stream));
+  }
+  return BLMM_OK;
+}
+
 int blmm_bulkscan_prerotated_dev(blmm_ctx* ctx, const blmm_opts* opts, const double* dY, int64_t m, int64_t p,
                                  const double* dXt_blocks, int64_t nblocks, int64_t block_cols, int64_t block_ld,
                                  const double* h2_grid_host, int64_t ngrid, double* dL_out, int64_t ldL, double* dh2_out,
@@ -1053,17 +1070,7 @@ int blmm_bulkscan_prerotated_dev(blmm_ctx* ctx, const blmm_opts* opts, const dou
   const bool lowrank = opts->method == BLMM_NULL_EXACT && !(exact_env && std::strcmp(exact_env, "full") == 0) && P.c <= 3;
   if (lowrank && m > 0 && p > 0 && (rc = start_wbasis(ctx, P))) return rc;
   if ((rc = rotate_traits(ctx, P, dY, m))) return rc;
-  // Xt (k-major, npad x ldx) from the gathered blocks [nblocks][npad][block_ld]: block b holds the columns [b block_cols, ..)
-  P.p = p; P.ldx = round_up(p > 0 ? p : 1, 128);
-  if ((rc = ensure(ctx, ctx->Xt, sizeof(double) * (size_t)P.npad * P.ldx))) return rc;
-  P.Xt = ptr<double>(ctx->Xt);
-  if (P.ldx > p) BLMM_HIP(hipMemset2DAsync(P.Xt + p, sizeof(double) * P.ldx, 0, sizeof(double) * (P.ldx - p), P.npad, ctx->stream));
-  for (int64_t b = 0; b < nblocks; ++b) {
-    const int64_t lo = b * block_cols, hi = (lo + block_cols < p) ? lo + block_cols : p;
-    if (hi <= lo) break;
-    BLMM_HIP(hipMemcpy2DAsync(P.Xt + lo, sizeof(double) * P.ldx, dXt_blocks + (size_t)b * P.npad * block_ld, sizeof(double) * block_ld,
-                              sizeof(double) * (hi - lo), P.npad, hipMemcpyDeviceToDevice, ctx->stream));
-  }
+  if ((rc = assemble_prerotated(ctx, P, p, dXt_blocks, nblocks, block_cols, block_ld))) return rc;
   tm.mark();
   return scan_pipeline(ctx, opts, P, tm, lowrank, lowrank && m > 0 && p > 0, dgrid, h2_grid_host, ngrid, dL_out, ldL, dh2_out, status);
 }
@@ -1110,6 +1117,10 @@ int blmm_bulkscan(blmm_ctx* ctx, const blmm_opts* opts, const double* Y, int64_t
 
 // ---------------------------------------------------------------------------------------------------
 // dLperms_out (fp64) or dLperms32_out (fp32, kernels_scan_f32.hip): exactly one of them when nperms > 0
+static int perms_pipeline(blmm_ctx* ctx, const blmm_opts* opts, Pipe& P, Timer& tm, int64_t nperms, uint64_t seed,
+                          const int32_t* dperm_idx, double* dscalars_out, double* dlod_out, double* dLperms_out,
+                          float* dLperms32_out, blmm_status* status);
+
 static int scan_perms_impl(blmm_ctx* ctx, const blmm_opts* opts, const double* dy, int64_t n, const double* dG, int64_t p,
                            const double* dCovar, int64_t ncov, const double* dK, const double* dweights, int64_t nperms,
                            uint64_t seed, const int32_t* dperm_idx, double* dscalars_out, double* dlod_out,
@@ -1125,6 +1136,15 @@ static int scan_perms_impl(blmm_ctx* ctx, const blmm_opts* opts, const double* d
   Timer tm(ctx);
   Pipe P;
   if ((rc = prepare(ctx, opts, dy, n, 1, dG, p, dCovar, ncov, dK, dweights, 1, P, tm))) return rc;
+  return perms_pipeline(ctx, opts, P, tm, nperms, seed, dperm_idx, dscalars_out, dlod_out, dLperms_out, dLperms32_out, status);
+}
+
+// Everything of the permutation test behind the rotations (shared with blmm_scan_perms_prerotated_dev)
+static int perms_pipeline(blmm_ctx* ctx, const blmm_opts* opts, Pipe& P, Timer& tm, int64_t nperms, uint64_t seed,
+                          const int32_t* dperm_idx, double* dscalars_out, double* dlod_out, double* dLperms_out,
+                          float* dLperms32_out, blmm_status* status) {
+  int rc;
+  const int64_t p = P.p;
   const NullModel nm = null_model(P, opts);
   // scalars: [sigma2_e, h2_null]
   if ((rc = launch_brent(ctx, nm, P.Yt, P.ldy, 1, P.Z0, P.lam, dscalars_out + 1, dscalars_out, nullptr, P.stat))) return rc;
@@ -1180,6 +1200,35 @@ int blmm_scan_perms_f32_dev(blmm_ctx* ctx, const blmm_opts* opts, const double* 
   if (ctx && nperms > 0 && !dLperms_out) return fail(ctx, BLMM_ERR_INVALID, "scan_perms: NULL buffer");
   return scan_perms_impl(ctx, opts, dy, n, dG, p, dCovar, ncov, dK, dweights, nperms, seed, dperm_idx, dscalars_out,
                          dlod_out, nullptr, dLperms_out, status);
+}
+
+// One process per GPU (include/bulklmm_hip.h: the pipeline in three calls): the permutation test on marker blocks rotated by the
+// ranks and gathered by the host -- this rank's permutations (nperms, seed / dperm_idx) against all p markers.  Exactly one of
+// dLperms_out (fp64) / dLperms32_out (fp32 matrix cores) is given.  Bit-identical to blmm_scan_perms[_f32]_dev.
+int blmm_scan_perms_prerotated_dev(blmm_ctx* ctx, const blmm_opts* opts, const double* dy, int64_t p, const double* dXt_blocks,
+                                   int64_t nblocks, int64_t block_cols, int64_t block_ld, int64_t nperms, uint64_t seed,
+                                   const int32_t* dperm_idx, double* dscalars_out, double* dlod_out, double* dLperms_out,
+                                   float* dLperms32_out, blmm_status* status) {
+  if (!ctx) return BLMM_ERR_INVALID;
+  int rc = check_opts(ctx, opts);
+  if (rc) return rc;
+  if (!ctx->prep_valid) return fail(ctx, BLMM_ERR_INVALID, "scan_perms_prerotated: blmm_prepare_dev has not run on this context");
+  if (nperms < 0) return fail(ctx, BLMM_ERR_NPERMS, "The required number of permutations must be a positive integer.");
+  if (!dy || !dXt_blocks || !dscalars_out || !dlod_out || (nperms > 0 && !dLperms_out == !dLperms32_out))
+    return fail(ctx, BLMM_ERR_INVALID, "scan_perms_prerotated: NULL buffer (exactly one of the fp64 / fp32 permutation matrices)");
+  if (p < 0 || nblocks < 1 || block_cols < 1 || block_ld < block_cols || nblocks * block_cols < p) return fail(ctx, BLMM_ERR_DIM, "Dimension mismatch.");
+  BLMM_HIP(hipSetDevice(ctx->device));
+  if ((rc = check_sticky(ctx))) return rc;
+  Timer tm(ctx);
+  Pipe P = ctx->prep;
+  BLMM_HIP(hipMemsetAsync(P.stat + 1, 0, sizeof(int64_t) * 4, ctx->stream));
+  BLMM_HIP(hipMemsetAsync(P.stat + 8, 0, sizeof(int64_t) * (NSTAT - 8), ctx->stream));
+  ctx->audit_ran = false;
+  tm.mark(); tm.mark();
+  if ((rc = rotate_traits(ctx, P, dy, 1))) return rc;
+  if ((rc = assemble_prerotated(ctx, P, p, dXt_blocks, nblocks, block_cols, block_ld))) return rc;
+  tm.mark();
+  return perms_pipeline(ctx, opts, P, tm, nperms, seed, dperm_idx, dscalars_out, dlod_out, dLperms_out, dLperms32_out, status);
 }
 
 static int scan_perms_host(blmm_ctx* ctx, const blmm_opts* opts, const double* y, int64_t n, const double* G, int64_t p,

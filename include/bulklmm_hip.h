@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define BLMM_VERSION 204 /* 0.2.2: blmm_status.n_h2_boundary / n_h2_multimodal / n_illcond_rescan (appended), BLMM_FLAG_H2_AUDIT;
+#define BLMM_VERSION 205 /* 0.2.2: blmm_status.n_h2_boundary / n_h2_multimodal / n_illcond_rescan (appended), BLMM_FLAG_H2_AUDIT;
                             201: lowrank_shared, readers, blmm_scan_alt; 200: lowrank_fallback, BLMM_STREAM_NULL, multi-GPU */
 
 typedef struct blmm_ctx blmm_ctx;
@@ -186,7 +186,9 @@ int blmm_bulkscan_dev(blmm_ctx* ctx, const blmm_opts* opts, const double* dY, in
  *   blmm_rotated_rows             rows of a rotated block (n rounded up to 8); 0 before blmm_prepare_dev
  *   blmm_rotate_block_dev         dG_block n x pb (column-major) -> dXt_block rows x ld (k-major: row k contiguous), ld >= pb
  *   blmm_bulkscan_prerotated_dev  dXt_blocks = nblocks consecutive blocks of rows x block_ld doubles, block b = the markers
- *                                 [b block_cols, min(p, (b+1) block_cols)); dY n x m = this rank's traits; outputs as blmm_bulkscan_dev */
+ *                                 [b block_cols, min(p, (b+1) block_cols)); dY n x m = this rank's traits; outputs as blmm_bulkscan_dev
+ *   blmm_scan_perms_prerotated_dev  the permutation test (blmm_scan_perms[_f32]_dev) on the same gathered blocks: this rank's
+ *                                 nperms permutations against all p markers; exactly one of dLperms_out (fp64) / dLperms32_out (fp32) */
 int blmm_prepare_dev(blmm_ctx* ctx, const blmm_opts* opts, int64_t n, const double* dCovar, int64_t ncov, const double* dK,
                      const double* dweights, blmm_status* status);
 int64_t blmm_rotated_rows(const blmm_ctx* ctx);
@@ -195,6 +197,10 @@ int blmm_bulkscan_prerotated_dev(blmm_ctx* ctx, const blmm_opts* opts, const dou
                                  const double* dXt_blocks, int64_t nblocks, int64_t block_cols, int64_t block_ld,
                                  const double* h2_grid_host, int64_t ngrid, double* dL_out, int64_t ldL, double* dh2_out,
                                  blmm_status* status);
+int blmm_scan_perms_prerotated_dev(blmm_ctx* ctx, const blmm_opts* opts, const double* dy, int64_t p, const double* dXt_blocks,
+                                   int64_t nblocks, int64_t block_cols, int64_t block_ld, int64_t nperms, uint64_t seed,
+                                   const int32_t* dperm_idx, double* dscalars_out, double* dlod_out, double* dLperms_out,
+                                   float* dLperms32_out, blmm_status* status);
 
 /* ---- the same call over several GPUs of one node (north_star: traits shard across the GPUs) -----------------------
  * Replaces the reference's thread blocking over contiguous trait ranges (src/bulkscan.jl:263-309): device r of R scans

@@ -58,3 +58,36 @@ for method in ("null-exact", "null-grid", "alt-grid"):
     for c in ctxs + [ref_ctx]:
         c.close()
     print("sharded rotation ok", method, flush=True)
+
+# ---- the permutation test on the same gathered blocks: fp64 and fp32, the permutations sharded over the ranks --------------
+nperms, R = 96, 3
+y1 = dYf[0].contiguous()
+pidx_all = torch.from_numpy(np.stack([np.random.default_rng(5 + b).permutation(n) for b in range(nperms)]).astype(np.int32)).to(dev)
+for dt in (torch.float64, torch.float32):
+    ref_ctx = blmm.Context(0)
+    sc_ref = torch.empty(2, dtype=torch.float64, device=dev); lod_ref = torch.empty(p, dtype=torch.float64, device=dev)
+    Lp_ref = torch.empty((nperms, p), dtype=dt, device=dev)
+    torch.cuda.synchronize()
+    blmm.scan_perms_dev(ref_ctx, y1, dG, dK, sc_ref, lod_ref, Lp_ref, nperms=nperms, perm_idx=pidx_all)
+    ref_ctx.synchronize()
+    ctxs = [blmm.Context(0) for _ in range(R)]
+    for c in ctxs:
+        blmm.prepare_dev(c, dK)
+    gathered = torch.zeros((R, rows, bld), dtype=torch.float64, device=dev)
+    torch.cuda.synchronize()
+    for r, c in enumerate(ctxs):
+        lo, hi = r * bc, min(p, (r + 1) * bc)
+        blmm.rotate_block_dev(c, dG[lo:hi], gathered[r])
+        c.synchronize()
+    for r, c in enumerate(ctxs):
+        lo, hi = blmm.trait_shard(nperms, r, R)
+        sc = torch.empty(2, dtype=torch.float64, device=dev); lod = torch.empty(p, dtype=torch.float64, device=dev)
+        Lp = torch.empty((hi - lo, p), dtype=dt, device=dev)
+        torch.cuda.synchronize()
+        blmm.scan_perms_prerotated_dev(c, y1, gathered, p, bc, sc, lod, Lp, nperms=hi - lo, perm_idx=pidx_all[lo:hi].contiguous())
+        c.synchronize()
+        assert torch.equal(sc, sc_ref) and torch.equal(lod, lod_ref), (dt, r)
+        assert torch.equal(Lp, Lp_ref[lo:hi]), (dt, r, float((Lp.double() - Lp_ref[lo:hi].double()).abs().max()))
+    for c in ctxs + [ref_ctx]:
+        c.close()
+    print("sharded rotation ok perms", dt, flush=True)

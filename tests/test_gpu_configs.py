@@ -120,11 +120,12 @@ def test_sharded_marker_rotation_equals_the_replicated_one():
     the scan takes the gathered blocks (blmm_prepare_dev / blmm_rotate_block_dev / blmm_bulkscan_prerotated_dev) -- at n = 500
     the replicated rotation of G is 0.75 ms of a rank's 6.5 ms step.  Rehearsed with R = 3 contexts on the one GPU, the
     all-gather emulated by writing the blocks into one buffer: every rank's LOD block must equal blmm_bulkscan_dev's bits
-    (null-exact, null-grid and alt-grid).  Own program: torch has to initialise the GPU before the library does."""
+    (null-exact, null-grid and alt-grid), and the same for the permutation test (blmm_scan_perms_prerotated_dev, fp64 and fp32,
+    the permutations sharded over the ranks).  Own program: torch has to initialise the GPU before the library does."""
     import os
     import subprocess
     import sys
     here = os.path.dirname(os.path.abspath(__file__))
     run = subprocess.run([sys.executable, os.path.join(here, "helpers", "sharded_rotation_check.py")], capture_output=True, text=True, timeout=600)
     assert run.returncode == 0, run.stdout[-2000:] + run.stderr[-3000:]
-    assert run.stdout.count("sharded rotation ok") == 3
+    assert run.stdout.count("sharded rotation ok") == 5
