@@ -243,7 +243,15 @@ def main():
                 B.prepare_dev(c, dK)
                 if self.gblk.shape[0] > 0:
                     B.rotate_block_dev(c, self.gblk, self.gx[rank])
-                dist.all_gather_into_tensor(self.gx.view(-1), self.gx[rank].reshape(-1))
+                if backend == "nccl":
+                    dist.all_gather_into_tensor(self.gx.view(-1), self.gx[rank].reshape(-1))
+                else:
+                    c.synchronize()
+                    mine = self.gx[rank].cpu()
+                    parts = [torch.empty_like(mine) for _ in range(world)]
+                    dist.all_gather(parts, mine)
+                    self.gx.copy_(torch.stack(parts))
+                    torch.cuda.synchronize()
                 if perms:
                     B.scan_perms_prerotated_dev(c, self.dy1, self.gx, p, self.bc, self.dsc, self.dlod, L, nperms=self.m, seed=1 + rank)
                 else:
@@ -257,7 +265,9 @@ def main():
             if self.full is not None and backend == "nccl":
                 dist.all_gather_into_tensor(self.full.view(-1), self.full[rank].reshape(-1))
 
-    shard_rotation = world > 1 and backend == "nccl" and n >= 256 and a.streams == 1
+    # (BLMM_BENCH_SHARD_ROT=1: the sharded form under gloo as well, the gather bounced through the host -- the one-GPU rehearsal
+    # of this code path in tests/test_gpu_parity.py; over RCCL it is the default from n = 256)
+    shard_rotation = world > 1 and n >= 256 and a.streams == 1 and (backend == "nccl" or os.environ.get("BLMM_BENCH_SHARD_ROT") == "1")
     work = Work(Y, mx if a.scaling == "strong" else a.m)
 
     # --streams S > 1: S independent contexts (own stream, own workspace, own outputs); step i runs on context i % S

@@ -712,6 +712,27 @@ def test_bench_starts_its_own_ranks_and_shards_ragged(tmp_path):
     assert j["value"] > 0 and j["ms_per_step"] > 0 and j["roofline"]["frac"] > 0
 
 
+@pytest.mark.parametrize("method", ["null-exact", "perms"])
+def test_bench_sharded_rotation_path_with_two_ranks(method):
+    """bench.py --gpus 2 at n >= 256: the marker rotation sharded over the ranks (prepare / rotate block / gather / prerotated
+    scan) INSIDE the step -- the code path the driver's multi-GPU run takes at the configs[2] / configs[4] shapes.  Rehearsed with
+    two gloo ranks on the one GPU (the gather bounced through the host, BLMM_BENCH_SHARD_ROT=1); bit-identity with the replicated
+    form is tests/test_gpu_configs.py's business, here the script's plumbing (shards, buffers, JSON line) is what runs."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env["BLMM_BENCH_BACKEND"] = "gloo"
+    env["BLMM_BENCH_SHARD_ROT"] = "1"
+    run = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--n", "300", "--p", "1501", "--m", "101",
+                          "--method", method, "--steps", "2", "--warmup", "1", "--no-cpu-baseline"], capture_output=True, text=True, timeout=600, env=env)
+    assert run.returncode == 0, run.stdout[-2000:] + run.stderr[-3000:]
+    j = json.loads([l for l in run.stdout.splitlines() if l.startswith("{")][-1])
+    assert j["n_gpus"] == 2 and j["output_finite"] is True and j["value"] > 0
+    assert "marker rotation sharded" in j["config"]["parallelism"]
+
+
 @pytest.mark.parametrize("n", [3, 5, 24, 25, 47, 64, 79, 92])
 def test_small_n_eigensolver_on_adversarial_matrices(blmm, n):
     """The default solver for n <= 124 -- the fast path (kernels_eig.hip: k_eigf_*) with its device-side check, the LDS Jacobi
