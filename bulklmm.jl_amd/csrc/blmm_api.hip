@@ -165,6 +165,7 @@ int reset_stat(blmm_ctx* ctx, int64_t** stat) {
   if (rc) return rc;
   *stat = ptr<int64_t>(ctx->stat);
   ctx->audit_ran = false;
+  ctx->brent_cnt_used = false;
   BLMM_HIP(hipMemsetAsync(*stat, 0, sizeof(int64_t) * NSTAT, ctx->stream));
   return BLMM_OK;
 }
@@ -1065,6 +1066,7 @@ int blmm_bulkscan_prerotated_dev(blmm_ctx* ctx, const blmm_opts* opts, const dou
   BLMM_HIP(hipMemsetAsync(P.stat + 1, 0, sizeof(int64_t) * 4, ctx->stream));
   BLMM_HIP(hipMemsetAsync(P.stat + 8, 0, sizeof(int64_t) * (NSTAT - 8), ctx->stream));
   ctx->audit_ran = false;
+  ctx->brent_cnt_used = false;
   tm.mark(); tm.mark();
   const char* exact_env = getenv("BLMM_EXACT");
   const bool lowrank = opts->method == BLMM_NULL_EXACT && !(exact_env && std::strcmp(exact_env, "full") == 0) && P.c <= 3;
@@ -1224,6 +1226,7 @@ int blmm_scan_perms_prerotated_dev(blmm_ctx* ctx, const blmm_opts* opts, const d
   BLMM_HIP(hipMemsetAsync(P.stat + 1, 0, sizeof(int64_t) * 4, ctx->stream));
   BLMM_HIP(hipMemsetAsync(P.stat + 8, 0, sizeof(int64_t) * (NSTAT - 8), ctx->stream));
   ctx->audit_ran = false;
+  ctx->brent_cnt_used = false;
   tm.mark(); tm.mark();
   if ((rc = rotate_traits(ctx, P, dy, 1))) return rc;
   if ((rc = assemble_prerotated(ctx, P, p, dXt_blocks, nblocks, block_cols, block_ld))) return rc;

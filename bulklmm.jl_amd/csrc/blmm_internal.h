@@ -26,7 +26,8 @@ constexpr int NSTAT = 24;        // device status counters ([6],[7]: eigensolver
 
 enum StatIdx { ST_NEG_EIG = 0, ST_NONPOS_W = 1, ST_ZERO_NORM = 2, ST_NAN_LOD = 3, ST_BRENT_MAXIT = 4, ST_JACOBI_SWEEPS = 5,
                ST_H2_BOUNDARY = 16, ST_H2_MULTIMODAL = 17, ST_ILLCOND = 18,
-               ST_EIG_FAST = 19 /* 1: the fast eigen path ran */, ST_EIG_BAD = 20 /* its largest check / bound, bits of a double: accepted up to 1.0 */ };
+               ST_EIG_FAST = 19 /* 1: the fast eigen path ran */, ST_EIG_BAD = 20 /* its largest check / bound, bits of a double: accepted up to 1.0 */,
+               ST_BRENT_CNT = 21 /* [21..22]: hand-over counter of the split h2 search (kernels_prep.hip: launch_brent_t) */ };
 
 inline int64_t round_up(int64_t x, int64_t q) { return (x + q - 1) / q * q; }
 
@@ -77,6 +78,7 @@ struct blmm_ctx {
   double* pv_cur = nullptr; int64_t pv_cur_ld = 0;
   const double* last_P = nullptr; int64_t last_P_ld = 0, last_P_df = 0;
   blmm::Pipe prep; bool prep_valid = false;   // state left by blmm_prepare_dev for blmm_rotate_block_dev / blmm_bulkscan_prerotated_dev
+  bool brent_cnt_used = false;         // the current call has run a split h2 search already (its counter in the status block is spent)
   bool audit_ran = false;              // the current call ran the BLMM_FLAG_H2_AUDIT pass (finish_status: n_h2_multimodal, else -1)
   int eig_plan_n = -1;                 // n whose merge tree sits in eigW (kernels_eig.hip)
   blmm::HostStage* hstage = nullptr;   // pinned staging ring + copy threads of the host-pointer entry points (host_path.hip)

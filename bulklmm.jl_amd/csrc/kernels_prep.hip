@@ -1637,10 +1637,16 @@ static int launch_brent_t(blmm_ctx* ctx, const NullModel& nm, const double* Yt, 
     if (!rc) rc = ensure(ctx, ctx->brList, sizeof(int) * 2 * (size_t)m + 16);
     if (rc) return rc;
     cont.st = ptr<double>(ctx->brSt);
-    cont.cnt = ptr<unsigned int>(ctx->brList);
+    // the hand-over counter lives in the status block (stat[21..22]), which the memset at the head of the call has zeroed: the
+    // first search of a call needs no fill of its own (a 5 us runtime kernel with a ~10 us gap in front of k_brent, on the
+    // critical path of the step); a second search inside the same call zeroes it again
+    cont.cnt = reinterpret_cast<unsigned int*>(stat + ST_BRENT_CNT);
     cont.list = ptr<int>(ctx->brList) + 4;
     cont.fin = cont.list + m;
-    if (phase != 2) BLMM_HIP(hipMemsetAsync(cont.cnt, 0, 16, ctx->stream));
+    if (phase != 2) {
+      if (ctx->brent_cnt_used) BLMM_HIP(hipMemsetAsync(cont.cnt, 0, 16, ctx->stream));
+      ctx->brent_cnt_used = true;
+    }
   }
   if (sp) { sp->active = two && phase == 1; sp->fin = cont.fin; sp->list = cont.list; sp->cnt = cont.cnt; }
   if (phase != 2) {

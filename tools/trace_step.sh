@@ -3,7 +3,7 @@
 cd /tmp && export TMPDIR=/tmp
 OUT=$GRAFT_REPO_ROOT/gpurun_out/trace_step
 rm -rf $OUT; mkdir -p $OUT
-rocprofv3 --kernel-trace --output-format csv -d $OUT -- python3 $GRAFT_REPO_ROOT/bench.py --steps 4 --warmup 2 --no-host-api "$@" > $OUT/bench.log 2>&1
+rocprofv3 --kernel-trace --output-format csv -d $OUT -- python3 $GRAFT_REPO_ROOT/bench.py --steps 4 --warmup 2 --no-host-api --no-cpu-baseline --no-all-rank-form "$@" > $OUT/bench.log 2>&1
 python3 - <<PY
 import csv, glob
 f = glob.glob("$OUT/**/*kernel_trace.csv", recursive=True)[0]
