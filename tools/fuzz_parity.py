@@ -105,13 +105,24 @@ for case in range(ncases):
                        optim_interval=oi, weights=w)
             got = blmm.scan(Y[:, :1], G[:, :pp], K, Cov, assumption="alt", alt_true_weights=true_w, **skw)
             own = O.scan(Y[:, :1], G[:, :pp], K, covar=Cov, assumption="alt", true_weights=true_w, **skw)
-            assert abs(got["h2_null"] - own["h2_null"]) <= 1e-6
+            null_differs = abs(got["h2_null"] - own["h2_null"]) > 1e-6
+            if null_differs:
+                # the same rule as for null-exact above: a two-humped null profile (rank-deficient kinship, REML) on which the two
+                # searches -- both local -- ended on different humps; the device's must be a local maximum of the ORACLE's likelihood
+                # (case 202 of seed 411: K of rank 39 at n = 260, device h2 = 6e-16 with ell -154.885, oracle 0.129 with -155.437)
+                Yw, Gw, Cw, Kw, ai = (Y[:, :1], G, Cov, K, True) if w is None else O._apply_weights(Y[:, :1], G, Cov if Cov is not None else np.ones((n, 0)), K, w, True)
+                Zc = np.ones((n, 1)) if Cw is None else (np.hstack([np.ones((n, 1)), Cw]) if ai else Cw)
+                y0, X0, lam0 = O.transform_rotation(Yw, np.hstack([Zc, Gw[:, :1]]), Kw, addIntercept=False, decomp_scheme=skw["decomp_scheme"])
+                ell = lambda h: O.wls(y0, X0[:, :Zc.shape[1]], O.makeweights(h, lam0), list(prior), reml=reml).ell
+                hg = float(got["h2_null"]); eg = ell(hg)
+                assert eg >= ell(min(hg + 1e-3, 1 - 1e-9)) - 1e-9 * abs(eg) and eg >= ell(max(hg - 1e-3, 0.0)) - 1e-9 * abs(eg), \
+                    f"h2_null {hg} vs {own['h2_null']} is not a local maximum"
             pin = O.scan(Y[:, :1], G[:, :pp], K, covar=Cov, assumption="alt", true_weights=true_w,
                          h2_each_override=got["h2_each_marker"], h2_null_override=got["h2_null"], **skw)
             assert_lod_close(got["lod"], pin["lod"], atol=1e-9)
             # each side's own per-marker search: h2 may differ where the profile is flat or two-humped, the LOD then barely
             dl = np.abs(got["lod"] - own["lod"])
-            if pp >= 10:      # (a handful of markers cannot carry a quantile: n = 8 with REML has flat profiles)
+            if pp >= 10 and not null_differs:      # (a handful of markers cannot carry a quantile: n = 8 with REML has flat profiles)
                 assert np.quantile(dl, 0.9) <= 1e-6 * max(1.0, np.abs(own["lod"]).max()) + 1e-7, "scan_alt LOD"
         elif method == "null-grid":
             got = blmm.bulkscan_null_grid(Y, G, K, grid, Cov, weights=w, **kw)
