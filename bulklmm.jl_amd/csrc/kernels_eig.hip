@@ -1195,11 +1195,12 @@ __global__ void __launch_bounds__(1024) k_eigf_reduce(const double* __restrict__
   }
 }
 
-__global__ void __launch_bounds__(256) k_eigf_pairs(int n, const double* __restrict__ wsb, double* __restrict__ lam_out,
+template <int NT>
+__global__ void __launch_bounds__(NT) k_eigf_pairs(int n, const double* __restrict__ wsb, double* __restrict__ lam_out,
                                                     int64_t* stat) {
   __shared__ double sd[128], se[128], sds[128], ses2[128], sDp[128], sDm[128];
   __shared__ double s_red[8];
-  __shared__ int s_cnt[2][4];
+  __shared__ int s_cnt[2][NT / 64];
   __shared__ int s_r;
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6, k = blockIdx.x;
   const EigfWs g = eigf_ws(const_cast<double*>(wsb), n);
@@ -1207,18 +1208,21 @@ __global__ void __launch_bounds__(256) k_eigf_pairs(int n, const double* __restr
   const double tn = g.par[0], bscale = g.par[1];
   double lo = g.par[2], hi = g.par[3];
   __syncthreads();
-  // ---- eigenvalue k: 512 interior points per round (two per thread) ------------------------------------------------------
-  for (int round = 0; round < 8; ++round) {          // 513^7 > 2^63
+  // ---- eigenvalue k: 2 NT interior points per round (two per thread) -----------------------------------------------------
+  constexpr int NPT = 2 * NT;
+  for (int round = 0; round < 8; ++round) {          // (2 NT + 1)^7 > 2^63 for NT >= 256
     const double wd = hi - lo;
-    const double x0 = lo + wd * ((2 * t + 1) * (1.0 / 513.0)), x1 = lo + wd * ((2 * t + 2) * (1.0 / 513.0));
+    const double x0 = lo + wd * ((2 * t + 1) * (1.0 / (NPT + 1))), x1 = lo + wd * ((2 * t + 2) * (1.0 / (NPT + 1)));
     int c0, c1;
     sturm2(sds, ses2, n, x0, x1, c0, c1);
     const int mle = (int)wsum((double)((c0 <= k) + (c1 <= k)));       // points with at most k eigenvalues below them
     if (lane == 0) s_cnt[round & 1][wave] = mle;
     __syncthreads();
-    const int tot = s_cnt[round & 1][0] + s_cnt[round & 1][1] + s_cnt[round & 1][2] + s_cnt[round & 1][3];
-    const double nlo = (tot == 0) ? lo : lo + wd * (tot * (1.0 / 513.0));
-    const double nhi = (tot == 512) ? hi : lo + wd * ((tot + 1) * (1.0 / 513.0));
+    int tot = 0;
+#pragma unroll
+    for (int q = 0; q < NT / 64; ++q) tot += s_cnt[round & 1][q];
+    const double nlo = (tot == 0) ? lo : lo + wd * (tot * (1.0 / (NPT + 1)));
+    const double nhi = (tot == NPT) ? hi : lo + wd * ((tot + 1) * (1.0 / (NPT + 1)));
     lo = nlo; hi = nhi;
     if (!(hi - lo > 4.0 * EPS * fmax(fabs(lo), fabs(hi)))) break;     // to 2 ulp of the midpoint; workgroup-uniform
   }
@@ -1245,11 +1249,17 @@ __global__ void __launch_bounds__(256) k_eigf_pairs(int n, const double* __restr
     sDm[0] = dm;
   }
   __syncthreads();
-  if (t == 0) {     // twist index r = argmin |gamma_i|, gamma_i = D+_i + D-_i - (d_i - lambda)
-    double gbest = INFINITY; int r = 0;
-    for (int i = 0; i < n; ++i) { const double gam = fabs(sDp[i] + sDm[i] - (sd[i] - l)); if (gam < gbest) { gbest = gam; r = i; } }
-    s_r = r;
+  // twist index r = argmin |gamma_i| (the first one), gamma_i = D+_i + D-_i - (d_i - lambda): waves 0 and 1 hold the n <= 128
+  // values one per lane; an arg-min by value, ties to the smaller index
+  if (wave < 2) {
+    const double gam = (t < n) ? fabs(sDp[t] + sDm[t] - (sd[t] - l)) : INFINITY;
+    const double gmin = -wmax(-gam);
+    unsigned long long m = __ballot(gam == gmin);
+    const int first = m ? (wave * 64 + (int)__builtin_ctzll(m)) : 0x7fffffff;
+    if (lane == 0) { s_red[2 + wave] = gmin; s_cnt[0][wave] = first; }
   }
+  __syncthreads();
+  if (t == 0) s_r = (s_red[2] <= s_red[3]) ? s_cnt[0][0] : s_cnt[0][1];
   __syncthreads();
   const int r = s_r;
   // z_r = 1, upwards through D+ (thread 0), downwards through D- (thread 64); the entries overwrite the factor they came from
@@ -1305,7 +1315,9 @@ int launch_eig_fast(blmm_ctx* ctx, const double* A, int n, double* lraw, double*
   BLMM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_eigf_reduce), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   hipLaunchKernelGGL(k_eigf_reduce, dim3(1), dim3(1024), lds, ctx->stream, A, n, Vg, wsb, stat);
   KCHECK();
-  hipLaunchKernelGGL(k_eigf_pairs, dim3(n), dim3(256), 0, ctx->stream, n, (const double*)wsb, lraw, stat);
+  // (256 threads: 512 / 1024 per workgroup -- more points per round, fewer rounds -- measured 0.265 / 0.286 ms of eigen phase against
+  // 0.256: the waves sharing a SIMD slow each other's dependent chains)
+  hipLaunchKernelGGL(k_eigf_pairs<256>, dim3(n), dim3(256), 0, ctx->stream, n, (const double*)wsb, lraw, stat);
   KCHECK();
   const size_t lds_bt = sizeof(double) * ((size_t)2 * (4 * n + 4) + (size_t)n * (n | 1));   // reflector buffers + the staged Z
   BLMM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_backtransform<2, 1, 256>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bt));
