@@ -1207,7 +1207,15 @@ __global__ void __launch_bounds__(NT) k_eigf_pairs(int n, const double* __restri
   if (t < n) { sd[t] = g.d[t]; se[t] = g.e[t]; sds[t] = g.ds[t]; ses2[t] = g.es2[t]; }
   const double tn = g.par[0], bscale = g.par[1];
   double lo = g.par[2], hi = g.par[3];
+#ifdef EIGF_PROF      // tools/eigf_prof.sh: cycles of the phases of workgroups 0, n/2, n-1
+  long long pf[4] = {0, 0, 0, 0}, pt0 = __builtin_amdgcn_s_memtime();
+  int prounds = 0;
+#define EPSTAMP(i) do { const long long t1__ = __builtin_amdgcn_s_memtime(); pf[i] += t1__ - pt0; pt0 = t1__; } while (0)
+#else
+#define EPSTAMP(i) do { } while (0)
+#endif
   __syncthreads();
+  EPSTAMP(0);
   // ---- eigenvalue k: 2 NT interior points per round (two per thread) -----------------------------------------------------
   constexpr int NPT = 2 * NT;
   for (int round = 0; round < 8; ++round) {          // (2 NT + 1)^7 > 2^63 for NT >= 256
@@ -1224,8 +1232,12 @@ __global__ void __launch_bounds__(NT) k_eigf_pairs(int n, const double* __restri
     const double nlo = (tot == 0) ? lo : lo + wd * (tot * (1.0 / (NPT + 1)));
     const double nhi = (tot == NPT) ? hi : lo + wd * ((tot + 1) * (1.0 / (NPT + 1)));
     lo = nlo; hi = nhi;
+#ifdef EIGF_PROF
+    ++prounds;
+#endif
     if (!(hi - lo > 4.0 * EPS * fmax(fabs(lo), fabs(hi)))) break;     // to 2 ulp of the midpoint; workgroup-uniform
   }
+  EPSTAMP(1);
   const double l = (0.5 * (lo + hi)) * bscale;
   // ---- its eigenvector of T: twisted factorisation; thread 0 runs the forward factor D+, thread 64 the backward D- ---------
   const double tiny = fmax(EPS * EPS * tn, 1e-300);
@@ -1274,6 +1286,7 @@ __global__ void __launch_bounds__(NT) k_eigf_pairs(int n, const double* __restri
     s_red[1] = nrm;
   }
   __syncthreads();
+  EPSTAMP(2);
   const double inv = fast_rsqrt(s_red[0] + s_red[1]);
   double res = 0.0;
   if (t < n) {
@@ -1291,6 +1304,11 @@ __global__ void __launch_bounds__(NT) k_eigf_pairs(int n, const double* __restri
     res = wmax(res);
     if (lane == 0) eigf_note(stat, res, 2e-14 * tn);
   }
+  EPSTAMP(3);
+#ifdef EIGF_PROF
+  if (t == 0 && (k == 0 || k == n / 2 || k == n - 1))
+    printf("eigf_pairs prof k %d: load %lld | %d rounds %lld | twisted %lld | finish %lld cycles\n", k, pf[0], prounds, pf[1], pf[2], pf[3]);
+#endif
 }
 
 }  // namespace

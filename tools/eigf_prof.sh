@@ -1,5 +1,5 @@
 #!/bin/bash
-# per-phase cycle counts of k_eig_fast on the BXD kinship (diagnostic build -DEIGF_PROF)
+# per-phase cycle counts of k_eigf_pairs (the fast eigen path, kernels_eig.hip) on the BXD kinship (diagnostic build -DEIGF_PROF)
 cd bulklmm.jl_amd/csrc && touch kernels_eig.hip && make EXTRA=-DEIGF_PROF -j8 > /dev/null 2>&1 && cd ../..
 python3 - <<'PY'
 import sys; sys.path.insert(0, "."); sys.path.insert(0, "tests")
