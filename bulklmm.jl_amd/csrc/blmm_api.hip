@@ -509,7 +509,15 @@ int lr_finish_split(blmm_ctx* ctx, const Pipe& P, const NullModel& nm, double* d
   r0.col0 = 0; r0.ncol = ldq; r0.counts = P.stat + 12;
   r1.col0 = ldq; r1.ncol = ldq; r1.counts = P.stat + 14;
   hipStream_t main_stream = ctx->stream;
-  // ---- second side stream: the rest of the h2 search, then region 1's columns
+  // ---- main stream: region 0's classification and panels (the perm preset is ready at ev_m, the weight basis at ev_q, the
+  //      marker-side products at ev_join) ...
+  BLMM_HIP(hipStreamWaitEvent(main_stream, ctx->ev_m, 0));
+  if ((rc = launch_lr_classify(ctx, P.n, P.m, lr_shared_tol(), P.lam, dh2, sp.fin, nullptr, nullptr, ptr<int>(ctx->lrPerm), r0))) return rc;
+  BLMM_HIP(hipStreamWaitEvent(main_stream, ctx->ev_q, 0));
+  if ((rc = lr_region_panels(ctx, P, nm, dh2, r0))) return rc;
+  // ---- ... and only then the second side stream: the rest of the h2 search, then region 1's columns.  Forked right behind
+  //      k_brent (rounds 2-3a) k_brent2's older waves won the issue arbitration against the 16-lane panels kernel on the
+  //      critical path (45 us beside it, 28 alone); its chain has ~0.5 ms of slack before region 1's scan needs it
   BLMM_HIP(hipEventRecord(ctx->ev_b1, main_stream));
   BLMM_HIP(hipStreamWaitEvent(ctx->side2, ctx->ev_b1, 0));
   ctx->stream = ctx->side2;
@@ -521,11 +529,6 @@ int lr_finish_split(blmm_ctx* ctx, const Pipe& P, const NullModel& nm, double* d
   ctx->stream = main_stream;
   if (rc) return rc;
   BLMM_HIP(hipEventRecord(ctx->ev_b2, ctx->side2));
-  // ---- main stream: region 0 (the perm preset is ready at ev_m, the weight basis at ev_q, the marker-side products at ev_join)
-  BLMM_HIP(hipStreamWaitEvent(main_stream, ctx->ev_m, 0));
-  if ((rc = launch_lr_classify(ctx, P.n, P.m, lr_shared_tol(), P.lam, dh2, sp.fin, nullptr, nullptr, ptr<int>(ctx->lrPerm), r0))) return rc;
-  BLMM_HIP(hipStreamWaitEvent(main_stream, ctx->ev_q, 0));
-  if ((rc = lr_region_panels(ctx, P, nm, dh2, r0))) return rc;
   tm.mark();
   BLMM_HIP(hipStreamWaitEvent(main_stream, ctx->ev_join, 0));
   BLMM_HIP(hipEventRecord(ctx->ev_fork, main_stream));
