@@ -929,10 +929,15 @@ static int scan_pipeline(blmm_ctx* ctx, const blmm_opts* opts, Pipe& P, Timer& t
     tm.mark();
     if ((rc = ensure(ctx, ctx->panels, sizeof(double) * (size_t)ngrid * P.npad * ldp))) return rc;
     if ((rc = ensure(ctx, ctx->h2, sizeof(double) * (size_t)m))) return rc;
-    for (int64_t g = 0; g < ngrid; ++g) {
-      if ((rc = fill(ctx, ptr<double>(ctx->h2), m, h2_grid_host[g]))) return rc;
-      if ((rc = launch_panels(ctx, nm, P.Yt, P.ldy, m, P.Z0, P.lam, ptr<double>(ctx->h2), 0,
-                              ptr<double>(ctx->panels) + (size_t)g * P.npad * ldp, ldp, P.stat))) return rc;
+    if (nm.c <= CTPL) {
+      // every grid point's panel in one launch (grid point on blockIdx.y)
+      if ((rc = launch_panels(ctx, nm, P.Yt, P.ldy, m, P.Z0, P.lam, nullptr, 0, ptr<double>(ctx->panels), ldp, P.stat, dgrid, (int)ngrid))) return rc;
+    } else {
+      for (int64_t g = 0; g < ngrid; ++g) {
+        if ((rc = fill(ctx, ptr<double>(ctx->h2), m, h2_grid_host[g]))) return rc;
+        if ((rc = launch_panels(ctx, nm, P.Yt, P.ldy, m, P.Z0, P.lam, ptr<double>(ctx->h2), 0,
+                                ptr<double>(ctx->panels) + (size_t)g * P.npad * ldp, ldp, P.stat))) return rc;
+      }
     }
     if ((rc = ensure(ctx, ctx->isx, sizeof(double) * (size_t)ngrid * P.ldx))) return rc;
     if ((rc = launch_isx(ctx, nm, P.Xt, P.ldx, p, P.Z0, P.lam, dgrid, (int)ngrid, ptr<double>(ctx->isx), P.ldx, P.stat))) return rc;

@@ -176,7 +176,8 @@ int launch_h2_audit(blmm_ctx* ctx, const double* EllTab, int ngrid, int64_t m, i
 // A-side panels for the scan kernels from per-trait h2: panel 0 = w.*resid/sqrt(yy); if full: panel 1 = w,
 // panels 2..1+c = w .* (Z0 Linv')_q.  panels: [np][npad][ldp]
 int launch_panels(blmm_ctx* ctx, const NullModel& nm, const double* Yt, int64_t ldy, int64_t m, const double* Z0,
-                  const double* lam, const double* h2, int full, double* panels, int64_t ldp, int64_t* stat);
+                  const double* lam, const double* h2, int full, double* panels, int64_t ldp, int64_t* stat,
+                  const double* gridv = nullptr, int ngrid = 0);   // gridv (c <= CTPL, !full): panel g = every trait at h2 = gridv[g], one launch
 // isx[g][i] = 1/||P_g sqrt(w_g) x_i|| for every grid point
 int launch_isx(blmm_ctx* ctx, const NullModel& nm, const double* Xt, int64_t ldx, int64_t p, const double* Z0,
                const double* lam, const double* grid_dev, int ngrid, double* isx, int64_t ld_isx, int64_t* stat);

@@ -2047,9 +2047,12 @@ template <int C>
 __global__ void __launch_bounds__(256) k_panels(NullModel nm, const double* __restrict__ Yt, int64_t ldy, int64_t m,
                                                 const double* __restrict__ Z0, const double* __restrict__ lam,
                                                 const double* __restrict__ h2v, int full, double* __restrict__ P,
-                                                int64_t ldp, int64_t* stat) {
+                                                int64_t ldp, int64_t* stat, const double* __restrict__ gridv) {
   extern __shared__ __attribute__((aligned(16))) double sh[];
   const int n = nm.n, npad = nm.npad;
+  // gridv (alt-grid): blockIdx.y = grid point g, every trait at h2 = gridv[g], panel g of the output -- the sixteen launches
+  // (and sixteen fills of a constant h2 vector) of rounds 1-3a were 0.57 ms of launch-bound prep per call
+  if (gridv) P += (int64_t)blockIdx.y * npad * ldp;
   double* sLam = sh;
   double* sZ = sh + n;
   for (int e = threadIdx.x; e < n; e += blockDim.x) sLam[e] = lam[e];
@@ -2065,7 +2068,7 @@ __global__ void __launch_bounds__(256) k_panels(NullModel nm, const double* __re
     return;
   }
   constexpr int NA = C * (C + 1) / 2;
-  const double h2 = h2v[j];
+  const double h2 = gridv ? gridv[blockIdx.y] : h2v[j];
   const double delta = h2 / (1.0 - h2);
   double A[NA], v[C], syy = 0.0;
 #pragma unroll
@@ -2153,11 +2156,17 @@ __global__ void __launch_bounds__(256) k_panels(NullModel nm, const double* __re
 }
 
 int launch_panels(blmm_ctx* ctx, const NullModel& nm, const double* Yt, int64_t ldy, int64_t m, const double* Z0,
-                  const double* lam, const double* h2, int full, double* panels, int64_t ldp, int64_t* stat) {
-  if (nm.c > CTPL && nm.c <= CMAX) return launch_dyn_panels(ctx, nm, Yt, ldy, m, Z0, lam, h2, full, panels, ldp, stat);
+                  const double* lam, const double* h2, int full, double* panels, int64_t ldp, int64_t* stat, const double* gridv,
+                  int ngrid) {
+  if (nm.c > CTPL && nm.c <= CMAX) {
+    if (gridv) return fail(ctx, BLMM_ERR_INVALID, "launch_panels: the batched grid form has no run-time-c kernel");
+    return launch_dyn_panels(ctx, nm, Yt, ldy, m, Z0, lam, h2, full, panels, ldp, stat);
+  }
   const unsigned blocks = (unsigned)((ldp + 255) / 256);
+  const unsigned gy = (unsigned)(gridv ? ngrid : 1);
+  if (gridv && (full || ngrid < 1)) return fail(ctx, BLMM_ERR_INVALID, "launch_panels: the batched grid form writes panel 0 only");
   const size_t lds = sizeof(double) * (size_t)nm.n * (1 + nm.c);
-#define PN(C) hipLaunchKernelGGL(k_panels<C>, dim3(blocks), dim3(256), lds, ctx->stream, nm, Yt, ldy, m, Z0, lam, h2, full, panels, ldp, stat)
+#define PN(C) hipLaunchKernelGGL(k_panels<C>, dim3(blocks, gy), dim3(256), lds, ctx->stream, nm, Yt, ldy, m, Z0, lam, h2, full, panels, ldp, stat, gridv)
   switch (nm.c) {
     BLMM_FOR_EACH_C(PN)
     default: return fail(ctx, BLMM_ERR_UNSUPPORTED, BLMM_C_ERR);
