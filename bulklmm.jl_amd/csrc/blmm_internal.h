@@ -253,6 +253,10 @@ int launch_scan_f32(blmm_ctx* ctx, const float* XF, int64_t ldxf, const float* P
 // launch_panels / launch_isx / launch_perm_panel, which route there
 int launch_dyn_brent(blmm_ctx* ctx, const NullModel& nm, const double* Yt, int64_t ldy, int64_t m, const double* Z0, const double* lam,
                      double* h2, double* sigma2, double* ell, int64_t* stat);
+// scan_alt's per-marker searches on the design [Z0 x_i] (c + 1 <= CMAX columns), the counterpart of launch_alt_brent
+int launch_dyn_alt_brent(blmm_ctx* ctx, const NullModel& nm, const double* Yt, int64_t ldy, const double* Xt, int64_t ldx, int64_t p,
+                         const double* Z0, const double* lam, const double* h2null, int true_w, double* lod, double* h2each,
+                         int64_t* stat, int64_t m, int64_t ldL, int64_t ldH);
 int launch_dyn_loglik_grid(blmm_ctx* ctx, const NullModel& nm, const double* Yt, int64_t ldy, int64_t m, const double* Z0,
                            const double* lam, const double* grid_dev, int ngrid, double* EllTab, int* h2idx, double* h2, int64_t* stat);
 int launch_dyn_panels(blmm_ctx* ctx, const NullModel& nm, const double* Yt, int64_t ldy, int64_t m, const double* Z0, const double* lam,

@@ -227,8 +227,14 @@ constexpr int DYN_NA = CMAX * (CMAX + 1) / 2;
 // skipped when null), sScal[0] = ln det A, sScal[1] = min_q d_q / A_qq (the conditioning guard's pivot share).
 // Every thread of the workgroup (NT threads, all of them in the call) takes part; Z0 is read from global memory (n x c,
 // column-major, L1 / L2-resident).
+// The design of the run-time-c kernels: columns 0 .. cz - 1 are Z0's (global memory, n x cz column-major); a column beyond is
+// `x` (n contiguous values; scan_alt's design [Z0 x_i], k_dyn_alt_brent).  x == nullptr: Z0 alone.
+struct DynCols {
+  const double* Z0; const double* x; int cz; int n;
+  __device__ __forceinline__ const double* col(int q) const { return q < cz ? Z0 + (size_t)q * n : x; }
+};
 template <int NT>
-__device__ __forceinline__ void dyn_factor(int n, int c, const double* __restrict__ Z0, const double* sW, double* sA, double* sLi,
+__device__ __forceinline__ void dyn_factor(int n, int c, const DynCols dc, const double* sW, double* sA, double* sLi,
                                            double* sScal) {
   const int t = threadIdx.x, na = c * (c + 1) / 2;
   __shared__ double s_diag[CMAX];
@@ -236,8 +242,8 @@ __device__ __forceinline__ void dyn_factor(int n, int c, const double* __restric
     int q = 0;
     while ((q + 1) * (q + 2) / 2 <= e) ++q;
     const int r = e - q * (q + 1) / 2;
-    const double* zq = Z0 + (size_t)q * n;
-    const double* zr = Z0 + (size_t)r * n;
+    const double* zq = dc.col(q);
+    const double* zr = dc.col(r);
     double acc = 0.0;
     for (int k = 0; k < n; ++k) acc = fma(sW[k] * zq[k], zr[k], acc);
     sA[e] = acc;
@@ -279,9 +285,16 @@ __device__ __forceinline__ void dyn_factor(int n, int c, const double* __restric
   __syncthreads();
 }
 
+template <int NT>
+__device__ __forceinline__ void dyn_factor(int n, int c, const double* __restrict__ Z0, const double* sW, double* sA, double* sLi,
+                                           double* sScal) {
+  dyn_factor<NT>(n, c, DynCols{Z0, nullptr, c, n}, sW, sA, sLi, sScal);
+}
+
 // weights of one h2 into sW; returns (to every thread) sum_k ln(delta lambda_k + 1) and sets *nonpos when a weight is <= 0
 // (`absw`: the scan's sqrt.(abs.(w)) convention, src/bulkscan_helpers.jl:138; the likelihood uses w itself, src/wls.jl:40)
-template <int NT>
+// SQW: the square roots of the weights (scan_alt's closing wls calls, src/scan.jl:431-437); the caller halves the returned sum
+template <int NT, bool SQW = false>
 __device__ __forceinline__ double dyn_weights(int n, double h2, const double* __restrict__ lam, double* sW, bool absw, int* nonpos,
                                               double* s_red /* NT / 64 + 1 */) {
   const double delta = h2 / (1.0 - h2);
@@ -291,7 +304,7 @@ __device__ __forceinline__ double dyn_weights(int n, double h2, const double* __
     const double tk = fma(delta, lam[k], 1.0);
     const double w = 1.0 / tk;
     bad |= !(w > 0.0);
-    sW[k] = absw ? fabs(w) : w;
+    sW[k] = SQW ? sqrt(w) : (absw ? fabs(w) : w);
     ls += log(tk);
   }
   ls = group_sum<64>(ls);
@@ -307,12 +320,12 @@ __device__ __forceinline__ double dyn_weights(int n, double h2, const double* __
 // ell of one trait (sY, n values in LDS) under the factor in sA (weights sW): v = Z0'Wy (one thread per covariate), t = L^-1 v
 // (every thread, redundantly), the reference's formula (src/wls.jl:69-88).  sV: c doubles of LDS.  Returns ell / sigma2 / rss.
 template <int NT>
-__device__ __forceinline__ void dyn_ell(int n, int c, const double* __restrict__ Z0, const double* sW, const double* sY, const double* sA,
+__device__ __forceinline__ void dyn_ell(int n, int c, const DynCols dc, const double* sW, const double* sY, const double* sA,
                                         double logdet, double logsum, double prior_a, double prior_b, int reml, double* sV,
                                         double* ell_out, double* sigma2_out, double* rss_out) {
   for (int q = threadIdx.x; q <= c; q += NT) {
     double acc = 0.0;
-    if (q < c) { const double* zq = Z0 + (size_t)q * n; for (int k = 0; k < n; ++k) acc = fma(sW[k] * sY[k], zq[k], acc); }
+    if (q < c) { const double* zq = dc.col(q); for (int k = 0; k < n; ++k) acc = fma(sW[k] * sY[k], zq[k], acc); }
     else { for (int k = 0; k < n; ++k) acc = fma(sW[k] * sY[k], sY[k], acc); }
     sV[q] = acc;                                          // sV[c] = y'Wy
   }
@@ -336,6 +349,13 @@ __device__ __forceinline__ void dyn_ell(int n, int c, const double* __restrict__
   if (reml) ell += 0.5 * ((double)c * ls - logdet);
   *ell_out = ell; *sigma2_out = sigma2; *rss_out = rss;
   __syncthreads();                                        // sV may be overwritten by the next evaluation
+}
+
+template <int NT>
+__device__ __forceinline__ void dyn_ell(int n, int c, const double* __restrict__ Z0, const double* sW, const double* sY, const double* sA,
+                                        double logdet, double logsum, double prior_a, double prior_b, int reml, double* sV,
+                                        double* ell_out, double* sigma2_out, double* rss_out) {
+  dyn_ell<NT>(n, c, DynCols{Z0, nullptr, c, n}, sW, sY, sA, logdet, logsum, prior_a, prior_b, reml, sV, ell_out, sigma2_out, rss_out);
 }
 
 // ---- fitlmm for every trait: one 64-thread workgroup (= one wave) per trait; brent_search is the template of kernels_prep.hip's
@@ -427,6 +447,55 @@ __global__ void __launch_bounds__(64) k_dyn_brent(NullModel nm, const double* __
     h2out[j] = best;
     if (s2out) s2out[j] = e_s2;
     if (ellout) ellout[j] = e_ell;
+    if (hit_max) atomicAdd((unsigned long long*)&stat[ST_BRENT_MAXIT], 1ull);
+    if (nonpos) atomicAdd((unsigned long long*)&stat[ST_NONPOS_W], 1ull);
+  }
+}
+
+// ---- scan_alt with a run-time covariate count (src/scan.jl:397-453; the counterpart of kernels_prep.hip's k_alt_brent, which is a
+// template over c <= 8): one 64-thread workgroup per (marker, trait); the design [Z0 x_i] has c + 1 <= CMAX columns, x_i staged in LDS.
+// The search on the likelihood of fitlmm(y0, [Z0 x_i], lambda; reml, optim_interval), then the reference's two closing wls calls
+// (ML, the SQUARE ROOTS of the weights handed over as weights; true_w: makeweights(h2) itself, BLMM_COMPAT_ALT_TRUE_WEIGHTS).
+__global__ void __launch_bounds__(64) k_dyn_alt_brent(NullModel nm, const double* __restrict__ Yt, int64_t ldy,
+                                                      const double* __restrict__ Xt, int64_t ldx, int64_t p,
+                                                      const double* __restrict__ Z0, const double* __restrict__ lam,
+                                                      const double* __restrict__ h2null, int true_w, double* __restrict__ lod,
+                                                      double* __restrict__ h2each, int64_t* stat, int64_t trait0, int64_t ldL, int64_t ldH) {
+  extern __shared__ __attribute__((aligned(16))) double sh[];
+  __shared__ double sA[DYN_NA], sV[CMAX + 1], sScal[2], s_red[2];
+  const int n = nm.n, c = nm.c, D = c + 1;
+  double* sW = sh;
+  double* sY = sh + n;
+  double* sX = sh + 2 * n;
+  const int64_t tr = trait0 + blockIdx.y;
+  const int64_t i = blockIdx.x;
+  lod += tr * ldL; h2each += tr * ldH;
+  for (int k = threadIdx.x; k < n; k += 64) { sY[k] = Yt[(int64_t)k * ldy + tr]; sX[k] = Xt[(int64_t)k * ldx + i]; }
+  __syncthreads();
+  const DynCols alt{Z0, sX, c, n}, nul{Z0, nullptr, c, n};
+  int nonpos = 0, hit_max = 0;
+  double e_ell = 0.0, e_s2 = 0.0, e_rss = 0.0;
+  auto f = [&](double h2) {
+    const double logsum = dyn_weights<64>(n, h2, lam, sW, false, &nonpos, s_red);
+    dyn_factor<64>(n, D, alt, sW, sA, nullptr, sScal);
+    dyn_ell<64>(n, D, alt, sW, sY, sA, sScal[0], logsum, nm.prior_a, nm.prior_b, nm.reml, sV, &e_ell, &e_s2, &e_rss);
+    return -e_ell;
+  };
+  const double hx = dyn_brent_search(f, nm.optim_interval < 1 ? 1 : nm.optim_interval, &hit_max);
+  const double h0 = h2null[tr];
+  auto closing = [&](double h2, const DynCols& dc, int d) {
+    double logsum;
+    if (true_w) logsum = dyn_weights<64, false>(n, h2, lam, sW, false, nullptr, s_red);
+    else logsum = 0.5 * dyn_weights<64, true>(n, h2, lam, sW, false, nullptr, s_red);
+    dyn_factor<64>(n, d, dc, sW, sA, nullptr, sScal);
+    dyn_ell<64>(n, d, dc, sW, sY, sA, sScal[0], logsum, nm.prior_a, nm.prior_b, 0, sV, &e_ell, &e_s2, &e_rss);
+    return e_ell;
+  };
+  const double e1 = closing(hx, alt, D);
+  const double e0 = closing(h0, nul, c);
+  if (threadIdx.x == 0) {
+    lod[i] = (e1 - e0) / log(10.0);
+    h2each[i] = hx;
     if (hit_max) atomicAdd((unsigned long long*)&stat[ST_BRENT_MAXIT], 1ull);
     if (nonpos) atomicAdd((unsigned long long*)&stat[ST_NONPOS_W], 1ull);
   }
@@ -691,6 +760,24 @@ int launch_dyn_brent(blmm_ctx* ctx, const NullModel& nm, const double* Yt, int64
   DYN_LDS_ATTR(k_dyn_brent, lds);
   hipLaunchKernelGGL(k_dyn_brent, dim3((unsigned)m), dim3(64), lds, ctx->stream, nm, Yt, ldy, m, Z0, lam, h2, sigma2, ell, stat);
   KCHECK();
+  return BLMM_OK;
+}
+
+int launch_dyn_alt_brent(blmm_ctx* ctx, const NullModel& nm, const double* Yt, int64_t ldy, const double* Xt, int64_t ldx, int64_t p,
+                         const double* Z0, const double* lam, const double* h2null, int true_w, double* lod, double* h2each,
+                         int64_t* stat, int64_t m, int64_t ldL, int64_t ldH) {
+  if (p <= 0 || m <= 0) return BLMM_OK;
+  if (nm.c + 1 > CMAX) return fail(ctx, BLMM_ERR_UNSUPPORTED, "scan(...; assumption = \"alt\"): at most 31 null covariates (incl. intercept): the per-marker design [Z0 x] has c + 1 <= 32 columns");
+  if (p > 0x7fffffffLL) return fail(ctx, BLMM_ERR_INVALID, "problem too large for one launch");
+  const int lds = dyn_lds(nm, 3);
+  if (lds > 150 * 1024) return fail(ctx, BLMM_ERR_UNSUPPORTED, "scan_alt: n too large for the LDS-resident trait");
+  DYN_LDS_ATTR(k_dyn_alt_brent, lds);
+  for (int64_t t0 = 0; t0 < m; t0 += 65535) {       // gridDim.y <= 65535
+    const int64_t mt = (m - t0 < 65535) ? m - t0 : 65535;
+    hipLaunchKernelGGL(k_dyn_alt_brent, dim3((unsigned)p, (unsigned)mt), dim3(64), lds, ctx->stream, nm, Yt, ldy, Xt, ldx, p, Z0, lam,
+                       h2null, true_w, lod, h2each, stat, t0, ldL, ldH);
+    KCHECK();
+  }
   return BLMM_OK;
 }
 

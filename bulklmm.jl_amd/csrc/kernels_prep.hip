@@ -1875,7 +1875,8 @@ int launch_alt_brent(blmm_ctx* ctx, const NullModel& nm, const double* Yt, int64
 #undef AG
   }
 #undef AB
-  return fail(ctx, BLMM_ERR_UNSUPPORTED, "scan(...; assumption = \"alt\"): at most 8 null covariates (incl. intercept) -- the per-marker search has no run-time-c form");
+  // beyond the instantiated counts: the run-time-c form (kernels_dyn.hip: one wave per marker, factorisations in LDS)
+  return launch_dyn_alt_brent(ctx, nm, Yt, ldy, Xt, ldx, p, Z0, lam, h2null, true_w, lod, h2each, stat, m, ldL, ldH);
 }
 
 // Ell[g, j] = wls_multivar(Y0, Z0, makeweights(grid[g]), prior).Ell  (src/bulkscan_helpers.jl:267-269),

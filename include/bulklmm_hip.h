@@ -276,7 +276,7 @@ int blmm_scan_alt_dev(blmm_ctx* ctx, const blmm_opts* opts, const double* dy, in
  * the LOD against the trait's null model.  L_out, h2_panel_out: p x m column-major (leading dimensions ldL, ldH in the _dev
  * form); h2_null_out m; sigma2_out m or NULL.  Column j equals blmm_scan_alt on trait j bit for bit.  ~0.02 us per test at
  * n = 79 (64 traits x 7321 markers: 8.6 ms host to host) -- the whole BXD matrix would take ~5 s where the 16-point grid of
- * bulkscan_alt_grid takes 15 ms: meant for subsets of traits.  At most 8 null covariates. */
+ * bulkscan_alt_grid takes 15 ms: meant for subsets of traits.  At most 31 null covariates (the per-marker design [Z0 x] has c + 1 <= 32 columns; beyond 8 the run-time-c kernel k_dyn_alt_brent). */
 int blmm_bulkscan_alt_exact(blmm_ctx* ctx, const blmm_opts* opts, const double* Y, int64_t n, int64_t m, const double* G, int64_t p,
                             const double* Covar, int64_t ncov, const double* K, const double* weights, double* L_out,
                             double* h2_panel_out, double* h2_null_out, double* sigma2_out, blmm_status* status);

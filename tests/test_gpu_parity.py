@@ -1033,10 +1033,32 @@ def test_covariate_cap_is_32_and_fails_loudly(blmm):
     with pytest.raises(blmm.BulkLMMError) as e:
         blmm.bulkscan_null(Y, G, K, Cov)
     assert "1..32" in e.value.msg
-    Y, G, K, Cov = make_data(p=20, m=3, seed=7102, ncov=9)
+    Y, G, K, Cov = make_data(p=20, m=3, seed=7102, ncov=31)      # scan_alt: the per-marker design [Z0 x] would have 33 columns
     with pytest.raises(blmm.BulkLMMError) as e:
         blmm.scan(Y[:, 0], G, K, Cov, assumption="alt")
-    assert "at most 8" in e.value.msg
+    assert "at most 31" in e.value.msg
+
+
+@pytest.mark.parametrize("ncov,kw", [(9, {}), (12, dict(reml=True, optim_interval=2)), (30, dict(alt_true_weights=True))])
+def test_scan_alt_runtime_covariate_counts(blmm, ncov, kw):
+    """scan(...; assumption = "alt") beyond the 8 covariates k_alt_brent is instantiated for: k_dyn_alt_brent (kernels_dyn.hip), one
+    wave per marker on the design [Z0 x_i] with the factorisations in LDS; same checks as test_scan_alt_matches_oracle, and the bulk
+    form (bulkscan_alt_exact) column by column."""
+    Y, G, K, Cov = make_data(n=79, p=60, m=3, seed=7300 + ncov, ncov=ncov, bxd=True)
+    y = Y[:, :1]
+    okw = dict(kw)
+    if okw.pop("alt_true_weights", False):
+        okw["true_weights"] = True
+    got = blmm.scan(y, G, K, Cov, assumption="alt", **kw)
+    own = O.scan(y, G, K, covar=Cov, assumption="alt", **okw)
+    assert abs(got["h2_null"] - own["h2_null"]) <= 1e-6 and abs(got["sigma2_e"] - own["sigma2_e"]) <= 1e-6 * abs(own["sigma2_e"])
+    dh = np.abs(got["h2_each_marker"] - own["h2_each_marker"])
+    assert np.quantile(dh, 0.9) <= 1e-6, dh.max()
+    ref = O.scan(y, G, K, covar=Cov, assumption="alt", h2_each_override=got["h2_each_marker"], h2_null_override=got["h2_null"], **okw)
+    assert_lod_close(got["lod"], ref["lod"], atol=1e-9)
+    assert np.abs(got["lod"] - own["lod"]).max() <= 1e-6 * max(1.0, np.abs(own["lod"]).max()) + 1e-7
+    bulk = blmm.bulkscan_alt_exact(Y, G, K, Cov, **kw)
+    assert np.array_equal(bulk["L"][:, 0], got["lod"]) and np.array_equal(bulk["h2_panel"][:, 0], got["h2_each_marker"])
 
 
 @pytest.mark.parametrize("n", [130, 333, 700])
