@@ -20,7 +20,7 @@ for case in range(ncases):
     ncov = int(rng.choice([0, 0, 1, 2, 3, 4, 5, 7, 8, 11, 19, 31]))      # beyond 7: the run-time-c kernels (kernels_dyn.hip)
     if ncov + 2 >= n: ncov = 0
     method = str(rng.choice(["null-exact", "null-exact", "null-grid", "alt-grid", "perms", "scan-alt"]))
-    if ncov > 7 and method == "scan-alt": ncov = 7                      # scan_alt: at most 8 covariates incl. the intercept
+    if ncov > 29 and method == "scan-alt": ncov = 19                    # scan_alt: its design [Z0 x] has c + 1 <= 32 columns (k_dyn_alt_brent beyond 8)
     if ncov > 7 and n < 3 * ncov: ncov = 7                              # keep the null design comfortably full rank
     oi = int(rng.choice([1, 1, 1, 2, 3]))
     reml = bool(rng.random() < 0.25)
