@@ -361,9 +361,12 @@ def main():
         Lh[:] = 0.0                                    # touch the pages: the caller's allocation cost is not ours
         meth = {"null-exact": B._lib.BLMM_NULL_EXACT, "null-grid": B._lib.BLMM_NULL_GRID, "alt-grid": B._lib.BLMM_ALT_GRID}[a.method]
         hctx = B.Context(dev_index)
+        # column-major inputs, as a Julia caller's Arrays are: the Python mirror would otherwise re-lay out the C-ordered synthetic Y
+        # on every call (np.asfortranarray of 22 MB, ~4 ms of NumPy inside the timed call -- not part of the C ABI's time)
+        Yf_, Gf_, Kf_ = np.asfortranarray(Y), np.asfortranarray(G), np.asfortranarray(K)
         def host_call(out):
             t0 = time.perf_counter()
-            B.api.bulkscan_into(hctx, meth, Y, G, K, out, h2_grid=grid)
+            B.api.bulkscan_into(hctx, meth, Yf_, Gf_, Kf_, out, h2_grid=grid)
             return (time.perf_counter() - t0) * 1e3
         host_call(Lh)
         t_page = min(host_call(Lh) for _ in range(2))

@@ -5,6 +5,7 @@
 #include "blmm_internal.h"
 #include "fastmath.h"
 #include <cmath>
+#include <chrono>
 #include <cstring>
 #include <limits>
 #include <cstdlib>
@@ -1101,6 +1102,10 @@ int blmm_bulkscan(blmm_ctx* ctx, const blmm_opts* opts, const double* Y, int64_t
   if ((rc = ensure(ctx, ctx->inK, sizeof(double) * n * n))) return rc;
   if ((rc = ensure(ctx, ctx->outL, sizeof(double) * (size_t)p * m))) return rc;
   if ((rc = ensure(ctx, ctx->outH2, sizeof(double) * h2_elems))) return rc;
+  // BLMM_HOST_PROF=1: wall-clock of the call's legs on stderr (diagnostic: it synchronises between them)
+  static const bool hprof = getenv("BLMM_HOST_PROF") && getenv("BLMM_HOST_PROF")[0] == '1';
+  auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+  const double hp0 = hprof ? now() : 0.0;
   BLMM_HIP(hipMemcpyAsync(ctx->inY.p, Y, sizeof(double) * n * m, hipMemcpyHostToDevice, ctx->stream));
   BLMM_HIP(hipMemcpyAsync(ctx->inG.p, G, sizeof(double) * n * p, hipMemcpyHostToDevice, ctx->stream));
   BLMM_HIP(hipMemcpyAsync(ctx->inK.p, K, sizeof(double) * n * n, hipMemcpyHostToDevice, ctx->stream));
@@ -1115,13 +1120,22 @@ int blmm_bulkscan(blmm_ctx* ctx, const blmm_opts* opts, const double* Y, int64_t
     BLMM_HIP(hipMemcpyAsync(ctx->inW.p, weights, sizeof(double) * n, hipMemcpyHostToDevice, ctx->stream));
     dW = ptr<double>(ctx->inW);
   }
+  if (hprof) (void)hipStreamSynchronize(ctx->stream);
+  const double hp1 = hprof ? now() : 0.0;
   rc = blmm_bulkscan_dev(ctx, opts, ptr<double>(ctx->inY), n, m, ptr<double>(ctx->inG), p, dCov, dCov ? ncov : 0,
                          ptr<double>(ctx->inK), dW, h2_grid, ngrid, ptr<double>(ctx->outL), p, ptr<double>(ctx->outH2), status);
   if (rc) { hipStreamSynchronize(ctx->stream); return rc; }
+  const double hp2 = hprof ? now() : 0.0;
+  if (hprof) (void)hipStreamSynchronize(ctx->stream);
+  const double hp3 = hprof ? now() : 0.0;
   ctx->last_L = ptr<double>(ctx->outL); ctx->last_p = p; ctx->last_m = m; ctx->last_f32 = false;
   if ((size_t)p * m > 0 && (rc = copy_to_host(ctx, L_out, ctx->outL.p, sizeof(double) * (size_t)p * m))) return rc;
+  const double hp4 = hprof ? now() : 0.0;
   if (h2_elems > 0 && (rc = copy_to_host(ctx, h2_out, ctx->outH2.p, sizeof(double) * h2_elems))) return rc;
   BLMM_HIP(hipStreamSynchronize(ctx->stream));
+  if (hprof)
+    fprintf(stderr, "blmm_bulkscan legs (ms): uploads %.2f | enqueue %.2f | device %.2f | L to host %.2f | h2 to host + sync %.2f\n", hp1 - hp0, hp2 - hp1,
+            hp3 - hp2, hp4 - hp3, now() - hp4);
   return check_sticky(ctx);   // a device-side failure of THIS call (no status passed): reported now, not by the next call
 }
 
