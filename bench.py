@@ -322,11 +322,12 @@ def main():
         finally:
             del os.environ["BLMM_LR_SHARED"]
         work.scan(); torch.cuda.synchronize()      # leave the default path's result in the outputs
-    lr_rank = lr_resid = lr_fallback = lr_shared = None
+    lr_rank = lr_resid = lr_fallback = lr_shared = lr_profile = None
     if a.method == "null-exact":   # one extra (untimed) call with a status read-back: the weight basis and its guard
         st = B.bulkscan_dev(ctx, work.dY, dG, dK, work.dL, work.dH, method=a.method, h2_grid=grid, status=True)
         lr_rank, lr_resid, lr_fallback = int(st.lowrank_rank), float(st.lowrank_resid), int(st.lowrank_fallback)
         lr_shared = int(st.lowrank_shared)
+        lr_profile = ctx.lowrank_profile()          # (shared-weights traits, [(traits, rank) per segment of the heritability axis])
     # sanity: the output must be finite (a fast kernel with wrong results is not a result)
     chk = torch.isfinite(work.dL[: min(64, work.m)]).all().item()
 
@@ -399,6 +400,9 @@ def main():
                 kr4 = 4 * (-(-lr_rank // 4))
                 rank_form_flops = 2.0 * (npad8 + (1 + c) * kr4) * p * m_local
                 flops_launch = 2.0 * p * (npad8 * m_local + (1 + c) * kr4 * (m_local - (lr_shared or 0)))
+                if lr_profile and lr_profile[1]:
+                    # every segment of the heritability axis has its own basis: a trait's rank-R phase runs over ITS segment's rank
+                    flops_launch = 2.0 * p * (npad8 * m_local + (1 + c) * sum(cnt * 4 * (-(-rk // 4)) for cnt, rk in lr_profile[1]))
             else:   # BLMM_EXACT=full: the (2+c) full-length contractions
                 flops_launch = survey_flops
         elif a.method in ("null-grid", "perms"):
@@ -423,6 +427,8 @@ def main():
             roof["weight_basis_resid"] = lr_resid
             roof["traits_rescanned_full_rank"] = lr_fallback
             roof["traits_shared_weights"] = lr_shared
+            if lr_profile:
+                roof["weight_basis_segments"] = [{"traits": cnt, "rank": rk} for cnt, rk in lr_profile[1]]
             if rank_form_flops and scan_ms > 0:   # the same launch priced as if every trait ran the rank-R phase (the r01 / r02a form)
                 roof["frac_if_all_traits_rank_form"] = rank_form_flops / (scan_ms * 1e-3) / 1e12 / FP64_MFMA_PEAK_TFLOPS
             roof["reference_formulation_flops_per_launch"] = survey_flops   # 2n(2+c) per test, SURVEY.md §8(d)

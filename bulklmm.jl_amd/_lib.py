@@ -15,7 +15,7 @@ LIB_PATH = os.path.join(CSRC, "libbulklmm_hip.so")
 # every symbol include/bulklmm_hip.h declares
 EXPORTS = [
     "blmm_version", "blmm_device_count", "blmm_create", "blmm_destroy", "blmm_last_error", "blmm_err_string",
-    "blmm_set_stream", "blmm_set_timing", "blmm_read_timings", "blmm_synchronize", "blmm_default_opts",
+    "blmm_set_stream", "blmm_set_timing", "blmm_read_timings", "blmm_lowrank_profile", "blmm_synchronize", "blmm_default_opts",
     "blmm_kinship", "blmm_kinship_dev", "blmm_bulkscan", "blmm_bulkscan_dev", "blmm_scan_perms",
     "blmm_scan_perms_dev", "blmm_scan_perms_f32", "blmm_scan_perms_f32_dev", "blmm_lod_colmax", "blmm_lod_colmax_dev", "blmm_rotate", "blmm_null_h2_brent", "blmm_null_loglik_grid",
     "blmm_weighted_liteqtl", "blmm_liteqtl_given_h2",
@@ -101,6 +101,7 @@ def load():
     lib.blmm_set_timing.argtypes = [vp, C.c_int]
     lib.blmm_synchronize.argtypes = [vp]
     lib.blmm_read_timings.argtypes = [vp, dp, C.POINTER(C.c_int64)]
+    lib.blmm_lowrank_profile.argtypes = [vp, C.POINTER(C.c_int64)]
     lib.blmm_default_opts.argtypes = [op]
     lib.blmm_default_opts.restype = None
     # data pointers are passed as void* so that both host (numpy) and device (torch data_ptr) addresses fit

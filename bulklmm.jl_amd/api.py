@@ -75,6 +75,13 @@ class Context:
         names = ("eigen", "rotate", "h2", "prep", "scan", "total")
         return {k: float(v) for k, v in zip(names, sums)}, int(cnt.value)
 
+    def lowrank_profile(self):
+        """blmm_lowrank_profile: (traits of the shared-weights class, [(traits, rank) per segment of the heritability axis]) of the
+        last null-exact call -- what its low-rank weights form executed."""
+        out = (C.c_int64 * 18)()
+        self.check(self.lib.blmm_lowrank_profile(self.h, out))
+        return int(out[1]), [(int(out[2 + 2 * s]), int(out[3 + 2 * s])) for s in range(int(out[0]))]
+
     def set_stream(self, stream: Optional[int]):
         self.check(self.lib.blmm_set_stream(self.h, _stream_arg(stream)))
 

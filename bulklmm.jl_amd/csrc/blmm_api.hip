@@ -280,14 +280,15 @@ int prepare_eigen(blmm_ctx* ctx, const blmm_opts* o, int64_t n, const double* dC
 int start_wbasis(blmm_ctx* ctx, const Pipe& P) {
   int rc;
   const int64_t n = P.n;
-  if ((rc = ensure(ctx, ctx->wbQ, sizeof(double) * (size_t)P.npad * n))) return rc;
+  const LrSeg seg = lr_segments(P.n);
+  if ((rc = ensure(ctx, ctx->wbQ, sizeof(double) * (size_t)seg.S * P.npad * n))) return rc;
   if ((rc = ensure(ctx, ctx->wbW, sizeof(double) * (size_t)n * (256 + 16)))) return rc;
-  if ((rc = ensure(ctx, ctx->wbRk, sizeof(int) * 4))) return rc;
+  if ((rc = ensure(ctx, ctx->wbRk, sizeof(int) * 4 * LR_SEG_MAX))) return rc;
   hipStream_t main_stream = ctx->stream;
   BLMM_HIP(hipEventRecord(ctx->ev_xt, main_stream));
   BLMM_HIP(hipStreamWaitEvent(ctx->side, ctx->ev_xt, 0));
   ctx->stream = ctx->side;                                           // the launchers enqueue on ctx->stream
-  rc = launch_wbasis(ctx, P.lam, (int)n, ptr<double>(ctx->wbW), ptr<double>(ctx->wbQ), ptr<int>(ctx->wbRk), P.stat);
+  rc = launch_wbasis(ctx, P.lam, (int)n, P.npad, seg, ptr<double>(ctx->wbW), ptr<double>(ctx->wbQ), ptr<int>(ctx->wbRk), P.stat);
   ctx->stream = main_stream;
   return rc;
 }
@@ -374,31 +375,38 @@ double lr_tolerance() {
 // Width of one region of the panel arrays (LrRegion): k_lr_classify fills it from both ends, so it needs a whole padding
 // tile beyond the traits.  The arrays hold two regions (leading dimension 2 * lr_ldq): the second one is used when the
 // h2 search is split and its second kernel runs beside the scan of the traits the first kernel finished.
-int64_t lr_ldq(const Pipe& P) { return P.ldy + 128; }
+int64_t lr_ldq(const Pipe& P) { return P.ldy + 128 + LR_TILE * LR_SEG_MAX; }   // + a partly filled tile per weight-basis segment
+// the per-region device counters of the class / segment layout (blmm_internal.h: NSTAT)
+static LrRegion lr_region(const Pipe& P, int r) {
+  LrRegion rg;
+  rg.col0 = r * lr_ldq(P); rg.ncol = lr_ldq(P); rg.counts = P.stat + 12 + 2 * r; rg.segcnt = P.stat + 24 + 20 * r;
+  return rg;
+}
 
 int lr_begin(blmm_ctx* ctx, const Pipe& P, bool wbasis_started) {
   int rc;
   const int64_t ldp = 2 * lr_ldq(P), tstride = (int64_t)P.npad * P.ldx;
   if ((rc = ensure(ctx, ctx->lrPerm, sizeof(int) * (size_t)ldp))) return rc;
   if ((rc = ensure(ctx, ctx->lrDen0, sizeof(double) * (size_t)P.ldx))) return rc;
-  if ((rc = ensure(ctx, ctx->lrT, sizeof(double) * (size_t)(1 + P.c) * tstride))) return rc;
+  const LrSeg seg = lr_segments(P.n);
+  if ((rc = ensure(ctx, ctx->lrT, sizeof(double) * (size_t)seg.S * (1 + P.c) * tstride))) return rc;
   if ((rc = ensure(ctx, ctx->lrC, sizeof(double) * (size_t)P.npad * ldp))) return rc;
   if ((rc = ensure(ctx, ctx->lrL, sizeof(double) * (size_t)(P.c * (P.c + 1) / 2) * ldp))) return rc;
   if ((rc = ensure(ctx, ctx->lrFlag, sizeof(int) * (size_t)ldp))) return rc;
   if ((rc = ensure(ctx, ctx->lrPart, sizeof(double) * 2 * (size_t)((P.n + 63) / 64) * ldp))) return rc;
   if ((rc = ensure(ctx, ctx->panels, sizeof(double) * (size_t)P.npad * ldp))) return rc;
-  if ((rc = ensure(ctx, ctx->wbQ, sizeof(double) * (size_t)P.npad * P.n))) return rc;
+  if ((rc = ensure(ctx, ctx->wbQ, sizeof(double) * (size_t)seg.S * P.npad * P.n))) return rc;
   if ((rc = ensure(ctx, ctx->wbW, sizeof(double) * (size_t)P.n * (256 + 16)))) return rc;
-  if ((rc = ensure(ctx, ctx->wbRk, sizeof(int) * 4))) return rc;
+  if ((rc = ensure(ctx, ctx->wbRk, sizeof(int) * 4 * LR_SEG_MAX))) return rc;
   int* rk = ptr<int>(ctx->wbRk);
   hipStream_t main_stream = ctx->stream;
   BLMM_HIP(hipEventRecord(ctx->ev_fork, main_stream));            // rotated operands are ready
   BLMM_HIP(hipStreamWaitEvent(ctx->side, ctx->ev_fork, 0));
   ctx->stream = ctx->side;                                         // the launchers enqueue on ctx->stream
   rc = BLMM_OK;
-  if (!wbasis_started) rc = launch_wbasis(ctx, P.lam, P.n, ptr<double>(ctx->wbW), ptr<double>(ctx->wbQ), rk, P.stat);
+  if (!wbasis_started) rc = launch_wbasis(ctx, P.lam, P.n, P.npad, seg, ptr<double>(ctx->wbW), ptr<double>(ctx->wbQ), rk, P.stat);
   if (!rc && hipEventRecord(ctx->ev_q, ctx->side) != hipSuccess) rc = fail(ctx, BLMM_ERR_HIP, "hipEventRecord failed");   // what the panels need
-  if (!rc) rc = launch_lr_tpanels(ctx, P.Xt, P.ldx, P.p, P.n, P.c, P.npad, P.Z0, ptr<double>(ctx->wbQ), rk, ptr<double>(ctx->lrT), tstride,
+  if (!rc) rc = launch_lr_tpanels(ctx, P.Xt, P.ldx, P.p, P.n, P.c, P.npad, P.Z0, ptr<double>(ctx->wbQ), rk, seg, ptr<double>(ctx->lrT), tstride,
                                   ptr<double>(ctx->lrDen0));
   ctx->stream = main_stream;
   if (rc) return rc;
@@ -426,6 +434,7 @@ LrArgs lr_args(blmm_ctx* ctx, const Pipe& P, const LrRegion& rg, double* dL, int
   la.Cp = ptr<double>(ctx->lrC); la.T = ptr<double>(ctx->lrT); la.tstride = (int64_t)P.npad * P.ldx; la.Ls = ptr<double>(ctx->lrL);
   la.rk = ptr<int>(ctx->wbRk); la.c = P.c; la.perm = ptr<int>(ctx->lrPerm); la.rg = rg; la.den0 = ptr<double>(ctx->lrDen0);
   la.skip_shared = 0;
+  la.seg = lr_segments(P.n);
   return la;
 }
 // LOD scan of one region on the current stream: the shared-weights class through the table kernel (one bin, 4 waves per
@@ -448,11 +457,11 @@ int lr_region_scan(blmm_ctx* ctx, const Pipe& P, const LrRegion& rg, double* dL,
 }
 // panels of one region on the current stream
 int lr_region_panels(blmm_ctx* ctx, const Pipe& P, const NullModel& nm, const double* dh2, const LrRegion& rg) {
-  return launch_lr_panels(ctx, nm, P.Yt, P.ldy, P.m, P.Z0, P.lam, dh2, ptr<double>(ctx->wbQ), ptr<int>(ctx->wbRk), ptr<int>(ctx->lrPerm),
+  return launch_lr_panels(ctx, nm, P.Yt, P.ldy, P.m, P.Z0, P.lam, dh2, ptr<double>(ctx->wbQ), ptr<int>(ctx->wbRk), lr_segments(P.n), ptr<int>(ctx->lrPerm),
                           rg, ptr<double>(ctx->panels), ptr<double>(ctx->lrC), ptr<double>(ctx->lrL), 2 * lr_ldq(P), P.stat);
 }
 int lr_region_resid(blmm_ctx* ctx, const Pipe& P, const NullModel& nm, const double* dh2, const LrRegion& rg) {
-  return launch_lr_resid(ctx, nm, P.m, lr_tolerance(), P.lam, dh2, ptr<double>(ctx->wbQ), ptr<int>(ctx->wbRk), ptr<int>(ctx->lrPerm), rg,
+  return launch_lr_resid(ctx, nm, P.m, lr_tolerance(), P.lam, dh2, ptr<double>(ctx->wbQ), ptr<int>(ctx->wbRk), lr_segments(P.n), ptr<int>(ctx->lrPerm), rg,
                          ptr<double>(ctx->lrC), 2 * lr_ldq(P), ptr<int>(ctx->lrFlag), ptr<double>(ctx->lrPart), P.stat);
 }
 int lr_fix(blmm_ctx* ctx, const Pipe& P, const NullModel& nm, const double* dh2, double* dL, int64_t ldL) {
@@ -476,11 +485,12 @@ int illcond_rescan(blmm_ctx* ctx, const Pipe& P, const NullModel& nm, int64_t m,
 // every trait's h2 is final: one region
 int lr_finish(blmm_ctx* ctx, const Pipe& P, const NullModel& nm, const double* dh2, double* dL, int64_t ldL, Timer& tm) {
   int rc;
-  LrRegion rg; rg.col0 = 0; rg.ncol = lr_ldq(P); rg.counts = P.stat + 12;
+  const LrRegion rg = lr_region(P, 0);
+  const LrSeg seg = lr_segments(P.n);
   hipStream_t main_stream = ctx->stream;
   BLMM_HIP(hipStreamWaitEvent(main_stream, ctx->ev_join, 0));
   BLMM_HIP(hipStreamWaitEvent(main_stream, ctx->ev_m, 0));
-  if ((rc = launch_lr_classify(ctx, P.n, P.m, lr_shared_tol(), P.lam, dh2, nullptr, nullptr, nullptr, ptr<int>(ctx->lrPerm), rg))) return rc;
+  if ((rc = launch_lr_classify(ctx, P.n, P.m, lr_shared_tol(), P.lam, dh2, nullptr, nullptr, nullptr, ptr<int>(ctx->lrPerm), rg, seg))) return rc;
   if ((rc = lr_region_panels(ctx, P, nm, dh2, rg))) return rc;
   tm.mark();
   // residual guard of the weight basis, every trait: side stream, beside the scan kernel; joined below
@@ -505,15 +515,13 @@ int lr_finish(blmm_ctx* ctx, const Pipe& P, const NullModel& nm, const double* d
 int lr_finish_split(blmm_ctx* ctx, const Pipe& P, const NullModel& nm, double* dh2, double* dL, int64_t ldL, Timer& tm,
                     const BrentSplit& sp) {
   int rc;
-  const int64_t ldq = lr_ldq(P);
-  LrRegion r0, r1;
-  r0.col0 = 0; r0.ncol = ldq; r0.counts = P.stat + 12;
-  r1.col0 = ldq; r1.ncol = ldq; r1.counts = P.stat + 14;
+  const LrRegion r0 = lr_region(P, 0), r1 = lr_region(P, 1);
+  const LrSeg seg = lr_segments(P.n);
   hipStream_t main_stream = ctx->stream;
   // ---- main stream: region 0's classification and panels (the perm preset is ready at ev_m, the weight basis at ev_q, the
   //      marker-side products at ev_join) ...
   BLMM_HIP(hipStreamWaitEvent(main_stream, ctx->ev_m, 0));
-  if ((rc = launch_lr_classify(ctx, P.n, P.m, lr_shared_tol(), P.lam, dh2, sp.fin, nullptr, nullptr, ptr<int>(ctx->lrPerm), r0))) return rc;
+  if ((rc = launch_lr_classify(ctx, P.n, P.m, lr_shared_tol(), P.lam, dh2, sp.fin, nullptr, nullptr, ptr<int>(ctx->lrPerm), r0, seg))) return rc;
   BLMM_HIP(hipStreamWaitEvent(main_stream, ctx->ev_q, 0));
   if ((rc = lr_region_panels(ctx, P, nm, dh2, r0))) return rc;
   // ---- ... and only then the second side stream: the rest of the h2 search, then region 1's columns.  Forked right behind
@@ -525,7 +533,7 @@ int lr_finish_split(blmm_ctx* ctx, const Pipe& P, const NullModel& nm, double* d
   BrentSplit sp2 = sp;
   rc = launch_brent(ctx, nm, P.Yt, P.ldy, P.m, P.Z0, P.lam, dh2, nullptr, nullptr, P.stat, 2, &sp2);
   if (!rc && hipStreamWaitEvent(ctx->side2, ctx->ev_q, 0) != hipSuccess) rc = fail(ctx, BLMM_ERR_HIP, "hipStreamWaitEvent failed");
-  if (!rc) rc = launch_lr_classify(ctx, P.n, P.m, lr_shared_tol(), P.lam, dh2, nullptr, sp.list, sp.cnt, ptr<int>(ctx->lrPerm), r1);
+  if (!rc) rc = launch_lr_classify(ctx, P.n, P.m, lr_shared_tol(), P.lam, dh2, nullptr, sp.list, sp.cnt, ptr<int>(ctx->lrPerm), r1, seg);
   if (!rc) rc = lr_region_panels(ctx, P, nm, dh2, r1);
   ctx->stream = main_stream;
   if (rc) return rc;
@@ -694,6 +702,26 @@ int blmm_read_timings(blmm_ctx* ctx, double* sums_ms, int64_t* ncalls) {
   }
   *ncalls = (int64_t)ctx->ev_used;
   ctx->ev_used = 0;
+  return BLMM_OK;
+}
+
+int blmm_lowrank_profile(blmm_ctx* ctx, int64_t* out) {
+  if (!ctx || !out) return BLMM_ERR_INVALID;
+  for (int i = 0; i < 2 + 2 * LR_SEG_MAX; ++i) out[i] = 0;
+  if (!ctx->stat.p || !ctx->wbRk.p) return BLMM_OK;           // no null-exact call yet
+  BLMM_HIP(hipSetDevice(ctx->device));
+  int64_t h[NSTAT];
+  int rk[4 * LR_SEG_MAX];
+  BLMM_HIP(hipMemcpyAsync(h, ctx->stat.p, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
+  BLMM_HIP(hipMemcpyAsync(rk, ctx->wbRk.p, sizeof(rk), hipMemcpyDeviceToHost, ctx->stream));
+  BLMM_HIP(hipStreamSynchronize(ctx->stream));
+  // the segments in use: those whose rank the basis kernel wrote (a single basis: segment 0 only, the other counts are zero)
+  int S = 0;
+  for (int s = 0; s < LR_SEG_MAX; ++s) {
+    const int64_t cnt = h[24 + s] + h[44 + s];
+    if (cnt > 0) { S = s + 1; out[2 + 2 * s] = cnt; out[3 + 2 * s] = rk[4 * s]; }
+  }
+  out[0] = S; out[1] = h[12] + h[14];
   return BLMM_OK;
 }
 

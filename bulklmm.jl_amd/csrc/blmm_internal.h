@@ -22,7 +22,7 @@ constexpr int CFAST = 4;         // ... with the tuned forms (LDS-resident evalu
   case 5: M(5); break; case 6: M(6); break; case 7: M(7); break; case 8: M(8); break;
 constexpr int TILE_T = 64;       // traits per workgroup tile of the scan kernels
 constexpr int TILE_I = 128;      // markers per workgroup tile of the scan kernels
-constexpr int NSTAT = 24;        // device status counters ([6],[7]: eigensolver clocks, [8]: weight-basis rank, [9]: its residual, [10]: traits re-scanned full rank, [11]: eigensolver abort code, [12..15]: shared-weights traits / the others of the two panel regions (k_lr_classify), [16..18]: StatIdx below)
+constexpr int NSTAT = 64;        // device status counters ([24 + 20 r ..]: per panel region r, 8 counts of traits per weight-basis segment and the 9 placement cursors of k_lr_classify; [6],[7]: eigensolver clocks, [8]: weight-basis rank, [9]: its residual, [10]: traits re-scanned full rank, [11]: eigensolver abort code, [12..15]: shared-weights traits / the others of the two panel regions (k_lr_classify), [16..18]: StatIdx below)
 
 enum StatIdx { ST_NEG_EIG = 0, ST_NONPOS_W = 1, ST_ZERO_NORM = 2, ST_NAN_LOD = 3, ST_BRENT_MAXIT = 4, ST_JACOBI_SWEEPS = 5,
                ST_H2_BOUNDARY = 16, ST_H2_MULTIMODAL = 17, ST_ILLCOND = 18,
@@ -220,14 +220,36 @@ int launch_scan_exact(blmm_ctx* ctx, const ScanArgs& a, int c);
 constexpr int LR_TILE = 64;   // a multiple of every trait-tile width of k_scan_lr (32 * MB); regions are multiples of it
 struct LrRegion {
   int64_t col0 = 0, ncol = 0;
-  int64_t* counts = nullptr;
+  int64_t* counts = nullptr;        // {shared-weights traits, columns of the other class (every segment's run rounded up to LR_TILE)}
+  int64_t* segcnt = nullptr;        // [LR_SEG_MAX] traits of the other class per weight-basis segment; segcnt + 8: the placement cursors {shared, segment 0, ..}
 };
+// Segments of the heritability axis, each with its OWN weight basis (kernels_lowrank.hip): the family { w(h2) : h2 in a segment }
+// has a far smaller numerical rank than the whole family (BXD spectrum: 11-12 per segment of the six below against 23), so the
+// rank-R phase of k_scan_lr runs 3 K steps where the single basis needs 6.  The other class of a region is laid out segment by
+// segment from the back of the region, every segment's run rounded up to LR_TILE columns: a tile of the scan never mixes segments.
+constexpr int LR_SEG_MAX = 8;
+struct LrSeg {
+  int S = 1;
+  double edge[LR_SEG_MAX + 1] = {0.0, 2.0, 2.0, 2.0, 2.0, 2.0, 2.0, 2.0, 2.0};   // segment s: edge[s] <= h2 < edge[s + 1] (the last one takes the rest)
+};
+// columns of the other class in front of segment s's run, counted from the END of the region, and the run's width
+__host__ __device__ inline int64_t lr_seg_width(int64_t cnt) { return (cnt + LR_TILE - 1) / LR_TILE * LR_TILE; }
+// segment of the column `dist` columns before the region's end (dist = 0: the last column); S - 1 beyond every run (padding)
+__host__ __device__ inline int lr_seg_of(int64_t dist, const int64_t* segcnt, int S) {
+  for (int s = 0; s + 1 < S; ++s) {
+    const int64_t w = lr_seg_width(segcnt[s]);
+    if (dist < w) return s;
+    dist -= w;
+  }
+  return S - 1;
+}
 struct LrArgs {
   ScanArgs s;                       // s.P = panel 0 only
   const double* Cp;                 // weight-basis coefficients [4*KR][ldp]
   const double* T; int64_t tstride; // marker-side basis products [1+c][4*KR][ldx]
   const double* Ls;                 // packed L_j^-1 [c(c+1)/2][ldp]
-  const int* rk;                    // {R, KR} on the device
+  const int* rk;                    // {R, KR, -, -} per segment on the device
+  LrSeg seg;                        // T, Q of segment s: s * (1 + c) * tstride, s * npad * n doubles further on
   const int* perm;                  // panel column -> trait (k_lr_classify; -1: padding)
   LrRegion rg;                      // the region of the panel arrays this launch scans
   const double* den0;               // the shared-weights class's 1/sqrt(Sxx - |u|^2), per marker (= isx of the unweighted model)
@@ -236,14 +258,14 @@ struct LrArgs {
 };
 int launch_scan_lr(blmm_ctx* ctx, const LrArgs& la);
 int launch_lr_resid(blmm_ctx* ctx, const NullModel& nm, int64_t m, double tol, const double* lam, const double* h2,
-                    const double* Q, const int* rk, const int* perm, const LrRegion& rg, const double* Cp, int64_t ldp,
+                    const double* Q, const int* rk, const LrSeg& seg, const int* perm, const LrRegion& rg, const double* Cp, int64_t ldp,
                     int* flag_list, double* part, int64_t* stat);
 int launch_scan_fix(blmm_ctx* ctx, const NullModel& nm, const double* Xt, int64_t ldx, int64_t p, const double* P0,
                     const double* Ls, int64_t ldp, const double* Z0, const double* lam, const double* h2,
                     const int* flag_list, const int* perm, double* L, int64_t ldL, int64_t* stat);
 // shared-weights class: column order of the panels (perm, info) and the per-marker denominators of the unweighted model
 int launch_lr_classify(blmm_ctx* ctx, int n, int64_t m, double tol, const double* lam, const double* h2, const int* fin,
-                       const int* list, const unsigned int* list_cnt, int* perm, const LrRegion& rg);
+                       const int* list, const unsigned int* list_cnt, int* perm, const LrRegion& rg, const LrSeg& seg);
 // kernels_scan_f32.hip: fp32 permutation LOD kernel and the fp64 k-major -> fp32 fragment-major conversion
 int launch_cvt_f32(blmm_ctx* ctx, const double* M, int64_t ld_in, int rows_valid, int64_t cols_valid, float* F,
                    int64_t ld_out, int kblocks);
@@ -271,11 +293,13 @@ int launch_illcond_flag(blmm_ctx* ctx, const NullModel& nm, int64_t m, const dou
 int launch_scan_qr(blmm_ctx* ctx, const NullModel& nm, const double* Yt, int64_t ldy, const double* Xt, int64_t ldx, int64_t p,
                    const double* Z0, const double* lam, const double* h2, const int* list, double* L, int64_t ldL, int64_t* stat);
 // kernels_lowrank.hip
-int launch_wbasis(blmm_ctx* ctx, const double* lam, int n, double* Wk, double* Q, int* rk, int64_t* stat);
+// the segments a call with n individuals uses (one when the basis comes from the multi-workgroup / LDS kernels: n > 80)
+LrSeg lr_segments(int n);
+int launch_wbasis(blmm_ctx* ctx, const double* lam, int n, int npad, const LrSeg& seg, double* Wk, double* Q, int* rk, int64_t* stat);
 int launch_lr_tpanels(blmm_ctx* ctx, const double* Xt, int64_t ldx, int64_t p, int n, int c, int npad, const double* Z0,
-                      const double* Q, const int* rk, double* T, int64_t tstride, double* den0);
+                      const double* Q, const int* rk, const LrSeg& seg, double* T, int64_t tstride, double* den0);
 int launch_lr_panels(blmm_ctx* ctx, const NullModel& nm, const double* Yt, int64_t ldy, int64_t m, const double* Z0,
-                     const double* lam, const double* h2, const double* Q, const int* rk, const int* perm, const LrRegion& rg,
+                     const double* lam, const double* h2, const double* Q, const int* rk, const LrSeg& seg, const int* perm, const LrRegion& rg,
                      double* P0, double* Cp, double* Ls, int64_t ldp, int64_t* stat);
 int launch_scan_table(blmm_ctx* ctx, const ScanArgs& a);
 // the shared-weights class of one panel region through the table kernel (isx = 1/sqrt(den0), one bin, stores through perm)

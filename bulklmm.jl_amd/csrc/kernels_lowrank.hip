@@ -174,11 +174,14 @@ __global__ void __launch_bounds__(WB_NS * TPS) k_wbasis(const double* __restrict
 // Register-resident variant for n <= 4 * NKR: the 256 sample columns live in the registers of their 4 lanes (NKR values
 // each), so the deflation of every column -- the bulk of an iteration -- touches LDS only for the new basis vector.  Same
 // greedy sequence as k_wbasis (same samples when that one runs with 256 of them, same pivot rule).
+// blockIdx.x = segment of the heritability axis (LrSeg): its own samples, its own basis Q + blockIdx.x * qstride, rk + 4 * blockIdx.x.
 template <int NKR>
 __global__ void __launch_bounds__(1024) k_wbasis_reg(const double* __restrict__ lam, int n, double* __restrict__ Q,
-                                                     int* __restrict__ rk, int64_t* stat, int qcap) {
+                                                     int* __restrict__ rk, int64_t* stat, int qcap, LrSeg seg, int64_t qstride) {
   extern __shared__ __attribute__((aligned(16))) double sh[];
   constexpr int TPS = 4, NS = 256, NT = 1024;
+  const int sg = blockIdx.x;
+  Q += (int64_t)sg * qstride; rk += 4 * sg;
   double* sq = sh;              // n : the pivot column / new basis vector
   double* sd = sh + n;          // n : re-orthogonalisation coefficients
   double* Ql = sh + 2 * n;      // qcap x n : LDS mirror of the first basis vectors
@@ -197,7 +200,16 @@ __global__ void __launch_bounds__(1024) k_wbasis_reg(const double* __restrict__ 
     if (t == 0) { rk[0] = n; rk[1] = (n + 3) / 4; stat[8] = n; }
     return;
   }
-  const double delta = (s == 0) ? 0.0 : exp(2.302585092994046 * (-6.0 + 15.0 * (double)(s - 1) / (double)(NS - 2)));
+  // one segment: delta_0 = 0 (w = 1), then log-spaced over [1e-6, 1e9] (h2 from 1e-6 to 1 - 1e-9).  Several: sample 0 is the
+  // segment's lower edge, the others log-spaced from there (1e-6 in the first segment) to its upper edge (1e9 in the last)
+  double delta;
+  if (seg.S <= 1) delta = (s == 0) ? 0.0 : exp(2.302585092994046 * (-6.0 + 15.0 * (double)(s - 1) / (double)(NS - 2)));
+  else {
+    const double ha = seg.edge[sg], hb = seg.edge[sg + 1];
+    const double da = ha / (1.0 - ha), db = (sg + 1 < seg.S && hb < 1.0) ? hb / (1.0 - hb) : 1e9;
+    const double lo = log(fmax(da, 1e-6)), hi = log(fmin(fmax(db, 2e-6), 1e9));
+    delta = (s == 0) ? da : exp(lo + (hi - lo) * (double)(s - 1) / (double)(NS - 2));
+  }
   double wv[NKR];
   double nrm = 0.0;
 #pragma unroll
@@ -289,7 +301,7 @@ __global__ void __launch_bounds__(1024) k_wbasis_reg(const double* __restrict__ 
     res2 = r2;
     __syncthreads();
   }
-  if (t == 0) { rk[0] = R; rk[1] = (R + 3) / 4; stat[8] = R; }
+  if (t == 0) { rk[0] = R; rk[1] = (R + 3) / 4; atomicMax((unsigned long long*)&stat[8], (unsigned long long)R); }   // stat[8]: the largest rank over the segments
 }
 
 // Multi-workgroup variant for n beyond the single-workgroup LDS budget.  The 256 sample columns are dealt S per
@@ -438,7 +450,29 @@ __global__ void __launch_bounds__(1024) k_wbasis_mw(const double* __restrict__ l
   }
 }
 
-int launch_wbasis(blmm_ctx* ctx, const double* lam, int n, double* Wk, double* Q, int* rk, int64_t* stat) {
+// Segments of the heritability axis (LrSeg): only the register-resident basis kernel builds several bases (n <= 80: the BXD case);
+// BLMM_LR_SEGMENTS=1: a single basis everywhere (A/B testing), =2..8: that many equal segments.  The default edges keep every
+// segment's rank at 11-12 on the BXD kinship spectrum (tools: see DESIGN §4.1).
+LrSeg lr_segments(int n) {
+  LrSeg sg;
+  static const char* mw_env = getenv("BLMM_WBASIS");
+  static const char* wide_env = getenv("BLMM_LR_PANELS_WIDE");
+  static const int nb_env = getenv("BLMM_LR_PANELS_BATCH") ? atoi(getenv("BLMM_LR_PANELS_BATCH")) : 0;
+  const char* se = getenv("BLMM_LR_SEGMENTS");       // read per call: tests compare segmented and single-basis results in one process
+  const int want = se ? atoi(se) : 0;
+  if (n > 80 || n < 8 || want == 1 || (mw_env && std::strcmp(mw_env, "lds") == 0) || (wide_env && wide_env[0] == '0') || nb_env > 1) return sg;
+  if (want >= 2 && want <= LR_SEG_MAX) {
+    sg.S = want;
+    for (int i = 0; i <= LR_SEG_MAX; ++i) sg.edge[i] = (i < want) ? (double)i / want : 2.0;
+    return sg;
+  }
+  static const double def[7] = {0.0, 0.25, 0.5, 0.7, 0.85, 0.95, 2.0};
+  sg.S = 6;
+  for (int i = 0; i <= LR_SEG_MAX; ++i) sg.edge[i] = (i < 7) ? def[i] : 2.0;
+  return sg;
+}
+
+int launch_wbasis(blmm_ctx* ctx, const double* lam, int n, int npad, const LrSeg& seg, double* Wk, double* Q, int* rk, int64_t* stat) {
   // LDS budget (156 KB dynamic): two work vectors, the sample columns when 256, 192 or 128 of them fit (padded to
   // ns + 16 per row) beside at least 16 mirrored basis vectors, then as many mirrored basis vectors as fit (<= WB_QCAP)
   const size_t budget = 156 * 1024, work = sizeof(double) * (size_t)2 * n, row = sizeof(double) * (size_t)n;
@@ -452,10 +486,11 @@ int launch_wbasis(blmm_ctx* ctx, const double* lam, int n, double* Wk, double* Q
     const int qcap = (int)std::min<size_t>(WB_QCAP, (budget - work) / row);
     const size_t lds = work + row * qcap;
     BLMM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wbasis_reg<20>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(k_wbasis_reg<20>, dim3(1), dim3(1024), lds, ctx->stream, lam, n, Q, rk, stat, qcap);
+    hipLaunchKernelGGL(k_wbasis_reg<20>, dim3((unsigned)seg.S), dim3(1024), lds, ctx->stream, lam, n, Q, rk, stat, qcap, seg, (int64_t)npad * n);
     KCHECK();
     return BLMM_OK;
   }
+  if (seg.S != 1) return fail(ctx, BLMM_ERR_INVALID, "launch_wbasis: several segments need the register-resident basis kernel");
   if (ns) {
     const size_t wbytes = row * (size_t)(ns + 16);
     const int qcap = (int)std::min<size_t>(WB_QCAP, (budget - work - wbytes) / row);
@@ -507,16 +542,20 @@ template <int C, bool STAGE>
 __global__ void __launch_bounds__(256) k_lr_tpanels(const double* __restrict__ Xt, int64_t ldx, int64_t p, int n,
                                                     const double* __restrict__ Z0, const double* __restrict__ Q,
                                                     const int* __restrict__ rk, double* __restrict__ T, int64_t tstride,
-                                                    double* __restrict__ den0) {
+                                                    double* __restrict__ den0, int nchunk, int64_t qstride) {
   // The chunk's 16 basis rows and Z0 are staged in LDS once (STAGE; beyond the LDS budget, n > ~1000, they are read from
   // L2 -- a template parameter, not a run-time pointer choice: a pointer that may be either loses its address space and
   // every access becomes a flat load), and a thread fetches its marker's x eight
   // individuals at a time before using them: with the loads next to their uses every k cost an L2 round trip (94 us at the
   // BXD shape for ~9 us of arithmetic -- on the critical path of the scan).
   extern __shared__ __attribute__((aligned(16))) double sh[];
+  // blockIdx.y = segment * nchunk + chunk of 16 basis rows (segment s: Q + s * qstride, rk + 4 s, T + s * (1 + C) * tstride)
+  const int sgi = blockIdx.y / nchunk;
+  Q += (int64_t)sgi * qstride; rk += 4 * sgi; T += (int64_t)sgi * (1 + C) * tstride;
   const int R = rk[0], R4 = rk[1] * 4;
-  const int r0 = blockIdx.y * 16;
-  if (r0 >= R4 && r0 > 0) return;                // workgroup-uniform
+  const int r0 = (blockIdx.y - sgi * nchunk) * 16;
+  const bool first = r0 == 0 && sgi == 0;        // this chunk also leaves den0 (the unweighted model)
+  if (r0 >= R4 && !first) return;                // workgroup-uniform
   if constexpr (STAGE) {
     for (int e = threadIdx.x; e < 16 * n; e += blockDim.x) { const int t = e / n; sh[e] = (r0 + t < R) ? Q[(size_t)(r0 + t) * n + (e % n)] : 0.0; }
     for (int e = threadIdx.x; e < C * n; e += blockDim.x) sh[16 * n + e] = Z0[e];
@@ -557,7 +596,7 @@ __global__ void __launch_bounds__(256) k_lr_tpanels(const double* __restrict__ X
           xv[0] = x * x;
 #pragma unroll
           for (int q = 0; q < C; ++q) xv[1 + q] = x * zval(q, k);
-          if (r0 == 0) {                         // workgroup-uniform
+          if (first) {                           // workgroup-uniform
 #pragma unroll
             for (int q = 0; q <= C; ++q) un[q] += xv[q];
 #pragma unroll
@@ -580,7 +619,7 @@ __global__ void __launch_bounds__(256) k_lr_tpanels(const double* __restrict__ X
     if (r0 + t < R4)
 #pragma unroll
       for (int q = 0; q <= C; ++q) T[q * tstride + (int64_t)(r0 + t) * ldx + i] = acc[q][t];
-  if (r0 == 0) {
+  if (first) {
     double xx = 1.0;
     if (i < p) {
       double L[NA];
@@ -607,15 +646,17 @@ __global__ void __launch_bounds__(256) k_lr_tpanels(const double* __restrict__ X
 }
 
 int launch_lr_tpanels(blmm_ctx* ctx, const double* Xt, int64_t ldx, int64_t p, int n, int c, int npad, const double* Z0,
-                      const double* Q, const int* rk, double* T, int64_t tstride, double* den0) {
-  dim3 grid((unsigned)((ldx + 255) / 256), (unsigned)((npad + 15) / 16));
+                      const double* Q, const int* rk, const LrSeg& seg, double* T, int64_t tstride, double* den0) {
+  const int nchunk = (npad + 15) / 16;
+  const int64_t qstride = (int64_t)npad * n;
+  dim3 grid((unsigned)((ldx + 255) / 256), (unsigned)(nchunk * seg.S));
   size_t lds = sizeof(double) * (size_t)n * (16 + c);
   const int stage = lds <= 150 * 1024;
   if (!stage) lds = 0;
 #define TP(C) do { if (stage) { \
     if (lds > 48 * 1024) BLMM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_lr_tpanels<C, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
-    hipLaunchKernelGGL((k_lr_tpanels<C, true>), grid, dim3(256), lds, ctx->stream, Xt, ldx, p, n, Z0, Q, rk, T, tstride, den0); \
-  } else hipLaunchKernelGGL((k_lr_tpanels<C, false>), grid, dim3(256), 0, ctx->stream, Xt, ldx, p, n, Z0, Q, rk, T, tstride, den0); } while (0)
+    hipLaunchKernelGGL((k_lr_tpanels<C, true>), grid, dim3(256), lds, ctx->stream, Xt, ldx, p, n, Z0, Q, rk, T, tstride, den0, nchunk, qstride); \
+  } else hipLaunchKernelGGL((k_lr_tpanels<C, false>), grid, dim3(256), 0, ctx->stream, Xt, ldx, p, n, Z0, Q, rk, T, tstride, den0, nchunk, qstride); } while (0)
   switch (c) {
     case 1: TP(1); break;
     case 2: TP(2); break;
@@ -800,7 +841,7 @@ __global__ void __launch_bounds__(256) k_lr_panels_w(NullModel nm, const double*
                                                      int64_t col0, int64_t ncol, const int64_t* __restrict__ counts, int nbatch, int hiprio,
                                                      double* __restrict__ P0,
                                                      double* __restrict__ Cp, double* __restrict__ Ls, int64_t ldp,
-                                                     int64_t* stat) {
+                                                     int64_t* stat, const int64_t* __restrict__ segcnt, int nseg, int64_t qstride) {
 #ifdef PW_DIAG
   if (threadIdx.x == 0 && blockIdx.x < 8192) g_pw_diag[3 * blockIdx.x] = __builtin_amdgcn_s_memrealtime();
 #endif
@@ -812,6 +853,12 @@ __global__ void __launch_bounds__(256) k_lr_panels_w(NullModel nm, const double*
   double* sLam = sh;
   double* sZ = sh + n;
   double* sQ = sZ + n * C;                     // min(R, qcap) x n : basis rows (the rest is read from L2)
+  // the workgroup's columns (16 consecutive ones, nbatch = 1 whenever there are several segments) lie in ONE segment's run: its basis
+  if (nseg > 1) {
+    const int64_t jc0 = col0 + (int64_t)blockIdx.x * nbatch * (256 / LPT);
+    const int sgi = lr_seg_of(col0 + ncol - 1 - jc0, segcnt, nseg);
+    Q += (int64_t)sgi * qstride; rk += 4 * sgi;
+  }
   const int R = rk[0], R4 = rk[1] * 4;
   const int rl = R < qcap ? R : qcap;
   for (int e = threadIdx.x; e < n; e += blockDim.x) sLam[e] = lam[e];
@@ -1031,8 +1078,14 @@ __global__ void __launch_bounds__(256) k_lr_resid(int n, int64_t m, const double
                                                   const int* __restrict__ rk, const int* __restrict__ perm, int64_t col0,
                                                   int64_t ncol, const int64_t* __restrict__ counts,
                                                   const double* __restrict__ Cp, int64_t ldp,
-                                                  double* __restrict__ part /* [nslice][2][ldp] */) {
+                                                  double* __restrict__ part /* [nslice][2][ldp] */, const int64_t* __restrict__ segcnt,
+                                                  int nseg, int64_t qstride) {
   extern __shared__ __attribute__((aligned(16))) double sh[];
+  // several segments: blocks of LR_TILE columns (one tile of the scan = one segment = one basis)
+  if (nseg > 1) {
+    const int sgi = lr_seg_of(ncol - 1 - (int64_t)blockIdx.x * blockDim.x, segcnt, nseg);
+    Q += (int64_t)sgi * qstride; rk += 4 * sgi;
+  }
   const int R = rk[0];
   if (R < 0) return;                       // the basis kernel gave up: the call fails as a whole (stat[8] < 0)
   const int k0 = blockIdx.y * LRR_KS, kc = (n - k0 < LRR_KS) ? (n - k0) : LRR_KS;
@@ -1191,85 +1244,90 @@ __global__ void __launch_bounds__(256) k_scan_fix(NullModel nm, const double* __
 // column it sits in.  The panel arrays hold two such regions (LrRegion): the traits k_brent finished, and the ones
 // k_brent2 finishes while the first region is already being scanned.
 // ------------------------------------------------------------------------------------------------
+// Two passes (MODE 0: count, MODE 1: place), one trait per thread.  Class 0 = shared weights, class 1 + s = segment s of the
+// heritability axis (LrSeg).  Per wave and class ONE atomic (lane c adds the wave's count of class c: nine addresses in a single
+// instruction).  Pass 0 -> counts[0], segcnt[s]; pass 1 places: the shared class from the front of the region, segment s from
+// the back behind the runs of the segments before it, every run rounded up to LR_TILE columns (cursors: segcnt[8 + class]);
+// counts[1] = the sum of the rounded runs (what the scan's tile arithmetic needs).
+template <int MODE>
 __global__ void __launch_bounds__(256) k_lr_classify(int n, int64_t m, double tol, const double* __restrict__ lam,
                                                      const double* __restrict__ h2v, const int* __restrict__ fin,
                                                      const int* __restrict__ list, const unsigned int* __restrict__ list_cnt,
                                                      int* __restrict__ perm, int64_t col0, int64_t ldq,
-                                                     int64_t* __restrict__ counts) {
+                                                     int64_t* __restrict__ counts, int64_t* __restrict__ segcnt, LrSeg seg) {
   // The traits of this pass: list[0 .. *list_cnt) when a list is given (the traits k_brent2 finished), otherwise every
   // trait j < m with fin[j] == 1 (fin == nullptr: all of them).  Its panel columns are [col0, col0 + ldq).
   __shared__ double s_red[4];
-  __shared__ int s_cnt[4];
-  __shared__ long long s_base[2];
-  const int t = threadIdx.x;
+  const int t = threadIdx.x, lane = t & 63;
   const int64_t E = list ? (int64_t)*list_cnt : m;
-  if ((int64_t)blockIdx.x * 1024 >= E) return;              // workgroup-uniform
+  if (MODE == 1 && blockIdx.x == 0 && t == 0) {
+    int64_t tot = 0;
+    for (int s = 0; s < seg.S; ++s) tot += lr_seg_width(segcnt[s]);
+    counts[1] = tot;
+  }
+  if ((int64_t)blockIdx.x * 256 >= E) return;               // workgroup-uniform
   double s2 = 0.0;
   for (int k = t; k < n; k += 256) s2 = fma(lam[k], lam[k], s2);
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) s2 += __shfl_xor(s2, o, 64);
-  if ((t & 63) == 0) s_red[t >> 6] = s2;
+  if (lane == 0) s_red[t >> 6] = s2;
   __syncthreads();
   const double rms = sqrt((s_red[0] + s_red[1] + s_red[2] + s_red[3]) / (double)n);
   const double thr = (tol > 0.0) ? ((rms > 0.0) ? tol / rms : INFINITY) : 0.0;
-  const int64_t e0 = (int64_t)blockIdx.x * 1024 + 4 * t;
-  int64_t jt[4];
-  bool inc[4], f[4];
-  int cs = 0, co = 0;
-#pragma unroll
-  for (int u = 0; u < 4; ++u) {
-    inc[u] = false; f[u] = false; jt[u] = 0;
-    if (e0 + u < E) {
-      jt[u] = list ? (int64_t)list[e0 + u] : e0 + u;
-      inc[u] = list ? true : (fin ? fin[jt[u]] == 1 : true);
-      if (inc[u]) {
-        const double h2 = h2v[jt[u]];
-        f[u] = fabs(h2 / (1.0 - h2)) <= thr;    // false for NaN
+  const int64_t e = (int64_t)blockIdx.x * 256 + t;
+  int cls = -1;
+  int64_t jt = 0;
+  if (e < E) {
+    jt = list ? (int64_t)list[e] : e;
+    const bool inc = list ? true : (fin ? fin[jt] == 1 : true);
+    if (inc) {
+      const double h2 = h2v[jt];
+      if (fabs(h2 / (1.0 - h2)) <= thr) cls = 0;            // false for NaN
+      else {
+        int sg = 0;
+        while (sg + 1 < seg.S && !(h2 < seg.edge[sg + 1])) ++sg;   // NaN: the last segment (its expansion fails the guard)
+        cls = 1 + sg;
       }
     }
-    cs += (inc[u] && f[u]) ? 1 : 0;
-    co += (inc[u] && !f[u]) ? 1 : 0;
   }
-  const int mine = cs | (co << 16);             // both counts in one scan (<= 1024 each)
-  int incl = mine;
-#pragma unroll
-  for (int o = 1; o < 64; o <<= 1) {
-    const int v = __shfl_up(incl, o, 64);
-    if ((t & 63) >= o) incl += v;
+  // the wave's count per class, and this lane's rank inside its class
+  int mycount = 0, myrank = 0;
+  const unsigned long long below = (1ull << lane) - 1ull;
+  for (int c = 0; c <= seg.S; ++c) {
+    const unsigned long long mask = __ballot(cls == c);
+    if (lane == c) mycount = __popcll(mask);
+    if (cls == c) myrank = __popcll(mask & below);
   }
-  if ((t & 63) == 63) s_cnt[t >> 6] = incl;
-  __syncthreads();
-  int before = incl - mine;
-  for (int w = 0; w < (t >> 6); ++w) before += s_cnt[w];
-  const int total = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
-  if (t == 0) {
-    s_base[0] = (long long)atomicAdd((unsigned long long*)&counts[0], (unsigned long long)(total & 0xffff));
-    s_base[1] = (long long)atomicAdd((unsigned long long*)&counts[1], (unsigned long long)(total >> 16));
+  long long base = 0;
+  if (lane <= seg.S && mycount > 0) {
+    int64_t* dst = (MODE == 0) ? (lane == 0 ? &counts[0] : &segcnt[lane - 1]) : &segcnt[8 + lane];
+    base = (long long)atomicAdd((unsigned long long*)dst, (unsigned long long)mycount);
   }
-  __syncthreads();
-  int64_t bpos = s_base[0] + (before & 0xffff);
-  int64_t opos = s_base[1] + (before >> 16);
-#pragma unroll
-  for (int u = 0; u < 4; ++u) {
-    if (inc[u]) {
-      if (f[u]) perm[col0 + bpos++] = (int)jt[u];
-      else perm[col0 + ldq - 1 - (opos++)] = (int)jt[u];
+  if (MODE == 1) {
+    const long long b = __shfl(base, cls < 0 ? 0 : cls, 64);
+    if (cls == 0) perm[col0 + b + myrank] = (int)jt;
+    else if (cls > 0) {
+      int64_t off = 0;
+      for (int s = 0; s + 1 < cls; ++s) off += lr_seg_width(segcnt[s]);
+      perm[col0 + ldq - 1 - off - (b + myrank)] = (int)jt;
     }
   }
 }
 
 int launch_lr_classify(blmm_ctx* ctx, int n, int64_t m, double tol, const double* lam, const double* h2, const int* fin,
-                       const int* list, const unsigned int* list_cnt, int* perm, const LrRegion& rg) {
+                       const int* list, const unsigned int* list_cnt, int* perm, const LrRegion& rg, const LrSeg& seg) {
   if (m > 0x7ffffff0LL) return fail(ctx, BLMM_ERR_INVALID, "too many traits for one launch");
   if (m <= 0) return BLMM_OK;
-  hipLaunchKernelGGL(k_lr_classify, dim3((unsigned)((m + 1023) / 1024)), dim3(256), 0, ctx->stream, n, m, tol, lam, h2, fin, list,
-                     list_cnt, perm, rg.col0, rg.ncol, rg.counts);
+  hipLaunchKernelGGL(k_lr_classify<0>, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, ctx->stream, n, m, tol, lam, h2, fin, list,
+                     list_cnt, perm, rg.col0, rg.ncol, rg.counts, rg.segcnt, seg);
+  hipLaunchKernelGGL(k_lr_classify<1>, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, ctx->stream, n, m, tol, lam, h2, fin, list,
+                     list_cnt, perm, rg.col0, rg.ncol, rg.counts, rg.segcnt, seg);
   KCHECK();
   return BLMM_OK;
 }
 
 int launch_lr_panels(blmm_ctx* ctx, const NullModel& nm, const double* Yt, int64_t ldy, int64_t m, const double* Z0,
-                     const double* lam, const double* h2, const double* Q, const int* rk, const int* perm, const LrRegion& rg,
+                     const double* lam, const double* h2, const double* Q, const int* rk, const LrSeg& seg, const int* perm, const LrRegion& rg,
                      double* P0, double* Cp, double* Ls, int64_t ldp, int64_t* stat) {
   // basis rows in LDS up to 56 KB, staged by every block: 64 threads per block give more blocks than CUs at m ~ 35k, 128
   // halve the staging per trait (BLMM_LR_PANELS_NT: A/B testing)
@@ -1282,7 +1340,7 @@ int launch_lr_panels(blmm_ctx* ctx, const NullModel& nm, const double* Yt, int64
     static const int nb_env = getenv("BLMM_LR_PANELS_BATCH") ? atoi(getenv("BLMM_LR_PANELS_BATCH")) : 0;
     const int ncu = ctx->num_cus > 0 ? ctx->num_cus : 256;
     (void)ncu;
-    const int nbatch = nb_env > 0 ? nb_env : 1;   // BXD shape, prep phase: 0.109 ms at 1, 0.106 at 2, 0.113 at 4, 0.164 at 8
+    const int nbatch = (nb_env > 0 && seg.S == 1) ? nb_env : 1;   // BXD shape, prep phase: 0.109 ms at 1, 0.106 at 2, 0.113 at 4, 0.164 at 8
     const unsigned wblocks = (unsigned)((wgroups + nbatch - 1) / nbatch);
     const int hiprio = (ctx->stream != ctx->side && ctx->stream != ctx->side2) ? 1 : 0;   // main stream = critical path
     const size_t wbase = sizeof(double) * (size_t)nm.n * (1 + nm.c);
@@ -1293,7 +1351,7 @@ int launch_lr_panels(blmm_ctx* ctx, const NullModel& nm, const double* Yt, int64
     const int wqcap = (wbase + sizeof(double) * nm.n <= 60 * 1024) ? (int)std::min<size_t>(std::min<size_t>((size_t)nm.n, qrows), (60 * 1024 - wbase) / (sizeof(double) * (size_t)nm.n)) : 0;
     const size_t wlds = wbase + sizeof(double) * (size_t)wqcap * nm.n;
 #define LPW(C) do { if (wlds > 48 * 1024) BLMM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_lr_panels_w<C, LPT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)wlds)); \
-    hipLaunchKernelGGL((k_lr_panels_w<C, LPT>), dim3(wblocks), dim3(256), wlds, ctx->stream, nm, Yt, ldy, m, Z0, lam, h2, Q, rk, wqcap, perm, rg.col0, rg.ncol, rg.counts, nbatch, hiprio, P0, Cp, Ls, ldp, stat); } while (0)
+    hipLaunchKernelGGL((k_lr_panels_w<C, LPT>), dim3(wblocks), dim3(256), wlds, ctx->stream, nm, Yt, ldy, m, Z0, lam, h2, Q, rk, wqcap, perm, rg.col0, rg.ncol, rg.counts, nbatch, hiprio, P0, Cp, Ls, ldp, stat, rg.segcnt, seg.S, (int64_t)nm.npad * nm.n); } while (0)
     switch (nm.c) {
       case 1: LPW(1); break;
       case 2: LPW(2); break;
@@ -1320,6 +1378,7 @@ int launch_lr_panels(blmm_ctx* ctx, const NullModel& nm, const double* Yt, int64
     KCHECK();
     return BLMM_OK;
   }
+  if (seg.S != 1) return fail(ctx, BLMM_ERR_INVALID, "launch_lr_panels: the one-thread-per-trait kernel takes a single weight basis");
   static const int nt_env = getenv("BLMM_LR_PANELS_NT") ? atoi(getenv("BLMM_LR_PANELS_NT")) : 0;
   const int nthr = (nt_env == 64 || nt_env == 128 || nt_env == 256) ? nt_env : 64;
   const unsigned blocks = (unsigned)((rg.ncol + nthr - 1) / nthr);
@@ -1340,15 +1399,16 @@ int launch_lr_panels(blmm_ctx* ctx, const NullModel& nm, const double* Yt, int64
 
 // The guard (all traits): the caller runs it on the side stream beside the scan kernel, then launch_scan_fix.
 int launch_lr_resid(blmm_ctx* ctx, const NullModel& nm, int64_t m, double tol, const double* lam, const double* h2,
-                    const double* Q, const int* rk, const int* perm, const LrRegion& rg, const double* Cp, int64_t ldp,
+                    const double* Q, const int* rk, const LrSeg& seg, const int* perm, const LrRegion& rg, const double* Cp, int64_t ldp,
                     int* flag_list, double* part, int64_t* stat) {
   if (m <= 0) return BLMM_OK;
   const int nslice = (nm.n + LRR_KS - 1) / LRR_KS;
   const size_t lds = sizeof(double) * ((size_t)LRR_KS * (1 + (size_t)LRR_QC));
   if (lds > 48 * 1024)
     BLMM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_lr_resid), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  hipLaunchKernelGGL(k_lr_resid, dim3((unsigned)((rg.ncol + 255) / 256), (unsigned)nslice), dim3(256), lds, ctx->stream, nm.n, m, lam, h2, Q,
-                     rk, perm, rg.col0, rg.ncol, rg.counts, Cp, ldp, part);
+  const int rthreads = seg.S > 1 ? LR_TILE : 256;
+  hipLaunchKernelGGL(k_lr_resid, dim3((unsigned)((rg.ncol + rthreads - 1) / rthreads), (unsigned)nslice), dim3(rthreads), lds, ctx->stream, nm.n, m, lam, h2, Q,
+                     rk, perm, rg.col0, rg.ncol, rg.counts, Cp, ldp, part, rg.segcnt, seg.S, (int64_t)nm.npad * nm.n);
   hipLaunchKernelGGL(k_lr_resid2, dim3((unsigned)((rg.ncol + 255) / 256)), dim3(256), 0, ctx->stream, nslice, m, tol * tol, part, ldp, rk,
                      perm, rg.col0, rg.ncol, rg.counts, flag_list, stat);
   KCHECK();

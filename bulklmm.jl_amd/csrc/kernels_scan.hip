@@ -484,7 +484,11 @@ __global__ void __launch_bounds__(256, 2) k_scan_lr(LrArgs la, int ntile_i, int6
   const double* PA = a.P + (int64_t)tile_t * TW;
   const double* PB = a.Xt + (int64_t)tile_i * (32 * NB);
   const double* PC = la.Cp + (int64_t)tile_t * TW;
-  const double* PT = la.T + (int64_t)tile_i * (32 * NB);
+  // the tile's segment of the heritability axis (its own basis: rank and marker-side products); runs are laid out from the region's end
+  int sgi = 0;
+  if (la.seg.S > 1 && !shared_w)
+    sgi = lr_seg_of(la.rg.ncol - 1 - ((int64_t)tile_t * TW - la.rg.col0), la.rg.segcnt, la.seg.S);
+  const double* PT = la.T + (int64_t)sgi * (1 + C) * la.tstride + (int64_t)tile_i * (32 * NB);
   const uint32_t voffA = (uint32_t)(((int64_t)kk * a.ldp + wt * (16 * MB) + MB * r) * 8);
   const uint32_t voffB = (uint32_t)(((int64_t)kk * a.ldx + wi * (16 * NB)) * 8) + mvoff<NB>(r);
   const int64_t sa = 4 * a.ldp, sb = 4 * a.ldx;
@@ -544,7 +548,7 @@ __global__ void __launch_bounds__(256, 2) k_scan_lr(LrArgs la, int ntile_i, int6
           acc[1 + q][mb][nb] = __builtin_amdgcn_mfma_f64_16x16x4f64(A[mb], B[q][nb], acc[1 + q][mb][nb], 0, 0, 0);
   };
   const int K2 = a.ks / 2;
-  const int KR = shared_w ? 0 : la.rk[1];
+  const int KR = shared_w ? 0 : la.rk[4 * sgi + 1];
   double c0[MB], d0[1 + C][NB];
   {
     double a0[2][MB], b0[2][NB], a1[2][MB], b1[2][NB];

@@ -129,6 +129,11 @@ int blmm_set_stream(blmm_ctx* ctx, void* hip_stream);
 int blmm_set_timing(blmm_ctx* ctx, int on);
 /* sums_ms[6] = {eigen, rotate, h2, prep, scan, total}; *ncalls = calls accumulated. */
 int blmm_read_timings(blmm_ctx* ctx, double* sums_ms, int64_t* ncalls);
+/* What the last null-exact call EXECUTED in its low-rank weights form (kernels_lowrank.hip; it synchronises the stream):
+ * out[18] = {segments of the heritability axis with traits, traits of the shared-weights class (no basis: 2 n flop per test),
+ * then per segment s: traits, rank R_s of its weight basis (2 (n + (1 + c) 4 ceil(R_s / 4)) flop per test)}.  A diagnostic for
+ * benchmarks that price the executed arithmetic (bench.py); the reference has no counterpart. */
+int blmm_lowrank_profile(blmm_ctx* ctx, int64_t* out);
 int blmm_synchronize(blmm_ctx* ctx);
 void blmm_default_opts(blmm_opts* o); /* bulkscan() defaults: null-grid, ML, prior (1.0, 0.0), eigen */
 

@@ -169,3 +169,30 @@ def test_shared_weights_class_extremes(blmm, h2val, m):
     h2 = np.full(m, 0.0 if h2val is None else h2val)
     got = blmm.liteqtl_given_h2(Y0, X0, lam, h2)
     assert_lod_close(got, oracle_given_h2(Y0, X0, lam, h2))
+
+
+@pytest.mark.parametrize("segments", ["default", "2", "8"])
+def test_segmented_weight_basis_equals_the_single_basis(blmm, segments, monkeypatch):
+    """The heritability axis is cut into segments with one weight basis each (kernels_lowrank.hip, LrSeg: rank 11-12 per segment on
+    the BXD spectrum against 23 for the whole family, so the rank-R phase of k_scan_lr runs half the K steps).  Same h2 (the search
+    does not see the basis), LODs equal to the single-basis form's to rounding, the guard flags nothing, and the profile of what
+    was executed (blmm_lowrank_profile) shows several segments of lower rank whose traits add up."""
+    Y, G, K, _ = make_data(n=79, p=300, m=2500, seed=8101, bxd=True)
+    ctx = blmm.Context(0)
+    monkeypatch.setenv("BLMM_LR_SEGMENTS", "1")
+    one = blmm.bulkscan_null(Y, G, K, ctx=ctx)
+    shared1, prof1 = ctx.lowrank_profile()
+    assert len(prof1) == 1
+    if segments == "default":
+        monkeypatch.delenv("BLMM_LR_SEGMENTS")
+    else:
+        monkeypatch.setenv("BLMM_LR_SEGMENTS", segments)
+    seg = blmm.bulkscan_null(Y, G, K, ctx=ctx)
+    shared, prof = ctx.lowrank_profile()
+    assert np.array_equal(seg.h2_null_list, one.h2_null_list)
+    assert np.abs(seg.L - one.L).max() <= 1e-11 * max(1.0, np.abs(one.L).max())
+    assert shared == shared1 and shared + sum(c for c, _ in prof) == Y.shape[1]
+    assert len([1 for c, _ in prof if c > 0]) >= 2 and max(r for _, r in prof) < prof1[0][1]
+    check = O.bulkscan_null(Y[:, :40], G, K, h2_override=seg.h2_null_list[:40])
+    assert_lod_close(seg.L[:, :40], check.L)
+    ctx.close()
