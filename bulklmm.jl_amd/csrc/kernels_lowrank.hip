@@ -10,6 +10,10 @@
 // R is found on the device by a greedy pivoted Gram-Schmidt over 256 sampled deltas (stops at a 1e-15 relative
 // residual, or at R = n where the form is exact by construction), so one code path serves every kinship; the
 // per-trait approximation residual is reported in blmm_status.lowrank_resid.
+// The rank of the family over a SEGMENT of the heritability axis is about half that of the whole family (BXD: 11-12 for each of
+// six segments), so for n <= 80 the traits of the rank-R class are grouped by segment (LrSeg; k_lr_classify lays a region's
+// columns out class by class, segment by segment, tile aligned), every segment has its own Q, T and rank, and a tile of the scan
+// kernel runs ceil(R_s / 4) = 3 K steps per accumulator where the single basis needs 6.
 #include "blmm_internal.h"
 #include <vector>
 #include <algorithm>
