@@ -9,6 +9,14 @@
 #include <cstdint>
 #include <cstddef>
 
+// function qualifiers of the inline helpers in blmm_internal.h
+#ifndef __host__
+#define __host__
+#endif
+#ifndef __device__
+#define __device__
+#endif
+
 typedef int hipError_t;
 enum { hipSuccess = 0, hipErrorInvalidValue = 1 };
 typedef struct stub_stream* hipStream_t;
