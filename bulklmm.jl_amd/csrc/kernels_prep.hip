@@ -1289,7 +1289,13 @@ __device__ __forceinline__ EllOut null_ell_reg(double h2, const NullRegs<C, LPT>
 }
 
 constexpr int BRENT_LPT = 4;
-constexpr int BRENT_PHASE1 = 26;   // iterations before the unfinished traits of a workgroup are repacked (k_brent)
+#ifndef BRENT_PHASE1_IT
+// build knob (tools/brent_phase1.sh).  26 (rounds 2-3a) kept every trait that converges in the interior in the first kernel; at 20 the
+// slowest of them join the boundary traits in k_brent2 (which runs beside the scan of the first region) and the scan starts 20 us
+// earlier: step 1.704-1.715 ms against 1.716-1.755 at 26, 1.708-1.722 at 22, 1.718-1.746 at 18, 1.703-1.725 at 16 (one box, two runs each)
+#define BRENT_PHASE1_IT 20
+#endif
+constexpr int BRENT_PHASE1 = BRENT_PHASE1_IT;   // iterations before the unfinished traits of a workgroup are repacked (k_brent)
 
 // Optim.jl Brent() restated (third-party; see oracle/bulklmm_oracle.py:brent_optim and SURVEY.md A.3) on the
 // gridbrent sub-intervals (src/gridbrent.jl:9-24).  Every lane of the wave runs the same number of function
