@@ -277,7 +277,11 @@ int prepare_eigen(blmm_ctx* ctx, const blmm_opts* o, int64_t n, const double* dC
 
 // null-exact, low-rank weights form: the basis of the weight family needs only the sorted eigenvalues, so it starts on the side
 // stream right behind the eigen-decomposition, beside the rotation and the Brent search (joined before k_lr_panels)
-int start_wbasis(blmm_ctx* ctx, const Pipe& P) {
+int rotate_markers(blmm_ctx* ctx, Pipe& P, const double* dG, int64_t p);
+// dG != nullptr: the marker rotation goes to the side stream as well, in front of the basis (the h2 search on the main stream needs
+// only the rotated traits; the marker-side products that follow the basis on the side stream and -- behind ev_join -- the scan
+// need Xt): 12 us less in front of k_brent at the BXD shape
+int start_wbasis(blmm_ctx* ctx, Pipe& P, const double* dG = nullptr, int64_t p = 0) {
   int rc;
   const int64_t n = P.n;
   const LrSeg seg = lr_segments(P.n);
@@ -288,7 +292,8 @@ int start_wbasis(blmm_ctx* ctx, const Pipe& P) {
   BLMM_HIP(hipEventRecord(ctx->ev_xt, main_stream));
   BLMM_HIP(hipStreamWaitEvent(ctx->side, ctx->ev_xt, 0));
   ctx->stream = ctx->side;                                           // the launchers enqueue on ctx->stream
-  rc = launch_wbasis(ctx, P.lam, (int)n, P.npad, seg, ptr<double>(ctx->wbW), ptr<double>(ctx->wbQ), ptr<int>(ctx->wbRk), P.stat);
+  rc = dG ? rotate_markers(ctx, P, dG, p) : BLMM_OK;
+  if (!rc) rc = launch_wbasis(ctx, P.lam, (int)n, P.npad, seg, ptr<double>(ctx->wbW), ptr<double>(ctx->wbQ), ptr<int>(ctx->wbRk), P.stat);
   ctx->stream = main_stream;
   return rc;
 }
@@ -320,9 +325,14 @@ int prepare(blmm_ctx* ctx, const blmm_opts* o, const double* dY, int64_t n, int6
   if (m < 0 || p < 0) return fail(ctx, BLMM_ERR_DIM, "Dimension mismatch.");
   int rc = prepare_eigen(ctx, o, n, dCovar, ncov, dK, dweights, centered, P, tm);
   if (rc) return rc;
-  if (early_wbasis && m > 0 && p > 0 && (rc = start_wbasis(ctx, P))) return rc;
+  // (BLMM_ROTATE_SIDE=0: the marker rotation stays on the main stream behind the traits' -- A/B testing)
+  static const bool rot_side = !(getenv("BLMM_ROTATE_SIDE") && getenv("BLMM_ROTATE_SIDE")[0] == '0');
+  // only where the rotation is the small latency-bound kernel (n <= 160): the GEMM of larger n fills the chip by itself, and behind it
+  // the basis and the marker-side products come later (n = 500 shard: 6.32 against 6.29 ms; BXD: 1.714 against 1.734 ms, 4 A/B rounds)
+  const bool side_g = early_wbasis && m > 0 && p > 0 && rot_side && n <= 160;
+  if (early_wbasis && m > 0 && p > 0 && (rc = start_wbasis(ctx, P, side_g ? dG : nullptr, p))) return rc;
   if ((rc = rotate_traits(ctx, P, dY, m))) return rc;
-  if ((rc = rotate_markers(ctx, P, dG, p))) return rc;
+  if (!side_g && (rc = rotate_markers(ctx, P, dG, p))) return rc;
   tm.mark();
   return BLMM_OK;
 }
