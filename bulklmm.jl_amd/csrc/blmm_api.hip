@@ -331,6 +331,7 @@ int prepare(blmm_ctx* ctx, const blmm_opts* o, const double* dY, int64_t n, int6
   // the basis and the marker-side products come later (n = 500 shard: 6.32 against 6.29 ms; BXD: 1.714 against 1.734 ms, 4 A/B rounds)
   const bool side_g = early_wbasis && m > 0 && p > 0 && rot_side && n <= 160;
   if (early_wbasis && m > 0 && p > 0 && (rc = start_wbasis(ctx, P, side_g ? dG : nullptr, p))) return rc;
+  P.xt_side = side_g;
   if ((rc = rotate_traits(ctx, P, dY, m))) return rc;
   if (!side_g && (rc = rotate_markers(ctx, P, dG, p))) return rc;
   tm.mark();
@@ -410,8 +411,10 @@ int lr_begin(blmm_ctx* ctx, const Pipe& P, bool wbasis_started) {
   if ((rc = ensure(ctx, ctx->wbRk, sizeof(int) * 4 * LR_SEG_MAX))) return rc;
   int* rk = ptr<int>(ctx->wbRk);
   hipStream_t main_stream = ctx->stream;
-  BLMM_HIP(hipEventRecord(ctx->ev_fork, main_stream));            // rotated operands are ready
-  BLMM_HIP(hipStreamWaitEvent(ctx->side, ctx->ev_fork, 0));
+  if (!(wbasis_started && P.xt_side)) {                            // (the side stream rotated the markers itself: nothing of the main stream to wait for)
+    BLMM_HIP(hipEventRecord(ctx->ev_fork, main_stream));          // rotated operands are ready
+    BLMM_HIP(hipStreamWaitEvent(ctx->side, ctx->ev_fork, 0));
+  }
   ctx->stream = ctx->side;                                         // the launchers enqueue on ctx->stream
   rc = BLMM_OK;
   if (!wbasis_started) rc = launch_wbasis(ctx, P.lam, P.n, P.npad, seg, ptr<double>(ctx->wbW), ptr<double>(ctx->wbQ), rk, P.stat);
@@ -421,11 +424,7 @@ int lr_begin(blmm_ctx* ctx, const Pipe& P, bool wbasis_started) {
   ctx->stream = main_stream;
   if (rc) return rc;
   BLMM_HIP(hipEventRecord(ctx->ev_join, ctx->side));                // ... and what the scan needs on top
-  // the column order's preset (-1 = padding) on the second side stream, idle until the h2 search forks: the classification
-  // needs nothing else from the side work
-  BLMM_HIP(hipStreamWaitEvent(ctx->side2, ctx->ev_fork, 0));
-  BLMM_HIP(hipMemsetAsync(ctx->lrPerm.p, 0xff, sizeof(int) * (size_t)ldp, ctx->side2));
-  BLMM_HIP(hipEventRecord(ctx->ev_m, ctx->side2));
+  // (the column order's preset, -1 = padding, is written by the count pass of k_lr_classify)
   return BLMM_OK;
 }
 
@@ -499,7 +498,6 @@ int lr_finish(blmm_ctx* ctx, const Pipe& P, const NullModel& nm, const double* d
   const LrSeg seg = lr_segments(P.n);
   hipStream_t main_stream = ctx->stream;
   BLMM_HIP(hipStreamWaitEvent(main_stream, ctx->ev_join, 0));
-  BLMM_HIP(hipStreamWaitEvent(main_stream, ctx->ev_m, 0));
   if ((rc = launch_lr_classify(ctx, P.n, P.m, lr_shared_tol(), P.lam, dh2, nullptr, nullptr, nullptr, ptr<int>(ctx->lrPerm), rg, seg))) return rc;
   if ((rc = lr_region_panels(ctx, P, nm, dh2, rg))) return rc;
   tm.mark();
@@ -528,9 +526,7 @@ int lr_finish_split(blmm_ctx* ctx, const Pipe& P, const NullModel& nm, double* d
   const LrRegion r0 = lr_region(P, 0), r1 = lr_region(P, 1);
   const LrSeg seg = lr_segments(P.n);
   hipStream_t main_stream = ctx->stream;
-  // ---- main stream: region 0's classification and panels (the perm preset is ready at ev_m, the weight basis at ev_q, the
-  //      marker-side products at ev_join) ...
-  BLMM_HIP(hipStreamWaitEvent(main_stream, ctx->ev_m, 0));
+  // ---- main stream: region 0's classification and panels (the weight basis is ready at ev_q, the marker-side products at ev_join) ...
   if ((rc = launch_lr_classify(ctx, P.n, P.m, lr_shared_tol(), P.lam, dh2, sp.fin, nullptr, nullptr, ptr<int>(ctx->lrPerm), r0, seg))) return rc;
   BLMM_HIP(hipStreamWaitEvent(main_stream, ctx->ev_q, 0));
   if ((rc = lr_region_panels(ctx, P, nm, dh2, r0))) return rc;
@@ -550,8 +546,7 @@ int lr_finish_split(blmm_ctx* ctx, const Pipe& P, const NullModel& nm, double* d
   BLMM_HIP(hipEventRecord(ctx->ev_b2, ctx->side2));
   tm.mark();
   BLMM_HIP(hipStreamWaitEvent(main_stream, ctx->ev_join, 0));
-  BLMM_HIP(hipEventRecord(ctx->ev_fork, main_stream));
-  BLMM_HIP(hipStreamWaitEvent(ctx->side, ctx->ev_fork, 0));
+  BLMM_HIP(hipStreamWaitEvent(ctx->side, ctx->ev_b1, 0));            // region 0's panels are done (the same point the second side stream forks at)
   ctx->stream = ctx->side;
   rc = lr_region_resid(ctx, P, nm, dh2, r0);
   ctx->stream = main_stream;

@@ -43,6 +43,7 @@ struct Pipe {
   double *Yt = nullptr, *Xt = nullptr, *Z0 = nullptr, *lam = nullptr;
   int64_t* stat = nullptr;
   bool big = false;                // n beyond the LDS Jacobi: the call ends with k_sticky
+  bool xt_side = false;            // the marker rotation was enqueued on the side stream (in front of the weight basis): Xt is ordered there
 };
 
 }  // namespace blmm

@@ -1264,6 +1264,10 @@ __global__ void __launch_bounds__(256) k_lr_classify(int n, int64_t m, double to
   __shared__ double s_red[4];
   const int t = threadIdx.x, lane = t & 63;
   const int64_t E = list ? (int64_t)*list_cnt : m;
+  // pass 0 also presets the region's column order to -1 = padding (every workgroup of the launch takes part, before any of them
+  // leaves): a fill on a side stream with its event pair on the main stream cost more than these stores
+  if (MODE == 0)
+    for (int64_t e = (int64_t)blockIdx.x * 256 + t; e < ldq; e += (int64_t)gridDim.x * 256) perm[col0 + e] = -1;
   if (MODE == 1 && blockIdx.x == 0 && t == 0) {
     int64_t tot = 0;
     for (int s = 0; s < seg.S; ++s) tot += lr_seg_width(segcnt[s]);
