@@ -149,6 +149,14 @@ function _last_log10p(dims, chisq_df::Int64)
     return P
 end
 
+# What the last null-exact call executed in its low-rank weights form (diagnostic; include/bulklmm_hip.h: blmm_lowrank_profile):
+# (traits of the shared-weights class, [(traits, rank) per segment of the heritability axis])
+function lowrank_profile()
+    out = zeros(Int64, 18)
+    GC.@preserve out check(ccall((:blmm_lowrank_profile, libblmm), Cint, (Ptr{Cvoid}, Ptr{Int64}), context(), out))
+    return (shared = out[2], segments = [(traits = out[3 + 2s], rank = out[4 + 2s]) for s in 0:(out[1] - 1)])
+end
+
 function lod2log10p(lod::Array{Float64}, df::Int64)
     P = similar(lod)
     (p, m) = ndims(lod) == 2 ? size(lod) : (length(lod), 1)
