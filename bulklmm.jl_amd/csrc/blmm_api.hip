@@ -321,7 +321,7 @@ int rotate_markers(blmm_ctx* ctx, Pipe& P, const double* dG, int64_t p) {
 
 int prepare(blmm_ctx* ctx, const blmm_opts* o, const double* dY, int64_t n, int64_t m, const double* dG, int64_t p,
             const double* dCovar, int64_t ncov, const double* dK, const double* dweights, int centered, Pipe& P, Timer& tm,
-            bool early_wbasis = false) {
+            bool early_wbasis = false, bool grid_side = false) {
   if (m < 0 || p < 0) return fail(ctx, BLMM_ERR_DIM, "Dimension mismatch.");
   int rc = prepare_eigen(ctx, o, n, dCovar, ncov, dK, dweights, centered, P, tm);
   if (rc) return rc;
@@ -332,8 +332,20 @@ int prepare(blmm_ctx* ctx, const blmm_opts* o, const double* dY, int64_t n, int6
   const bool side_g = early_wbasis && m > 0 && p > 0 && rot_side && n <= 160;
   if (early_wbasis && m > 0 && p > 0 && (rc = start_wbasis(ctx, P, side_g ? dG : nullptr, p))) return rc;
   P.xt_side = side_g;
+  // the grid methods (grid_side): the marker rotation and, later, the marker norms of every grid point (launch_isx) on the side stream,
+  // beside the traits' rotation, the grid log-likelihoods and the trait panels on the main stream; joined in front of the scan
+  if (grid_side && !early_wbasis && m > 0 && p > 0 && rot_side && n <= 160) {
+    hipStream_t main_stream = ctx->stream;
+    BLMM_HIP(hipEventRecord(ctx->ev_xt, main_stream));
+    BLMM_HIP(hipStreamWaitEvent(ctx->side, ctx->ev_xt, 0));
+    ctx->stream = ctx->side;
+    rc = rotate_markers(ctx, P, dG, p);
+    ctx->stream = main_stream;
+    if (rc) return rc;
+    P.xt_side = true;
+  }
   if ((rc = rotate_traits(ctx, P, dY, m))) return rc;
-  if (!side_g && (rc = rotate_markers(ctx, P, dG, p))) return rc;
+  if (!P.xt_side && (rc = rotate_markers(ctx, P, dG, p))) return rc;
   tm.mark();
   return BLMM_OK;
 }
@@ -889,6 +901,23 @@ struct PvCall {
 };
 }  // namespace
 
+// marker norms of every grid point; on the side stream behind the marker rotation when prepare() put that there (P.xt_side), then
+// joined into the main stream: the scan that follows needs both
+static int isx_maybe_side(blmm_ctx* ctx, const Pipe& P, const NullModel& nm, const double* dgrid, int ngrid) {
+  int rc;
+  if ((rc = ensure(ctx, ctx->isx, sizeof(double) * (size_t)ngrid * P.ldx))) return rc;
+  hipStream_t main_stream = ctx->stream;
+  if (P.xt_side) ctx->stream = ctx->side;
+  rc = launch_isx(ctx, nm, P.Xt, P.ldx, P.p, P.Z0, P.lam, dgrid, ngrid, ptr<double>(ctx->isx), P.ldx, P.stat);
+  ctx->stream = main_stream;
+  if (rc) return rc;
+  if (P.xt_side) {
+    BLMM_HIP(hipEventRecord(ctx->ev_join, ctx->side));
+    BLMM_HIP(hipStreamWaitEvent(main_stream, ctx->ev_join, 0));
+  }
+  return BLMM_OK;
+}
+
 static int scan_pipeline(blmm_ctx* ctx, const blmm_opts* opts, Pipe& P, Timer& tm, bool lowrank, bool wbasis_started, double* dgrid,
                          const double* h2_grid_host, int64_t ngrid, double* dL_out, int64_t ldL, double* dh2_out, blmm_status* status) {
   int rc;
@@ -950,8 +979,7 @@ static int scan_pipeline(blmm_ctx* ctx, const blmm_opts* opts, Pipe& P, Timer& t
     tm.mark();
     if ((rc = ensure(ctx, ctx->panels, sizeof(double) * (size_t)P.npad * ldp))) return rc;
     if ((rc = launch_panels(ctx, nm, P.Yt, P.ldy, m, P.Z0, P.lam, dh2_out, 0, ptr<double>(ctx->panels), ldp, P.stat))) return rc;
-    if ((rc = ensure(ctx, ctx->isx, sizeof(double) * (size_t)ngrid * P.ldx))) return rc;
-    if ((rc = launch_isx(ctx, nm, P.Xt, P.ldx, p, P.Z0, P.lam, dgrid, (int)ngrid, ptr<double>(ctx->isx), P.ldx, P.stat))) return rc;
+    if ((rc = isx_maybe_side(ctx, P, nm, dgrid, (int)ngrid))) return rc;
     tm.mark();
     ScanArgs a = scan_args(ctx, P, ptr<double>(ctx->panels), ldp, dL_out, ldL, m);
     a.isx = ptr<double>(ctx->isx); a.ld_isx = P.ldx; a.bin = ptr<int>(ctx->h2idx);
@@ -973,8 +1001,7 @@ static int scan_pipeline(blmm_ctx* ctx, const blmm_opts* opts, Pipe& P, Timer& t
                                 ptr<double>(ctx->panels) + (size_t)g * P.npad * ldp, ldp, P.stat))) return rc;
       }
     }
-    if ((rc = ensure(ctx, ctx->isx, sizeof(double) * (size_t)ngrid * P.ldx))) return rc;
-    if ((rc = launch_isx(ctx, nm, P.Xt, P.ldx, p, P.Z0, P.lam, dgrid, (int)ngrid, ptr<double>(ctx->isx), P.ldx, P.stat))) return rc;
+    if ((rc = isx_maybe_side(ctx, P, nm, dgrid, (int)ngrid))) return rc;
     tm.mark();
     AltArgs aa;
     aa.s = scan_args(ctx, P, ptr<double>(ctx->panels), ldp, dL_out, ldL, m);
@@ -1022,7 +1049,7 @@ int blmm_bulkscan_dev(blmm_ctx* ctx, const blmm_opts* opts, const double* dY, in
   const int c_eff = (int)((ncov == 0 || !dCovar) ? 1 : ncov + (opts->add_intercept ? 1 : 0));
   const bool lowrank = opts->method == BLMM_NULL_EXACT && !(exact_env && std::strcmp(exact_env, "full") == 0) &&
                        c_eff <= 3 && n <= 6000;
-  if ((rc = prepare(ctx, opts, dY, n, m, dG, p, dCovar, ncov, dK, dweights, 1, P, tm, lowrank))) return rc;
+  if ((rc = prepare(ctx, opts, dY, n, m, dG, p, dCovar, ncov, dK, dweights, 1, P, tm, lowrank, opts->method != BLMM_NULL_EXACT))) return rc;
   return scan_pipeline(ctx, opts, P, tm, lowrank, /*wbasis_started*/ lowrank && m > 0 && p > 0, dgrid, h2_grid_host, ngrid, dL_out, ldL, dh2_out, status);
 }
 
