@@ -721,6 +721,157 @@ __global__ void __launch_bounds__(256, 2) k_scan_lr(LrArgs la, int ntile_i, int6
 #endif
 }
 
+// ------------------------------------------------------------------------------------------------
+// k_scan_lr3: the rank-R tiles of k_scan_lr<1, 2, 4> at THREE waves per SIMD (the default for c = 1 without the p-value output and
+// with the shared-weights class in the table kernel; BLMM_LR3=0: k_scan_lr).  Phase 2 comes FIRST and in two halves over the wave's trait blocks: a half
+// accumulates Sxx and s for four 16 x 16 blocks (64 VGPRs), converts them to 1 / (Sxx - u^2) (32 VGPRs) and lets them go; then
+// phase 1 accumulates num (64 VGPRs) beside the 64 of the reciprocals -- 128 accumulator registers at the peak where k_scan_lr
+// holds 192 -- and the epilogue is r^2 = num^2 * that reciprocal.  Same arithmetic per output, same bits.
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256, 3) k_scan_lr3(LrArgs la, int ntile_i, int64_t nwg) {
+  const ScanArgs& a = la.s;
+  constexpr int MB = 2, NB = 4, TW = 64;
+  __shared__ dpair s_lod[BLMM_LOD_TABLE_N];
+  __shared__ double s_li[TW];
+  __shared__ int s_perm[TW];
+  LodStage<256> lst;
+  lod_stage_load<256>(lst, a.lodtab);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  uint32_t tile_t, tile_i;
+  {
+    const uint32_t q = (uint32_t)(nwg >> 3);
+    if (blockIdx.x >= (q << 3)) return;
+    const uint32_t x = blockIdx.x & 7, local = blockIdx.x >> 3;
+    const uint32_t noth = (uint32_t)la.rg.counts[1];
+    const uint32_t tb = (uint32_t)(la.rg.col0 / TW);
+    const uint32_t ncolt = (uint32_t)(la.rg.ncol / TW);
+    const uint32_t fo = ((uint32_t)la.rg.ncol - noth) / TW, nf = ncolt - fo;
+    const uint64_t NF = (uint64_t)nf * (uint32_t)ntile_i;
+    const uint32_t sF = (uint32_t)((x * NF) >> 3), cF = (uint32_t)(((x + 1) * NF) >> 3) - sF;
+    if (local >= cF) return;
+    tile_of32(sF + local, nf, (uint32_t)ntile_i, tile_t, tile_i);
+    tile_t += tb + fo;
+  }
+  double li_st = 0.0; int perm_st = -1;
+  if (threadIdx.x < TW) { li_st = la.Ls[(int64_t)tile_t * TW + threadIdx.x]; perm_st = la.perm[(int64_t)tile_t * TW + threadIdx.x]; }
+  const int wt = wave >> 1, wi = wave & 1;
+  const int64_t i0 = (int64_t)tile_i * (32 * NB) + wi * (16 * NB);
+  const int r = lane & 15, kk = lane >> 4;
+  const double* PA = a.P + (int64_t)tile_t * TW;
+  const double* PB = a.Xt + (int64_t)tile_i * (32 * NB);
+  const double* PC = la.Cp + (int64_t)tile_t * TW;
+  int sgi = 0;
+  if (la.seg.S > 1) sgi = lr_seg_of(la.rg.ncol - 1 - ((int64_t)tile_t * TW - la.rg.col0), la.rg.segcnt, la.seg.S);
+  const double* PT = la.T + (int64_t)sgi * 2 * la.tstride + (int64_t)tile_i * (32 * NB);
+  const uint32_t voffA = (uint32_t)(((int64_t)kk * a.ldp + wt * (16 * MB) + MB * r) * 8);
+  const uint32_t voffB = (uint32_t)(((int64_t)kk * a.ldx + wi * (16 * NB)) * 8) + mvoff<NB>(r);
+  const int64_t sa = 4 * a.ldp, sb = 4 * a.ldx;
+  const int KR = la.rk[4 * sgi + 1];
+  // first fragments of phase 2 on their way, then the staged tables to LDS
+  double c0[MB], d0[2][NB];
+  auto load2 = [&](double (&A)[MB], double (&B)[2][NB], int step) {
+    bufload<MB>(A, make_srd(PC + (int64_t)step * sa), voffA);
+#pragma unroll
+    for (int q = 0; q < 2; ++q) bufload_m<NB>(B[q], make_srd(PT + q * la.tstride + (int64_t)step * sb), voffB);
+  };
+  if (KR > 0) load2(c0, d0, 0);
+  __builtin_amdgcn_sched_barrier(0);
+  lod_stage_store<256>(lst, s_lod, a.lodc[0]);
+  if (threadIdx.x < TW) { s_li[threadIdx.x] = li_st; s_perm[threadIdx.x] = perm_st; }
+  __syncthreads();
+  d4 den[MB][NB];
+#pragma unroll
+  for (int mb = 0; mb < MB; ++mb) {
+    d4 sx[NB], ss[NB];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) { sx[nb] = (d4){0, 0, 0, 0}; ss[nb] = (d4){0, 0, 0, 0}; }
+    auto mf = [&](const double (&A)[MB], const double (&B)[2][NB]) {
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) {
+        sx[nb] = __builtin_amdgcn_mfma_f64_16x16x4f64(A[mb], B[0][nb], sx[nb], 0, 0, 0);
+        ss[nb] = __builtin_amdgcn_mfma_f64_16x16x4f64(A[mb], B[1][nb], ss[nb], 0, 0, 0);
+      }
+    };
+    // one fragment set: the next step's loads go out right behind the MFMAs that read this step's (the matrix pipe drains them
+    // for 8 x 64 cycles meanwhile, and two other waves share the SIMD)
+    for (int ks = 0; ks < KR; ++ks) {
+      __builtin_amdgcn_sched_barrier(0);
+      mf(c0, d0);
+      __builtin_amdgcn_sched_barrier(0);
+      if (ks + 1 < KR) load2(c0, d0, ks + 1);
+      else if (mb + 1 < MB) load2(c0, d0, 0);            // (the second half starts over at step 0)
+    }
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) {
+      const double li = s_li[wt * (16 * MB) + MB * (kk + 4 * reg) + mb];
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) {
+        const double u = fma(li, ss[nb][reg], 0.0);
+        den[mb][nb][reg] = fast_rcp1(fma(-u, u, sx[nb][reg]));
+      }
+    }
+    // pin the reciprocals HERE: left alone the compiler sinks the whole conversion into the epilogue, next to its uses, and keeps the
+    // 128 registers of Sxx and s alive through phase 1 (142 spilled dwords)
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) asm volatile("" : "+v"(den[mb][nb]));
+  }
+  // ---- phase 1: num over n, one K step per fragment set
+  d4 num[MB][NB];
+#pragma unroll
+  for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) num[mb][nb] = (d4){0, 0, 0, 0};
+  {
+    double a0[MB], b0[NB];
+    auto load1 = [&](double (&A)[MB], double (&B)[NB], int step) {
+      bufload<MB>(A, make_srd(PA + (int64_t)step * sa), voffA);
+      bufload_m<NB>(B, make_srd(PB + (int64_t)step * sb), voffB);
+    };
+    auto mf1 = [&](const double (&A)[MB], const double (&B)[NB]) {
+#pragma unroll
+      for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) num[mb][nb] = __builtin_amdgcn_mfma_f64_16x16x4f64(A[mb], B[nb], num[mb][nb], 0, 0, 0);
+    };
+    const int K = a.ks;
+    load1(a0, b0, 0);
+    for (int s1 = 0; s1 < K; ++s1) {
+      __builtin_amdgcn_sched_barrier(0);
+      mf1(a0, b0);
+      __builtin_amdgcn_sched_barrier(0);
+      if (s1 + 1 < K) load1(a0, b0, s1 + 1);
+    }
+  }
+  // ---- epilogue
+  const double scale = a.lodc[0];
+  const LodPoly5 lp = lod_poly5_of(a.lodc);
+  int nnan = 0;
+#pragma unroll
+  for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) {
+      const int64_t trait = s_perm[wt * (16 * MB) + MB * (kk + 4 * reg) + mb];
+      if (trait < 0) continue;
+      double uv[NB], out[NB];
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) {
+        const double nm = num[mb][nb][reg];
+        const double r2 = (nm * nm) * den[mb][nb][reg];   // (its own statement, as in k_scan_lr: -ffp-contract=on would fuse `1 - a * b` into one fma)
+        uv[nb] = 1.0 - r2;
+      }
+      bool ok = true;
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) { out[nb] = fast_lod5(uv[nb], s_lod, lp); ok = ok && lod_fast_ok(uv[nb]); }
+      if (__builtin_expect(!ok, 0)) {
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+          if (!lod_fast_ok(uv[nb])) out[nb] = lod_out_of_range(uv[nb], s_lod, lp, scale, i0 + mslot<NB>(r, nb) < a.p, &nnan);
+      }
+      store_m<NB>(a.L + trait * a.ldL + i0, r, out, a.p - i0);
+    }
+  if (nnan) atomicAdd((unsigned long long*)&a.stat[ST_NAN_LOD], (unsigned long long)nnan);
+}
+
 template <int C, int MB>
 static int launch_scan_lr_t(blmm_ctx* ctx, const LrArgs& la) {
   constexpr int NB = 4;
@@ -740,8 +891,13 @@ static int launch_scan_lr_t(blmm_ctx* ctx, const LrArgs& la) {
   (void)hipMemcpyToSymbol(HIP_SYMBOL(g_lr_phase), zp, sizeof(zp));
   (void)hipStreamSynchronize(ctx->stream);
 #endif
+  // k_scan_lr3 (three waves per SIMD) is the default for c = 1 without the p-value output; BLMM_LR3=0: k_scan_lr (A/B testing).
+  // One box, four alternating rounds: scan 1.164-1.183 against 1.206-1.240 ms, step 1.636-1.654 against 1.674-1.714.
+  static const bool lr3 = !(getenv("BLMM_LR3") && getenv("BLMM_LR3")[0] == '0');
   if (a.Pv)
     hipLaunchKernelGGL((k_scan_lr<C, MB, NB, true>), dim3((unsigned)nwg), dim3(256), 0, ctx->stream, la, (int)ntile_i, nwg);
+  else if (lr3 && C == 1 && MB == 2 && la.skip_shared)
+    hipLaunchKernelGGL(k_scan_lr3, dim3((unsigned)nwg), dim3(256), 0, ctx->stream, la, (int)ntile_i, nwg);
   else
     hipLaunchKernelGGL((k_scan_lr<C, MB, NB>), dim3((unsigned)nwg), dim3(256), 0, ctx->stream, la, (int)ntile_i, nwg);
 #ifdef LR_PHASE
