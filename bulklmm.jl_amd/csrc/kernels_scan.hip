@@ -891,12 +891,12 @@ static int launch_scan_lr_t(blmm_ctx* ctx, const LrArgs& la) {
   (void)hipMemcpyToSymbol(HIP_SYMBOL(g_lr_phase), zp, sizeof(zp));
   (void)hipStreamSynchronize(ctx->stream);
 #endif
-  // k_scan_lr3 (three waves per SIMD) is the default for c = 1 without the p-value output; BLMM_LR3=0: k_scan_lr (A/B testing).
+  // k_scan_lr3 (three waves per SIMD) is the default for c = 1 and n <= 128 without the p-value output; BLMM_LR3=0: k_scan_lr (A/B testing).
   // One box, four alternating rounds: scan 1.164-1.183 against 1.206-1.240 ms, step 1.636-1.654 against 1.674-1.714.
   static const bool lr3 = !(getenv("BLMM_LR3") && getenv("BLMM_LR3")[0] == '0');
   if (a.Pv)
     hipLaunchKernelGGL((k_scan_lr<C, MB, NB, true>), dim3((unsigned)nwg), dim3(256), 0, ctx->stream, la, (int)ntile_i, nwg);
-  else if (lr3 && C == 1 && MB == 2 && la.skip_shared)
+  else if (lr3 && C == 1 && MB == 2 && la.skip_shared && a.n <= 128)   // beyond: phase 1 is long and its single fragment set shows (n = 200: +1.7 %, n = 500: +4 %; n = 124: -1 %, n = 79: -3.8 % of the scan)
     hipLaunchKernelGGL(k_scan_lr3, dim3((unsigned)nwg), dim3(256), 0, ctx->stream, la, (int)ntile_i, nwg);
   else
     hipLaunchKernelGGL((k_scan_lr<C, MB, NB>), dim3((unsigned)nwg), dim3(256), 0, ctx->stream, la, (int)ntile_i, nwg);
