@@ -413,7 +413,7 @@ def main():
         roof = {"bound": "mfma", "achieved": flops_launch / (scan_ms * 1e-3) / 1e12 if scan_ms > 0 else None,
                 "peak": FP32_MFMA_PEAK_TFLOPS if f32 else FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": (flops_launch / (scan_ms * 1e-3) / 1e12 / (FP32_MFMA_PEAK_TFLOPS if f32 else FP64_MFMA_PEAK_TFLOPS)) if scan_ms > 0 else None,
-                "traffic": None, "kernel": "k_scan_lr (exact, low-rank weights)" if a.method == "null-exact" else ("k_scan_f32" if f32 else "k_scan"),
+                "traffic": None, "kernel": "k_scan_lr3 / k_scan_lr (rank-R class, weight basis per h2 segment) + k_scan<table, perm> (shared-weights class)" if a.method == "null-exact" else ("k_scan_f32" if f32 else "k_scan"),
                 "kernel_ms": scan_ms, "alg_flops_per_launch": flops_launch,
                 "alg_bytes_per_launch": (4.0 if f32 else 8.0) * p * m_local,
                 "hbm_write_GBps": (4.0 if f32 else 8.0) * p * m_local / (scan_ms * 1e-3) / 1e9 if scan_ms > 0 else None,
