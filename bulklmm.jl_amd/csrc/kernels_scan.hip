@@ -723,17 +723,19 @@ __global__ void __launch_bounds__(256, 2) k_scan_lr(LrArgs la, int ntile_i, int6
 
 // ------------------------------------------------------------------------------------------------
 // k_scan_lr3: the rank-R tiles of k_scan_lr<1, 2, 4> at THREE waves per SIMD (the default for c = 1 without the p-value output and
-// with the shared-weights class in the table kernel; BLMM_LR3=0: k_scan_lr).  Phase 2 comes FIRST and in two halves over the wave's trait blocks: a half
+// with the shared-weights class in the table kernel; BLMM_LR3=0: k_scan_lr).  PV: -log10 p as a second output.  Phase 2 comes FIRST and in two halves over the wave's trait blocks: a half
 // accumulates Sxx and s for four 16 x 16 blocks (64 VGPRs), converts them to 1 / (Sxx - u^2) (32 VGPRs) and lets them go; then
 // phase 1 accumulates num (64 VGPRs) beside the 64 of the reciprocals -- 128 accumulator registers at the peak where k_scan_lr
 // holds 192 -- and the epilogue is r^2 = num^2 * that reciprocal.  Same arithmetic per output, same bits.
 // ------------------------------------------------------------------------------------------------
+template <bool PV>
 __global__ void __launch_bounds__(256, 3) k_scan_lr3(LrArgs la, int ntile_i, int64_t nwg) {
   const ScanArgs& a = la.s;
   constexpr int MB = 2, NB = 4, TW = 64;
   __shared__ dpair s_lod[BLMM_LOD_TABLE_N];
   __shared__ double s_li[TW];
   __shared__ int s_perm[TW];
+  __shared__ dpair s_pv[PV ? BLMM_PV_TABLE_N * (BLMM_PV_STRIDE / 2) : 1];   // PV: -log10 p as a second output (see k_scan)
   LodStage<256> lst;
   lod_stage_load<256>(lst, a.lodtab);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -778,6 +780,10 @@ __global__ void __launch_bounds__(256, 3) k_scan_lr3(LrArgs la, int ntile_i, int
   __builtin_amdgcn_sched_barrier(0);
   lod_stage_store<256>(lst, s_lod, a.lodc[0]);
   if (threadIdx.x < TW) { s_li[threadIdx.x] = li_st; s_perm[threadIdx.x] = perm_st; }
+  if constexpr (PV) {
+    const dpair* g = reinterpret_cast<const dpair*>(a.pvtab);
+    for (int i = threadIdx.x; i < BLMM_PV_TABLE_N * (BLMM_PV_STRIDE / 2); i += 256) s_pv[i] = g[i];
+  }
   __syncthreads();
   d4 den[MB][NB];
 #pragma unroll
@@ -868,6 +874,12 @@ __global__ void __launch_bounds__(256, 3) k_scan_lr3(LrArgs la, int ntile_i, int
           if (!lod_fast_ok(uv[nb])) out[nb] = lod_out_of_range(uv[nb], s_lod, lp, scale, i0 + mslot<NB>(r, nb) < a.p, &nnan);
       }
       store_m<NB>(a.L + trait * a.ldL + i0, r, out, a.p - i0);
+      if constexpr (PV) {
+        double pv[NB];
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) pv[nb] = fast_log10p1(out[nb], s_pv);
+        store_m<NB>(a.Pv + trait * a.ldPv + i0, r, pv, a.p - i0);
+      }
     }
   if (nnan) atomicAdd((unsigned long long*)&a.stat[ST_NAN_LOD], (unsigned long long)nnan);
 }
@@ -894,10 +906,12 @@ static int launch_scan_lr_t(blmm_ctx* ctx, const LrArgs& la) {
   // k_scan_lr3 (three waves per SIMD) is the default for c = 1 and n <= 128 without the p-value output; BLMM_LR3=0: k_scan_lr (A/B testing).
   // One box, four alternating rounds: scan 1.164-1.183 against 1.206-1.240 ms, step 1.636-1.654 against 1.674-1.714.
   static const bool lr3 = !(getenv("BLMM_LR3") && getenv("BLMM_LR3")[0] == '0');
-  if (a.Pv)
+  if (a.Pv && lr3 && C == 1 && MB == 2 && la.skip_shared && a.n <= 128)
+    hipLaunchKernelGGL(k_scan_lr3<true>, dim3((unsigned)nwg), dim3(256), 0, ctx->stream, la, (int)ntile_i, nwg);
+  else if (a.Pv)
     hipLaunchKernelGGL((k_scan_lr<C, MB, NB, true>), dim3((unsigned)nwg), dim3(256), 0, ctx->stream, la, (int)ntile_i, nwg);
   else if (lr3 && C == 1 && MB == 2 && la.skip_shared && a.n <= 128)   // beyond: phase 1 is long and its single fragment set shows (n = 200: +1.7 %, n = 500: +4 %; n = 124: -1 %, n = 79: -3.8 % of the scan)
-    hipLaunchKernelGGL(k_scan_lr3, dim3((unsigned)nwg), dim3(256), 0, ctx->stream, la, (int)ntile_i, nwg);
+    hipLaunchKernelGGL(k_scan_lr3<false>, dim3((unsigned)nwg), dim3(256), 0, ctx->stream, la, (int)ntile_i, nwg);
   else
     hipLaunchKernelGGL((k_scan_lr<C, MB, NB>), dim3((unsigned)nwg), dim3(256), 0, ctx->stream, la, (int)ntile_i, nwg);
 #ifdef LR_PHASE
