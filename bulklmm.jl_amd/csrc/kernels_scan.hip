@@ -903,7 +903,7 @@ static int launch_scan_lr_t(blmm_ctx* ctx, const LrArgs& la) {
   (void)hipMemcpyToSymbol(HIP_SYMBOL(g_lr_phase), zp, sizeof(zp));
   (void)hipStreamSynchronize(ctx->stream);
 #endif
-  // k_scan_lr3 (three waves per SIMD) is the default for c = 1 and n <= 128 without the p-value output; BLMM_LR3=0: k_scan_lr (A/B testing).
+  // k_scan_lr3 (three waves per SIMD) is the default for c = 1 and n <= 128; BLMM_LR3=0: k_scan_lr (A/B testing).
   // One box, four alternating rounds: scan 1.164-1.183 against 1.206-1.240 ms, step 1.636-1.654 against 1.674-1.714.
   static const bool lr3 = !(getenv("BLMM_LR3") && getenv("BLMM_LR3")[0] == '0');
   if (a.Pv && lr3 && C == 1 && MB == 2 && la.skip_shared && a.n <= 128)
