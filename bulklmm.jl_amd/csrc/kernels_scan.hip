@@ -728,12 +728,16 @@ __global__ void __launch_bounds__(256, 2) k_scan_lr(LrArgs la, int ntile_i, int6
 // phase 1 accumulates num (64 VGPRs) beside the 64 of the reciprocals -- 128 accumulator registers at the peak where k_scan_lr
 // holds 192 -- and the epilogue is r^2 = num^2 * that reciprocal.  Same arithmetic per output, same bits.
 // ------------------------------------------------------------------------------------------------
-template <bool PV>
+template <int C, bool PV>
 __global__ void __launch_bounds__(256, 3) k_scan_lr3(LrArgs la, int ntile_i, int64_t nwg) {
   const ScanArgs& a = la.s;
   constexpr int MB = 2, NB = 4, TW = 64;
+  constexpr int NL = C * (C + 1) / 2;
+  // phase 2 goes chunk by chunk: (trait block mb) x (NBC marker blocks) with 1 + C accumulators per block -- four marker blocks for
+  // c = 1 (64 registers), two for c = 2, 3 (48, 64) -- so that a chunk's sums and the reciprocals already made stay within three waves
+  constexpr int NBC = (C == 1) ? 4 : 2;
   __shared__ dpair s_lod[BLMM_LOD_TABLE_N];
-  __shared__ double s_li[TW];
+  __shared__ double s_li[NL][TW];
   __shared__ int s_perm[TW];
   __shared__ dpair s_pv[PV ? BLMM_PV_TABLE_N * (BLMM_PV_STRIDE / 2) : 1];   // PV: -log10 p as a second output (see k_scan)
   LodStage<256> lst;
@@ -754,8 +758,14 @@ __global__ void __launch_bounds__(256, 3) k_scan_lr3(LrArgs la, int ntile_i, int
     tile_of32(sF + local, nf, (uint32_t)ntile_i, tile_t, tile_i);
     tile_t += tb + fo;
   }
-  double li_st = 0.0; int perm_st = -1;
-  if (threadIdx.x < TW) { li_st = la.Ls[(int64_t)tile_t * TW + threadIdx.x]; perm_st = la.perm[(int64_t)tile_t * TW + threadIdx.x]; }
+  static_assert(NL * TW <= 2 * 256, "L^-1 staging: two elements per thread");
+  double li_st[2]; int perm_st = -1;
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const int e = (int)threadIdx.x + 256 * u;
+    li_st[u] = (e < NL * TW) ? la.Ls[(int64_t)(e / TW) * a.ldp + (int64_t)tile_t * TW + (e % TW)] : 0.0;
+  }
+  if (threadIdx.x < TW) perm_st = la.perm[(int64_t)tile_t * TW + threadIdx.x];
   const int wt = wave >> 1, wi = wave & 1;
   const int64_t i0 = (int64_t)tile_i * (32 * NB) + wi * (16 * NB);
   const int r = lane & 15, kk = lane >> 4;
@@ -764,22 +774,27 @@ __global__ void __launch_bounds__(256, 3) k_scan_lr3(LrArgs la, int ntile_i, int
   const double* PC = la.Cp + (int64_t)tile_t * TW;
   int sgi = 0;
   if (la.seg.S > 1) sgi = lr_seg_of(la.rg.ncol - 1 - ((int64_t)tile_t * TW - la.rg.col0), la.rg.segcnt, la.seg.S);
-  const double* PT = la.T + (int64_t)sgi * 2 * la.tstride + (int64_t)tile_i * (32 * NB);
+  const double* PT = la.T + (int64_t)sgi * (1 + C) * la.tstride + (int64_t)tile_i * (32 * NB);
   const uint32_t voffA = (uint32_t)(((int64_t)kk * a.ldp + wt * (16 * MB) + MB * r) * 8);
   const uint32_t voffB = (uint32_t)(((int64_t)kk * a.ldx + wi * (16 * NB)) * 8) + mvoff<NB>(r);
   const int64_t sa = 4 * a.ldp, sb = 4 * a.ldx;
   const int KR = la.rk[4 * sgi + 1];
   // first fragments of phase 2 on their way, then the staged tables to LDS
-  double c0[MB], d0[2][NB];
-  auto load2 = [&](double (&A)[MB], double (&B)[2][NB], int step) {
+  double c0[MB], d0[1 + C][NBC];
+  auto load2 = [&](double (&A)[MB], double (&B)[1 + C][NBC], int step, int nb0) {
     bufload<MB>(A, make_srd(PC + (int64_t)step * sa), voffA);
 #pragma unroll
-    for (int q = 0; q < 2; ++q) bufload_m<NB>(B[q], make_srd(PT + q * la.tstride + (int64_t)step * sb), voffB);
+    for (int q = 0; q <= C; ++q) bufload<NBC>(B[q], make_srd(PT + q * la.tstride + (int64_t)step * sb), voffB + (uint32_t)(8 * nb0));
   };
-  if (KR > 0) load2(c0, d0, 0);
+  if (KR > 0) load2(c0, d0, 0, 0);
   __builtin_amdgcn_sched_barrier(0);
   lod_stage_store<256>(lst, s_lod, a.lodc[0]);
-  if (threadIdx.x < TW) { s_li[threadIdx.x] = li_st; s_perm[threadIdx.x] = perm_st; }
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const int e = (int)threadIdx.x + 256 * u;
+    if (e < NL * TW) s_li[e / TW][e % TW] = li_st[u];
+  }
+  if (threadIdx.x < TW) s_perm[threadIdx.x] = perm_st;
   if constexpr (PV) {
     const dpair* g = reinterpret_cast<const dpair*>(a.pvtab);
     for (int i = threadIdx.x; i < BLMM_PV_TABLE_N * (BLMM_PV_STRIDE / 2); i += 256) s_pv[i] = g[i];
@@ -787,40 +802,50 @@ __global__ void __launch_bounds__(256, 3) k_scan_lr3(LrArgs la, int ntile_i, int
   __syncthreads();
   d4 den[MB][NB];
 #pragma unroll
-  for (int mb = 0; mb < MB; ++mb) {
-    d4 sx[NB], ss[NB];
+  for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
-    for (int nb = 0; nb < NB; ++nb) { sx[nb] = (d4){0, 0, 0, 0}; ss[nb] = (d4){0, 0, 0, 0}; }
-    auto mf = [&](const double (&A)[MB], const double (&B)[2][NB]) {
+    for (int nb0 = 0; nb0 < NB; nb0 += NBC) {
+      d4 sm[1 + C][NBC];
 #pragma unroll
-      for (int nb = 0; nb < NB; ++nb) {
-        sx[nb] = __builtin_amdgcn_mfma_f64_16x16x4f64(A[mb], B[0][nb], sx[nb], 0, 0, 0);
-        ss[nb] = __builtin_amdgcn_mfma_f64_16x16x4f64(A[mb], B[1][nb], ss[nb], 0, 0, 0);
+      for (int q = 0; q <= C; ++q)
+#pragma unroll
+        for (int nb = 0; nb < NBC; ++nb) sm[q][nb] = (d4){0, 0, 0, 0};
+      // one fragment set: the next step's loads go out right behind the MFMAs that read this step's (the matrix pipe drains them
+      // meanwhile, and two other waves share the SIMD); behind a chunk's last step, the first set of the next chunk
+      for (int ks = 0; ks < KR; ++ks) {
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int nb = 0; nb < NBC; ++nb)
+#pragma unroll
+          for (int q = 0; q <= C; ++q) sm[q][nb] = __builtin_amdgcn_mfma_f64_16x16x4f64(c0[mb], d0[q][nb], sm[q][nb], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (ks + 1 < KR) load2(c0, d0, ks + 1, nb0);
+        else if (nb0 + NBC < NB) load2(c0, d0, 0, nb0 + NBC);
+        else if (mb + 1 < MB) load2(c0, d0, 0, 0);
       }
-    };
-    // one fragment set: the next step's loads go out right behind the MFMAs that read this step's (the matrix pipe drains them
-    // for 8 x 64 cycles meanwhile, and two other waves share the SIMD)
-    for (int ks = 0; ks < KR; ++ks) {
-      __builtin_amdgcn_sched_barrier(0);
-      mf(c0, d0);
-      __builtin_amdgcn_sched_barrier(0);
-      if (ks + 1 < KR) load2(c0, d0, ks + 1);
-      else if (mb + 1 < MB) load2(c0, d0, 0);            // (the second half starts over at step 0)
-    }
 #pragma unroll
-    for (int reg = 0; reg < 4; ++reg) {
-      const double li = s_li[wt * (16 * MB) + MB * (kk + 4 * reg) + mb];
+      for (int reg = 0; reg < 4; ++reg) {
+        double li[NL];
 #pragma unroll
-      for (int nb = 0; nb < NB; ++nb) {
-        const double u = fma(li, ss[nb][reg], 0.0);
-        den[mb][nb][reg] = fast_rcp1(fma(-u, u, sx[nb][reg]));
+        for (int e = 0; e < NL; ++e) li[e] = s_li[e][wt * (16 * MB) + MB * (kk + 4 * reg) + mb];
+#pragma unroll
+        for (int nb = 0; nb < NBC; ++nb) {
+          double xx = sm[0][nb][reg];
+#pragma unroll
+          for (int q = 0; q < C; ++q) {
+            double u = 0.0;
+#pragma unroll
+            for (int e = 0; e <= q; ++e) u = fma(li[q * (q + 1) / 2 + e], sm[1 + e][nb][reg], u);
+            xx = fma(-u, u, xx);
+          }
+          den[mb][nb0 + nb][reg] = fast_rcp1(xx);
+        }
       }
-    }
-    // pin the reciprocals HERE: left alone the compiler sinks the whole conversion into the epilogue, next to its uses, and keeps the
-    // 128 registers of Sxx and s alive through phase 1 (142 spilled dwords)
+      // pin the reciprocals HERE: left alone the compiler sinks the whole conversion into the epilogue, next to its uses, and keeps
+      // the registers of Sxx and s alive through phase 1 (142 spilled dwords)
 #pragma unroll
-    for (int nb = 0; nb < NB; ++nb) asm volatile("" : "+v"(den[mb][nb]));
-  }
+      for (int nb = 0; nb < NBC; ++nb) asm volatile("" : "+v"(den[mb][nb0 + nb]));
+    }
   // ---- phase 1: num over n, one K step per fragment set
   d4 num[MB][NB];
 #pragma unroll
@@ -907,11 +932,11 @@ static int launch_scan_lr_t(blmm_ctx* ctx, const LrArgs& la) {
   // One box, four alternating rounds: scan 1.164-1.183 against 1.206-1.240 ms, step 1.636-1.654 against 1.674-1.714.
   static const bool lr3 = !(getenv("BLMM_LR3") && getenv("BLMM_LR3")[0] == '0');
   if (a.Pv && lr3 && C == 1 && MB == 2 && la.skip_shared && a.n <= 128)
-    hipLaunchKernelGGL(k_scan_lr3<true>, dim3((unsigned)nwg), dim3(256), 0, ctx->stream, la, (int)ntile_i, nwg);
+    hipLaunchKernelGGL((k_scan_lr3<1, true>), dim3((unsigned)nwg), dim3(256), 0, ctx->stream, la, (int)ntile_i, nwg);
   else if (a.Pv)
     hipLaunchKernelGGL((k_scan_lr<C, MB, NB, true>), dim3((unsigned)nwg), dim3(256), 0, ctx->stream, la, (int)ntile_i, nwg);
   else if (lr3 && C == 1 && MB == 2 && la.skip_shared && a.n <= 128)   // beyond: phase 1 is long and its single fragment set shows (n = 200: +1.7 %, n = 500: +4 %; n = 124: -1 %, n = 79: -3.8 % of the scan)
-    hipLaunchKernelGGL(k_scan_lr3<false>, dim3((unsigned)nwg), dim3(256), 0, ctx->stream, la, (int)ntile_i, nwg);
+    hipLaunchKernelGGL((k_scan_lr3<1, false>), dim3((unsigned)nwg), dim3(256), 0, ctx->stream, la, (int)ntile_i, nwg);
   else
     hipLaunchKernelGGL((k_scan_lr<C, MB, NB>), dim3((unsigned)nwg), dim3(256), 0, ctx->stream, la, (int)ntile_i, nwg);
 #ifdef LR_PHASE
@@ -936,14 +961,34 @@ static int launch_scan_lr_t(blmm_ctx* ctx, const LrArgs& la) {
   return BLMM_OK;
 }
 
+// c = 2, 3 through the three-wave kernel (64-trait tiles; k_scan_lr<C, 1> holds 16 x 64 per wave at two waves): same conditions as for
+// c = 1 -- n <= 128, the shared-weights class in the table kernel, BLMM_LR3 != 0
+template <int C>
+static bool lr3_covariates(blmm_ctx*, const LrArgs& la) {
+  static const bool lr3 = !(getenv("BLMM_LR3") && getenv("BLMM_LR3")[0] == '0');
+  return lr3 && la.skip_shared && la.s.n <= 128;
+}
+template <int C>
+static int launch_scan_lr3_c(blmm_ctx* ctx, const LrArgs& la) {
+  const ScanArgs& a = la.s;
+  const int64_t ntile_t = (a.m + 63) / 64, ntile_i = (a.p + 127) / 128;
+  if (ntile_t * ntile_i <= 0) return BLMM_OK;
+  const int64_t nwg = (ntile_t * ntile_i + 16 + 7) / 8 * 8;
+  if (nwg > 0x7fffffffLL) return fail(ctx, BLMM_ERR_INVALID, "problem too large for one launch");
+  if (a.Pv) hipLaunchKernelGGL((k_scan_lr3<C, true>), dim3((unsigned)nwg), dim3(256), 0, ctx->stream, la, (int)ntile_i, nwg);
+  else hipLaunchKernelGGL((k_scan_lr3<C, false>), dim3((unsigned)nwg), dim3(256), 0, ctx->stream, la, (int)ntile_i, nwg);
+  KCHECK();
+  return BLMM_OK;
+}
+
 int launch_scan_lr(blmm_ctx* ctx, const LrArgs& la) {
   switch (la.c) {
     case 1: {
       static const int mb1 = getenv("BLMM_LR_MB1") ? atoi(getenv("BLMM_LR_MB1")) : 0;
       return mb1 ? launch_scan_lr_t<1, 1>(ctx, la) : launch_scan_lr_t<1, 2>(ctx, la);
     }
-    case 2: return launch_scan_lr_t<2, 1>(ctx, la);
-    case 3: return launch_scan_lr_t<3, 1>(ctx, la);
+    case 2: return lr3_covariates<2>(ctx, la) ? launch_scan_lr3_c<2>(ctx, la) : launch_scan_lr_t<2, 1>(ctx, la);
+    case 3: return lr3_covariates<3>(ctx, la) ? launch_scan_lr3_c<3>(ctx, la) : launch_scan_lr_t<3, 1>(ctx, la);
   }
   return fail(ctx, BLMM_ERR_UNSUPPORTED, BLMM_C_ERR);
 }
