@@ -945,7 +945,11 @@ static int scan_pipeline(blmm_ctx* ctx, const blmm_opts* opts, Pipe& P, Timer& t
       // per-trait Brent search
       if ((rc = lr_begin(ctx, P, wbasis_started))) return rc;
       // the second kernel of a split h2 search runs beside the scan of the traits the first one finished (BLMM_LR_SPLIT=0: A/B)
-      static const bool split_on = !(getenv("BLMM_LR_SPLIT") && getenv("BLMM_LR_SPLIT")[0] == '0');
+      // ... when there are enough traits for two regions (BLMM_LR_SPLIT unset): below ~8 k each region's scan is a few dispatch rounds
+      // with their ramps, and one region wins (m = 4445, a rank's share of the BXD problem on 8 GPUs: 0.651 against 0.677 ms per
+      // step; m = 8889: 0.777 against 0.776; m = 35554: the split is worth 2.7 %).  BLMM_LR_SPLIT=1: always
+      const char* split_env = getenv("BLMM_LR_SPLIT");                // (read per call: tests hold the two forms against each other)
+      const bool split_on = split_env ? split_env[0] != '0' : m >= 8192;
       BrentSplit sp;
       if ((rc = launch_brent(ctx, nm, P.Yt, P.ldy, m, P.Z0, P.lam, dh2_out, nullptr, nullptr, P.stat, split_on ? 1 : 0, &sp))) return rc;
       tm.mark();

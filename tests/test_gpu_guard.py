@@ -196,3 +196,20 @@ def test_segmented_weight_basis_equals_the_single_basis(blmm, segments, monkeypa
     check = O.bulkscan_null(Y[:, :40], G, K, h2_override=seg.h2_null_list[:40])
     assert_lod_close(seg.L[:, :40], check.L)
     ctx.close()
+
+
+def test_split_h2_search_equals_the_single_region_form(blmm, monkeypatch):
+    """Two panel regions (the traits the first Brent kernel finished are scanned while the second kernel finishes the others; the
+    default from 8192 traits) against one region (below): the same per-trait arithmetic, so h2 and every LOD bit for bit."""
+    Y, G, K, _ = make_data(n=79, p=260, m=3000, seed=8202, bxd=True)
+    ctx = blmm.Context(0)
+    monkeypatch.setenv("BLMM_LR_SPLIT", "0")
+    one = blmm.bulkscan_null(Y, G, K, ctx=ctx)
+    monkeypatch.setenv("BLMM_LR_SPLIT", "1")
+    two = blmm.bulkscan_null(Y, G, K, ctx=ctx)
+    monkeypatch.delenv("BLMM_LR_SPLIT")
+    auto = blmm.bulkscan_null(Y, G, K, ctx=ctx)
+    assert np.array_equal(one.h2_null_list, two.h2_null_list) and np.array_equal(one.L, two.L) and np.array_equal(one.L, auto.L)
+    shared, prof = ctx.lowrank_profile()
+    assert shared + sum(c for c, _ in prof) == Y.shape[1]
+    ctx.close()
