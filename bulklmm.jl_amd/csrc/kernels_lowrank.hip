@@ -587,10 +587,17 @@ __global__ void __launch_bounds__(256) k_lr_tpanels(const double* __restrict__ X
 #pragma unroll
     for (int t = 0; t < 16; ++t) acc[q][t] = 0.0;
   if (i < p) {
+    // the next eight individuals are requested before the current eight are used (one wave per SIMD here: every batch was a full
+    // memory round trip in front of its arithmetic)
+    double xn[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) xn[u] = (u < n) ? Xt[(int64_t)u * ldx + i] : 0.0;
     for (int k0 = 0; k0 < n; k0 += 8) {
       double xs[8];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) xs[u] = (k0 + u < n) ? Xt[(int64_t)(k0 + u) * ldx + i] : 0.0;
+      for (int u = 0; u < 8; ++u) xs[u] = xn[u];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) xn[u] = (k0 + 8 + u < n) ? Xt[(int64_t)(k0 + 8 + u) * ldx + i] : 0.0;
 #pragma unroll
       for (int u = 0; u < 8; ++u) {
         const int k = k0 + u;
