@@ -46,24 +46,34 @@ def cpu_baseline(Y, G, K, budget_s=15.0):
     QR-based wls, re-weighting and QR-residualising the whole rotated marker matrix, src/bulkscan.jl:268-286 and
     src/bulkscan_helpers.jl:127-150), traits spread over OpenMP threads the way the reference spreads trait blocks over
     Julia threads, on a bounded sample of the same workload.  It is the checker used as the timed CPU stand-in (the
-    reference is pure Julia and cannot run here); it is never on the product path."""
+    reference is pure Julia and cannot run here); it is never on the product path.
+    `value` uses EVERY core the box grants this process (north_star: "the GPU box's own host cores, core count stated");
+    `threads16` is the same sample on 16 threads, the count of the reference's own published run (README.md:322-332)."""
     from oracle import cref   # test infrastructure, used here only as the timed CPU baseline
     p = G.shape[1]
-    # 16 = the CPU share of a one-GPU box (more OpenMP threads than that only fight over the same cores); the reference's own
-    # published run used 16 Julia threads too (README.md:322-332)
-    cores = max(1, min(16, cref.load().blmm_ref_max_threads(), len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)))
-    probe = min(Y.shape[1], 4 * cores)
-    cref.bulkscan_null(Y[:, :probe], G, K, nthreads=cores)          # warm-up (thread pool, page faults)
-    t0 = time.perf_counter()
-    cref.bulkscan_null(Y[:, :probe], G, K, nthreads=cores)
-    per_trait = (time.perf_counter() - t0) / probe
-    sample = int(min(Y.shape[1], max(probe, budget_s / max(per_trait, 1e-6))))
-    t0 = time.perf_counter()
-    cref.bulkscan_null(Y[:, :sample], G, K, nthreads=cores)
-    dt = time.perf_counter() - t0
-    return {"value": p * sample / dt, "unit": "tests/s", "cores": cores, "kind": "port",
-            "sample": f"bulkscan_null (oracle/bulkscan_null_ref.c, C + OpenMP, eigen + rotation + per-trait Brent + scan) on the "
-                      f"first {sample} of {Y.shape[1]} traits x {p} markers, {cores} threads, {dt:.1f} s"}
+    granted = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    cores = max(1, min(cref.load().blmm_ref_max_threads(), granted))
+
+    def run(threads, budget):
+        probe = min(Y.shape[1], 4 * threads)
+        cref.bulkscan_null(Y[:, :probe], G, K, nthreads=threads)          # warm-up (thread pool, page faults)
+        t0 = time.perf_counter()
+        cref.bulkscan_null(Y[:, :probe], G, K, nthreads=threads)
+        per_trait = (time.perf_counter() - t0) / probe
+        sample = int(min(Y.shape[1], max(probe, budget / max(per_trait, 1e-6))))
+        t0 = time.perf_counter()
+        cref.bulkscan_null(Y[:, :sample], G, K, nthreads=threads)
+        dt = time.perf_counter() - t0
+        return p * sample / dt, sample, dt
+
+    v, sample, dt = run(cores, budget_s)
+    out = {"value": v, "unit": "tests/s", "cores": cores, "cores_granted": granted, "kind": "port",
+           "sample": f"bulkscan_null (oracle/bulkscan_null_ref.c, C + OpenMP, eigen + rotation + per-trait Brent + scan) on the "
+                     f"first {sample} of {Y.shape[1]} traits x {p} markers, {cores} threads, {dt:.1f} s"}
+    if cores != 16 and cores > 16:
+        v16, s16, d16 = run(16, min(budget_s, 8.0))
+        out["threads16"] = {"value": v16, "cores": 16, "sample": f"first {s16} traits, 16 threads, {d16:.1f} s (the reference's published run used 16 Julia threads)"}
+    return out
 
 
 def workload_name(a, n, p, m_total, m_local, f32, world):
@@ -109,8 +119,9 @@ def main():
                          "reference's layout and the default; 16 = every column starts on a 128-byte line)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--pvals", action="store_true",
-                    help="`output_pvals = true`: the step also produces the -log10 p matrix (blmm_set_log10p_output; BLMM_PVAL_FUSED=0 "
-                         "in the environment runs it as the column pass over the finished L instead of from the scan epilogues)")
+                    help="`output_pvals = true`: the step also produces the -log10 p matrix (blmm_set_log10p_output; --pvals-pass runs it as "
+                         "the column pass over the finished L instead of from the scan epilogues: tuning key pval_fused = 0)")
+    ap.add_argument("--pvals-pass", action="store_true")
     ap.add_argument("--no-all-rank-form", action="store_true",
                     help="skip the extra timed loop with every trait in the rank-R form (profiling runs: its launches would be averaged into the kernel statistics)")
     ap.add_argument("--cpu-budget", type=float, default=15.0)
@@ -204,6 +215,8 @@ def main():
     grid = [i / 16.0 for i in range(16)] if a.method in ("null-grid", "alt-grid") else None
     stream = torch.cuda.current_stream()
     ctx = B.Context(dev_index, stream.cuda_stream)   # torch's current stream (handle 0 = the legacy default stream is adopted as such)
+    if a.pvals_pass:
+        ctx.set_tuning("pval_fused", 0)
 
     class Work:
         """One rank's operands and outputs for a trait block Ycols (n x mloc)."""
@@ -312,15 +325,15 @@ def main():
     dt, phases, ncalls = timed(work, a.gather, a.steps, a.warmup)
     # The headline workload's h2 = 0 share (about half of the synthetic traits end at the boundary and take the cheaper
     # shared-weights class) is a property of the DATA: one more timed loop with the class switched off (every trait through the
-    # rank-R form, BLMM_LR_SHARED=0, read per call by the library) says what the step costs without it.
+    # rank-R form: tuning key lr_shared = 0) says what the step costs without it.
     all_rank = None
-    if a.method == "null-exact" and world == 1 and a.streams == 1 and not a.no_all_rank_form and not os.environ.get("BLMM_LR_SHARED"):
-        os.environ["BLMM_LR_SHARED"] = "0"
+    if a.method == "null-exact" and world == 1 and a.streams == 1 and not a.no_all_rank_form:
+        ctx.set_tuning("lr_shared", 0)
         try:
             dt_r, ph_r, nc_r = timed(work, False, max(a.steps // 2, 3), 1)
             all_rank = {"ms_per_step": dt_r / max(a.steps // 2, 3) * 1e3, "scan_ms": ph_r["scan"] / max(nc_r, 1)}
         finally:
-            del os.environ["BLMM_LR_SHARED"]
+            ctx.set_tuning("lr_shared", 1)
         work.scan(); torch.cuda.synchronize()      # leave the default path's result in the outputs
     lr_rank = lr_resid = lr_fallback = lr_shared = lr_profile = None
     if a.method == "null-exact":   # one extra (untimed) call with a status read-back: the weight basis and its guard
@@ -333,7 +346,48 @@ def main():
 
     ag_ms = gathered_ms = None
     weak = None
+    multi = None
     if world > 1:
+        # ---- who is here: every rank reports (rank, local device index, device name / UUID / PCI bus id, its trait count), so that
+        #      the first run on a real node can be read from the JSON line alone
+        pr = torch.cuda.get_device_properties(dev)
+        me = {"rank": rank, "local_rank": local_rank, "device_index": dev_index, "name": pr.name, "uuid": str(getattr(pr, "uuid", "")),
+              "pci_bus_id": getattr(pr, "pci_bus_id", None), "m_local": int(work.m), "cols": [int(lo), int(hi)] if a.scaling == "strong" else [0, int(a.m)]}
+        seen = [None] * world
+        dist.all_gather_object(seen, me)
+        multi = {"ranks_seen": sorted(x["rank"] for x in seen), "devices": seen, "backend": backend,
+                 "rccl_world": dist.get_world_size(), "distinct_devices": len({(x["uuid"], x["pci_bus_id"], x["device_index"]) for x in seen}),
+                 "rccl_version": None,
+                 "marker_rotation_sharded": bool(shard_rotation)}
+        try:
+            multi["rccl_version"] = ".".join(str(v) for v in torch.cuda.nccl.version()) if backend == "nccl" else None
+        except Exception:   # noqa: BLE001
+            pass
+        # ---- is the gathered matrix the single-GPU matrix?  After one all-gather every rank recomputes 8 columns that OTHER ranks
+        #      own (a trait's column does not depend on which other traits are in the call: tests/test_gpu_fullsize.py's shard
+        #      consistency) and compares them with its gathered copy bit for bit
+        if backend == "nccl" and work.full is not None and not perms:
+            work.scan(); work.gather(); torch.cuda.synchronize(); barrier()
+            picks = []
+            for k in range(8):
+                s_ = (rank + 1 + k) % world
+                if s_ == rank or sizes[s_] == 0:
+                    continue
+                j_ = (17 * k + 5 * rank) % (sizes[s_] if a.scaling == "strong" else a.m)
+                picks.append((s_, j_, (sharding.trait_shard(a.m, s_, world)[0] + j_) if a.scaling == "strong" else j_))
+            ok = True
+            if picks:
+                w8 = Work(np.ascontiguousarray(Yf[:, [g for _, _, g in picks]]), None)
+                w8.scan(); torch.cuda.synchronize()
+                for k, (s_, j_, _) in enumerate(picks):
+                    ok = ok and bool(torch.equal(work.full[s_][j_], w8.dL[k]))
+                del w8
+            okt = torch.tensor([1 if ok else 0], dtype=torch.int32, device=dev)
+            dist.all_reduce(okt, op=dist.ReduceOp.MIN)
+            multi["gather_verified"] = bool(okt.item())
+            multi["gather_verified_columns_per_rank"] = len(picks)
+        else:
+            multi["gather_verified"] = None
         if backend == "nccl":
             work.gather(); torch.cuda.synchronize(); barrier()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -379,9 +433,39 @@ def main():
             B.api.host_unregister(Lh)
         except Exception as e:   # noqa: BLE001
             t_pin = None
+        # ... and what the caller pays when L does not have to cross PCIe: (a) L_out == NULL -- the matrix stays in
+        # HBM -- followed by the per-trait peaks and the LOD > 5 triplets from the resident matrix; (b) blmm_bulkscan_reduced -- the
+        # same results out of the scan kernels' epilogues, L never written
+        t_keep = t_red = red_route = None
+        n_trip = None
+        if a.method in ("null-exact", "null-grid"):
+            def keep_call():
+                t0 = time.perf_counter()
+                r = B.api._bulkscan_call(meth, Yf_, Gf_, Kf_, None, grid, True, None, 1.0, 0.0, False, 1, "eigen", 0, hctx, keep_on_device=True)
+                d = r[0]
+                mxk, _ = d.colmax()
+                trip = d.threshold(5.0, cap=1 << 21)
+                return (time.perf_counter() - t0) * 1e3, mxk, trip
+            def red_call():
+                t0 = time.perf_counter()
+                r = B.api.bulkscan_reduced(Yf_, Gf_, Kf_, method=a.method, h2_grid=grid, threshold=5.0, cap=1 << 21, ctx=hctx)
+                return (time.perf_counter() - t0) * 1e3, r
+            keep_call()
+            t_keep, mxk, tripk = min((keep_call() for _ in range(3)), key=lambda x: x[0])
+            red_call()
+            t_red, rr = min((red_call() for _ in range(3)), key=lambda x: x[0])
+            red_route = rr["route"]
+            n_trip = int(rr["triplets"][0].size)
+            same = bool(np.array_equal(rr["max_lod"], mxk) and all(np.array_equal(x, y) for x, y in zip(rr["triplets"], tripk)))
         host_api = {"end_to_end_ms_pageable_out": t_page, "end_to_end_ms_pinned_out": t_pin,
+                    "end_to_end_ms_keep_on_device": t_keep, "end_to_end_ms_reduced_out": t_red,
+                    "reduced_route": red_route, "reduced_triplets_lod_gt_5": n_trip,
+                    "reduced_equals_keep_on_device": same if t_red is not None else None,
                     "tests_per_s_end_to_end": p * m_local / ((t_pin or t_page) * 1e-3),
-                    "note": "host Y/G/K in, host L out (2.08 GB over PCIe at BXD size); never `value`"}
+                    "tests_per_s_end_to_end_reduced_out": (p * m_local / (t_red * 1e-3)) if t_red else None,
+                    "note": "host Y/G/K in; *_out: host L out (2.08 GB over PCIe at BXD size); keep_on_device: L stays in HBM "
+                            "(blmm_bulkscan, L_out == NULL) + per-trait peaks + LOD > 5 triplets from the resident matrix; reduced_out: the "
+                            "same results from the scan epilogues, L never written (blmm_bulkscan_reduced); never `value`"}
         hctx.close()
 
     if rank == 0:
@@ -467,6 +551,7 @@ def main():
                        "streams": max(a.streams, 1)},
             "phases_ms": {k: v / max(ncalls, 1) for k, v in phases.items()},
             "allgather_ms": ag_ms, "gathered_ms_per_step": gathered_ms, "other_scaling": weak, "output_finite": bool(chk),
+            "multi_gpu": multi,
             "host_api": host_api,
             "roofline": roof, "cpu_baseline": cpu,
             # the only number the reference publishes for this shape (default null-grid, 10-point grid, 16 Julia threads,

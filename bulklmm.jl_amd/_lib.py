@@ -27,6 +27,8 @@ EXPORTS = [
     "blmm_read_csv", "blmm_read_he", "blmm_table_rows", "blmm_table_cols", "blmm_table_copy", "blmm_table_free",
     "blmm_kinship_rounded", "blmm_scan_alt", "blmm_scan_alt_dev", "blmm_bulkscan_alt_exact", "blmm_bulkscan_alt_exact_dev",
     "blmm_prepare_dev", "blmm_rotated_rows", "blmm_rotate_block_dev", "blmm_bulkscan_prerotated_dev", "blmm_scan_perms_prerotated_dev",
+    "blmm_set_tuning", "blmm_get_tuning", "blmm_lowrank_columns", "blmm_bulkscan_reduced", "blmm_bulkscan_reduced_dev", "blmm_last_reduced_route",
+    "blmm_last_dims", "blmm_last_lod_colmax", "blmm_last_lod_columns", "blmm_multi_last_colmax", "blmm_multi_last_lod_threshold",
 ]
 
 BLMM_NULL_EXACT, BLMM_NULL_GRID, BLMM_ALT_GRID = 0, 1, 2
@@ -57,6 +59,12 @@ class blmm_status(C.Structure):
                 ("t_eigen_ms", C.c_double), ("t_rotate_ms", C.c_double), ("t_h2_ms", C.c_double),
                 ("t_prep_ms", C.c_double), ("t_scan_ms", C.c_double), ("t_total_ms", C.c_double),
                 ("n_h2_boundary", C.c_int64), ("n_h2_multimodal", C.c_int64), ("n_illcond_rescan", C.c_int64)]
+
+
+class blmm_reduced(C.Structure):
+    """blmm_bulkscan_reduced[_dev]: pointers as integers (host addresses for the host form, device addresses for _dev)."""
+    _fields_ = [("colmax", C.c_void_p), ("argmax", C.c_void_p), ("want_triplets", C.c_int64), ("thr", C.c_double),
+                ("cap", C.c_int64), ("ti", C.c_void_p), ("tj", C.c_void_p), ("tlod", C.c_void_p), ("count", C.c_void_p)]
 
 
 def build(force: bool = False) -> str:
@@ -170,6 +178,18 @@ def load():
     lib.blmm_host_alloc.restype = vp
     lib.blmm_host_free.argtypes = [vp]
     lib.blmm_host_free.restype = None
+    lib.blmm_lowrank_columns.argtypes = [vp, i64, vp, C.POINTER(i64), C.POINTER(i64)]
+    lib.blmm_set_tuning.argtypes = [vp, C.c_char_p, C.c_double]
+    lib.blmm_get_tuning.argtypes = [vp, C.c_char_p, dp]
+    rp = C.POINTER(blmm_reduced)
+    lib.blmm_bulkscan_reduced.argtypes = [vp, op, vp, i64, i64, vp, i64, vp, i64, vp, vp, vp, i64, rp, vp, sp]
+    lib.blmm_bulkscan_reduced_dev.argtypes = [vp, op, vp, i64, i64, vp, i64, vp, i64, vp, vp, vp, i64, rp, vp, sp]
+    lib.blmm_last_reduced_route.argtypes = [vp]
+    lib.blmm_last_dims.argtypes = [vp, C.POINTER(i64), C.POINTER(i64)]
+    lib.blmm_last_lod_colmax.argtypes = [vp, vp, vp]
+    lib.blmm_last_lod_columns.argtypes = [vp, vp, i64, vp]
+    lib.blmm_multi_last_colmax.argtypes = [vp, vp, vp]
+    lib.blmm_multi_last_lod_threshold.argtypes = [vp, C.c_double, i64, vp, vp, vp, C.POINTER(i64)]
     for name in EXPORTS:
         getattr(lib, name)  # AttributeError if a declared symbol is not exported
     _lib = lib

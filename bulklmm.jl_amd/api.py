@@ -82,6 +82,25 @@ class Context:
         self.check(self.lib.blmm_lowrank_profile(self.h, out))
         return int(out[1]), [(int(out[2 + 2 * s]), int(out[3 + 2 * s])) for s in range(int(out[0]))]
 
+    def lowrank_columns(self, m: int):
+        """blmm_lowrank_columns: (panel column of each of the m traits, region width, [shared, others] per region) of the last
+        null-exact call's low-rank form."""
+        col = np.empty(m, dtype=np.int32)
+        w = C.c_int64(0)
+        cnt = (C.c_int64 * 4)()
+        self.check(self.lib.blmm_lowrank_columns(self.h, int(m), col.ctypes.data_as(C.c_void_p), C.byref(w), cnt))
+        return col, int(w.value), [int(x) for x in cnt]
+
+    def set_tuning(self, key: str, value: float):
+        """blmm_set_tuning: the switches that select another arithmetic path (include/bulklmm_hip.h); key "defaults" resets."""
+        self.check(self.lib.blmm_set_tuning(self.h, key.encode(), float(value)))
+
+    def get_tuning(self, key: str) -> float:
+        v = C.c_double(0.0)
+        if self.lib.blmm_get_tuning(self.h, key.encode(), C.byref(v)) != 0:
+            raise BulkLMMError("get_tuning: unknown key " + key)
+        return float(v.value)
+
     def set_stream(self, stream: Optional[int]):
         self.check(self.lib.blmm_set_stream(self.h, _stream_arg(stream)))
 
@@ -133,6 +152,28 @@ class MultiContext:
         ld, lo, hi = C.c_int64(0), C.c_int64(0), C.c_int64(0)
         self.check(self.lib.blmm_multi_device_result(self.h, int(rank), C.byref(dL), C.byref(ld), C.byref(lo), C.byref(hi), C.byref(dH)))
         return dL.value, int(ld.value), int(lo.value), int(hi.value), dH.value
+
+
+    def last_colmax(self):
+        """Per-trait maximum LOD and its marker (0-based) of the last bulkscan_multi call, reduced on the devices."""
+        m = self._last_m
+        mx = np.empty(m); arg = np.empty(m, dtype=np.int64)
+        self.check(self.lib.blmm_multi_last_colmax(self.h, _p(mx), arg.ctypes.data_as(C.c_void_p)))
+        return mx, arg
+
+    def last_lod_threshold(self, thr: float, cap: int = 1 << 16):
+        """(marker, trait, LOD) of every LOD > thr of the last bulkscan_multi call, sorted by (trait, marker)."""
+        while True:
+            ii = np.empty(cap, dtype=np.int32); jj = np.empty(cap, dtype=np.int32); ll = np.empty(cap)
+            cnt = C.c_int64(0)
+            self.check(self.lib.blmm_multi_last_lod_threshold(self.h, float(thr), cap, ii.ctypes.data_as(C.c_void_p),
+                                                              jj.ctypes.data_as(C.c_void_p), _p(ll), C.byref(cnt)))
+            if cnt.value <= cap:
+                break
+            cap = int(cnt.value)
+        k = int(cnt.value)
+        order = np.lexsort((ii[:k], jj[:k]))
+        return ii[:k][order], jj[:k][order], ll[:k][order]
 
 
 _GATHER = {"none": L.BLMM_GATHER_NONE, "host_shards": L.BLMM_GATHER_HOST_SHARDS, "allgather": L.BLMM_GATHER_ALLGATHER}
@@ -246,8 +287,67 @@ def readhe(file: str) -> np.ndarray:
     return _read_table("he", file)
 
 
+class DeviceLOD:
+    """The LOD matrix of a `keep_on_device=True` call: it stays in the context's HBM workspace (blmm_bulkscan with L_out == NULL)
+    and is reduced there -- what README.md:246-255, 354-359 and get_thresholds do with L -- until the context's next call that
+    produces a matrix.  `shape`, `colmax()`, `threshold(t)`, `get_thresholds(probs)`, `columns(idx)`, `log10p(df)`,
+    `to_host()`."""
+
+    def __init__(self, ctx: Context, p: int, m: int):
+        self.ctx, self.shape = ctx, (p, m)
+
+    def _alive(self):
+        pp, mm = C.c_int64(0), C.c_int64(0)
+        if self.ctx.lib.blmm_last_dims(self.ctx.h, C.byref(pp), C.byref(mm)) != 0 or (pp.value, mm.value) != self.shape:
+            raise BulkLMMError("the device-resident LOD matrix has been replaced by a later call on its context")
+
+    def colmax(self):
+        self._alive()
+        m = self.shape[1]
+        mx = np.empty(m); arg = np.empty(m, dtype=np.int64)
+        self.ctx.check(self.ctx.lib.blmm_last_lod_colmax(self.ctx.h, _p(mx), arg.ctypes.data_as(C.c_void_p)))
+        return mx, arg
+
+    def threshold(self, thr: float, cap: int = 1 << 16):
+        """(marker, trait, LOD) triplets of every LOD > thr, 0-based, sorted by (trait, marker)."""
+        self._alive()
+        while True:
+            ii = np.empty(cap, dtype=np.int32); jj = np.empty(cap, dtype=np.int32); ll = np.empty(cap)
+            cnt = C.c_int64(0)
+            self.ctx.check(self.ctx.lib.blmm_last_lod_threshold(self.ctx.h, float(thr), cap, ii.ctypes.data_as(C.c_void_p),
+                                                                jj.ctypes.data_as(C.c_void_p), _p(ll), C.byref(cnt)))
+            if cnt.value <= cap:
+                break
+            cap = int(cnt.value)
+        k = int(cnt.value)
+        order = np.lexsort((ii[:k], jj[:k]))
+        return ii[:k][order], jj[:k][order], ll[:k][order]
+
+    def get_thresholds(self, probs):
+        self._alive()
+        pr = np.ascontiguousarray(np.asarray(probs, dtype=np.float64).ravel())
+        out = np.empty(pr.shape[0])
+        self.ctx.check(self.ctx.lib.blmm_last_get_thresholds(self.ctx.h, _p(pr), pr.shape[0], _p(out)))
+        return out
+
+    def columns(self, idx):
+        """L[:, idx] (p x len(idx)) -- the LOD profiles of a few traits, the only part of L that crosses PCIe."""
+        self._alive()
+        ix = np.ascontiguousarray(np.asarray(idx, dtype=np.int64).ravel())
+        out = np.empty((self.shape[0], ix.shape[0]), order="F")
+        self.ctx.check(self.ctx.lib.blmm_last_lod_columns(self.ctx.h, ix.ctypes.data_as(C.c_void_p), ix.shape[0], _p(out)))
+        return out
+
+    def log10p(self, df: int = 1):
+        self._alive()
+        return _last_log10p(self.ctx, self.shape, df)
+
+    def to_host(self):
+        return self.columns(np.arange(self.shape[1]))
+
+
 def _bulkscan_call(method, Y, G, K, Covar, h2_grid, addIntercept, weights, prior_variance, prior_sample_size, reml,
-                   optim_interval, decomp_scheme, compat_flags, ctx, return_status=False):
+                   optim_interval, decomp_scheme, compat_flags, ctx, return_status=False, keep_on_device=False, pvals_df=None):
     Y = _F(Y)
     G = _F(G)
     K = _F(K)
@@ -274,12 +374,22 @@ def _bulkscan_call(method, Y, G, K, Covar, h2_grid, addIntercept, weights, prior
         ngrid = grid.shape[0]
     o = _opts(method, reml, addIntercept, decomp_scheme, optim_interval, prior_variance, prior_sample_size, compat_flags)
     ctx = ctx or default_context()  # after the argument checks: those must not need a GPU
-    Lout = np.empty((p, m), dtype=np.float64, order="F")
+    Lout = None if keep_on_device else np.empty((p, m), dtype=np.float64, order="F")
     h2 = np.empty((p, m) if method == L.BLMM_ALT_GRID else (m,), dtype=np.float64, order="F")
     st = L.blmm_status()
-    ctx.check(ctx.lib.blmm_bulkscan(ctx.h, C.byref(o), _p(Y), n, m, _p(G), p, _p(cov), ncov, _p(K), _p(w), _p(grid), ngrid,
-                                    _p(Lout), _p(h2), C.byref(st)))
+    # `output_pvals` (src/bulkscan.jl:154-157) is asked for right in front of the call -- after every check above, so that no
+    # request is left armed by an exception -- and the library consumes it first thing in the call whatever happens next
+    if pvals_df is not None:
+        ctx.check(ctx.lib.blmm_set_log10p_output(ctx.h, None, 0, int(pvals_df)))
+    try:
+        ctx.check(ctx.lib.blmm_bulkscan(ctx.h, C.byref(o), _p(Y), n, m, _p(G), p, _p(cov), ncov, _p(K), _p(w), _p(grid), ngrid,
+                                        _p(Lout), _p(h2), C.byref(st)))
+    finally:
+        if pvals_df is not None:
+            ctx.lib.blmm_set_log10p_output(ctx.h, None, 0, 0)
     _raise_status(st)
+    if keep_on_device:
+        Lout = DeviceLOD(ctx, p, m)
     if return_status:
         return Lout, h2, st
     return Lout, h2
@@ -318,29 +428,33 @@ def bulkscan_into(ctx: Context, method: int, Y, G, K, L_out: np.ndarray, h2_out:
 
 def bulkscan_null(Y, G, K, Covar=None, *, nb: int = 1, nt_blas: int = 1, addIntercept: bool = True, weights=None,
                   prior_variance: float = 1.0, prior_sample_size: float = 0.0, reml: bool = False, optim_interval: int = 1,
-                  decomp_scheme: str = "eigen", ctx: Optional[Context] = None) -> BulkscanNullResult:
-    """src/bulkscan.jl:188-314.  `nb` / `nt_blas` are accepted and ignored (CPU thread blocking)."""
+                  decomp_scheme: str = "eigen", ctx: Optional[Context] = None, keep_on_device: bool = False,
+                  _pvals_df=None) -> BulkscanNullResult:
+    """src/bulkscan.jl:188-314.  `nb` / `nt_blas` are accepted and ignored (CPU thread blocking).  keep_on_device: `L` is a
+    DeviceLOD (the matrix stays in HBM)."""
     Lo, h2 = _bulkscan_call(L.BLMM_NULL_EXACT, Y, G, K, Covar, None, addIntercept, weights, prior_variance, prior_sample_size,
-                            reml, optim_interval, decomp_scheme, 0, ctx)
+                            reml, optim_interval, decomp_scheme, 0, ctx, keep_on_device=keep_on_device, pvals_df=_pvals_df)
     return BulkscanNullResult(Lo, h2)
 
 
 def bulkscan_null_grid(Y, G, K, grid_list, Covar=None, *, weights=None, addIntercept: bool = True, prior_variance: float = 1.0,
                        prior_sample_size: float = 0.0, reml: bool = False, decomp_scheme: str = "eigen",
-                       ctx: Optional[Context] = None) -> BulkscanNullResult:
+                       ctx: Optional[Context] = None, keep_on_device: bool = False, _pvals_df=None) -> BulkscanNullResult:
     """src/bulkscan.jl:321-385."""
     Lo, h2 = _bulkscan_call(L.BLMM_NULL_GRID, Y, G, K, Covar, grid_list, addIntercept, weights, prior_variance,
-                            prior_sample_size, reml, 1, decomp_scheme, 0, ctx)
+                            prior_sample_size, reml, 1, decomp_scheme, 0, ctx, keep_on_device=keep_on_device, pvals_df=_pvals_df)
     return BulkscanNullResult(Lo, h2)
 
 
 def bulkscan_alt_grid(Y, G, K, hsq_list, Covar=None, *, reml: bool = False, prior_variance: float = 1.0,
                       prior_sample_size: float = 0.0, weights=None, addIntercept: bool = True, decomp_scheme: str = "eigen",
-                      compat_counter_quirk: bool = False, ctx: Optional[Context] = None) -> BulkscanAltResult:
+                      compat_counter_quirk: bool = False, ctx: Optional[Context] = None, keep_on_device: bool = False,
+                      _pvals_df=None) -> BulkscanAltResult:
     """src/bulkscan.jl:428-526 (h2_panel = grid value at the arg-max)."""
     Lo, h2 = _bulkscan_call(L.BLMM_ALT_GRID, Y, G, K, Covar, hsq_list, addIntercept, weights, prior_variance,
                             prior_sample_size, reml, 1, decomp_scheme,
-                            L.BLMM_COMPAT_ALT_COUNTER if compat_counter_quirk else 0, ctx)
+                            L.BLMM_COMPAT_ALT_COUNTER if compat_counter_quirk else 0, ctx, keep_on_device=keep_on_device,
+                            pvals_df=_pvals_df)
     return BulkscanAltResult(Lo, h2)
 
 
@@ -384,7 +498,8 @@ def bulkscan_alt_exact(Y, G, K, Covar=None, *, reml: bool = False, prior_varianc
 
 def bulkscan_multi(mctx: MultiContext, Y, G, K, Covar=None, *, method: str = "null-grid", h2_grid=None, gather: str = "host_shards",
                    addIntercept: bool = True, weights=None, prior_variance: float = 1.0, prior_sample_size: float = 0.0,
-                   reml: bool = False, optim_interval: int = 1, decomp_scheme: str = "eigen", return_status: bool = False) -> dict:
+                   reml: bool = False, optim_interval: int = 1, decomp_scheme: str = "eigen", return_status: bool = False,
+                   keep_on_device: bool = False) -> dict:
     """bulkscan over every GPU of `mctx` in ONE call (blmm_bulkscan_multi): the trait blocks the reference deals to its
     threads (src/bulkscan.jl:263-309) go to the devices.  Same result fields as `bulkscan`; `gather` = "host_shards"
     (default), "none" or "allgather" (include/bulklmm_hip.h)."""
@@ -415,8 +530,10 @@ def bulkscan_multi(mctx: MultiContext, Y, G, K, Covar=None, *, method: str = "nu
         ngrid = grid.shape[0]
     o = _opts(meth, reml, addIntercept, decomp_scheme, optim_interval, prior_variance, prior_sample_size)
     mo = L.blmm_multi_opts(_GATHER[gather], 0)
-    Lout = np.empty((p, m), dtype=np.float64, order="F")
+    # keep_on_device: no L_out -- every device keeps its block in HBM; mctx.last_colmax() / last_lod_threshold() reduce them there
+    Lout = None if keep_on_device else np.empty((p, m), dtype=np.float64, order="F")
     h2 = np.empty((p, m) if meth == L.BLMM_ALT_GRID else (m,), dtype=np.float64, order="F")
+    mctx._last_m = m
     sts = (L.blmm_status * mctx.ndev)()
     mctx.check(mctx.lib.blmm_bulkscan_multi(mctx.h, C.byref(o), C.byref(mo), _p(Y), n, m, _p(G), p, _p(cov), ncov, _p(K), _p(w),
                                             _p(grid), ngrid, _p(Lout), _p(h2), sts))
@@ -469,35 +586,97 @@ def lod_threshold(L_mat, thr: float, ctx: Optional[Context] = None, cap: Optiona
 def bulkscan(Y, G, K, Covar=None, *, method: str = "null-grid", h2_grid=None, nb: int = 1, nt_blas: int = 1,
              addIntercept: bool = True, weights=None, prior_variance: float = 1.0, prior_sample_size: float = 0.0,
              reml: bool = False, optim_interval: int = 1, decomp_scheme: str = "eigen", output_pvals: bool = False,
-             chisq_df: int = 1, ctx: Optional[Context] = None) -> dict:
-    """src/bulkscan.jl:81-162.  Returns a dict with the reference NamedTuple's field names."""
+             chisq_df: int = 1, ctx: Optional[Context] = None, keep_on_device: bool = False) -> dict:
+    """src/bulkscan.jl:81-162.  Returns a dict with the reference NamedTuple's field names.  keep_on_device=True (not in the
+    reference): `L` is a DeviceLOD handle -- the p x m matrix stays in HBM and is reduced there (colmax, threshold triplets,
+    permutation quantiles, single columns); the call then costs ~2 ms at BXD size instead of ~39 ms, 36 of which are L's trip
+    over PCIe."""
     if h2_grid is None:
         h2_grid = [i / 10.0 for i in range(10)]  # collect(0.0:0.1:0.9)
     if method not in _METHODS:
         raise BulkLMMError("Unknown method `%s`; choose null-exact, null-grid or alt-grid." % method, -5)
-    if output_pvals:
-        # lod2log10p.(L, chisq_df) merged into the result (src/bulkscan.jl:154-157): asked for BEFORE the scan, so that the
-        # scan kernels write it from their epilogues (chisq_df = 1, null-* methods) into a buffer of the context
-        c_ = ctx or default_context()
-        c_.check(c_.lib.blmm_set_log10p_output(c_.h, None, 0, int(chisq_df)))
+    # lod2log10p.(L, chisq_df) merged into the result (src/bulkscan.jl:154-157): asked for with the scan, so that the scan
+    # kernels write it from their epilogues (chisq_df = 1, null-* methods) into a buffer of the context
+    pv = int(chisq_df) if output_pvals else None
     if method == "null-exact":
         r = bulkscan_null(Y, G, K, Covar, addIntercept=addIntercept, weights=weights, prior_variance=prior_variance,
                           prior_sample_size=prior_sample_size, reml=reml, optim_interval=optim_interval,
-                          decomp_scheme=decomp_scheme, ctx=ctx)
+                          decomp_scheme=decomp_scheme, ctx=ctx, keep_on_device=keep_on_device, _pvals_df=pv)
         out = {"L": r.L, "h2_null_list": r.h2_null_list}
     elif method == "null-grid":
         r = bulkscan_null_grid(Y, G, K, h2_grid, Covar, weights=weights, addIntercept=addIntercept,
                                prior_variance=prior_variance, prior_sample_size=prior_sample_size, reml=reml,
-                               decomp_scheme=decomp_scheme, ctx=ctx)
+                               decomp_scheme=decomp_scheme, ctx=ctx, keep_on_device=keep_on_device, _pvals_df=pv)
         out = {"L": r.L, "h2_null_list": r.h2_null_list}
     else:
         r = bulkscan_alt_grid(Y, G, K, h2_grid, Covar, reml=reml, prior_variance=prior_variance,
                               prior_sample_size=prior_sample_size, weights=weights, addIntercept=addIntercept,
-                              decomp_scheme=decomp_scheme, ctx=ctx)
+                              decomp_scheme=decomp_scheme, ctx=ctx, keep_on_device=keep_on_device, _pvals_df=pv)
         out = {"L": r.L, "h2_panel": r.h2_panel}
     if output_pvals:
         out["log10Pvals_mat"] = _last_log10p(ctx or default_context(), out["L"].shape, chisq_df)
         out["Chisq_df"] = chisq_df
+    return out
+
+
+def bulkscan_reduced(Y, G, K, Covar=None, *, method: str = "null-grid", h2_grid=None, threshold: Optional[float] = None,
+                     cap: int = 1 << 16, addIntercept: bool = True, weights=None, prior_variance: float = 1.0,
+                     prior_sample_size: float = 0.0, reml: bool = False, optim_interval: int = 1, decomp_scheme: str = "eigen",
+                     ctx: Optional[Context] = None, return_status: bool = False) -> dict:
+    """bulkscan WITHOUT the LOD matrix (blmm_bulkscan_reduced; not in the reference, whose users reduce L on the CPU:
+    README.md:246-255, 354-359): per trait the peak LOD and its marker, and -- `threshold` given -- every (marker, trait, LOD) with
+    LOD > threshold, computed in the scan kernels' epilogues; L is never written.  Returns {"max_lod": m, "argmax": m (0-based),
+    "h2_null_list": m [, "triplets": (i, j, lod) sorted by (trait, marker)], "route": 1 fused | 2 through a resident matrix}."""
+    if h2_grid is None:
+        h2_grid = [i / 10.0 for i in range(10)]
+    if method not in _METHODS:
+        raise BulkLMMError("Unknown method `%s`; choose null-exact, null-grid or alt-grid." % method, -5)
+    meth = _METHODS[method]
+    Y = _F(Y); G = _F(G); K = _F(K)
+    n, m = Y.shape
+    p = G.shape[1]
+    if G.shape[0] != n or K.shape[0] != n or K.shape[1] != n:
+        raise BulkLMMError("Dimension mismatch.", -2)
+    cov, ncov = None, 0
+    if Covar is not None:
+        cov = _F(Covar)
+        if cov.shape[0] != n:
+            raise BulkLMMError("Dimension mismatch.", -2)
+        ncov = cov.shape[1]
+    else:
+        addIntercept = True
+    w = None if weights is None else np.ascontiguousarray(np.asarray(weights, dtype=np.float64).ravel())
+    if w is not None and w.shape[0] != n:
+        raise BulkLMMError("Dimension mismatch.", -2)
+    grid, ngrid = None, 0
+    if meth != L.BLMM_NULL_EXACT:
+        grid = np.ascontiguousarray(np.asarray(h2_grid, dtype=np.float64).ravel())
+        ngrid = grid.shape[0]
+    o = _opts(meth, reml, addIntercept, decomp_scheme, optim_interval, prior_variance, prior_sample_size)
+    ctx = ctx or default_context()
+    mx = np.empty(m); arg = np.empty(m, dtype=np.int64); h2 = np.empty(m)
+    st = L.blmm_status()
+    want = threshold is not None
+    while True:
+        cnt = C.c_int64(0)
+        ii = np.empty(max(cap, 1), dtype=np.int32); jj = np.empty(max(cap, 1), dtype=np.int32); ll = np.empty(max(cap, 1))
+        r = L.blmm_reduced(mx.ctypes.data, arg.ctypes.data, 1 if want else 0, float(threshold) if want else 0.0, int(cap) if want else 0,
+                           ii.ctypes.data, jj.ctypes.data, ll.ctypes.data, C.addressof(cnt))
+        ctx.check(ctx.lib.blmm_bulkscan_reduced(ctx.h, C.byref(o), _p(Y), n, m, _p(G), p, _p(cov), ncov, _p(K), _p(w), _p(grid), ngrid,
+                                                C.byref(r), _p(h2), C.byref(st)))
+        if not want or cnt.value <= cap:
+            break
+        cap = int(cnt.value)
+    _raise_status(st)
+    out = {"max_lod": mx, "argmax": arg, "route": int(ctx.lib.blmm_last_reduced_route(ctx.h))}
+    if meth != L.BLMM_ALT_GRID:
+        out["h2_null_list"] = h2
+    if want:
+        k = int(cnt.value)
+        order = np.lexsort((ii[:k], jj[:k]))
+        out["triplets"] = (ii[:k][order], jj[:k][order], ll[:k][order])
+    if return_status:
+        out["status"] = st
     return out
 
 
@@ -712,8 +891,6 @@ def bulkscan_dev(ctx: Context, Y, G, K, L_out, h2_out, *, method: str = "null-ex
     Enqueues on the context's stream and does not synchronise unless `status` is requested."""
     m, n = Y.shape
     p = G.shape[0]
-    if log10p_out is not None:
-        ctx.check(ctx.lib.blmm_set_log10p_output(ctx.h, log10p_out.data_ptr(), _ld(log10p_out, p), int(chisq_df)))
     grid = None
     ngrid = 0
     if method != "null-exact":
@@ -724,10 +901,46 @@ def bulkscan_dev(ctx: Context, Y, G, K, L_out, h2_out, *, method: str = "null-ex
         addIntercept = True
     o = _opts(_METHODS[method], reml, addIntercept, decomp_scheme, optim_interval, prior_variance, prior_sample_size)
     st = L.blmm_status() if status else None
-    ctx.check(ctx.lib.blmm_bulkscan_dev(ctx.h, C.byref(o), Y.data_ptr(), n, m, G.data_ptr(), p,
-                                        None if Covar is None else Covar.data_ptr(), ncov, K.data_ptr(),
-                                        None if weights is None else weights.data_ptr(), _p(grid), ngrid,
-                                        L_out.data_ptr(), _ld(L_out, p), h2_out.data_ptr(), C.byref(st) if status else None))
+    # armed right in front of the call (after everything above that can raise); the library consumes the request first thing
+    if log10p_out is not None:
+        ctx.check(ctx.lib.blmm_set_log10p_output(ctx.h, log10p_out.data_ptr(), _ld(log10p_out, p), int(chisq_df)))
+    try:
+        ctx.check(ctx.lib.blmm_bulkscan_dev(ctx.h, C.byref(o), Y.data_ptr(), n, m, G.data_ptr(), p,
+                                            None if Covar is None else Covar.data_ptr(), ncov, K.data_ptr(),
+                                            None if weights is None else weights.data_ptr(), _p(grid), ngrid,
+                                            L_out.data_ptr(), _ld(L_out, p), h2_out.data_ptr(), C.byref(st) if status else None))
+    finally:
+        if log10p_out is not None:
+            ctx.lib.blmm_set_log10p_output(ctx.h, None, 0, 0)
+    return st
+
+
+def bulkscan_reduced_dev(ctx: Context, Y, G, K, max_out, argmax_out, h2_out, *, method: str = "null-exact", h2_grid=None, Covar=None,
+                         weights=None, addIntercept: bool = True, prior_variance: float = 1.0, prior_sample_size: float = 0.0,
+                         reml: bool = False, optim_interval: int = 1, decomp_scheme: str = "eigen", threshold: Optional[float] = None,
+                         trip_i=None, trip_j=None, trip_lod=None, trip_count=None, status: bool = False):
+    """blmm_bulkscan_reduced_dev on torch CUDA tensors (layouts as bulkscan_dev): max_out (m, float64), argmax_out (m, int64);
+    threshold given: trip_i / trip_j (int32, cap), trip_lod (float64, cap), trip_count (int64, 1).  Synchronises the stream."""
+    m, n = Y.shape
+    p = G.shape[0]
+    grid, ngrid = None, 0
+    if method != "null-exact":
+        grid = np.ascontiguousarray(np.asarray(h2_grid if h2_grid is not None else [i / 10.0 for i in range(10)], dtype=np.float64))
+        ngrid = grid.shape[0]
+    ncov = 0 if Covar is None else Covar.shape[0]
+    if Covar is None:
+        addIntercept = True
+    o = _opts(_METHODS[method], reml, addIntercept, decomp_scheme, optim_interval, prior_variance, prior_sample_size)
+    st = L.blmm_status() if status else None
+    want = threshold is not None
+    r = L.blmm_reduced(None if max_out is None else max_out.data_ptr(), None if argmax_out is None else argmax_out.data_ptr(),
+                       1 if want else 0, float(threshold) if want else 0.0, int(trip_i.numel()) if want else 0,
+                       trip_i.data_ptr() if want else None, trip_j.data_ptr() if want else None,
+                       trip_lod.data_ptr() if want else None, trip_count.data_ptr() if want else None)
+    ctx.check(ctx.lib.blmm_bulkscan_reduced_dev(ctx.h, C.byref(o), Y.data_ptr(), n, m, G.data_ptr(), p,
+                                                None if Covar is None else Covar.data_ptr(), ncov, K.data_ptr(),
+                                                None if weights is None else weights.data_ptr(), _p(grid), ngrid, C.byref(r),
+                                                None if h2_out is None else h2_out.data_ptr(), C.byref(st) if status else None))
     return st
 
 

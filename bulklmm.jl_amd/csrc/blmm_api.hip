@@ -5,6 +5,7 @@
 #include "blmm_internal.h"
 #include "fastmath.h"
 #include <cmath>
+#include <cstddef>
 #include <chrono>
 #include <cstring>
 #include <limits>
@@ -220,6 +221,9 @@ int end_call(blmm_ctx* ctx, const Pipe& P, blmm_status* st, Timer* tm) {
 // unweighted projection on the null covariates (kernels_prep.hip:k_post_eigen).
 int prepare_eigen(blmm_ctx* ctx, const blmm_opts* o, int64_t n, const double* dCovar, int64_t ncov, const double* dK,
                   const double* dweights, int centered, Pipe& P, Timer& tm) {
+  // whatever blmm_prepare_dev left in this context (Rp, Z0, lambda, the status block) is about to be overwritten or reallocated:
+  // the *_prerotated entry points must not run on it afterwards (blmm_prepare_dev sets the flag again when IT got here)
+  ctx->prep_valid = false;
   if (n < 1 || ncov < 0) return fail(ctx, BLMM_ERR_DIM, "Dimension mismatch.");
   if (n > 2048) return fail(ctx, BLMM_ERR_UNSUPPORTED, "more than 2048 individuals: the device eigensolver (tridiagonalisation + divide and conquer) stops at n = 2048");
   int add_int = o->add_intercept ? 1 : 0;
@@ -247,7 +251,9 @@ int prepare_eigen(blmm_ctx* ctx, const blmm_opts* o, int64_t n, const double* dC
   // use in a process takes MINUTES on this image (code-object load) and its path could not be part of the default test run.
   // BLMM_EIGEN = dc | jacobi overrides the choice (A/B timing and tests; "dc" also for n <= 124; "jacobi" beyond 124 is the
   // single-workgroup global-memory Jacobi: 0.74 s at n = 333).
-  const char* eig_env = getenv("BLMM_EIGEN");
+  const char* eig_env = dev_env("BLMM_EIGEN");                 // tuning key "eigen_solver": 1 = "jacobi", 2 = "dc"
+  if (!eig_env && ctx->tune.eigen_solver == 1) eig_env = "jacobi";
+  if (!eig_env && ctx->tune.eigen_solver == 2) eig_env = "dc";
   const bool big = n > jacobi_lds_max_n();
   P.big = big;
   bool done = false;
@@ -284,7 +290,7 @@ int rotate_markers(blmm_ctx* ctx, Pipe& P, const double* dG, int64_t p);
 int start_wbasis(blmm_ctx* ctx, Pipe& P, const double* dG = nullptr, int64_t p = 0) {
   int rc;
   const int64_t n = P.n;
-  const LrSeg seg = lr_segments(P.n);
+  const LrSeg seg = lr_segments(ctx, P.n);
   if ((rc = ensure(ctx, ctx->wbQ, sizeof(double) * (size_t)seg.S * P.npad * n))) return rc;
   if ((rc = ensure(ctx, ctx->wbW, sizeof(double) * (size_t)n * (256 + 16)))) return rc;
   if ((rc = ensure(ctx, ctx->wbRk, sizeof(int) * 4 * LR_SEG_MAX))) return rc;
@@ -326,7 +332,7 @@ int prepare(blmm_ctx* ctx, const blmm_opts* o, const double* dY, int64_t n, int6
   int rc = prepare_eigen(ctx, o, n, dCovar, ncov, dK, dweights, centered, P, tm);
   if (rc) return rc;
   // (BLMM_ROTATE_SIDE=0: the marker rotation stays on the main stream behind the traits' -- A/B testing)
-  static const bool rot_side = !(getenv("BLMM_ROTATE_SIDE") && getenv("BLMM_ROTATE_SIDE")[0] == '0');
+  static const bool rot_side = !(dev_env("BLMM_ROTATE_SIDE") && dev_env("BLMM_ROTATE_SIDE")[0] == '0');
   // only where the rotation is the small latency-bound kernel (n <= 160): the GEMM of larger n fills the chip by itself, and behind it
   // the basis and the marker-side products come later (n = 500 shard: 6.32 against 6.29 ms; BXD: 1.714 against 1.734 ms, 4 A/B rounds)
   const bool side_g = early_wbasis && m > 0 && p > 0 && rot_side && n <= 160;
@@ -379,6 +385,7 @@ ScanArgs scan_args(blmm_ctx* ctx, const Pipe& P, const double* panels, int64_t l
   a.ks = P.npad / 4; a.n = P.n; a.p = P.p; a.m = m; a.L = L; a.ldL = ldL;
   a.isx = nullptr; a.ld_isx = 0; a.bin = nullptr; a.stat = P.stat; a.logtab = ptr<double>(ctx->logtab); a.lodtab = ptr<double>(ctx->lodtab);
   a.Pv = ctx->pv_cur; a.ldPv = ctx->pv_cur_ld; a.pvtab = ptr<double>(ctx->pvtab);
+  a.red = ctx->red_cur;                    // blmm_bulkscan_reduced: the scan kernels reduce in their epilogues, L == nullptr
   a.c = P.c;
   lod_poly5_host(-0.5 * (double)P.n, a.lodc);
   return a;
@@ -388,11 +395,11 @@ ScanArgs scan_args(blmm_ctx* ctx, const Pipe& P, const double* panels, int64_t l
 // liteqtl_given_h2 seam.  lr_begin: weight basis (unless prepare() already started it) and the marker-side products on
 // the side stream; the caller may then enqueue the h2 search on the main stream; lr_finish: per-trait panels, the
 // MFMA scan, the all-trait residual guard beside it, and the full-rank re-scan of the flagged traits.
-double lr_tolerance() {
-  // relative residual |w_j - Q Q'w_j| / |w_j| above which a trait's column is recomputed from the full-length sums.
-  // BLMM_LR_TOL overrides it (tests: 0 flags every trait, so the re-scan kernel is compared with the oracle as a whole)
-  const char* e = getenv("BLMM_LR_TOL");
-  return e ? atof(e) : 1e-13;
+double lr_tolerance(const blmm_ctx* ctx) {
+  // relative residual |w_j - Q Q'w_j| / |w_j| above which a trait's column is recomputed from the full-length sums: tuning key
+  // "lr_tol" (tests: 0 flags every trait, so the re-scan kernel is compared with the oracle as a whole)
+  const char* e = dev_env("BLMM_LR_TOL");
+  return e ? atof(e) : ctx->tune.lr_tol;
 }
 
 // Width of one region of the panel arrays (LrRegion): k_lr_classify fills it from both ends, so it needs a whole padding
@@ -408,10 +415,11 @@ static LrRegion lr_region(const Pipe& P, int r) {
 
 int lr_begin(blmm_ctx* ctx, const Pipe& P, bool wbasis_started) {
   int rc;
+  ctx->lr_last_ldq = lr_ldq(P); ctx->lr_last_m = P.m;            // blmm_lowrank_columns
   const int64_t ldp = 2 * lr_ldq(P), tstride = (int64_t)P.npad * P.ldx;
   if ((rc = ensure(ctx, ctx->lrPerm, sizeof(int) * (size_t)ldp))) return rc;
   if ((rc = ensure(ctx, ctx->lrDen0, sizeof(double) * (size_t)P.ldx))) return rc;
-  const LrSeg seg = lr_segments(P.n);
+  const LrSeg seg = lr_segments(ctx, P.n);
   if ((rc = ensure(ctx, ctx->lrT, sizeof(double) * (size_t)seg.S * (1 + P.c) * tstride))) return rc;
   if ((rc = ensure(ctx, ctx->lrC, sizeof(double) * (size_t)P.npad * ldp))) return rc;
   if ((rc = ensure(ctx, ctx->lrL, sizeof(double) * (size_t)(P.c * (P.c + 1) / 2) * ldp))) return rc;
@@ -442,10 +450,11 @@ int lr_begin(blmm_ctx* ctx, const Pipe& P, bool wbasis_started) {
 
 namespace {
 // the shared-weights class uses the tolerance of the expansion guard; BLMM_LR_SHARED=0 switches the class off (A/B testing)
-double lr_shared_tol() {
-  // read per call (not cached): bench.py times the same process with and without the class (ms_per_step_all_rank_form)
-  const char* e = getenv("BLMM_LR_SHARED");
-  return !(e && e[0] == '0') ? lr_tolerance() : 0.0;
+double lr_shared_tol(const blmm_ctx* ctx) {
+  // tuning key "lr_shared" = 0: no class (bench.py times the same process with and without it: ms_per_step_all_rank_form)
+  const char* e = dev_env("BLMM_LR_SHARED");
+  const bool on = e ? e[0] != '0' : ctx->tune.lr_shared != 0;
+  return on ? lr_tolerance(ctx) : 0.0;
 }
 LrArgs lr_args(blmm_ctx* ctx, const Pipe& P, const LrRegion& rg, double* dL, int64_t ldL) {
   const int64_t ldp = 2 * lr_ldq(P);
@@ -455,15 +464,15 @@ LrArgs lr_args(blmm_ctx* ctx, const Pipe& P, const LrRegion& rg, double* dL, int
   la.Cp = ptr<double>(ctx->lrC); la.T = ptr<double>(ctx->lrT); la.tstride = (int64_t)P.npad * P.ldx; la.Ls = ptr<double>(ctx->lrL);
   la.rk = ptr<int>(ctx->wbRk); la.c = P.c; la.perm = ptr<int>(ctx->lrPerm); la.rg = rg; la.den0 = ptr<double>(ctx->lrDen0);
   la.skip_shared = 0;
-  la.seg = lr_segments(P.n);
+  la.seg = lr_segments(ctx, P.n);
   return la;
 }
 // LOD scan of one region on the current stream: the shared-weights class through the table kernel (one bin, 4 waves per
 // SIMD), the other traits through k_scan_lr.  BLMM_LR_LEAN=0: both classes in k_scan_lr (A/B testing).
 int lr_region_scan(blmm_ctx* ctx, const Pipe& P, const LrRegion& rg, double* dL, int64_t ldL) {
-  static const bool lean = !(getenv("BLMM_LR_LEAN") && getenv("BLMM_LR_LEAN")[0] == '0');
+  static const bool lean = !(dev_env("BLMM_LR_LEAN") && dev_env("BLMM_LR_LEAN")[0] == '0');
   // diagnostic: the scan kernels alone on the chip (their rocprofv3 durations are then free of the side streams' kernels)
-  static const bool serial = getenv("BLMM_LR_SERIAL") && getenv("BLMM_LR_SERIAL")[0] == '1';
+  static const bool serial = dev_env("BLMM_LR_SERIAL") && dev_env("BLMM_LR_SERIAL")[0] == '1';
   if (serial) { (void)hipStreamSynchronize(ctx->side); (void)hipStreamSynchronize(ctx->side2); (void)hipStreamSynchronize(ctx->stream); }
   LrArgs la = lr_args(ctx, P, rg, dL, ldL);
   int rc;
@@ -478,15 +487,16 @@ int lr_region_scan(blmm_ctx* ctx, const Pipe& P, const LrRegion& rg, double* dL,
 }
 // panels of one region on the current stream
 int lr_region_panels(blmm_ctx* ctx, const Pipe& P, const NullModel& nm, const double* dh2, const LrRegion& rg) {
-  return launch_lr_panels(ctx, nm, P.Yt, P.ldy, P.m, P.Z0, P.lam, dh2, ptr<double>(ctx->wbQ), ptr<int>(ctx->wbRk), lr_segments(P.n), ptr<int>(ctx->lrPerm),
+  return launch_lr_panels(ctx, nm, P.Yt, P.ldy, P.m, P.Z0, P.lam, dh2, ptr<double>(ctx->wbQ), ptr<int>(ctx->wbRk), lr_segments(ctx, P.n), ptr<int>(ctx->lrPerm),
                           rg, ptr<double>(ctx->panels), ptr<double>(ctx->lrC), ptr<double>(ctx->lrL), 2 * lr_ldq(P), P.stat);
 }
 int lr_region_resid(blmm_ctx* ctx, const Pipe& P, const NullModel& nm, const double* dh2, const LrRegion& rg) {
-  return launch_lr_resid(ctx, nm, P.m, lr_tolerance(), P.lam, dh2, ptr<double>(ctx->wbQ), ptr<int>(ctx->wbRk), lr_segments(P.n), ptr<int>(ctx->lrPerm), rg,
+  return launch_lr_resid(ctx, nm, P.m, lr_tolerance(ctx), P.lam, dh2, ptr<double>(ctx->wbQ), ptr<int>(ctx->wbRk), lr_segments(ctx, P.n), ptr<int>(ctx->lrPerm), rg,
                          ptr<double>(ctx->lrC), 2 * lr_ldq(P), ptr<int>(ctx->lrFlag), ptr<double>(ctx->lrPart), P.stat);
 }
 int lr_fix(blmm_ctx* ctx, const Pipe& P, const NullModel& nm, const double* dh2, double* dL, int64_t ldL) {
   // flagged traits (normally none: the kernel reads the count on the device and returns): full-length sums
+  if (ctx->red_cur.pmax) return BLMM_OK;   // reduce-in-epilogue: there is no L to patch -- reduced_impl() reads the count and re-runs
   return launch_scan_fix(ctx, nm, P.Xt, P.ldx, P.p, ptr<double>(ctx->panels), ptr<double>(ctx->lrL), 2 * lr_ldq(P), P.Z0, P.lam, dh2,
                          ptr<int>(ctx->lrFlag), ptr<int>(ctx->lrPerm), dL, ldL, P.stat);
 }
@@ -500,6 +510,7 @@ int illcond_rescan(blmm_ctx* ctx, const Pipe& P, const NullModel& nm, int64_t m,
   int rc = ensure(ctx, ctx->illList, sizeof(int) * (size_t)m);
   if (rc) return rc;
   if ((rc = launch_illcond_flag(ctx, nm, m, P.Z0, P.lam, dh2, ptr<int>(ctx->illList), P.stat))) return rc;
+  if (ctx->red_cur.pmax) return BLMM_OK;   // (as lr_fix)
   return launch_scan_qr(ctx, nm, P.Yt, P.ldy, P.Xt, P.ldx, P.p, P.Z0, P.lam, dh2, ptr<int>(ctx->illList), dL, ldL, P.stat);
 }
 
@@ -507,10 +518,10 @@ int illcond_rescan(blmm_ctx* ctx, const Pipe& P, const NullModel& nm, int64_t m,
 int lr_finish(blmm_ctx* ctx, const Pipe& P, const NullModel& nm, const double* dh2, double* dL, int64_t ldL, Timer& tm) {
   int rc;
   const LrRegion rg = lr_region(P, 0);
-  const LrSeg seg = lr_segments(P.n);
+  const LrSeg seg = lr_segments(ctx, P.n);
   hipStream_t main_stream = ctx->stream;
   BLMM_HIP(hipStreamWaitEvent(main_stream, ctx->ev_join, 0));
-  if ((rc = launch_lr_classify(ctx, P.n, P.m, lr_shared_tol(), P.lam, dh2, nullptr, nullptr, nullptr, ptr<int>(ctx->lrPerm), rg, seg))) return rc;
+  if ((rc = launch_lr_classify(ctx, P.n, P.m, lr_shared_tol(ctx), P.lam, dh2, nullptr, nullptr, nullptr, ptr<int>(ctx->lrPerm), rg, seg))) return rc;
   if ((rc = lr_region_panels(ctx, P, nm, dh2, rg))) return rc;
   tm.mark();
   // residual guard of the weight basis, every trait: side stream, beside the scan kernel; joined below
@@ -536,10 +547,10 @@ int lr_finish_split(blmm_ctx* ctx, const Pipe& P, const NullModel& nm, double* d
                     const BrentSplit& sp) {
   int rc;
   const LrRegion r0 = lr_region(P, 0), r1 = lr_region(P, 1);
-  const LrSeg seg = lr_segments(P.n);
+  const LrSeg seg = lr_segments(ctx, P.n);
   hipStream_t main_stream = ctx->stream;
   // ---- main stream: region 0's classification and panels (the weight basis is ready at ev_q, the marker-side products at ev_join) ...
-  if ((rc = launch_lr_classify(ctx, P.n, P.m, lr_shared_tol(), P.lam, dh2, sp.fin, nullptr, nullptr, ptr<int>(ctx->lrPerm), r0, seg))) return rc;
+  if ((rc = launch_lr_classify(ctx, P.n, P.m, lr_shared_tol(ctx), P.lam, dh2, sp.fin, nullptr, nullptr, ptr<int>(ctx->lrPerm), r0, seg))) return rc;
   BLMM_HIP(hipStreamWaitEvent(main_stream, ctx->ev_q, 0));
   if ((rc = lr_region_panels(ctx, P, nm, dh2, r0))) return rc;
   // ---- ... and only then the second side stream: the rest of the h2 search, then region 1's columns.  Forked right behind
@@ -551,7 +562,7 @@ int lr_finish_split(blmm_ctx* ctx, const Pipe& P, const NullModel& nm, double* d
   BrentSplit sp2 = sp;
   rc = launch_brent(ctx, nm, P.Yt, P.ldy, P.m, P.Z0, P.lam, dh2, nullptr, nullptr, P.stat, 2, &sp2);
   if (!rc && hipStreamWaitEvent(ctx->side2, ctx->ev_q, 0) != hipSuccess) rc = fail(ctx, BLMM_ERR_HIP, "hipStreamWaitEvent failed");
-  if (!rc) rc = launch_lr_classify(ctx, P.n, P.m, lr_shared_tol(), P.lam, dh2, nullptr, sp.list, sp.cnt, ptr<int>(ctx->lrPerm), r1, seg);
+  if (!rc) rc = launch_lr_classify(ctx, P.n, P.m, lr_shared_tol(ctx), P.lam, dh2, nullptr, sp.list, sp.cnt, ptr<int>(ctx->lrPerm), r1, seg);
   if (!rc) rc = lr_region_panels(ctx, P, nm, dh2, r1);
   ctx->stream = main_stream;
   if (rc) return rc;
@@ -669,7 +680,7 @@ void blmm_destroy(blmm_ctx* ctx) {
                     &ctx->iyy, &ctx->h2, &ctx->h2idx, &ctx->sig2, &ctx->ell, &ctx->isx, &ctx->stat, &ctx->gridd, &ctx->misc,
                     &ctx->EllTab, &ctx->inY, &ctx->inG, &ctx->inK, &ctx->inCov, &ctx->inW, &ctx->outL, &ctx->outH2,
                     &ctx->tmpA, &ctx->tmpB, &ctx->tmpC, &ctx->perm, &ctx->r0, &ctx->altbuf, &ctx->logtab, &ctx->lraw,
-                    &ctx->wbQ, &ctx->wbW, &ctx->wbRk, &ctx->lrT, &ctx->lrC, &ctx->lrL, &ctx->lrFlag, &ctx->lrPart, &ctx->lrPerm, &ctx->lrDen0, &ctx->eigW, &ctx->xf32, &ctx->pf32, &ctx->brSt, &ctx->brList, &ctx->illList, &ctx->qrSlab, &ctx->lodtab, &ctx->dynFac, &ctx->pvtab, &ctx->outP};
+                    &ctx->wbQ, &ctx->wbW, &ctx->wbRk, &ctx->lrT, &ctx->lrC, &ctx->lrL, &ctx->lrFlag, &ctx->lrPart, &ctx->lrPerm, &ctx->lrDen0, &ctx->eigW, &ctx->xf32, &ctx->pf32, &ctx->brSt, &ctx->brList, &ctx->illList, &ctx->qrSlab, &ctx->lodtab, &ctx->dynFac, &ctx->pvtab, &ctx->outP, &ctx->redbuf, &ctx->redtrip};
   for (DevBuf* b : bufs) if (b->p) hipFree(b->p);
   for (auto& s : ctx->evsets) for (auto& e : s.e) (void)hipEventDestroy(e);
   if (ctx->side) { (void)hipStreamSynchronize(ctx->side); (void)hipStreamDestroy(ctx->side); }
@@ -742,6 +753,35 @@ int blmm_lowrank_profile(blmm_ctx* ctx, int64_t* out) {
   return BLMM_OK;
 }
 
+// Diagnostic for tests that report WHERE in the data-dependent panel layout a trait sat (k_lr_classify: two regions split by the
+// h2 search's hand-over, in each the shared-weights class from the front and the weight-basis segments from the back): col_out[j] =
+// panel column of trait j in the last null-exact call (-1: none), *region_width = columns per region (region = col / width),
+// counts_out[4] = {shared-weights traits, columns of the other class} of region 0, then of region 1.
+int blmm_lowrank_columns(blmm_ctx* ctx, int64_t m, int32_t* col_out, int64_t* region_width, int64_t* counts_out) {
+  if (!ctx || !col_out || m < 0) return BLMM_ERR_INVALID;
+  for (int64_t j = 0; j < m; ++j) col_out[j] = -1;
+  if (region_width) *region_width = ctx->lr_last_ldq;
+  if (counts_out) for (int i = 0; i < 4; ++i) counts_out[i] = 0;
+  if (!ctx->lrPerm.p || !ctx->stat.p || ctx->lr_last_ldq <= 0) return BLMM_OK;
+  BLMM_HIP(hipSetDevice(ctx->device));
+  const int64_t ldq = ctx->lr_last_ldq;
+  std::vector<int> perm((size_t)(2 * ldq));
+  int64_t h[NSTAT];
+  BLMM_HIP(hipMemcpyAsync(perm.data(), ctx->lrPerm.p, sizeof(int) * perm.size(), hipMemcpyDeviceToHost, ctx->stream));
+  BLMM_HIP(hipMemcpyAsync(h, ctx->stat.p, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
+  BLMM_HIP(hipStreamSynchronize(ctx->stream));
+  for (int r = 0; r < 2; ++r) {
+    const int64_t nsh = h[12 + 2 * r], noth = h[13 + 2 * r];
+    if (counts_out) { counts_out[2 * r] = nsh; counts_out[2 * r + 1] = noth; }
+    for (int64_t cidx = 0; cidx < ldq; ++cidx) {
+      if (!(cidx < nsh || cidx >= ldq - noth)) continue;
+      const int t = perm[(size_t)(r * ldq + cidx)];
+      if (t >= 0 && t < m) col_out[t] = (int32_t)(r * ldq + cidx);
+    }
+  }
+  return BLMM_OK;
+}
+
 int blmm_synchronize(blmm_ctx* ctx) {
   if (!ctx) return BLMM_ERR_INVALID;
   BLMM_HIP(hipStreamSynchronize(ctx->stream));
@@ -753,6 +793,43 @@ void blmm_default_opts(blmm_opts* o) {
   std::memset(o, 0, sizeof(*o));
   o->method = BLMM_NULL_GRID; o->reml = 0; o->add_intercept = 1; o->decomp_scheme = BLMM_EIGEN;
   o->optim_interval = 1; o->compat_flags = 0; o->prior_variance = 1.0; o->prior_sample_size = 0.0;
+}
+
+// What selects another ARITHMETIC path is a property of the context, not of the caller's environment (blmm_internal.h: Tuning).
+static const struct { const char* key; int kind; size_t off; double lo, hi; } kTune[] = {
+  {"lr_tol", 0, offsetof(blmm::Tuning, lr_tol), 0.0, 1.0},
+  {"illcond_rho", 0, offsetof(blmm::Tuning, illcond_rho), 0.0, 1e300},
+  {"exact_full_rank", 1, offsetof(blmm::Tuning, exact_full_rank), 0, 1},
+  {"pval_libm", 1, offsetof(blmm::Tuning, pval_libm), 0, 1},
+  {"pval_fused", 1, offsetof(blmm::Tuning, pval_fused), 0, 1},
+  {"lr_segments", 1, offsetof(blmm::Tuning, lr_segments), 0, LR_SEG_MAX},
+  {"lr_shared", 1, offsetof(blmm::Tuning, lr_shared), 0, 1},
+  {"lr_split", 1, offsetof(blmm::Tuning, lr_split), -1, 1},
+  {"eigen_solver", 1, offsetof(blmm::Tuning, eigen_solver), 0, 2},
+};
+int blmm_set_tuning(blmm_ctx* ctx, const char* key, double value) {
+  if (!ctx) return BLMM_ERR_INVALID;
+  if (!key) return fail(ctx, BLMM_ERR_INVALID, "set_tuning: key is NULL");
+  if (std::strcmp(key, "defaults") == 0) { ctx->tune = blmm::Tuning(); return BLMM_OK; }
+  for (const auto& t : kTune)
+    if (std::strcmp(key, t.key) == 0) {
+      if (!(value >= t.lo && value <= t.hi) || (t.kind == 1 && value != std::floor(value)))
+        return fail(ctx, BLMM_ERR_INVALID, std::string("set_tuning: value out of range for ") + key);
+      char* base = reinterpret_cast<char*>(&ctx->tune) + t.off;
+      if (t.kind == 0) *reinterpret_cast<double*>(base) = value; else *reinterpret_cast<int*>(base) = (int)value;
+      return BLMM_OK;
+    }
+  return fail(ctx, BLMM_ERR_INVALID, std::string("set_tuning: unknown key ") + key);
+}
+int blmm_get_tuning(const blmm_ctx* ctx, const char* key, double* value) {
+  if (!ctx || !key || !value) return BLMM_ERR_INVALID;
+  for (const auto& t : kTune)
+    if (std::strcmp(key, t.key) == 0) {
+      const char* base = reinterpret_cast<const char*>(&ctx->tune) + t.off;
+      *value = t.kind == 0 ? *reinterpret_cast<const double*>(base) : (double)*reinterpret_cast<const int*>(base);
+      return BLMM_OK;
+    }
+  return BLMM_ERR_INVALID;
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -871,23 +948,36 @@ int blmm_get_thresholds(blmm_ctx* ctx, const double* Lperms, int64_t p, int64_t 
 // null-* method: the scan kernels write -log10 p from their epilogues (ScanArgs::Pv, set through ctx->pv_cur while they run);
 // otherwise (alt-grid: the LOD is only final after the last grid point; other degrees of freedom: incomplete gamma function)
 // the column pass of kernels_post.hip runs over the finished L, still inside the call.
+extern "C++" {
 namespace {
+// The request of blmm_set_log10p_output, TAKEN out of the context by the first statement of every bulkscan entry point: whatever
+// that call then does -- fail its argument checks, fail in prepare, succeed -- the context is disarmed, so a later unrelated call
+// can never write to a stale pointer.
+struct PvReq { bool armed = false; double* out = nullptr; int64_t ld = 0, df = 1; };
+PvReq pv_take(blmm_ctx* ctx) {
+  PvReq r; r.armed = ctx->pv_armed; r.out = ctx->pv_out; r.ld = ctx->pv_ld; r.df = ctx->pv_df;
+  ctx->pv_armed = false; ctx->pv_out = nullptr; ctx->pv_ld = 0; ctx->pv_df = 1;
+  return r;
+}
+void pv_hand_over(blmm_ctx* ctx, const PvReq& r) {   // host-pointer entry point -> the *_dev call it makes next
+  ctx->pv_armed = r.armed; ctx->pv_out = r.out; ctx->pv_ld = r.ld; ctx->pv_df = r.df;
+}
 struct PvCall {
-  blmm_ctx* ctx; double* P = nullptr; int64_t ld = 0, df = 1; bool fused = false, owned = false;
-  explicit PvCall(blmm_ctx* c) : ctx(c) {}
+  blmm_ctx* ctx; PvReq req; double* P = nullptr; int64_t ld = 0, df = 1; bool fused = false, owned = false;
+  PvCall(blmm_ctx* c, const PvReq& r) : ctx(c), req(r) {}
   ~PvCall() { ctx->pv_cur = nullptr; ctx->pv_cur_ld = 0; }
   int begin(const Pipe& Pp, const blmm_opts* o) {
-    if (!ctx->pv_armed) return BLMM_OK;
-    ctx->pv_armed = false;
+    if (!req.armed) return BLMM_OK;
     if (Pp.p <= 0 || Pp.m <= 0) return BLMM_OK;
-    df = ctx->pv_df; P = ctx->pv_out; ld = ctx->pv_ld;
+    df = req.df; P = req.out; ld = req.ld;
     if (P && ld < Pp.p) { P = nullptr; return fail(ctx, BLMM_ERR_INVALID, "log10p output: ldP < p"); }
     if (!P) {
       int rc = ensure(ctx, ctx->outP, sizeof(double) * (size_t)Pp.p * (size_t)Pp.m);
       if (rc) return rc;
       P = ptr<double>(ctx->outP); ld = Pp.p; owned = true;
     }
-    fused = df == 1 && o->method != BLMM_ALT_GRID && !(getenv("BLMM_PVAL_FUSED") && getenv("BLMM_PVAL_FUSED")[0] == '0');
+    const char* pf = dev_env("BLMM_PVAL_FUSED");             // tuning key "pval_fused"
+    fused = df == 1 && o->method != BLMM_ALT_GRID && (pf ? pf[0] != '0' : ctx->tune.pval_fused != 0);
     if (fused) { ctx->pv_cur = P; ctx->pv_cur_ld = ld; }
     return BLMM_OK;
   }
@@ -900,6 +990,7 @@ struct PvCall {
   }
 };
 }  // namespace
+}  // extern "C++"
 
 // marker norms of every grid point; on the side stream behind the marker rotation when prepare() put that there (P.xt_side), then
 // joined into the main stream: the scan that follows needs both
@@ -919,12 +1010,13 @@ static int isx_maybe_side(blmm_ctx* ctx, const Pipe& P, const NullModel& nm, con
 }
 
 static int scan_pipeline(blmm_ctx* ctx, const blmm_opts* opts, Pipe& P, Timer& tm, bool lowrank, bool wbasis_started, double* dgrid,
-                         const double* h2_grid_host, int64_t ngrid, double* dL_out, int64_t ldL, double* dh2_out, blmm_status* status) {
+                         const double* h2_grid_host, int64_t ngrid, double* dL_out, int64_t ldL, double* dh2_out, blmm_status* status,
+                         const PvReq& pvreq) {
   int rc;
   const int64_t m = P.m, p = P.p;
   const NullModel nm = null_model(P, opts);
   const int64_t ldp = P.ldy;
-  PvCall pvc(ctx);
+  PvCall pvc(ctx, pvreq);
   if ((rc = pvc.begin(P, opts))) return rc;
   if (m == 0) { tm.mark(); tm.mark(); tm.mark(); return end_call(ctx, P, status, &tm); }
   if (p == 0) {
@@ -948,8 +1040,8 @@ static int scan_pipeline(blmm_ctx* ctx, const blmm_opts* opts, Pipe& P, Timer& t
       // ... when there are enough traits for two regions (BLMM_LR_SPLIT unset): below ~8 k each region's scan is a few dispatch rounds
       // with their ramps, and one region wins (m = 4445, a rank's share of the BXD problem on 8 GPUs: 0.651 against 0.677 ms per
       // step; m = 8889: 0.777 against 0.776; m = 35554: the split is worth 2.7 %).  BLMM_LR_SPLIT=1: always
-      const char* split_env = getenv("BLMM_LR_SPLIT");                // (read per call: tests hold the two forms against each other)
-      const bool split_on = split_env ? split_env[0] != '0' : m >= 8192;
+      const char* split_env = dev_env("BLMM_LR_SPLIT");                // tuning key "lr_split" (tests hold the two forms against each other)
+      const bool split_on = split_env ? split_env[0] != '0' : (ctx->tune.lr_split < 0 ? m >= 8192 : ctx->tune.lr_split != 0);
       BrentSplit sp;
       if ((rc = launch_brent(ctx, nm, P.Yt, P.ldy, m, P.Z0, P.lam, dh2_out, nullptr, nullptr, P.stat, split_on ? 1 : 0, &sp))) return rc;
       tm.mark();
@@ -1028,14 +1120,25 @@ int blmm_set_log10p_output(blmm_ctx* ctx, double* dP_out, int64_t ldP, int64_t c
   return BLMM_OK;
 }
 
-int blmm_bulkscan_dev(blmm_ctx* ctx, const blmm_opts* opts, const double* dY, int64_t n, int64_t m, const double* dG,
-                      int64_t p, const double* dCovar, int64_t ncov, const double* dK, const double* dweights,
-                      const double* h2_grid_host, int64_t ngrid, double* dL_out, int64_t ldL, double* dh2_out,
-                      blmm_status* status) {
-  if (!ctx) return BLMM_ERR_INVALID;
+// null-exact runs the low-rank weights form (kernels_lowrank.hip) unless BLMM_EXACT=full (A/B testing), c >= 4 (the
+// kernel would spill) or n is beyond what the basis kernel keeps in LDS
+static bool exact_full(const blmm_ctx* ctx) {   // tuning key "exact_full_rank"
+  const char* e = dev_env("BLMM_EXACT");
+  return e ? std::strcmp(e, "full") == 0 : ctx->tune.exact_full_rank != 0;
+}
+static bool wants_lowrank(const blmm_ctx* ctx, const blmm_opts* opts, int64_t n, const double* dCovar, int64_t ncov) {
+  const int c_eff = (int)((ncov == 0 || !dCovar) ? 1 : ncov + (opts->add_intercept ? 1 : 0));
+  return opts->method == BLMM_NULL_EXACT && !exact_full(ctx) && c_eff <= 3 && n <= 6000;
+}
+
+// dL_out == nullptr: only with ctx->red_cur set (blmm_bulkscan_reduced: the scan kernels reduce in their epilogues)
+static int bulkscan_dev_impl(blmm_ctx* ctx, const blmm_opts* opts, const double* dY, int64_t n, int64_t m, const double* dG,
+                             int64_t p, const double* dCovar, int64_t ncov, const double* dK, const double* dweights,
+                             const double* h2_grid_host, int64_t ngrid, double* dL_out, int64_t ldL, double* dh2_out,
+                             blmm_status* status, const PvReq& pvreq) {
   int rc = check_opts(ctx, opts);
   if (rc) return rc;
-  if (!dY || !dG || !dK || !dL_out || !dh2_out) return fail(ctx, BLMM_ERR_INVALID, "bulkscan: NULL buffer");
+  if (!dY || !dG || !dK || (!dL_out && !ctx->red_cur.pmax) || !dh2_out) return fail(ctx, BLMM_ERR_INVALID, "bulkscan: NULL buffer");
   if (ldL < p) return fail(ctx, BLMM_ERR_INVALID, "bulkscan: ldL < p");
   if (opts->method != BLMM_NULL_EXACT && opts->method != BLMM_NULL_GRID && opts->method != BLMM_ALT_GRID)
     return fail(ctx, BLMM_ERR_METHOD, "Unknown method; choose null-exact, null-grid or alt-grid.");
@@ -1047,14 +1150,91 @@ int blmm_bulkscan_dev(blmm_ctx* ctx, const blmm_opts* opts, const double* dY, in
   if (opts->method != BLMM_NULL_EXACT) {
     if ((rc = grid_to_device(ctx, h2_grid_host, ngrid, &dgrid))) return rc;
   }
-  // null-exact runs the low-rank weights form (kernels_lowrank.hip) unless BLMM_EXACT=full (A/B testing), c = 4 (the
-  // kernel would spill) or n is beyond what the basis kernel keeps in LDS
-  const char* exact_env = getenv("BLMM_EXACT");
-  const int c_eff = (int)((ncov == 0 || !dCovar) ? 1 : ncov + (opts->add_intercept ? 1 : 0));
-  const bool lowrank = opts->method == BLMM_NULL_EXACT && !(exact_env && std::strcmp(exact_env, "full") == 0) &&
-                       c_eff <= 3 && n <= 6000;
+  const bool lowrank = wants_lowrank(ctx, opts, n, dCovar, ncov);
   if ((rc = prepare(ctx, opts, dY, n, m, dG, p, dCovar, ncov, dK, dweights, 1, P, tm, lowrank, opts->method != BLMM_NULL_EXACT))) return rc;
-  return scan_pipeline(ctx, opts, P, tm, lowrank, /*wbasis_started*/ lowrank && m > 0 && p > 0, dgrid, h2_grid_host, ngrid, dL_out, ldL, dh2_out, status);
+  return scan_pipeline(ctx, opts, P, tm, lowrank, /*wbasis_started*/ lowrank && m > 0 && p > 0, dgrid, h2_grid_host, ngrid, dL_out, ldL, dh2_out, status, pvreq);
+}
+
+int blmm_bulkscan_dev(blmm_ctx* ctx, const blmm_opts* opts, const double* dY, int64_t n, int64_t m, const double* dG,
+                      int64_t p, const double* dCovar, int64_t ncov, const double* dK, const double* dweights,
+                      const double* h2_grid_host, int64_t ngrid, double* dL_out, int64_t ldL, double* dh2_out,
+                      blmm_status* status) {
+  if (!ctx) return BLMM_ERR_INVALID;
+  const PvReq pvreq = pv_take(ctx);
+  ctx->red_cur = RedArgs();
+  return bulkscan_dev_impl(ctx, opts, dY, n, m, dG, p, dCovar, ncov, dK, dweights, h2_grid_host, ngrid, dL_out, ldL, dh2_out, status, pvreq);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// bulkscan without the LOD matrix (include/bulklmm_hip.h: blmm_bulkscan_reduced).  `out` holds DEVICE pointers here.
+// Native route (null-grid; null-exact in the low-rank weights form): the scan kernels' reduce-in-epilogue instantiations write
+// per-(trait, 64-marker slot) partial maxima and the triplets, k_red_final finishes the maxima -- L is never written.  The rare
+// per-trait re-scans (k_scan_fix: expansion residual of the weight basis; k_scan_qr: ill-conditioned weighted covariates) patch
+// columns of a stored L, which does not exist here: the route SPECULATES that no trait is flagged, reads the two device counts at
+// the end, and when one is non-zero -- or the method / covariate count has no fused instantiation (alt-grid, c >= 4, BLMM_EXACT=full)
+// -- the call runs once more into the context's resident L and reduces it with k_colmax / k_threshold (the same values by
+// construction).  Synchronises the stream before it returns.
+static int reduced_impl(blmm_ctx* ctx, const blmm_opts* opts, const double* dY, int64_t n, int64_t m, const double* dG, int64_t p,
+                        const double* dCovar, int64_t ncov, const double* dK, const double* dweights, const double* h2_grid_host,
+                        int64_t ngrid, const blmm_reduced* out, double* dh2_out, blmm_status* status, int* route_out) {
+  int rc = check_opts(ctx, opts);
+  if (rc) return rc;
+  if (!out || !dY || !dG || !dK || (!dh2_out && opts->method != BLMM_ALT_GRID)) return fail(ctx, BLMM_ERR_INVALID, "bulkscan_reduced: NULL buffer");
+  if (out->cap < 0 || (out->cap > 0 && (!out->ti || !out->tj || !out->tlod)) || (out->want_triplets && !out->count))
+    return fail(ctx, BLMM_ERR_INVALID, "bulkscan_reduced: triplet buffers");
+  if (opts->method != BLMM_NULL_EXACT && opts->method != BLMM_NULL_GRID && opts->method != BLMM_ALT_GRID)
+    return fail(ctx, BLMM_ERR_METHOD, "Unknown method; choose null-exact, null-grid or alt-grid.");
+  if (n < 1 || m < 0 || p < 0 || p > 0x7fffffffLL || m > 0x7fffffffLL) return fail(ctx, BLMM_ERR_DIM, "Dimension mismatch.");
+  BLMM_HIP(hipSetDevice(ctx->device));
+  const bool native = p > 0 && m > 0 && (opts->method == BLMM_NULL_GRID || wants_lowrank(ctx, opts, n, dCovar, ncov));
+  if (route_out) *route_out = 0;
+  if (native) {
+    const int nslot = 2 * (int)((p + 127) / 128);
+    const int64_t ldm = round_up(m, 64);
+    if ((rc = ensure(ctx, ctx->redbuf, (sizeof(double) + sizeof(int)) * (size_t)nslot * (size_t)ldm))) return rc;
+    RedArgs r;
+    r.pmax = ptr<double>(ctx->redbuf); r.parg = reinterpret_cast<int*>(r.pmax + (size_t)nslot * ldm); r.ldm = ldm;
+    r.want_trip = out->want_triplets ? 1 : 0; r.thr = out->thr; r.cap = out->cap;
+    r.ti = out->ti; r.tj = out->tj; r.tl = out->tlod; r.cnt = reinterpret_cast<unsigned long long*>(out->count);
+    if (out->count) BLMM_HIP(hipMemsetAsync(out->count, 0, sizeof(int64_t), ctx->stream));
+    ctx->red_cur = r;
+    rc = bulkscan_dev_impl(ctx, opts, dY, n, m, dG, p, dCovar, ncov, dK, dweights, h2_grid_host, ngrid, nullptr, p, dh2_out, status, PvReq());
+    ctx->red_cur = RedArgs();
+    if (rc) { (void)hipStreamSynchronize(ctx->stream); return rc; }
+    if ((rc = launch_red_final(ctx, r, nslot, m, out->colmax, out->argmax))) return rc;
+    int64_t h[NSTAT];
+    BLMM_HIP(hipMemcpyAsync(h, ctx->stat.p, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
+    BLMM_HIP(hipStreamSynchronize(ctx->stream));
+    if ((rc = check_sticky(ctx))) return rc;
+    if (h[10] == 0 && h[ST_ILLCOND] == 0) { if (route_out) *route_out = 1; return BLMM_OK; }
+  }
+  // through a resident L
+  if ((rc = ensure(ctx, ctx->outL, sizeof(double) * (size_t)(p > 0 ? p : 1) * (size_t)(m > 0 ? m : 1)))) return rc;
+  double* dL = ptr<double>(ctx->outL);
+  double* dH = dh2_out;
+  if (opts->method == BLMM_ALT_GRID) {      // h2_panel (p x m) is not part of the reduced result: into the workspace
+    if ((rc = ensure(ctx, ctx->altbuf, sizeof(double) * (size_t)(p > 0 ? p : 1) * (size_t)(m > 0 ? m : 1)))) return rc;
+    dH = ptr<double>(ctx->altbuf);
+  }
+  if ((rc = bulkscan_dev_impl(ctx, opts, dY, n, m, dG, p, dCovar, ncov, dK, dweights, h2_grid_host, ngrid, dL, p > 0 ? p : 1, dH, status, PvReq()))) {
+    (void)hipStreamSynchronize(ctx->stream);
+    return rc;
+  }
+  if (m > 0) { ctx->last_L = dL; ctx->last_p = p; ctx->last_m = m; ctx->last_f32 = false; }
+  if (out->colmax && m > 0 && (rc = launch_colmax(ctx, dL, p, m, p > 0 ? p : 1, out->colmax, out->argmax))) return rc;
+  if (out->want_triplets && (rc = launch_threshold(ctx, dL, p, m, p > 0 ? p : 1, out->thr, out->cap, out->ti, out->tj, out->tlod, out->count))) return rc;
+  BLMM_HIP(hipStreamSynchronize(ctx->stream));
+  if (route_out) *route_out = 2;
+  return check_sticky(ctx);
+}
+
+int blmm_bulkscan_reduced_dev(blmm_ctx* ctx, const blmm_opts* opts, const double* dY, int64_t n, int64_t m, const double* dG,
+                              int64_t p, const double* dCovar, int64_t ncov, const double* dK, const double* dweights,
+                              const double* h2_grid_host, int64_t ngrid, const blmm_reduced* out, double* dh2_out,
+                              blmm_status* status) {
+  if (!ctx) return BLMM_ERR_INVALID;
+  (void)pv_take(ctx);
+  return reduced_impl(ctx, opts, dY, n, m, dG, p, dCovar, ncov, dK, dweights, h2_grid_host, ngrid, out, dh2_out, status, &ctx->last_reduced_route);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -1085,6 +1265,14 @@ int blmm_prepare_dev(blmm_ctx* ctx, const blmm_opts* opts, int64_t n, const doub
   return end_call(ctx, P, status, &tm);
 }
 
+// The state blmm_prepare_dev left, with the device pointers taken from the workspace as it is NOW (never from the copy)
+static Pipe prepared_pipe(blmm_ctx* ctx) {
+  Pipe P = ctx->prep;
+  P.Z0 = ptr<double>(ctx->Z0); P.lam = ptr<double>(ctx->lam); P.stat = ptr<int64_t>(ctx->stat);
+  P.Yt = nullptr; P.Xt = nullptr;
+  return P;
+}
+
 int64_t blmm_rotated_rows(const blmm_ctx* ctx) { return (ctx && ctx->prep_valid) ? ctx->prep.npad : 0; }
 
 int blmm_rotate_block_dev(blmm_ctx* ctx, const double* dG_block, int64_t pb, double* dXt_block, int64_t ld) {
@@ -1092,7 +1280,7 @@ int blmm_rotate_block_dev(blmm_ctx* ctx, const double* dG_block, int64_t pb, dou
   if (!ctx->prep_valid) return fail(ctx, BLMM_ERR_INVALID, "rotate_block: blmm_prepare_dev has not run on this context");
   if (!dG_block || !dXt_block || pb < 0 || ld < pb) return fail(ctx, BLMM_ERR_INVALID, "rotate_block: bad arguments");
   BLMM_HIP(hipSetDevice(ctx->device));
-  const Pipe& P = ctx->prep;
+  const Pipe P = prepared_pipe(ctx);
   return launch_rotate(ctx, ptr<double>(ctx->Rp), P.ldr, P.n, P.npad, dG_block, pb, dXt_block, ld, ld);
 }
 
@@ -1118,6 +1306,7 @@ int blmm_bulkscan_prerotated_dev(blmm_ctx* ctx, const blmm_opts* opts, const dou
                                  const double* h2_grid_host, int64_t ngrid, double* dL_out, int64_t ldL, double* dh2_out,
                                  blmm_status* status) {
   if (!ctx) return BLMM_ERR_INVALID;
+  const PvReq pvreq = pv_take(ctx);
   int rc = check_opts(ctx, opts);
   if (rc) return rc;
   if (!ctx->prep_valid) return fail(ctx, BLMM_ERR_INVALID, "bulkscan_prerotated: blmm_prepare_dev has not run on this context");
@@ -1130,7 +1319,7 @@ int blmm_bulkscan_prerotated_dev(blmm_ctx* ctx, const blmm_opts* opts, const dou
   BLMM_HIP(hipSetDevice(ctx->device));
   if ((rc = check_sticky(ctx))) return rc;
   Timer tm(ctx);
-  Pipe P = ctx->prep;
+  Pipe P = prepared_pipe(ctx);
   double* dgrid = nullptr;
   if (opts->method != BLMM_NULL_EXACT) {
     if ((rc = grid_to_device(ctx, h2_grid_host, ngrid, &dgrid))) return rc;
@@ -1141,51 +1330,65 @@ int blmm_bulkscan_prerotated_dev(blmm_ctx* ctx, const blmm_opts* opts, const dou
   ctx->audit_ran = false;
   ctx->brent_cnt_used = false;
   tm.mark(); tm.mark();
-  const char* exact_env = getenv("BLMM_EXACT");
-  const bool lowrank = opts->method == BLMM_NULL_EXACT && !(exact_env && std::strcmp(exact_env, "full") == 0) && P.c <= 3;
+  const bool lowrank = opts->method == BLMM_NULL_EXACT && !exact_full(ctx) && P.c <= 3;
   if (lowrank && m > 0 && p > 0 && (rc = start_wbasis(ctx, P))) return rc;
   if ((rc = rotate_traits(ctx, P, dY, m))) return rc;
   if ((rc = assemble_prerotated(ctx, P, p, dXt_blocks, nblocks, block_cols, block_ld))) return rc;
   tm.mark();
-  return scan_pipeline(ctx, opts, P, tm, lowrank, lowrank && m > 0 && p > 0, dgrid, h2_grid_host, ngrid, dL_out, ldL, dh2_out, status);
+  return scan_pipeline(ctx, opts, P, tm, lowrank, lowrank && m > 0 && p > 0, dgrid, h2_grid_host, ngrid, dL_out, ldL, dh2_out, status, pvreq);
 }
 
+// host inputs of a bulkscan call -> the context's input buffers (asynchronous on the context's stream)
+static int upload_bulk_inputs(blmm_ctx* ctx, const double* Y, int64_t n, int64_t m, const double* G, int64_t p, const double* Covar,
+                              int64_t ncov, const double* K, const double* weights, const double** dCov, const double** dW) {
+  int rc;
+  if ((rc = ensure(ctx, ctx->inY, sizeof(double) * n * (m > 0 ? m : 1)))) return rc;
+  if ((rc = ensure(ctx, ctx->inG, sizeof(double) * n * (p > 0 ? p : 1)))) return rc;
+  if ((rc = ensure(ctx, ctx->inK, sizeof(double) * n * n))) return rc;
+  BLMM_HIP(hipMemcpyAsync(ctx->inY.p, Y, sizeof(double) * n * m, hipMemcpyHostToDevice, ctx->stream));
+  BLMM_HIP(hipMemcpyAsync(ctx->inG.p, G, sizeof(double) * n * p, hipMemcpyHostToDevice, ctx->stream));
+  BLMM_HIP(hipMemcpyAsync(ctx->inK.p, K, sizeof(double) * n * n, hipMemcpyHostToDevice, ctx->stream));
+  *dCov = nullptr; *dW = nullptr;
+  if (Covar && ncov > 0) {
+    if ((rc = ensure(ctx, ctx->inCov, sizeof(double) * n * ncov))) return rc;
+    BLMM_HIP(hipMemcpyAsync(ctx->inCov.p, Covar, sizeof(double) * n * ncov, hipMemcpyHostToDevice, ctx->stream));
+    *dCov = ptr<double>(ctx->inCov);
+  }
+  if (weights) {
+    if ((rc = ensure(ctx, ctx->inW, sizeof(double) * n))) return rc;
+    BLMM_HIP(hipMemcpyAsync(ctx->inW.p, weights, sizeof(double) * n, hipMemcpyHostToDevice, ctx->stream));
+    *dW = ptr<double>(ctx->inW);
+  }
+  return BLMM_OK;
+}
+
+// L_out == NULL: the matrix stays in HBM (2.08 GB at BXD size: 36 of the call's 39 ms are its trip over PCIe) and the blmm_last_*
+// consumers serve it -- peaks, LOD > t triplets, permutation quantiles, -log10 p, single columns (README.md:246-255, 354-359;
+// src/analysis_helpers/single_trait_analysis.jl:13-23 are what the reference's users do with L).  alt-grid: h2_out (the p x m
+// h2_panel) may be NULL likewise.
 int blmm_bulkscan(blmm_ctx* ctx, const blmm_opts* opts, const double* Y, int64_t n, int64_t m, const double* G, int64_t p,
                   const double* Covar, int64_t ncov, const double* K, const double* weights, const double* h2_grid,
                   int64_t ngrid, double* L_out, double* h2_out, blmm_status* status) {
   if (!ctx) return BLMM_ERR_INVALID;
+  const PvReq pvreq = pv_take(ctx);
   if (!opts) return fail(ctx, BLMM_ERR_INVALID, "opts is NULL");
-  if (!Y || !G || !K || !L_out || !h2_out) return fail(ctx, BLMM_ERR_INVALID, "bulkscan: NULL buffer");
+  const bool alt = opts->method == BLMM_ALT_GRID;
+  if (!Y || !G || !K || (!h2_out && !alt)) return fail(ctx, BLMM_ERR_INVALID, "bulkscan: NULL buffer");
   if (n < 1 || m < 0 || p < 0) return fail(ctx, BLMM_ERR_DIM, "Dimension mismatch.");
   BLMM_HIP(hipSetDevice(ctx->device));
   int rc;
-  const bool alt = opts->method == BLMM_ALT_GRID;
   const size_t h2_elems = alt ? (size_t)p * m : (size_t)m;
-  if ((rc = ensure(ctx, ctx->inY, sizeof(double) * n * (m > 0 ? m : 1)))) return rc;
-  if ((rc = ensure(ctx, ctx->inG, sizeof(double) * n * (p > 0 ? p : 1)))) return rc;
-  if ((rc = ensure(ctx, ctx->inK, sizeof(double) * n * n))) return rc;
   if ((rc = ensure(ctx, ctx->outL, sizeof(double) * (size_t)p * m))) return rc;
   if ((rc = ensure(ctx, ctx->outH2, sizeof(double) * h2_elems))) return rc;
   // BLMM_HOST_PROF=1: wall-clock of the call's legs on stderr (diagnostic: it synchronises between them)
   static const bool hprof = getenv("BLMM_HOST_PROF") && getenv("BLMM_HOST_PROF")[0] == '1';
   auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
   const double hp0 = hprof ? now() : 0.0;
-  BLMM_HIP(hipMemcpyAsync(ctx->inY.p, Y, sizeof(double) * n * m, hipMemcpyHostToDevice, ctx->stream));
-  BLMM_HIP(hipMemcpyAsync(ctx->inG.p, G, sizeof(double) * n * p, hipMemcpyHostToDevice, ctx->stream));
-  BLMM_HIP(hipMemcpyAsync(ctx->inK.p, K, sizeof(double) * n * n, hipMemcpyHostToDevice, ctx->stream));
   const double* dCov = nullptr; const double* dW = nullptr;
-  if (Covar && ncov > 0) {
-    if ((rc = ensure(ctx, ctx->inCov, sizeof(double) * n * ncov))) return rc;
-    BLMM_HIP(hipMemcpyAsync(ctx->inCov.p, Covar, sizeof(double) * n * ncov, hipMemcpyHostToDevice, ctx->stream));
-    dCov = ptr<double>(ctx->inCov);
-  }
-  if (weights) {
-    if ((rc = ensure(ctx, ctx->inW, sizeof(double) * n))) return rc;
-    BLMM_HIP(hipMemcpyAsync(ctx->inW.p, weights, sizeof(double) * n, hipMemcpyHostToDevice, ctx->stream));
-    dW = ptr<double>(ctx->inW);
-  }
+  if ((rc = upload_bulk_inputs(ctx, Y, n, m, G, p, Covar, ncov, K, weights, &dCov, &dW))) return rc;
   if (hprof) (void)hipStreamSynchronize(ctx->stream);
   const double hp1 = hprof ? now() : 0.0;
+  pv_hand_over(ctx, pvreq);
   rc = blmm_bulkscan_dev(ctx, opts, ptr<double>(ctx->inY), n, m, ptr<double>(ctx->inG), p, dCov, dCov ? ncov : 0,
                          ptr<double>(ctx->inK), dW, h2_grid, ngrid, ptr<double>(ctx->outL), p, ptr<double>(ctx->outH2), status);
   if (rc) { hipStreamSynchronize(ctx->stream); return rc; }
@@ -1193,15 +1396,67 @@ int blmm_bulkscan(blmm_ctx* ctx, const blmm_opts* opts, const double* Y, int64_t
   if (hprof) (void)hipStreamSynchronize(ctx->stream);
   const double hp3 = hprof ? now() : 0.0;
   ctx->last_L = ptr<double>(ctx->outL); ctx->last_p = p; ctx->last_m = m; ctx->last_f32 = false;
-  if ((size_t)p * m > 0 && (rc = copy_to_host(ctx, L_out, ctx->outL.p, sizeof(double) * (size_t)p * m))) return rc;
+  if (L_out && (size_t)p * m > 0 && (rc = copy_to_host(ctx, L_out, ctx->outL.p, sizeof(double) * (size_t)p * m))) return rc;
   const double hp4 = hprof ? now() : 0.0;
-  if (h2_elems > 0 && (rc = copy_to_host(ctx, h2_out, ctx->outH2.p, sizeof(double) * h2_elems))) return rc;
+  if (h2_out && h2_elems > 0 && (rc = copy_to_host(ctx, h2_out, ctx->outH2.p, sizeof(double) * h2_elems))) return rc;
   BLMM_HIP(hipStreamSynchronize(ctx->stream));
   if (hprof)
     fprintf(stderr, "blmm_bulkscan legs (ms): uploads %.2f | enqueue %.2f | device %.2f | L to host %.2f | h2 to host + sync %.2f\n", hp1 - hp0, hp2 - hp1,
             hp3 - hp2, hp4 - hp3, now() - hp4);
   return check_sticky(ctx);   // a device-side failure of THIS call (no status passed): reported now, not by the next call
 }
+
+// host-pointer form of the reduce-in-epilogue scan: `out` holds HOST pointers; the small results come back, nothing p x m moves
+int blmm_bulkscan_reduced(blmm_ctx* ctx, const blmm_opts* opts, const double* Y, int64_t n, int64_t m, const double* G, int64_t p,
+                          const double* Covar, int64_t ncov, const double* K, const double* weights, const double* h2_grid,
+                          int64_t ngrid, const blmm_reduced* out, double* h2_out, blmm_status* status) {
+  if (!ctx) return BLMM_ERR_INVALID;
+  (void)pv_take(ctx);
+  if (!opts) return fail(ctx, BLMM_ERR_INVALID, "opts is NULL");
+  const bool alt = opts->method == BLMM_ALT_GRID;
+  if (!out || !Y || !G || !K || (!h2_out && !alt)) return fail(ctx, BLMM_ERR_INVALID, "bulkscan_reduced: NULL buffer");
+  if (out->cap < 0 || (out->cap > 0 && (!out->ti || !out->tj || !out->tlod)) || (out->want_triplets && !out->count))
+    return fail(ctx, BLMM_ERR_INVALID, "bulkscan_reduced: triplet buffers");
+  if (n < 1 || m < 0 || p < 0) return fail(ctx, BLMM_ERR_DIM, "Dimension mismatch.");
+  BLMM_HIP(hipSetDevice(ctx->device));
+  int rc;
+  const int64_t cap = out->cap > 0 ? out->cap : 0, mm = m > 0 ? m : 1;
+  // device side of `out`: maxima / arg-maxima (tmpA / tmpB), triplets + count (redtrip), h2 (outH2)
+  if ((rc = ensure(ctx, ctx->tmpA, sizeof(double) * (size_t)mm))) return rc;
+  if ((rc = ensure(ctx, ctx->tmpB, sizeof(int64_t) * (size_t)mm))) return rc;
+  if ((rc = ensure(ctx, ctx->redtrip, (sizeof(double) + 2 * sizeof(int32_t)) * (size_t)(cap > 0 ? cap : 1) + 64))) return rc;
+  if ((rc = ensure(ctx, ctx->outH2, sizeof(double) * (size_t)mm))) return rc;
+  blmm_reduced d = *out;
+  d.colmax = (out->colmax || out->argmax) ? ptr<double>(ctx->tmpA) : nullptr;
+  d.argmax = out->argmax ? ptr<int64_t>(ctx->tmpB) : nullptr;
+  d.count = ptr<int64_t>(ctx->redtrip);
+  d.tlod = reinterpret_cast<double*>(d.count + 8);
+  d.ti = reinterpret_cast<int32_t*>(d.tlod + (cap > 0 ? cap : 1));
+  d.tj = d.ti + (cap > 0 ? cap : 1);
+  const double* dCov = nullptr; const double* dW = nullptr;
+  if ((rc = upload_bulk_inputs(ctx, Y, n, m, G, p, Covar, ncov, K, weights, &dCov, &dW))) return rc;
+  if ((rc = reduced_impl(ctx, opts, ptr<double>(ctx->inY), n, m, ptr<double>(ctx->inG), p, dCov, dCov ? ncov : 0, ptr<double>(ctx->inK), dW,
+                         h2_grid, ngrid, &d, ptr<double>(ctx->outH2), status, &ctx->last_reduced_route))) return rc;
+  if (m > 0) {
+    if (out->colmax) BLMM_HIP(hipMemcpyAsync(out->colmax, d.colmax, sizeof(double) * (size_t)m, hipMemcpyDeviceToHost, ctx->stream));
+    if (out->argmax) BLMM_HIP(hipMemcpyAsync(out->argmax, d.argmax, sizeof(int64_t) * (size_t)m, hipMemcpyDeviceToHost, ctx->stream));
+    if (h2_out && !alt) BLMM_HIP(hipMemcpyAsync(h2_out, ctx->outH2.p, sizeof(double) * (size_t)m, hipMemcpyDeviceToHost, ctx->stream));
+  }
+  if (out->want_triplets) {
+    BLMM_HIP(hipMemcpyAsync(out->count, d.count, sizeof(int64_t), hipMemcpyDeviceToHost, ctx->stream));
+    BLMM_HIP(hipStreamSynchronize(ctx->stream));
+    const int64_t got = *out->count < cap ? *out->count : cap;
+    if (got > 0) {
+      BLMM_HIP(hipMemcpyAsync(out->tlod, d.tlod, sizeof(double) * (size_t)got, hipMemcpyDeviceToHost, ctx->stream));
+      BLMM_HIP(hipMemcpyAsync(out->ti, d.ti, sizeof(int32_t) * (size_t)got, hipMemcpyDeviceToHost, ctx->stream));
+      BLMM_HIP(hipMemcpyAsync(out->tj, d.tj, sizeof(int32_t) * (size_t)got, hipMemcpyDeviceToHost, ctx->stream));
+    }
+  }
+  BLMM_HIP(hipStreamSynchronize(ctx->stream));
+  return check_sticky(ctx);
+}
+
+int blmm_last_reduced_route(const blmm_ctx* ctx) { return ctx ? ctx->last_reduced_route : 0; }
 
 // ---------------------------------------------------------------------------------------------------
 // dLperms_out (fp64) or dLperms32_out (fp32, kernels_scan_f32.hip): exactly one of them when nperms > 0
@@ -1308,7 +1563,7 @@ int blmm_scan_perms_prerotated_dev(blmm_ctx* ctx, const blmm_opts* opts, const d
   BLMM_HIP(hipSetDevice(ctx->device));
   if ((rc = check_sticky(ctx))) return rc;
   Timer tm(ctx);
-  Pipe P = ctx->prep;
+  Pipe P = prepared_pipe(ctx);
   BLMM_HIP(hipMemsetAsync(P.stat + 1, 0, sizeof(int64_t) * 4, ctx->stream));
   BLMM_HIP(hipMemsetAsync(P.stat + 8, 0, sizeof(int64_t) * (NSTAT - 8), ctx->stream));
   ctx->audit_ran = false;
@@ -1571,6 +1826,7 @@ namespace {
 int upload_rotated(blmm_ctx* ctx, const double* Y0, int64_t n, int64_t m, const double* Z0, int64_t c, const double* X0m,
                    int64_t p, const double* lambda, Pipe& P) {
   if (n < 1 || m < 1 || c < 1 || c > CMAX || c >= n) return fail(ctx, BLMM_ERR_DIM, "Dimension mismatch.");
+  ctx->prep_valid = false;   // Z0 / lambda / the status block of a blmm_prepare_dev are overwritten below
   P.n = (int)n; P.c = (int)c; P.npad = (int)round_up(n, 8); P.ldr = (int)round_up(P.npad, 16);
   P.m = m; P.p = p; P.ldy = round_up(m, 128); P.ldx = round_up(p > 0 ? p : 1, 128);
   int rc;
@@ -1676,8 +1932,7 @@ int blmm_liteqtl_given_h2(blmm_ctx* ctx, const double* Y0, int64_t n, int64_t m,
   if ((rc = ensure(ctx, ctx->outL, sizeof(double) * (size_t)p * m))) return rc;
   // the same kernel choice as bulkscan(method = null-exact): low-rank weights form with its residual guard unless
   // BLMM_EXACT=full, c = 4 or n beyond the basis kernel
-  const char* exact_env = getenv("BLMM_EXACT");
-  if (!(exact_env && std::strcmp(exact_env, "full") == 0) && P.c <= 3 && n <= 6000) {
+  if (!exact_full(ctx) && P.c <= 3 && n <= 6000) {
     Timer tm(ctx);
     if ((rc = lr_begin(ctx, P, /*wbasis_started*/ false))) return rc;
     if ((rc = lr_finish(ctx, P, nm, ptr<double>(ctx->h2), ptr<double>(ctx->outL), p, tm))) return rc;

@@ -3,6 +3,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include <string>
 #include <vector>
 #include "../../include/bulklmm_hip.h"
@@ -31,6 +32,27 @@ enum StatIdx { ST_NEG_EIG = 0, ST_NONPOS_W = 1, ST_ZERO_NORM = 2, ST_NAN_LOD = 3
 
 inline int64_t round_up(int64_t x, int64_t q) { return (x + q - 1) / q * q; }
 
+// BLMM_* environment switches are DEVELOPER switches (A/B timing, diagnostics): the library reads them only when BLMM_DEV_ENV=1 is
+// set as well, so that a caller's environment can never silently select another code path.  What changes the arithmetic of a
+// result is a property of the context instead: blmm_set_tuning (include/bulklmm_hip.h); under BLMM_DEV_ENV=1 the old variable
+// names still override it (tools/*.sh).
+inline const char* dev_env(const char* name) {
+  const char* on = getenv("BLMM_DEV_ENV");
+  return (on && on[0] == '1') ? getenv(name) : nullptr;
+}
+// blmm_set_tuning / blmm_get_tuning (keys = the field names)
+struct Tuning {
+  double lr_tol = 1e-13;        // residual |w - QQ'w| / |w| above which a trait's column is re-scanned full rank; tolerance of the shared-weights class (0: every trait flagged, class empty)
+  double illcond_rho = 1e-4;    // pivot-share threshold of the conditioning guard (0: off; 2: every trait with c >= 2 re-scanned)
+  int exact_full_rank = 0;      // 1: null-exact through the full-rank kernel k_scan<NX = 1 + c> instead of the low-rank weights form
+  int pval_libm = 0;            // 1: -log10 p through erfc / erfcx / log instead of the bucketed polynomials (df = 1)
+  int pval_fused = 1;           // 0: output_pvals as a column pass over the finished L instead of the scan epilogues
+  int lr_segments = 0;          // 0: default (six segments of the heritability axis for n <= 80); 1: one weight basis; 2..8: that many equal segments
+  int lr_shared = 1;            // 0: no shared-weights class (every trait through the rank-R form)
+  int lr_split = -1;            // -1: split the h2 search into two panel regions from 8192 traits on; 0 / 1: never / always
+  int eigen_solver = 0;         // 0: by n (fast path + Jacobi up to 124, tridiagonalisation + divide and conquer beyond); 1: Jacobi; 2: divide and conquer
+};
+
 struct DevBuf {
   void* p = nullptr;
   size_t cap = 0;
@@ -46,6 +68,16 @@ struct Pipe {
   bool xt_side = false;            // the marker rotation was enqueued on the side stream (in front of the weight basis): Xt is ordered there
 };
 
+// Reduce-in-epilogue output of the scan kernels (blmm_bulkscan_reduced; SURVEY.md N1: "the matrix never has to leave HBM" -- here
+// it is never WRITTEN): instead of a lane's four LODs of one trait going to L, the 16 lanes of the MFMA row reduce them to the
+// trait's (maximum, marker) over the wave's 64 markers -> pmax / parg [slot = first marker / 64][ldm], finished by k_red_final;
+// and every LOD > thr becomes a (marker, trait, LOD) triplet behind a device counter.  Same values, same tie rule (lowest marker)
+// and same NaN rule (never the maximum, never > thr) as k_colmax / k_threshold on a stored L: the results are bit-identical.
+struct RedArgs {
+  double* pmax = nullptr; int* parg = nullptr; int64_t ldm = 0;
+  int want_trip = 0; double thr = 0.0; int64_t cap = 0;
+  int32_t* ti = nullptr; int32_t* tj = nullptr; double* tl = nullptr; unsigned long long* cnt = nullptr;
+};
 }  // namespace blmm
 
 namespace blmm { struct HostStage; }
@@ -58,7 +90,7 @@ struct blmm_ctx {
   std::string err;
   // grow-only workspace
   blmm::DevBuf Ks, V, lam, U, Zs, Z0, Rp, Yt, Xt, panels, iyy, h2, h2idx, sig2, ell, isx, stat, gridd, misc, EllTab,
-      inY, inG, inK, inCov, inW, outL, outH2, tmpA, tmpB, tmpC, perm, r0, altbuf, logtab, lraw, wbQ, wbW, wbRk, lrT, lrC, lrL, lrFlag, lrPart, lrPerm, lrDen0, eigW, xf32, pf32, brSt, brList, illList, qrSlab, lodtab, dynFac, pvtab, outP;
+      inY, inG, inK, inCov, inW, outL, outH2, tmpA, tmpB, tmpC, perm, r0, altbuf, logtab, lraw, wbQ, wbW, wbRk, lrT, lrC, lrL, lrFlag, lrPart, lrPerm, lrDen0, eigW, xf32, pf32, brSt, brList, illList, qrSlab, lodtab, dynFac, pvtab, outP, redbuf, redtrip;
   // event sets: one per timed call since the last blmm_read_timings (grown on demand, reused afterwards)
   struct EvSet { hipEvent_t e[8]; int n; };
   std::vector<EvSet> evsets;
@@ -78,6 +110,11 @@ struct blmm_ctx {
   bool pv_armed = false; double* pv_out = nullptr; int64_t pv_ld = 0, pv_df = 1;
   double* pv_cur = nullptr; int64_t pv_cur_ld = 0;
   const double* last_P = nullptr; int64_t last_P_ld = 0, last_P_df = 0;
+  // blmm_bulkscan_reduced: set while that call's scan kernels run (blmm_api.hip: scan_args); last_reduced_route: 1 = the
+  // reduce-in-epilogue kernels stood, 2 = through a resident L (no fused instantiation, or a trait needed a re-scan)
+  blmm::RedArgs red_cur; int last_reduced_route = 0;
+  blmm::Tuning tune;                   // blmm_set_tuning
+  int64_t lr_last_ldq = 0, lr_last_m = 0;   // panel-region width / trait count of the last low-rank null-exact scan (blmm_lowrank_columns)
   blmm::Pipe prep; bool prep_valid = false;   // state left by blmm_prepare_dev for blmm_rotate_block_dev / blmm_bulkscan_prerotated_dev
   bool brent_cnt_used = false;         // the current call has run a split h2 search already (its counter in the status block is spent)
   bool audit_ran = false;              // the current call ran the BLMM_FLAG_H2_AUDIT pass (finish_status: n_h2_multimodal, else -1)
@@ -214,7 +251,12 @@ struct ScanArgs {
   // pval_table.h.  Kernels without the fused form (alt-grid, fp32 permutations, the rare per-trait re-scans) leave Pv to a
   // column pass over the finished L (launch_lod2log10p / launch_pv_list).
   double* Pv = nullptr; int64_t ldPv = 0; const double* pvtab = nullptr;
+  RedArgs red;                             // red.pmax != nullptr: the reduce-in-epilogue instantiation runs and L is not touched
 };
+// kernels_post.hip: threshold triplets of a resident L; the second pass of the reduce-in-epilogue scan (RedArgs partials -> per trait)
+int launch_threshold(blmm_ctx* ctx, const double* dL, int64_t p, int64_t m, int64_t ldL, double thr, int64_t cap,
+                     int32_t* di, int32_t* dj, double* dlod, int64_t* dcount);
+int launch_red_final(blmm_ctx* ctx, const RedArgs& r, int nslot, int64_t m, double* mx, int64_t* arg);
 int launch_scan_exact(blmm_ctx* ctx, const ScanArgs& a, int c);
 // A region of the panel arrays of the low-rank form: columns [col0, col0 + ncol), the shared-weights class at its front
 // (counts[0] traits) and the other class at its back (counts[1]); counts live on the device.
@@ -295,7 +337,7 @@ int launch_scan_qr(blmm_ctx* ctx, const NullModel& nm, const double* Yt, int64_t
                    const double* Z0, const double* lam, const double* h2, const int* list, double* L, int64_t ldL, int64_t* stat);
 // kernels_lowrank.hip
 // the segments a call with n individuals uses (one when the basis comes from the multi-workgroup / LDS kernels: n > 80)
-LrSeg lr_segments(int n);
+LrSeg lr_segments(const blmm_ctx* ctx, int n);
 int launch_wbasis(blmm_ctx* ctx, const double* lam, int n, int npad, const LrSeg& seg, double* Wk, double* Q, int* rk, int64_t* stat);
 int launch_lr_tpanels(blmm_ctx* ctx, const double* Xt, int64_t ldx, int64_t p, int n, int c, int npad, const double* Z0,
                       const double* Q, const int* rk, const LrSeg& seg, double* T, int64_t tstride, double* den0);

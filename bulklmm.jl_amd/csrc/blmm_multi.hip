@@ -17,6 +17,7 @@
 //                runs as R-1 direct hipMemcpyPeerAsync copies per device instead.
 #include "blmm_internal.h"
 #include <condition_variable>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <dlfcn.h>
@@ -236,7 +237,9 @@ int blmm_bulkscan_multi(blmm_multi* mc, const blmm_opts* opts, const blmm_multi_
   if (gather != BLMM_GATHER_NONE && gather != BLMM_GATHER_HOST_SHARDS && gather != BLMM_GATHER_ALLGATHER)
     return mfail(mc, BLMM_ERR_INVALID, "unknown gather_mode");
   if (!Y || !G || !K) return mfail(mc, BLMM_ERR_INVALID, "bulkscan: NULL buffer");
-  if (gather == BLMM_GATHER_HOST_SHARDS && (!L_out || !h2_out)) return mfail(mc, BLMM_ERR_INVALID, "bulkscan: NULL output buffer");
+  // host_shards with L_out == NULL: every device keeps its block in its context's workspace (blmm_bulkscan with L_out == NULL) and
+  // blmm_multi_last_colmax / blmm_multi_last_lod_threshold reduce the blocks where they are
+  if (gather == BLMM_GATHER_HOST_SHARDS && !h2_out && opts->method != BLMM_ALT_GRID) return mfail(mc, BLMM_ERR_INVALID, "bulkscan: NULL output buffer");
   if (n < 1 || m < 0 || p < 0) return mfail(mc, BLMM_ERR_DIM, "Dimension mismatch.");
   DeviceRestore keep_device;
   const int R = mc->ndev;
@@ -250,9 +253,11 @@ int blmm_bulkscan_multi(blmm_multi* mc, const blmm_opts* opts, const blmm_multi_
       int64_t lo, hi;
       blmm_multi_shard(m, r, R, &lo, &hi);
       return blmm_bulkscan(mc->ctx[r], opts, Y + (size_t)lo * n, n, hi - lo, G, p, Covar, ncov, K, weights, h2_grid, ngrid,
-                           L_out + (size_t)lo * p, alt ? h2_out + (size_t)lo * p : h2_out + lo, status ? status + r : nullptr);
+                           L_out ? L_out + (size_t)lo * p : nullptr, !h2_out ? nullptr : (alt ? h2_out + (size_t)lo * p : h2_out + lo),
+                           status ? status + r : nullptr);
     });
-    mc->last_gather = gather;
+    mc->last_gather = gather; mc->last_m = m; mc->last_p = p; mc->last_block = blk; mc->last_method = opts->method;
+    if (getenv("BLMM_MULTI_LOG")) fprintf(stderr, "blmm_bulkscan_multi: %d devices, gather host_shards%s, rc %d\n", R, L_out ? "" : " (L stays in HBM)", rc);
     return rc;
   }
 
@@ -299,11 +304,12 @@ int blmm_bulkscan_multi(blmm_multi* mc, const blmm_opts* opts, const blmm_multi_
   if (rc) return rc;
   mc->last_m = m; mc->last_p = p; mc->last_block = blk; mc->last_gather = gather; mc->last_method = opts->method;
 
-  const char* env = getenv("BLMM_ALLGATHER");   // "peer": direct copies; "rccl": RCCL even for a single device (tests)
+  const char* env = dev_env("BLMM_ALLGATHER");   // "peer": direct copies; "rccl": RCCL even for a single device (tests)
   const bool force_rccl = env && std::strcmp(env, "rccl") == 0;
   if (full && (R > 1 || force_rccl) && blk > 0 && p > 0) {
     const size_t cntL = (size_t)blk * p, cntH = alt ? (size_t)blk * p : (size_t)blk;
     const bool want_peer = (env && std::strcmp(env, "peer") == 0) || !distinct_devices(mc);
+    if (getenv("BLMM_MULTI_LOG")) fprintf(stderr, "blmm_bulkscan_multi: %d devices, all-gather through %s (%zu doubles per block)\n", R, want_peer ? "hipMemcpyPeerAsync" : "RCCL ncclAllGather", cntL);
     if (!want_peer) {
       if ((rc = load_rccl(mc))) return rc;   // no silent fallback: a missing / failing RCCL is the caller's to know
       // in-place all-gather: device r's block already sits at slot r of its own full-size buffer
@@ -361,6 +367,86 @@ int blmm_bulkscan_multi(blmm_multi* mc, const blmm_opts* opts, const blmm_multi_
       if (rc) return rc;
     }
   }
+  return BLMM_OK;
+}
+
+// ---- consumers of the blocks where they are (no gather, nothing p x m crosses PCIe): per-trait maxima and threshold triplets
+// of the LAST blmm_bulkscan_multi call, whatever its gather mode.  Column / trait indices are global (0 .. m-1).
+static int block_source(blmm_multi* mc, int r, const double** dL, int64_t* lo, int64_t* hi) {
+  blmm_multi_shard(mc->last_m, r, mc->ndev, lo, hi);
+  if (mc->last_gather == BLMM_GATHER_HOST_SHARDS) {
+    *dL = mc->ctx[r]->last_L;
+    if (*hi > *lo && (!*dL || mc->ctx[r]->last_m != *hi - *lo || mc->ctx[r]->last_p != mc->last_p)) return BLMM_ERR_INVALID;
+  } else {
+    const int64_t off = mc->last_gather == BLMM_GATHER_ALLGATHER ? *lo : 0;
+    *dL = blmm::ptr<double>(mc->dL[r]) + (size_t)off * mc->last_p;
+  }
+  return BLMM_OK;
+}
+
+int blmm_multi_last_colmax(blmm_multi* mc, double* max_out, int64_t* argmax_out) {
+  using namespace blmm;
+  if (!mc || !max_out) return BLMM_ERR_INVALID;
+  if (mc->last_gather < 0) return mfail(mc, BLMM_ERR_INVALID, "multi_last_colmax: no previous blmm_bulkscan_multi call");
+  DeviceRestore keep_device;
+  return on_all(mc, [&](int r) -> int {
+    blmm_ctx* ctx = mc->ctx[r];
+    const double* dL; int64_t lo, hi;
+    if (block_source(mc, r, &dL, &lo, &hi)) return fail(ctx, BLMM_ERR_INVALID, "multi_last_colmax: the block of the last call is no longer resident");
+    if (hi <= lo) return BLMM_OK;
+    BLMM_HIP(hipSetDevice(ctx->device));
+    int e;
+    if ((e = ensure(ctx, ctx->tmpA, sizeof(double) * (size_t)(hi - lo)))) return e;
+    if ((e = ensure(ctx, ctx->tmpB, sizeof(int64_t) * (size_t)(hi - lo)))) return e;
+    if ((e = launch_colmax(ctx, dL, mc->last_p, hi - lo, mc->last_p > 0 ? mc->last_p : 1, ptr<double>(ctx->tmpA), ptr<int64_t>(ctx->tmpB)))) return e;
+    BLMM_HIP(hipMemcpyAsync(max_out + lo, ctx->tmpA.p, sizeof(double) * (size_t)(hi - lo), hipMemcpyDeviceToHost, ctx->stream));
+    if (argmax_out) BLMM_HIP(hipMemcpyAsync(argmax_out + lo, ctx->tmpB.p, sizeof(int64_t) * (size_t)(hi - lo), hipMemcpyDeviceToHost, ctx->stream));
+    BLMM_HIP(hipStreamSynchronize(ctx->stream));
+    return BLMM_OK;
+  });
+}
+
+int blmm_multi_last_lod_threshold(blmm_multi* mc, double thr, int64_t cap, int32_t* i_out, int32_t* j_out, double* lod_out, int64_t* count_out) {
+  using namespace blmm;
+  if (!mc || !count_out || cap < 0 || (cap > 0 && (!i_out || !j_out || !lod_out))) return BLMM_ERR_INVALID;
+  if (mc->last_gather < 0) return mfail(mc, BLMM_ERR_INVALID, "multi_last_lod_threshold: no previous blmm_bulkscan_multi call");
+  DeviceRestore keep_device;
+  const int R = mc->ndev;
+  // every device filters its block with the whole cap; the host concatenates in device order up to cap
+  std::vector<std::vector<int32_t>> vi(R), vj(R); std::vector<std::vector<double>> vl(R); std::vector<int64_t> cnt(R, 0);
+  int rc = on_all(mc, [&](int r) -> int {
+    blmm_ctx* ctx = mc->ctx[r];
+    const double* dL; int64_t lo, hi;
+    if (block_source(mc, r, &dL, &lo, &hi)) return fail(ctx, BLMM_ERR_INVALID, "multi_last_lod_threshold: the block of the last call is no longer resident");
+    if (hi <= lo || mc->last_p <= 0) return BLMM_OK;
+    BLMM_HIP(hipSetDevice(ctx->device));
+    const int64_t c1 = cap > 0 ? cap : 1;
+    int e;
+    if ((e = ensure(ctx, ctx->redtrip, (sizeof(double) + 2 * sizeof(int32_t)) * (size_t)c1 + 64))) return e;
+    int64_t* dcount = ptr<int64_t>(ctx->redtrip);
+    double* dl = reinterpret_cast<double*>(dcount + 8);
+    int32_t* di = reinterpret_cast<int32_t*>(dl + c1); int32_t* dj = di + c1;
+    if ((e = launch_threshold(ctx, dL, mc->last_p, hi - lo, mc->last_p, thr, cap, di, dj, dl, dcount))) return e;
+    BLMM_HIP(hipMemcpyAsync(&cnt[r], dcount, sizeof(int64_t), hipMemcpyDeviceToHost, ctx->stream));
+    BLMM_HIP(hipStreamSynchronize(ctx->stream));
+    const int64_t got = cnt[r] < cap ? cnt[r] : cap;
+    if (got > 0) {
+      vi[r].resize(got); vj[r].resize(got); vl[r].resize(got);
+      BLMM_HIP(hipMemcpyAsync(vl[r].data(), dl, sizeof(double) * (size_t)got, hipMemcpyDeviceToHost, ctx->stream));
+      BLMM_HIP(hipMemcpyAsync(vi[r].data(), di, sizeof(int32_t) * (size_t)got, hipMemcpyDeviceToHost, ctx->stream));
+      BLMM_HIP(hipMemcpyAsync(vj[r].data(), dj, sizeof(int32_t) * (size_t)got, hipMemcpyDeviceToHost, ctx->stream));
+      BLMM_HIP(hipStreamSynchronize(ctx->stream));
+      for (auto& j : vj[r]) j += (int32_t)lo;
+    }
+    return BLMM_OK;
+  });
+  if (rc) return rc;
+  int64_t total = 0, at = 0;
+  for (int r = 0; r < R; ++r) {
+    total += cnt[r];
+    for (size_t k = 0; k < vi[r].size() && at < cap; ++k, ++at) { i_out[at] = vi[r][k]; j_out[at] = vj[r][k]; lod_out[at] = vl[r][k]; }
+  }
+  *count_out = total;
   return BLMM_OK;
 }
 

@@ -102,7 +102,7 @@ static bool is_pinned(const void* p) {
 // Device -> caller memory on ctx->stream's order; returns when the bytes are in place.
 int copy_to_host(blmm_ctx* ctx, void* dst, const void* dsrc, size_t bytes) {
   if (bytes == 0) return BLMM_OK;
-  const char* mode = getenv("BLMM_D2H");   // "plain": one hipMemcpyAsync whatever the destination (A/B timing)
+  const char* mode = dev_env("BLMM_D2H");   // "plain": one hipMemcpyAsync whatever the destination (A/B timing)
   if (bytes < ((size_t)8 << 20) || is_pinned(dst) || (mode && std::strcmp(mode, "plain") == 0)) {
     BLMM_HIP(hipMemcpyAsync(dst, dsrc, bytes, hipMemcpyDeviceToHost, ctx->stream));
     BLMM_HIP(hipStreamSynchronize(ctx->stream));
@@ -119,7 +119,7 @@ int copy_to_host(blmm_ctx* ctx, void* dst, const void* dsrc, size_t bytes) {
     }
     unsigned hw = std::thread::hardware_concurrency();
     int nt = hw >= 16 ? 7 : (hw >= 8 ? 3 : 1);
-    if (const char* e = getenv("BLMM_D2H_THREADS")) nt = std::max(0, atoi(e) - 1);
+    if (const char* e = dev_env("BLMM_D2H_THREADS")) nt = std::max(0, atoi(e) - 1);
     hs->pool = new CopyPool(nt);
     ctx->hstage = hs;
   }

@@ -842,17 +842,17 @@ int launch_dyn_perm(blmm_ctx* ctx, const NullModel& nm, const double* Yt, int64_
   return BLMM_OK;
 }
 
-double illcond_rho_min() {
-  // BLMM_ILLCOND_RHO overrides the threshold (tests: 2 flags every trait with c >= 2, so that the QR-grade kernel is compared
-  // with the oracle as a whole; 0 switches the guard off)
-  const char* e = getenv("BLMM_ILLCOND_RHO");
-  return e ? atof(e) : 1e-4;
+double illcond_rho_min(const blmm_ctx* ctx) {
+  // tuning key "illcond_rho" (tests: 2 flags every trait with c >= 2, so that the QR-grade kernel is compared with the oracle
+  // as a whole; 0 switches the guard off)
+  const char* e = dev_env("BLMM_ILLCOND_RHO");
+  return e ? atof(e) : ctx->tune.illcond_rho;
 }
 
 int launch_illcond_flag(blmm_ctx* ctx, const NullModel& nm, int64_t m, const double* Z0, const double* lam, const double* h2,
                         int* list, int64_t* stat) {
   if (m <= 0 || nm.c < 2) return BLMM_OK;
-  const double rho = illcond_rho_min();
+  const double rho = illcond_rho_min(ctx);
   if (!(rho > 0.0)) return BLMM_OK;
   const unsigned blocks = (unsigned)((m + 255) / 256);
   const size_t lds = sizeof(double) * (size_t)nm.n * (1 + nm.c);
@@ -878,7 +878,7 @@ int launch_illcond_flag(blmm_ctx* ctx, const NullModel& nm, int64_t m, const dou
 int launch_scan_qr(blmm_ctx* ctx, const NullModel& nm, const double* Yt, int64_t ldy, const double* Xt, int64_t ldx, int64_t p,
                    const double* Z0, const double* lam, const double* h2, const int* list, double* L, int64_t ldL,
                    int64_t* stat) {
-  if (p <= 0 || nm.c < 2 || !(illcond_rho_min() > 0.0)) return BLMM_OK;
+  if (p <= 0 || nm.c < 2 || !(illcond_rho_min(ctx) > 0.0)) return BLMM_OK;
   const size_t per = (size_t)(nm.c + 2) * nm.n;
   const unsigned grid = (unsigned)(2 * (ctx->num_cus > 0 ? ctx->num_cus : 256));
   double* slab = nullptr;

@@ -1355,7 +1355,7 @@ int launch_eig_dc(blmm_ctx* ctx, const double* A, int n, double* lraw, double* e
   // a merge level of tiny nodes costs ~50 us since the secular solver stops on LAPACK's test.  The number of leaves is a power
   // of two; tools/sweep_leaf.sh over n = 130 .. 1400 with bounds 6 .. 32: leaves of 6-12 rows are best or tied everywhere
   // (n = 500: eigen 2.83 ms at <= 12, 2.86 at <= 24, 3.02 at <= 32; n = 300: 1.74 / 1.78 / 1.77) (BLMM_EIG_LEAF: A/B testing)
-  static const int leaf_env = getenv("BLMM_EIG_LEAF") ? atoi(getenv("BLMM_EIG_LEAF")) : 0;
+  static const int leaf_env = dev_env("BLMM_EIG_LEAF") ? atoi(dev_env("BLMM_EIG_LEAF")) : 0;
   const int leaf = (leaf_env >= 2 && leaf_env <= LEAF) ? leaf_env : 12;
   int nl = 1;
   while ((n + nl - 1) / nl > leaf) nl *= 2;
@@ -1412,12 +1412,12 @@ int launch_eig_dc(blmm_ctx* ctx, const double* A, int n, double* lraw, double* e
     int nloc = (int)(budget / (sizeof(double) * (size_t)n));
     int G = nloc >= 1 ? (n + nloc - 1) / nloc : cus + 1;
     // the rows of a workgroup in global memory when the LDS cannot hold them with one workgroup per CU (BLMM_SYTRD_GLB=1: always)
-    const bool glb = G > cus || (getenv("BLMM_SYTRD_GLB") && getenv("BLMM_SYTRD_GLB")[0] == '1');
+    const bool glb = G > cus || (dev_env("BLMM_SYTRD_GLB") && dev_env("BLMM_SYTRD_GLB")[0] == '1');
     if (glb) G = 1;
     // ~10 rows per workgroup measured best (n = 500: 3.6 ms at G = 48 against 4.0 at the LDS minimum of 16; tools/sweep_sytrd.sh)
     const int Gmin = G;
     if ((n + 9) / 10 > G) G = std::min(cus, (n + 9) / 10);
-    if (const char* ge = getenv("BLMM_SYTRD_G")) { const int gv = atoi(ge); if (gv >= Gmin && gv <= cus) G = gv; }
+    if (const char* ge = dev_env("BLMM_SYTRD_G")) { const int gv = atoi(ge); if (gv >= Gmin && gv <= cus) G = gv; }
     nloc = (n + G - 1) / G;
     const size_t lds = sizeof(double) * ((size_t)7 * n + 128 + (glb ? 0 : (size_t)nloc * n));
     double* Aw = Qa;                          // G * nloc * n <= n^2 + G n doubles: the two Q buffers are unused until the leaves
@@ -1429,7 +1429,7 @@ int launch_eig_dc(blmm_ctx* ctx, const double* A, int n, double* lraw, double* e
     BLMM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sytrd<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     BLMM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sytrd<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     int nthr = 512;                                           // barriers at 1024 threads cost almost twice as much
-    if (const char* te = getenv("BLMM_SYTRD_NT")) { const int tv = atoi(te); if (tv == 256 || tv == 512) nthr = tv; }
+    if (const char* te = dev_env("BLMM_SYTRD_NT")) { const int tv = atoi(te); if (tv == 256 || tv == 512) nthr = tv; }
     auto launch = [&]() {
       if (glb) hipLaunchKernelGGL(k_sytrd<true>, dim3(G), dim3(nthr), lds, ctx->stream, A, n, nloc, d, e, tau, V, ex, stat, Aw);
       else hipLaunchKernelGGL(k_sytrd<false>, dim3(G), dim3(nthr), lds, ctx->stream, A, n, nloc, d, e, tau, V, ex, stat, Aw);
@@ -1454,7 +1454,7 @@ int launch_eig_dc(blmm_ctx* ctx, const double* A, int n, double* lraw, double* e
   // ---- 3. merges ----
   DcWs w;
   w.tnorm = rho + nnodes_total;
-  { const char* de = getenv("BLMM_DC_DEFLATE"); w.serial_deflate = (de && de[0] == 's') ? 1 : 0; }   // read per call: a test flips it
+  { const char* de = dev_env("BLMM_DC_DEFLATE"); w.serial_deflate = (de && de[0] == 's') ? 1 : 0; }   // read per call: a test flips it
   w.n = n; w.e = e; w.Dm = Dm; w.Wt = Wt; w.dl = dl; w.zl = zl; w.zh = zh; w.defld = defld; w.lamnew = lamnew;
   w.rotc = rotc; w.rots = rots; w.colidx = colidx; w.deflcol = deflcol; w.rota = rota; w.rotb = rotb; w.posn = posn; w.posd = posd;
   double* lamIn = lamA; double* lamOut = lamB; double* Qin = Qa; double* Qout = Qb;
@@ -1496,7 +1496,7 @@ int launch_eig_dc(blmm_ctx* ctx, const double* A, int n, double* lraw, double* e
   {
     const size_t lds = sizeof(double) * (size_t)2 * (4 * n + 4);     // 2 buffers x (RB = 4 reflectors + their tau)
     const int nr = (n + 63) / 64;
-    static const bool bt_wide = getenv("BLMM_BT_WIDE") && getenv("BLMM_BT_WIDE")[0] == '1';
+    static const bool bt_wide = dev_env("BLMM_BT_WIDE") && dev_env("BLMM_BT_WIDE")[0] == '1';
 #define BT(NR)                                                                                                             \
   do {                                                                                                                     \
     /* one column per wave, four waves per workgroup: the kernel is VALU-issue bound per SIMD (~110 instructions per        \

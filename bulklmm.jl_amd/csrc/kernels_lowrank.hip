@@ -457,13 +457,13 @@ __global__ void __launch_bounds__(1024) k_wbasis_mw(const double* __restrict__ l
 // Segments of the heritability axis (LrSeg): only the register-resident basis kernel builds several bases (n <= 80: the BXD case);
 // BLMM_LR_SEGMENTS=1: a single basis everywhere (A/B testing), =2..8: that many equal segments.  The default edges keep every
 // segment's rank at 11-12 on the BXD kinship spectrum (tools: see DESIGN §4.1).
-LrSeg lr_segments(int n) {
+LrSeg lr_segments(const blmm_ctx* ctx, int n) {
   LrSeg sg;
-  static const char* mw_env = getenv("BLMM_WBASIS");
-  static const char* wide_env = getenv("BLMM_LR_PANELS_WIDE");
-  static const int nb_env = getenv("BLMM_LR_PANELS_BATCH") ? atoi(getenv("BLMM_LR_PANELS_BATCH")) : 0;
-  const char* se = getenv("BLMM_LR_SEGMENTS");       // read per call: tests compare segmented and single-basis results in one process
-  const int want = se ? atoi(se) : 0;
+  static const char* mw_env = dev_env("BLMM_WBASIS");
+  static const char* wide_env = dev_env("BLMM_LR_PANELS_WIDE");
+  static const int nb_env = dev_env("BLMM_LR_PANELS_BATCH") ? atoi(dev_env("BLMM_LR_PANELS_BATCH")) : 0;
+  const char* se = dev_env("BLMM_LR_SEGMENTS");       // read per call: tests compare segmented and single-basis results in one process
+  const int want = se ? atoi(se) : ctx->tune.lr_segments;   // tuning key "lr_segments"
   if (n > 80 || n < 8 || want == 1 || (mw_env && std::strcmp(mw_env, "lds") == 0) || (wide_env && wide_env[0] == '0') || nb_env > 1) return sg;
   if (want >= 2 && want <= LR_SEG_MAX) {
     sg.S = want;
@@ -484,7 +484,7 @@ int launch_wbasis(blmm_ctx* ctx, const double* lam, int n, int npad, const LrSeg
   int ns = 0;
   for (int cand : {256, 192, 128})
     if (work + row * (size_t)(cand + 16) + row * 16 <= budget) { ns = cand; break; }
-  static const char* mw_env = getenv("BLMM_WBASIS");   // "single": never take the multi-workgroup variant; "lds": never the register one (A/B testing)
+  static const char* mw_env = dev_env("BLMM_WBASIS");   // "single": never take the multi-workgroup variant; "lds": never the register one (A/B testing)
   if (n <= 80 && !(mw_env && std::strcmp(mw_env, "lds") == 0)) {
     // sample columns in registers (20 per lane; 32 for n <= 128 would spill at 1024 threads)
     const int qcap = (int)std::min<size_t>(WB_QCAP, (budget - work) / row);
@@ -1348,11 +1348,11 @@ int launch_lr_panels(blmm_ctx* ctx, const NullModel& nm, const double* Yt, int64
   // halve the staging per trait (BLMM_LR_PANELS_NT: A/B testing)
   // 16 lanes per trait at every n (BXD shape: prep 0.143 -> 0.122 ms, step -2.7 %; n = 500 shard: 0.42 -> 0.23 ms for the
   // kernel); BLMM_LR_PANELS_WIDE=0: one thread per trait (A/B testing)
-  static const char* wide_env = getenv("BLMM_LR_PANELS_WIDE");
+  static const char* wide_env = dev_env("BLMM_LR_PANELS_WIDE");
   if (!(wide_env && wide_env[0] == '0')) {
     constexpr int LPT = 16;
     const int64_t wgroups = (rg.ncol + (256 / LPT) - 1) / (256 / LPT);
-    static const int nb_env = getenv("BLMM_LR_PANELS_BATCH") ? atoi(getenv("BLMM_LR_PANELS_BATCH")) : 0;
+    static const int nb_env = dev_env("BLMM_LR_PANELS_BATCH") ? atoi(dev_env("BLMM_LR_PANELS_BATCH")) : 0;
     const int ncu = ctx->num_cus > 0 ? ctx->num_cus : 256;
     (void)ncu;
     const int nbatch = (nb_env > 0 && seg.S == 1) ? nb_env : 1;   // BXD shape, prep phase: 0.109 ms at 1, 0.106 at 2, 0.113 at 4, 0.164 at 8
@@ -1361,7 +1361,7 @@ int launch_lr_panels(blmm_ctx* ctx, const NullModel& nm, const double* Yt, int64
     const size_t wbase = sizeof(double) * (size_t)nm.n * (1 + nm.c);
     // rows of the basis mirrored in LDS: the rank is only known on the device (20-24 on kinship spectra); 32 rows keep the
     // workgroup at 22 KB at n = 80 (7 per CU; n rows = 52 KB held it at 3), rows beyond come from L2
-    static const int qrows_env = getenv("BLMM_LR_PANELS_QROWS") ? atoi(getenv("BLMM_LR_PANELS_QROWS")) : 0;
+    static const int qrows_env = dev_env("BLMM_LR_PANELS_QROWS") ? atoi(dev_env("BLMM_LR_PANELS_QROWS")) : 0;
     const size_t qrows = qrows_env > 0 ? (size_t)qrows_env : 32;
     const int wqcap = (wbase + sizeof(double) * nm.n <= 60 * 1024) ? (int)std::min<size_t>(std::min<size_t>((size_t)nm.n, qrows), (60 * 1024 - wbase) / (sizeof(double) * (size_t)nm.n)) : 0;
     const size_t wlds = wbase + sizeof(double) * (size_t)wqcap * nm.n;
@@ -1394,7 +1394,7 @@ int launch_lr_panels(blmm_ctx* ctx, const NullModel& nm, const double* Yt, int64
     return BLMM_OK;
   }
   if (seg.S != 1) return fail(ctx, BLMM_ERR_INVALID, "launch_lr_panels: the one-thread-per-trait kernel takes a single weight basis");
-  static const int nt_env = getenv("BLMM_LR_PANELS_NT") ? atoi(getenv("BLMM_LR_PANELS_NT")) : 0;
+  static const int nt_env = dev_env("BLMM_LR_PANELS_NT") ? atoi(dev_env("BLMM_LR_PANELS_NT")) : 0;
   const int nthr = (nt_env == 64 || nt_env == 128 || nt_env == 256) ? nt_env : 64;
   const unsigned blocks = (unsigned)((rg.ncol + nthr - 1) / nthr);
   const int qcap = (int)std::min<size_t>((size_t)nm.n, (56 * 1024) / (sizeof(double) * (size_t)nm.n));

@@ -85,7 +85,8 @@ __global__ void __launch_bounds__(256) k_lod2log10p1(const double* __restrict__ 
 
 int launch_lod2log10p(blmm_ctx* ctx, const double* dL, int64_t p, int64_t m, int64_t ldL, int df, double* dP, int64_t ldP) {
   if (p <= 0 || m <= 0) return BLMM_OK;
-  static const bool exact_route = getenv("BLMM_PVAL_LIBM") && getenv("BLMM_PVAL_LIBM")[0] == '1';   // A/B: erfc / erfcx / log for df = 1 too
+  const char* le = dev_env("BLMM_PVAL_LIBM");                         // tuning key "pval_libm": erfc / erfcx / log for df = 1 too
+  const bool exact_route = le ? le[0] == '1' : ctx->tune.pval_libm != 0;
   if (df == 1 && ctx->pvtab.p && !exact_route) {
     // few, long columns walks: the table is staged once per workgroup
     dim3 grid1((unsigned)((p + 255) / 256), (unsigned)(m < 64 ? m : 64));
@@ -131,6 +132,37 @@ int launch_threshold(blmm_ctx* ctx, const double* dL, int64_t p, int64_t m, int6
                      reinterpret_cast<unsigned long long*>(dcount));
   KCHECK();
   return BLMM_OK;
+}
+
+// Second pass of the reduce-in-epilogue scan (RedArgs, blmm_internal.h): the scan kernels left, per trait and 64-marker slot, the
+// slot's maximum LOD and its marker; one thread per trait walks the slots in marker order with k_colmax's rule (strictly larger,
+// or equal at the lower marker; NaN never), so (max, argmax) equal k_colmax's on the stored matrix bit for bit.
+__global__ void __launch_bounds__(256) k_red_final(const double* __restrict__ pmax, const int* __restrict__ parg, int64_t ldm, int nslot,
+                                                   int64_t m, double* __restrict__ mx, int64_t* __restrict__ arg) {
+  const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (j >= m) return;
+  double best = -INFINITY; int64_t bi = -1;
+  for (int s = 0; s < nslot; ++s) {
+    const double v = pmax[(int64_t)s * ldm + j];
+    const int64_t i = parg[(int64_t)s * ldm + j];
+    if (v > best || (v == best && i >= 0 && (bi < 0 || i < bi))) { best = v; bi = i; }
+  }
+  if (mx) mx[j] = best;
+  if (arg) arg[j] = bi;
+}
+
+int launch_red_final(blmm_ctx* ctx, const RedArgs& r, int nslot, int64_t m, double* mx, int64_t* arg) {
+  if (m <= 0 || (!mx && !arg)) return BLMM_OK;
+  hipLaunchKernelGGL(k_red_final, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, ctx->stream, r.pmax, r.parg, r.ldm, nslot, m, mx, arg);
+  KCHECK();
+  return BLMM_OK;
+}
+
+// column j of the resident matrix -> out column k (blmm_last_lod_columns)
+__global__ void __launch_bounds__(256) k_gather_cols(const double* __restrict__ L, int64_t p, int64_t ldL, const int64_t* __restrict__ cols,
+                                                     double* __restrict__ out) {
+  const int64_t j = cols[blockIdx.y];
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < p; i += (int64_t)gridDim.x * 256) out[(int64_t)blockIdx.y * p + i] = L[j * ldL + i];
 }
 
 // ---- quantiles of a device vector (the per-permutation maxima): bitonic sort + linear interpolation ------------------
@@ -301,6 +333,55 @@ int blmm_last_lod_threshold(blmm_ctx* ctx, double thr, int64_t cap, int32_t* i_o
     BLMM_HIP(hipMemcpyAsync(j_out, dj, sizeof(int32_t) * (size_t)got, hipMemcpyDeviceToHost, ctx->stream));
     BLMM_HIP(hipStreamSynchronize(ctx->stream));
   }
+  return BLMM_OK;
+}
+
+int blmm_last_dims(const blmm_ctx* ctx, int64_t* p_out, int64_t* m_out) {
+  if (!ctx) return BLMM_ERR_INVALID;
+  if (p_out) *p_out = ctx->last_L ? ctx->last_p : 0;
+  if (m_out) *m_out = ctx->last_L ? ctx->last_m : 0;
+  return ctx->last_L ? BLMM_OK : BLMM_ERR_INVALID;
+}
+
+int blmm_last_lod_colmax(blmm_ctx* ctx, double* max_out, int64_t* argmax_out) {
+  if (!ctx) return BLMM_ERR_INVALID;
+  if (!max_out) return fail(ctx, BLMM_ERR_INVALID, "last_lod_colmax: bad arguments");
+  if (!ctx->last_L || ctx->last_f32) return fail(ctx, BLMM_ERR_INVALID, "last_lod_colmax: no fp64 LOD matrix of a previous host-pointer call is resident");
+  BLMM_HIP(hipSetDevice(ctx->device));
+  const int64_t p = ctx->last_p, m = ctx->last_m;
+  if (m <= 0) return BLMM_OK;
+  int rc;
+  if ((rc = ensure(ctx, ctx->tmpA, sizeof(double) * (size_t)m))) return rc;
+  if ((rc = ensure(ctx, ctx->tmpB, sizeof(int64_t) * (size_t)m))) return rc;
+  if ((rc = launch_colmax(ctx, ctx->last_L, p, m, p, ptr<double>(ctx->tmpA), ptr<int64_t>(ctx->tmpB)))) return rc;
+  BLMM_HIP(hipMemcpyAsync(max_out, ctx->tmpA.p, sizeof(double) * (size_t)m, hipMemcpyDeviceToHost, ctx->stream));
+  if (argmax_out) BLMM_HIP(hipMemcpyAsync(argmax_out, ctx->tmpB.p, sizeof(int64_t) * (size_t)m, hipMemcpyDeviceToHost, ctx->stream));
+  BLMM_HIP(hipStreamSynchronize(ctx->stream));
+  return BLMM_OK;
+}
+
+int blmm_last_lod_columns(blmm_ctx* ctx, const int64_t* cols, int64_t ncols, double* out) {
+  if (!ctx) return BLMM_ERR_INVALID;
+  if (ncols < 0 || (ncols > 0 && (!cols || !out))) return fail(ctx, BLMM_ERR_INVALID, "last_lod_columns: bad arguments");
+  if (!ctx->last_L || ctx->last_f32) return fail(ctx, BLMM_ERR_INVALID, "last_lod_columns: no fp64 LOD matrix of a previous host-pointer call is resident");
+  const int64_t p = ctx->last_p, m = ctx->last_m;
+  for (int64_t k = 0; k < ncols; ++k)
+    if (cols[k] < 0 || cols[k] >= m) return fail(ctx, BLMM_ERR_INVALID, "last_lod_columns: column index out of range");
+  if (ncols == 0 || p == 0) return BLMM_OK;
+  BLMM_HIP(hipSetDevice(ctx->device));
+  int rc;
+  if ((rc = ensure(ctx, ctx->altbuf, sizeof(double) * (size_t)p * (size_t)ncols + sizeof(int64_t) * (size_t)ncols + 64))) return rc;
+  double* dout = ptr<double>(ctx->altbuf);
+  int64_t* dcols = reinterpret_cast<int64_t*>(dout + (size_t)p * ncols);
+  BLMM_HIP(hipMemcpyAsync(dcols, cols, sizeof(int64_t) * (size_t)ncols, hipMemcpyHostToDevice, ctx->stream));
+  for (int64_t k0 = 0; k0 < ncols; k0 += 32768) {
+    const int64_t nk = ncols - k0 < 32768 ? ncols - k0 : 32768;
+    hipLaunchKernelGGL(k_gather_cols, dim3((unsigned)((p + 255) / 256 < 64 ? (p + 255) / 256 : 64), (unsigned)nk), dim3(256), 0, ctx->stream, ctx->last_L, p, p,
+                       dcols + k0, dout + (size_t)k0 * p);
+  }
+  KCHECK();
+  if ((rc = copy_to_host(ctx, out, dout, sizeof(double) * (size_t)p * (size_t)ncols))) return rc;
+  BLMM_HIP(hipStreamSynchronize(ctx->stream));
   return BLMM_OK;
 }
 

@@ -493,16 +493,16 @@ int jacobi_lds_max_n() { return JAC_NMAX; }
 int launch_jacobi(blmm_ctx* ctx, double* A, double* V, int n, double* lraw, int64_t* stat) {
   if (n <= JAC_NMAX) {
     const int N = n + (n & 1), NP2 = N / 2, ld = N + 1;
-    static const int nwg_env = getenv("BLMM_JAC_NWG") ? atoi(getenv("BLMM_JAC_NWG")) : 0;
+    static const int nwg_env = dev_env("BLMM_JAC_NWG") ? atoi(dev_env("BLMM_JAC_NWG")) : 0;
     const int nwg = (nwg_env >= 1 && nwg_env <= 64) ? nwg_env : JAC_NWG;
     const int rows_per = (n + nwg - 1) / nwg;
     const int PL = (NP2 * (NP2 - 1) / 2 + 1) & ~1, AO = (4 * PL + 3 * NP2 + 1) & ~1;
     const size_t lds = sizeof(double) * ((size_t)2 * AO + (size_t)2 * rows_per * ld + 5 * NP2 + 2) + 64;
     BLMM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_jacobi_lds), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    static const double stop2 = getenv("BLMM_JAC_STOP2") ? atof(getenv("BLMM_JAC_STOP2")) : 1e-15;
+    static const double stop2 = dev_env("BLMM_JAC_STOP2") ? atof(dev_env("BLMM_JAC_STOP2")) : 1e-15;
     // 768 threads (11 worker waves + the angle wave) when two items per worker thread cover the blocks: fewer waves at
     // the barrier and in the LDS queue measured ~8 % faster than 1024 at n = 79.  BLMM_JAC_NT overrides.
-    static const int nt_env = getenv("BLMM_JAC_NT") ? atoi(getenv("BLMM_JAC_NT")) : 0;
+    static const int nt_env = dev_env("BLMM_JAC_NT") ? atoi(dev_env("BLMM_JAC_NT")) : 0;
     const int nblk = NP2 * (NP2 - 1) / 2;
     int nthr = (nblk <= 2 * (768 - 64)) ? 768 : 1024;
     if (nt_env >= 256 && nt_env <= 1024 && nt_env % 64 == 0 && nblk <= 2 * (nt_env - 64)) nthr = nt_env;
@@ -1014,11 +1014,11 @@ int launch_rotate(blmm_ctx* ctx, const double* Rp, int ldr, int n, int npad, con
     KCHECK();
     return BLMM_OK;
   }
-  if (n > 160 && ncols >= 64 && !(getenv("BLMM_ROTATE") && std::strcmp(getenv("BLMM_ROTATE"), "small") == 0)) {
+  if (n > 160 && ncols >= 64 && !(dev_env("BLMM_ROTATE") && std::strcmp(dev_env("BLMM_ROTATE"), "small") == 0)) {
     const int nkt = (npad + 127) / 128;
     // BLMM_ROTATE_TILE (A/B timing): "64": 128 x 64 tiles with the B fragments prefetched; "128p": 128 x 128 tiles, 32-byte
     // pieces, the next trip's B fragments prefetched
-    const char* rv = getenv("BLMM_ROTATE_TILE");
+    const char* rv = dev_env("BLMM_ROTATE_TILE");
     const bool wide = !(rv && std::strcmp(rv, "64") == 0);     // "128": the plain 128 x 128 form at every n
     // default: the prefetching form from n = 900 (n = 1000, p = 1e5: 3.75 against 3.87 ms, 53.4 TF; n = 700: 1.32 against 1.31;
     // n = 500: 0.78 against 0.75); the choice depends on n only, so a column's bits do not depend on the call's width
@@ -1636,7 +1636,7 @@ static int launch_brent_t(blmm_ctx* ctx, const NullModel& nm, const double* Yt, 
   if (lds > 48 * 1024)
     BLMM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_brent<C, LPT, REG>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   BrentCont cont{nullptr, nullptr, nullptr, nullptr};
-  static const char* two_env = getenv("BLMM_BRENT_TWO");   // "0": keep the single-kernel form (A/B testing)
+  static const char* two_env = dev_env("BLMM_BRENT_TWO");   // "0": keep the single-kernel form (A/B testing)
   const bool two = REG && (64 / LPT) > 1 && nm.optim_interval <= 1 && m >= 1024 && !(two_env && two_env[0] == '0');
   if (two) {
     int rc = ensure(ctx, ctx->brSt, sizeof(double) * (size_t)12 * m);
@@ -1666,7 +1666,7 @@ static int launch_brent_t(blmm_ctx* ctx, const NullModel& nm, const double* Yt, 
     if (two) {
       // A/B testing: 8 / 16 spread a trait of the second kernel over more lanes than k_brent's 4 (measured at BXD size:
       // h2 phase 0.250 ms at 4, 0.259 at 8, 0.372 at 16 -- the wider cross-lane sums cost more than the shorter loop saves)
-      static const int lpt2_env = getenv("BLMM_BRENT2_LPT") ? atoi(getenv("BLMM_BRENT2_LPT")) : 0;
+      static const int lpt2_env = dev_env("BLMM_BRENT2_LPT") ? atoi(dev_env("BLMM_BRENT2_LPT")) : 0;
       auto launch2 = [&](auto kern, int lpt2, int nk2) -> int {
         const size_t lds2 = sizeof(double) * ((size_t)lpt2 * nk2 * (1 + C) + (size_t)nk2 * 256);
         if (lds2 > 48 * 1024)
@@ -1691,7 +1691,7 @@ template <int C>
 static int launch_brent_c(blmm_ctx* ctx, const NullModel& nm, const double* Yt, int64_t ldy, int64_t m, const double* Z0,
                           const double* lam, double* h2, double* sigma2, double* ell, int64_t* stat, int phase, BrentSplit* sp) {
   const int n = nm.n;
-  static const int lpt_env = getenv("BLMM_BRENT_LPT") ? atoi(getenv("BLMM_BRENT_LPT")) : 0;
+  static const int lpt_env = dev_env("BLMM_BRENT_LPT") ? atoi(dev_env("BLMM_BRENT_LPT")) : 0;
   if (lpt_env == 8 && n <= 8 * NULL_NK) return launch_brent_t<C, 8, true>(ctx, nm, Yt, ldy, m, Z0, lam, h2, sigma2, ell, stat, phase, sp);
   if (lpt_env == 16 && n <= 16 * NULL_NK) return launch_brent_t<C, 16, true>(ctx, nm, Yt, ldy, m, Z0, lam, h2, sigma2, ell, stat, phase, sp);
   if (n <= 4 * NULL_NK) return launch_brent_t<C, 4, true>(ctx, nm, Yt, ldy, m, Z0, lam, h2, sigma2, ell, stat, phase, sp);
@@ -1988,7 +1988,7 @@ int launch_loglik_grid(blmm_ctx* ctx, const NullModel& nm, const double* Yt, int
                        const double* lam, const double* grid_dev, int ngrid, double* EllTab, int* h2idx, double* h2,
                        int64_t* stat) {
   if (nm.c > CTPL && nm.c <= CMAX) return launch_dyn_loglik_grid(ctx, nm, Yt, ldy, m, Z0, lam, grid_dev, ngrid, EllTab, h2idx, h2, stat);
-  static const char* gen_env = getenv("BLMM_LOGLIK_GENERIC");   // "1": the generic evaluator for every n (A/B testing)
+  static const char* gen_env = dev_env("BLMM_LOGLIK_GENERIC");   // "1": the generic evaluator for every n (A/B testing)
   if (!(gen_env && gen_env[0] == '1')) {
     bool done = false;
     int rc = BLMM_OK;
@@ -2656,7 +2656,7 @@ int launch_perm_panel(blmm_ctx* ctx, const NullModel& nm, const double* Yt, int6
     return launch_dyn_perm(ctx, nm, Yt, ldy, Z0, lam, h2, pidx, ncols, orig, r0, panel, ldp, stat);
   }
   // large n: the multi-kernel form (BLMM_PERM_PATH=old|new forces one; read per call so that a test can compare them)
-  const char* path_env = getenv("BLMM_PERM_PATH");
+  const char* path_env = dev_env("BLMM_PERM_PATH");
   const bool newpath = path_env ? std::strcmp(path_env, "new") == 0 : nm.n > 256;
   if (newpath && nm.n <= 65535) {
     const int64_t ncols = orig ? 1 : nperms;

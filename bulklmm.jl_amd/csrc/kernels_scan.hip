@@ -120,6 +120,60 @@ __device__ __forceinline__ void store_m(double* __restrict__ col, int c, const d
   }
 }
 
+// ---- reduce-in-epilogue (RedArgs, blmm_internal.h): what replaces store_m when no L is written --------------------------------
+template <int CTRL>
+__device__ __forceinline__ int dpp_movi(int x) { return __builtin_amdgcn_update_dpp(x, x, CTRL, 0xf, 0xf, false); }
+// the better of two (value, marker) candidates by k_colmax's rule: strictly larger value, or the same value at the lower marker;
+// a NaN never wins (every comparison with it is false), -1 marks "no candidate yet"
+__device__ __forceinline__ void red_comb(double& best, int& bi, double ob, int oi) {
+  if (ob > best || (ob == best && oi >= 0 && (bi < 0 || oi < bi))) { best = ob; bi = oi; }
+}
+// a lane's NB LODs of one trait: lane c (= lane & 15) of the 16-lane DPP row holds the markers i0 + NB c + nb; vl = markers that
+// exist from i0 on (at most 16 NB); all 16 lanes of a row are in the same trait, so the row is active or skipped as a whole
+template <int NB>
+__device__ __forceinline__ void red_row(const RedArgs& R, int64_t trait, int64_t i0, int c, int lane, const double (&out)[NB], int vl) {
+  double best = -INFINITY; int bi = -1;
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb) {
+    const int idx = NB * c + nb;
+    if (idx < vl && out[nb] > best) { best = out[nb]; bi = idx; }
+  }
+  { const double ob = blmm_dpp_mov<0xB1>(best); const int oi = dpp_movi<0xB1>(bi); red_comb(best, bi, ob, oi); }     // lane ^ 1
+  { const double ob = blmm_dpp_mov<0x4E>(best); const int oi = dpp_movi<0x4E>(bi); red_comb(best, bi, ob, oi); }     // lane ^ 2
+  { const double ob = blmm_dpp_mov<0x141>(best); const int oi = dpp_movi<0x141>(bi); red_comb(best, bi, ob, oi); }   // row_half_mirror
+  { const double ob = blmm_dpp_mov<0x140>(best); const int oi = dpp_movi<0x140>(bi); red_comb(best, bi, ob, oi); }   // row_mirror
+  if (c == 0) {
+    const int64_t at = (i0 >> 6) * R.ldm + trait;
+    R.pmax[at] = best;
+    R.parg[at] = bi < 0 ? -1 : (int)i0 + bi;
+  }
+  if (R.want_trip) {                                           // kernel argument: a scalar branch
+    bool h[NB]; int my = 0;
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) { h[nb] = (NB * c + nb < vl) && out[nb] > R.thr; my += h[nb] ? 1 : 0; }
+    const unsigned long long any = __ballot(my != 0);
+    if (any != 0ull) {                                         // rare: one wave-aggregated atomic reserves the slots (as k_threshold)
+      const unsigned long long b0 = __ballot((my & 1) != 0), b1 = __ballot((my & 2) != 0), b2 = __ballot((my & 4) != 0);
+      const unsigned long long lt = (1ull << lane) - 1ull;
+      const int pre = __builtin_popcountll(b0 & lt) + 2 * __builtin_popcountll(b1 & lt) + 4 * __builtin_popcountll(b2 & lt);
+      const int tot = __builtin_popcountll(b0) + 2 * __builtin_popcountll(b1) + 4 * __builtin_popcountll(b2);
+      const int leader = (int)__builtin_ctzll(any);
+      unsigned long long base = 0;
+      if (lane == leader) base = atomicAdd(R.cnt, (unsigned long long)tot);
+      const unsigned int blo = __builtin_amdgcn_readlane((unsigned int)base, leader);
+      const unsigned int bhi = __builtin_amdgcn_readlane((unsigned int)(base >> 32), leader);
+      unsigned long long slot = (((unsigned long long)bhi << 32) | blo) + (unsigned long long)pre;
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb)
+        if (h[nb]) {
+          if ((int64_t)slot < R.cap) { R.ti[slot] = (int32_t)(i0 + NB * c + nb); R.tj[slot] = (int32_t)trait; R.tl[slot] = out[nb]; }
+          ++slot;
+        }
+    }
+  }
+}
+__device__ __forceinline__ int red_valid(int64_t p, int64_t i0, int span) { const int64_t v = p - i0; return v > span ? span : (int)v; }
+
 __device__ __forceinline__ int64_t xcd_swizzle(int64_t bid, int64_t nwg) {
   // Workgroups are dealt round-robin over the 8 XCDs (bid % 8).  Give each XCD a contiguous range of tiles
   // so the A-side panels of a trait tile stay in ONE XCD's L2 (speed only; any placement is correct).
@@ -158,8 +212,9 @@ __device__ __forceinline__ void tile_of32(uint32_t id, uint32_t ntile_t, uint32_
 // MORE (exact mode, c > CFAST): the covariate panels beyond the first CFAST are contracted CFAST at a time ahead of the main
 // loop and folded into the Sxx accumulator as -u_q^2 (an MFMA accumulates on top of whatever its accumulator holds), so the
 // register budget does not grow with c; the marker tile is re-read from L2 once per chunk.
-template <int NX, int MB, int NB, bool TABLE, int W2, bool PERM = false, bool MORE = false, bool PV = false>
+template <int NX, int MB, int NB, bool TABLE, int W2, bool PERM = false, bool MORE = false, bool PV = false, bool RED = false>
 __global__ void __launch_bounds__(64 * W2 * W2, 2) k_scan(ScanArgs a, int ntile_i, int64_t nwg) {
+  static_assert(!(RED && PV), "reduce-in-epilogue: no p-value output");
   constexpr int NP = 1 + NX;  // A-side panels consumed
   constexpr int NT = 64 * W2 * W2;
   static_assert(!PERM || (TABLE && NX == 0), "permuted columns: table mode");
@@ -355,7 +410,8 @@ __global__ void __launch_bounds__(64 * W2 * W2, 2) k_scan(ScanArgs a, int ntile_
         for (int nb = 0; nb < NB; ++nb)
           if (!lod_fast_ok(uv[nb])) out[nb] = lod_out_of_range(uv[nb], s_lod, lp, scale, i0 + mslot<NB>(r, nb) < a.p, &nnan);
       }
-      store_m<NB>(a.L + trait * a.ldL + i0, r, out, a.p - i0);
+      if constexpr (RED) red_row<NB>(a.red, trait, i0, r, lane, out, red_valid(a.p, i0, 16 * NB));
+      else store_m<NB>(a.L + trait * a.ldL + i0, r, out, a.p - i0);
       if constexpr (PV) {
         double pv[NB];
 #pragma unroll
@@ -375,7 +431,14 @@ static int launch_scan_t(blmm_ctx* ctx, const ScanArgs& a) {
   const int64_t nwg = ntile_t * ntile_i;
   if (nwg <= 0) return BLMM_OK;
   if (nwg > 0x7fffffffLL) return fail(ctx, BLMM_ERR_INVALID, "problem too large for one launch");
-  if (a.Pv)
+  if (a.red.pmax) {
+    // reduce-in-epilogue: instantiated for the table kernel at its default tile only (the callers route everything else through a
+    // resident L and the column passes)
+    if constexpr (TABLE && MB == 2 && W2 == 2 && !MORE)
+      hipLaunchKernelGGL((k_scan<NX, MB, NB, TABLE, W2, false, MORE, false, true>), dim3((unsigned)nwg), dim3(64 * W2 * W2), 0, ctx->stream, a, (int)ntile_i, nwg);
+    else
+      return fail(ctx, BLMM_ERR_UNSUPPORTED, "reduce-in-epilogue: no such instantiation of k_scan");
+  } else if (a.Pv)
     hipLaunchKernelGGL((k_scan<NX, MB, NB, TABLE, W2, false, MORE, true>), dim3((unsigned)nwg), dim3(64 * W2 * W2), 0, ctx->stream, a, (int)ntile_i, nwg);
   else
     hipLaunchKernelGGL((k_scan<NX, MB, NB, TABLE, W2, false, MORE>), dim3((unsigned)nwg), dim3(64 * W2 * W2), 0, ctx->stream, a, (int)ntile_i, nwg);
@@ -413,8 +476,9 @@ __device__ unsigned long long g_lr_diag[24];   // per class {sum of workgroup cy
 // per class (0: shared-weights tiles, 1: rank-R tiles) sums over the waves of {K loops, barrier wait, epilogue} cycles and the count
 __device__ unsigned long long g_lr_phase[8];
 #endif
-template <int C, int MB, int NB, bool PV = false>
+template <int C, int MB, int NB, bool PV = false, bool RED = false>
 __global__ void __launch_bounds__(256, 2) k_scan_lr(LrArgs la, int ntile_i, int64_t nwg) {
+  static_assert(!(RED && PV), "reduce-in-epilogue: no p-value output");
   const ScanArgs& a = la.s;
 #ifdef LR_DIAG
   const unsigned long long diag_t0 = __builtin_amdgcn_s_memtime();
@@ -689,7 +753,8 @@ __global__ void __launch_bounds__(256, 2) k_scan_lr(LrArgs la, int ntile_i, int6
 #ifdef LR_NOSTORE   // diagnostic: everything but the stream of stores
         if (out[0] + out[1] + out[2] + out[3] != 1.2345e-300) continue;
 #endif
-        store_m<NB>(a.L + trait * a.ldL + i0, r, out, a.p - i0);
+        if constexpr (RED) red_row<NB>(a.red, trait, i0, r, lane, out, red_valid(a.p, i0, 16 * NB));
+        else store_m<NB>(a.L + trait * a.ldL + i0, r, out, a.p - i0);
         if constexpr (PV) {
           double pv[NB];
 #pragma unroll
@@ -728,8 +793,9 @@ __global__ void __launch_bounds__(256, 2) k_scan_lr(LrArgs la, int ntile_i, int6
 // phase 1 accumulates num (64 VGPRs) beside the 64 of the reciprocals -- 128 accumulator registers at the peak where k_scan_lr
 // holds 192 -- and the epilogue is r^2 = num^2 * that reciprocal.  Same arithmetic per output, same bits.
 // ------------------------------------------------------------------------------------------------
-template <int C, bool PV>
+template <int C, bool PV, bool RED = false>
 __global__ void __launch_bounds__(256, 3) k_scan_lr3(LrArgs la, int ntile_i, int64_t nwg) {
+  static_assert(!(RED && PV), "reduce-in-epilogue: no p-value output");
   const ScanArgs& a = la.s;
   constexpr int MB = 2, NB = 4, TW = 64;
   constexpr int NL = C * (C + 1) / 2;
@@ -898,7 +964,8 @@ __global__ void __launch_bounds__(256, 3) k_scan_lr3(LrArgs la, int ntile_i, int
         for (int nb = 0; nb < NB; ++nb)
           if (!lod_fast_ok(uv[nb])) out[nb] = lod_out_of_range(uv[nb], s_lod, lp, scale, i0 + mslot<NB>(r, nb) < a.p, &nnan);
       }
-      store_m<NB>(a.L + trait * a.ldL + i0, r, out, a.p - i0);
+      if constexpr (RED) red_row<NB>(a.red, trait, i0, r, lane, out, red_valid(a.p, i0, 16 * NB));
+      else store_m<NB>(a.L + trait * a.ldL + i0, r, out, a.p - i0);
       if constexpr (PV) {
         double pv[NB];
 #pragma unroll
@@ -930,8 +997,12 @@ static int launch_scan_lr_t(blmm_ctx* ctx, const LrArgs& la) {
 #endif
   // k_scan_lr3 (three waves per SIMD) is the default for c = 1 and n <= 128; BLMM_LR3=0: k_scan_lr (A/B testing).
   // One box, four alternating rounds: scan 1.164-1.183 against 1.206-1.240 ms, step 1.636-1.654 against 1.674-1.714.
-  static const bool lr3 = !(getenv("BLMM_LR3") && getenv("BLMM_LR3")[0] == '0');
-  if (a.Pv && lr3 && C == 1 && MB == 2 && la.skip_shared && a.n <= 128)
+  static const bool lr3 = !(dev_env("BLMM_LR3") && dev_env("BLMM_LR3")[0] == '0');
+  if (a.red.pmax && lr3 && C == 1 && MB == 2 && la.skip_shared && a.n <= 128)
+    hipLaunchKernelGGL((k_scan_lr3<1, false, true>), dim3((unsigned)nwg), dim3(256), 0, ctx->stream, la, (int)ntile_i, nwg);
+  else if (a.red.pmax)
+    hipLaunchKernelGGL((k_scan_lr<C, MB, NB, false, true>), dim3((unsigned)nwg), dim3(256), 0, ctx->stream, la, (int)ntile_i, nwg);
+  else if (a.Pv && lr3 && C == 1 && MB == 2 && la.skip_shared && a.n <= 128)
     hipLaunchKernelGGL((k_scan_lr3<1, true>), dim3((unsigned)nwg), dim3(256), 0, ctx->stream, la, (int)ntile_i, nwg);
   else if (a.Pv)
     hipLaunchKernelGGL((k_scan_lr<C, MB, NB, true>), dim3((unsigned)nwg), dim3(256), 0, ctx->stream, la, (int)ntile_i, nwg);
@@ -965,7 +1036,7 @@ static int launch_scan_lr_t(blmm_ctx* ctx, const LrArgs& la) {
 // c = 1 -- n <= 128, the shared-weights class in the table kernel, BLMM_LR3 != 0
 template <int C>
 static bool lr3_covariates(blmm_ctx*, const LrArgs& la) {
-  static const bool lr3 = !(getenv("BLMM_LR3") && getenv("BLMM_LR3")[0] == '0');
+  static const bool lr3 = !(dev_env("BLMM_LR3") && dev_env("BLMM_LR3")[0] == '0');
   return lr3 && la.skip_shared && la.s.n <= 128;
 }
 template <int C>
@@ -975,7 +1046,8 @@ static int launch_scan_lr3_c(blmm_ctx* ctx, const LrArgs& la) {
   if (ntile_t * ntile_i <= 0) return BLMM_OK;
   const int64_t nwg = (ntile_t * ntile_i + 16 + 7) / 8 * 8;
   if (nwg > 0x7fffffffLL) return fail(ctx, BLMM_ERR_INVALID, "problem too large for one launch");
-  if (a.Pv) hipLaunchKernelGGL((k_scan_lr3<C, true>), dim3((unsigned)nwg), dim3(256), 0, ctx->stream, la, (int)ntile_i, nwg);
+  if (a.red.pmax) hipLaunchKernelGGL((k_scan_lr3<C, false, true>), dim3((unsigned)nwg), dim3(256), 0, ctx->stream, la, (int)ntile_i, nwg);
+  else if (a.Pv) hipLaunchKernelGGL((k_scan_lr3<C, true>), dim3((unsigned)nwg), dim3(256), 0, ctx->stream, la, (int)ntile_i, nwg);
   else hipLaunchKernelGGL((k_scan_lr3<C, false>), dim3((unsigned)nwg), dim3(256), 0, ctx->stream, la, (int)ntile_i, nwg);
   KCHECK();
   return BLMM_OK;
@@ -984,7 +1056,7 @@ static int launch_scan_lr3_c(blmm_ctx* ctx, const LrArgs& la) {
 int launch_scan_lr(blmm_ctx* ctx, const LrArgs& la) {
   switch (la.c) {
     case 1: {
-      static const int mb1 = getenv("BLMM_LR_MB1") ? atoi(getenv("BLMM_LR_MB1")) : 0;
+      static const int mb1 = dev_env("BLMM_LR_MB1") ? atoi(dev_env("BLMM_LR_MB1")) : 0;
       return mb1 ? launch_scan_lr_t<1, 1>(ctx, la) : launch_scan_lr_t<1, 2>(ctx, la);
     }
     case 2: return lr3_covariates<2>(ctx, la) ? launch_scan_lr3_c<2>(ctx, la) : launch_scan_lr_t<2, 1>(ctx, la);
@@ -1000,7 +1072,9 @@ int launch_scan_shared(blmm_ctx* ctx, const ScanArgs& a) {
   if (ntile_t * ntile_i <= 0) return BLMM_OK;
   const int64_t nwg = (ntile_t * ntile_i + 8 + 7) / 8 * 8;              // every XCD's share rounds up
   if (nwg > 0x7fffffffLL) return fail(ctx, BLMM_ERR_INVALID, "problem too large for one launch");
-  if (a.Pv)
+  if (a.red.pmax)
+    hipLaunchKernelGGL((k_scan<0, MB, NB, true, W2, true, false, false, true>), dim3((unsigned)nwg), dim3(64 * W2 * W2), 0, ctx->stream, a, (int)ntile_i, nwg);
+  else if (a.Pv)
     hipLaunchKernelGGL((k_scan<0, MB, NB, true, W2, true, false, true>), dim3((unsigned)nwg), dim3(64 * W2 * W2), 0, ctx->stream, a, (int)ntile_i, nwg);
   else
     hipLaunchKernelGGL((k_scan<0, MB, NB, true, W2, true>), dim3((unsigned)nwg), dim3(64 * W2 * W2), 0, ctx->stream, a, (int)ntile_i, nwg);
@@ -1009,7 +1083,7 @@ int launch_scan_shared(blmm_ctx* ctx, const ScanArgs& a) {
 }
 
 int launch_scan_table(blmm_ctx* ctx, const ScanArgs& a) {
-  static const int mb = getenv("BLMM_TABLE_MB") ? atoi(getenv("BLMM_TABLE_MB")) : 2;
+  static const int mb = dev_env("BLMM_TABLE_MB") ? atoi(dev_env("BLMM_TABLE_MB")) : 2;
   if (mb == 4) return launch_scan_t<0, true, 4>(ctx, a);
   if (mb == 1) return launch_scan_t<0, true, 1>(ctx, a);
   return launch_scan_t<0, true, 2>(ctx, a);

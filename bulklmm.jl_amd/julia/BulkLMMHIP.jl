@@ -11,7 +11,7 @@
 # every `ccall`'s symbol, return type and argument tuple (arity and types) against the prototype in include/bulklmm_hip.h.
 module BulkLMMHIP
 
-export calcKinship, bulkscan, bulkscan_null, bulkscan_null_grid, bulkscan_alt_grid, bulkscan_alt_exact, scan, bulkscan_multi, lod2log10p, get_thresholds,
+export bulkscan_reduced, DeviceLOD, lod_columns, set_tuning, calcKinship, bulkscan, bulkscan_null, bulkscan_null_grid, bulkscan_alt_grid, bulkscan_alt_exact, scan, bulkscan_multi, lod2log10p, get_thresholds,
        lod_threshold, lod_colmax, pinned_matrix, host_register, host_unregister
 
 const libblmm = get(ENV, "BULKLMM_HIP_LIB", joinpath(@__DIR__, "..", "csrc", "libbulklmm_hip.so"))
@@ -65,7 +65,7 @@ end
 
 function _bulkscan(method::Int32, Y::Array{Float64, 2}, G::Array{Float64, 2}, Covar, K::Array{Float64, 2}, grid::Vector{Float64};
                    addIntercept::Bool, weights, prior_variance::Float64, prior_sample_size::Float64, reml::Bool,
-                   optim_interval::Int64, decomp_scheme::String)
+                   optim_interval::Int64, decomp_scheme::String, keep_on_device::Bool = false, pvals_df::Int64 = 0)
     (n, m) = size(Y); p = size(G, 2)
     (size(G, 1) != n || size(K, 1) != n || size(K, 2) != n) && error("Dimension mismatch.")   # src/transform_helpers.jl:9-11
     (Covar !== nothing && size(Covar, 1) != n) && error("Dimension mismatch.")
@@ -73,72 +73,186 @@ function _bulkscan(method::Int32, Y::Array{Float64, 2}, G::Array{Float64, 2}, Co
     ncov = Covar === nothing ? 0 : size(Covar, 2)
     o = BlmmOpts(method, reml, Covar === nothing ? true : addIntercept, decomp(decomp_scheme), optim_interval, 0,
                  prior_variance, prior_sample_size)
-    L = Array{Float64, 2}(undef, p, m)
+    # keep_on_device: L_out == NULL -- the matrix stays in the context's HBM workspace and `L` is a DeviceLOD handle
+    L = keep_on_device ? nothing : Array{Float64, 2}(undef, p, m)
     h2 = method == ALT_GRID ? Array{Float64, 2}(undef, p, m) : Array{Float64, 1}(undef, m)
     st = BlmmStatus()
+    # `output_pvals`: asked for right in front of the scan (after every check above), so that the scan kernels write -log10 p from
+    # their epilogues (chisq_df = 1, null-* methods; otherwise the column pass runs inside the call) into a buffer of the context
+    # that _last_log10p hands out; the library consumes the request first thing in the call, whatever happens next
+    if pvals_df > 0
+        check(ccall((:blmm_set_log10p_output, libblmm), Cint, (Ptr{Cvoid}, Ptr{Float64}, Int64, Int64),
+                    context(), Ptr{Float64}(C_NULL), Int64(0), pvals_df))
+    end
     GC.@preserve Y G Covar K weights grid L h2 begin
         check(ccall((:blmm_bulkscan, libblmm), Cint,
                     (Ptr{Cvoid}, Ref{BlmmOpts}, Ptr{Float64}, Int64, Int64, Ptr{Float64}, Int64, Ptr{Float64}, Int64,
                      Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Int64, Ptr{Float64}, Ptr{Float64}, Ref{BlmmStatus}),
-                    context(), o, Y, n, m, G, p, ptr_or_null(Covar), ncov, K, ptr_or_null(weights), grid, length(grid), L, h2, st))
+                    context(), o, Y, n, m, G, p, ptr_or_null(Covar), ncov, K, ptr_or_null(weights), grid, length(grid),
+                    ptr_or_null(L), h2, st))
     end
     raise_status(st)
-    return L, h2
+    return (keep_on_device ? DeviceLOD(p, m) : L), h2
 end
+
+# ---- the LOD matrix of a `keep_on_device = true` call: it stays in HBM (2.08 GB at BXD size: 36 of a call's 39 ms are its trip over
+# PCIe) and is reduced there -- what README.md:246-255, 354-359 and get_thresholds do with L -- until the context's next call
+struct DeviceLOD
+    p::Int64
+    m::Int64
+end
+Base.size(d::DeviceLOD) = (d.p, d.m)
+function _alive(d::DeviceLOD)
+    pp = Ref{Int64}(0); mm = Ref{Int64}(0)
+    rc = ccall((:blmm_last_dims, libblmm), Cint, (Ptr{Cvoid}, Ref{Int64}, Ref{Int64}), context(), pp, mm)
+    (rc == 0 && pp[] == d.p && mm[] == d.m) || error("the device-resident LOD matrix has been replaced by a later call")
+end
+function lod_colmax(d::DeviceLOD)
+    _alive(d)
+    mx = Vector{Float64}(undef, d.m); arg = Vector{Int64}(undef, d.m)
+    GC.@preserve mx arg check(ccall((:blmm_last_lod_colmax, libblmm), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Int64}), context(), mx, arg))
+    return (max = mx, argmax = arg .+ 1)
+end
+function lod_threshold(d::DeviceLOD, thr::Float64; cap::Int64 = 65536)
+    _alive(d)
+    while true
+        ii = Vector{Int32}(undef, cap); jj = Vector{Int32}(undef, cap); ll = Vector{Float64}(undef, cap)
+        cnt = Ref{Int64}(0)
+        GC.@preserve ii jj ll check(ccall((:blmm_last_lod_threshold, libblmm), Cint,
+            (Ptr{Cvoid}, Float64, Int64, Ptr{Int32}, Ptr{Int32}, Ptr{Float64}, Ref{Int64}), context(), thr, cap, ii, jj, ll, cnt))
+        if cnt[] <= cap
+            k = cnt[]
+            ord = sortperm(collect(zip(jj[1:k], ii[1:k])))
+            return (marker = Int.(ii[1:k][ord]) .+ 1, trait = Int.(jj[1:k][ord]) .+ 1, lod = ll[1:k][ord])
+        end
+        cap = cnt[]
+    end
+end
+function get_thresholds(d::DeviceLOD, signif_level::Array{Float64, 1})
+    _alive(d)
+    probs = 1.0 .- signif_level
+    thrs = similar(probs)
+    GC.@preserve probs thrs check(ccall((:blmm_last_get_thresholds, libblmm), Cint, (Ptr{Cvoid}, Ptr{Float64}, Int64, Ptr{Float64}),
+                                        context(), probs, length(probs), thrs))
+    return (probs = probs, thrs = thrs)
+end
+# L[:, traits] (1-based): the LOD profiles of a few traits -- the only part of L that crosses PCIe
+function lod_columns(d::DeviceLOD, traits::Vector{Int64})
+    _alive(d)
+    cols = traits .- 1
+    out = Array{Float64, 2}(undef, d.p, length(cols))
+    GC.@preserve cols out check(ccall((:blmm_last_lod_columns, libblmm), Cint, (Ptr{Cvoid}, Ptr{Int64}, Int64, Ptr{Float64}),
+                                      context(), cols, length(cols), out))
+    return out
+end
+Base.Array(d::DeviceLOD) = lod_columns(d, collect(1:d.m))
+
+# ---- tuning (include/bulklmm_hip.h): the switches that select another arithmetic path are properties of the context
+set_tuning(key::String, value::Real) = check(ccall((:blmm_set_tuning, libblmm), Cint, (Ptr{Cvoid}, Cstring, Float64), context(), key, Float64(value)))
+
+# ---- bulkscan WITHOUT the LOD matrix (blmm_bulkscan_reduced): per trait the peak LOD and its marker and, `threshold` given, every
+# (marker, trait, LOD) with LOD > threshold, out of the scan kernels' epilogues; L is never written.  Not in the reference, whose
+# users reduce L on the CPU (README.md:246-255, 354-359).
+struct BlmmReduced   # include/bulklmm_hip.h: blmm_reduced
+    colmax::Ptr{Float64}; argmax::Ptr{Int64}; want_triplets::Int64; thr::Float64; cap::Int64
+    ti::Ptr{Int32}; tj::Ptr{Int32}; tlod::Ptr{Float64}; count::Ptr{Int64}
+end
+function bulkscan_reduced(Y::Array{Float64, 2}, G::Array{Float64, 2}, Covar::Union{Nothing, Array{Float64, 2}}, K::Array{Float64, 2};
+                          method::String = "null-grid", h2_grid::Array{Float64, 1} = collect(0.0:0.1:0.9),
+                          threshold::Union{Nothing, Float64} = nothing, cap::Int64 = 65536, addIntercept::Bool = true,
+                          weights::Union{Missing, Array{Float64, 1}} = missing, prior_variance::Float64 = 1.0,
+                          prior_sample_size::Float64 = 0.0, reml::Bool = false, optim_interval::Int64 = 1,
+                          decomp_scheme::String = "eigen")
+    meth = method == "null-exact" ? NULL_EXACT : method == "null-grid" ? NULL_GRID : method == "alt-grid" ? ALT_GRID :
+           error("Unknown method `$method`; choose null-exact, null-grid or alt-grid.")
+    (n, m) = size(Y); p = size(G, 2)
+    (size(G, 1) != n || size(K, 1) != n || size(K, 2) != n) && error("Dimension mismatch.")
+    (Covar !== nothing && size(Covar, 1) != n) && error("Dimension mismatch.")
+    (weights !== missing && length(weights) != n) && error("Dimension mismatch.")
+    ncov = Covar === nothing ? 0 : size(Covar, 2)
+    o = BlmmOpts(meth, reml, Covar === nothing ? true : addIntercept, decomp(decomp_scheme), optim_interval, 0,
+                 prior_variance, prior_sample_size)
+    grid = meth == NULL_EXACT ? Float64[] : h2_grid
+    mx = Vector{Float64}(undef, m); arg = Vector{Int64}(undef, m); h2 = Vector{Float64}(undef, m)
+    want = threshold !== nothing
+    st = BlmmStatus()
+    while true
+        c1 = max(cap, 1)
+        ii = Vector{Int32}(undef, c1); jj = Vector{Int32}(undef, c1); ll = Vector{Float64}(undef, c1); cnt = zeros(Int64, 1)
+        GC.@preserve Y G Covar K weights grid mx arg h2 ii jj ll cnt begin
+            r = BlmmReduced(pointer(mx), pointer(arg), want ? 1 : 0, want ? threshold : 0.0, want ? cap : 0,
+                            pointer(ii), pointer(jj), pointer(ll), pointer(cnt))
+            check(ccall((:blmm_bulkscan_reduced, libblmm), Cint,
+                        (Ptr{Cvoid}, Ref{BlmmOpts}, Ptr{Float64}, Int64, Int64, Ptr{Float64}, Int64, Ptr{Float64}, Int64,
+                         Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Int64, Ref{BlmmReduced}, Ptr{Float64}, Ref{BlmmStatus}),
+                        context(), o, Y, n, m, G, p, ptr_or_null(Covar), ncov, K, ptr_or_null(weights), grid, length(grid), r, h2, st))
+        end
+        if !want || cnt[1] <= cap
+            raise_status(st)
+            res = (max_lod = mx, argmax = arg .+ 1, h2_null_list = h2)
+            want || return res
+            k = cnt[1]
+            ord = sortperm(collect(zip(jj[1:k], ii[1:k])))
+            return merge(res, (marker = Int.(ii[1:k][ord]) .+ 1, trait = Int.(jj[1:k][ord]) .+ 1, lod = ll[1:k][ord]))
+        end
+        cap = cnt[1]
+    end
+end
+bulkscan_reduced(Y::Array{Float64, 2}, G::Array{Float64, 2}, K::Array{Float64, 2}; kwargs...) = bulkscan_reduced(Y, G, nothing, K; kwargs...)
 
 # nb / nt_blas are accepted and ignored (thread blocking knobs of the CPU implementation)
 function bulkscan_null(Y::Array{Float64, 2}, G::Array{Float64, 2}, K::Array{Float64, 2};
                        nb::Int64 = Threads.nthreads(), nt_blas::Int64 = 1, weights = missing,
                        prior_variance::Float64 = 1.0, prior_sample_size::Float64 = 0.0, reml::Bool = false,
-                       optim_interval::Int64 = 1, decomp_scheme::String = "eigen")
+                       optim_interval::Int64 = 1, decomp_scheme::String = "eigen", keep_on_device::Bool = false, pvals_df::Int64 = 0)
     (L, h2) = _bulkscan(NULL_EXACT, Y, G, nothing, K, Float64[]; addIntercept = true, weights = weights,
                         prior_variance = prior_variance, prior_sample_size = prior_sample_size, reml = reml,
-                        optim_interval = optim_interval, decomp_scheme = decomp_scheme)
+                        optim_interval = optim_interval, decomp_scheme = decomp_scheme, keep_on_device = keep_on_device, pvals_df = pvals_df)
     return (L = L, h2_null_list = h2)
 end
 function bulkscan_null(Y::Array{Float64, 2}, G::Array{Float64, 2}, Covar::Array{Float64, 2}, K::Array{Float64, 2};
                        nb::Int64 = Threads.nthreads(), nt_blas::Int64 = 1, addIntercept::Bool = true, weights = missing,
                        prior_variance::Float64 = 1.0, prior_sample_size::Float64 = 0.0, reml::Bool = false,
-                       optim_interval::Int64 = 1, decomp_scheme::String = "eigen")
+                       optim_interval::Int64 = 1, decomp_scheme::String = "eigen", keep_on_device::Bool = false, pvals_df::Int64 = 0)
     (L, h2) = _bulkscan(NULL_EXACT, Y, G, Covar, K, Float64[]; addIntercept = addIntercept, weights = weights,
                         prior_variance = prior_variance, prior_sample_size = prior_sample_size, reml = reml,
-                        optim_interval = optim_interval, decomp_scheme = decomp_scheme)
+                        optim_interval = optim_interval, decomp_scheme = decomp_scheme, keep_on_device = keep_on_device, pvals_df = pvals_df)
     return (L = L, h2_null_list = h2)
 end
 
 function bulkscan_null_grid(Y::Array{Float64, 2}, G::Array{Float64, 2}, K::Array{Float64, 2}, grid_list::Array{Float64, 1};
                             weights = missing, prior_variance::Float64 = 1.0, prior_sample_size::Float64 = 0.0,
-                            reml::Bool = false, decomp_scheme::String = "eigen")
+                            reml::Bool = false, decomp_scheme::String = "eigen", keep_on_device::Bool = false, pvals_df::Int64 = 0)
     (L, h2) = _bulkscan(NULL_GRID, Y, G, nothing, K, grid_list; addIntercept = true, weights = weights,
                         prior_variance = prior_variance, prior_sample_size = prior_sample_size, reml = reml,
-                        optim_interval = 1, decomp_scheme = decomp_scheme)
+                        optim_interval = 1, decomp_scheme = decomp_scheme, keep_on_device = keep_on_device, pvals_df = pvals_df)
     return (L = L, h2_null_list = h2)
 end
 function bulkscan_null_grid(Y::Array{Float64, 2}, G::Array{Float64, 2}, Covar::Array{Float64, 2}, K::Array{Float64, 2},
                             grid_list::Array{Float64, 1}; weights = missing, addIntercept::Bool = true,
                             prior_variance::Float64 = 1.0, prior_sample_size::Float64 = 0.0, reml::Bool = false,
-                            decomp_scheme::String = "eigen")
+                            decomp_scheme::String = "eigen", keep_on_device::Bool = false, pvals_df::Int64 = 0)
     (L, h2) = _bulkscan(NULL_GRID, Y, G, Covar, K, grid_list; addIntercept = addIntercept, weights = weights,
                         prior_variance = prior_variance, prior_sample_size = prior_sample_size, reml = reml,
-                        optim_interval = 1, decomp_scheme = decomp_scheme)
+                        optim_interval = 1, decomp_scheme = decomp_scheme, keep_on_device = keep_on_device, pvals_df = pvals_df)
     return (L = L, h2_null_list = h2)
 end
 
 function bulkscan_alt_grid(Y::Array{Float64, 2}, G::Array{Float64, 2}, K::Array{Float64, 2}, hsq_list::Array{Float64, 1};
                            reml::Bool = false, prior_variance::Float64 = 1.0, prior_sample_size::Float64 = 0.0,
-                           weights = missing, decomp_scheme::String = "eigen")
+                           weights = missing, decomp_scheme::String = "eigen", keep_on_device::Bool = false, pvals_df::Int64 = 0)
     (L, h2) = _bulkscan(ALT_GRID, Y, G, nothing, K, hsq_list; addIntercept = true, weights = weights,
                         prior_variance = prior_variance, prior_sample_size = prior_sample_size, reml = reml,
-                        optim_interval = 1, decomp_scheme = decomp_scheme)
+                        optim_interval = 1, decomp_scheme = decomp_scheme, keep_on_device = keep_on_device, pvals_df = pvals_df)
     return (L = L, h2_panel = h2)
 end
 function bulkscan_alt_grid(Y::Array{Float64, 2}, G::Array{Float64, 2}, Covar::Array{Float64, 2}, K::Array{Float64, 2},
                            hsq_list::Array{Float64, 1}; reml::Bool = false, prior_variance::Float64 = 1.0,
                            prior_sample_size::Float64 = 0.0, weights = missing, addIntercept::Bool = true,
-                           decomp_scheme::String = "eigen")
+                           decomp_scheme::String = "eigen", keep_on_device::Bool = false, pvals_df::Int64 = 0)
     (L, h2) = _bulkscan(ALT_GRID, Y, G, Covar, K, hsq_list; addIntercept = addIntercept, weights = weights,
                         prior_variance = prior_variance, prior_sample_size = prior_sample_size, reml = reml,
-                        optim_interval = 1, decomp_scheme = decomp_scheme)
+                        optim_interval = 1, decomp_scheme = decomp_scheme, keep_on_device = keep_on_device, pvals_df = pvals_df)
     return (L = L, h2_panel = h2)
 end
 
@@ -174,12 +288,12 @@ function bulkscan(Y::Array{Float64, 2}, G::Array{Float64, 2}, K::Array{Float64, 
                   prior_variance::Float64 = 1.0, prior_sample_size::Float64 = 0.0,
                   reml::Bool = false, optim_interval::Int64 = 1,
                   decomp_scheme::String = "eigen",
-                  output_pvals::Bool = false, chisq_df::Int64 = 1)
+                  output_pvals::Bool = false, chisq_df::Int64 = 1, keep_on_device::Bool = false)
     # when no covariates are added, make the intercept the only covariate (src/bulkscan.jl:97-108)
     return bulkscan(Y, G, ones(size(Y, 1), 1), K; method = method, h2_grid = h2_grid, nb = nb, nt_blas = nt_blas,
                     addIntercept = false, weights = weights, prior_variance = prior_variance,
                     prior_sample_size = prior_sample_size, reml = reml, optim_interval = optim_interval,
-                    decomp_scheme = decomp_scheme, output_pvals = output_pvals, chisq_df = chisq_df)
+                    decomp_scheme = decomp_scheme, output_pvals = output_pvals, chisq_df = chisq_df, keep_on_device = keep_on_device)
 end
 function bulkscan(Y::Array{Float64, 2}, G::Array{Float64, 2}, Covar::Array{Float64, 2}, K::Array{Float64, 2};
                   method::String = "null-grid", h2_grid::Array{Float64, 1} = collect(0.0:0.1:0.9),
@@ -188,25 +302,22 @@ function bulkscan(Y::Array{Float64, 2}, G::Array{Float64, 2}, Covar::Array{Float
                   prior_variance::Float64 = 1.0, prior_sample_size::Float64 = 0.0,
                   reml::Bool = false, optim_interval::Int64 = 1,
                   decomp_scheme::String = "eigen",
-                  output_pvals::Bool = false, chisq_df::Int64 = 1)
-    # `output_pvals`: asked for before the scan, so that the scan kernels write -log10 p from their epilogues (chisq_df = 1,
-    # null-* methods; otherwise the column pass runs inside the call) into a buffer of the context that _last_log10p hands out
-    if output_pvals && method in ("null-exact", "null-grid", "alt-grid")
-        check(ccall((:blmm_set_log10p_output, libblmm), Cint, (Ptr{Cvoid}, Ptr{Float64}, Int64, Int64),
-                    context(), Ptr{Float64}(C_NULL), Int64(0), chisq_df))
-    end
+                  output_pvals::Bool = false, chisq_df::Int64 = 1, keep_on_device::Bool = false)
+    # keep_on_device = true (not in the reference): `L` is a DeviceLOD -- the p x m matrix stays in HBM and lod_colmax /
+    # lod_threshold / get_thresholds / lod_columns reduce it there
+    pv = output_pvals ? chisq_df : Int64(0)
     if method == "null-exact"
         res = bulkscan_null(Y, G, Covar, K; addIntercept = addIntercept, weights = weights, prior_variance = prior_variance,
                             prior_sample_size = prior_sample_size, reml = reml, optim_interval = optim_interval,
-                            decomp_scheme = decomp_scheme)
+                            decomp_scheme = decomp_scheme, keep_on_device = keep_on_device, pvals_df = pv)
     elseif method == "null-grid"
         res = bulkscan_null_grid(Y, G, Covar, K, h2_grid; addIntercept = addIntercept, weights = weights,
                                  prior_variance = prior_variance, prior_sample_size = prior_sample_size, reml = reml,
-                                 decomp_scheme = decomp_scheme)
+                                 decomp_scheme = decomp_scheme, keep_on_device = keep_on_device, pvals_df = pv)
     elseif method == "alt-grid"
         res = bulkscan_alt_grid(Y, G, Covar, K, h2_grid; addIntercept = addIntercept, weights = weights,
                                 prior_variance = prior_variance, prior_sample_size = prior_sample_size, reml = reml,
-                                decomp_scheme = decomp_scheme)
+                                decomp_scheme = decomp_scheme, keep_on_device = keep_on_device, pvals_df = pv)
     else
         error("Unknown method `$method`; choose null-exact, null-grid or alt-grid.")  # the reference hits an UndefVarError here
     end

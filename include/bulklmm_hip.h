@@ -28,7 +28,9 @@
 extern "C" {
 #endif
 
-#define BLMM_VERSION 205 /* 0.2.2: blmm_status.n_h2_boundary / n_h2_multimodal / n_illcond_rescan (appended), BLMM_FLAG_H2_AUDIT;
+#define BLMM_VERSION 210 /* 0.2.3: L_out == NULL keeps the matrix in HBM (blmm_bulkscan, blmm_bulkscan_multi), blmm_last_lod_colmax /
+                            blmm_last_lod_columns / blmm_last_dims, blmm_bulkscan_reduced[_dev] (no L at all), blmm_tuning;
+                            205 (0.2.2): blmm_status.n_h2_boundary / n_h2_multimodal / n_illcond_rescan (appended), BLMM_FLAG_H2_AUDIT;
                             201: lowrank_shared, readers, blmm_scan_alt; 200: lowrank_fallback, BLMM_STREAM_NULL, multi-GPU */
 
 typedef struct blmm_ctx blmm_ctx;
@@ -134,7 +136,28 @@ int blmm_read_timings(blmm_ctx* ctx, double* sums_ms, int64_t* ncalls);
  * then per segment s: traits, rank R_s of its weight basis (2 (n + (1 + c) 4 ceil(R_s / 4)) flop per test)}.  A diagnostic for
  * benchmarks that price the executed arithmetic (bench.py); the reference has no counterpart. */
 int blmm_lowrank_profile(blmm_ctx* ctx, int64_t* out);
+/* Where each trait sat in that call's data-dependent panel layout (two regions split by the h2 search's hand-over; in each the
+ * shared-weights class from the front, the weight-basis segments from the back): col_out[j] = panel column of trait j (-1: none),
+ * *region_width = columns per region (region = col / width), counts_out[4] = {shared-weights traits, columns of the other class}
+ * of region 0, then of region 1.  For tests that report the class / region of their worst entry. */
+int blmm_lowrank_columns(blmm_ctx* ctx, int64_t m, int32_t* col_out, int64_t* region_width, int64_t* counts_out);
 int blmm_synchronize(blmm_ctx* ctx);
+/* ---- tuning: the switches that select another ARITHMETIC path are properties of the context (they were BLMM_* environment
+ * variables up to 0.2.2; the environment is now read only under BLMM_DEV_ENV=1, for A/B timing by developers).  Keys and defaults:
+ *   "lr_tol"          1e-13  relative residual of the weight-basis expansion above which a trait's LOD column is recomputed from
+ *                            the full-length sums, and the tolerance of the shared-weights class (0: every trait re-scanned)
+ *   "illcond_rho"     1e-4   pivot-share threshold of the conditioning guard (0: off; 2: every trait with >= 2 covariates re-scanned)
+ *   "exact_full_rank" 0      1: null-exact through the full-rank kernel (2n(2+c) flop per test) instead of the low-rank weights form
+ *   "pval_libm"       0      1: -log10 p through erfc / erfcx / log instead of the bucketed polynomials (chisq_df = 1)
+ *   "pval_fused"      1      0: output_pvals as a pass over the finished L instead of a second output of the scan epilogues
+ *   "lr_segments"     0      weight bases per heritability axis: 0 = default (six for n <= 80, else one), 1, or 2..8 equal segments
+ *   "lr_shared"       1      0: no shared-weights class (traits with h2 = 0 go through the rank-R form like the others)
+ *   "lr_split"        -1     split h2 search / two panel regions: -1 = from 8192 traits on, 0 never, 1 always
+ *   "eigen_solver"    0      0 = by n; 1 = Jacobi; 2 = tridiagonalisation + divide and conquer
+ *   "defaults"               (set only) every key back to its default
+ * Every setting gives results within the library's stated tolerances; they exist for tests and for A/B measurements. */
+int blmm_set_tuning(blmm_ctx* ctx, const char* key, double value);
+int blmm_get_tuning(const blmm_ctx* ctx, const char* key, double* value);
 void blmm_default_opts(blmm_opts* o); /* bulkscan() defaults: null-grid, ML, prior (1.0, 0.0), eigen */
 
 /* ---- pinned host memory for the outputs of the host-pointer entry points ------------------------------------------
@@ -173,7 +196,10 @@ int blmm_kinship_rounded(blmm_ctx* ctx, const double* G, int64_t n, int64_t p, i
  * K n x n, weights n (NULL = missing), h2_grid ngrid doubles in HOST memory for both variants
  * (ignored by null-exact).
  * Outputs: L p x m (column j = trait j, leading dimension ldL >= p); h2_out: m doubles
- * (h2_null_list; null-exact / null-grid) or p x m, ld = p (h2_panel; alt-grid). */
+ * (h2_null_list; null-exact / null-grid) or p x m, ld = p (h2_panel; alt-grid).
+ * blmm_bulkscan with L_out == NULL: the matrix is not copied to the host; it stays in the context's workspace, where
+ * blmm_last_lod_colmax / blmm_last_lod_threshold / blmm_last_get_thresholds / blmm_last_log10p / blmm_last_lod_columns serve it
+ * until the next call that produces a matrix (alt-grid: h2_out may be NULL likewise). */
 int blmm_bulkscan(blmm_ctx* ctx, const blmm_opts* opts, const double* Y, int64_t n, int64_t m, const double* G,
                   int64_t p, const double* Covar, int64_t ncov, const double* K, const double* weights,
                   const double* h2_grid, int64_t ngrid, double* L_out, double* h2_out, blmm_status* status);
@@ -181,6 +207,40 @@ int blmm_bulkscan_dev(blmm_ctx* ctx, const blmm_opts* opts, const double* dY, in
                       const double* dG, int64_t p, const double* dCovar, int64_t ncov, const double* dK,
                       const double* dweights, const double* h2_grid_host, int64_t ngrid, double* dL_out,
                       int64_t ldL, double* dh2_out, blmm_status* status);
+
+/* ---- bulkscan WITHOUT the LOD matrix.  What the reference's users do with L is reduce it: the peak LOD of every
+ * trait and its marker, the (marker, trait) pairs above a threshold (README.md:246-255, 354-359;
+ * src/analysis_helpers/single_trait_analysis.jl:13-23).  Here the scan kernels do that in their epilogues and L is never
+ * written (2.08 GB of HBM writes and 36 ms of PCIe at BXD size):
+ *   colmax[j]  = max_i L[i, j],  argmax[j] = the lowest such i (0-based; -1: no finite-comparable entry)   -- m each, or NULL
+ *   want_triplets != 0: every (i, j) with L[i, j] > thr as (ti, tj, tlod), order unspecified; *count = how many exist, the first
+ *   `cap` of them are stored (call again with a larger cap when *count > cap)
+ * bit-identical to blmm_lod_colmax_dev / blmm_lod_threshold_dev on the matrix blmm_bulkscan_dev writes.  The pointers inside
+ * `out` are HOST pointers for blmm_bulkscan_reduced and DEVICE pointers for blmm_bulkscan_reduced_dev; h2_out as in
+ * blmm_bulkscan (null-exact / null-grid: m; alt-grid: not written, may be NULL).  null-grid, and null-exact with up to 3 null
+ * covariates, run fused; alt-grid, more covariates, or a call in which a trait needs one of the per-trait re-scans
+ * (blmm_status.lowrank_fallback / n_illcond_rescan > 0) go through a matrix that stays in the context's workspace -- same results,
+ * and the blmm_last_* consumers then serve that matrix.  blmm_last_reduced_route: 1 fused, 2 through the resident matrix.
+ * Both forms return when the results are complete (they synchronise the stream). */
+typedef struct blmm_reduced {
+  double* colmax;
+  int64_t* argmax;
+  int64_t want_triplets;
+  double thr;
+  int64_t cap;
+  int32_t* ti;
+  int32_t* tj;
+  double* tlod;
+  int64_t* count;
+} blmm_reduced;
+int blmm_bulkscan_reduced(blmm_ctx* ctx, const blmm_opts* opts, const double* Y, int64_t n, int64_t m, const double* G,
+                          int64_t p, const double* Covar, int64_t ncov, const double* K, const double* weights,
+                          const double* h2_grid, int64_t ngrid, const blmm_reduced* out, double* h2_out, blmm_status* status);
+int blmm_bulkscan_reduced_dev(blmm_ctx* ctx, const blmm_opts* opts, const double* dY, int64_t n, int64_t m, const double* dG,
+                              int64_t p, const double* dCovar, int64_t ncov, const double* dK, const double* dweights,
+                              const double* h2_grid_host, int64_t ngrid, const blmm_reduced* out, double* dh2_out,
+                              blmm_status* status);
+int blmm_last_reduced_route(const blmm_ctx* ctx);
 
 /* ---- the pipeline in three calls, for hosts that run ONE PROCESS PER GPU (torch.distributed, MPI; bench.py --gpus N):
  * blmm_bulkscan_dev on every rank repeats the rotation of the whole G (10-25 % of a rank's step at n >= 500).  Instead every
@@ -212,7 +272,8 @@ int blmm_scan_perms_prerotated_dev(blmm_ctx* ctx, const blmm_opts* opts, const d
  * the column block [r*ceil(m/R), min(m, (r+1)*ceil(m/R))) (blmm_multi_shard) and owns that block of the column-major
  * L.  One host worker thread per device; G/K/Covar/weights are replicated; no collective on the data path.
  *   gather_mode  BLMM_GATHER_HOST_SHARDS (default): every device copies its block straight into the caller's L_out /
- *                  h2_out over its own PCIe link -- the reference's result, L in host memory;
+ *                  h2_out over its own PCIe link -- the reference's result, L in host memory; L_out == NULL: the blocks stay in
+ *                  HBM and blmm_multi_last_colmax / blmm_multi_last_lod_threshold reduce them there;
  *                BLMM_GATHER_NONE: the blocks stay in HBM (blmm_multi_device_result); L_out / h2_out may be NULL
  *                  (when given they are filled as well);
  *                BLMM_GATHER_ALLGATHER: an RCCL all-gather over xGMI leaves the FULL p x m matrix (ld = p, columns
@@ -235,6 +296,12 @@ int blmm_bulkscan_multi(blmm_multi* mc, const blmm_opts* opts, const blmm_multi_
                         int64_t m, const double* G, int64_t p, const double* Covar, int64_t ncov, const double* K,
                         const double* weights, const double* h2_grid, int64_t ngrid, double* L_out, double* h2_out,
                         blmm_status* status);
+/* Consumers of the last blmm_bulkscan_multi call's blocks WHERE THEY ARE (any gather mode; with host_shards and L_out == NULL the
+ * matrix never leaves the devices): per-trait maxima (max_out m, argmax_out m or NULL) and LOD > thr triplets with global trait
+ * indices, every device reducing its own block (the rules of blmm_lod_colmax / blmm_lod_threshold). */
+int blmm_multi_last_colmax(blmm_multi* mc, double* max_out, int64_t* argmax_out);
+int blmm_multi_last_lod_threshold(blmm_multi* mc, double thr, int64_t cap, int32_t* i_out, int32_t* j_out, double* lod_out,
+                                  int64_t* count_out);
 /* Device-resident result of the last blmm_bulkscan_multi with gather_mode none / allgather on device `rank`:
  * *dL (ld *ldL) holds the columns [*col_lo, *col_hi) of L, *dh2 the matching h2 entries. */
 int blmm_multi_device_result(blmm_multi* mc, int rank, double** dL, int64_t* ldL, int64_t* col_lo, int64_t* col_hi,
@@ -328,6 +395,11 @@ int blmm_last_log10p(blmm_ctx* ctx, int64_t chisq_df, double* P_out);
 int blmm_last_lod_threshold(blmm_ctx* ctx, double thr, int64_t cap, int32_t* i_out, int32_t* j_out, double* lod_out,
                             int64_t* count_out);
 int blmm_last_get_thresholds(blmm_ctx* ctx, const double* probs, int64_t nprobs, double* thrs_out);
+/* shape of the resident matrix (0 x 0 and BLMM_ERR_INVALID when there is none); its column maxima (max_out m, argmax_out m or
+ * NULL; the rule of blmm_lod_colmax); selected columns: out is p x ncols, column k = L[:, cols[k]] (0-based) */
+int blmm_last_dims(const blmm_ctx* ctx, int64_t* p_out, int64_t* m_out);
+int blmm_last_lod_colmax(blmm_ctx* ctx, double* max_out, int64_t* argmax_out);
+int blmm_last_lod_columns(blmm_ctx* ctx, const int64_t* cols, int64_t ncols, double* out);
 
 /* ---- lower-level seams (1:1 with the reference's internal functions; used by the parity tests) ---- */
 /* transform_rotation(y, [Z G], K)  (src/transform_helpers.jl:1-54): Y0 n x m, X0 n x (c+p) (first c

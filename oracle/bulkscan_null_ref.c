@@ -200,9 +200,13 @@ static void brent_min(const NullFit* f, double x_lower, double x_upper, double* 
 
 /* Y n x m, G n x p, Covar n x ncov (may be NULL), K n x n, all column-major.  add_intercept != 0: [1 Covar] is the null design.
  * L p x m (ld = p), h2 m.  Returns 0, or -1 on a bad argument. */
-int blmm_ref_bulkscan_null(const double* Y, int64_t n64, int64_t m, const double* G, int64_t p, const double* Covar, int64_t ncov,
-                           int add_intercept, const double* K, double prior_variance, double prior_sample_size, int reml,
-                           int optim_interval, double* L, double* h2_out, int nthreads) {
+/* h2_override (NULL or m values): the LOD columns are evaluated at THESE heritabilities instead of the search's own (the tests
+ * hand in the device's estimates, so that every entry of L can be held to 1e-6 without the optimiser's stopping rule in between:
+ * oracle/bulklmm_oracle.py's bulkscan_null(..., h2_override=...) does the same); h2_out then still receives the restatement's OWN
+ * Brent estimates unless skip_search != 0 (h2_out = the override then). */
+static int ref_bulkscan_null(const double* Y, int64_t n64, int64_t m, const double* G, int64_t p, const double* Covar, int64_t ncov,
+                             int add_intercept, const double* K, double prior_variance, double prior_sample_size, int reml,
+                             int optim_interval, double* L, double* h2_out, int nthreads, const double* h2_override, int skip_search) {
   const int n = (int)n64;
   const int c = (int)ncov + (add_intercept ? 1 : 0);
   if (n < 2 || c < 1 || c > CMAXR || c >= n || m < 0 || p < 0) return -1;
@@ -252,13 +256,15 @@ int blmm_ref_bulkscan_null(const double* Y, int64_t n64, int64_t m, const double
       /* fitlmm: gridbrent over optim_interval sub-intervals of [0, 1], first smallest minimum wins */
       NullFit f = {n, c, reml, prior_variance, prior_sample_size, Y0 + (size_t)j * n, Z0, lam, ws};
       double best_x = 0.0, best_f = INFINITY;
-      for (int s = 0; s < optim_interval; ++s) {
-        double x, fx;
-        brent_min(&f, (double)s / optim_interval, (double)(s + 1) / optim_interval, &x, &fx);
-        if (fx < best_f) { best_f = fx; best_x = x; }
-      }
-      const double h2 = best_x;
-      h2_out[j] = h2;
+      if (!(h2_override && skip_search))
+        for (int s = 0; s < optim_interval; ++s) {
+          double x, fx;
+          brent_min(&f, (double)s / optim_interval, (double)(s + 1) / optim_interval, &x, &fx);
+          if (fx < best_f) { best_f = fx; best_x = x; }
+        }
+      else best_x = h2_override[j];
+      const double h2 = h2_override ? h2_override[j] : best_x;
+      h2_out[j] = best_x;
       /* univar_liteqtl: sqrtw = sqrt.(abs.(makeweights(h2, lambda))); row scaling; computeR_LMM; r2lod */
       const double delta = h2 / (1.0 - h2);
       for (int k = 0; k < n; ++k) sqrtw[k] = sqrt(fabs(1.0 / (delta * lam[k] + 1.0)));
@@ -322,6 +328,20 @@ int blmm_ref_bulkscan_null(const double* Y, int64_t n64, int64_t m, const double
   }
   free(U); free(lam); free(Z0); free(X0); free(Y0);
   return bad ? -8 : 0;
+}
+
+int blmm_ref_bulkscan_null(const double* Y, int64_t n64, int64_t m, const double* G, int64_t p, const double* Covar, int64_t ncov,
+                           int add_intercept, const double* K, double prior_variance, double prior_sample_size, int reml,
+                           int optim_interval, double* L, double* h2_out, int nthreads) {
+  return ref_bulkscan_null(Y, n64, m, G, p, Covar, ncov, add_intercept, K, prior_variance, prior_sample_size, reml, optim_interval, L,
+                           h2_out, nthreads, NULL, 0);
+}
+
+int blmm_ref_bulkscan_null_at(const double* Y, int64_t n64, int64_t m, const double* G, int64_t p, const double* Covar, int64_t ncov,
+                              int add_intercept, const double* K, double prior_variance, double prior_sample_size, int reml,
+                              int optim_interval, double* L, double* h2_out, int nthreads, const double* h2_override, int skip_search) {
+  return ref_bulkscan_null(Y, n64, m, G, p, Covar, ncov, add_intercept, K, prior_variance, prior_sample_size, reml, optim_interval, L,
+                           h2_out, nthreads, h2_override, skip_search);
 }
 
 int blmm_ref_max_threads(void) {

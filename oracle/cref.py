@@ -45,14 +45,18 @@ def load():
         lib = C.CDLL(build())
         vp, i64 = C.c_void_p, C.c_int64
         lib.blmm_ref_bulkscan_null.argtypes = [vp, i64, i64, vp, i64, vp, i64, C.c_int, vp, C.c_double, C.c_double, C.c_int, C.c_int, vp, vp, C.c_int]
+        lib.blmm_ref_bulkscan_null_at.argtypes = [vp, i64, i64, vp, i64, vp, i64, C.c_int, vp, C.c_double, C.c_double, C.c_int, C.c_int, vp, vp, C.c_int,
+                                                  vp, C.c_int]
         lib.blmm_ref_max_threads.restype = C.c_int
         _lib = lib
     return _lib
 
 
 def bulkscan_null(Y, G, K, Covar=None, addIntercept=True, prior_variance=1.0, prior_sample_size=0.0, reml=False, optim_interval=1,
-                  nthreads=0):
-    """(L p x m, h2 m) of src/bulkscan.jl:212-314 computed by the C restatement; nthreads = 0: OpenMP's default."""
+                  nthreads=0, h2_override=None, skip_search=False):
+    """(L p x m, h2 m) of src/bulkscan.jl:212-314 computed by the C restatement; nthreads = 0: OpenMP's default.
+    h2_override (m values): L is evaluated at these heritabilities (as bulklmm_oracle.bulkscan_null(..., h2_override=...)); the
+    returned h2 is still the restatement's own Brent estimate unless skip_search."""
     lib = load()
     Y = np.asfortranarray(np.asarray(Y, dtype=np.float64).reshape(np.shape(Y)[0], -1))
     G = np.asfortranarray(np.asarray(G, dtype=np.float64))
@@ -68,8 +72,14 @@ def bulkscan_null(Y, G, K, Covar=None, addIntercept=True, prior_variance=1.0, pr
     L = np.empty((p, m), order="F")
     h2 = np.empty(m)
     ptr = lambda a: None if a is None else a.ctypes.data_as(C.c_void_p)   # noqa: E731
-    rc = lib.blmm_ref_bulkscan_null(ptr(Y), n, m, ptr(G), p, ptr(cov), ncov, int(bool(addIntercept)), ptr(K), float(prior_variance),
-                                    float(prior_sample_size), int(bool(reml)), int(optim_interval), ptr(L), ptr(h2), int(nthreads))
+    ov = None
+    if h2_override is not None:
+        ov = np.ascontiguousarray(np.asarray(h2_override, dtype=np.float64).ravel())
+        if ov.shape[0] != m:
+            raise ValueError("h2_override: one value per trait")
+    rc = lib.blmm_ref_bulkscan_null_at(ptr(Y), n, m, ptr(G), p, ptr(cov), ncov, int(bool(addIntercept)), ptr(K), float(prior_variance),
+                                       float(prior_sample_size), int(bool(reml)), int(optim_interval), ptr(L), ptr(h2), int(nthreads),
+                                       ptr(ov), int(bool(skip_search)))
     if rc == -8:
         raise ZeroDivisionError("Dividing by zeros: the input vector can not contain any zeros!")
     if rc != 0:

@@ -24,3 +24,14 @@ def blmm():
 def gpu_ctx(blmm):
     ctx = blmm.default_context()
     return ctx
+
+
+@pytest.fixture(autouse=True)
+def _default_tuning_after_each_test():
+    """Tests that change the tuning of the shared default context (blmm_set_tuning: the switches that select another arithmetic
+    path) get it back to the defaults afterwards, whatever they did."""
+    yield
+    mod = sys.modules.get("bulklmm_jl_amd.api") or sys.modules.get("bulklmm.jl_amd.api")
+    ctx = getattr(mod, "_default_ctx", None) if mod else None
+    if ctx is not None and getattr(ctx, "h", None):
+        ctx.set_tuning("defaults", 0)

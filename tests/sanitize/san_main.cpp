@@ -24,6 +24,24 @@ int ensure(blmm_ctx* ctx, DevBuf& b, size_t bytes) {
   b.p = std::malloc(bytes); b.cap = bytes;
   return b.p ? BLMM_OK : fail(ctx, BLMM_ERR_ALLOC, "malloc");
 }
+// CPU stand-ins for the two column-pass launchers the multi-device consumers call (kernels_prep.hip / kernels_post.hip)
+int launch_colmax(blmm_ctx*, const double* L, int64_t p, int64_t m, int64_t ldL, double* mx, int64_t* arg) {
+  for (int64_t j = 0; j < m; ++j) {
+    double best = -INFINITY; int64_t bi = -1;
+    for (int64_t i = 0; i < p; ++i) if (L[j * ldL + i] > best) { best = L[j * ldL + i]; bi = i; }
+    mx[j] = best; if (arg) arg[j] = bi;
+  }
+  return BLMM_OK;
+}
+int launch_threshold(blmm_ctx*, const double* L, int64_t p, int64_t m, int64_t ldL, double thr, int64_t cap, int32_t* di, int32_t* dj,
+                     double* dl, int64_t* dcount) {
+  int64_t c = 0;
+  for (int64_t j = 0; j < m; ++j)
+    for (int64_t i = 0; i < p; ++i)
+      if (L[j * ldL + i] > thr) { if (c < cap) { di[c] = (int32_t)i; dj[c] = (int32_t)j; dl[c] = L[j * ldL + i]; } ++c; }
+  *dcount = c;
+  return BLMM_OK;
+}
 }  // namespace blmm
 using namespace blmm;
 
@@ -50,7 +68,7 @@ int blmm_create(int device_id, void*, blmm_ctx** out) {
 }
 void blmm_destroy(blmm_ctx* ctx) {
   if (!ctx) return;
-  std::free(ctx->outL.p); std::free(ctx->outH2.p);
+  std::free(ctx->outL.p); std::free(ctx->outH2.p); std::free(ctx->tmpA.p); std::free(ctx->tmpB.p); std::free(ctx->redtrip.p);
   destroy_host_stage(ctx->hstage);
   delete ctx;
 }
@@ -70,9 +88,10 @@ int blmm_bulkscan(blmm_ctx* ctx, const blmm_opts* o, const double* Y, int64_t n,
   if ((rc = ensure(ctx, ctx->outH2, sizeof(double) * (size_t)((alt ? p * m : m) + 1)))) return rc;
   rc = blmm_bulkscan_dev(ctx, o, Y, n, m, G, p, C, nc, K, w, grid, ng, ptr<double>(ctx->outL), p, ptr<double>(ctx->outH2), st);
   if (rc) return rc;
-  // through the real device -> host leg (staging ring + CopyPool when the block is large)
-  if (p * m > 0 && (rc = copy_to_host(ctx, L_out, ctx->outL.p, sizeof(double) * (size_t)(p * m)))) return rc;
-  if ((rc = copy_to_host(ctx, h2_out, ctx->outH2.p, sizeof(double) * (size_t)(alt ? p * m : m)))) return rc;
+  ctx->last_L = ptr<double>(ctx->outL); ctx->last_p = p; ctx->last_m = m; ctx->last_f32 = false;
+  // through the real device -> host leg (staging ring + CopyPool when the block is large); L_out == NULL: the block stays "in HBM"
+  if (L_out && p * m > 0 && (rc = copy_to_host(ctx, L_out, ctx->outL.p, sizeof(double) * (size_t)(p * m)))) return rc;
+  if (h2_out && (rc = copy_to_host(ctx, h2_out, ctx->outH2.p, sizeof(double) * (size_t)(alt ? p * m : m)))) return rc;
   return BLMM_OK;
 }
 }  // extern "C"
@@ -83,6 +102,7 @@ static void test_copy_pool() {
   blmm_ctx* ctx = nullptr;
   REQUIRE(blmm_create(0, nullptr, &ctx) == BLMM_OK);
   const size_t sizes[] = {0, 1, 4095, 4097, ((size_t)8 << 20) - 1, ((size_t)8 << 20) + 3, ((size_t)40 << 20) + 12345, ((size_t)140 << 20) + 7};
+  setenv("BLMM_DEV_ENV", "1", 1);                                 // the library reads BLMM_* switches only as developer switches
   for (const char* nt : {"1", "2", "5", "9"}) {
     setenv("BLMM_D2H_THREADS", nt, 1);
     destroy_host_stage(ctx->hstage); ctx->hstage = nullptr;       // a fresh pool with this thread count
@@ -126,6 +146,21 @@ static void test_multi() {
             REQUIRE(std::memcmp(L.data(), Lref.data(), sizeof(double) * (size_t)(p * m)) == 0);
             REQUIRE(std::memcmp(H.data(), Href.data(), sizeof(double) * (size_t)(alt ? p * m : m)) == 0);
             (void)hipGetDevice(&cur); REQUIRE(cur == cfg);
+            if (rep == 0 && m > 0) {
+              // the consumers of the blocks where they are, in every gather mode -- and with host_shards also without any L_out
+              std::vector<double> mx((size_t)m), mref((size_t)m); std::vector<int64_t> ax((size_t)m), aref((size_t)m);
+              launch_colmax(nullptr, Lref.data(), p, m, p, mref.data(), aref.data());
+              if (gather == BLMM_GATHER_HOST_SHARDS)
+                REQUIRE(blmm_bulkscan_multi(mc, &o, &mo, Y.data(), n, m, G.data(), p, nullptr, 0, K.data(), nullptr, nullptr, 0, nullptr, H.data(), st.data()) == BLMM_OK);
+              REQUIRE(blmm_multi_last_colmax(mc, mx.data(), ax.data()) == BLMM_OK);
+              REQUIRE(mx == mref && ax == aref);
+              const int64_t cap = 17;
+              std::vector<int32_t> ti((size_t)cap), tj((size_t)cap); std::vector<double> tl((size_t)cap); int64_t cnt = -1, cref = 0;
+              for (int64_t e = 0; e < p * m; ++e) cref += Lref[(size_t)e] > 0.5;
+              REQUIRE(blmm_multi_last_lod_threshold(mc, 0.5, cap, ti.data(), tj.data(), tl.data(), &cnt) == BLMM_OK);
+              REQUIRE(cnt == cref);
+              for (int64_t e = 0; e < (cnt < cap ? cnt : cap); ++e) REQUIRE(tl[(size_t)e] == Lref[(size_t)(tj[(size_t)e] * p + ti[(size_t)e])] && tl[(size_t)e] > 0.5);
+            }
             if (gather != BLMM_GATHER_HOST_SHARDS && m > 0) {
               double* dL = nullptr; double* dh = nullptr; int64_t ld = 0, lo = 0, hi = 0;
               REQUIRE(blmm_multi_device_result(mc, R - 1, &dL, &ld, &lo, &hi, &dh) == BLMM_OK);

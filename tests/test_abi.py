@@ -23,7 +23,7 @@ def test_library_exports_every_declared_symbol(blmm):
     for s in syms:
         assert hasattr(lib, s), s
     assert sorted(blmm.EXPORTS) == syms
-    assert lib.blmm_version() == 205
+    assert lib.blmm_version() == 210
 
 
 def header_struct(name):

@@ -77,7 +77,7 @@ def julia_structs():
     out = {}
     for mt in re.finditer(r"(?:mutable\s+)?struct\s+(\w+)\s*;?(.*?)\bend\b", julia_text(), flags=re.S):
         body = re.sub(r"\b\w+\(\)\s*=\s*new\(.*?\)", "", mt.group(2), flags=re.S)    # inner constructor
-        out[mt.group(1)] = re.findall(r"(\w+)::(\w+)", body)
+        out[mt.group(1)] = re.findall(r"(\w+)::([\w{}]+)", body)
     return out
 
 
@@ -117,9 +117,10 @@ def julia_ccalls():
     return out
 
 
-JL2C = {"Int32": "int32_t", "Int64": "int64_t", "Float64": "double", "UInt64": "uint64_t"}
-SIZE = {"int32_t": 4, "int64_t": 8, "double": 8, "uint64_t": 8}
-STRUCTS = {"BlmmOpts": "blmm_opts", "BlmmStatus": "blmm_status", "BlmmMultiOpts": "blmm_multi_opts"}
+JL2C = {"Int32": "int32_t", "Int64": "int64_t", "Float64": "double", "UInt64": "uint64_t",
+        "Ptr{Float64}": "double*", "Ptr{Int64}": "int64_t*", "Ptr{Int32}": "int32_t*"}
+SIZE = {"int32_t": 4, "int64_t": 8, "double": 8, "uint64_t": 8, "double*": 8, "int64_t*": 8, "int32_t*": 8}
+STRUCTS = {"BlmmOpts": "blmm_opts", "BlmmStatus": "blmm_status", "BlmmMultiOpts": "blmm_multi_opts", "BlmmReduced": "blmm_reduced"}
 
 OPAQUE = {"Ptr{Cvoid}"}
 ALLOWED = {
@@ -132,7 +133,8 @@ ALLOWED = {
     "int64_t": {"Int64"}, "uint64_t": {"UInt64"}, "int": {"Cint"}, "double": {"Float64", "Cdouble"},
     "const blmm_opts*": {"Ref{BlmmOpts}"}, "blmm_opts*": {"Ref{BlmmOpts}"},
     "blmm_status*": {"Ref{BlmmStatus}", "Ptr{Cvoid}"},      # Ptr{Cvoid}: C_NULL, or the per-device array of bulkscan_multi
-    "const blmm_multi_opts*": {"Ref{BlmmMultiOpts}"}, "const char*": {"Cstring"},
+    "const blmm_multi_opts*": {"Ref{BlmmMultiOpts}"}, "const char*": {"Cstring"}, "const blmm_reduced*": {"Ref{BlmmReduced}"},
+    "const int64_t*": {"Ptr{Int64}"},
 }
 RET = {"int": {"Cint"}, "void": {"Cvoid"}, "const char*": {"Cstring"}, "int64_t": {"Int64"}, "void*": {"Ptr{Cvoid}"}}
 
@@ -189,7 +191,9 @@ def test_every_ccall_matches_its_prototype():
     need = {"blmm_create", "blmm_kinship", "blmm_kinship_rounded", "blmm_bulkscan", "blmm_bulkscan_multi", "blmm_scan_perms",
             "blmm_scan_perms_f32", "blmm_scan_alt", "blmm_lod2log10p", "blmm_last_log10p", "blmm_get_thresholds", "blmm_lod_threshold",
             "blmm_lod_colmax", "blmm_host_alloc", "blmm_host_free", "blmm_host_register", "blmm_host_unregister", "blmm_read_csv",
-            "blmm_read_he", "blmm_create_multi", "blmm_destroy_multi", "blmm_multi_ndev", "blmm_set_log10p_output"}
+            "blmm_read_he", "blmm_create_multi", "blmm_destroy_multi", "blmm_multi_ndev", "blmm_set_log10p_output",
+            "blmm_bulkscan_reduced", "blmm_last_lod_colmax", "blmm_last_lod_threshold", "blmm_last_lod_columns", "blmm_last_dims",
+            "blmm_set_tuning"}
     assert need <= seen, sorted(need - seen)
 
 

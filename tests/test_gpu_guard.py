@@ -1,7 +1,7 @@
 """The null-exact LOD kernel runs a low-rank form of the per-trait weights (kernels_lowrank.hip).  These tests pin its
 guard: every trait's expansion residual is measured on the device, traits above 1e-13 are re-scanned from the full-length
 sums (k_scan_fix), and blmm_status says how many.  Adversarial spectra and heritabilities, the re-scan kernel compared
-with the oracle as a whole (BLMM_LR_TOL=0 flags every trait), and the full-size audit of all 35,554 h2 estimates against
+with the oracle as a whole (tuning lr_tol = 0 flags every trait), and the full-size audit of all 35,554 h2 estimates against
 the oracle's own Brent search.  Reference: src/bulkscan_helpers.jl:127-150, src/lmm.jl:15-33,56-86."""
 import os
 import subprocess
@@ -64,14 +64,17 @@ def test_lowrank_guard_on_adversarial_spectra_and_h2(blmm, spectrum):
 def test_rescan_kernel_equals_oracle_when_every_trait_is_flagged(blmm, ncov, monkeypatch):
     Y, G, K, Cov = make_data(p=333, m=77, seed=4100 + ncov, ncov=ncov)
     base = blmm.bulkscan_null(Y, G, K, Cov)
-    monkeypatch.setenv("BLMM_LR_TOL", "0")
-    L, h2, st = blmm.api._bulkscan_call(blmm._lib.BLMM_NULL_EXACT, Y, G, K, Cov, None, True, None, 1.0, 0.0, False, 1,
-                                        "eigen", 0, None, return_status=True)
+    dctx = blmm.default_context()
+    dctx.set_tuning("lr_tol", 0.0)      # (was BLMM_LR_TOL=0: numerics-changing switches are context tuning since 0.2.3)
+    try:
+        L, h2, st = blmm.api._bulkscan_call(blmm._lib.BLMM_NULL_EXACT, Y, G, K, Cov, None, True, None, 1.0, 0.0, False, 1,
+                                            "eigen", 0, None, return_status=True)
+    finally:
+        dctx.set_tuning("defaults", 0)
     assert st.lowrank_fallback == 77 and np.array_equal(h2, base.h2_null_list)
     pin = O.bulkscan_null(Y, G, K, Covar=Cov, h2_override=h2)
     assert_lod_close(L, pin.L)
     assert_lod_close(L, base.L, rtol=1e-9, atol=1e-12)      # the MFMA low-rank form and the plain full-length sums
-    monkeypatch.delenv("BLMM_LR_TOL")
     L2, _, st2 = blmm.api._bulkscan_call(blmm._lib.BLMM_NULL_EXACT, Y, G, K, Cov, None, True, None, 1.0, 0.0, False, 1,
                                          "eigen", 0, None, return_status=True)
     assert st2.lowrank_fallback == 0 and st2.lowrank_resid <= 1e-13 and np.array_equal(L2, base.L)
@@ -179,14 +182,11 @@ def test_segmented_weight_basis_equals_the_single_basis(blmm, segments, monkeypa
     was executed (blmm_lowrank_profile) shows several segments of lower rank whose traits add up."""
     Y, G, K, _ = make_data(n=79, p=300, m=2500, seed=8101, bxd=True)
     ctx = blmm.Context(0)
-    monkeypatch.setenv("BLMM_LR_SEGMENTS", "1")
+    ctx.set_tuning("lr_segments", 1)
     one = blmm.bulkscan_null(Y, G, K, ctx=ctx)
     shared1, prof1 = ctx.lowrank_profile()
     assert len(prof1) == 1
-    if segments == "default":
-        monkeypatch.delenv("BLMM_LR_SEGMENTS")
-    else:
-        monkeypatch.setenv("BLMM_LR_SEGMENTS", segments)
+    ctx.set_tuning("lr_segments", 0 if segments == "default" else int(segments))
     seg = blmm.bulkscan_null(Y, G, K, ctx=ctx)
     shared, prof = ctx.lowrank_profile()
     assert np.array_equal(seg.h2_null_list, one.h2_null_list)
@@ -203,11 +203,11 @@ def test_split_h2_search_equals_the_single_region_form(blmm, monkeypatch):
     default from 8192 traits) against one region (below): the same per-trait arithmetic, so h2 and every LOD bit for bit."""
     Y, G, K, _ = make_data(n=79, p=260, m=3000, seed=8202, bxd=True)
     ctx = blmm.Context(0)
-    monkeypatch.setenv("BLMM_LR_SPLIT", "0")
+    ctx.set_tuning("lr_split", 0)
     one = blmm.bulkscan_null(Y, G, K, ctx=ctx)
-    monkeypatch.setenv("BLMM_LR_SPLIT", "1")
+    ctx.set_tuning("lr_split", 1)
     two = blmm.bulkscan_null(Y, G, K, ctx=ctx)
-    monkeypatch.delenv("BLMM_LR_SPLIT")
+    ctx.set_tuning("lr_split", -1)
     auto = blmm.bulkscan_null(Y, G, K, ctx=ctx)
     assert np.array_equal(one.h2_null_list, two.h2_null_list) and np.array_equal(one.L, two.L) and np.array_equal(one.L, auto.L)
     shared, prof = ctx.lowrank_profile()

@@ -298,6 +298,7 @@ def test_scan_perms_multi_kernel_panel_equals_single_kernel(blmm, ncov, monkeypa
     Y, G, K, Cov = make_data(n=61, p=97, m=1, seed=515 + ncov, ncov=ncov, bxd=False)
     pidx = O.make_perm_idx(61, 70, 3)
     out = {}
+    monkeypatch.setenv("BLMM_DEV_ENV", "1")       # BLMM_PERM_PATH is a developer switch (same arithmetic, two kernel forms)
     for path in ("old", "new"):
         monkeypatch.setenv("BLMM_PERM_PATH", path)
         a = blmm.scan(Y[:, 0], G, K, Cov, permutation_test=True, nperms=70, perm_idx=pidx)
@@ -448,6 +449,7 @@ def test_own_eigensolver_up_to_2048_and_no_vendor_fallback(blmm, monkeypatch):
     the LDS budget of the tridiagonalisation its rows live in L2-resident global memory (k_sytrd<GLB>): bit-identical to the
     LDS form where both apply (forced with BLMM_SYTRD_GLB=1 at n = 300 and 700), accurate at n = 1500 and 2048, and
     n = 2049 fails loudly."""
+    monkeypatch.setenv("BLMM_DEV_ENV", "1")       # BLMM_SYTRD_GLB is a developer switch (bit-identical results, checked here)
     for n in (300, 700):
         rng = np.random.default_rng(n)
         K = kinship_of(make_geno(n, 2 * n, rng))
@@ -575,6 +577,7 @@ def test_multi_gpu_entry_point_with_shards_on_one_device(blmm, method, monkeypat
     mc.close()
     # one device through RCCL itself (librccl.so is loaded with dlopen, a communicator is created, the in-place
     # all-gather of a single rank runs): the RCCL path of gather_mode allgather cannot meet a second GPU on this box
+    monkeypatch.setenv("BLMM_DEV_ENV", "1")
     monkeypatch.setenv("BLMM_ALLGATHER", "rccl")
     mc1 = blmm.MultiContext([0])
     got = blmm.bulkscan_multi(mc1, Y, G, K, Cov, method=method, h2_grid=grid, gather="allgather")
@@ -673,11 +676,11 @@ def test_dc_eigensolver_accuracy(blmm, n):
 
 
 def test_dc_eigensolver_small_n_and_end_to_end(blmm, monkeypatch):
-    """BLMM_EIGEN=dc sends n <= 124 through the same solver (single-workgroup tridiagonalisation, two merge levels);
+    """Tuning eigen_solver = 2 ("dc") sends n <= 124 through the same solver (single-workgroup tridiagonalisation, two merge levels);
     bulkscan results must not depend on which eigensolver ran (LOD is invariant to the eigenbasis)."""
     Y, G, K, _ = make_data(p=130, m=40, seed=777)
     base = blmm.bulkscan_null(Y, G, K)
-    monkeypatch.setenv("BLMM_EIGEN", "dc")
+    blmm.default_context().set_tuning("eigen_solver", 2)     # reset by the conftest fixture
     for n in (5, 33, 64, 79, 124):
         Kn = K[:n, :n] if n <= 79 else np.round(np.cov(np.random.default_rng(n).standard_normal((n, 3 * n))), 12)
         Y0, _, lam = blmm.transform_rotation(np.eye(n), np.ones((n, 2)), Kn)
@@ -1072,6 +1075,7 @@ def test_dc_parallel_deflation_equals_the_serial_scan(blmm, n, monkeypatch):
             "rank-deficient": A @ A.T / 40.0}
     for name, K in mats.items():
         K = 0.5 * (K + K.T)
+        monkeypatch.setenv("BLMM_DEV_ENV", "1")   # BLMM_DC_DEFLATE is a developer switch (bit-identical results, checked here)
         monkeypatch.delenv("BLMM_DC_DEFLATE", raising=False)
         Y0, _, lam = blmm.transform_rotation(np.eye(n), np.ones((n, 2)), K)
         monkeypatch.setenv("BLMM_DC_DEFLATE", "serial")
@@ -1114,22 +1118,22 @@ def test_illconditioned_weighted_covariates_at_the_h2_one_boundary(blmm):
 
 @pytest.mark.parametrize("ncov,n", [(1, 79), (2, 79), (7, 79), (3, 200), (5, 300)])
 def test_qr_grade_rescan_equals_oracle_when_every_trait_is_flagged(blmm, ncov, n, monkeypatch):
-    """BLMM_ILLCOND_RHO=2 puts EVERY trait on the guard's list (the pivot shares are <= 1): the orthogonalised re-scan kernel
+    """Tuning illcond_rho = 2 puts EVERY trait on the guard's list (the pivot shares are <= 1): the orthogonalised re-scan kernel
     (k_scan_qr) is then compared with the oracle as a whole, for the low-rank path (c = 2, 3), the full-rank path (c = 8, 6)
     and beyond the LDS Jacobi (n = 200, 300)."""
     Y, G, K, Cov = make_data(n=n, p=333, m=70, seed=9100 + ncov, ncov=ncov, bxd=(n == 79))
-    monkeypatch.setenv("BLMM_ILLCOND_RHO", "2")
+    dctx = blmm.default_context()
+    dctx.set_tuning("illcond_rho", 2)                  # (reset by the conftest fixture)
     L, h2, st = _null_exact_with_status(blmm, Y, G, K, Cov)
     assert st.n_illcond_rescan == Y.shape[1]
     pin = O.bulkscan_null(Y, G, K, Covar=Cov, h2_override=h2)
     assert_lod_close(L, pin.L)
-    monkeypatch.setenv("BLMM_ILLCOND_RHO", "0")        # guard off: the Cholesky form alone (well conditioned here)
+    dctx.set_tuning("illcond_rho", 0)                  # guard off: the Cholesky form alone (well conditioned here)
     L0, h20, st0 = _null_exact_with_status(blmm, Y, G, K, Cov)
     assert st0.n_illcond_rescan == 0 and np.array_equal(h2, h20)
     assert_lod_close(L0, pin.L)
-    monkeypatch.delenv("BLMM_ILLCOND_RHO")
     y = Y[:, 0]
-    monkeypatch.setenv("BLMM_ILLCOND_RHO", "2")
+    dctx.set_tuning("illcond_rho", 2)
     s = blmm.scan(y, G, K, Cov)                        # scan(): the trait's own LOD vector takes the guard too
     r = O.bulkscan_null(Y[:, :1], G, K, Covar=Cov, h2_override=[s["h2_null"]])
     assert_lod_close(s["lod"], r.L[:, 0])
@@ -1169,9 +1173,9 @@ def test_output_pvals_written_by_the_scan(blmm, route, monkeypatch):
     method = route if route in ("null-grid", "alt-grid") else "null-exact"
     df = 3 if route == "df3" else 1
     if route == "fix-rescan":
-        monkeypatch.setenv("BLMM_LR_TOL", "0")          # every trait through k_scan_fix
+        blmm.default_context().set_tuning("lr_tol", 0)          # every trait through k_scan_fix
     if route == "qr-rescan":
-        monkeypatch.setenv("BLMM_ILLCOND_RHO", "2")     # every trait through k_scan_qr
+        blmm.default_context().set_tuning("illcond_rho", 2)     # every trait through k_scan_qr
     r = blmm.bulkscan(Y, G, K, Cov, method=method, output_pvals=True, chisq_df=df)
     P, L = r["log10Pvals_mat"], r["L"]
     assert P.shape == L.shape == (333, 150) and r["Chisq_df"] == df
@@ -1181,7 +1185,7 @@ def test_output_pvals_written_by_the_scan(blmm, route, monkeypatch):
     fin = np.isfinite(ref)
     assert fin.all() and np.all(np.abs(P - ref) <= 1e-10 * np.abs(ref) + 1e-14)
     # and the scan's own output is what it is without the second output
-    monkeypatch.setenv("BLMM_PVAL_FUSED", "0")
+    blmm.default_context().set_tuning("pval_fused", 0)
     r0 = blmm.bulkscan(Y, G, K, Cov, method=method, output_pvals=True, chisq_df=df)
     assert np.array_equal(r0["L"], L) and np.all(np.abs(r0["log10Pvals_mat"] - P) <= 1e-14 * np.abs(P) + 1e-300)
 
@@ -1232,13 +1236,13 @@ def test_fast_eigen_path_is_taken_on_kinships_and_falls_back_on_repeated_eigenva
         assert np.abs(U.T @ U - np.eye(n)).max() <= 2e-13, (n, kind)
         assert np.abs((U * lam) @ U.T - K).max() <= 5e-13 * sc * np.sqrt(n), (n, kind)
         assert np.abs(np.sort(lam) - np.linalg.eigvalsh(K)).max() <= 1e-12 * sc, (n, kind)
-    os.environ["BLMM_EIGEN"] = "jacobi"
+    blmm.default_context().set_tuning("eigen_solver", 1)      # the Jacobi alone
     try:
         Y, G, K, _ = make_data(n=79, p=60, m=3, seed=4179)
         _, _, st = _null_exact_with_status(blmm, Y, G, K, None)
         assert st.jacobi_sweeps > 0
     finally:
-        del os.environ["BLMM_EIGEN"]
+        blmm.default_context().set_tuning("eigen_solver", 0)
 
 
 @pytest.mark.parametrize("ncov,reml,oi", [(0, False, 1), (2, True, 3)])

@@ -279,6 +279,21 @@ def test_c_openmp_restatement_equals_numpy_restatement(ncov, reml, prior, oi):
     pin = O.bulkscan_null(Y, G, K, Covar=Cov, prior_variance=prior[0], prior_sample_size=prior[1], reml=reml, h2_override=h2)
     assert np.abs(L - pin.L).max() <= 1e-9 * max(1.0, np.abs(pin.L).max())
     assert np.sum((L - ref.L) ** 2, axis=0).max() <= 1e-7
+    # the override used by the every-entry GPU comparisons (tests/test_gpu_fullmatrix.py): L at heritabilities handed in -- here
+    # values that are NOT the search's result -- equals the NumPy restatement at the same values; the search still runs beside it,
+    # or is skipped
+    rng = np.random.default_rng(5 + ncov)
+    hov = np.clip(h2 + rng.uniform(-0.2, 0.2, h2.shape), 0.0, 0.95)
+    hov[0] = 0.0
+    hov[1] = 1e-15
+    L2, h2own = cref.bulkscan_null(Y, G, K, Cov, prior_variance=prior[0], prior_sample_size=prior[1], reml=reml, optim_interval=oi,
+                                   nthreads=2, h2_override=hov)
+    assert np.array_equal(h2own, h2)
+    pin2 = O.bulkscan_null(Y, G, K, Covar=Cov, prior_variance=prior[0], prior_sample_size=prior[1], reml=reml, h2_override=hov)
+    assert np.abs(L2 - pin2.L).max() <= 1e-9 * max(1.0, np.abs(pin2.L).max())
+    L3, h3 = cref.bulkscan_null(Y, G, K, Cov, prior_variance=prior[0], prior_sample_size=prior[1], reml=reml, nthreads=2,
+                                h2_override=hov, skip_search=True)
+    assert np.array_equal(L3, L2) and np.array_equal(h3, hov)
 
 
 def test_oracle_scan_alt_is_the_profile_likelihood_ratio_and_restates_the_closing_calls():
