@@ -94,3 +94,39 @@ def assert_h2_panel_ties_only(got_panel, ref_panel, logL1, grid, quirk=False, re
             assert abs(col[gg] - col[gr]) <= rel * scale, \
                 f"{what}[{i},{j}]: {got_panel[i, j]} vs {ref_panel[i, j]}: logL1 {col[gg]!r} vs {col[gr]!r} is not a tie"
     return len(bad)
+
+
+class DevBuf:
+    """A device buffer through the HIP runtime itself (ctypes on libamdhip64.so), for tests that drive the *_dev entry points of the
+    C ABI in-process: torch cannot be initialised in a process whose HIP runtime the library brought up first on these boxes (the
+    torch-based checks run as their own programs: tests/helpers/)."""
+    _hip = None
+
+    def __init__(self, arr=None, nbytes=None):
+        import ctypes as C
+        if DevBuf._hip is None:
+            DevBuf._hip = C.CDLL("libamdhip64.so")
+        self.nbytes = int(arr.nbytes if arr is not None else nbytes)
+        p = C.c_void_p()
+        assert DevBuf._hip.hipMalloc(C.byref(p), C.c_size_t(max(self.nbytes, 8))) == 0
+        self.ptr = p.value
+        if arr is not None:
+            a = np.ascontiguousarray(arr)
+            assert DevBuf._hip.hipMemcpy(C.c_void_p(self.ptr), a.ctypes.data_as(C.c_void_p), C.c_size_t(a.nbytes), 1) == 0
+
+    def fill(self, arr):
+        import ctypes as C
+        a = np.ascontiguousarray(arr)
+        assert a.nbytes <= self.nbytes and DevBuf._hip.hipMemcpy(C.c_void_p(self.ptr), a.ctypes.data_as(C.c_void_p), C.c_size_t(a.nbytes), 1) == 0
+
+    def get(self, shape, dtype=np.float64):
+        import ctypes as C
+        out = np.empty(shape, dtype=dtype)
+        assert out.nbytes <= self.nbytes and DevBuf._hip.hipMemcpy(out.ctypes.data_as(C.c_void_p), C.c_void_p(self.ptr), C.c_size_t(out.nbytes), 2) == 0
+        return out
+
+    def free(self):
+        import ctypes as C
+        if self.ptr:
+            DevBuf._hip.hipFree(C.c_void_p(self.ptr))
+            self.ptr = None

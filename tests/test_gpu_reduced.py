@@ -12,7 +12,7 @@ import ctypes as C
 import numpy as np
 import pytest
 
-from common import make_data
+from common import DevBuf, make_data
 
 pytestmark = pytest.mark.gpu
 
@@ -78,30 +78,40 @@ def test_reduced_scan_reruns_through_a_resident_matrix_when_a_trait_needs_a_resc
 
 
 def test_reduced_scan_dev_entry_point_and_empty_shapes(blmm):
-    torch = pytest.importorskip("torch")
+    L_ = blmm._lib
     Y, G, K, _ = make_data(p=300, m=150, seed=3402)
+    n, m, p = 79, 150, 300
     ctx = blmm.Context(0)
-    dev = torch.device("cuda:0")
-    tY = torch.tensor(np.ascontiguousarray(Y.T), device=dev); tG = torch.tensor(np.ascontiguousarray(G.T), device=dev)
-    tK = torch.tensor(K, device=dev)
-    tL = torch.empty((150, 300), dtype=torch.float64, device=dev); th2 = torch.empty(150, dtype=torch.float64, device=dev)
-    torch.cuda.synchronize()
-    blmm.bulkscan_dev(ctx, tY, tG, tK, tL, th2, method="null-exact")
+    lib = ctx.lib
+    o = blmm.api._opts(L_.BLMM_NULL_EXACT)
+    dY, dG, dK = DevBuf(np.asfortranarray(Y).ravel("F")), DevBuf(np.asfortranarray(G).ravel("F")), DevBuf(np.asfortranarray(K).ravel("F"))
+    dL, dh = DevBuf(nbytes=8 * p * m), DevBuf(nbytes=8 * m)
+    ctx.check(lib.blmm_bulkscan_dev(ctx.h, C.byref(o), dY.ptr, n, m, dG.ptr, p, None, 0, dK.ptr, None, None, 0, dL.ptr, p, dh.ptr, None))
     ctx.synchronize()
-    L = tL.cpu().numpy().T
-    mx = torch.empty(150, dtype=torch.float64, device=dev); ax = torch.empty(150, dtype=torch.int64, device=dev)
-    h2 = torch.empty(150, dtype=torch.float64, device=dev)
-    ti = torch.empty(4096, dtype=torch.int32, device=dev); tj = torch.empty(4096, dtype=torch.int32, device=dev)
-    tl = torch.empty(4096, dtype=torch.float64, device=dev); tc = torch.zeros(1, dtype=torch.int64, device=dev)
-    torch.cuda.synchronize()
-    blmm.bulkscan_reduced_dev(ctx, tY, tG, tK, mx, ax, h2, method="null-exact", threshold=2.5, trip_i=ti, trip_j=tj, trip_lod=tl, trip_count=tc)
+    L = dL.get((m, p)).T
+    dmx, dax, dh2 = DevBuf(nbytes=8 * m), DevBuf(nbytes=8 * m), DevBuf(nbytes=8 * m)
+    cap = 4096
+    dti, dtj, dtl, dtc = DevBuf(nbytes=4 * cap), DevBuf(nbytes=4 * cap), DevBuf(nbytes=8 * cap), DevBuf(np.zeros(1, dtype=np.int64))
+    r = L_.blmm_reduced(dmx.ptr, dax.ptr, 1, 2.5, cap, dti.ptr, dtj.ptr, dtl.ptr, dtc.ptr)
+    ctx.check(lib.blmm_bulkscan_reduced_dev(ctx.h, C.byref(o), dY.ptr, n, m, dG.ptr, p, None, 0, dK.ptr, None, None, 0, C.byref(r), dh2.ptr, None))
+    assert lib.blmm_last_reduced_route(ctx.h) == 1
     rmx, rarg = colmax_ref(L)
-    assert np.array_equal(mx.cpu().numpy(), rmx) and np.array_equal(ax.cpu().numpy(), rarg)
-    assert np.array_equal(h2.cpu().numpy(), th2.cpu().numpy())
-    k = int(tc.item())
+    assert np.array_equal(dmx.get(m), rmx) and np.array_equal(dax.get(m, np.int64), rarg)
+    assert np.array_equal(dh2.get(m), dh.get(m))
+    k = int(dtc.get(1, np.int64)[0])
     ri, rj, rl = triplets_ref(L, 2.5)
-    order = np.lexsort((ti.cpu().numpy()[:k], tj.cpu().numpy()[:k]))
-    assert k == ri.size and np.array_equal(ti.cpu().numpy()[:k][order], ri) and np.array_equal(tl.cpu().numpy()[:k][order], rl)
+    gi, gj, gl = dti.get(cap, np.int32)[:k], dtj.get(cap, np.int32)[:k], dtl.get(cap)[:k]
+    order = np.lexsort((gi, gj))
+    assert k == ri.size and np.array_equal(gi[order], ri) and np.array_equal(gj[order], rj) and np.array_equal(gl[order], rl)
+    # cap smaller than the count: the count is still the total, only `cap` triplets are stored (all of them genuine)
+    r2 = L_.blmm_reduced(None, None, 1, 2.5, 10, dti.ptr, dtj.ptr, dtl.ptr, dtc.ptr)
+    dtl.fill(np.full(cap, -1.0))
+    ctx.check(lib.blmm_bulkscan_reduced_dev(ctx.h, C.byref(o), dY.ptr, n, m, dG.ptr, p, None, 0, dK.ptr, None, None, 0, C.byref(r2), dh2.ptr, None))
+    assert int(dtc.get(1, np.int64)[0]) == k and k > 10
+    g10 = dtl.get(cap)
+    assert np.all(g10[10:] == -1.0) and np.all(g10[:10] == L[dti.get(cap, np.int32)[:10], dtj.get(cap, np.int32)[:10]])
+    for b in (dY, dG, dK, dL, dh, dmx, dax, dh2, dti, dtj, dtl, dtc):
+        b.free()
     # no markers / no traits: -inf and -1, nothing crashes
     e = blmm.bulkscan_reduced(Y, G[:, :0], K, method="null-exact", ctx=ctx)
     assert np.all(np.isneginf(e["max_lod"])) and np.all(e["argmax"] == -1) and e["h2_null_list"].shape == (150,)
@@ -163,87 +173,90 @@ def test_prepare_state_is_invalidated_by_any_other_call_that_redoes_the_eigen_fr
     """blmm_prepare_dev leaves U / lambda / Z0 / the rotation matrix in the context for blmm_rotate_block_dev and the
     *_prerotated calls.  Any other entry point overwrites (and at a larger n reallocates) them: the three-call state must then be
     refused, not used."""
-    torch = pytest.importorskip("torch")
-    dev = torch.device("cuda:0")
     ctx = blmm.Context(0)
     lib = ctx.lib
     Ya, Ga, Ka, _ = make_data(n=150, p=64, m=8, seed=3700, bxd=False)
     Yb, Gb, Kb, _ = make_data(n=300, p=64, m=8, seed=3701, bxd=False)
-    tKa = torch.tensor(Ka, device=dev)
-    torch.cuda.synchronize()
-    blmm.prepare_dev(ctx, tKa)
-    rows = blmm.rotated_rows(ctx)
-    assert rows == 152
-    tG = torch.tensor(np.ascontiguousarray(Ga.T), device=dev)
-    tX = torch.empty((rows, 64), dtype=torch.float64, device=dev)
-    torch.cuda.synchronize()
-    blmm.rotate_block_dev(ctx, tG, tX)                      # fine: prepared
-    ctx.synchronize()
-    blmm.bulkscan(Yb, Gb, Kb, method="null-grid", ctx=ctx)  # n = 300 on the same context: the eigen front runs again
-    assert blmm.rotated_rows(ctx) == 0
-    with pytest.raises(blmm.BulkLMMError, match="blmm_prepare_dev has not run"):
-        blmm.rotate_block_dev(ctx, tG, tX)
     o = blmm.api._opts(blmm._lib.BLMM_NULL_EXACT)
-    tY = torch.tensor(np.ascontiguousarray(Ya.T), device=dev)
-    tL = torch.empty((8, 64), dtype=torch.float64, device=dev); th = torch.empty(8, dtype=torch.float64, device=dev)
-    rc = lib.blmm_bulkscan_prerotated_dev(ctx.h, C.byref(o), tY.data_ptr(), 8, 64, tX.data_ptr(), 1, 64, 64, None, 0, tL.data_ptr(), 64,
-                                          th.data_ptr(), None)
+    dKa, dGa, dYa = DevBuf(np.asfortranarray(Ka).ravel("F")), DevBuf(np.asfortranarray(Ga).ravel("F")), DevBuf(np.asfortranarray(Ya).ravel("F"))
+    ctx.check(lib.blmm_prepare_dev(ctx.h, C.byref(o), 150, None, 0, dKa.ptr, None, None))
+    rows = int(lib.blmm_rotated_rows(ctx.h))
+    assert rows == 152
+    dX = DevBuf(nbytes=8 * rows * 64)
+    ctx.check(lib.blmm_rotate_block_dev(ctx.h, dGa.ptr, 64, dX.ptr, 64))            # fine: prepared
+    ctx.synchronize()
+    first = dX.get((rows, 64))
+    blmm.bulkscan(Yb, Gb, Kb, method="null-grid", ctx=ctx)  # n = 300 on the same context: the eigen front runs again
+    assert int(lib.blmm_rotated_rows(ctx.h)) == 0
+    assert lib.blmm_rotate_block_dev(ctx.h, dGa.ptr, 64, dX.ptr, 64) != 0 and b"blmm_prepare_dev has not run" in lib.blmm_last_error(ctx.h)
+    dL, dh = DevBuf(nbytes=8 * 64 * 8), DevBuf(nbytes=8 * 8)
+    rc = lib.blmm_bulkscan_prerotated_dev(ctx.h, C.byref(o), dYa.ptr, 8, 64, dX.ptr, 1, 64, 64, None, 0, dL.ptr, 64, dh.ptr, None)
     assert rc != 0 and b"blmm_prepare_dev has not run" in lib.blmm_last_error(ctx.h)
-    blmm.prepare_dev(ctx, tKa)                              # and it comes back with a new prepare
-    assert blmm.rotated_rows(ctx) == 152
+    # the lower-level seams overwrite Z0 / lambda as well
+    ctx.check(lib.blmm_prepare_dev(ctx.h, C.byref(o), 150, None, 0, dKa.ptr, None, None))
+    assert int(lib.blmm_rotated_rows(ctx.h)) == 152
+    Y0, X0, lam = blmm.transform_rotation(Ya, Ga, Ka, ctx=ctx)
+    assert int(lib.blmm_rotated_rows(ctx.h)) == 0
+    blmm.fitlmm_bulk(Y0, X0[:, :1], lam, ctx=ctx)
+    assert int(lib.blmm_rotated_rows(ctx.h)) == 0
+    # and it comes back with a new prepare, giving the same rotated block as before
+    ctx.check(lib.blmm_prepare_dev(ctx.h, C.byref(o), 150, None, 0, dKa.ptr, None, None))
+    ctx.check(lib.blmm_rotate_block_dev(ctx.h, dGa.ptr, 64, dX.ptr, 64))
+    ctx.check(lib.blmm_bulkscan_prerotated_dev(ctx.h, C.byref(o), dYa.ptr, 8, 64, dX.ptr, 1, 64, 64, None, 0, dL.ptr, 64, dh.ptr, None))
+    ctx.synchronize()
+    assert np.array_equal(dX.get((rows, 64)), first)
+    whole = blmm.bulkscan(Ya, Ga, Ka, method="null-exact", ctx=ctx)
+    assert np.array_equal(dL.get((8, 64)).T, whole["L"]) and np.array_equal(dh.get(8), whole["h2_null_list"])
+    for b in (dKa, dGa, dYa, dX, dL, dh):
+        b.free()
     ctx.close()
 
 
 def test_pvalue_request_does_not_survive_a_failed_call(blmm):
     """blmm_set_log10p_output arms ONE call.  If that call fails its checks the request must be gone: the next, unrelated scan
     must neither compute p-values nor write to the pointer of the failed call."""
-    torch = pytest.importorskip("torch")
-    dev = torch.device("cuda:0")
     ctx = blmm.Context(0)
     lib = ctx.lib
     Y, G, K, _ = make_data(p=96, m=24, seed=3800)
     n = Y.shape[0]
-    tY = torch.tensor(np.ascontiguousarray(Y.T), device=dev); tG = torch.tensor(np.ascontiguousarray(G.T), device=dev)
-    tK = torch.tensor(K, device=dev)
-    tL = torch.empty((24, 96), dtype=torch.float64, device=dev); th = torch.empty(24, dtype=torch.float64, device=dev)
-    tP = torch.full((24, 96), -7.0, dtype=torch.float64, device=dev)
-    torch.cuda.synchronize()
+    dY, dG, dK = DevBuf(np.asfortranarray(Y).ravel("F")), DevBuf(np.asfortranarray(G).ravel("F")), DevBuf(np.asfortranarray(K).ravel("F"))
+    dL, dh, dP = DevBuf(nbytes=8 * 96 * 24), DevBuf(nbytes=8 * 24), DevBuf(np.full(96 * 24, -7.0))
+    dCov = DevBuf(np.zeros(n * n))
     o = blmm.api._opts(blmm._lib.BLMM_NULL_EXACT)
-    for kind in ("ldL", "decomp", "c>=n", "null"):
-        assert lib.blmm_set_log10p_output(ctx.h, tP.data_ptr(), 96, 1) == 0
-        if kind == "ldL":
-            rc = lib.blmm_bulkscan_dev(ctx.h, C.byref(o), tY.data_ptr(), n, 24, tG.data_ptr(), 96, None, 0, tK.data_ptr(), None, None, 0,
-                                       tL.data_ptr(), 95, th.data_ptr(), None)
-        elif kind == "decomp":
-            bad = blmm.api._opts(blmm._lib.BLMM_NULL_EXACT); bad.decomp_scheme = 99
-            rc = lib.blmm_bulkscan_dev(ctx.h, C.byref(bad), tY.data_ptr(), n, 24, tG.data_ptr(), 96, None, 0, tK.data_ptr(), None, None, 0,
-                                       tL.data_ptr(), 96, th.data_ptr(), None)
-        elif kind == "c>=n":
-            cov = torch.zeros((n, n), dtype=torch.float64, device=dev)
-            rc = lib.blmm_bulkscan_dev(ctx.h, C.byref(o), tY.data_ptr(), n, 24, tG.data_ptr(), 96, cov.data_ptr(), n, tK.data_ptr(), None,
-                                       None, 0, tL.data_ptr(), 96, th.data_ptr(), None)
-        else:
-            rc = lib.blmm_bulkscan_dev(ctx.h, C.byref(o), None, n, 24, tG.data_ptr(), 96, None, 0, tK.data_ptr(), None, None, 0,
-                                       tL.data_ptr(), 96, th.data_ptr(), None)
-        assert rc != 0, kind
-        rc = lib.blmm_bulkscan_dev(ctx.h, C.byref(o), tY.data_ptr(), n, 24, tG.data_ptr(), 96, None, 0, tK.data_ptr(), None, None, 0,
-                                   tL.data_ptr(), 96, th.data_ptr(), None)
-        assert rc == 0
+    bad = blmm.api._opts(blmm._lib.BLMM_NULL_EXACT); bad.decomp_scheme = 99
+    calls = {
+        "ldL": lambda: lib.blmm_bulkscan_dev(ctx.h, C.byref(o), dY.ptr, n, 24, dG.ptr, 96, None, 0, dK.ptr, None, None, 0, dL.ptr, 95, dh.ptr, None),
+        "decomp": lambda: lib.blmm_bulkscan_dev(ctx.h, C.byref(bad), dY.ptr, n, 24, dG.ptr, 96, None, 0, dK.ptr, None, None, 0, dL.ptr, 96, dh.ptr, None),
+        "c>=n": lambda: lib.blmm_bulkscan_dev(ctx.h, C.byref(o), dY.ptr, n, 24, dG.ptr, 96, dCov.ptr, n, dK.ptr, None, None, 0, dL.ptr, 96, dh.ptr, None),
+        "null": lambda: lib.blmm_bulkscan_dev(ctx.h, C.byref(o), None, n, 24, dG.ptr, 96, None, 0, dK.ptr, None, None, 0, dL.ptr, 96, dh.ptr, None),
+    }
+    for kind, failing in calls.items():
+        assert lib.blmm_set_log10p_output(ctx.h, dP.ptr, 96, 1) == 0
+        assert failing() != 0, kind
+        ctx.check(lib.blmm_bulkscan_dev(ctx.h, C.byref(o), dY.ptr, n, 24, dG.ptr, 96, None, 0, dK.ptr, None, None, 0, dL.ptr, 96, dh.ptr, None))
         ctx.synchronize()
-        assert bool((tP == -7.0).all()), kind + ": the next call wrote p-values nobody asked for"
+        assert np.all(dP.get(96 * 24) == -7.0), kind + ": the next call wrote p-values nobody asked for"
+    # a request that is honoured does write (the check above is not vacuous)
+    assert lib.blmm_set_log10p_output(ctx.h, dP.ptr, 96, 1) == 0
+    ctx.check(lib.blmm_bulkscan_dev(ctx.h, C.byref(o), dY.ptr, n, 24, dG.ptr, 96, None, 0, dK.ptr, None, None, 0, dL.ptr, 96, dh.ptr, None))
+    ctx.synchronize()
+    assert np.all(dP.get(96 * 24) >= 0.0)
     # the host-pointer form: a request that dies with a failed call leaves no matrix behind for blmm_last_log10p to hand out
     assert lib.blmm_set_log10p_output(ctx.h, None, 0, 1) == 0
     Lh = np.empty((96, 24), order="F"); hh = np.empty(24)
-    rc = lib.blmm_bulkscan(ctx.h, C.byref(o), None, n, 24, blmm.api._p(np.asfortranarray(G)), 96, None, 0, blmm.api._p(np.asfortranarray(K)), None, None, 0,
-                           blmm.api._p(Lh), blmm.api._p(hh), None)
+    Gf, Kf = np.asfortranarray(G), np.asfortranarray(K)
+    rc = lib.blmm_bulkscan(ctx.h, C.byref(o), None, n, 24, blmm.api._p(Gf), 96, None, 0, blmm.api._p(Kf), None, None, 0, blmm.api._p(Lh), blmm.api._p(hh), None)
     assert rc != 0
     r = blmm.bulkscan(Y, G, K, method="null-exact", ctx=ctx)
+    Pm = np.empty((96, 24), order="F")
     assert "log10Pvals_mat" not in r
     # and the Python mirror arms only after its own argument checks
     with pytest.raises(blmm.BulkLMMError):
         blmm.bulkscan(Y, G[:-1], K, method="null-exact", output_pvals=True, ctx=ctx)
     r2 = blmm.bulkscan(Y, G, K, method="null-exact", ctx=ctx)
     assert np.array_equal(r2["L"], r["L"])
+    for b in (dY, dG, dK, dL, dh, dP, dCov):
+        b.free()
     ctx.close()
 
 

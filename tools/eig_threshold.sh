@@ -1,4 +1,5 @@
 #!/bin/bash
+export BLMM_DEV_ENV=1   # the BLMM_* switches below are developer switches: the library reads them only with this set
 cd $GRAFT_REPO_ROOT
 for n in 130 200 333; do
   for e in jacobi rocsolver; do

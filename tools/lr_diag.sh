@@ -1,5 +1,6 @@
 #!/bin/bash
 # per-class workgroup durations and per-XCD end times of k_scan_lr (diagnostic build): tools/lr_diag.sh
+export BLMM_DEV_ENV=1   # the BLMM_* switches below are developer switches: the library reads them only with this set
 set -o pipefail
 ROOT=$(pwd)
 cd bulklmm.jl_amd/csrc && touch kernels_scan.hip && make EXTRA=-DLR_DIAG -j8 > /dev/null 2>&1; cd $ROOT

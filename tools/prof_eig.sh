@@ -1,5 +1,6 @@
 #!/bin/bash
 # kernel-trace stats of the eigensolver phases at n = 500 / 1000 / 79(dc): tools/prof_eig.sh <tag>
+export BLMM_DEV_ENV=1   # the BLMM_* switches below are developer switches: the library reads them only with this set
 set -o pipefail
 TAG=${1:-eig}
 OUT=gpurun_out/$TAG

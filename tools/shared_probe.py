@@ -16,7 +16,7 @@ if len(sys.argv) > 1:
     print("shared", st.lowrank_shared, "fallback", st.lowrank_fallback, "rank", st.lowrank_rank, "resid", st.lowrank_resid, "nan", st.n_nan_lod)
 else:
     for v in ("0", "1"):
-        env = dict(os.environ, BLMM_LR_SHARED=v)
+        env = dict(os.environ, BLMM_DEV_ENV="1", BLMM_LR_SHARED=v)
         subprocess.run([sys.executable, __file__, f"/tmp/L{v}.npy"], env=env, check=True)
         subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "20", "--warmup", "3", "--no-host-api"], env=env, check=True,
                        stdout=open(f"/tmp/b{v}.json", "w"))

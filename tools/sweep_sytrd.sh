@@ -1,5 +1,6 @@
 #!/bin/bash
 # eigen phase time vs the workgroup count / thread count of k_sytrd
+export BLMM_DEV_ENV=1   # the BLMM_* switches below are developer switches: the library reads them only with this set
 for n in 500 1000; do
   for G in 0 24 32 48 64 96 128; do
     for NT in 512 256; do

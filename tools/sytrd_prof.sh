@@ -1,5 +1,6 @@
 #!/bin/bash
 # per-phase cycle counts of k_sytrd (s_memtime stamps; diagnostic build): tools/sytrd_prof.sh
+export BLMM_DEV_ENV=1   # the BLMM_* switches below are developer switches: the library reads them only with this set
 set -o pipefail
 cd bulklmm.jl_amd/csrc && touch kernels_eig.hip && make EXTRA=-DSYTRD_PROF -j8 > /dev/null 2>&1 && cd ../..
 python3 - <<'PY'
