@@ -256,7 +256,7 @@ int prepare_eigen(blmm_ctx* ctx, const blmm_opts* o, int64_t n, const double* dC
   if (!eig_env && ctx->tune.eigen_solver == 2) eig_env = "dc";
   const bool big = n > jacobi_lds_max_n();
   P.big = big;
-  bool done = false;
+  bool done = false, post_done = false;
   const bool want_dc = eig_env ? std::strcmp(eig_env, "dc") == 0 : big;
   if (!done && want_dc && n >= 3) {
     rc = launch_eig_dc(ctx, ptr<double>(ctx->Ks), (int)n, ptr<double>(ctx->lraw), ptr<double>(ctx->V), P.stat);
@@ -272,9 +272,12 @@ int prepare_eigen(blmm_ctx* ctx, const blmm_opts* o, int64_t n, const double* dC
       rc = launch_eig_fast(ctx, ptr<double>(ctx->Ks), (int)n, ptr<double>(ctx->lraw), ptr<double>(ctx->V), P.stat);
       if (rc != BLMM_OK && rc != BLMM_ERR_UNSUPPORTED) return rc;
     }
-    if ((rc = launch_jacobi(ctx, ptr<double>(ctx->Ks), ptr<double>(ctx->V), (int)n, ptr<double>(ctx->lraw), P.stat))) return rc;
+    // (the post-eigen work rides in the tail of this launch where its LDS fits: one dependent-launch boundary less)
+    if ((rc = launch_jacobi_post(ctx, ptr<double>(ctx->Ks), ptr<double>(ctx->V), (int)n, ptr<double>(ctx->lraw), P.stat, ptr<double>(ctx->Zs),
+                                 dweights, c, P.npad, P.ldr, o->decomp_scheme, centered, P.lam, ptr<double>(ctx->U), P.Z0, ptr<double>(ctx->Rp),
+                                 &post_done))) return rc;
   }
-  if ((rc = launch_post_eigen(ctx, ptr<double>(ctx->lraw), evec, ptr<double>(ctx->Zs), dweights, (int)n, c,
+  if (!post_done && (rc = launch_post_eigen(ctx, ptr<double>(ctx->lraw), evec, ptr<double>(ctx->Zs), dweights, (int)n, c,
                               P.npad, P.ldr, o->decomp_scheme, centered, P.lam, ptr<double>(ctx->U), P.Z0,
                               ptr<double>(ctx->Rp), P.stat))) return rc;
   tm.mark();
@@ -552,6 +555,9 @@ int lr_finish_split(blmm_ctx* ctx, const Pipe& P, const NullModel& nm, double* d
   // ---- main stream: region 0's classification and panels (the weight basis is ready at ev_q, the marker-side products at ev_join) ...
   if ((rc = launch_lr_classify(ctx, P.n, P.m, lr_shared_tol(ctx), P.lam, dh2, sp.fin, nullptr, nullptr, ptr<int>(ctx->lrPerm), r0, seg))) return rc;
   BLMM_HIP(hipStreamWaitEvent(main_stream, ctx->ev_q, 0));
+  // the marker-side products (ev_join) are done before the panels kernel can start anyway (profiles/r03_timeline_bxd_step.txt: 410 us
+  // against 425): waiting for them HERE takes one barrier packet out of the gap between the panels and region 0's first scan launch
+  BLMM_HIP(hipStreamWaitEvent(main_stream, ctx->ev_join, 0));
   if ((rc = lr_region_panels(ctx, P, nm, dh2, r0))) return rc;
   // ---- ... and only then the second side stream: the rest of the h2 search, then region 1's columns.  Forked right behind
   //      k_brent (rounds 2-3a) k_brent2's older waves won the issue arbitration against the 16-lane panels kernel on the
@@ -568,7 +574,6 @@ int lr_finish_split(blmm_ctx* ctx, const Pipe& P, const NullModel& nm, double* d
   if (rc) return rc;
   BLMM_HIP(hipEventRecord(ctx->ev_b2, ctx->side2));
   tm.mark();
-  BLMM_HIP(hipStreamWaitEvent(main_stream, ctx->ev_join, 0));
   BLMM_HIP(hipStreamWaitEvent(ctx->side, ctx->ev_b1, 0));            // region 0's panels are done (the same point the second side stream forks at)
   ctx->stream = ctx->side;
   rc = lr_region_resid(ctx, P, nm, dh2, r0);
@@ -680,7 +685,7 @@ void blmm_destroy(blmm_ctx* ctx) {
                     &ctx->iyy, &ctx->h2, &ctx->h2idx, &ctx->sig2, &ctx->ell, &ctx->isx, &ctx->stat, &ctx->gridd, &ctx->misc,
                     &ctx->EllTab, &ctx->inY, &ctx->inG, &ctx->inK, &ctx->inCov, &ctx->inW, &ctx->outL, &ctx->outH2,
                     &ctx->tmpA, &ctx->tmpB, &ctx->tmpC, &ctx->perm, &ctx->r0, &ctx->altbuf, &ctx->logtab, &ctx->lraw,
-                    &ctx->wbQ, &ctx->wbW, &ctx->wbRk, &ctx->lrT, &ctx->lrC, &ctx->lrL, &ctx->lrFlag, &ctx->lrPart, &ctx->lrPerm, &ctx->lrDen0, &ctx->eigW, &ctx->xf32, &ctx->pf32, &ctx->brSt, &ctx->brList, &ctx->illList, &ctx->qrSlab, &ctx->lodtab, &ctx->dynFac, &ctx->pvtab, &ctx->outP, &ctx->redbuf, &ctx->redtrip};
+                    &ctx->wbQ, &ctx->wbW, &ctx->wbRk, &ctx->lrT, &ctx->lrC, &ctx->lrL, &ctx->lrFlag, &ctx->lrPart, &ctx->lrPerm, &ctx->lrDen0, &ctx->eigW, &ctx->xf32, &ctx->pf32, &ctx->brSt, &ctx->brList, &ctx->illList, &ctx->qrSlab, &ctx->lodtab, &ctx->dynFac, &ctx->pvtab, &ctx->outP, &ctx->redbuf, &ctx->redtrip, &ctx->altC};
   for (DevBuf* b : bufs) if (b->p) hipFree(b->p);
   for (auto& s : ctx->evsets) for (auto& e : s.e) (void)hipEventDestroy(e);
   if (ctx->side) { (void)hipStreamSynchronize(ctx->side); (void)hipStreamDestroy(ctx->side); }
@@ -1098,12 +1103,14 @@ static int scan_pipeline(blmm_ctx* ctx, const blmm_opts* opts, Pipe& P, Timer& t
       }
     }
     if ((rc = isx_maybe_side(ctx, P, nm, dgrid, (int)ngrid))) return rc;
+    if ((rc = ensure(ctx, ctx->altC, sizeof(double) * (size_t)ngrid * m))) return rc;
+    if ((rc = launch_alt_ctab(ctx, ptr<double>(ctx->EllTab), (int)ngrid, m, P.n, ptr<double>(ctx->altC)))) return rc;
     tm.mark();
     AltArgs aa;
     aa.s = scan_args(ctx, P, ptr<double>(ctx->panels), ldp, dL_out, ldL, m);
     aa.s.isx = ptr<double>(ctx->isx); aa.s.ld_isx = P.ldx;
-    lod_poly5_host(-0.5 * (double)P.n * 2.302585092994046, aa.s.lodc);   // ln10 * LOD = -(n/2) ln(1 - r^2)
     aa.ngrid = (int)ngrid; aa.EllTab = ptr<double>(ctx->EllTab); aa.grid_dev = dgrid; aa.H2 = dh2_out; aa.ldH = p;
+    aa.Ctab = ptr<double>(ctx->altC);
     aa.counter_quirk = (opts->compat_flags & BLMM_COMPAT_ALT_COUNTER) ? 1 : 0;
     if ((rc = launch_scan_alt(ctx, aa))) return rc;
     tm.mark();

@@ -28,7 +28,8 @@ constexpr int NSTAT = 64;        // device status counters ([24 + 20 r ..]: per 
 enum StatIdx { ST_NEG_EIG = 0, ST_NONPOS_W = 1, ST_ZERO_NORM = 2, ST_NAN_LOD = 3, ST_BRENT_MAXIT = 4, ST_JACOBI_SWEEPS = 5,
                ST_H2_BOUNDARY = 16, ST_H2_MULTIMODAL = 17, ST_ILLCOND = 18,
                ST_EIG_FAST = 19 /* 1: the fast eigen path ran */, ST_EIG_BAD = 20 /* its largest check / bound, bits of a double: accepted up to 1.0 */,
-               ST_BRENT_CNT = 21 /* [21..22]: hand-over counter of the split h2 search (kernels_prep.hip: launch_brent_t) */ };
+               ST_BRENT_CNT = 21 /* [21..22]: hand-over counter of the split h2 search (kernels_prep.hip: launch_brent_t) */,
+               ST_EIG_DONE = 23 /* workgroups of k_jacobi_lds that have finished (the last one does the post-eigen work) */ };
 
 inline int64_t round_up(int64_t x, int64_t q) { return (x + q - 1) / q * q; }
 
@@ -90,7 +91,7 @@ struct blmm_ctx {
   std::string err;
   // grow-only workspace
   blmm::DevBuf Ks, V, lam, U, Zs, Z0, Rp, Yt, Xt, panels, iyy, h2, h2idx, sig2, ell, isx, stat, gridd, misc, EllTab,
-      inY, inG, inK, inCov, inW, outL, outH2, tmpA, tmpB, tmpC, perm, r0, altbuf, logtab, lraw, wbQ, wbW, wbRk, lrT, lrC, lrL, lrFlag, lrPart, lrPerm, lrDen0, eigW, xf32, pf32, brSt, brList, illList, qrSlab, lodtab, dynFac, pvtab, outP, redbuf, redtrip;
+      inY, inG, inK, inCov, inW, outL, outH2, tmpA, tmpB, tmpC, perm, r0, altbuf, logtab, lraw, wbQ, wbW, wbRk, lrT, lrC, lrL, lrFlag, lrPart, lrPerm, lrDen0, eigW, xf32, pf32, brSt, brList, illList, qrSlab, lodtab, dynFac, pvtab, outP, redbuf, redtrip, altC;
   // event sets: one per timed call since the last blmm_read_timings (grown on demand, reused afterwards)
   struct EvSet { hipEvent_t e[8]; int n; };
   std::vector<EvSet> evsets;
@@ -167,7 +168,11 @@ int launch_design(blmm_ctx* ctx, const double* dK, const double* dCovar, int nco
                   const double* dweights, int n, double* Ks, double* Zs);
 // One-sided Jacobi eigen-decomposition of the symmetric n x n matrix in A (destroyed); V gets the eigenvectors
 // (unsorted), then post_eigen sorts/derives everything the rotation needs.
-int launch_jacobi(blmm_ctx* ctx, double* A, double* V, int n, double* lraw, int64_t* stat);
+struct PostEigenArgs;
+int launch_jacobi(blmm_ctx* ctx, double* A, double* V, int n, double* lraw, int64_t* stat, const PostEigenArgs* pe = nullptr, bool* fused = nullptr);
+// ... with launch_post_eigen's work in the tail of the same launch where its LDS fits (*fused)
+int launch_jacobi_post(blmm_ctx* ctx, double* A, double* V, int n, double* lraw, int64_t* stat, const double* Zs, const double* dweights,
+                       int c, int npad, int ldr, int decomp, int centered, double* lam, double* U, double* Z0, double* Rp, bool* fused);
 // kernels_eig.hip: tridiagonalisation + divide and conquer for n beyond the LDS Jacobi; A is not modified
 int launch_eig_dc(blmm_ctx* ctx, const double* A, int n, double* lraw, double* evec, int64_t* stat);
 int eig_dc_max_n(const blmm_ctx* ctx);
@@ -348,9 +353,11 @@ int launch_scan_table(blmm_ctx* ctx, const ScanArgs& a);
 // the shared-weights class of one panel region through the table kernel (isx = 1/sqrt(den0), one bin, stores through perm)
 int launch_scan_shared(blmm_ctx* ctx, const ScanArgs& a);
 struct AltArgs {
-  ScanArgs s;            // s.lodc: scale = -(n/2) ln 10 here (the kernel folds ln10 * LOD + Ell)
+  ScanArgs s;
   int ngrid; const double* EllTab; /* ngrid x m */ const double* grid_dev; double* H2; int64_t ldH; int counter_quirk;
+  const double* Ctab;    // exp(-(2/n)(Ell[g, j] - max_g Ell[g, j])), ngrid x m (launch_alt_ctab): the fold's monotone image of logL1
 };
 int launch_scan_alt(blmm_ctx* ctx, const AltArgs& a);
+int launch_alt_ctab(blmm_ctx* ctx, const double* EllTab, int ngrid, int64_t m, int n, double* C);
 
 }  // namespace blmm

@@ -1329,6 +1329,11 @@ __global__ void __launch_bounds__(256) k_lr_classify(int n, int64_t m, double to
   }
 }
 
+// (Round 4 built the same layout in ONE launch -- 1024 entries per workgroup, class counts exchanged as data-tagged words, every
+// workgroup waiting for all of them, deterministic placement without atomics -- and measured it WORSE: region 0's launch 24.7 us
+// against 12 + 11 for these two passes, and region 1's, which runs beside the first region's scan, 533 us: its 1024-thread
+// workgroups only become resident as scan workgroups retire, the resident ones spin meanwhile, and the scan itself slowed from
+// 0.70 to 0.90 ms.  DESIGN.md "tried, not adopted".)
 int launch_lr_classify(blmm_ctx* ctx, int n, int64_t m, double tol, const double* lam, const double* h2, const int* fin,
                        const int* list, const unsigned int* list_cnt, int* perm, const LrRegion& rg, const LrSeg& seg) {
   if (m > 0x7ffffff0LL) return fail(ctx, BLMM_ERR_INVALID, "too many traits for one launch");

@@ -101,12 +101,142 @@ __device__ __forceinline__ int jac_pi(int pos, int NP2) {
   return (s == NP2 - 1) ? 2 * s + 1 : 2 * (s + 1);            // tops move up, the last top -> last bottom
 }
 
+// ------------------------------------------------------------------------------------------------
+// post-eigen: eigenvalues, ordering, Z0 = U' Zs, and the rotation matrix
+//   R = Q U' Wd,  Q = I - Z0 (Z0'Z0)^-1 Z0'  (centered = 1; the LOD statistic and the null likelihood are
+//   invariant to this unweighted projection -- SURVEY.md A.4 -- it only tames cancellation), or
+//   R = U' Wd (centered = 0; literal transform_rotation, src/transform_helpers.jl:34).
+// Rp[i*ldr + k] = R[k, i], zero padded to npad x ldr (the A-operand layout of k_rotate).
+// One workgroup.  A kernel of its own (k_post_eigen) and -- round 4, where its LDS fits beside nothing else -- the TAIL of
+// k_jacobi_lds: that launch sat between k_backtransform and k_post_eigen as a 6 us no-op whenever the fast eigen path's result
+// stood (every kinship of full rank), one more dependent-launch boundary on the critical path of the step; now its first workgroup
+// does this work instead of returning, and when the Jacobi has to run the LAST workgroup to finish does it.
+// ------------------------------------------------------------------------------------------------
+struct PostEigenArgs {
+  const double* Zs; const double* wd; int c, npad, ldr, decomp, centered;
+  double* lam; double* U; double* Z0; double* Rp; double* tmp;
+};
+template <bool VLDS>
+__device__ __forceinline__ void post_eigen_body(const double* __restrict__ lraw_in, const double* __restrict__ Vg, int n, const PostEigenArgs& pa,
+                                                int64_t* stat, double* shv, double* Ginv /* CMAX x CMAX */, double* Gw /* CMAX x 2 CMAX */,
+                                                int* s_neg) {
+  const double* __restrict__ Zs_g = pa.Zs; const double* __restrict__ wd = pa.wd;
+  const int c = pa.c, npad = pa.npad, ldr = pa.ldr, decomp = pa.decomp, centered = pa.centered;
+  double* __restrict__ lam = pa.lam; double* __restrict__ Ug = pa.U; double* __restrict__ Z0g = pa.Z0; double* __restrict__ Rp = pa.Rp;
+  double* __restrict__ tmp = pa.tmp;
+  const int tid = threadIdx.x, nt = blockDim.x;
+  // VLDS: V, U, Zs, Z0, Bq and the raw eigenvalues live in LDS (the loops below walk them with stride n and would
+  // otherwise pay a global-memory round trip per phase); results are also written to their global buffers.
+  double* Vl = shv;                    // n x n
+  double* Ul = shv + (size_t)n * n;    // n x n
+  double* Zsl = Ul + (size_t)n * n;    // n x c
+  double* Z0l = Zsl + (size_t)n * c;   // n x c
+  double* Bql = Z0l + (size_t)n * c;   // c x n
+  double* lrl = Bql + (size_t)n * c;   // n
+  if (VLDS) {
+    for (int e = tid; e < n * n; e += nt) Vl[e] = Vg[e];
+    for (int e = tid; e < n * c; e += nt) Zsl[e] = Zs_g[e];
+  }
+  const double* V = VLDS ? Vl : Vg;
+  const double* Zs = VLDS ? Zsl : Zs_g;
+  double* U = VLDS ? Ul : Ug;
+  double* Z0 = VLDS ? Z0l : Z0g;
+  double* lraw = VLDS ? lrl : tmp;          // n
+  double* Bq = VLDS ? Bql : tmp + n;        // c x n : Ginv * (Zs' Wd)
+  if (tid == 0) *s_neg = 0;
+  for (int i = tid; i < n; i += nt) lraw[i] = (decomp == BLMM_SVD) ? fabs(lraw_in[i]) : lraw_in[i];
+  __syncthreads();
+  for (int i = tid; i < n; i += nt) {
+    const double li = lraw[i];
+    int rank = 0;
+    for (int j = 0; j < n; ++j) {
+      const double lj = lraw[j];
+      if (decomp == BLMM_SVD) rank += (lj > li) || (lj == li && j < i);
+      else rank += (lj < li) || (lj == li && j < i);
+    }
+    lam[rank] = li;
+    if (li < -1e-7) atomicAdd(s_neg, 1);
+    // deterministic sign: the largest-magnitude component of every eigenvector is positive (LAPACK leaves the
+    // sign unspecified; only the permutation test depends on it, see DESIGN.md)
+    double big = 0.0;
+    for (int k = 0; k < n; ++k) { const double v = V[(size_t)i * n + k]; if (fabs(v) > fabs(big)) big = v; }
+    const double sg = (big < 0.0) ? -1.0 : 1.0;
+    for (int k = 0; k < n; ++k) U[(size_t)rank * n + k] = sg * V[(size_t)i * n + k];
+  }
+  __syncthreads();
+  if (tid == 0 && *s_neg) stat[ST_NEG_EIG] += *s_neg;
+  if (VLDS) { for (int e = tid; e < n * n; e += nt) Ug[e] = Ul[e]; }
+  // Z0[k,q] = sum_i U[i,k] Zs[i,q]
+  for (int e = tid; e < n * c; e += nt) {
+    const int k = e % n, q = e / n;
+    double s = 0;
+    for (int i = 0; i < n; ++i) s = fma(U[(size_t)k * n + i], Zs[(size_t)q * n + i], s);
+    Z0[e] = s;
+    if (VLDS) Z0g[e] = s;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    // Gram = Z0'Z0, inverse by Gauss-Jordan (c <= CMAX)
+    auto G = [&](int r_, int c_) -> double& { return Gw[r_ * (2 * CMAX) + c_]; };   // (LDS: 16 KB at CMAX = 32 -- as a local array it would be scratch memory of every thread)
+    for (int a = 0; a < c; ++a)
+      for (int b = 0; b < c; ++b) {
+        double s = 0;
+        for (int k = 0; k < n; ++k) s = fma(Z0[(size_t)a * n + k], Z0[(size_t)b * n + k], s);
+        G(a, b) = s; G(a, c + b) = (a == b) ? 1.0 : 0.0;
+      }
+    for (int a = 0; a < c; ++a) {
+      int piv = a;
+      for (int r = a + 1; r < c; ++r) if (fabs(G(r, a)) > fabs(G(piv, a))) piv = r;
+      if (piv != a) for (int b = 0; b < 2 * c; ++b) { double t = G(a, b); G(a, b) = G(piv, b); G(piv, b) = t; }
+      const double d = 1.0 / G(a, a);
+      for (int b = 0; b < 2 * c; ++b) G(a, b) *= d;
+      for (int r = 0; r < c; ++r) if (r != a) { const double f = G(r, a); for (int b = 0; b < 2 * c; ++b) G(r, b) -= f * G(a, b); }
+    }
+    for (int a = 0; a < c; ++a) for (int b = 0; b < c; ++b) Ginv[a * CMAX + b] = G(a, c + b);
+  }
+  __syncthreads();
+  // Bq[q,i] = sum_r Ginv[q,r] * (Z0' U' Wd)[r,i] = sum_r Ginv[q,r] * Zs[i,r] * wd_i   (U Z0 = Zs)
+  for (int e = tid; e < n * c; e += nt) {
+    const int i = e % n, q = e / n;
+    double s = 0;
+    for (int r = 0; r < c; ++r) s = fma(Ginv[q * CMAX + r], Zs[(size_t)r * n + i], s);
+    Bq[(size_t)q * n + i] = s * (wd ? wd[i] : 1.0);
+  }
+  __syncthreads();
+  for (int e = tid; e < npad * ldr; e += nt) {
+    const int k = e % ldr, i = e / ldr;
+    double v = 0.0;
+    if (i < n && k < n) {
+      v = U[(size_t)k * n + i] * (wd ? wd[i] : 1.0);
+      if (centered)
+        for (int q = 0; q < c; ++q) v = fma(-Z0[(size_t)q * n + k], Bq[(size_t)q * n + i], v);
+    }
+    Rp[e] = v;
+  }
+}
+
+template <bool VLDS>
+__global__ void __launch_bounds__(1024) k_post_eigen(const double* __restrict__ lraw_in, const double* __restrict__ Vg, int n, PostEigenArgs pa,
+                                                     int64_t* stat) {
+  __shared__ double Ginv[CMAX * CMAX];
+  __shared__ double Gw[CMAX * 2 * CMAX];
+  __shared__ int s_neg;
+  extern __shared__ __attribute__((aligned(16))) double shv[];
+  post_eigen_body<VLDS>(lraw_in, Vg, n, pa, stat, shv, Ginv, Gw, &s_neg);
+}
+
 __global__ void __launch_bounds__(1024) k_jacobi_lds(const double* __restrict__ Ag, double* __restrict__ Vg, int n,
-                                                     double* __restrict__ lraw, int64_t* stat, double stop2) {
+                                                     double* __restrict__ lraw, int64_t* stat, double stop2, PostEigenArgs pa, int fuse_post,
+                                                     int pe_off /* doubles: where the post-eigen work arrays start in smem */) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   __shared__ double s_anorm;
-  // the fast path (kernels_eig.hip: k_eigf_*) ran ahead of this launch and its checks passed: nothing to do (workgroup-uniform)
-  if (stat[ST_EIG_FAST] == 1 && __longlong_as_double((long long)stat[ST_EIG_BAD]) <= 1.0) return;
+  __shared__ int s_pe_neg, s_pe_last;
+  // the fast path (kernels_eig.hip: k_eigf_*) ran ahead of this launch and its checks passed: no Jacobi (workgroup-uniform).
+  // fuse_post: the first workgroup then does the post-eigen work (what the next launch used to do) instead of returning.
+  if (stat[ST_EIG_FAST] == 1 && __longlong_as_double((long long)stat[ST_EIG_BAD]) <= 1.0) {
+    if (fuse_post && blockIdx.x == 0) post_eigen_body<true>(lraw, Vg, n, pa, stat, smem, smem + pe_off, smem + pe_off + CMAX * CMAX, &s_pe_neg);
+    return;
+  }
   const int tid = threadIdx.x, nt = blockDim.x;
   const unsigned long long dbg_t0 = __builtin_amdgcn_s_memtime(), dbg_r0 = __builtin_amdgcn_s_memrealtime();
   const int N = n + (n & 1), NP2 = N / 2, ld = N + 1;       // ld: leading dimension of the V slices (odd)
@@ -400,6 +530,15 @@ __global__ void __launch_bounds__(1024) k_jacobi_lds(const double* __restrict__ 
     const int o = (odd && pos > dpos) ? pos - 1 : pos;
     Vg[(size_t)o * n + (r0 + r)] = Vc[r * ld + pos];      // compact n x n column-major: Vg[col*n + row]
   }
+  if (!fuse_post) return;
+  // the last workgroup to get here has every slice of V (and workgroup 0's eigenvalues) in front of it: post-eigen work
+  __threadfence();
+  __syncthreads();
+  if (tid == 0) s_pe_last = (atomicAdd((unsigned long long*)&stat[ST_EIG_DONE], 1ull) == (unsigned long long)gridDim.x - 1ull) ? 1 : 0;
+  __syncthreads();
+  if (!s_pe_last) return;
+  __threadfence();
+  post_eigen_body<true>(lraw, Vg, n, pa, stat, smem, smem + pe_off, smem + pe_off + CMAX * CMAX, &s_pe_neg);
 }
 
 // Global-memory variant for larger n (one workgroup; A, V in L2): the straightforward column/row form.
@@ -490,14 +629,26 @@ __global__ void __launch_bounds__(1024) k_jacobi_glb(double* __restrict__ A, dou
 
 int jacobi_lds_max_n() { return JAC_NMAX; }
 
-int launch_jacobi(blmm_ctx* ctx, double* A, double* V, int n, double* lraw, int64_t* stat) {
+// pe != nullptr: the caller wants the post-eigen work done as well; *fused says whether this launch did it (LDS permitting)
+int launch_jacobi(blmm_ctx* ctx, double* A, double* V, int n, double* lraw, int64_t* stat, const PostEigenArgs* pe, bool* fused) {
+  if (fused) *fused = false;
   if (n <= JAC_NMAX) {
     const int N = n + (n & 1), NP2 = N / 2, ld = N + 1;
     static const int nwg_env = dev_env("BLMM_JAC_NWG") ? atoi(dev_env("BLMM_JAC_NWG")) : 0;
     const int nwg = (nwg_env >= 1 && nwg_env <= 64) ? nwg_env : JAC_NWG;
     const int rows_per = (n + nwg - 1) / nwg;
     const int PL = (NP2 * (NP2 - 1) / 2 + 1) & ~1, AO = (4 * PL + 3 * NP2 + 1) & ~1;
-    const size_t lds = sizeof(double) * ((size_t)2 * AO + (size_t)2 * rows_per * ld + 5 * NP2 + 2) + 64;
+    size_t lds = sizeof(double) * ((size_t)2 * AO + (size_t)2 * rows_per * ld + 5 * NP2 + 2) + 64;
+    // post-eigen work in the same launch: its arrays (2 n^2 + 3 n c + n doubles) and the Gauss-Jordan work arrays behind them
+    static const bool fuse_on = !(dev_env("BLMM_EIG_FUSE_POST") && dev_env("BLMM_EIG_FUSE_POST")[0] == '0');   // A/B: the separate launch of round 3
+    PostEigenArgs pa{};
+    int fuse = 0, pe_off = 0;
+    if (pe && fuse_on) {
+      pe_off = (int)(((size_t)2 * n * n + (size_t)3 * n * pe->c + n + 1) & ~(size_t)1);
+      const size_t lds_pe = sizeof(double) * ((size_t)pe_off + 3 * CMAX * CMAX) + 64;
+      if (lds_pe <= 150 * 1024) { fuse = 1; pa = *pe; if (lds_pe > lds) lds = lds_pe; }
+    }
+    if (fused) *fused = fuse != 0;
     BLMM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_jacobi_lds), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     static const double stop2 = dev_env("BLMM_JAC_STOP2") ? atof(dev_env("BLMM_JAC_STOP2")) : 1e-15;
     // 768 threads (11 worker waves + the angle wave) when two items per worker thread cover the blocks: fewer waves at
@@ -506,7 +657,7 @@ int launch_jacobi(blmm_ctx* ctx, double* A, double* V, int n, double* lraw, int6
     const int nblk = NP2 * (NP2 - 1) / 2;
     int nthr = (nblk <= 2 * (768 - 64)) ? 768 : 1024;
     if (nt_env >= 256 && nt_env <= 1024 && nt_env % 64 == 0 && nblk <= 2 * (nt_env - 64)) nthr = nt_env;
-    hipLaunchKernelGGL(k_jacobi_lds, dim3(nwg), dim3(nthr), lds, ctx->stream, A, V, n, lraw, stat, stop2);
+    hipLaunchKernelGGL(k_jacobi_lds, dim3(nwg), dim3(nthr), lds, ctx->stream, A, V, n, lraw, stat, stop2, pa, fuse, pe_off);
   } else {
     hipLaunchKernelGGL(k_jacobi_glb, dim3(1), dim3(1024), 0, ctx->stream, A, V, n, lraw, stat);
   }
@@ -514,112 +665,12 @@ int launch_jacobi(blmm_ctx* ctx, double* A, double* V, int n, double* lraw, int6
   return BLMM_OK;
 }
 
-// ------------------------------------------------------------------------------------------------
-// post-eigen: eigenvalues, ordering, Z0 = U' Zs, and the rotation matrix
-//   R = Q U' Wd,  Q = I - Z0 (Z0'Z0)^-1 Z0'  (centered = 1; the LOD statistic and the null likelihood are
-//   invariant to this unweighted projection -- SURVEY.md A.4 -- it only tames cancellation), or
-//   R = U' Wd (centered = 0; literal transform_rotation, src/transform_helpers.jl:34).
-// Rp[i*ldr + k] = R[k, i], zero padded to npad x ldr (the A-operand layout of k_rotate).
-// ------------------------------------------------------------------------------------------------
-template <bool VLDS>
-__global__ void __launch_bounds__(1024) k_post_eigen(const double* __restrict__ lraw_in, const double* __restrict__ Vg,
-                                                     const double* __restrict__ Zs_g, const double* __restrict__ wd, int n,
-                                                     int c, int npad, int ldr, int decomp, int centered,
-                                                     double* __restrict__ lam, double* __restrict__ Ug,
-                                                     double* __restrict__ Z0g, double* __restrict__ Rp,
-                                                     double* __restrict__ tmp /* n + c*n */, int64_t* stat) {
-  __shared__ double Ginv[CMAX * CMAX];
-  __shared__ int s_neg;
-  extern __shared__ __attribute__((aligned(16))) double shv[];
-  const int tid = threadIdx.x, nt = blockDim.x;
-  // VLDS: V, U, Zs, Z0, Bq and the raw eigenvalues live in LDS (the loops below walk them with stride n and would
-  // otherwise pay a global-memory round trip per phase); results are also written to their global buffers.
-  double* Vl = shv;                    // n x n
-  double* Ul = shv + (size_t)n * n;    // n x n
-  double* Zsl = Ul + (size_t)n * n;    // n x c
-  double* Z0l = Zsl + (size_t)n * c;   // n x c
-  double* Bql = Z0l + (size_t)n * c;   // c x n
-  double* lrl = Bql + (size_t)n * c;   // n
-  if (VLDS) {
-    for (int e = tid; e < n * n; e += nt) Vl[e] = Vg[e];
-    for (int e = tid; e < n * c; e += nt) Zsl[e] = Zs_g[e];
-  }
-  const double* V = VLDS ? Vl : Vg;
-  const double* Zs = VLDS ? Zsl : Zs_g;
-  double* U = VLDS ? Ul : Ug;
-  double* Z0 = VLDS ? Z0l : Z0g;
-  double* lraw = VLDS ? lrl : tmp;          // n
-  double* Bq = VLDS ? Bql : tmp + n;        // c x n : Ginv * (Zs' Wd)
-  if (tid == 0) s_neg = 0;
-  for (int i = tid; i < n; i += nt) lraw[i] = (decomp == BLMM_SVD) ? fabs(lraw_in[i]) : lraw_in[i];
-  __syncthreads();
-  for (int i = tid; i < n; i += nt) {
-    const double li = lraw[i];
-    int rank = 0;
-    for (int j = 0; j < n; ++j) {
-      const double lj = lraw[j];
-      if (decomp == BLMM_SVD) rank += (lj > li) || (lj == li && j < i);
-      else rank += (lj < li) || (lj == li && j < i);
-    }
-    lam[rank] = li;
-    if (li < -1e-7) atomicAdd(&s_neg, 1);
-    // deterministic sign: the largest-magnitude component of every eigenvector is positive (LAPACK leaves the
-    // sign unspecified; only the permutation test depends on it, see DESIGN.md)
-    double big = 0.0;
-    for (int k = 0; k < n; ++k) { const double v = V[(size_t)i * n + k]; if (fabs(v) > fabs(big)) big = v; }
-    const double sg = (big < 0.0) ? -1.0 : 1.0;
-    for (int k = 0; k < n; ++k) U[(size_t)rank * n + k] = sg * V[(size_t)i * n + k];
-  }
-  __syncthreads();
-  if (tid == 0 && s_neg) stat[ST_NEG_EIG] += s_neg;
-  if (VLDS) { for (int e = tid; e < n * n; e += nt) Ug[e] = Ul[e]; }
-  // Z0[k,q] = sum_i U[i,k] Zs[i,q]
-  for (int e = tid; e < n * c; e += nt) {
-    const int k = e % n, q = e / n;
-    double s = 0;
-    for (int i = 0; i < n; ++i) s = fma(U[(size_t)k * n + i], Zs[(size_t)q * n + i], s);
-    Z0[e] = s;
-    if (VLDS) Z0g[e] = s;
-  }
-  __syncthreads();
-  if (tid == 0) {
-    // Gram = Z0'Z0, inverse by Gauss-Jordan (c <= CMAX)
-    __shared__ double G[CMAX][2 * CMAX];        // (LDS: 16 KB at CMAX = 32 -- as a local array it would be scratch memory of every thread)
-    for (int a = 0; a < c; ++a)
-      for (int b = 0; b < c; ++b) {
-        double s = 0;
-        for (int k = 0; k < n; ++k) s = fma(Z0[(size_t)a * n + k], Z0[(size_t)b * n + k], s);
-        G[a][b] = s; G[a][c + b] = (a == b) ? 1.0 : 0.0;
-      }
-    for (int a = 0; a < c; ++a) {
-      int piv = a;
-      for (int r = a + 1; r < c; ++r) if (fabs(G[r][a]) > fabs(G[piv][a])) piv = r;
-      if (piv != a) for (int b = 0; b < 2 * c; ++b) { double t = G[a][b]; G[a][b] = G[piv][b]; G[piv][b] = t; }
-      const double d = 1.0 / G[a][a];
-      for (int b = 0; b < 2 * c; ++b) G[a][b] *= d;
-      for (int r = 0; r < c; ++r) if (r != a) { const double f = G[r][a]; for (int b = 0; b < 2 * c; ++b) G[r][b] -= f * G[a][b]; }
-    }
-    for (int a = 0; a < c; ++a) for (int b = 0; b < c; ++b) Ginv[a * CMAX + b] = G[a][c + b];
-  }
-  __syncthreads();
-  // Bq[q,i] = sum_r Ginv[q,r] * (Z0' U' Wd)[r,i] = sum_r Ginv[q,r] * Zs[i,r] * wd_i   (U Z0 = Zs)
-  for (int e = tid; e < n * c; e += nt) {
-    const int i = e % n, q = e / n;
-    double s = 0;
-    for (int r = 0; r < c; ++r) s = fma(Ginv[q * CMAX + r], Zs[(size_t)r * n + i], s);
-    Bq[(size_t)q * n + i] = s * (wd ? wd[i] : 1.0);
-  }
-  __syncthreads();
-  for (int e = tid; e < npad * ldr; e += nt) {
-    const int k = e % ldr, i = e / ldr;
-    double v = 0.0;
-    if (i < n && k < n) {
-      v = U[(size_t)k * n + i] * (wd ? wd[i] : 1.0);
-      if (centered)
-        for (int q = 0; q < c; ++q) v = fma(-Z0[(size_t)q * n + k], Bq[(size_t)q * n + i], v);
-    }
-    Rp[e] = v;
-  }
+// Jacobi launch (a no-op on the device when the fast eigen path's result stood) with the post-eigen work in its tail when the LDS
+// allows; *fused = false: the caller launches launch_post_eigen behind it as before
+int launch_jacobi_post(blmm_ctx* ctx, double* A, double* V, int n, double* lraw, int64_t* stat, const double* Zs, const double* dweights,
+                       int c, int npad, int ldr, int decomp, int centered, double* lam, double* U, double* Z0, double* Rp, bool* fused) {
+  const PostEigenArgs pa{Zs, dweights, c, npad, ldr, decomp, centered, lam, U, Z0, Rp, nullptr};
+  return launch_jacobi(ctx, A, V, n, lraw, stat, &pa, fused);
 }
 
 // ---- the same steps as k_post_eigen for n beyond its LDS budget, spread over the chip (k_post_eigen<false>, one
@@ -763,10 +814,10 @@ int launch_post_eigen(blmm_ctx* ctx, const double* lraw, const double* V, const 
     hipFuncAttributes fa;
     return hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(&k_post_eigen<true>)) == hipSuccess ? (size_t)fa.sharedSizeBytes : (size_t)32768;
   }();
+  const PostEigenArgs pa{Zs, dweights, c, npad, ldr, decomp, centered, lam, U, Z0, Rp, ptr<double>(ctx->misc)};
   if (lds + lds_static <= 158 * 1024) {
     BLMM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_post_eigen<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(k_post_eigen<true>, dim3(1), dim3(1024), lds, ctx->stream, lraw, V, Zs, dweights, n, c, npad, ldr, decomp,
-                       centered, lam, U, Z0, Rp, ptr<double>(ctx->misc), stat);
+    hipLaunchKernelGGL(k_post_eigen<true>, dim3(1), dim3(1024), lds, ctx->stream, lraw, V, n, pa, stat);
   } else {
     double* Bq = ptr<double>(ctx->misc);                        // c x n
     int* rankof = reinterpret_cast<int*>(Bq + (size_t)c * n);   // n ints (the workspace holds n more doubles)

@@ -197,11 +197,12 @@ __device__ __forceinline__ void tile_of(int64_t id, int64_t ntile_t, int ntile_i
 
 // the same walk in 32-bit arithmetic (launchers bound the workgroup count by 2^31): a 64-bit division is ~100 scalar
 // instructions, and the walk has two of them at the head of every workgroup
+template <int GTV = GT>
 __device__ __forceinline__ void tile_of32(uint32_t id, uint32_t ntile_t, uint32_t ntile_i, uint32_t& tile_t, uint32_t& tile_i) {
-  const uint32_t per_group = (uint32_t)GT * ntile_i;
+  const uint32_t per_group = (uint32_t)GTV * ntile_i;
   const uint32_t g = id / per_group, rem = id - g * per_group;
-  const uint32_t t_first = g * GT;
-  const uint32_t gt = (ntile_t - t_first < (uint32_t)GT) ? (ntile_t - t_first) : (uint32_t)GT;  // last group may be short
+  const uint32_t t_first = g * GTV;
+  const uint32_t gt = (ntile_t - t_first < (uint32_t)GTV) ? (ntile_t - t_first) : (uint32_t)GTV;  // last group may be short
   tile_i = rem / gt;
   tile_t = t_first + (rem - tile_i * gt);
 }
@@ -1090,19 +1091,34 @@ int launch_scan_table(blmm_ctx* ctx, const ScanArgs& a) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// alt-grid: for every (trait, marker) the maximum over the h2 grid of  ln10*LOD_g + Ell[g, j];
+// alt-grid: for every (trait, marker) the maximum over the h2 grid of  logL1_g = ln10*LOD_g + Ell[g, j];
 //   L = (max_g logL1_g - max_g Ell[g, j]) / ln10,  h2_panel = grid value at the first arg-max
 // (src/bulkscan.jl:495-522).  counter_quirk reproduces tmax!'s improvement counter.
 // Panels: P[g][k][j] = panel 0 under h2 = grid[g].
+// Round 4: the running maximum is kept in a MONOTONE IMAGE of logL1 that needs no logarithm per grid point.  With l0_j = max_g
+// Ell[g, j] and c[g, j] = exp(-(2/n) (Ell[g, j] - l0_j)) (k_alt_ctab, G x m values),
+//     logL1_g - l0_j = -(n/2) ln(1 - r_g^2) + (Ell[g, j] - l0_j) = -(n/2) ln( (1 - r_g^2) c[g, j] ),
+// so  max_g logL1_g  <=>  min_g v_g,  v_g = (1.0 - r_g^2) c[g, j]  (strict <: the first extremum wins, as tmax!'s strict <), and
+//     L = -(n/2) log10(v_min)  -- ONE table logarithm per test instead of one per grid point and test: the fold is five fp64
+// operations where it was ~20 plus an LDS lookup, and every one of them is matrix-pipe time (fp64 VALU and MFMA exclude each other).
+// Two grid points are ordered differently from the reference only when their logL1 agree to rounding (the tests' tie rule).
 // ------------------------------------------------------------------------------------------------
-template <int MB, int NB>
-__global__ void __launch_bounds__(256, 3) k_scan_alt(AltArgs aa, int ntile_i, int64_t nwg) {
+#ifndef ALT_GT
+#define ALT_GT 8
+#endif
+// BIDX8: the running arg-max (grid index, or the improvement counter of the compat quirk) of a lane's 4 NB outputs of one trait
+// packed into the four bytes of ONE register (grids of at most 255 points; longer grids: the unpacked instantiation).  With 16
+// index registers the kernel held 168 VGPRs + 10 spilled dwords at three waves per SIMD, and the spill traffic -- scratch lines
+// pushed out of L2 by the stream of L / h2_panel stores -- showed in WRITE_SIZE (6.19 GB against 4.16 GB of output in round 3,
+// 4.71 GB before the kernel ran three waves).
+#ifndef ALT_MINW
+#define ALT_MINW 3
+#endif
+template <int MB, int NB, bool BIDX8>
+__global__ void __launch_bounds__(256, ALT_MINW) k_scan_alt(AltArgs aa, int ntile_i, int64_t nwg) {
   const ScanArgs& a = aa.s;
   __shared__ dpair s_lod[BLMM_LOD_TABLE_N];
-  const double ln10 = 2.302585092994046;  // log(10)
-  // the table carries -(n/2) ln c: fast_lod5 then returns ln10 * LOD = -(n/2) ln(u) directly (one multiply less per grid
-  // point and test than ln10 * (-(n/2) log10 u))
-  const double scale = a.lodc[0];
+  const double scale = a.lodc[0];         // -(n/2): the table of the other scan kernels, used once per test at the end
   {
     LodStage<256> lst;
     lod_stage_load<256>(lst, a.lodtab);
@@ -1112,14 +1128,18 @@ __global__ void __launch_bounds__(256, 3) k_scan_alt(AltArgs aa, int ntile_i, in
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const uint32_t bid = (uint32_t)xcd_swizzle(blockIdx.x, nwg);
   uint32_t tile_t, tile_i;
-  tile_of32(bid, (uint32_t)nwg / (uint32_t)ntile_i, (uint32_t)ntile_i, tile_t, tile_i);
+  // groups of ALT_GT trait tiles: a trait tile's panels are G x npad x 32 MB doubles (327 KB at BXD size with 16 grid points) -- 16 of
+  // them (the group of the other scan kernels, whose tile has ONE panel set) are 5.2 MB and do not stay in an XCD's 4 MB L2: round 3
+  // measured 11.5 GB of operand fetches per launch for 0.37 GB of panels
+  tile_of32<ALT_GT>(bid, (uint32_t)nwg / (uint32_t)ntile_i, (uint32_t)ntile_i, tile_t, tile_i);
   const int64_t t0 = (int64_t)tile_t * (32 * MB) + (wave >> 1) * (16 * MB);
   const int64_t i0 = (int64_t)tile_i * (32 * NB) + (wave & 1) * (16 * NB);
   const int r = lane & 15, kk = lane >> 4;
   const LodPoly5 lp = lod_poly5_of(a.lodc);
 
+  static_assert(!BIDX8 || NB == 4, "packed arg-max: four outputs per register");
   double best[MB][NB][4];
-  int bidx[MB][NB][4];
+  int bidx[MB][BIDX8 ? 1 : NB][4];
   d4 acc[MB][NB];
 #pragma unroll
   for (int mb = 0; mb < MB; ++mb)
@@ -1127,7 +1147,7 @@ __global__ void __launch_bounds__(256, 3) k_scan_alt(AltArgs aa, int ntile_i, in
     for (int nb = 0; nb < NB; ++nb) {
       acc[mb][nb] = (d4){0, 0, 0, 0};
 #pragma unroll
-      for (int reg = 0; reg < 4; ++reg) { best[mb][nb][reg] = 0.0; bidx[mb][nb][reg] = 0; }
+      for (int reg = 0; reg < 4; ++reg) { best[mb][nb][reg] = 0.0; bidx[mb][BIDX8 ? 0 : nb][reg] = 0; }
     }
 
   // one flat loop over (grid point g, K step ks) with the same two-fragment-set prefetch as k_scan; the prefetch
@@ -1151,9 +1171,9 @@ __global__ void __launch_bounds__(256, 3) k_scan_alt(AltArgs aa, int ntile_i, in
       for (int nb = 0; nb < NB; ++nb)
         acc[mb][nb] = __builtin_amdgcn_mfma_f64_16x16x4f64(A[mb], B[nb], acc[mb][nb], 0, 0, 0);
   };
-  // operands of fold(g) -- the marker norms of grid point g and Ell[g, trait] of the lane's 4*MB traits -- are fetched
+  // operands of fold(g) -- the marker norms of grid point g and c[g, trait] of the lane's 4*MB traits -- are fetched
   // at the START of g's K loop: at fold time they used to cost one exposed global round trip per grid point
-  double sc[NB], ellv[MB][4];
+  double sc[NB], cv[MB][4];
   auto fold_fetch = [&](int g) {
     loadv_m<NB>(sc, a.isx + (int64_t)g * a.ld_isx + i0, r);
 #pragma unroll
@@ -1161,36 +1181,31 @@ __global__ void __launch_bounds__(256, 3) k_scan_alt(AltArgs aa, int ntile_i, in
 #pragma unroll
       for (int reg = 0; reg < 4; ++reg) {
         const int64_t trait = t0 + MB * (kk + 4 * reg) + mb;
-        ellv[mb][reg] = (trait < a.m) ? aa.EllTab[trait * (int64_t)G + g] : 0.0;
+        cv[mb][reg] = (trait < a.m) ? aa.Ctab[trait * (int64_t)G + g] : 1.0;
       }
   };
-  auto fold = [&](int g) {  // logL1_g = ln10*LOD_g + Ell[g, j]; keep the running maximum (tmax!, strict <)
+  auto fold = [&](int g) {  // v_g = (1 - r_g^2) c[g, j]; keep the running minimum = the running maximum of logL1 (tmax!, strict <)
 #pragma unroll
     for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
       for (int reg = 0; reg < 4; ++reg) {
-        const double ell = ellv[mb][reg];
-        double uv[NB], lv[NB];
-        bool ok = true;
+        const double cg = cv[mb][reg];
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) {
           const double rr = acc[mb][nb][reg] * sc[nb];
-          uv[nb] = 1.0 - rr * rr;
-          lv[nb] = fast_lod5(uv[nb], s_lod, lp);
-          ok = ok && lod_fast_ok(uv[nb]);
-        }
-        if (__builtin_expect(!ok, 0)) {   // rare: LOD beyond ~1.2 n / 2, r^2 >= 1 (+Inf / NaN), NaN
-#pragma unroll
-          for (int nb = 0; nb < NB; ++nb)
-            if (!lod_fast_ok(uv[nb])) { int dummy = 0; lv[nb] = lod_out_of_range(uv[nb], s_lod, lp, scale, false, &dummy); }
-        }
-#pragma unroll
-        for (int nb = 0; nb < NB; ++nb) {
-          const double l1 = lv[nb] + ell;
+          const double r2 = rr * rr;                 // (its own statement: -ffp-contract=on would fuse 1 - rr * rr into one fma)
+          const double u = 1.0 - r2;                 // r2lod's operand, same operation order (src/bulkscan_helpers.jl:22-24)
+          const double l1 = u * cg;
           const bool first = g == 0;
-          const bool better = best[mb][nb][reg] < l1;
+          const bool better = l1 < best[mb][nb][reg];
           if (first || better) best[mb][nb][reg] = l1;
-          if (!first && better) bidx[mb][nb][reg] = aa.counter_quirk ? bidx[mb][nb][reg] + 1 : g;
+          if constexpr (BIDX8) {
+            const unsigned int w = (unsigned int)bidx[mb][0][reg], sh = 8u * (unsigned int)nb, msk = 0xffu << sh;
+            const unsigned int nv = aa.counter_quirk ? ((w >> sh) & 0xffu) + 1u : (unsigned int)g;
+            if (!first && better) bidx[mb][0][reg] = (int)((w & ~msk) | (nv << sh));
+          } else {
+            if (!first && better) bidx[mb][nb][reg] = aa.counter_quirk ? bidx[mb][nb][reg] + 1 : g;
+          }
         }
       }
 #pragma unroll
@@ -1234,13 +1249,18 @@ __global__ void __launch_bounds__(256, 3) k_scan_alt(AltArgs aa, int ntile_i, in
     for (int reg = 0; reg < 4; ++reg) {
       const int64_t trait = t0 + MB * (kk + 4 * reg) + mb;
       if (trait >= a.m) continue;
-      double l0 = aa.EllTab[trait * (int64_t)G];
-      for (int g = 1; g < G; ++g) l0 = fmax(l0, aa.EllTab[trait * (int64_t)G + g]);
       double lv[NB], hv[NB];
+      bool ok = true;
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) { lv[nb] = fast_lod5(best[mb][nb][reg], s_lod, lp); ok = ok && lod_fast_ok(best[mb][nb][reg]); }
+      if (__builtin_expect(!ok, 0)) {   // LOD beyond ~1.2 n / 2; r^2 >= 1 at the winning grid point (+Inf / NaN); NaN
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+          if (!lod_fast_ok(best[mb][nb][reg])) { int dummy = 0; lv[nb] = lod_out_of_range(best[mb][nb][reg], s_lod, lp, scale, false, &dummy); }
+      }
 #pragma unroll
       for (int nb = 0; nb < NB; ++nb) {
-        lv[nb] = (best[mb][nb][reg] - l0) / ln10;
-        hv[nb] = aa.grid_dev[bidx[mb][nb][reg]];
+        hv[nb] = aa.grid_dev[BIDX8 ? (int)(((unsigned int)bidx[mb][0][reg] >> (8 * nb)) & 0xffu) : bidx[mb][BIDX8 ? 0 : nb][reg]];
         nnan += (lv[nb] != lv[nb]) && (i0 + mslot<NB>(r, nb) < a.p);
       }
       // 16-byte stores (8-byte aligned: ld = p may be odd), whole 128-byte lines per instruction (store_m)
@@ -1248,6 +1268,21 @@ __global__ void __launch_bounds__(256, 3) k_scan_alt(AltArgs aa, int ntile_i, in
       store_m<NB>(aa.H2 + trait * aa.ldH + i0, r, hv, a.p - i0);
     }
   if (nnan) atomicAdd((unsigned long long*)&a.stat[ST_NAN_LOD], (unsigned long long)nnan);
+}
+
+// c[g, j] = exp(-(2/n) (Ell[g, j] - max_g Ell[g, j])) for the fold of k_scan_alt (see there); one thread per trait
+__global__ void __launch_bounds__(256) k_alt_ctab(const double* __restrict__ EllTab, int G, int64_t m, double two_over_n, double* __restrict__ C) {
+  const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (j >= m) return;
+  double l0 = EllTab[j * G];
+  for (int g = 1; g < G; ++g) l0 = fmax(l0, EllTab[j * G + g]);
+  for (int g = 0; g < G; ++g) C[j * G + g] = exp(-two_over_n * (EllTab[j * G + g] - l0));
+}
+int launch_alt_ctab(blmm_ctx* ctx, const double* EllTab, int ngrid, int64_t m, int n, double* C) {
+  if (m <= 0) return BLMM_OK;
+  hipLaunchKernelGGL(k_alt_ctab, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, ctx->stream, EllTab, ngrid, m, 2.0 / (double)n, C);
+  KCHECK();
+  return BLMM_OK;
 }
 
 #ifndef ALT_MB
@@ -1262,7 +1297,10 @@ int launch_scan_alt(blmm_ctx* ctx, const AltArgs& aa) {
   const int64_t nwg = ntile_t * ntile_i;
   if (nwg <= 0) return BLMM_OK;
   if (nwg > 0x7fffffffLL) return fail(ctx, BLMM_ERR_INVALID, "problem too large for one launch");
-  hipLaunchKernelGGL((k_scan_alt<MB, NB>), dim3((unsigned)nwg), dim3(256), 0, ctx->stream, aa, (int)ntile_i, nwg);
+  if (aa.ngrid <= 255)
+    hipLaunchKernelGGL((k_scan_alt<MB, NB, true>), dim3((unsigned)nwg), dim3(256), 0, ctx->stream, aa, (int)ntile_i, nwg);
+  else
+    hipLaunchKernelGGL((k_scan_alt<MB, NB, false>), dim3((unsigned)nwg), dim3(256), 0, ctx->stream, aa, (int)ntile_i, nwg);
   KCHECK();
   return BLMM_OK;
 }
