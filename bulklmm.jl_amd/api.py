@@ -188,6 +188,16 @@ def default_context() -> Context:
     return _default_ctx
 
 
+MAX_INDIVIDUALS = 2048   # blmm_api.hip: prepare_eigen -- the device eigensolver (tridiagonalisation + divide and conquer) stops there
+
+
+def _check_n(n: int):
+    """The one documented capability gap against the reference (whose LAPACK eigen has no size limit, src/transform_helpers.jl:21-34):
+    refused HERE, before anything is uploaded, with the library's own message and code."""
+    if n > MAX_INDIVIDUALS:
+        raise BulkLMMError("more than 2048 individuals: the device eigensolver (tridiagonalisation + divide and conquer) stops at n = 2048", -10)
+
+
 def _F(a, ndim=2) -> np.ndarray:
     a = np.asarray(a, dtype=np.float64)
     if ndim == 2 and a.ndim == 1:
@@ -355,6 +365,7 @@ def _bulkscan_call(method, Y, G, K, Covar, h2_grid, addIntercept, weights, prior
     p = G.shape[1]
     if G.shape[0] != n or K.shape[0] != n or K.shape[1] != n:
         raise BulkLMMError("Dimension mismatch.", -2)  # src/transform_helpers.jl:9-11
+    _check_n(n)
     cov = None
     ncov = 0
     if Covar is not None:
@@ -471,6 +482,7 @@ def bulkscan_alt_exact(Y, G, K, Covar=None, *, reml: bool = False, prior_varianc
     p = G.shape[1]
     if G.shape[0] != n or K.shape[0] != n or K.shape[1] != n:
         raise BulkLMMError("Dimension mismatch.", -2)
+    _check_n(n)
     if Covar is None and not addIntercept:
         raise BulkLMMError("Intercept has to be added when no other covariate is given.", -7)
     cov, ncov = None, 0
@@ -512,6 +524,7 @@ def bulkscan_multi(mctx: MultiContext, Y, G, K, Covar=None, *, method: str = "nu
     p = G.shape[1]
     if G.shape[0] != n or K.shape[0] != n or K.shape[1] != n:
         raise BulkLMMError("Dimension mismatch.", -2)
+    _check_n(n)
     cov, ncov = None, 0
     if Covar is not None:
         cov = _F(Covar)
@@ -637,6 +650,7 @@ def bulkscan_reduced(Y, G, K, Covar=None, *, method: str = "null-grid", h2_grid=
     p = G.shape[1]
     if G.shape[0] != n or K.shape[0] != n or K.shape[1] != n:
         raise BulkLMMError("Dimension mismatch.", -2)
+    _check_n(n)
     cov, ncov = None, 0
     if Covar is not None:
         cov = _F(Covar)
@@ -711,6 +725,7 @@ def scan(y, g, K, covar=None, *, weights=None, prior_variance: float = 0.0, prio
     p = G.shape[1]
     if G.shape[0] != n or K.shape[0] != n or K.shape[1] != n:
         raise BulkLMMError("Dimension mismatch.", -2)
+    _check_n(n)
     cov = None
     ncov = 0
     if covar is not None:
@@ -794,13 +809,14 @@ def get_thresholds(L_perms, signif_level, ctx: Optional[Context] = None):
 def transform_rotation(y, g, K, *, addIntercept: bool = True, decomp_scheme: str = "eigen", ctx: Optional[Context] = None):
     """src/transform_helpers.jl:1-54: (Ut*y, Ut*[1 g], lambda).  Eigenvector signs/order within equal
     eigenvalues are arbitrary, exactly as with LAPACK."""
-    ctx = ctx or default_context()
     y = _F(y)
     g = _F(g)
     K = _F(K)
     n, m = y.shape
     if g.shape[0] != n or K.shape[0] != n:
         raise BulkLMMError("Dimension mismatch.", -2)
+    _check_n(n)
+    ctx = ctx or default_context()  # after the argument checks: those must not need a GPU
     o = _opts(decomp_scheme=decomp_scheme, addIntercept=addIntercept)
     if addIntercept:
         cov, ncov, G, c = None, 0, g, 1

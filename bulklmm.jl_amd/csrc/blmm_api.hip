@@ -330,7 +330,7 @@ int rotate_markers(blmm_ctx* ctx, Pipe& P, const double* dG, int64_t p) {
 
 int prepare(blmm_ctx* ctx, const blmm_opts* o, const double* dY, int64_t n, int64_t m, const double* dG, int64_t p,
             const double* dCovar, int64_t ncov, const double* dK, const double* dweights, int centered, Pipe& P, Timer& tm,
-            bool early_wbasis = false, bool grid_side = false) {
+            bool early_wbasis = false, bool grid_side = false, bool skip_markers = false) {
   if (m < 0 || p < 0) return fail(ctx, BLMM_ERR_DIM, "Dimension mismatch.");
   int rc = prepare_eigen(ctx, o, n, dCovar, ncov, dK, dweights, centered, P, tm);
   if (rc) return rc;
@@ -354,7 +354,8 @@ int prepare(blmm_ctx* ctx, const blmm_opts* o, const double* dY, int64_t n, int6
     P.xt_side = true;
   }
   if ((rc = rotate_traits(ctx, P, dY, m))) return rc;
-  if (!P.xt_side && (rc = rotate_markers(ctx, P, dG, p))) return rc;
+  if (skip_markers) { P.p = p; P.ldx = round_up(p > 0 ? p : 1, 128); P.Xt = nullptr; }   // the caller rotates them itself (fp32 permutation path)
+  else if (!P.xt_side && (rc = rotate_markers(ctx, P, dG, p))) return rc;
   tm.mark();
   return BLMM_OK;
 }
@@ -685,7 +686,7 @@ void blmm_destroy(blmm_ctx* ctx) {
                     &ctx->iyy, &ctx->h2, &ctx->h2idx, &ctx->sig2, &ctx->ell, &ctx->isx, &ctx->stat, &ctx->gridd, &ctx->misc,
                     &ctx->EllTab, &ctx->inY, &ctx->inG, &ctx->inK, &ctx->inCov, &ctx->inW, &ctx->outL, &ctx->outH2,
                     &ctx->tmpA, &ctx->tmpB, &ctx->tmpC, &ctx->perm, &ctx->r0, &ctx->altbuf, &ctx->logtab, &ctx->lraw,
-                    &ctx->wbQ, &ctx->wbW, &ctx->wbRk, &ctx->lrT, &ctx->lrC, &ctx->lrL, &ctx->lrFlag, &ctx->lrPart, &ctx->lrPerm, &ctx->lrDen0, &ctx->eigW, &ctx->xf32, &ctx->pf32, &ctx->brSt, &ctx->brList, &ctx->illList, &ctx->qrSlab, &ctx->lodtab, &ctx->dynFac, &ctx->pvtab, &ctx->outP, &ctx->redbuf, &ctx->redtrip, &ctx->altC};
+                    &ctx->wbQ, &ctx->wbW, &ctx->wbRk, &ctx->lrT, &ctx->lrC, &ctx->lrL, &ctx->lrFlag, &ctx->lrPart, &ctx->lrPerm, &ctx->lrDen0, &ctx->eigW, &ctx->xf32, &ctx->pf32, &ctx->brSt, &ctx->brList, &ctx->illList, &ctx->qrSlab, &ctx->lodtab, &ctx->dynFac, &ctx->pvtab, &ctx->outP, &ctx->redbuf, &ctx->redtrip, &ctx->altC, &ctx->rf32};
   for (DevBuf* b : bufs) if (b->p) hipFree(b->p);
   for (auto& s : ctx->evsets) for (auto& e : s.e) (void)hipEventDestroy(e);
   if (ctx->side) { (void)hipStreamSynchronize(ctx->side); (void)hipStreamDestroy(ctx->side); }
@@ -811,6 +812,7 @@ static const struct { const char* key; int kind; size_t off; double lo, hi; } kT
   {"lr_shared", 1, offsetof(blmm::Tuning, lr_shared), 0, 1},
   {"lr_split", 1, offsetof(blmm::Tuning, lr_split), -1, 1},
   {"eigen_solver", 1, offsetof(blmm::Tuning, eigen_solver), 0, 2},
+  {"f32_rotation", 1, offsetof(blmm::Tuning, f32_rotation), 0, 1},
 };
 int blmm_set_tuning(blmm_ctx* ctx, const char* key, double value) {
   if (!ctx) return BLMM_ERR_INVALID;
@@ -1469,7 +1471,13 @@ int blmm_last_reduced_route(const blmm_ctx* ctx) { return ctx ? ctx->last_reduce
 // dLperms_out (fp64) or dLperms32_out (fp32, kernels_scan_f32.hip): exactly one of them when nperms > 0
 static int perms_pipeline(blmm_ctx* ctx, const blmm_opts* opts, Pipe& P, Timer& tm, int64_t nperms, uint64_t seed,
                           const int32_t* dperm_idx, double* dscalars_out, double* dlod_out, double* dLperms_out,
-                          float* dLperms32_out, blmm_status* status);
+                          float* dLperms32_out, blmm_status* status, const double* dG_raw = nullptr);
+// fp32 permutation path with its own fp32 rotation (kernels_scan_f32.hip: k_rotate_f32): intercept-only null model (the
+// conditioning guard of more covariates re-scans from the fp64 rotated markers), tuning key "f32_rotation"
+static bool f32_rotation_route(const blmm_ctx* ctx, const blmm_opts* o, const double* dCovar, int64_t ncov, int64_t nperms, int64_t p, bool f32) {
+  const int c_eff = (int)((ncov == 0 || !dCovar) ? 1 : ncov + (o->add_intercept ? 1 : 0));
+  return f32 && nperms > 0 && p > 0 && c_eff == 1 && ctx->tune.f32_rotation != 0;
+}
 
 static int scan_perms_impl(blmm_ctx* ctx, const blmm_opts* opts, const double* dy, int64_t n, const double* dG, int64_t p,
                            const double* dCovar, int64_t ncov, const double* dK, const double* dweights, int64_t nperms,
@@ -1485,14 +1493,15 @@ static int scan_perms_impl(blmm_ctx* ctx, const blmm_opts* opts, const double* d
   if ((rc = check_sticky(ctx))) return rc;
   Timer tm(ctx);
   Pipe P;
-  if ((rc = prepare(ctx, opts, dy, n, 1, dG, p, dCovar, ncov, dK, dweights, 1, P, tm))) return rc;
-  return perms_pipeline(ctx, opts, P, tm, nperms, seed, dperm_idx, dscalars_out, dlod_out, dLperms_out, dLperms32_out, status);
+  const bool own_rot = f32_rotation_route(ctx, opts, dCovar, ncov, nperms, p, dLperms32_out != nullptr);
+  if ((rc = prepare(ctx, opts, dy, n, 1, dG, p, dCovar, ncov, dK, dweights, 1, P, tm, false, false, /*skip_markers*/ own_rot))) return rc;
+  return perms_pipeline(ctx, opts, P, tm, nperms, seed, dperm_idx, dscalars_out, dlod_out, dLperms_out, dLperms32_out, status, own_rot ? dG : nullptr);
 }
 
 // Everything of the permutation test behind the rotations (shared with blmm_scan_perms_prerotated_dev)
 static int perms_pipeline(blmm_ctx* ctx, const blmm_opts* opts, Pipe& P, Timer& tm, int64_t nperms, uint64_t seed,
                           const int32_t* dperm_idx, double* dscalars_out, double* dlod_out, double* dLperms_out,
-                          float* dLperms32_out, blmm_status* status) {
+                          float* dLperms32_out, blmm_status* status, const double* dG_raw) {
   int rc;
   const int64_t p = P.p;
   const NullModel nm = null_model(P, opts);
@@ -1507,6 +1516,29 @@ static int perms_pipeline(blmm_ctx* ctx, const blmm_opts* opts, Pipe& P, Timer& 
   if (nperms > 0)
     if ((rc = launch_perm_panel(ctx, nm, P.Yt, P.ldy, P.Z0, P.lam, dscalars_out + 1, dperm_idx, nperms, seed, 0, pan1, ldp1, P.stat))) return rc;
   if ((rc = ensure(ctx, ctx->isx, sizeof(double) * (size_t)P.ldx))) return rc;
+  if (dG_raw) {
+    // ---- fp32 from the rotation on (round 4): XF = R G on the fp32 matrix cores straight into k_scan_f32's operand layout (no fp64
+    //      rotated markers, no conversion pass), the marker norms from XF (fp64 sums), and the original trait's LOD vector with an
+    //      fp64 numerator taken from G itself (g_i' R'a0) -- it agrees with the fp64 path to ~1e-7 relative (the norms carry the
+    //      fp32 rounding of the rotated markers, averaged over n)
+    const int64_t ldxf = round_up(p, 256), ldpf = ldp1;
+    const int kpad = (int)round_up(P.npad, 128), ldrr = (int)round_up(P.n, 16);
+    if ((rc = ensure(ctx, ctx->xf32, sizeof(float) * (size_t)P.npad * ldxf))) return rc;
+    if ((rc = ensure(ctx, ctx->pf32, sizeof(float) * (size_t)P.npad * ldpf))) return rc;
+    if ((rc = ensure(ctx, ctx->rf32, sizeof(float) * (size_t)kpad * ldrr + sizeof(double) * ((size_t)ldrr + (size_t)p) + 64))) return rc;
+    float* RF = ptr<float>(ctx->rf32);
+    double* vwork = reinterpret_cast<double*>(RF + (((size_t)kpad * ldrr + 3) & ~(size_t)3));
+    double* numv = vwork + ldrr;
+    if ((rc = launch_rotate_f32(ctx, ptr<double>(ctx->Rp), P.ldr, P.n, P.npad, dG_raw, p, RF, ptr<float>(ctx->xf32), ldxf, pan0, ldp0, vwork, numv))) return rc;
+    if ((rc = launch_isx_f32(ctx, nm, ptr<float>(ctx->xf32), ldxf, p, P.Z0, P.lam, dscalars_out + 1, ptr<double>(ctx->isx), P.ldx, P.stat))) return rc;
+    tm.mark();
+    if ((rc = launch_lod_from_num(ctx, numv, ptr<double>(ctx->isx), P.n, p, dlod_out, P.stat))) return rc;
+    if ((rc = launch_cvt_f32(ctx, pan1, ldp1, P.n, nperms, ptr<float>(ctx->pf32), ldpf, P.npad / 8))) return rc;
+    if ((rc = launch_scan_f32(ctx, ptr<float>(ctx->xf32), ldxf, ptr<float>(ctx->pf32), ldpf, P.npad, P.n, p, nperms,
+                              ptr<double>(ctx->isx), dLperms32_out, p, P.stat))) return rc;
+    tm.mark();
+    return end_call(ctx, P, status, &tm);
+  }
   if ((rc = launch_isx(ctx, nm, P.Xt, P.ldx, p, P.Z0, P.lam, dscalars_out + 1, 1, ptr<double>(ctx->isx), P.ldx, P.stat))) return rc;
   tm.mark();
   if (p > 0) {

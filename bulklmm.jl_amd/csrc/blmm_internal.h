@@ -51,6 +51,7 @@ struct Tuning {
   int lr_segments = 0;          // 0: default (six segments of the heritability axis for n <= 80); 1: one weight basis; 2..8: that many equal segments
   int lr_shared = 1;            // 0: no shared-weights class (every trait through the rank-R form)
   int lr_split = -1;            // -1: split the h2 search into two panel regions from 8192 traits on; 0 / 1: never / always
+  int f32_rotation = 1;         // fp32 permutation path (blmm_scan_perms_f32, c <= 3): 1 = rotate G on the fp32 matrix cores straight into k_scan_f32's operand layout; 0 = fp64 rotation + conversion (round 3)
   int eigen_solver = 0;         // 0: by n (fast path + Jacobi up to 124, tridiagonalisation + divide and conquer beyond); 1: Jacobi; 2: divide and conquer
 };
 
@@ -91,7 +92,7 @@ struct blmm_ctx {
   std::string err;
   // grow-only workspace
   blmm::DevBuf Ks, V, lam, U, Zs, Z0, Rp, Yt, Xt, panels, iyy, h2, h2idx, sig2, ell, isx, stat, gridd, misc, EllTab,
-      inY, inG, inK, inCov, inW, outL, outH2, tmpA, tmpB, tmpC, perm, r0, altbuf, logtab, lraw, wbQ, wbW, wbRk, lrT, lrC, lrL, lrFlag, lrPart, lrPerm, lrDen0, eigW, xf32, pf32, brSt, brList, illList, qrSlab, lodtab, dynFac, pvtab, outP, redbuf, redtrip, altC;
+      inY, inG, inK, inCov, inW, outL, outH2, tmpA, tmpB, tmpC, perm, r0, altbuf, logtab, lraw, wbQ, wbW, wbRk, lrT, lrC, lrL, lrFlag, lrPart, lrPerm, lrDen0, eigW, xf32, pf32, brSt, brList, illList, qrSlab, lodtab, dynFac, pvtab, outP, redbuf, redtrip, altC, rf32;
   // event sets: one per timed call since the last blmm_read_timings (grown on demand, reused afterwards)
   struct EvSet { hipEvent_t e[8]; int n; };
   std::vector<EvSet> evsets;
@@ -317,6 +318,13 @@ int launch_lr_classify(blmm_ctx* ctx, int n, int64_t m, double tol, const double
 // kernels_scan_f32.hip: fp32 permutation LOD kernel and the fp64 k-major -> fp32 fragment-major conversion
 int launch_cvt_f32(blmm_ctx* ctx, const double* M, int64_t ld_in, int rows_valid, int64_t cols_valid, float* F,
                    int64_t ld_out, int kblocks);
+// fp32 rotation of the fp32 permutation path: XF (fragment-major) = R G from the caller's fp64 column-major G; the marker norms
+// from XF; the original trait's fp64 LOD from G itself (kernels_scan_f32.hip, kernels_prep.hip)
+int launch_rotate_f32(blmm_ctx* ctx, const double* Rp, int ldr, int n, int npad, const double* dG, int64_t p, float* RF, float* XF, int64_t ldxf,
+                      const double* a0, int64_t lda, double* v_work /* n rounded up to 16 */, double* num /* p: g_i' R'a0 in fp64 */);
+int launch_lod_from_num(blmm_ctx* ctx, const double* num, const double* isx, int n, int64_t p, double* lod, int64_t* stat);
+int launch_isx_f32(blmm_ctx* ctx, const NullModel& nm, const float* XF, int64_t ldxf, int64_t p, const double* Z0, const double* lam,
+                   const double* h2_dev, double* isx, int64_t ld_isx, int64_t* stat);
 int launch_scan_f32(blmm_ctx* ctx, const float* XF, int64_t ldxf, const float* PF, int64_t ldpf, int npad, int n,
                     int64_t p, int64_t m, const double* isx, float* L, int64_t ldL, int64_t* stat);
 // kernels_dyn.hip: run-time covariate counts (c = CTPL + 1 .. CMAX): the counterparts of launch_brent / launch_loglik_grid /

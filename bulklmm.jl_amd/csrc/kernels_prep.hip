@@ -2239,7 +2239,9 @@ int launch_panels(blmm_ctx* ctx, const NullModel& nm, const double* Yt, int64_t 
 // normalisation of computeR_LMM (src/bulkscan_helpers.jl:51,55,58) under the shared weights of
 // weighted_liteqtl (src/bulkscan_helpers.jl:182-193).  grid = (p/256, ngrid).
 // ------------------------------------------------------------------------------------------------
-template <int C>
+// XF32: the markers are the fragment-major fp32 matrix of kernels_scan_f32.hip (F[kb][h][col][j] = x[8 kb + 2 j + h][col], ld = ldx) --
+// the fp32 permutation path never forms the fp64 rotated markers; sums in fp64 either way
+template <int C, bool XF32 = false>
 __global__ void __launch_bounds__(256) k_isx(NullModel nm, const double* __restrict__ Xt, int64_t ldx, int64_t p,
                                              const double* __restrict__ Z0, const double* __restrict__ lam,
                                              const double* __restrict__ grid, double* __restrict__ isx, int64_t ld_isx,
@@ -2285,12 +2287,23 @@ __global__ void __launch_bounds__(256) k_isx(NullModel nm, const double* __restr
     double sxx = 0.0, sxz[C];
 #pragma unroll
     for (int q = 0; q < C; ++q) sxz[q] = 0.0;
-    for (int k = 0; k < n; ++k) {
-      const double x = Xt[(int64_t)k * ldx + i];
+    auto term = [&](int k, double x) {
       const double wx = sW[k] * x;
       sxx = fma(wx, x, sxx);
 #pragma unroll
       for (int q = 0; q < C; ++q) sxz[q] = fma(wx, sZ[q * n + k], sxz[q]);
+    };
+    if constexpr (XF32) {
+      typedef float f4x __attribute__((ext_vector_type(4)));
+      const f4x* F = reinterpret_cast<const f4x*>(Xt);
+      for (int kh = 0; kh < 2 * ((n + 7) / 8); ++kh) {      // kh = kb * 2 + h holds k = 8 kb + 2 j + h, j = 0 .. 3
+        const f4x v = F[(int64_t)kh * ldx + i];
+        const int kb = kh >> 1, h = kh & 1;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { const int k = 8 * kb + 2 * j + h; if (k < n) term(k, (double)v[j]); }
+      }
+    } else {
+      for (int k = 0; k < n; ++k) term(k, Xt[(int64_t)k * ldx + i]);
     }
     double uu = 0.0;
 #pragma unroll
@@ -2318,6 +2331,22 @@ int launch_isx(blmm_ctx* ctx, const NullModel& nm, const double* Xt, int64_t ldx
     default: return fail(ctx, BLMM_ERR_UNSUPPORTED, BLMM_C_ERR);
   }
 #undef IX
+  KCHECK();
+  return BLMM_OK;
+}
+
+// marker norms from the fragment-major fp32 markers XF (ldxf >= ld_isx); c <= 3 (the fp32 rotation path is taken for those)
+int launch_isx_f32(blmm_ctx* ctx, const NullModel& nm, const float* XF, int64_t ldxf, int64_t p, const double* Z0, const double* lam,
+                   const double* h2_dev, double* isx, int64_t ld_isx, int64_t* stat) {
+  dim3 grid((unsigned)((ld_isx + 255) / 256), 1u);
+  const size_t lds = sizeof(double) * (size_t)nm.n * (1 + nm.c);
+  const double* X = reinterpret_cast<const double*>(XF);
+  switch (nm.c) {
+    case 1: hipLaunchKernelGGL((k_isx<1, true>), grid, dim3(256), lds, ctx->stream, nm, X, ldxf, p, Z0, lam, h2_dev, isx, ld_isx, stat); break;
+    case 2: hipLaunchKernelGGL((k_isx<2, true>), grid, dim3(256), lds, ctx->stream, nm, X, ldxf, p, Z0, lam, h2_dev, isx, ld_isx, stat); break;
+    case 3: hipLaunchKernelGGL((k_isx<3, true>), grid, dim3(256), lds, ctx->stream, nm, X, ldxf, p, Z0, lam, h2_dev, isx, ld_isx, stat); break;
+    default: return fail(ctx, BLMM_ERR_UNSUPPORTED, "isx_f32: c <= 3");
+  }
   KCHECK();
   return BLMM_OK;
 }

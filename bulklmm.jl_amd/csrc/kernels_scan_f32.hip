@@ -59,6 +59,229 @@ int launch_cvt_f32(blmm_ctx* ctx, const double* M, int64_t ld_in, int rows_valid
   return BLMM_OK;
 }
 
+// ------------------------------------------------------------------------------------------------
+// fp32 ROTATION for the fp32 permutation path (round 4; BASELINE.json configs[4] asks the whole permutation config in fp32 -- round
+// 3 rotated G on the fp64 matrix cores, 3.7 ms of a 14.6 ms shard step, and converted the result):
+//     XF = fragment-major fp32 of  R G      (transform_rotation's Ut * X, src/transform_helpers.jl:34, centring folded into R)
+// G arrives as the caller's fp64 column-major n x p matrix and is converted in registers; R as a row-major fp32 copy RF[k][r]
+// (k_cvt_r32).  v_mfma_f32_32x32x2_f32: A (32 rows) = rotated index k, B (32 cols) = markers; the two k slots of an MFMA (lane >> 5)
+// take the contraction indices r0 + 8 h + s, s = 0 .. 7 -- the order of a sum is free, and with this one a lane reads 64
+// CONTIGUOUS bytes of its marker column per 16 contraction steps (and 32 contiguous bytes of its row of RF).  Workgroup = 4 waves
+// (2 x 2), 128 rotated rows x 128 markers, four 32 x 32 accumulators per wave; the next chunk's raw operands are requested before
+// the 32 MFMAs of the current one.  The output is written straight in the operand layout of k_scan_f32 (F[kb][h'][col][j], k = 8 kb +
+// 2 j + h'): a lane's rows 8 g + 4 h + {t, t + 2} of a marker are two consecutive floats, and the two halves of the wave fill the
+// 16-byte vector -- 512 dense bytes per store instruction, no conversion pass.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int64_t xcd_swizzle32(int64_t bid, int64_t nwg);
+typedef double d2v __attribute__((ext_vector_type(2), aligned(8)));
+template <int CTRL>
+__device__ __forceinline__ double blmm_dpp_mov8(double x) {      // quad_perm / row_half_mirror exchanges inside eight lanes
+  int lo = __double2loint(x), hi = __double2hiint(x);
+  lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xf, 0xf, false);
+  hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xf, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+typedef float f2u __attribute__((ext_vector_type(2), aligned(8)));
+
+// RF[k * ldrr + r] = (float) R[k, r] = (float) Rp[r * ldr + k], zero beyond n (rows up to kpad, columns up to ldrr)
+__global__ void __launch_bounds__(256) k_cvt_r32(const double* __restrict__ Rp, int ldr, int n, float* __restrict__ RF, int kpad, int ldrr) {
+  const int r = blockIdx.x * 256 + threadIdx.x, k = blockIdx.y;
+  if (r >= ldrr) return;
+  RF[(size_t)k * ldrr + r] = (k < n && r < n) ? (float)Rp[(size_t)r * ldr + k] : 0.0f;
+}
+
+struct RotF32Args {
+  const double* G; int n; int64_t p;        // column-major n x p
+  const float* RF; int ldrr;                // row-major kpad x ldrr
+  float* XF; int64_t ldxf; int kblocks;     // fragment-major output, kblocks = npad / 8
+  const double* v; double* num;             // optional: num[i] = g_i' v in fp64 (v: ldrr doubles, zero beyond n), by the row-tile-0 workgroups
+};
+
+// Operands through LDS (the first form read its fragments straight from global memory, a lane per marker column: 3072 64-byte
+// requests per workgroup and 16 contraction steps -- the L1 / address path, not the matrix pipe, set its 3.2 ms at n = 1000,
+// p = 1e5): per chunk of 16 contraction steps the workgroup fetches the 128 x 16 tile of G (16 KB of fp64, four lanes per 64-byte
+// segment: 256 fully used requests) and the 128 x 16 tile of RF (8 KB, 128 requests), converts G, and lays both out in LDS as
+// [h][row or marker][8 floats] -- exactly the eight values a lane feeds to the chunk's eight MFMA steps (two ds_read_b128).
+// Double-buffered: the next chunk's global loads are in flight during the current chunk's 32 MFMAs per wave, one barrier per chunk.
+__global__ void __launch_bounds__(256, 2) k_rotate_f32(RotF32Args a, int ntile_i) {
+  // [buffer][h][steps 0-3 | 4-7][marker or rotated row][4]: consecutive lanes read consecutive 16-byte vectors (no bank conflicts)
+  __shared__ __attribute__((aligned(16))) float s_b[2][2][2][128][4];
+  __shared__ __attribute__((aligned(16))) float s_a[2][2][2][128][4];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int wk = wave >> 1, wi = wave & 1, c = lane & 31, h = lane >> 5;
+  // marker tile slow, row tile fast inside an XCD's range: the row tiles of a marker tile reuse its slice of G out of L2
+  const int64_t nwg = gridDim.x;
+  const int64_t bid = xcd_swizzle32(blockIdx.x, nwg);
+  const int nkt = (int)(nwg / ntile_i);
+  const int tile_k = (int)(bid % nkt);
+  const int64_t tile_i = bid / nkt;
+  const int k0 = tile_k * 128;
+  const int64_t i0 = tile_i * 128;
+  f16v acc[2][2];
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) acc[mt][nt] = (f16v){0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  // staging map: G -- pass q (4): segment sg = 64 q + (t >> 2) = (marker = sg >> 1, half = sg & 1), piece = t & 3: two doubles
+  //              RF -- pass q (2): row = 64 q + (t >> 2), piece = t & 3: four floats of the row's 16
+  const int piece = t & 3;
+  const double* gsrc[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int sg = 64 * q + (t >> 2);
+    int64_t col = i0 + (sg >> 1);
+    if (col >= a.p) col = a.p - 1;                       // pad columns: a finite duplicate (k_scan_f32 never stores them)
+    gsrc[q] = a.G + col * (int64_t)a.n + 8 * (sg & 1) + 2 * piece;
+  }
+  const float* rsrc[2];
+#pragma unroll
+  for (int q = 0; q < 2; ++q) rsrc[q] = a.RF + (size_t)(k0 + 64 * q + (t >> 2)) * a.ldrr + 4 * piece;
+  const int nch = (a.n + 15) / 16;
+  d2v graw[4];
+  f4 rraw[2];
+  // the original trait's fp64 numerator rides along: this thread's two individuals of each of its four markers times v
+  const bool do_num = a.v != nullptr && tile_k == 0;
+  double pnum[4] = {0.0, 0.0, 0.0, 0.0};
+  const double* vsrc = a.v + 8 * ((t >> 2) & 1) + 2 * piece;
+  auto num_chunk = [&](int ch) {
+    const d2v vv = *reinterpret_cast<const d2v*>(vsrc + 16 * ch);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) pnum[q] = fma(graw[q][1], vv[1], fma(graw[q][0], vv[0], pnum[q]));
+  };
+  auto load_chunk = [&](int ch) {
+    const int R0 = 16 * ch;
+    if (R0 + 16 <= a.n) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) graw[q] = *reinterpret_cast<const d2v*>(gsrc[q] + R0);
+    } else {                                             // the last, partial chunk: RF is zero there; G must stay inside its column
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int sg = 64 * q + (t >> 2);
+        const int r0 = R0 + 8 * (sg & 1) + 2 * piece, ra = r0 < a.n ? r0 : a.n - 1, rb = r0 + 1 < a.n ? r0 + 1 : a.n - 1;
+        const double* base = gsrc[q] - (8 * (sg & 1) + 2 * piece);
+        graw[q] = (d2v){base[ra], base[rb]};
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < 2; ++q) rraw[q] = *reinterpret_cast<const f4*>(rsrc[q] + R0);
+  };
+  auto store_chunk = [&](int buf) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int sg = 64 * q + (t >> 2);
+      *reinterpret_cast<f2u*>(&s_b[buf][sg & 1][piece >> 1][sg >> 1][2 * (piece & 1)]) = (f2u){(float)graw[q][0], (float)graw[q][1]};
+    }
+#pragma unroll
+    for (int q = 0; q < 2; ++q) *reinterpret_cast<f4*>(&s_a[buf][piece >> 1][piece & 1][64 * q + (t >> 2)][0]) = rraw[q];
+  };
+  load_chunk(0);
+  if (do_num) num_chunk(0);
+  store_chunk(0);
+  __syncthreads();
+  for (int ch = 0; ch < nch; ++ch) {
+    const int buf = ch & 1;
+    if (ch + 1 < nch) load_chunk(ch + 1);
+    f4 bf[2][2], af[2][2];
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+      bf[nt][0] = *reinterpret_cast<const f4*>(&s_b[buf][h][0][64 * wi + 32 * nt + c][0]);
+      bf[nt][1] = *reinterpret_cast<const f4*>(&s_b[buf][h][1][64 * wi + 32 * nt + c][0]);
+    }
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+      af[mt][0] = *reinterpret_cast<const f4*>(&s_a[buf][h][0][64 * wk + 32 * mt + c][0]);
+      af[mt][1] = *reinterpret_cast<const f4*>(&s_a[buf][h][1][64 * wk + 32 * mt + c][0]);
+    }
+#pragma unroll
+    for (int s8 = 0; s8 < 8; ++s8)
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+          acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[mt][s8 >> 2][s8 & 3], bf[nt][s8 >> 2][s8 & 3], acc[mt][nt], 0, 0, 0);
+    if (ch + 1 < nch) { if (do_num) num_chunk(ch + 1); store_chunk(buf ^ 1); }
+    __syncthreads();
+  }
+  if (do_num) {                                          // the eight lanes t & 7 of a marker (two halves x four pieces), fixed order
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      double x = pnum[q];
+      x += blmm_dpp_mov8<0xB1>(x); x += blmm_dpp_mov8<0x4E>(x); x += blmm_dpp_mov8<0x141>(x);
+      const int64_t col = i0 + ((64 * q + (t >> 2)) >> 1);
+      if ((t & 7) == 0 && col < a.p) a.num[col] = x;
+    }
+  }
+  // fragment-major stores: rows k = k0 + 64 wk + 32 mt + 8 g + 4 h + t of marker col; t = hp, hp + 2 are floats 2 h, 2 h + 1 of vector (kb, hp)
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int kb = (k0 + 64 * wk + 32 * mt) / 8 + g;
+      if (kb >= a.kblocks) continue;
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt) {
+        const int64_t col = i0 + 64 * wi + 32 * nt + c;
+#pragma unroll
+        for (int hp = 0; hp < 2; ++hp) {
+          float* dst = a.XF + (((int64_t)(kb * 2 + hp) * a.ldxf + col) * 4 + 2 * h);
+          *reinterpret_cast<f2u*>(dst) = (f2u){acc[mt][nt][4 * g + hp], acc[mt][nt][4 * g + hp + 2]};
+        }
+      }
+    }
+}
+
+// The original trait's LOD vector of the fp32 permutation path, with an fp64 numerator that never needs the fp64 rotated markers:
+//   num_i = x~_i' a0 = (R g_i)' a0 = g_i' v,  v = R' a0   (k_backproject: v[r] = sum_k Rp[r ldr + k] a0[k], zero from n to ldrr)
+// The sum g_i' v rides along in k_rotate_f32, which has every element of G in registers as fp64 on its way to LDS.
+__global__ void __launch_bounds__(256) k_backproject(const double* __restrict__ Rp, int ldr, int n, int ldrr, const double* __restrict__ a0,
+                                                     int64_t lda, double* __restrict__ v) {
+  const int lane = threadIdx.x & 63;
+  const int r = blockIdx.x * 4 + (threadIdx.x >> 6);       // one wave per r: its row of Rp is contiguous
+  if (r >= ldrr) return;
+  double s = 0.0;
+  if (r < n)
+    for (int k = lane; k < n; k += 64) s = fma(Rp[(size_t)r * ldr + k], a0[(int64_t)k * lda], s);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+  if (lane == 0) v[r] = s;
+}
+
+// XF (npad x ldxf, fragment-major fp32) = R G; scratch RF: kpad x ldrr floats, kpad = npad rounded up to 128, ldrr = n rounded up to 16
+int launch_rotate_f32(blmm_ctx* ctx, const double* Rp, int ldr, int n, int npad, const double* dG, int64_t p, float* RF, float* XF, int64_t ldxf,
+                      const double* a0, int64_t lda, double* v_work, double* num) {
+  if (p <= 0) return BLMM_OK;
+  if (npad % 8 != 0 || ldxf % 256 != 0) return fail(ctx, BLMM_ERR_INVALID, "rotate_f32: operands are not padded to the tile");
+  const int kpad = (npad + 127) / 128 * 128, ldrr = (n + 15) / 16 * 16;
+  hipLaunchKernelGGL(k_cvt_r32, dim3((unsigned)((ldrr + 255) / 256), (unsigned)kpad), dim3(256), 0, ctx->stream, Rp, ldr, n, RF, kpad, ldrr);
+  if (a0) hipLaunchKernelGGL(k_backproject, dim3((unsigned)((ldrr + 3) / 4)), dim3(256), 0, ctx->stream, Rp, ldr, n, ldrr, a0, lda, v_work);
+  RotF32Args a;
+  a.G = dG; a.n = n; a.p = p; a.RF = RF; a.ldrr = ldrr; a.XF = XF; a.ldxf = ldxf; a.kblocks = npad / 8;
+  a.v = a0 ? v_work : nullptr; a.num = num;
+  const int64_t ntile_i = ldxf / 128, nkt = kpad / 128;
+  if (ntile_i * nkt > 0x7fffffffLL) return fail(ctx, BLMM_ERR_INVALID, "problem too large for one launch");
+  hipLaunchKernelGGL(k_rotate_f32, dim3((unsigned)(ntile_i * nkt)), dim3(256), 0, ctx->stream, a, (int)ntile_i);
+  KCHECK();
+  return BLMM_OK;
+}
+
+// lod_i = -(n/2) log10(1 - (num_i isx_i)^2) of the original trait, num from k_rotate_f32's fp64 side sum (r2lod, src/bulkscan_helpers.jl:22-24)
+__global__ void __launch_bounds__(256) k_lod_from_num(const double* __restrict__ num, const double* __restrict__ isx, int n, int64_t p,
+                                                      double* __restrict__ lod, int64_t* stat) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= p) return;
+  const double rr = num[i] * isx[i];
+  const double r2 = rr * rr;
+  const double u = 1.0 - r2;
+  if (!(u >= 0.0)) atomicAdd((unsigned long long*)&stat[ST_NAN_LOD], 1ull);
+  lod[i] = -0.5 * (double)n * log10(u);
+}
+int launch_lod_from_num(blmm_ctx* ctx, const double* num, const double* isx, int n, int64_t p, double* lod, int64_t* stat) {
+  if (p <= 0) return BLMM_OK;
+  hipLaunchKernelGGL(k_lod_from_num, dim3((unsigned)((p + 255) / 256)), dim3(256), 0, ctx->stream, num, isx, n, p, lod, stat);
+  KCHECK();
+  return BLMM_OK;
+}
+
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t srd_f32(const float* p) {
   return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p), /*stride*/ 0, /*bytes*/ 0xffffffffu, 0x00020000);
 }

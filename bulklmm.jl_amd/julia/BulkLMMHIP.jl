@@ -53,6 +53,10 @@ function raise_status(st)   # BlmmStatus, or one element of the per-device Vecto
 end
 
 decomp(s::String) = s == "eigen" ? Int32(0) : s == "svd" ? Int32(1) : Int32(99)
+# The one capability gap against the reference (LAPACK's eigen has no size limit, src/transform_helpers.jl:21-34): the device
+# eigensolver stops at 2048 individuals.  Refused here, before anything is uploaded, with the library's own message.
+const MAX_INDIVIDUALS = 2048
+check_n(n) = n <= MAX_INDIVIDUALS || error("more than 2048 individuals: the device eigensolver (tridiagonalisation + divide and conquer) stops at n = 2048")
 ptr_or_null(x) = x === missing || x === nothing ? Ptr{Float64}(C_NULL) : pointer(x)
 
 function calcKinship(geno::Array{Float64, 2})
@@ -67,7 +71,8 @@ function _bulkscan(method::Int32, Y::Array{Float64, 2}, G::Array{Float64, 2}, Co
                    addIntercept::Bool, weights, prior_variance::Float64, prior_sample_size::Float64, reml::Bool,
                    optim_interval::Int64, decomp_scheme::String, keep_on_device::Bool = false, pvals_df::Int64 = 0)
     (n, m) = size(Y); p = size(G, 2)
-    (size(G, 1) != n || size(K, 1) != n || size(K, 2) != n) && error("Dimension mismatch.")   # src/transform_helpers.jl:9-11
+    (size(G, 1) != n || size(K, 1) != n || size(K, 2) != n) && error("Dimension mismatch.")
+    check_n(n)   # src/transform_helpers.jl:9-11
     (Covar !== nothing && size(Covar, 1) != n) && error("Dimension mismatch.")
     (weights !== missing && length(weights) != n) && error("Dimension mismatch.")
     ncov = Covar === nothing ? 0 : size(Covar, 2)
@@ -167,6 +172,7 @@ function bulkscan_reduced(Y::Array{Float64, 2}, G::Array{Float64, 2}, Covar::Uni
            error("Unknown method `$method`; choose null-exact, null-grid or alt-grid.")
     (n, m) = size(Y); p = size(G, 2)
     (size(G, 1) != n || size(K, 1) != n || size(K, 2) != n) && error("Dimension mismatch.")
+    check_n(n)
     (Covar !== nothing && size(Covar, 1) != n) && error("Dimension mismatch.")
     (weights !== missing && length(weights) != n) && error("Dimension mismatch.")
     ncov = Covar === nothing ? 0 : size(Covar, 2)
@@ -335,6 +341,7 @@ function bulkscan_alt_exact(Y::Array{Float64, 2}, G::Array{Float64, 2}, Covar::A
                             optim_interval::Int64 = 1, decomp_scheme::String = "eigen")
     n = size(Y, 1); m = size(Y, 2); p = size(G, 2)
     (size(G, 1) != n || size(K, 1) != n || size(K, 2) != n || size(Covar, 1) != n) && error("Dimension mismatch.")
+    check_n(n)
     (weights !== missing && length(weights) != n) && error("Dimension mismatch.")
     o = BlmmOpts(NULL_EXACT, reml, addIntercept, decomp(decomp_scheme), optim_interval, 0, prior_variance, prior_sample_size)
     L = Array{Float64, 2}(undef, p, m); H = Array{Float64, 2}(undef, p, m)
@@ -379,6 +386,7 @@ function bulkscan_multi(Y::Array{Float64, 2}, G::Array{Float64, 2}, K::Array{Flo
            error("Unknown method `$method`; choose null-exact, null-grid or alt-grid.")
     (n, m) = size(Y); p = size(G, 2)
     (size(G, 1) != n || size(K, 1) != n || size(K, 2) != n) && error("Dimension mismatch.")
+    check_n(n)
     (weights !== missing && length(weights) != n) && error("Dimension mismatch.")
     o = BlmmOpts(meth, reml, true, decomp(decomp_scheme), optim_interval, 0, prior_variance, prior_sample_size)
     mo = BlmmMultiOpts(gather == :none ? 0 : gather == :allgather ? 2 : 1, 0)
@@ -467,6 +475,7 @@ function scan(y::Array{Float64, 2}, g::Array{Float64, 2}, covar::Array{Float64, 
     size(y, 2) == 1 || error("Can only handle one trait.")                                   # src/scan.jl:496-498
     n = size(y, 1); p = size(g, 2)
     (size(g, 1) != n || size(K, 1) != n || size(K, 2) != n || size(covar, 1) != n) && error("Dimension mismatch.")
+    check_n(n)
     (weights !== missing && length(weights) != n) && error("Dimension mismatch.")
     np = permutation_test ? nperms : 0
     np < 0 && error("The required number of permutations must be a positive integer.")

@@ -154,6 +154,8 @@ int blmm_synchronize(blmm_ctx* ctx);
  *   "lr_shared"       1      0: no shared-weights class (traits with h2 = 0 go through the rank-R form like the others)
  *   "lr_split"        -1     split h2 search / two panel regions: -1 = from 8192 traits on, 0 never, 1 always
  *   "eigen_solver"    0      0 = by n; 1 = Jacobi; 2 = tridiagonalisation + divide and conquer
+ *   "f32_rotation"    1      blmm_scan_perms_f32 with an intercept-only null model: 1 = the marker rotation runs on the fp32 matrix
+ *                            cores as well; 0 = fp64 rotation, converted (0.2.2)
  *   "defaults"               (set only) every key back to its default
  * Every setting gives results within the library's stated tolerances; they exist for tests and for A/B measurements. */
 int blmm_set_tuning(blmm_ctx* ctx, const char* key, double value);
@@ -321,9 +323,12 @@ int blmm_scan_perms_dev(blmm_ctx* ctx, const blmm_opts* opts, const double* dy, 
                         int64_t nperms, uint64_t seed, const int32_t* dperm_idx, double* dscalars_out,
                         double* dlod_out, double* dLperms_out, blmm_status* status);
 
-/* fp32 permutation matrix (BASELINE.json configs[4]): the null model, rotation, panel construction and the original
- * trait's lod_out stay fp64; the p x nperms contraction runs on the fp32 matrix cores and Lperms_out is float
- * (p x nperms, ld = p).  Expected agreement with the fp64 path: |d| <= 1e-3 |ref| + 1e-4. */
+/* fp32 permutation matrix (BASELINE.json configs[4]): the null model (eigen-decomposition, h2, residuals, panel construction)
+ * stays fp64; the marker rotation and the p x nperms contraction run on the fp32 matrix cores and Lperms_out is float
+ * (p x nperms, ld = p).  Expected agreement with the fp64 path: |d| <= 1e-3 |ref| + 1e-4.  The original trait's lod_out keeps an
+ * fp64 numerator (taken from G itself); its marker norms come from the fp32-rotated markers, so it agrees with blmm_scan_perms'
+ * lod_out to ~1e-7 relative, not bit for bit.  With null covariates beyond the intercept (or tuning "f32_rotation" = 0) the
+ * rotation is the fp64 one, converted, and lod_out is blmm_scan_perms' bit for bit. */
 int blmm_scan_perms_f32(blmm_ctx* ctx, const blmm_opts* opts, const double* y, int64_t n, const double* G, int64_t p,
                         const double* Covar, int64_t ncov, const double* K, const double* weights, int64_t nperms,
                         uint64_t seed, const int32_t* perm_idx, double* scalars_out, double* lod_out,

@@ -65,6 +65,9 @@ y1 = dYf[0].contiguous()
 pidx_all = torch.from_numpy(np.stack([np.random.default_rng(5 + b).permutation(n) for b in range(nperms)]).astype(np.int32)).to(dev)
 for dt in (torch.float64, torch.float32):
     ref_ctx = blmm.Context(0)
+    # (the gathered blocks are fp64-rotated: the one-call fp32 path is held to them with its own fp32 rotation switched off --
+    #  tuning f32_rotation = 0 -- and, below, with it on to the fp32 contract)
+    ref_ctx.set_tuning("f32_rotation", 0)
     sc_ref = torch.empty(2, dtype=torch.float64, device=dev); lod_ref = torch.empty(p, dtype=torch.float64, device=dev)
     Lp_ref = torch.empty((nperms, p), dtype=dt, device=dev)
     torch.cuda.synchronize()
@@ -88,6 +91,17 @@ for dt in (torch.float64, torch.float32):
         c.synchronize()
         assert torch.equal(sc, sc_ref) and torch.equal(lod, lod_ref), (dt, r)
         assert torch.equal(Lp, Lp_ref[lo:hi]), (dt, r, float((Lp.double() - Lp_ref[lo:hi].double()).abs().max()))
+    if dt == torch.float32:
+        ref_ctx.set_tuning("f32_rotation", 1)
+        sc2 = torch.empty(2, dtype=torch.float64, device=dev); lod2 = torch.empty(p, dtype=torch.float64, device=dev)
+        Lp2 = torch.empty((nperms, p), dtype=dt, device=dev)
+        torch.cuda.synchronize()
+        blmm.scan_perms_dev(ref_ctx, y1, dG, dK, sc2, lod2, Lp2, nperms=nperms, perm_idx=pidx_all)
+        ref_ctx.synchronize()
+        assert torch.equal(sc2, sc_ref)
+        assert bool(((lod2 - lod_ref).abs() <= 1e-6 * lod_ref.abs() + 1e-10).all()), float((lod2 - lod_ref).abs().max())
+        d = (Lp2.double() - Lp_ref.double()).abs()
+        assert bool((d <= 1e-3 * Lp_ref.double().abs() + 1e-4).all()), float(d.max())
     for c in ctxs + [ref_ctx]:
         c.close()
     print("sharded rotation ok perms", dt, flush=True)

@@ -73,6 +73,18 @@ def test_no_gpu_fails_loudly(blmm):
         blmm.bulkscan_null(np.zeros((5, 2)), np.zeros((5, 3)), np.eye(5))
 
 
+def test_more_than_2048_individuals_is_refused_before_anything_is_uploaded(blmm):
+    """The one capability gap against the reference (LAPACK's eigen takes any n, src/transform_helpers.jl:21-34): the host mirror
+    refuses n > 2048 with the library's message and code BEFORE it creates a context or uploads data (this test runs without a GPU)."""
+    n = 2049
+    Y = np.zeros((n, 1)); G = np.zeros((n, 2)); K = np.eye(n)
+    for call in (lambda: blmm.bulkscan(Y, G, K), lambda: blmm.bulkscan_null(Y, G, K), lambda: blmm.bulkscan_reduced(Y, G, K),
+                 lambda: blmm.scan(Y[:, 0], G, K), lambda: blmm.bulkscan_alt_exact(Y, G, K), lambda: blmm.transform_rotation(Y, G, K)):
+        with pytest.raises(blmm.BulkLMMError) as e:
+            call()
+        assert e.value.code == -10 and "2048" in e.value.msg
+
+
 def test_product_path_never_touches_the_oracle():
     pkg = os.path.join(ROOT, "bulklmm.jl_amd")
     for dirpath, _, files in os.walk(pkg):

@@ -91,7 +91,10 @@ def test_config4_permutations_fp64_and_fp32(blmm, perm_cfg):
         assert r["L_perms"].shape == (p, nperms) and np.isfinite(r["L_perms"]).all() and (r["L_perms"] >= -1e-4).all()
         assert np.isfinite(r["lod"]).all()
     assert g32["L_perms"].dtype == np.float32 and g64["L_perms"].dtype == np.float64
-    assert g32["h2_null"] == g64["h2_null"] and np.array_equal(g32["lod"], g64["lod"])   # the null model stays fp64
+    # the null model stays fp64; the original trait's LOD keeps an fp64 numerator, its marker norms come from the fp32-rotated
+    # markers (round 4: the rotation runs on the fp32 matrix cores too): 1e-6, not bit for bit
+    assert g32["h2_null"] == g64["h2_null"]
+    assert_lod_close(g32["lod"], g64["lod"], what="lod of the fp32 permutation path")
     # the oracle on sampled markers (a marker's LOD row depends on no other marker), all permutations, shared rotation
     idx = MARKERS(p)
     y0, X0, lam = blmm.transform_rotation(y.reshape(-1, 1), np.hstack([np.ones((n, 1)), G]), K, addIntercept=False)
