@@ -85,9 +85,18 @@ typedef float f2u __attribute__((ext_vector_type(2), aligned(8)));
 
 // RF[k * ldrr + r] = (float) R[k, r] = (float) Rp[r * ldr + k], zero beyond n (rows up to kpad, columns up to ldrr)
 __global__ void __launch_bounds__(256) k_cvt_r32(const double* __restrict__ Rp, int ldr, int n, float* __restrict__ RF, int kpad, int ldrr) {
-  const int r = blockIdx.x * 256 + threadIdx.x, k = blockIdx.y;
-  if (r >= ldrr) return;
-  RF[(size_t)k * ldrr + r] = (k < n && r < n) ? (float)Rp[(size_t)r * ldr + k] : 0.0f;
+  __shared__ float tile[32][33];                            // 32 x 32 transpose: reads run along k, writes along r
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const int r0 = blockIdx.x * 32, k0 = blockIdx.y * 32;
+  for (int rr = ty; rr < 32; rr += 8) {
+    const int r = r0 + rr, k = k0 + tx;
+    tile[rr][tx] = (r < n && k < n) ? (float)Rp[(size_t)r * ldr + k] : 0.0f;
+  }
+  __syncthreads();
+  for (int kk = ty; kk < 32; kk += 8) {
+    const int k = k0 + kk, r = r0 + tx;
+    if (k < kpad && r < ldrr) RF[(size_t)k * ldrr + r] = tile[tx][kk];
+  }
 }
 
 struct RotF32Args {
@@ -252,7 +261,7 @@ int launch_rotate_f32(blmm_ctx* ctx, const double* Rp, int ldr, int n, int npad,
   if (p <= 0) return BLMM_OK;
   if (npad % 8 != 0 || ldxf % 256 != 0) return fail(ctx, BLMM_ERR_INVALID, "rotate_f32: operands are not padded to the tile");
   const int kpad = (npad + 127) / 128 * 128, ldrr = (n + 15) / 16 * 16;
-  hipLaunchKernelGGL(k_cvt_r32, dim3((unsigned)((ldrr + 255) / 256), (unsigned)kpad), dim3(256), 0, ctx->stream, Rp, ldr, n, RF, kpad, ldrr);
+  hipLaunchKernelGGL(k_cvt_r32, dim3((unsigned)((ldrr + 31) / 32), (unsigned)((kpad + 31) / 32)), dim3(256), 0, ctx->stream, Rp, ldr, n, RF, kpad, ldrr);
   if (a0) hipLaunchKernelGGL(k_backproject, dim3((unsigned)((ldrr + 3) / 4)), dim3(256), 0, ctx->stream, Rp, ldr, n, ldrr, a0, lda, v_work);
   RotF32Args a;
   a.G = dG; a.n = n; a.p = p; a.RF = RF; a.ldrr = ldrr; a.XF = XF; a.ldxf = ldxf; a.kblocks = npad / 8;
