@@ -103,6 +103,8 @@ def workload_name(a, n, p, m_total, m_local, f32, world):
         which = "no BASELINE.json config has this method and shape"
     unit = "permutations" if a.method == "perms" else "traits"
     pv = " + output_pvals (-log10 p matrix written by the same step)" if getattr(a, "pvals", False) and a.method != "perms" else ""
+    if getattr(a, "reduced", False):
+        pv += " REDUCED OUTPUT (blmm_bulkscan_reduced_dev: per-trait peaks + LOD > 5 triplets, no L matrix; each call synchronises)"
     return (f"method={a.method} n={n} p={p} m={m_total} {dt}{pv}, {which}; {m_local} {unit} on rank 0 of {world}")
 
 
@@ -133,10 +135,15 @@ def main():
                     help="`output_pvals = true`: the step also produces the -log10 p matrix (blmm_set_log10p_output; --pvals-pass runs it as "
                          "the column pass over the finished L instead of from the scan epilogues: tuning key pval_fused = 0)")
     ap.add_argument("--pvals-pass", action="store_true")
+    ap.add_argument("--reduced", action="store_true",
+                    help="the step is blmm_bulkscan_reduced_dev: per-trait peak LOD + marker and the LOD > 5 triplets out of the scan "
+                         "kernels' epilogues, the p x m matrix is never written (NOT the reported default; null-exact / null-grid, N = 1)")
     ap.add_argument("--no-all-rank-form", action="store_true",
                     help="skip the extra timed loop with every trait in the rank-R form (profiling runs: its launches would be averaged into the kernel statistics)")
     ap.add_argument("--cpu-budget", type=float, default=15.0)
     a = ap.parse_args()
+    if a.reduced and (a.method not in ("null-exact", "null-grid") or a.gpus > 1 or a.streams > 1):
+        raise SystemExit("--reduced: null-exact / null-grid on one GPU, one stream")
 
     if "WORLD_SIZE" not in os.environ and a.gpus > 1:
         # start the ranks ourselves, one child process per GPU with the torchrun environment (RANK / LOCAL_RANK /
@@ -245,6 +252,11 @@ def main():
                 ldl = -(-p // a.ldl_align) * a.ldl_align
                 self.dL = torch.empty((self.m, ldl), dtype=ldt, device=dev)[:, :p]
             self.dH = torch.empty((self.m, p) if alt else (max(self.m, 1),), dtype=torch.float64, device=dev)
+            if a.reduced:
+                self.rmax = torch.empty(max(self.m, 1), dtype=torch.float64, device=dev)
+                self.rarg = torch.empty(max(self.m, 1), dtype=torch.int64, device=dev)
+                self.ti = torch.empty(1 << 21, dtype=torch.int32, device=dev); self.tj = torch.empty(1 << 21, dtype=torch.int32, device=dev)
+                self.tl = torch.empty(1 << 21, dtype=torch.float64, device=dev); self.tc = torch.zeros(1, dtype=torch.int64, device=dev)
             self.dP = torch.empty((self.m, p), dtype=torch.float64, device=dev) if a.pvals and not perms else None
             if perms:
                 self.dy1 = self.dY[0].contiguous()
@@ -282,6 +294,9 @@ def main():
                     B.bulkscan_prerotated_dev(c, self.dY, self.gx, p, self.bc, L, H, method=a.method, h2_grid=grid)
             elif perms:
                 B.scan_perms_dev(c, self.dy1, dG, dK, self.dsc, self.dlod, L, nperms=self.m, seed=1 + rank)
+            elif a.reduced:
+                B.bulkscan_reduced_dev(c, self.dY, dG, dK, self.rmax, self.rarg, H, method=a.method, h2_grid=grid, threshold=5.0,
+                                       trip_i=self.ti, trip_j=self.tj, trip_lod=self.tl, trip_count=self.tc)
             else:
                 B.bulkscan_dev(c, self.dY, dG, dK, L, H, method=a.method, h2_grid=grid, log10p_out=self.dP)
 
@@ -338,7 +353,7 @@ def main():
     # shared-weights class) is a property of the DATA: one more timed loop with the class switched off (every trait through the
     # rank-R form: tuning key lr_shared = 0) says what the step costs without it.
     all_rank = None
-    if a.method == "null-exact" and world == 1 and a.streams == 1 and not a.no_all_rank_form:
+    if a.method == "null-exact" and world == 1 and a.streams == 1 and not a.no_all_rank_form and not a.reduced:
         ctx.set_tuning("lr_shared", 0)
         try:
             dt_r, ph_r, nc_r = timed(work, False, max(a.steps // 2, 3), 1)
@@ -353,7 +368,7 @@ def main():
         lr_shared = int(st.lowrank_shared)
         lr_profile = ctx.lowrank_profile()          # (shared-weights traits, [(traits, rank) per segment of the heritability axis])
     # sanity: the output must be finite (a fast kernel with wrong results is not a result)
-    chk = torch.isfinite(work.dL[: min(64, work.m)]).all().item()
+    chk = torch.isfinite(work.rmax).all().item() if a.reduced else torch.isfinite(work.dL[: min(64, work.m)]).all().item()
 
     ag_ms = gathered_ms = None
     weak = None
@@ -420,7 +435,7 @@ def main():
         del w2
 
     host_api = None
-    if rank == 0 and world == 1 and not a.no_host_api and not perms and a.streams == 1:
+    if rank == 0 and world == 1 and not a.no_host_api and not perms and a.streams == 1 and not a.reduced:
         # SURVEY.md §8(d)'s third time: host inputs -> host L through the drop-in entry point (H2D of Y/G/K, the same
         # kernels, D2H of L into caller memory); once into a fresh pageable array, once into a pinned (registered) one
         Lh = np.empty((p, m_local), order="F")

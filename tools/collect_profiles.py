@@ -10,12 +10,12 @@ import shutil
 import sys
 
 out = sys.argv[1]
-RND = sys.argv[2] if len(sys.argv) > 2 else "r03"
+RND = sys.argv[2] if len(sys.argv) > 2 else "r04"
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 prof = os.path.join(root, "profiles")
 # substrings of the kernel names that make up a configuration's LOD scan: null-exact = k_scan_lr (rank-R class) + the table
 # kernel in permuted-column mode (shared-weights class), each launched once per panel region
-KERN = {"exact": ("k_scan_lr", "k_scan<0, 2, 4, true, 2, true"), "grid": ("k_scan<",), "alt": ("k_scan_alt",), "perm32": ("k_scan_f32",)}
+KERN = {"exact": ("k_scan_lr", "k_scan<0, 2, 4, true, 2, true"), "grid": ("k_scan<",), "alt": ("k_scan_alt",), "perm32": ("k_scan_f32",)}   # (k_rotate_f32 of the perm32 run: in the kernel-stats CSV)
 ARGS = {"exact": "(default)", "grid": "--method null-grid", "alt": "--method alt-grid",
         "perm32": "--method perms --perm-dtype f32 --n 1000 --p 100000 --m 1250"}
 
@@ -58,7 +58,14 @@ for tag, kern in KERN.items():
             s["effective_clock_GHz"] = s["GRBM_GUI_ACTIVE"] / 8 / (s["rocprof_avg_ms"] * 1e-3) / 1e9
     summary[tag] = s
 json.dump(summary, open(os.path.join(prof, RND + "_summary.json"), "w"), indent=1)
-for name in ("bench.json", "configs.jsonl", "mb3_f64.log", "mb_f64.log", "mb4_rcp.log", "mb_lod.log"):
+for tag in ("n500_shard", "n1000_perm_shard"):        # trace-only runs: the kernel statistics as they are
+    st = glob.glob(os.path.join(out, tag, "trace", "**", "*kernel_stats.csv"), recursive=True)
+    if st:
+        shutil.copy(st[0], os.path.join(prof, f"{RND}_kernel_stats_{tag}.csv"))
+if os.path.exists(os.path.join(out, "timeline_bxd_step.txt")):
+    shutil.copy(os.path.join(out, "timeline_bxd_step.txt"), os.path.join(prof, RND + "_timeline_bxd_step.txt"))
+for name in ("bench.json", "bench_reduced.json", "configs.jsonl", "mb3_f64.log", "mb_f64.log", "mb4_rcp.log", "mb_lod.log", "power_null_exact.log",
+             "power_null_exact_reduced.log"):
     src = os.path.join(out, name)
     if os.path.exists(src):
         shutil.copy(src, os.path.join(prof, RND + "_" + name))
