@@ -12,6 +12,25 @@ seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 rng = np.random.default_rng(seed0)
 fails = 0
 t0 = time.time()
+
+
+def check_reduced(method, L, h2, Y, G, K, Cov, w, oi, kw, grid):
+    """blmm_bulkscan_reduced (the scan kernels reduce in their epilogues / the routes through a resident matrix) against the
+    reductions of the matrix the ordinary call returned: bit for bit."""
+    thr = float(np.quantile(L, 0.98)) if L.size else 1.0
+    red = blmm.bulkscan_reduced(Y, G, K, Cov, method=method, h2_grid=grid, threshold=thr, cap=16, weights=w, optim_interval=oi, **kw)
+    Lm = np.where(np.isnan(L), -np.inf, L)
+    if L.shape[0] > 0:
+        arg = np.argmax(Lm, axis=0)
+        assert np.array_equal(red["max_lod"], Lm[arg, np.arange(L.shape[1])]) and np.array_equal(red["argmax"], arg), "reduced: maxima"
+    i, j = np.nonzero(L > thr)
+    o = np.lexsort((i, j))
+    ti, tj, tl = red["triplets"]
+    assert np.array_equal(ti, i[o]) and np.array_equal(tj, j[o]) and np.array_equal(tl, L[i[o], j[o]]), "reduced: triplets"
+    if method != "alt-grid":
+        assert np.array_equal(red["h2_null_list"], h2), "reduced: h2"
+
+
 for case in range(ncases):
     n = int(rng.choice([5, 8, 13, 31, 47, 64, 79, 80, 93, 100, 111, 124, 125, 140, 160, 200, 260]))
     kkind = str(rng.choice(["markers", "markers", "one-marker", "few-markers", "duplicated-individuals"]))
@@ -74,6 +93,8 @@ for case in range(ncases):
             # strict for every trait: the h2 -> 1 boundary traits with badly conditioned weighted covariates (case 237 of seed
             # 201: n = 13, 8 null covariates, cond 2e4) are re-scanned with an orthogonalised projection (kernels_dyn.hip)
             assert_lod_close(got.L, pin.L)
+            if case % 2 == 1:
+                check_reduced("null-exact", got.L, got.h2_null_list, Y, G, K, Cov, w, oi, kw, grid)
             if case % 3 == 0:       # `output_pvals` written by the scan itself (low-rank, exact, dyn and re-scan kernels alike)
                 rp = blmm.bulkscan(Y, G, K, Cov, method="null-exact", weights=w, optim_interval=oi, output_pvals=True, **kw)
                 refp = O.lod2log10p(rp["L"], 1)
@@ -130,12 +151,16 @@ for case in range(ncases):
             same = got.h2_null_list == ref.h2_null_list      # Ell ties between grid points may resolve differently
             assert same.mean() >= 0.98, "grid choice"
             assert_lod_close(got.L[:, same], ref.L[:, same])
+            if case % 2 == 1:
+                check_reduced("null-grid", got.L, got.h2_null_list, Y, G, K, Cov, w, 1, kw, grid)
         else:
             if ncov > 0 and Cov is not None and Cov.shape[1] + 1 > 1:
                 pass
             got = blmm.bulkscan_alt_grid(Y, G, K, grid, Cov, weights=w, **kw)
             ref = O.bulkscan_alt_grid(Y, G, K, grid, Covar=Cov, weights=w, **kw)
             assert_lod_close(got.L, ref.L, atol=1e-9)
+            if case % 4 == 1:
+                check_reduced("alt-grid", got.L, None, Y, G, K, Cov, w, 1, kw, grid)
         print("ok  ", desc, flush=True)
     except blmm.BulkLMMError as e:
         # an input the reference rejects (e.g. a zero-norm marker at n = 5): fine if the oracle raises the same message
