@@ -1493,8 +1493,25 @@ static int scan_perms_impl(blmm_ctx* ctx, const blmm_opts* opts, const double* d
   if ((rc = check_sticky(ctx))) return rc;
   Timer tm(ctx);
   Pipe P;
+  // the library's own permutation indices depend on nothing in the call: generated on the side stream, beside the eigen-decomposition
+  // (the multi-kernel panel form, n > 256, consumes them; ev_m orders them in front of the panels)
+  ctx->perm_ready = false;
+  bool perm_side = false;
+  if (!dperm_idx && nperms > 0 && n > 256 && n <= 65535) {
+    hipStream_t main_stream = ctx->stream;
+    BLMM_HIP(hipEventRecord(ctx->ev_xt, main_stream));
+    BLMM_HIP(hipStreamWaitEvent(ctx->side, ctx->ev_xt, 0));
+    ctx->stream = ctx->side;
+    rc = launch_perm_gen(ctx, (int)n, nperms, seed);
+    ctx->stream = main_stream;
+    if (rc) return rc;
+    BLMM_HIP(hipEventRecord(ctx->ev_m, ctx->side));
+    perm_side = true;
+  }
   const bool own_rot = f32_rotation_route(ctx, opts, dCovar, ncov, nperms, p, dLperms32_out != nullptr);
-  if ((rc = prepare(ctx, opts, dy, n, 1, dG, p, dCovar, ncov, dK, dweights, 1, P, tm, false, false, /*skip_markers*/ own_rot))) return rc;
+  rc = prepare(ctx, opts, dy, n, 1, dG, p, dCovar, ncov, dK, dweights, 1, P, tm, false, false, /*skip_markers*/ own_rot);
+  if (perm_side) BLMM_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_m, 0));      // (also on the error path: the side stream joins the call)
+  if (rc) { ctx->perm_ready = false; return rc; }
   return perms_pipeline(ctx, opts, P, tm, nperms, seed, dperm_idx, dscalars_out, dlod_out, dLperms_out, dLperms32_out, status, own_rot ? dG : nullptr);
 }
 
@@ -1607,6 +1624,7 @@ int blmm_scan_perms_prerotated_dev(blmm_ctx* ctx, const blmm_opts* opts, const d
   BLMM_HIP(hipMemsetAsync(P.stat + 8, 0, sizeof(int64_t) * (NSTAT - 8), ctx->stream));
   ctx->audit_ran = false;
   ctx->brent_cnt_used = false;
+  ctx->perm_ready = false;
   tm.mark(); tm.mark();
   if ((rc = rotate_traits(ctx, P, dy, 1))) return rc;
   if ((rc = assemble_prerotated(ctx, P, p, dXt_blocks, nblocks, block_cols, block_ld))) return rc;

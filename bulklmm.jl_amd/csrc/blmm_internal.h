@@ -116,6 +116,7 @@ struct blmm_ctx {
   // reduce-in-epilogue kernels stood, 2 = through a resident L (no fused instantiation, or a trait needed a re-scan)
   blmm::RedArgs red_cur; int last_reduced_route = 0;
   blmm::Tuning tune;                   // blmm_set_tuning
+  bool perm_ready = false; int perm_ready_n = 0; int64_t perm_ready_nperms = 0; uint64_t perm_ready_seed = 0;   // launch_perm_gen -> launch_perm_panel
   int64_t lr_last_ldq = 0, lr_last_m = 0;   // panel-region width / trait count of the last low-rank null-exact scan (blmm_lowrank_columns)
   blmm::Pipe prep; bool prep_valid = false;   // state left by blmm_prepare_dev for blmm_rotate_block_dev / blmm_bulkscan_prerotated_dev
   bool brent_cnt_used = false;         // the current call has run a split h2 search already (its counter in the status block is spent)
@@ -230,6 +231,7 @@ int launch_colmax(blmm_ctx* ctx, const double* L, int64_t p, int64_t m, int64_t 
 // kernels_post.hip
 int launch_lod2log10p(blmm_ctx* ctx, const double* dL, int64_t p, int64_t m, int64_t ldL, int df, double* dP, int64_t ldP);
 // permutation panel: column b = sqrt(w) .* P_w( pi_b(r0) ) / ||r0||  etc.  (see kernels_prep.hip)
+int launch_perm_gen(blmm_ctx* ctx, int n, int64_t nperms, uint64_t seed);   // the library's own permutation indices into ctx->perm, ahead of launch_perm_panel
 int launch_perm_panel(blmm_ctx* ctx, const NullModel& nm, const double* Yt, int64_t ldy, const double* Z0,
                       const double* lam, const double* h2, const int32_t* perm_idx, int64_t nperms, uint64_t seed,
                       int orig, double* panel, int64_t ldp, int64_t* stat);

@@ -2707,11 +2707,33 @@ __global__ void __launch_bounds__(256) k_perm_fill(NullModel nm, const double* _
   }
 }
 
+// The library's own permutations (Fisher-Yates from the splitmix64 counter stream of `seed`) depend on nothing but (n, nperms,
+// seed): the permutation test starts this on the side stream at the head of the call, beside the eigen-decomposition (0.38 ms at
+// n = 1000, 1250 permutations, a few latency-bound workgroups; k_sytrd leaves 150 CUs idle meanwhile); launch_perm_panel then
+// finds the indices in ctx->perm (ctx->perm_ready) instead of generating them on the critical path.
+int launch_perm_gen(blmm_ctx* ctx, int n, int64_t nperms, uint64_t seed) {
+  if (nperms <= 0 || n > 65535) return BLMM_OK;
+  int rc = ensure(ctx, ctx->perm, sizeof(int32_t) * (size_t)n * (size_t)(nperms + 1));
+  if (rc) return rc;
+  int cols = (int)std::min<size_t>(64, (150 * 1024) / (sizeof(unsigned short) * (size_t)n));
+  if (cols < 1) cols = 1;
+  const size_t lds = sizeof(unsigned short) * (size_t)n * cols;
+  BLMM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_perm_gen), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(k_perm_gen, dim3((unsigned)((nperms + cols - 1) / cols)), dim3(64), lds, ctx->stream, n, nperms, seed, cols, ptr<int32_t>(ctx->perm));
+  KCHECK();
+  ctx->perm_ready_n = n; ctx->perm_ready_nperms = nperms; ctx->perm_ready_seed = seed; ctx->perm_ready = true;
+  return BLMM_OK;
+}
+
 int launch_perm_panel(blmm_ctx* ctx, const NullModel& nm, const double* Yt, int64_t ldy, const double* Z0,
                       const double* lam, const double* h2, const int32_t* perm_idx, int64_t nperms, uint64_t seed,
                       int orig, double* panel, int64_t ldp, int64_t* stat) {
   int rc = ensure(ctx, ctx->r0, sizeof(double) * (size_t)nm.n);
   if (rc) return rc;
+  // indices generated ahead of this call (launch_perm_gen, ordered in front of this stream position by the caller)
+  const bool pregen = !perm_idx && !orig && ctx->perm_ready && ctx->perm_ready_n == nm.n && ctx->perm_ready_nperms == nperms &&
+                      ctx->perm_ready_seed == seed;
+  if (!orig) ctx->perm_ready = false;
   int32_t* permbuf = nullptr;
   if (!perm_idx && !orig) {
     rc = ensure(ctx, ctx->perm, sizeof(int32_t) * (size_t)nm.n * (size_t)(nperms + 1));
@@ -2724,7 +2746,8 @@ int launch_perm_panel(blmm_ctx* ctx, const NullModel& nm, const double* Yt, int6
     if (nm.n > 65535) return fail(ctx, BLMM_ERR_UNSUPPORTED, "permutation test: n > 65535");
     const int64_t ncols = orig ? 1 : nperms;
     const int32_t* pidx = perm_idx;
-    if (!orig && !perm_idx && nperms > 0) {
+    if (pregen) pidx = permbuf;
+    else if (!orig && !perm_idx && nperms > 0) {
       int cols = (int)std::min<size_t>(64, (150 * 1024) / (sizeof(unsigned short) * (size_t)nm.n));
       if (cols < 1) cols = 1;
       const size_t lds = sizeof(unsigned short) * (size_t)nm.n * cols;
@@ -2744,7 +2767,8 @@ int launch_perm_panel(blmm_ctx* ctx, const NullModel& nm, const double* Yt, int6
     if (rc) return rc;
     double* coef = ptr<double>(ctx->tmpB);
     const int32_t* pidx = perm_idx;
-    if (!orig && !perm_idx && nperms > 0) {
+    if (pregen) pidx = permbuf;
+    else if (!orig && !perm_idx && nperms > 0) {
       int cols = (int)std::min<size_t>(64, (150 * 1024) / (sizeof(unsigned short) * (size_t)nm.n));
       if (cols < 1) cols = 1;
       const size_t lds = sizeof(unsigned short) * (size_t)nm.n * cols;

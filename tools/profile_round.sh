@@ -14,8 +14,8 @@ done
 echo "== default bench"; python3 bench.py > $OUT/bench.json 2> $OUT/bench.err || { tail -5 $OUT/bench.err; exit 1; }
 echo "== the step without the matrix (blmm_bulkscan_reduced_dev), and socket power with / without the L stores"
 python3 bench.py --reduced --no-cpu-baseline > $OUT/bench_reduced.json 2> $OUT/bench_reduced.err || tail -3 $OUT/bench_reduced.err
-STEPS=4000 bash tools/power_probe.sh $OUT/power_null_exact.log || true
-STEPS=4000 bash tools/power_probe.sh $OUT/power_null_exact_reduced.log --reduced || true
+bash tools/power_probe.sh $OUT/power_null_exact.log || true
+bash tools/power_probe.sh $OUT/power_null_exact_reduced.log --reduced || true
 prof() {  # tag, kernel regex, bench args...
   local tag=$1 kre=$2; shift 2
   echo "== $tag: kernel trace"
