@@ -92,7 +92,7 @@ struct blmm_ctx {
   std::string err;
   // grow-only workspace
   blmm::DevBuf Ks, V, lam, U, Zs, Z0, Rp, Yt, Xt, panels, iyy, h2, h2idx, sig2, ell, isx, stat, gridd, misc, EllTab,
-      inY, inG, inK, inCov, inW, outL, outH2, tmpA, tmpB, tmpC, perm, r0, altbuf, logtab, lraw, wbQ, wbW, wbRk, lrT, lrC, lrL, lrFlag, lrPart, lrPerm, lrDen0, eigW, xf32, pf32, brSt, brList, illList, qrSlab, lodtab, dynFac, pvtab, outP, redbuf, redtrip, altC, rf32;
+      inY, inG, inK, inCov, inW, outL, outH2, tmpA, tmpB, tmpC, perm, r0, altbuf, logtab, lraw, wbQ, wbW, wbRk, lrT, lrC, lrL, lrFlag, lrPart, lrPerm, lrDen0, eigW, xf32, pf32, brSt, brList, illList, qrSlab, lodtab, dynFac, pvtab, outP, redbuf, redtrip, altC, rf32, btG;
   // event sets: one per timed call since the last blmm_read_timings (grown on demand, reused afterwards)
   struct EvSet { hipEvent_t e[8]; int n; };
   std::vector<EvSet> evsets;

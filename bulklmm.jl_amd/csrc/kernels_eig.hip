@@ -60,6 +60,28 @@ __device__ __forceinline__ double wprod(double x) {
   x *= dpp_mov<0xB1>(x); x *= dpp_mov<0x4E>(x); x *= dpp_mov<0x141>(x); x *= dpp_mov<0x140>(x);
   return (lane_bcast(x, 0) * lane_bcast(x, 16)) * (lane_bcast(x, 32) * lane_bcast(x, 48));
 }
+// Four wave-wide sums for the price of (about) two: the first two butterfly stages fold the four values into ONE per lane (lane l
+// then carries the quad's partial sum of d_(l & 3)), two row rotations and the gfx950 row / half-wave swaps finish all four at
+// once -- 45 instructions against 4 x 23 of four wsum()s.  Every lane returns all four totals.
+__device__ __forceinline__ double swap_rows_sum(double x, bool half) {      // x + (x of the partner row / partner half-wave)
+  typedef unsigned v2u __attribute__((ext_vector_type(2)));
+  const unsigned lo = (unsigned)__double2loint(x), hi = (unsigned)__double2hiint(x);
+  const v2u a = half ? __builtin_amdgcn_permlane32_swap(lo, lo, false, false) : __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+  const v2u b = half ? __builtin_amdgcn_permlane32_swap(hi, hi, false, false) : __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+  return __hiloint2double((int)b.x, (int)a.x) + __hiloint2double((int)b.y, (int)a.y);
+}
+__device__ __forceinline__ void wsum4(double& d0, double& d1, double& d2, double& d3) {
+  const int lane = threadIdx.x & 63;
+  const bool b0 = lane & 1, b1 = lane & 2;
+  const double x01 = (b0 ? d1 : d0) + dpp_mov<0xB1>(b0 ? d0 : d1);     // even lanes: d0 over the pair, odd lanes: d1
+  const double x23 = (b0 ? d3 : d2) + dpp_mov<0xB1>(b0 ? d2 : d3);     //             d2                       d3
+  double x = (b1 ? x23 : x01) + dpp_mov<0x4E>(b1 ? x01 : x23);         // lane l: d_(l & 3) over its quad
+  x += dpp_mov<0x124>(x);                                              // row_ror:4
+  x += dpp_mov<0x128>(x);                                              // row_ror:8 -> over its row of 16
+  x = swap_rows_sum(x, false);                                         // rows 0+1, 2+3
+  x = swap_rows_sum(x, true);                                          // both half-waves
+  d0 = lane_bcast(x, 0); d1 = lane_bcast(x, 1); d2 = lane_bcast(x, 2); d3 = lane_bcast(x, 3);
+}
 // 1/sqrt(h) from v_rsq_f64 (good to ~5e-8) and two Newton steps (~1 ulp), for h > 0: the QL rotations take one of these
 // instead of an IEEE sqrt followed by an IEEE division (~400 dependent cycles)
 __device__ __forceinline__ double fast_rsqrt(double h) {
@@ -333,15 +355,44 @@ __global__ void __launch_bounds__(512) k_sytrd(const double* __restrict__ A, int
   if (g == (n - 1) % G && t == 0) d[n - 1] = Al[(size_t)((n - 1) / G) * n + (n - 1)] - 2.0 * svp[n - 1] * swp[n - 1];
 }
 
+// Inner products of the reflectors of one group of the back-transformation (BT_RB = 4 reflectors applied together, section 4):
+// group grp = reflectors k_b = n - 3 - 4 grp - b (b = 0 .. 3, the order they are applied in); G[8 grp + ..] = v_k1'v_k0, v_k2'v_k0,
+// v_k2'v_k1, v_k3'v_k0, v_k3'v_k1, v_k3'v_k2.  One wave per group, spare workgroups of k_tql_leaves / k_eigf_pairs (they need only
+// the reflectors, which are complete when those kernels start): off the critical path, no launch of their own.
+constexpr int BT_RB = 4;
+__device__ __forceinline__ void bt_gram_wave(const double* __restrict__ V, int n, int grp, double* __restrict__ G) {
+  const int lane = threadIdx.x & 63, nref = n - 2;
+  int k[BT_RB];
+#pragma unroll
+  for (int b = 0; b < BT_RB; ++b) k[b] = nref - 1 - BT_RB * grp - b;
+  double c[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+  for (int j = lane; j < n; j += 64) {
+    double v[BT_RB];
+#pragma unroll
+    for (int b = 0; b < BT_RB; ++b) v[b] = (k[b] >= 0 && j > k[b]) ? V[(size_t)k[b] * n + j] : 0.0;
+    c[0] = fma(v[1], v[0], c[0]); c[1] = fma(v[2], v[0], c[1]); c[2] = fma(v[2], v[1], c[2]);
+    c[3] = fma(v[3], v[0], c[3]); c[4] = fma(v[3], v[1], c[4]); c[5] = fma(v[3], v[2], c[5]);
+  }
+#pragma unroll
+  for (int i = 0; i < 6; ++i) c[i] = wsum(c[i]);
+  if (lane == 0) {
+#pragma unroll
+    for (int i = 0; i < 6; ++i) G[(size_t)8 * grp + i] = c[i];
+  }
+}
+__host__ __device__ inline int bt_groups(int n) { return (n - 2 + BT_RB - 1) / BT_RB; }
+
 // ---------------------------------------------------------------------------------------------------------------------
 // 2. leaves: implicit QL with eigenvectors (EISPACK tql2) on T[lo:hi, lo:hi] with the rank-one corrections of the splits
 // taken off its two end diagonals; one wave per leaf, lane r owns row r of Z.
 // ---------------------------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(64) k_tql_leaves(const double* __restrict__ d, const double* __restrict__ e, int n,
                                                    const int* __restrict__ bounds, double* __restrict__ lam,
-                                                   double* __restrict__ Q, int64_t* stat, double* __restrict__ tnorm_out) {
+                                                   double* __restrict__ Q, int64_t* stat, double* __restrict__ tnorm_out,
+                                                   int nleaves, const double* __restrict__ V, double* __restrict__ G) {
   __shared__ double sd[LEAF + 1], se[LEAF + 1], Z[LEAF][LEAF + 1];
   __shared__ int sidx[LEAF];
+  if ((int)blockIdx.x >= nleaves) { bt_gram_wave(V, n, (int)blockIdx.x - nleaves, G); return; }   // (see bt_gram_wave)
   const int lo = bounds[blockIdx.x], hi = bounds[blockIdx.x + 1], N = hi - lo, r = threadIdx.x;
   if (r < N) {
     double dv = d[lo + r];
@@ -836,51 +887,139 @@ __device__ __forceinline__ void eigf_note(int64_t* stat, double v, double bound)
 
 // ---------------------------------------------------------------------------------------------------------------------
 // 4. back-transformation U = H_0 H_1 ... H_(n-3) Z: reflectors applied in reverse order, each wave owns CPW columns of Z
-// in registers (rows lane, lane + 64, ...); the reflector of a step is staged in LDS for the workgroup.
+// in registers (rows lane, lane + 64, ...); the reflectors are staged in LDS for the workgroup, BT_RB = 4 at a time.
+//
+// The four reflectors of a group are applied TOGETHER (the compact WY form written out for four): with d_b = v_b'z taken from the
+// column as it stands BEFORE the group,
+//   s_0 = tau_0 d_0,   s_b = tau_b (d_b - sum_(a < b) s_a v_b'v_a),   z <- z - sum_b s_b v_b
+// is H_3 H_2 H_1 H_0 z exactly; the four dot products and their wave reductions are independent chains that overlap, where the
+// one-at-a-time form of rounds 2-3 ran LDS read -> NR dependent FMAs -> reduction -> update four times in sequence.  The inner
+// products v_b'v_a come from bt_gram_wave.
+//
+// NO conditional memory access in the loops: every `(r < n) ? load : 0` of the earlier form became its own basic block (exec-mask
+// branch, s_waitcnt at the join) -- 60+ of them per group at n = 1000.  Reflectors are staged at a padded length LDR = 64 NR with
+// zeros beyond n (and at j <= k), global loads take a clamped index and a select, Z's LDS copy carries 128 doubles of padding.
 // ---------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int div_small(int e, int n, float rn) {      // e / n for 0 <= e < 2^22, n <= 2048, rn = 1.0f / n
+  int q = (int)((float)e * rn);
+  q -= (q * n > e);
+  q += ((q + 1) * n <= e);
+  return q;
+}
+// LDS bytes of k_backtransform<NR, ..>: plain (the multi-workgroup solver), with the orthogonality check (n <= 124), and with
+// everything staged (check + all reflectors, tau, inner products: where it fits)
+__host__ __device__ inline size_t bt_lds_plain(int NR) { return sizeof(double) * 2 * ((size_t)BT_RB * 64 * NR + 16); }
+__host__ __device__ inline size_t bt_lds_chk(int NR, int n) { return bt_lds_plain(NR) + sizeof(double) * ((size_t)n * (n | 1) + 128); }
+__host__ __device__ inline size_t bt_lds_staged(int NR, int n) {
+  return sizeof(double) * ((size_t)n * (n | 1) + 128 + (size_t)BT_RB * bt_groups(n) * 64 * NR + 16 * (size_t)bt_groups(n));
+}
+
 template <int NR, int CPW, int NT>
-__global__ void __launch_bounds__(NT) k_backtransform(const double* __restrict__ V, const double* __restrict__ tau, int n,
-                                                       double* __restrict__ Z, const double* __restrict__ Zc_chk,
-                                                       int64_t* __restrict__ stat_chk) {
-  extern __shared__ __attribute__((aligned(16))) double sh[];   // 2 x n : double-buffered reflector
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwave = blockDim.x >> 6;
+__global__ void __launch_bounds__(NT) k_backtransform(const double* __restrict__ V, const double* __restrict__ tau,
+                                                       const double* __restrict__ G, int n, double* __restrict__ Z, const double* __restrict__ Zc_chk,
+                                                       int64_t* __restrict__ stat_chk, int stage_v) {
+  extern __shared__ __attribute__((aligned(16))) double sh[];
+  constexpr int RB = BT_RB, LDR = 64 * NR;
+  constexpr size_t BUF = (size_t)RB * LDR + 16;     // one group: RB padded reflectors, then tau_0..3 and the six inner products
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwave = NT >> 6;
   const int c0 = (blockIdx.x * nwave + wave) * CPW;
+  const int nref = n - 2, ngrp = (nref + RB - 1) / RB;
+  const bool staged = NR == 2 && Zc_chk && stage_v;  // (uniform over the grid)
+  // LDS map.  plain: [2 BUF].  check: [2 BUF][Zs].  staged: [Zs][Vs: RB ngrp rows of LDR][Ts: 16 per group]
+  double* Zs = sh + (staged ? 0 : 2 * BUF);
+  const int lz = n | 1;                              // odd column stride: lane <-> column reads spread over the banks
+  double* Vs = Zs + (size_t)n * lz + 128;
+  double* Ts = Vs + (size_t)RB * ngrp * LDR;
+  double z[CPW][NR];
+#ifdef EIGF_PROF      // tools/eigf_prof.sh: cycles of the phases (first and last workgroup, wave 0)
+  long long bpf[6] = {0, 0, 0, 0, 0, 0}, bpt0 = __builtin_amdgcn_s_memtime();
+#define BPSTAMP(i) do { const long long t1__ = __builtin_amdgcn_s_memtime(); bpf[i] += t1__ - bpt0; bpt0 = t1__; } while (0)
+#else
+#define BPSTAMP(i) do { } while (0)
+#endif
   // Behind k_eigf_pairs (NR = 2, CPW = 1, n <= 128): the whole uncorrected Z (Zc_chk, column-major, written by workgroups on
   // every XCD: a dependent chain of reads from it would pay the cross-XCD round trip each time -- 52 us for this kernel, 35 with
   // the staging) is copied into LDS with one batch of loads.  Row a of E = Z'Z - I first -- its largest entry / 3e-8 ->
   // stat[ST_EIG_BAD] --, then the symmetric first-order correction z_a <- z_a - (1/2) sum_b E_ab z_b: every workgroup corrects
   // from the same uncorrected Z, together Z (I - E / 2), orthogonal to ~|E|^2.  On kinships |E| is ~4e-14 and the correction only
   // takes the vectors from there to rounding level; it is what lets near-repeated eigenvalues through (|E| up to 3e-8).
-  double z[CPW][NR];
   if (Zc_chk) {
-    double* Zs = sh + 2 * (4 * (size_t)n + 4);        // behind the two reflector buffers; odd column stride: lane <-> column reads
-    const int lz = n | 1;                             // spread over the banks (n = 64 with stride 64: one bank for all lanes)
-    for (int e = threadIdx.x; e < n * n; e += NT) { const int cb = e / n; Zs[cb * lz + (e - cb * n)] = Zc_chk[e]; }
-    __syncthreads();
-    const int a = c0;
-    double e0 = 0.0, e1 = 0.0, z0 = 0.0, z1 = 0.0;
-    if (a < n) {
-      double acc0 = 0.0, acc1 = 0.0;
-      const double* za = Zs + (size_t)a * lz;
-      const double* zb0 = Zs + (size_t)((lane < n) ? lane : 0) * lz;
-      const double* zb1 = Zs + (size_t)((lane + 64 < n) ? lane + 64 : 0) * lz;
-      for (int i = 0; i < n; ++i) { const double v = za[i]; acc0 = fma(v, zb0[i], acc0); acc1 = fma(v, zb1[i], acc1); }
-      e0 = (lane < n) ? acc0 - ((lane == a) ? 1.0 : 0.0) : 0.0;
-      e1 = (lane + 64 < n) ? acc1 - ((lane + 64 == a) ? 1.0 : 0.0) : 0.0;
-      double bad = fmax(fabs(e0), fabs(e1));
-      if (!(e0 == e0) || !(e1 == e1)) bad = INFINITY;
-      bad = wmax(bad);
-      if (lane == 0) eigf_note(stat_chk, bad, 3e-8);
-      z0 = (lane < n) ? za[lane] : 0.0; z1 = (lane + 64 < n) ? za[lane + 64] : 0.0;
-      double c0v = 0.0, c1v = 0.0;
-      for (int b = 0; b < n; ++b) {
-        const double eab = lane_bcast((b < 64) ? e0 : e1, b & 63);     // (b is wave-uniform)
-        const double* zb = Zs + (size_t)b * lz;
-        c0v = fma(eab, (lane < n) ? zb[lane] : 0.0, c0v);
-        c1v = fma(eab, (lane + 64 < n) ? zb[lane + 64] : 0.0, c1v);
+    // Loads in batches of 16 per thread: Zc_chk and V were written by workgroups on other XCDs, a load costs 1-2 us, and batches of
+    // four (the unrolled loop of the earlier form) paid that 15 times: 13 of this kernel's 34 us at n = 79.
+    const int nn = n * n;
+    const float rn = 1.0f / (float)n;
+    const int zpad = (n - 1) * lz + n;                 // 128 doubles of padding behind the last column (zeroed)
+    const int ziters = (nn + 128 + NT - 1) / NT;
+    constexpr int SB = 16;                             // loads in flight per thread (a fully unrolled copy -- 61 + 44 loads -- spent
+                                                       // more time fetching its straight-line code, cold on every launch, than it saved)
+    for (int it0 = 0; it0 < ziters; it0 += SB) {
+      double rg[SB];
+#pragma unroll
+      for (int u = 0; u < SB; ++u) { const int e = threadIdx.x + NT * (it0 + u); rg[u] = Zc_chk[(e < nn) ? e : 0]; }
+#pragma unroll
+      for (int u = 0; u < SB; ++u) {
+        const int e = threadIdx.x + NT * (it0 + u), ee = (e < nn) ? e : 0;
+        const int cb = div_small(ee, n, rn);
+        Zs[(e < nn) ? cb * lz + (ee - cb * n) : zpad + min(e - nn, 127)] = (e < nn) ? rg[u] : 0.0;      // (past the end: zeros into the padding)
       }
-      z0 = fma(-0.5, c0v, z0); z1 = fma(-0.5, c1v, z1);
     }
+    // staged (the launcher: it fits, n <= 90): ALL reflectors (row RB g + b = reflector n - 3 - RB g - b, zero rows past the first
+    // reflector), their tau and the groups' inner products go to LDS as well -- the group loop below then touches neither global
+    // memory (a group of four two-register reflectors is shorter than the L2 round trip of its successor's prefetch) nor a barrier.
+    // (Issuing these loads ahead of the check and the correction, which need only Z, and storing them afterwards measured no
+    // better: the copy is bound by the misses a CU can keep in flight against ~1.5 us of cross-XCD latency, not by their order.)
+    if (staged) {
+      const int vtot = RB * ngrp * LDR;                // (a multiple of NT)
+      for (int e0 = 0; e0 < vtot; e0 += NT * SB) {
+        double rg[SB];
+#pragma unroll
+        for (int u = 0; u < SB; ++u) {
+          const int e = e0 + threadIdx.x + NT * u;
+          const int i = e / LDR, r = e - i * LDR, kk = nref - 1 - i;
+          rg[u] = V[(e < vtot && kk >= 0 && r > kk && r < n) ? (size_t)kk * n + r : 0];
+        }
+#pragma unroll
+        for (int u = 0; u < SB; ++u) {
+          const int e = e0 + threadIdx.x + NT * u;
+          const int i = e / LDR, r = e - i * LDR, kk = nref - 1 - i;
+          if (e < vtot) Vs[e] = (kk >= 0 && r > kk && r < n) ? rg[u] : 0.0;
+        }
+      }
+      for (int e = threadIdx.x; e < 16 * ngrp; e += NT) {
+        const int gg = e >> 4, i = e & 15, kk = nref - 1 - RB * gg - i;
+        const bool isT = i < RB && kk >= 0, isG = i >= RB && i < RB + 6;
+        const double tv = tau[isT ? kk : 0], gv = G[isG ? (size_t)8 * gg + (i - RB) : 0];
+        Ts[e] = isT ? tv : (isG ? gv : 0.0);
+      }
+    }
+    __syncthreads();
+    BPSTAMP(0);
+    const int a = (c0 < n) ? c0 : n - 1;               // (a wave past the last column works on a copy of it and stores nothing)
+    const double* za = Zs + (size_t)a * lz;
+    const double* zb0 = Zs + (size_t)((lane < n) ? lane : 0) * lz;
+    const double* zb1 = Zs + (size_t)((lane + 64 < n) ? lane + 64 : 0) * lz;
+    double acc0 = 0.0, acc1 = 0.0;
+#pragma unroll 4
+    for (int i = 0; i < n; ++i) { const double v = za[i]; acc0 = fma(v, zb0[i], acc0); acc1 = fma(v, zb1[i], acc1); }
+    const double e0 = (lane < n) ? acc0 - ((lane == a) ? 1.0 : 0.0) : 0.0;
+    const double e1 = (lane + 64 < n) ? acc1 - ((lane + 64 == a) ? 1.0 : 0.0) : 0.0;
+    double bad = fmax(fabs(e0), fabs(e1));
+    if (!(e0 == e0) || !(e1 == e1)) bad = INFINITY;
+    bad = wmax(bad);
+    if (lane == 0 && c0 < n) eigf_note(stat_chk, bad, 3e-8);
+    BPSTAMP(1);
+    double c0v = 0.0, c1v = 0.0;
+    auto corr = [&](int b) {
+      const double eab = lane_bcast((b < 64) ? e0 : e1, b & 63);     // (b is wave-uniform)
+      const double* zb = Zs + (size_t)b * lz;
+      c0v = fma(eab, zb[lane], c0v);                                 // (lanes past n read the next column / the padding; masked below)
+      c1v = fma(eab, zb[lane + 64], c1v);
+    };
+    int b4 = 0;                                                      // (unrolled by hand: v_readlane is convergent, the optimizer
+    for (; b4 + 4 <= n; b4 += 4) { corr(b4); corr(b4 + 1); corr(b4 + 2); corr(b4 + 3); }   //  will not unroll a run-time trip count around it)
+    for (; b4 < n; ++b4) corr(b4);
+    const double z0 = (lane < n) ? fma(-0.5, c0v, za[lane]) : 0.0;
+    const double z1 = (lane + 64 < n) ? fma(-0.5, c1v, za[lane + 64]) : 0.0;
     z[0][0] = z0;
     if constexpr (NR > 1) z[0][1] = z1;
   } else {
@@ -889,65 +1028,104 @@ __global__ void __launch_bounds__(NT) k_backtransform(const double* __restrict__
 #pragma unroll
       for (int q = 0; q < NR; ++q) {
         const int r = lane + 64 * q;
-        z[c][q] = (c0 + c < n && r < n) ? Z[(size_t)(c0 + c) * n + r] : 0.0;
+        const bool ok = c0 + c < n && r < n;
+        const double val = Z[ok ? (size_t)(c0 + c) * n + r : 0];
+        z[c][q] = ok ? val : 0.0;
       }
   }
-  const int nref = n - 2;
-  // Reflectors are handled in groups of RB per barrier.  Group g = reflectors k = nref-1-RB*g ... (descending); a group is
-  // read from global memory two iterations before its use (into registers) and written to LDS one iteration before, so
-  // neither the L2 round trip nor the LDS write sits between two barriers.  LDS: 2 buffers x RB x n.
-  constexpr int RB = 4;
-  constexpr int PF = (NR * 64 + NT - 1) / NT;     // elements per thread of one reflector (NT threads)
+  BPSTAMP(2);
+  // Streamed form (not staged): group g = reflectors k = nref-1-RB*g ... (descending) is read from global memory two iterations
+  // before its use (into registers) and written to LDS one iteration before, so neither the L2 round trip nor the LDS write sits
+  // between two barriers.  One barrier per group.
+  constexpr int PF = (LDR + NT - 1) / NT;         // elements per thread of one padded reflector
   double pre[RB][PF];
-  double pret = 0.0;              // tau of reflector threadIdx.x of the group (threads < RB): staged with the vectors, a
-                                  // scalar load of tau[k] next to its use put an L2 round trip into every reflector's chain
-  const size_t bufsz = (size_t)RB * n + RB;
+  double pret = 0.0;              // threads 0 .. 9 (of every 16): tau_b / inner product of the group, staged with the vectors (a
+                                  // scalar load of tau[k] next to its use put an L2 round trip into every reflector's chain)
   auto fetch = [&](int grp) {
 #pragma unroll
     for (int b = 0; b < RB; ++b) {
       const int k = nref - 1 - RB * grp - b;
 #pragma unroll
-      for (int u = 0; u < PF; ++u) { const int j = threadIdx.x + NT * u; pre[b][u] = (k >= 0 && j > k && j < n) ? V[(size_t)k * n + j] : 0.0; }
+      for (int u = 0; u < PF; ++u) {
+        const int j = threadIdx.x + NT * u;
+        const bool ok = k >= 0 && j > k && j < n;
+        const double val = V[ok ? (size_t)k * n + j : 0];
+        pre[b][u] = ok ? val : 0.0;
+      }
     }
-    if (threadIdx.x < RB) { const int k = nref - 1 - RB * grp - (int)threadIdx.x; pret = (k >= 0) ? tau[k] : 0.0; }
+    const int i = threadIdx.x & 15, kk = nref - 1 - RB * grp - i;
+    const bool isT = i < RB && kk >= 0, isG = i >= RB && i < RB + 6 && RB * grp < nref;
+    const double tv = tau[isT ? kk : 0], gv = G[isG ? (size_t)8 * grp + (i - RB) : 0];
+    pret = isT ? tv : (isG ? gv : 0.0);
   };
   auto stash = [&](double* dst) {
 #pragma unroll
     for (int b = 0; b < RB; ++b)
 #pragma unroll
-      for (int u = 0; u < PF; ++u) { const int j = threadIdx.x + NT * u; if (j < n) dst[(size_t)b * n + j] = pre[b][u]; }
-    if (threadIdx.x < RB) dst[(size_t)RB * n + threadIdx.x] = pret;
+      for (int u = 0; u < PF; ++u) { const int j = threadIdx.x + NT * u; if (LDR % NT == 0 || j < LDR) dst[(size_t)b * LDR + j] = pre[b][u]; }
+    if (threadIdx.x < 16) dst[(size_t)RB * LDR + threadIdx.x] = pret;
   };
-  const int ngrp = (nref + RB - 1) / RB;
-  fetch(0); stash(sh);
-  fetch(1);
-  __syncthreads();
-  for (int grp = 0; grp < ngrp; ++grp) {
-    const double* vb = sh + (size_t)(grp & 1) * bufsz;
-    double* vn = sh + (size_t)((grp + 1) & 1) * bufsz;
-    stash(vn);            // group grp+1 (fetched during the previous iteration)
-    fetch(grp + 2);       // lands during this iteration and the next
-#pragma unroll
-    for (int b = 0; b < RB; ++b) {
-      const int k = nref - 1 - RB * grp - b;
-      if (k < 0) break;
-      const double* v = vb + (size_t)b * n;
-      const double tk = vb[(size_t)RB * n + b];
-      double vr[NR];
-#pragma unroll
-      for (int q = 0; q < NR; ++q) { const int r = lane + 64 * q; vr[q] = (r > k && r < n) ? v[r] : 0.0; }
-#pragma unroll
-      for (int c = 0; c < CPW; ++c) {
-        double dot = 0.0;
-#pragma unroll
-        for (int q = 0; q < NR; ++q) dot = fma(vr[q], z[c][q], dot);
-        dot = wsum(dot) * tk;
-#pragma unroll
-        for (int q = 0; q < NR; ++q) z[c][q] = fma(-dot, vr[q], z[c][q]);
-      }
-    }
+  if (!staged) {
+    fetch(0); stash(sh);
+    fetch(1);
     __syncthreads();
   }
+  double vr[RB][NR], tgr[10];                        // the group's reflectors (zero past n, and whole zero rows past the first
+                                                     // reflector, tau = 0: no special case), tau_0..3, v_1'v_0, v_2'v_0, v_2'v_1, v_3'v_0, v_3'v_1, v_3'v_2
+  auto load_group = [&](const double* vb, const double* tg, double (&v)[RB][NR], double (&t)[10]) {
+#pragma unroll
+    for (int b = 0; b < RB; ++b)
+#pragma unroll
+      for (int q = 0; q < NR; ++q) v[b][q] = vb[(size_t)b * LDR + lane + 64 * q];
+#pragma unroll
+    for (int i = 0; i < 10; ++i) t[i] = tg[i];
+  };
+  if (staged) load_group(Vs, Ts, vr, tgr);
+  for (int grp = 0; grp < ngrp; ++grp) {
+    if (!staged) {
+      const double* vb = sh + (size_t)(grp & 1) * BUF;
+      stash(sh + (size_t)((grp + 1) & 1) * BUF);      // group grp+1 (fetched during the previous iteration)
+      fetch(grp + 2);                                 // lands during this iteration and the next
+      load_group(vb, vb + (size_t)RB * LDR, vr, tgr);
+    }
+    double vn[(NR == 2) ? RB : 1][NR], tn[10];        // staged: the next group's operands are read while this one is applied
+    if constexpr (NR == 2) {
+      if (staged) { const int gn = min(grp + 1, ngrp - 1); load_group(Vs + (size_t)gn * RB * LDR, Ts + 16 * gn, vn, tn); }
+    }
+    const double t0 = tgr[0], t1 = tgr[1], t2 = tgr[2], t3 = tgr[3];
+    const double c10 = tgr[4], c20 = tgr[5], c21 = tgr[6], c30 = tgr[7], c31 = tgr[8], c32 = tgr[9];
+#pragma unroll
+    for (int c = 0; c < CPW; ++c) {
+      double d[RB];
+#pragma unroll
+      for (int b = 0; b < RB; ++b) {
+        double a0 = 0.0, a1 = 0.0;
+#pragma unroll
+        for (int q = 0; q < NR; q += 2) { a0 = fma(vr[b][q], z[c][q], a0); if (q + 1 < NR) a1 = fma(vr[b][q + 1], z[c][q + 1], a1); }
+        d[b] = a0 + a1;
+      }
+      wsum4(d[0], d[1], d[2], d[3]);
+      const double s0 = t0 * d[0];
+      const double s1 = t1 * fma(-s0, c10, d[1]);
+      const double s2 = t2 * fma(-s1, c21, fma(-s0, c20, d[2]));
+      const double s3 = t3 * fma(-s2, c32, fma(-s1, c31, fma(-s0, c30, d[3])));
+#pragma unroll
+      for (int q = 0; q < NR; ++q)
+        z[c][q] = fma(-s3, vr[3][q], fma(-s2, vr[2][q], fma(-s1, vr[1][q], fma(-s0, vr[0][q], z[c][q]))));
+    }
+    if constexpr (NR == 2) {
+      if (staged) {
+#pragma unroll
+        for (int b = 0; b < RB; ++b)
+#pragma unroll
+          for (int q = 0; q < NR; ++q) vr[b][q] = vn[b][q];
+#pragma unroll
+        for (int i = 0; i < 10; ++i) tgr[i] = tn[i];
+      }
+    }
+    if (!staged) __syncthreads();
+  }
+  BPSTAMP(3);
 #pragma unroll
   for (int c = 0; c < CPW; ++c)
 #pragma unroll
@@ -955,6 +1133,12 @@ __global__ void __launch_bounds__(NT) k_backtransform(const double* __restrict__
       const int r = lane + 64 * q;
       if (c0 + c < n && r < n) Z[(size_t)(c0 + c) * n + r] = z[c][q];
     }
+  BPSTAMP(4);
+#ifdef EIGF_PROF
+  if (threadIdx.x == 0 && (blockIdx.x == 0 || blockIdx.x == gridDim.x - 1))
+    printf("backtransform prof wg %d n %d staged %d: stage %lld | check %lld | correct %lld | %d groups %lld | store %lld cycles\n", (int)blockIdx.x, n, (int)staged,
+           bpf[0], bpf[1], bpf[2], ngrp, bpf[3], bpf[4]);
+#endif
 }
 
 
@@ -1197,12 +1381,17 @@ __global__ void __launch_bounds__(1024) k_eigf_reduce(const double* __restrict__
 
 template <int NT>
 __global__ void __launch_bounds__(NT) k_eigf_pairs(int n, const double* __restrict__ wsb, double* __restrict__ lam_out,
-                                                    int64_t* stat) {
+                                                    int64_t* stat, const double* __restrict__ Vg, double* __restrict__ G) {
   __shared__ double sd[128], se[128], sds[128], ses2[128], sDp[128], sDm[128];
   __shared__ double s_red[8];
   __shared__ int s_cnt[2][NT / 64];
   __shared__ int s_r;
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6, k = blockIdx.x;
+  if (k >= n) {                                        // spare workgroups: the back-transformation's group inner products (bt_gram_wave)
+    const int grp = (k - n) * (NT / 64) + wave;
+    if (grp < bt_groups(n)) bt_gram_wave(Vg, n, grp, G);
+    return;
+  }
   const EigfWs g = eigf_ws(const_cast<double*>(wsb), n);
   if (t < n) { sd[t] = g.d[t]; se[t] = g.e[t]; sds[t] = g.ds[t]; ses2[t] = g.es2[t]; }
   const double tn = g.par[0], bscale = g.par[1];
@@ -1335,11 +1524,15 @@ int launch_eig_fast(blmm_ctx* ctx, const double* A, int n, double* lraw, double*
   KCHECK();
   // (256 threads: 512 / 1024 per workgroup -- more points per round, fewer rounds -- measured 0.265 / 0.286 ms of eigen phase against
   // 0.256: the waves sharing a SIMD slow each other's dependent chains)
-  hipLaunchKernelGGL(k_eigf_pairs<256>, dim3(n), dim3(256), 0, ctx->stream, n, (const double*)wsb, lraw, stat);
+  if ((rc = ensure(ctx, ctx->btG, sizeof(double) * 8 * (size_t)bt_groups(n)))) return rc;
+  double* btG = ptr<double>(ctx->btG);
+  hipLaunchKernelGGL(k_eigf_pairs<256>, dim3(n + (bt_groups(n) + 3) / 4), dim3(256), 0, ctx->stream, n, (const double*)wsb, lraw, stat, (const double*)Vg, btG);
   KCHECK();
-  const size_t lds_bt = sizeof(double) * ((size_t)2 * (4 * n + 4) + (size_t)n * (n | 1));   // reflector buffers + the staged Z
+  static const bool bt_stage_off = dev_env("BLMM_BT_STAGE") && dev_env("BLMM_BT_STAGE")[0] == '0';
+  const int stage_v = (bt_lds_staged(2, n) <= 158 * 1024 && !bt_stage_off) ? 1 : 0;
+  const size_t lds_bt = stage_v ? bt_lds_staged(2, n) : bt_lds_chk(2, n);
   BLMM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_backtransform<2, 1, 256>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bt));
-  hipLaunchKernelGGL((k_backtransform<2, 1, 256>), dim3((n + 3) / 4), dim3(256), lds_bt, ctx->stream, Vg, g.tau, n, evec, (const double*)g.Zc, stat);
+  hipLaunchKernelGGL((k_backtransform<2, 1, 256>), dim3((n + 3) / 4), dim3(256), lds_bt, ctx->stream, Vg, g.tau, (const double*)btG, n, evec, (const double*)g.Zc, stat, stage_v);
   KCHECK();
   ctx->eig_plan_n = -1;    // the workspace was reused: a cached merge tree of the multi-workgroup solver is gone
   return BLMM_OK;
@@ -1449,7 +1642,10 @@ int launch_eig_dc(blmm_ctx* ctx, const double* A, int n, double* lraw, double* e
   // a node reads the full square [lo, hi)^2 of its input Q: the blocks off the solved halves' diagonal must read as zero
   // (block-diagonal eigenvector matrix); both ping-pong buffers, because every level leaves such blocks unwritten
   BLMM_HIP(hipMemsetAsync(Qa, 0, sizeof(double) * 2 * nn, ctx->stream));
-  hipLaunchKernelGGL(k_tql_leaves, dim3(nl), dim3(64), 0, ctx->stream, d, e, n, bounds_dev, lamA, Qa, stat, rho + nnodes_total);   // |T| -> the spare doubles behind rho
+  if ((rc = ensure(ctx, ctx->btG, sizeof(double) * 8 * (size_t)bt_groups(n)))) return rc;
+  double* btG = ptr<double>(ctx->btG);
+  hipLaunchKernelGGL(k_tql_leaves, dim3(nl + bt_groups(n)), dim3(64), 0, ctx->stream, d, e, n, bounds_dev, lamA, Qa, stat, rho + nnodes_total,   // |T| -> the spare doubles behind rho
+                     nl, (const double*)V, btG);
   KCHECK();
   // ---- 3. merges ----
   DcWs w;
@@ -1494,22 +1690,28 @@ int launch_eig_dc(blmm_ctx* ctx, const double* A, int n, double* lraw, double* e
   }
   // ---- 4. back-transformation (in place on the final Q), results out ----
   {
-    const size_t lds = sizeof(double) * (size_t)2 * (4 * n + 4);     // 2 buffers x (RB = 4 reflectors + their tau)
     const int nr = (n + 63) / 64;
     static const bool bt_wide = dev_env("BLMM_BT_WIDE") && dev_env("BLMM_BT_WIDE")[0] == '1';
+    static const bool bt_cpw2 = dev_env("BLMM_BT_CPW") && dev_env("BLMM_BT_CPW")[0] == '2';
 #define BT(NR)                                                                                                             \
   do {                                                                                                                     \
     /* one column per wave, four waves per workgroup: the kernel is VALU-issue bound per SIMD (~110 instructions per        \
        reflector and column), so the columns are spread over as many CUs as there are (n = 500: 125 workgroups instead of   \
        32 of eight two-column waves: 302 -> 228 us; n = 200: 95 -> 59; n = 1000: 721 -> 739; BLMM_BT_WIDE=1: the old shape) */  \
     constexpr int CPWW = (NR <= 8) ? 2 : 1;                                                                                \
-    if (bt_wide) {                                                                                                         \
+    const size_t lds = bt_lds_plain(NR);                                                                                   \
+    if (bt_wide && NR <= 16) {             /* (beyond: four reflectors x NR registers do not fit two waves per SIMD) */        \
+      constexpr int NRW = (NR <= 16) ? NR : 16;                                                                            \
       const int cols_per_wg = 8 * CPWW;                                                                                    \
-      if (lds > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_backtransform<NR, CPWW, 512>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-      hipLaunchKernelGGL((k_backtransform<NR, CPWW, 512>), dim3((n + cols_per_wg - 1) / cols_per_wg), dim3(512), lds, ctx->stream, V, tau, n, Qin, (const double*)nullptr, (int64_t*)nullptr); \
+      if (lds > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_backtransform<NRW, CPWW, 512>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+      hipLaunchKernelGGL((k_backtransform<NRW, CPWW, 512>), dim3((n + cols_per_wg - 1) / cols_per_wg), dim3(512), lds, ctx->stream, V, tau, (const double*)btG, n, Qin, (const double*)nullptr, (int64_t*)nullptr, 0); \
+    } else if (bt_cpw2 && NR <= 16) {      /* two columns per wave, 8 per workgroup: half the LDS reads and L2 fetches per column */ \
+      constexpr int NRW = (NR <= 16) ? NR : 16;                                                                            \
+      if (lds > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_backtransform<NRW, 2, 256>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+      hipLaunchKernelGGL((k_backtransform<NRW, 2, 256>), dim3((n + 7) / 8), dim3(256), lds, ctx->stream, V, tau, (const double*)btG, n, Qin, (const double*)nullptr, (int64_t*)nullptr, 0);   \
     } else {                                                                                                               \
       if (lds > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_backtransform<NR, 1, 256>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-      hipLaunchKernelGGL((k_backtransform<NR, 1, 256>), dim3((n + 3) / 4), dim3(256), lds, ctx->stream, V, tau, n, Qin, (const double*)nullptr, (int64_t*)nullptr);   \
+      hipLaunchKernelGGL((k_backtransform<NR, 1, 256>), dim3((n + 3) / 4), dim3(256), lds, ctx->stream, V, tau, (const double*)btG, n, Qin, (const double*)nullptr, (int64_t*)nullptr, 0);   \
     }                                                                                                                      \
   } while (0)
     if (nr <= 2) BT(2); else if (nr <= 4) BT(4); else if (nr <= 8) BT(8); else if (nr <= 16) BT(16); else if (nr <= 24) BT(24); else BT(32);

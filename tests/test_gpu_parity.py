@@ -24,7 +24,11 @@ def check_null_exact(got, Y, G, K, Cov=None, **kw):
     side with its OWN h2 estimate -- the north-star bound 1e-6 relative is asserted for every trait whose two estimates agree
     to 1e-8 (Brent stops at x_tol = sqrt(eps) |x| + eps on a likelihood that is flat to rounding over ~1e-7 around its
     maximum: two correct searches agree on h2 only to ~1e-7, and d LOD / d h2 is O(LOD)); the other traits get the
-    reference's own criterion sum d^2 <= 1e-7 (test/bulkscan_test.jl:77-78) and 1e-4."""
+    reference's own criterion sum d^2 <= 1e-7 (test/bulkscan_test.jl:77-78) and 1e-4.
+    The absolute term of that 1e-8 class: LOD = -(n/2) log10(1 - r^2), so |d LOD| ~ (n / ln 10) |r| |dr| with |dr| up to O(1) |dh2|;
+    at n = 300, LOD 3.5e-4 (r = 2.3e-3) and |dh2| = 1e-8 that is 3e-9 -- observed 1.4e-9 on such an entry when the
+    back-transformation's rounding changed (round 4) and both searches moved by a few 1e-9.  Hence 5e-9 n / 300 here; the bound proper,
+    1e-6 |ref| + 1e-10, is the `pinned` comparison below, where both sides use the SAME h2."""
     ref = O.bulkscan_null(Y, G, K, Covar=Cov, **kw)
     dh = np.abs(got.h2_null_list - ref.h2_null_list)
     assert dh.max() <= 1e-6
@@ -32,7 +36,7 @@ def check_null_exact(got, Y, G, K, Cov=None, **kw):
     assert_lod_close(got.L, ref.L, rtol=1e-4, atol=1e-8, what="LOD (own h2 each side)")
     close = dh <= 1e-8
     if close.any():
-        assert_lod_close(got.L[:, close], ref.L[:, close], rtol=1e-6, atol=1e-9, what="LOD (own h2 each side, |dh2| <= 1e-8)")
+        assert_lod_close(got.L[:, close], ref.L[:, close], rtol=1e-6, atol=max(1e-9, 5e-9 * Y.shape[0] / 300.0), what="LOD (own h2 each side, |dh2| <= 1e-8)")
     pinned = O.bulkscan_null(Y, G, K, Covar=Cov, h2_override=got.h2_null_list, **kw)
     assert_lod_close(got.L, pinned.L, what="LOD (oracle at the GPU h2)")
 
