@@ -1205,9 +1205,12 @@ __device__ void small_sytrd(const SmallWs& w, const double* __restrict__ A, int 
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
         const int j = lane + 64 * h;
-        double p = 0.0;
-        if (j > k && j < n) { for (int rs = 0; rs < 8; ++rs) p += w.part[rs * 128 + j]; p *= tk; }
-        pj[h] = p; vj[h] = (j > k && j < n) ? w.sv[j] : 0.0;
+        // (columns outside (k, n) were summed as zeros by the pass: no branch around the eight reads; pairwise sums)
+        const double q0 = w.part[j], q1 = w.part[128 + j], q2 = w.part[256 + j], q3 = w.part[384 + j];
+        const double q4 = w.part[512 + j], q5 = w.part[640 + j], q6 = w.part[768 + j], q7 = w.part[896 + j];
+        const double svj = w.sv[(j < n) ? j : 0];
+        const double p = tk * (((q0 + q1) + (q2 + q3)) + ((q4 + q5) + (q6 + q7)));
+        pj[h] = p; vj[h] = (j > k && j < n) ? svj : 0.0;
         pv = fma(p, vj[h], pv);
       }
       pv = wsum(pv);
@@ -1222,14 +1225,17 @@ __device__ void small_sytrd(const SmallWs& w, const double* __restrict__ A, int 
       // serves the last step): no LDS round trip, one reciprocal square root and one reciprocal instead of an IEEE square root
       // and two IEEE divisions on the critical path of every step (149 -> 141 us at n = 79)
       double akk = 0.0, xj[2] = {0.0, 0.0};
+      double arow[2];
+#pragma unroll
+      for (int h = 0; h < 2; ++h) { const int j = lane + 64 * h; arow[h] = w.M1[(k + 1) * n + ((j < n) ? j : 0)]; }   // (loads first, no branch)
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
         const int j = lane + 64 * h;
-        if (j > k && j < n) {
-          w.svp[j] = vj[h]; w.swp[j] = wj[h];
-          const double a = w.M1[(k + 1) * n + j];
-          if (j == k + 1) akk = a - 2.0 * wk1; else { xj[h] = a - wj[h] - wk1 * vj[h]; w.sx[j] = xj[h]; }
-        }
+        const bool in = j > k && j < n;
+        const double a = arow[h];
+        akk = (in && j == k + 1) ? a - 2.0 * wk1 : akk;
+        xj[h] = (in && j != k + 1) ? a - wj[h] - wk1 * vj[h] : 0.0;
+        if (in) { w.svp[j] = vj[h]; w.swp[j] = wj[h]; if (j != k + 1) w.sx[j] = xj[h]; }
       }
       akk = lane_bcast(akk, (k + 1) & 63);   // held by the lane that owns j = k+1 ... in half h = (k+1) >> 6
       if (k + 3 < n) {
