@@ -1148,103 +1148,127 @@ __global__ void __launch_bounds__(NT) k_backtransform(const double* __restrict__
 // same workgroup with QL leaves, the merge tree and the back-transformation (`k_eig_small`: 0.89 ms, slower than the Jacobi);
 // round 3 keeps only the reduction and hands T to the parallel fast path of section 6.
 // ---------------------------------------------------------------------------------------------------------------------
-struct SmallWs {   // LDS carve-up of the reduction (doubles); M2 optional (zeroed when given)
+struct SmallWs {   // LDS carve-up of the reduction (doubles); M2 optional (zeroed when given); svp / swp: two parities of n each
   double *M1, *M2, *sx, *sv, *svp, *swp, *part, *d, *e, *tau, *red;
 };
 
 // Householder tridiagonalisation of the n x n matrix A inside ONE workgroup of 1024 threads (n <= 128; k_eigf_reduce): A is
 // copied to w.M1 (LDS, full symmetric storage), on return w.d / w.e / w.tau hold the diagonal, the
-// off-diagonal and the reflector scalars of T = H' A H and Vg[k * n + j] the reflector vectors (v[k + 1] = 1).  Column form of the
-// matrix-vector product (thread (j, rs) sums A[i][j] v[i] over its row subset: no cross-lane reduction), the rank-2 update of the
-// previous step applied in the same pass; wave 0 does the O(n) vector work of a step while the others wait: two barriers per step.
+// off-diagonal and the reflector scalars of T = H' A H and Vg[k * n + j] the reflector vectors (v[k + 1] = 1).
+//
+// A step is two phases with one barrier behind each (round 4; rounds 2-3 applied the rank-2 update inside the product pass -- five
+// LDS operations per element on the critical path -- and left fifteen waves idle during wave 0's vector work):
+//   pass  all 16 waves: y_j = sum_(i > k) M1[i][j] v_k[i], column form (thread (j, rs) sums its row subset: no cross-lane
+//         reduction), M1 carrying the updates of the steps <= k-2 only: two LDS operations per element.
+//   B     wave 0: p = tau (y - v_(k-1) (w_(k-1)'v_k) - w_(k-1) (v_(k-1)'v_k)) -- the pending pair's correction, as in k_sytrd --,
+//         w_k, row k+1 with the pending update applied by hand, the next column and its reflector v_(k+1), the two inner
+//         products the next correction needs (one wsum4 with |x|^2); v_(k-1), w_(k-1), v_k, tau live in its registers.
+//         waves 1-15 MEANWHILE: the rank-2 update of step k-1 on rows and columns >= k+2 (the pair is read from the parity
+//         buffer wave 0 wrote a step ago; wave 0 writes this step's pair to the other one): off the critical path.
 __device__ void small_sytrd(const SmallWs& w, const double* __restrict__ A, int n, double* __restrict__ Vg, double* s_sc) {
   const int t = threadIdx.x, NT = blockDim.x, lane = t & 63, wave = t >> 6;
   double amax = 0.0;
   for (int e0 = t; e0 < n * n; e0 += NT) { const double a = A[e0]; w.M1[e0] = a; if (w.M2) w.M2[e0] = 0.0; amax = fmax(amax, fabs(a)); }
-  for (int j = t; j < n; j += NT) { w.svp[j] = 0.0; w.swp[j] = 0.0; }
+  for (int j = t; j < 2 * n; j += NT) { w.svp[j] = 0.0; w.swp[j] = 0.0; }
   amax = block_max(amax, w.red);                 // (two barriers inside)
   const double s1_negl = (EPS * amax) * (EPS * amax);   // see k_sytrd: no reflector for a column negligible against |A|
   __syncthreads();
-  // ---- 1. tridiagonalisation ----------------------------------------------------------------------------------------
-  // wave 0 prepares step 0: x = column 0, its Householder vector
-  auto householder = [&](int k, double akk) {   // wave 0: from sx[k+1 ..] -> sv, s_sc; reflector k -> Vg
+  // wave 0's state across the steps (lane <-> index j = lane + 64 h): v_k, the pending pair (v_(k-1), w_(k-1)), tau_k and the two
+  // inner products of the pending pair with v_k
+  double vcur[2] = {0.0, 0.0}, vprv[2] = {0.0, 0.0}, wprv[2] = {0.0, 0.0}, tkc = 0.0, wpvc = 0.0, vpvc = 0.0;
+  if (wave == 0) {
+    // step 0: x = column 0 (= row 0), its Householder vector
+    for (int j = lane; j < n; j += 64) w.sx[j] = (j >= 1) ? w.M1[j] : 0.0;
     double s1 = 0.0;
-    for (int j = k + 2 + lane; j < n; j += 64) s1 = fma(w.sx[j], w.sx[j], s1);
+    for (int j = 2 + lane; j < n; j += 64) s1 = fma(w.sx[j], w.sx[j], s1);
     s1 = wsum(s1);
-    const double alpha = w.sx[k + 1];
+    const double alpha = w.sx[1];
     double beta, tk, sc;
     if (s1 <= s1_negl) { beta = alpha; tk = 0.0; sc = 0.0; }
     else { beta = -copysign(sqrt(fma(alpha, alpha, s1)), alpha); tk = (beta - alpha) / beta; sc = 1.0 / (alpha - beta); }
-    for (int j = k + 1 + lane; j < n; j += 64) { const double v = (j == k + 1) ? 1.0 : w.sx[j] * sc; w.sv[j] = v; Vg[k * n + j] = v; }
-    if (lane == 0) { w.d[k] = akk; w.e[k] = beta; w.tau[k] = tk; s_sc[0] = tk; }
-  };
-  if (wave == 0) {
-    for (int j = lane; j < n; j += 64) w.sx[j] = (j >= 1) ? w.M1[j] : 0.0;     // row 0 = column 0
-    householder(0, w.M1[0]);
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int j = lane + 64 * h;
+      const double v = (j == 1) ? 1.0 : ((j > 1 && j < n) ? w.sx[j] * sc : 0.0);
+      vcur[h] = v;
+      if (j >= 1 && j < n) { w.sv[j] = v; Vg[j] = v; }
+    }
+    if (lane == 0) { w.d[0] = w.M1[0]; w.e[0] = beta; w.tau[0] = tk; s_sc[0] = tk; }
+    tkc = tk;
   }
   __syncthreads();
+#ifdef EIGF_PROF      // tools/eigf_prof.sh: cycles per step of the phases, threads 0 (wave 0) and 64 (wave 1)
+  long long spf[4] = {0, 0, 0, 0}, spt0 = __builtin_amdgcn_s_memtime();
+#define SPSTAMP(i) do { const long long t1__ = __builtin_amdgcn_s_memtime(); spf[i] += t1__ - spt0; spt0 = t1__; } while (0)
+#else
+#define SPSTAMP(i) do { } while (0)
+#endif
   for (int k = 0; k + 2 < n; ++k) {
-    // pass over the trailing matrix: apply the pending update (step k-1), accumulate column sums of A v (rows split 8 ways)
+    // ---- pass: y = M1 v_k over the rows and columns > k ----
     {
       const int j = t & 127, rs = t >> 7;
       double acc = 0.0;
-      if (j > k && j < n) {
-        const double vpj = w.svp[j], wpj = w.swp[j];
-        for (int i = k + 1 + rs; i < n; i += 8) {
-          double a = w.M1[i * n + j];
-          if (k > 0) { a = fma(-w.svp[i], wpj, fma(-w.swp[i], vpj, a)); w.M1[i * n + j] = a; }
-          acc = fma(a, w.sv[i], acc);
-        }
-      }
-      if (j < 128) w.part[rs * 128 + j] = acc;
+      if (j > k && j < n)
+        for (int i = k + 1 + rs; i < n; i += 8) acc = fma(w.M1[i * n + j], w.sv[i], acc);
+      w.part[rs * 128 + j] = acc;
     }
+    SPSTAMP(0);
     __syncthreads();
+    SPSTAMP(1);
     if (wave == 0) {
-      const double tk = s_sc[0];
-      double pj[2], vj[2], pv = 0.0;
+      __builtin_amdgcn_s_setprio(3);        // the step's critical path; the three waves that share its SIMD only run the update
+      const double tk = tkc;
+      double arow[2], pj[2], vj[2], pv = 0.0;
+#pragma unroll
+      for (int h = 0; h < 2; ++h) { const int j = lane + 64 * h; arow[h] = w.M1[(k + 1) * n + ((j < n) ? j : 0)]; }   // (loads first, no branch)
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
         const int j = lane + 64 * h;
         // (columns outside (k, n) were summed as zeros by the pass: no branch around the eight reads; pairwise sums)
         const double q0 = w.part[j], q1 = w.part[128 + j], q2 = w.part[256 + j], q3 = w.part[384 + j];
         const double q4 = w.part[512 + j], q5 = w.part[640 + j], q6 = w.part[768 + j], q7 = w.part[896 + j];
-        const double svj = w.sv[(j < n) ? j : 0];
-        const double p = tk * (((q0 + q1) + (q2 + q3)) + ((q4 + q5) + (q6 + q7)));
-        pj[h] = p; vj[h] = (j > k && j < n) ? svj : 0.0;
+        const double y = ((q0 + q1) + (q2 + q3)) + ((q4 + q5) + (q6 + q7));
+        const bool in = j > k && j < n;
+        const double p = in ? tk * fma(-wprv[h], vpvc, fma(-vprv[h], wpvc, y)) : 0.0;
+        pj[h] = p; vj[h] = in ? vcur[h] : 0.0;
         pv = fma(p, vj[h], pv);
       }
       pv = wsum(pv);
       const double cw = 0.5 * tk * pv;
-      // w, the pending pair for the next pass, and the next column x = A[k+1][:] - w - w[k+1] v  (row k+1 of M1 already
-      // carries every update but this step's; v[k+1] = 1)
       double wj[2];
 #pragma unroll
       for (int h = 0; h < 2; ++h) { wj[h] = fma(-cw, vj[h], pj[h]); }
-      const double wk1 = lane_bcast(wj[(k + 1) >> 6], (k + 1) & 63);
-      // the next column x (rows k+2 ..) stays in registers for its reflector (lane <-> row as everywhere in this wave; sx only
-      // serves the last step): no LDS round trip, one reciprocal square root and one reciprocal instead of an IEEE square root
-      // and two IEEE divisions on the critical path of every step (149 -> 141 us at n = 79)
-      double akk = 0.0, xj[2] = {0.0, 0.0};
-      double arow[2];
-#pragma unroll
-      for (int h = 0; h < 2; ++h) { const int j = lane + 64 * h; arow[h] = w.M1[(k + 1) * n + ((j < n) ? j : 0)]; }   // (loads first, no branch)
+      const int hk1 = (k + 1) >> 6, lk1 = (k + 1) & 63;
+      const double wk1 = lane_bcast(wj[hk1], lk1);
+      const double vpk1 = lane_bcast(vprv[hk1], lk1), wpk1 = lane_bcast(wprv[hk1], lk1);
+      // row k+1: the pending update (step k-1) by hand, then this step's; the next column x (rows k+2 ..) stays in registers for
+      // its reflector: one reciprocal square root and one reciprocal instead of an IEEE square root and two IEEE divisions
+      double akk = 0.0, xj[2];
+      const int par = k & 1;
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
         const int j = lane + 64 * h;
         const bool in = j > k && j < n;
-        const double a = arow[h];
+        const double a = fma(-wpk1, vprv[h], fma(-vpk1, wprv[h], arow[h]));
         akk = (in && j == k + 1) ? a - 2.0 * wk1 : akk;
         xj[h] = (in && j != k + 1) ? a - wj[h] - wk1 * vj[h] : 0.0;
-        if (in) { w.svp[j] = vj[h]; w.swp[j] = wj[h]; if (j != k + 1) w.sx[j] = xj[h]; }
+        if (j < n) { w.svp[par * n + j] = vj[h]; w.swp[par * n + j] = wj[h]; }     // this step's pair: the other waves apply it a step later
       }
-      akk = lane_bcast(akk, (k + 1) & 63);   // held by the lane that owns j = k+1 ... in half h = (k+1) >> 6
+      akk = lane_bcast(akk, lk1);   // held by the lane that owns j = k+1 ... in half (k+1) >> 6
+      // (read here, with every lane active: v_readlane ignores EXEC, and inside the lane-0 region below the compiler is free to
+      //  evaluate xj for lane 0 only -- the last off-diagonal entry came out 0)
+      const double xlast = lane_bcast(xj[(n - 1) >> 6], (n - 1) & 63);
       if (k + 3 < n) {
-        const int k1 = k + 1;
-        const double alpha = lane_bcast(xj[(k1 + 1) >> 6], (k1 + 1) & 63);
-        double s1 = 0.0;
+        const int k1 = k + 1, hk2 = (k1 + 1) >> 6, lk2 = (k1 + 1) & 63;
+        const double alpha = lane_bcast(xj[hk2], lk2);
+        double s1 = 0.0, s2 = 0.0, s3 = 0.0, s4 = 0.0;
 #pragma unroll
-        for (int h = 0; h < 2; ++h) { const int j = lane + 64 * h; if (j > k1 + 1 && j < n) s1 = fma(xj[h], xj[h], s1); }
-        s1 = wsum(s1);
+        for (int h = 0; h < 2; ++h) {
+          const int j = lane + 64 * h;
+          const double xm = (j > k1 + 1) ? xj[h] : 0.0;             // (xj is zero at and beyond n)
+          s1 = fma(xm, xm, s1); s2 = fma(wj[h], xm, s2); s3 = fma(vj[h], xm, s3);
+        }
+        wsum4(s1, s2, s3, s4);
         double beta, tk1, sc;
         if (s1 <= s1_negl) { beta = alpha; tk1 = 0.0; sc = 0.0; }
         else {
@@ -1256,19 +1280,72 @@ __device__ void small_sytrd(const SmallWs& w, const double* __restrict__ A, int 
           y = fma(y, fma(-(fabs(alpha) + nrm), y, 1.0), y);
           sc = copysign(y, alpha);
         }
+        // w_k'v_(k+1) and v_k'v_(k+1) with v_(k+1) = (1 at k+2, sc x beyond)
+        wpvc = fma(sc, s2, lane_bcast(wj[hk2], lk2));
+        vpvc = fma(sc, s3, lane_bcast(vj[hk2], lk2));
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
           const int j = lane + 64 * h;
-          if (j > k1 && j < n) { const double v = (j == k1 + 1) ? 1.0 : xj[h] * sc; w.sv[j] = v; Vg[k1 * n + j] = v; }
+          const double v = (j == k1 + 1) ? 1.0 : ((j > k1 + 1) ? xj[h] * sc : 0.0);
+          vcur[h] = v;
+          if (j > k1 && j < n) { w.sv[j] = v; Vg[k1 * n + j] = v; }
         }
         if (lane == 0) { w.d[k1] = akk; w.e[k1] = beta; w.tau[k1] = tk1; s_sc[0] = tk1; }
+        tkc = tk1;
       } else if (lane == 0) {
-        // the reduction ends: last two diagonal entries and the last off-diagonal one
-        w.d[n - 2] = akk; w.e[n - 2] = w.sx[n - 1];
-        w.d[n - 1] = w.M1[(n - 1) * n + (n - 1)] - 2.0 * w.svp[n - 1] * w.swp[n - 1];
+        // the reduction ends: the last off-diagonal entry and the last but one diagonal entry (d[n-1]: behind the loop)
+        w.d[n - 2] = akk; w.e[n - 2] = xlast;
+      }
+#pragma unroll
+      for (int h = 0; h < 2; ++h) { vprv[h] = vj[h]; wprv[h] = wj[h]; }
+      __builtin_amdgcn_s_setprio(0);
+    } else if (k > 0) {
+      // waves 1 .. 15: the rank-2 update of step k-1 on rows / columns >= k+2 (row k+1 is wave 0's, above; nothing below is read again)
+      const double* vpb = w.svp + ((k - 1) & 1) * n;
+      const double* wpb = w.swp + ((k - 1) & 1) * n;
+      double vpj[2], wpj[2];
+      int jc[2]; bool cin[2];
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int j = lane + 64 * h;
+        cin[h] = j >= k + 2 && j < n; jc[h] = cin[h] ? j : k + 2;
+        vpj[h] = vpb[jc[h]]; wpj[h] = wpb[jc[h]];
+      }
+      const int w1 = __builtin_amdgcn_readfirstlane(wave) - 1;
+      for (int i0 = k + 2 + w1; i0 < n; i0 += 45) {                 // three rows per trip: i0, i0 + 15, i0 + 30
+        double a[3][2], vi[3], wi[3];
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+          const int i = i0 + 15 * r, ic = (i < n) ? i : n - 1;
+          vi[r] = vpb[ic]; wi[r] = wpb[ic];
+#pragma unroll
+          for (int h = 0; h < 2; ++h) a[r][h] = w.M1[ic * n + jc[h]];
+        }
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+          const int i = i0 + 15 * r;
+          if (i < n) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+              if (cin[h]) w.M1[i * n + lane + 64 * h] = fma(-wi[r], vpj[h], fma(-vi[r], wpj[h], a[r][h]));
+          }
+        }
       }
     }
+    SPSTAMP(2);
     __syncthreads();
+    SPSTAMP(3);
+  }
+#ifdef EIGF_PROF
+  if (t == 0 || t == 64)
+    printf("small_sytrd prof thread %d n %d: pass %lld | barrier %lld | %s %lld | barrier %lld cycles/step\n", t, n, spf[0] / (n - 2), spf[1] / (n - 2),
+           t == 0 ? "vector work" : "update", spf[2] / (n - 2), spf[3] / (n - 2));
+#endif
+  // d[n-1]: the last diagonal entry carries the updates <= n-4 (applied above) and, by hand, the final step's
+  if (wave == 0) {
+    const int hl = (n - 1) >> 6, ll = (n - 1) & 63;
+    const double vl = lane_bcast(vprv[hl], ll), wl = lane_bcast(wprv[hl], ll);
+    if (lane == 0) w.d[n - 1] = w.M1[(n - 1) * n + (n - 1)] - 2.0 * vl * wl;
   }
 }
 
@@ -1351,11 +1428,14 @@ __global__ void __launch_bounds__(1024) k_eigf_reduce(const double* __restrict__
   {
     double* q = sh;
     w.M1 = q; q += n * n;
-    w.sx = q; q += n; w.sv = q; q += n; w.svp = q; q += n; w.swp = q; q += n;
+    w.sx = q; q += n; w.sv = q; q += n; w.svp = q; q += 2 * n; w.swp = q; q += 2 * n;
     w.part = q; q += 8 * 128;
     w.d = q; q += n; w.e = q; q += n; w.tau = q; q += n; w.red = q; q += 16;
   }
   small_sytrd(w, A, n, Vg, s_sc);
+#ifdef SMALL_SYTRD_DBG      // tools/dbg_small_sytrd.sh: the tridiagonal matrix as the reduction left it
+  if (t == 0) { for (int j = 0; j < n; ++j) printf("sytrd_dbg n %d j %d d %.17g e %.17g tau %.17g\n", n, j, w.d[j], (j < n - 1) ? w.e[j] : 0.0, (j < n - 2) ? w.tau[j] : 0.0); }
+#endif
   const EigfWs g = eigf_ws(wsb, n);
   if (wave == 0) {
     double tn = 0.0;
@@ -1520,7 +1600,7 @@ int launch_eig_fast(blmm_ctx* ctx, const double* A, int n, double* lraw, double*
   if (n < 3 || n > eig_fast_max_n()) return BLMM_ERR_UNSUPPORTED;
   int rc;
   if ((rc = ensure(ctx, ctx->eigW, sizeof(double) * ((size_t)2 * n * n + (size_t)5 * n + 8) + 256))) return rc;
-  const size_t lds = sizeof(double) * ((size_t)n * n + (size_t)7 * n + 8 * 128 + 16) + 64;
+  const size_t lds = sizeof(double) * ((size_t)n * n + (size_t)9 * n + 8 * 128 + 16) + 64;
   if (lds > 158 * 1024) return BLMM_ERR_UNSUPPORTED;
   double* Vg = ptr<double>(ctx->eigW);
   double* wsb = Vg + (size_t)n * n;
