@@ -826,43 +826,58 @@ __global__ void __launch_bounds__(256) k_dc_wt_copy(DcWs w, int nw) {
 typedef double d4v __attribute__((ext_vector_type(4)));
 template <int MB, int NB>
 __global__ void __launch_bounds__(256) k_dc_gemm(DcWs w, int tiles_r) {
+  __shared__ int s_col[2048];                                      // the node's column list (K <= n <= 2048)
   const int node = blockIdx.x, lo = w.nodes[3 * node], hi = w.nodes[3 * node + 2], n = w.n;
   const int K = w.info[4 * node];
   const int tile_i = blockIdx.y / tiles_r, tile_r = blockIdx.y % tiles_r;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int i0 = tile_i * (32 * MB) + (wave >> 1) * (16 * MB);     // roots
   const int r0 = lo + tile_r * (32 * NB) + (wave & 1) * (16 * NB); // rows of Q
-  if (tile_i * (32 * MB) >= K || lo + tile_r * (32 * NB) >= hi) return;
+  if (tile_i * (32 * MB) >= K || lo + tile_r * (32 * NB) >= hi) return;     // (uniform over the workgroup)
   const int c16 = lane & 15, g = lane >> 4;
+  // The K loop had two DEPENDENT global round trips per step of 16 -- the column index, then the column of Q it names -- each
+  // inside its own `(k < K) ? load : 0` branch: ~1.5 us per step against 0.2 us of MFMAs (30 us per level at n = 1000).  Now the
+  // column list sits in LDS, every load takes a clamped address (the W operand is zeroed past K, rows / roots past the edge are
+  // computed on a copy and not stored), and the operands of steps it+2 / it+3 are in flight while step it / it+1 multiply.
+  for (int k = threadIdx.x; k < K; k += 256) s_col[k] = w.colidx[lo + k];
+  __syncthreads();
   d4v acc[MB][NB];
 #pragma unroll
   for (int a = 0; a < MB; ++a)
 #pragma unroll
     for (int b = 0; b < NB; ++b) acc[a][b] = (d4v){0, 0, 0, 0};
-  for (int k0 = 0; k0 < K; k0 += 16) {
-    double av[MB][4], bv[NB][4];
-    int col[4];
+  const double* wr[MB];
+  const double* qr[NB];
 #pragma unroll
-    for (int s = 0; s < 4; ++s) { const int k = k0 + 4 * g + s; col[s] = (k < K) ? w.colidx[lo + k] : -1; }
+  for (int a = 0; a < MB; ++a) { const int i = i0 + 16 * a + c16; wr[a] = w.Wt + (size_t)(lo + (i < K ? i : K - 1)) * n + lo; }
 #pragma unroll
-    for (int a = 0; a < MB; ++a) {
-      const int i = i0 + 16 * a + c16;
-      const double* wr = w.Wt + (size_t)(lo + (i < K ? i : 0)) * n + lo;
+  for (int b = 0; b < NB; ++b) { const int r = r0 + 16 * b + c16; qr[b] = w.Qin + (r < hi ? r : hi - 1); }
+  auto load = [&](int it, double (&av)[MB][4], double (&bv)[NB][4]) {
 #pragma unroll
-      for (int s = 0; s < 4; ++s) { const int k = k0 + 4 * g + s; av[a][s] = (i < K && k < K) ? wr[k] : 0.0; }
+    for (int s = 0; s < 4; ++s) {
+      const int k = 16 * it + 4 * g + s, kc = (k < K) ? k : K - 1;
+      const int col = s_col[kc];
+#pragma unroll
+      for (int a = 0; a < MB; ++a) { const double x = wr[a][kc]; av[a][s] = (k < K) ? x : 0.0; }
+#pragma unroll
+      for (int b = 0; b < NB; ++b) bv[b][s] = qr[b][(size_t)col * n];
     }
-#pragma unroll
-    for (int b = 0; b < NB; ++b) {
-      const int r = r0 + 16 * b + c16;
-#pragma unroll
-      for (int s = 0; s < 4; ++s) bv[b][s] = (col[s] >= 0 && r < hi) ? w.Qin[(size_t)col[s] * n + r] : 0.0;
-    }
+  };
+  auto mult = [&](const double (&av)[MB][4], const double (&bv)[NB][4]) {
 #pragma unroll
     for (int s = 0; s < 4; ++s)
 #pragma unroll
       for (int a = 0; a < MB; ++a)
 #pragma unroll
         for (int b = 0; b < NB; ++b) acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[a][s], bv[b][s], acc[a][b], 0, 0, 0);
+  };
+  const int KT = (K + 15) >> 4;
+  double a0[MB][4], b0[NB][4], a1[MB][4], b1[NB][4];
+  load(0, a0, b0);
+  load(1, a1, b1);                                                  // (a step past the end loads valid addresses and multiplies zeros)
+  for (int it = 0; it < KT; it += 2) {
+    mult(a0, b0); load(it + 2, a0, b0);
+    mult(a1, b1); load(it + 3, a1, b1);
   }
 #pragma unroll
   for (int a = 0; a < MB; ++a)
