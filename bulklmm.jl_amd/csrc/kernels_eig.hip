@@ -826,7 +826,7 @@ __global__ void __launch_bounds__(256) k_dc_wt_copy(DcWs w, int nw) {
 typedef double d4v __attribute__((ext_vector_type(4)));
 template <int MB, int NB>
 __global__ void __launch_bounds__(256) k_dc_gemm(DcWs w, int tiles_r) {
-  __shared__ int s_col[2048];                                      // the node's column list (K <= n <= 2048)
+  __shared__ __attribute__((aligned(16))) int s_col[2048];         // the node's column list (K <= n <= 2048)
   const int node = blockIdx.x, lo = w.nodes[3 * node], hi = w.nodes[3 * node + 2], n = w.n;
   const int K = w.info[4 * node];
   const int tile_i = blockIdx.y / tiles_r, tile_r = blockIdx.y % tiles_r;
@@ -852,15 +852,32 @@ __global__ void __launch_bounds__(256) k_dc_gemm(DcWs w, int tiles_r) {
   for (int a = 0; a < MB; ++a) { const int i = i0 + 16 * a + c16; wr[a] = w.Wt + (size_t)(lo + (i < K ? i : K - 1)) * n + lo; }
 #pragma unroll
   for (int b = 0; b < NB; ++b) { const int r = r0 + 16 * b + c16; qr[b] = w.Qin + (r < hi ? r : hi - 1); }
+  struct __attribute__((packed, aligned(8))) D4 { double x[4]; };   // a lane's four consecutive k of W: one 32-byte access
   auto load = [&](int it, double (&av)[MB][4], double (&bv)[NB][4]) {
+    if (16 * it + 16 <= K) {                                          // (uniform) a whole step: no clamps
+      const int kb = 16 * it + 4 * g;
+      const int4 cl = *reinterpret_cast<const int4*>(&s_col[kb]);
+      const int col[4] = {cl.x, cl.y, cl.z, cl.w};
 #pragma unroll
-    for (int s = 0; s < 4; ++s) {
-      const int k = 16 * it + 4 * g + s, kc = (k < K) ? k : K - 1;
-      const int col = s_col[kc];
+      for (int a = 0; a < MB; ++a) {
+        const D4 x = *reinterpret_cast<const D4*>(wr[a] + kb);
 #pragma unroll
-      for (int a = 0; a < MB; ++a) { const double x = wr[a][kc]; av[a][s] = (k < K) ? x : 0.0; }
+        for (int s = 0; s < 4; ++s) av[a][s] = x.x[s];
+      }
 #pragma unroll
-      for (int b = 0; b < NB; ++b) bv[b][s] = qr[b][(size_t)col * n];
+      for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int b = 0; b < NB; ++b) bv[b][s] = qr[b][(size_t)col[s] * n];
+    } else {
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const int k = 16 * it + 4 * g + s, kc = (k < K) ? k : K - 1;
+        const int col = s_col[kc];
+#pragma unroll
+        for (int a = 0; a < MB; ++a) { const double x = wr[a][kc]; av[a][s] = (k < K) ? x : 0.0; }
+#pragma unroll
+        for (int b = 0; b < NB; ++b) bv[b][s] = qr[b][(size_t)col * n];
+      }
     }
   };
   auto mult = [&](const double (&av)[MB][4], const double (&bv)[NB][4]) {
@@ -1770,9 +1787,16 @@ int launch_eig_dc(blmm_ctx* ctx, const double* A, int n, double* lraw, double* e
     hipLaunchKernelGGL(k_dc_secular_rot, dim3(nnode, nq4 + nb256), dim3(256), lds_sec, ctx->stream, w, nq4);
     hipLaunchKernelGGL(k_dc_zhat_fin, dim3(nnode, nq4 + nb256), dim3(256), sizeof(double) * (size_t)Nmax, ctx->stream, w, nq4);
     hipLaunchKernelGGL(k_dc_wt_copy, dim3(nnode, nq4 + nb256 * DC_COPY_Z), dim3(256), 0, ctx->stream, w, nq4);
-    constexpr int MB = 2, NB = 2;
-    const int tiles_i = (Nmax + 32 * MB - 1) / (32 * MB), tiles_r = (Nmax + 32 * NB - 1) / (32 * NB);
-    hipLaunchKernelGGL((k_dc_gemm<MB, NB>), dim3(nnode, tiles_i * tiles_r), dim3(256), 0, ctx->stream, w, tiles_r);
+    {
+      // 64 x 64 tiles per workgroup where they fill the chip, 32 x 32 where they would not (n = 500, top level: 64 workgroups
+      // against 256; BLMM_DC_TILE=1 / 2 forces one: A/B testing)
+      const int t2 = (Nmax + 63) / 64, t1 = (Nmax + 31) / 32;
+      static const int tile_env = dev_env("BLMM_DC_TILE") ? atoi(dev_env("BLMM_DC_TILE")) : 0;
+      const int cus = ctx->num_cus > 0 ? ctx->num_cus : 256;
+      const bool small = tile_env == 1 || (tile_env != 2 && (long)nnode * t2 * t2 < cus);
+      if (small) hipLaunchKernelGGL((k_dc_gemm<1, 1>), dim3(nnode, t1 * t1), dim3(256), 0, ctx->stream, w, t1);
+      else hipLaunchKernelGGL((k_dc_gemm<2, 2>), dim3(nnode, t2 * t2), dim3(256), 0, ctx->stream, w, t2);
+    }
     KCHECK();
 #ifdef SEC_DIAG
     {
