@@ -348,6 +348,89 @@ def main():
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         return float(tmax.item()), ph, nc
 
+    # The end-to-end section (its own context, ~0.5 s of complete host-to-host calls) runs BEFORE the timed loop: a device fresh out
+    # of its idle power state scans ~4 % slower for its first ~50 steps (tools/warmup_sweep.sh: 1.65 ms per step behind 5 warm-up
+    # steps, 1.61 behind 50 or 800; the eigen phase does not move), and `value` is meant to be the rate a long job sees.  The order
+    # is reported in the line (`sections_before_timed_loop`).
+    host_api = None
+    if rank == 0 and world == 1 and not a.no_host_api and not perms and a.streams == 1 and not a.reduced:
+        # SURVEY.md §8(d)'s third time: host inputs -> host L through the drop-in entry point (H2D of Y/G/K, the same
+        # kernels, D2H of L into caller memory); once into a fresh pageable array, once into a pinned (registered) one
+        Lh = np.empty((p, m_local), order="F")
+        Lh[:] = 0.0                                    # touch the pages: the caller's allocation cost is not ours
+        meth = {"null-exact": B._lib.BLMM_NULL_EXACT, "null-grid": B._lib.BLMM_NULL_GRID, "alt-grid": B._lib.BLMM_ALT_GRID}[a.method]
+        hctx = B.Context(dev_index)
+        # column-major inputs, as a Julia caller's Arrays are: the Python mirror would otherwise re-lay out the C-ordered synthetic Y
+        # on every call (np.asfortranarray of 22 MB, ~4 ms of NumPy inside the timed call -- not part of the C ABI's time)
+        Yf_, Gf_, Kf_ = np.asfortranarray(Y), np.asfortranarray(G), np.asfortranarray(K)
+        def host_call(out):
+            t0 = time.perf_counter()
+            B.api.bulkscan_into(hctx, meth, Yf_, Gf_, Kf_, out, h2_grid=grid)
+            return (time.perf_counter() - t0) * 1e3
+        host_call(Lh)
+        t_page = min(host_call(Lh) for _ in range(2))
+        t_pin = None
+        try:
+            B.api.host_register(Lh)
+            host_call(Lh)
+            t_pin = min(host_call(Lh) for _ in range(2))
+            B.api.host_unregister(Lh)
+        except Exception as e:   # noqa: BLE001
+            t_pin = None
+        # ... and what the caller pays when L does not have to cross PCIe (SURVEY.md N1): (a) L_out == NULL -- the matrix stays in
+        # HBM -- followed by the per-trait peaks and the LOD > 5 triplets from the resident matrix; (b) blmm_bulkscan_reduced -- the
+        # same results out of the scan kernels' epilogues, L never written
+        t_keep = t_red = red_route = None
+        n_trip = None
+        same = None
+        if a.method in ("null-exact", "null-grid"):
+            # the C ABI calls themselves, into buffers the caller already has (as for the L_out timings above: the Python mirror's
+            # own allocations and its sort of the triplets are not the library's time)
+            import ctypes as C
+            cap = 1 << 21
+            lib = hctx.lib
+            o = B.api._opts(meth, False, True, "eigen", 1, 1.0, 0.0)
+            gridv = None if grid is None else np.ascontiguousarray(np.asarray(grid, dtype=np.float64))
+            ng = 0 if grid is None else len(grid)
+            pp = lambda x: None if x is None else x.ctypes.data_as(C.c_void_p)   # noqa: E731
+            mxk = np.empty(m_local); axk = np.empty(m_local, dtype=np.int64); h2k = np.empty(m_local)
+            ik = np.empty(cap, dtype=np.int32); jk = np.empty(cap, dtype=np.int32); lk = np.empty(cap); ck = C.c_int64(0)
+            mxr = np.empty(m_local); axr = np.empty(m_local, dtype=np.int64); h2r = np.empty(m_local)
+            ir = np.empty(cap, dtype=np.int32); jr = np.empty(cap, dtype=np.int32); lr_ = np.empty(cap); cr = C.c_int64(0)
+            for arr in (ik, jk, lk, ir, jr, lr_):
+                arr[:] = 0                           # touch the pages
+            def keep_call():
+                t0 = time.perf_counter()
+                hctx.check(lib.blmm_bulkscan(hctx.h, C.byref(o), pp(Yf_), n, m_local, pp(Gf_), p, None, 0, pp(Kf_), None, pp(gridv), ng, None, pp(h2k), None))
+                hctx.check(lib.blmm_last_lod_colmax(hctx.h, pp(mxk), pp(axk)))
+                hctx.check(lib.blmm_last_lod_threshold(hctx.h, 5.0, cap, pp(ik), pp(jk), pp(lk), C.byref(ck)))
+                return (time.perf_counter() - t0) * 1e3
+            red = B._lib.blmm_reduced(mxr.ctypes.data, axr.ctypes.data, 1, 5.0, cap, ir.ctypes.data, jr.ctypes.data, lr_.ctypes.data, C.addressof(cr))
+            def red_call():
+                t0 = time.perf_counter()
+                hctx.check(lib.blmm_bulkscan_reduced(hctx.h, C.byref(o), pp(Yf_), n, m_local, pp(Gf_), p, None, 0, pp(Kf_), None, pp(gridv), ng, C.byref(red), pp(h2r), None))
+                return (time.perf_counter() - t0) * 1e3
+            keep_call()
+            t_keep = min(keep_call() for _ in range(4))
+            red_call()
+            t_red = min(red_call() for _ in range(4))
+            red_route = int(lib.blmm_last_reduced_route(hctx.h))
+            n_trip = int(cr.value)
+            kk, kr = int(ck.value), int(cr.value)
+            ok_ = np.lexsort((ik[:kk], jk[:kk])); or_ = np.lexsort((ir[:kr], jr[:kr]))
+            same = bool(kk == kr and np.array_equal(mxk, mxr) and np.array_equal(axk, axr) and np.array_equal(h2k, h2r)
+                        and np.array_equal(ik[:kk][ok_], ir[:kr][or_]) and np.array_equal(jk[:kk][ok_], jr[:kr][or_])
+                        and np.array_equal(lk[:kk][ok_], lr_[:kr][or_]))
+        host_api = {"end_to_end_ms_pageable_out": t_page, "end_to_end_ms_pinned_out": t_pin,
+                    "end_to_end_ms_keep_on_device": t_keep, "end_to_end_ms_reduced_out": t_red,
+                    "reduced_route": red_route, "reduced_triplets_lod_gt_5": n_trip,
+                    "reduced_equals_keep_on_device": same,
+                    "tests_per_s_end_to_end": p * m_local / ((t_pin or t_page) * 1e-3),
+                    "tests_per_s_end_to_end_reduced_out": (p * m_local / (t_red * 1e-3)) if t_red else None,
+                    "note": "host Y/G/K in; *_out: host L out (2.08 GB over PCIe at BXD size); keep_on_device: L stays in HBM "
+                            "(blmm_bulkscan, L_out == NULL) + per-trait peaks + LOD > 5 triplets from the resident matrix; reduced_out: the "
+                            "same results from the scan epilogues, L never written (blmm_bulkscan_reduced); never `value`"}
+        hctx.close()
     dt, phases, ncalls = timed(work, a.gather, a.steps, a.warmup)
     # The headline workload's h2 = 0 share (about half of the synthetic traits end at the boundary and take the cheaper
     # shared-weights class) is a property of the DATA: one more timed loop with the class switched off (every trait through the
@@ -434,85 +517,6 @@ def main():
                 "m_per_gpu": a.m if other == "weak" else mx}
         del w2
 
-    host_api = None
-    if rank == 0 and world == 1 and not a.no_host_api and not perms and a.streams == 1 and not a.reduced:
-        # SURVEY.md §8(d)'s third time: host inputs -> host L through the drop-in entry point (H2D of Y/G/K, the same
-        # kernels, D2H of L into caller memory); once into a fresh pageable array, once into a pinned (registered) one
-        Lh = np.empty((p, m_local), order="F")
-        Lh[:] = 0.0                                    # touch the pages: the caller's allocation cost is not ours
-        meth = {"null-exact": B._lib.BLMM_NULL_EXACT, "null-grid": B._lib.BLMM_NULL_GRID, "alt-grid": B._lib.BLMM_ALT_GRID}[a.method]
-        hctx = B.Context(dev_index)
-        # column-major inputs, as a Julia caller's Arrays are: the Python mirror would otherwise re-lay out the C-ordered synthetic Y
-        # on every call (np.asfortranarray of 22 MB, ~4 ms of NumPy inside the timed call -- not part of the C ABI's time)
-        Yf_, Gf_, Kf_ = np.asfortranarray(Y), np.asfortranarray(G), np.asfortranarray(K)
-        def host_call(out):
-            t0 = time.perf_counter()
-            B.api.bulkscan_into(hctx, meth, Yf_, Gf_, Kf_, out, h2_grid=grid)
-            return (time.perf_counter() - t0) * 1e3
-        host_call(Lh)
-        t_page = min(host_call(Lh) for _ in range(2))
-        t_pin = None
-        try:
-            B.api.host_register(Lh)
-            host_call(Lh)
-            t_pin = min(host_call(Lh) for _ in range(2))
-            B.api.host_unregister(Lh)
-        except Exception as e:   # noqa: BLE001
-            t_pin = None
-        # ... and what the caller pays when L does not have to cross PCIe (SURVEY.md N1): (a) L_out == NULL -- the matrix stays in
-        # HBM -- followed by the per-trait peaks and the LOD > 5 triplets from the resident matrix; (b) blmm_bulkscan_reduced -- the
-        # same results out of the scan kernels' epilogues, L never written
-        t_keep = t_red = red_route = None
-        n_trip = None
-        same = None
-        if a.method in ("null-exact", "null-grid"):
-            # the C ABI calls themselves, into buffers the caller already has (as for the L_out timings above: the Python mirror's
-            # own allocations and its sort of the triplets are not the library's time)
-            import ctypes as C
-            cap = 1 << 21
-            lib = hctx.lib
-            o = B.api._opts(meth, False, True, "eigen", 1, 1.0, 0.0)
-            gridv = None if grid is None else np.ascontiguousarray(np.asarray(grid, dtype=np.float64))
-            ng = 0 if grid is None else len(grid)
-            pp = lambda x: None if x is None else x.ctypes.data_as(C.c_void_p)   # noqa: E731
-            mxk = np.empty(m_local); axk = np.empty(m_local, dtype=np.int64); h2k = np.empty(m_local)
-            ik = np.empty(cap, dtype=np.int32); jk = np.empty(cap, dtype=np.int32); lk = np.empty(cap); ck = C.c_int64(0)
-            mxr = np.empty(m_local); axr = np.empty(m_local, dtype=np.int64); h2r = np.empty(m_local)
-            ir = np.empty(cap, dtype=np.int32); jr = np.empty(cap, dtype=np.int32); lr_ = np.empty(cap); cr = C.c_int64(0)
-            for arr in (ik, jk, lk, ir, jr, lr_):
-                arr[:] = 0                           # touch the pages
-            def keep_call():
-                t0 = time.perf_counter()
-                hctx.check(lib.blmm_bulkscan(hctx.h, C.byref(o), pp(Yf_), n, m_local, pp(Gf_), p, None, 0, pp(Kf_), None, pp(gridv), ng, None, pp(h2k), None))
-                hctx.check(lib.blmm_last_lod_colmax(hctx.h, pp(mxk), pp(axk)))
-                hctx.check(lib.blmm_last_lod_threshold(hctx.h, 5.0, cap, pp(ik), pp(jk), pp(lk), C.byref(ck)))
-                return (time.perf_counter() - t0) * 1e3
-            red = B._lib.blmm_reduced(mxr.ctypes.data, axr.ctypes.data, 1, 5.0, cap, ir.ctypes.data, jr.ctypes.data, lr_.ctypes.data, C.addressof(cr))
-            def red_call():
-                t0 = time.perf_counter()
-                hctx.check(lib.blmm_bulkscan_reduced(hctx.h, C.byref(o), pp(Yf_), n, m_local, pp(Gf_), p, None, 0, pp(Kf_), None, pp(gridv), ng, C.byref(red), pp(h2r), None))
-                return (time.perf_counter() - t0) * 1e3
-            keep_call()
-            t_keep = min(keep_call() for _ in range(4))
-            red_call()
-            t_red = min(red_call() for _ in range(4))
-            red_route = int(lib.blmm_last_reduced_route(hctx.h))
-            n_trip = int(cr.value)
-            kk, kr = int(ck.value), int(cr.value)
-            ok_ = np.lexsort((ik[:kk], jk[:kk])); or_ = np.lexsort((ir[:kr], jr[:kr]))
-            same = bool(kk == kr and np.array_equal(mxk, mxr) and np.array_equal(axk, axr) and np.array_equal(h2k, h2r)
-                        and np.array_equal(ik[:kk][ok_], ir[:kr][or_]) and np.array_equal(jk[:kk][ok_], jr[:kr][or_])
-                        and np.array_equal(lk[:kk][ok_], lr_[:kr][or_]))
-        host_api = {"end_to_end_ms_pageable_out": t_page, "end_to_end_ms_pinned_out": t_pin,
-                    "end_to_end_ms_keep_on_device": t_keep, "end_to_end_ms_reduced_out": t_red,
-                    "reduced_route": red_route, "reduced_triplets_lod_gt_5": n_trip,
-                    "reduced_equals_keep_on_device": same,
-                    "tests_per_s_end_to_end": p * m_local / ((t_pin or t_page) * 1e-3),
-                    "tests_per_s_end_to_end_reduced_out": (p * m_local / (t_red * 1e-3)) if t_red else None,
-                    "note": "host Y/G/K in; *_out: host L out (2.08 GB over PCIe at BXD size); keep_on_device: L stays in HBM "
-                            "(blmm_bulkscan, L_out == NULL) + per-trait peaks + LOD > 5 triplets from the resident matrix; reduced_out: the "
-                            "same results from the scan epilogues, L never written (blmm_bulkscan_reduced); never `value`"}
-        hctx.close()
 
     if rank == 0:
         ms_step = dt / a.steps * 1e3
@@ -598,7 +602,7 @@ def main():
             "phases_ms": {k: v / max(ncalls, 1) for k, v in phases.items()},
             "allgather_ms": ag_ms, "gathered_ms_per_step": gathered_ms, "other_scaling": weak, "output_finite": bool(chk),
             "multi_gpu": multi,
-            "host_api": host_api,
+            "host_api": host_api, "sections_before_timed_loop": (["cpu_baseline (host only)"] if cpu else []) + (["host_api"] if host_api else []),
             "roofline": roof, "cpu_baseline": cpu,
             # the only number the reference publishes for this shape (default null-grid, 10-point grid, 16 Julia threads,
             # Xeon Silver 4214): 2.112 s -- different method and hardware, so it is context, not a vs_baseline
