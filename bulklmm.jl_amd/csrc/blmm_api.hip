@@ -290,7 +290,7 @@ int rotate_markers(blmm_ctx* ctx, Pipe& P, const double* dG, int64_t p);
 // dG != nullptr: the marker rotation goes to the side stream as well, in front of the basis (the h2 search on the main stream needs
 // only the rotated traits; the marker-side products that follow the basis on the side stream and -- behind ev_join -- the scan
 // need Xt): 12 us less in front of k_brent at the BXD shape
-int start_wbasis(blmm_ctx* ctx, Pipe& P, const double* dG = nullptr, int64_t p = 0) {
+int start_wbasis(blmm_ctx* ctx, Pipe& P, const double* dG = nullptr, int64_t p = 0, bool xt_recorded = false) {
   int rc;
   const int64_t n = P.n;
   const LrSeg seg = lr_segments(ctx, P.n);
@@ -298,11 +298,26 @@ int start_wbasis(blmm_ctx* ctx, Pipe& P, const double* dG = nullptr, int64_t p =
   if ((rc = ensure(ctx, ctx->wbW, sizeof(double) * (size_t)n * (256 + 16)))) return rc;
   if ((rc = ensure(ctx, ctx->wbRk, sizeof(int) * 4 * LR_SEG_MAX))) return rc;
   hipStream_t main_stream = ctx->stream;
-  BLMM_HIP(hipEventRecord(ctx->ev_xt, main_stream));
+  if (!xt_recorded) BLMM_HIP(hipEventRecord(ctx->ev_xt, main_stream));     // (else: recorded by the eigen phase's last kernel itself)
   BLMM_HIP(hipStreamWaitEvent(ctx->side, ctx->ev_xt, 0));
-  ctx->stream = ctx->side;                                           // the launchers enqueue on ctx->stream
-  rc = dG ? rotate_markers(ctx, P, dG, p) : BLMM_OK;
-  if (!rc) rc = launch_wbasis(ctx, P.lam, (int)n, P.npad, seg, ptr<double>(ctx->wbW), ptr<double>(ctx->wbQ), ptr<int>(ctx->wbRk), P.stat);
+  if (dG) {
+    // The basis (a handful of 1024-thread workgroups, 70 us of dependent steps) goes to the SECOND side stream, beside the marker
+    // rotation instead of behind it: queued behind the rotation it became dispatchable at the same moment as the h2 search,
+    // whose 2,200 waves then held every CU until the first of them retired -- 126 us instead of 70, and with the marker-side
+    // products behind it the critical path of the front whenever nothing else delayed the main stream (a caller that does not
+    // ask for phase timings: +35 us per call; profiles/r04_timeline_notiming_*.txt).  The side stream waits for it (ev_wb):
+    // everything queued there later -- ev_q, the marker-side products -- stays ordered behind the basis.
+    BLMM_HIP(hipStreamWaitEvent(ctx->side2, ctx->ev_xt, 0));
+    ctx->stream = ctx->side2;
+    rc = launch_wbasis(ctx, P.lam, (int)n, P.npad, seg, ptr<double>(ctx->wbW), ptr<double>(ctx->wbQ), ptr<int>(ctx->wbRk), P.stat);
+    if (!rc && hipEventRecord(ctx->ev_wb, ctx->side2) != hipSuccess) rc = fail(ctx, BLMM_ERR_HIP, "hipEventRecord failed");
+    ctx->stream = ctx->side;                                         // the launchers enqueue on ctx->stream
+    if (!rc) rc = rotate_markers(ctx, P, dG, p);
+    if (!rc && hipStreamWaitEvent(ctx->side, ctx->ev_wb, 0) != hipSuccess) rc = fail(ctx, BLMM_ERR_HIP, "hipStreamWaitEvent failed");
+  } else {
+    ctx->stream = ctx->side;
+    rc = launch_wbasis(ctx, P.lam, (int)n, P.npad, seg, ptr<double>(ctx->wbW), ptr<double>(ctx->wbQ), ptr<int>(ctx->wbRk), P.stat);
+  }
   ctx->stream = main_stream;
   return rc;
 }
@@ -332,20 +347,26 @@ int prepare(blmm_ctx* ctx, const blmm_opts* o, const double* dY, int64_t n, int6
             const double* dCovar, int64_t ncov, const double* dK, const double* dweights, int centered, Pipe& P, Timer& tm,
             bool early_wbasis = false, bool grid_side = false, bool skip_markers = false) {
   if (m < 0 || p < 0) return fail(ctx, BLMM_ERR_DIM, "Dimension mismatch.");
+  // the side streams fork where the eigen phase ends: its last kernel records the fork event itself (BLMM_LAUNCH_STOP)
+  const bool forks = m > 0 && p > 0 && (early_wbasis || grid_side);
+  ctx->stop_event_used = false;
+  ctx->stop_event_next = forks ? ctx->ev_xt : nullptr;
   int rc = prepare_eigen(ctx, o, n, dCovar, ncov, dK, dweights, centered, P, tm);
+  const bool xt_recorded = ctx->stop_event_used;
+  ctx->stop_event_next = nullptr; ctx->stop_event_used = false;
   if (rc) return rc;
   // (BLMM_ROTATE_SIDE=0: the marker rotation stays on the main stream behind the traits' -- A/B testing)
   static const bool rot_side = !(dev_env("BLMM_ROTATE_SIDE") && dev_env("BLMM_ROTATE_SIDE")[0] == '0');
   // only where the rotation is the small latency-bound kernel (n <= 160): the GEMM of larger n fills the chip by itself, and behind it
   // the basis and the marker-side products come later (n = 500 shard: 6.32 against 6.29 ms; BXD: 1.714 against 1.734 ms, 4 A/B rounds)
   const bool side_g = early_wbasis && m > 0 && p > 0 && rot_side && n <= 160;
-  if (early_wbasis && m > 0 && p > 0 && (rc = start_wbasis(ctx, P, side_g ? dG : nullptr, p))) return rc;
+  if (early_wbasis && m > 0 && p > 0 && (rc = start_wbasis(ctx, P, side_g ? dG : nullptr, p, xt_recorded))) return rc;
   P.xt_side = side_g;
   // the grid methods (grid_side): the marker rotation and, later, the marker norms of every grid point (launch_isx) on the side stream,
   // beside the traits' rotation, the grid log-likelihoods and the trait panels on the main stream; joined in front of the scan
   if (grid_side && !early_wbasis && m > 0 && p > 0 && rot_side && n <= 160) {
     hipStream_t main_stream = ctx->stream;
-    BLMM_HIP(hipEventRecord(ctx->ev_xt, main_stream));
+    if (!xt_recorded) BLMM_HIP(hipEventRecord(ctx->ev_xt, main_stream));
     BLMM_HIP(hipStreamWaitEvent(ctx->side, ctx->ev_xt, 0));
     ctx->stream = ctx->side;
     rc = rotate_markers(ctx, P, dG, p);
@@ -555,15 +576,20 @@ int lr_finish_split(blmm_ctx* ctx, const Pipe& P, const NullModel& nm, double* d
   hipStream_t main_stream = ctx->stream;
   // ---- main stream: region 0's classification and panels (the weight basis is ready at ev_q, the marker-side products at ev_join) ...
   if ((rc = launch_lr_classify(ctx, P.n, P.m, lr_shared_tol(ctx), P.lam, dh2, sp.fin, nullptr, nullptr, ptr<int>(ctx->lrPerm), r0, seg))) return rc;
-  BLMM_HIP(hipStreamWaitEvent(main_stream, ctx->ev_q, 0));
-  // the marker-side products (ev_join) are done before the panels kernel can start anyway (profiles/r03_timeline_bxd_step.txt: 410 us
-  // against 425): waiting for them HERE takes one barrier packet out of the gap between the panels and region 0's first scan launch
+  // ONE wait: ev_join is recorded on the side stream behind ev_q (the basis) and behind the marker-side products, which are done
+  // before the panels kernel can start anyway (profiles/r03_timeline_bxd_step.txt: 410 us against 425) -- every barrier packet
+  // between two dependent kernels of this stream costs ~10 us
   BLMM_HIP(hipStreamWaitEvent(main_stream, ctx->ev_join, 0));
-  if ((rc = lr_region_panels(ctx, P, nm, dh2, r0))) return rc;
+  ctx->stop_event_used = false;
+  ctx->stop_event_next = ctx->ev_b1;                                 // recorded by the panels kernel itself
+  rc = lr_region_panels(ctx, P, nm, dh2, r0);
+  const bool b1_recorded = ctx->stop_event_used;
+  ctx->stop_event_next = nullptr; ctx->stop_event_used = false;
+  if (rc) return rc;
   // ---- ... and only then the second side stream: the rest of the h2 search, then region 1's columns.  Forked right behind
   //      k_brent (rounds 2-3a) k_brent2's older waves won the issue arbitration against the 16-lane panels kernel on the
   //      critical path (45 us beside it, 28 alone); its chain has ~0.5 ms of slack before region 1's scan needs it
-  BLMM_HIP(hipEventRecord(ctx->ev_b1, main_stream));
+  if (!b1_recorded) BLMM_HIP(hipEventRecord(ctx->ev_b1, main_stream));
   BLMM_HIP(hipStreamWaitEvent(ctx->side2, ctx->ev_b1, 0));
   ctx->stream = ctx->side2;
   BrentSplit sp2 = sp;
@@ -653,7 +679,8 @@ int blmm_create(int device_id, void* hip_stream, blmm_ctx** out) {
       hipEventCreateWithFlags(&ctx->ev_b1, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&ctx->ev_b2, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&ctx->ev_q, hipEventDisableTiming) != hipSuccess ||
-      hipEventCreateWithFlags(&ctx->ev_m, hipEventDisableTiming) != hipSuccess) {
+      hipEventCreateWithFlags(&ctx->ev_m, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&ctx->ev_wb, hipEventDisableTiming) != hipSuccess) {
     blmm_destroy(ctx);
     return BLMM_ERR_HIP;
   }
@@ -697,6 +724,7 @@ void blmm_destroy(blmm_ctx* ctx) {
   if (ctx->ev_b2) (void)hipEventDestroy(ctx->ev_b2);
   if (ctx->ev_q) (void)hipEventDestroy(ctx->ev_q);
   if (ctx->ev_m) (void)hipEventDestroy(ctx->ev_m);
+  if (ctx->ev_wb) (void)hipEventDestroy(ctx->ev_wb);
   if (ctx->side2) { (void)hipStreamSynchronize(ctx->side2); (void)hipStreamDestroy(ctx->side2); }
   if (ctx->own_stream) hipStreamDestroy(ctx->stream);
   if (ctx->hflag) (void)hipHostFree(const_cast<int64_t*>(ctx->hflag));

@@ -2,6 +2,7 @@
 // Not part of the public ABI (that is include/bulklmm_hip.h).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 #include <stdlib.h>
 #include <string>
@@ -99,7 +100,11 @@ struct blmm_ctx {
   size_t ev_used = 0;
   // side stream: work that only depends on the eigenvalues / rotated markers runs beside the per-trait Brent search
   hipStream_t side = nullptr, side2 = nullptr;
-  hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_xt = nullptr, ev_b1 = nullptr, ev_b2 = nullptr, ev_q = nullptr, ev_m = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_xt = nullptr, ev_b1 = nullptr, ev_b2 = nullptr, ev_q = nullptr, ev_m = nullptr, ev_wb = nullptr;
+  // An event to be recorded BY the next launch that honours it (BLMM_LAUNCH_STOP: hipExtLaunchKernel's stop event = the kernel's own
+  // completion signal) instead of by a marker packet behind that kernel: a hipEventRecord between two dependent kernels of the main
+  // stream cost 10-12 us of its critical path (profiles/r04_timeline_notiming_*.txt).  stop_event_used: the launch took it.
+  hipEvent_t stop_event_next = nullptr; bool stop_event_used = false;
   int num_cus = 0;                 // multiProcessorCount of the device (bounds every co-resident grid)
   // sticky device-side abort word in pinned, device-mapped host memory: a kernel that gives up (bounded spin of the
   // multi-workgroup weight-basis kernel) is reported by the NEXT API call / blmm_synchronize even when the failing
@@ -371,3 +376,12 @@ int launch_scan_alt(blmm_ctx* ctx, const AltArgs& a);
 int launch_alt_ctab(blmm_ctx* ctx, const double* EllTab, int ngrid, int64_t m, int n, double* C);
 
 }  // namespace blmm
+
+// launch on ctx->stream; a pending ctx->stop_event_next is recorded by this kernel's completion (see blmm_ctx)
+#define BLMM_LAUNCH_STOP(ctx_, kernel_, grid_, block_, lds_, ...)                                                          \
+  do {                                                                                                                   \
+    if ((ctx_)->stop_event_next) {                                                                                       \
+      hipExtLaunchKernelGGL(kernel_, grid_, block_, (std::uint32_t)(lds_), (ctx_)->stream, nullptr, (ctx_)->stop_event_next, 0, __VA_ARGS__); \
+      (ctx_)->stop_event_next = nullptr; (ctx_)->stop_event_used = true;                                                 \
+    } else hipLaunchKernelGGL(kernel_, grid_, block_, lds_, (ctx_)->stream, __VA_ARGS__);                                 \
+  } while (0)

@@ -1371,7 +1371,7 @@ int launch_lr_panels(blmm_ctx* ctx, const NullModel& nm, const double* Yt, int64
     const int wqcap = (wbase + sizeof(double) * nm.n <= 60 * 1024) ? (int)std::min<size_t>(std::min<size_t>((size_t)nm.n, qrows), (60 * 1024 - wbase) / (sizeof(double) * (size_t)nm.n)) : 0;
     const size_t wlds = wbase + sizeof(double) * (size_t)wqcap * nm.n;
 #define LPW(C) do { if (wlds > 48 * 1024) BLMM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_lr_panels_w<C, LPT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)wlds)); \
-    hipLaunchKernelGGL((k_lr_panels_w<C, LPT>), dim3(wblocks), dim3(256), wlds, ctx->stream, nm, Yt, ldy, m, Z0, lam, h2, Q, rk, wqcap, perm, rg.col0, rg.ncol, rg.counts, nbatch, hiprio, P0, Cp, Ls, ldp, stat, rg.segcnt, seg.S, (int64_t)nm.npad * nm.n); } while (0)
+    BLMM_LAUNCH_STOP(ctx, (k_lr_panels_w<C, LPT>), dim3(wblocks), dim3(256), wlds, nm, Yt, ldy, m, Z0, lam, h2, Q, rk, wqcap, perm, rg.col0, rg.ncol, rg.counts, nbatch, hiprio, P0, Cp, Ls, ldp, stat, rg.segcnt, seg.S, (int64_t)nm.npad * nm.n); } while (0)
     switch (nm.c) {
       case 1: LPW(1); break;
       case 2: LPW(2); break;

@@ -657,7 +657,8 @@ int launch_jacobi(blmm_ctx* ctx, double* A, double* V, int n, double* lraw, int6
     const int nblk = NP2 * (NP2 - 1) / 2;
     int nthr = (nblk <= 2 * (768 - 64)) ? 768 : 1024;
     if (nt_env >= 256 && nt_env <= 1024 && nt_env % 64 == 0 && nblk <= 2 * (nt_env - 64)) nthr = nt_env;
-    hipLaunchKernelGGL(k_jacobi_lds, dim3(nwg), dim3(nthr), lds, ctx->stream, A, V, n, lraw, stat, stop2, pa, fuse, pe_off);
+    if (fuse) BLMM_LAUNCH_STOP(ctx, k_jacobi_lds, dim3(nwg), dim3(nthr), lds, A, V, n, lraw, stat, stop2, pa, fuse, pe_off);   // (the eigen phase's last launch)
+    else hipLaunchKernelGGL(k_jacobi_lds, dim3(nwg), dim3(nthr), lds, ctx->stream, A, V, n, lraw, stat, stop2, pa, fuse, pe_off);
   } else {
     hipLaunchKernelGGL(k_jacobi_glb, dim3(1), dim3(1024), 0, ctx->stream, A, V, n, lraw, stat);
   }
@@ -817,7 +818,7 @@ int launch_post_eigen(blmm_ctx* ctx, const double* lraw, const double* V, const 
   const PostEigenArgs pa{Zs, dweights, c, npad, ldr, decomp, centered, lam, U, Z0, Rp, ptr<double>(ctx->misc)};
   if (lds + lds_static <= 158 * 1024) {
     BLMM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_post_eigen<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(k_post_eigen<true>, dim3(1), dim3(1024), lds, ctx->stream, lraw, V, n, pa, stat);
+    BLMM_LAUNCH_STOP(ctx, (k_post_eigen<true>), dim3(1), dim3(1024), lds, lraw, V, n, pa, stat);
   } else {
     double* Bq = ptr<double>(ctx->misc);                        // c x n
     int* rankof = reinterpret_cast<int*>(Bq + (size_t)c * n);   // n ints (the workspace holds n more doubles)
