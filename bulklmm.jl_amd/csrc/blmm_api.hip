@@ -300,20 +300,22 @@ int start_wbasis(blmm_ctx* ctx, Pipe& P, const double* dG = nullptr, int64_t p =
   hipStream_t main_stream = ctx->stream;
   if (!xt_recorded) BLMM_HIP(hipEventRecord(ctx->ev_xt, main_stream));     // (else: recorded by the eigen phase's last kernel itself)
   BLMM_HIP(hipStreamWaitEvent(ctx->side, ctx->ev_xt, 0));
+  ctx->wb_on_side2 = false;
   if (dG) {
     // The basis (a handful of 1024-thread workgroups, 70 us of dependent steps) goes to the SECOND side stream, beside the marker
     // rotation instead of behind it: queued behind the rotation it became dispatchable at the same moment as the h2 search,
     // whose 2,200 waves then held every CU until the first of them retired -- 126 us instead of 70, and with the marker-side
     // products behind it the critical path of the front whenever nothing else delayed the main stream (a caller that does not
-    // ask for phase timings: +35 us per call; profiles/r04_timeline_notiming_*.txt).  The side stream waits for it (ev_wb):
-    // everything queued there later -- ev_q, the marker-side products -- stays ordered behind the basis.
+    // ask for phase timings: +35 us per call; profiles/r04_timeline_notiming_*.txt).  The marker-side products follow the basis
+    // on ITS stream (lr_begin: no cross-queue wait between the two, each of which costs 14-20 us here) and wait there for
+    // the rotation (ev_wb), which is done long before.
     BLMM_HIP(hipStreamWaitEvent(ctx->side2, ctx->ev_xt, 0));
     ctx->stream = ctx->side2;
     rc = launch_wbasis(ctx, P.lam, (int)n, P.npad, seg, ptr<double>(ctx->wbW), ptr<double>(ctx->wbQ), ptr<int>(ctx->wbRk), P.stat);
-    if (!rc && hipEventRecord(ctx->ev_wb, ctx->side2) != hipSuccess) rc = fail(ctx, BLMM_ERR_HIP, "hipEventRecord failed");
     ctx->stream = ctx->side;                                         // the launchers enqueue on ctx->stream
     if (!rc) rc = rotate_markers(ctx, P, dG, p);
-    if (!rc && hipStreamWaitEvent(ctx->side, ctx->ev_wb, 0) != hipSuccess) rc = fail(ctx, BLMM_ERR_HIP, "hipStreamWaitEvent failed");
+    if (!rc && hipEventRecord(ctx->ev_wb, ctx->side) != hipSuccess) rc = fail(ctx, BLMM_ERR_HIP, "hipEventRecord failed");   // ev_wb: the rotated markers
+    ctx->wb_on_side2 = true;
   } else {
     ctx->stream = ctx->side;
     rc = launch_wbasis(ctx, P.lam, (int)n, P.npad, seg, ptr<double>(ctx->wbW), ptr<double>(ctx->wbQ), ptr<int>(ctx->wbRk), P.stat);
@@ -460,15 +462,19 @@ int lr_begin(blmm_ctx* ctx, const Pipe& P, bool wbasis_started) {
     BLMM_HIP(hipEventRecord(ctx->ev_fork, main_stream));          // rotated operands are ready
     BLMM_HIP(hipStreamWaitEvent(ctx->side, ctx->ev_fork, 0));
   }
-  ctx->stream = ctx->side;                                         // the launchers enqueue on ctx->stream
+  // (start_wbasis put the basis on the second side stream: the marker-side products follow it THERE, behind the rotation's event)
+  const bool on2 = wbasis_started && P.xt_side && ctx->wb_on_side2;
+  hipStream_t lr_side = on2 ? ctx->side2 : ctx->side;
+  ctx->stream = lr_side;                                           // the launchers enqueue on ctx->stream
   rc = BLMM_OK;
   if (!wbasis_started) rc = launch_wbasis(ctx, P.lam, P.n, P.npad, seg, ptr<double>(ctx->wbW), ptr<double>(ctx->wbQ), rk, P.stat);
-  if (!rc && hipEventRecord(ctx->ev_q, ctx->side) != hipSuccess) rc = fail(ctx, BLMM_ERR_HIP, "hipEventRecord failed");   // what the panels need
+  if (!rc && hipEventRecord(ctx->ev_q, lr_side) != hipSuccess) rc = fail(ctx, BLMM_ERR_HIP, "hipEventRecord failed");   // what the panels need
+  if (!rc && on2 && hipStreamWaitEvent(lr_side, ctx->ev_wb, 0) != hipSuccess) rc = fail(ctx, BLMM_ERR_HIP, "hipStreamWaitEvent failed");
   if (!rc) rc = launch_lr_tpanels(ctx, P.Xt, P.ldx, P.p, P.n, P.c, P.npad, P.Z0, ptr<double>(ctx->wbQ), rk, seg, ptr<double>(ctx->lrT), tstride,
                                   ptr<double>(ctx->lrDen0));
   ctx->stream = main_stream;
   if (rc) return rc;
-  BLMM_HIP(hipEventRecord(ctx->ev_join, ctx->side));                // ... and what the scan needs on top
+  BLMM_HIP(hipEventRecord(ctx->ev_join, lr_side));                  // ... and what the scan needs on top
   // (the column order's preset, -1 = padding, is written by the count pass of k_lr_classify)
   return BLMM_OK;
 }

@@ -105,6 +105,7 @@ struct blmm_ctx {
   // completion signal) instead of by a marker packet behind that kernel: a hipEventRecord between two dependent kernels of the main
   // stream cost 10-12 us of its critical path (profiles/r04_timeline_notiming_*.txt).  stop_event_used: the launch took it.
   hipEvent_t stop_event_next = nullptr; bool stop_event_used = false;
+  bool wb_on_side2 = false;            // start_wbasis: the weight basis went to the second side stream (lr_begin follows it there)
   int num_cus = 0;                 // multiProcessorCount of the device (bounds every co-resident grid)
   // sticky device-side abort word in pinned, device-mapped host memory: a kernel that gives up (bounded spin of the
   // multi-workgroup weight-basis kernel) is reported by the NEXT API call / blmm_synchronize even when the failing
