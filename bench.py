@@ -326,12 +326,13 @@ def main():
         if gather:
             w.gather()
 
-    def timed(w, gather, steps, warmup):
-        """`steps` steps bracketed by barrier + synchronize on both sides; the MAX over ranks of the wall time."""
+    def timed(w, gather, steps, warmup, marks=True):
+        """`steps` steps bracketed by barrier + synchronize on both sides; the MAX over ranks of the wall time.  marks: the library's
+        phase timings (HIP events between the phases, on its streams) are on -- what `phases_ms` and `roofline` are read from."""
         for _ in range(max(warmup, 1)):
             step(w, gather)
         torch.cuda.synchronize()
-        ctx.set_timing(not os.environ.get("BLMM_BENCH_NOTIMING"))
+        ctx.set_timing(marks and not os.environ.get("BLMM_BENCH_NOTIMING"))
         ctx.read_timings()
         barrier()
         torch.cuda.synchronize()
@@ -432,6 +433,11 @@ def main():
                             "same results from the scan epilogues, L never written (blmm_bulkscan_reduced); never `value`"}
         hctx.close()
     dt, phases, ncalls = timed(work, a.gather, a.steps, a.warmup)
+    # ... and the same loop as a caller runs it by default -- no phase timings: every event record between two dependent kernels of
+    # the library's main stream is a marker packet the next kernel waits for (profiles/r04_timeline_*timing*.txt)
+    dt_nomarks = None
+    if world == 1 and a.streams == 1:
+        dt_nomarks, _, _ = timed(work, a.gather, a.steps, 1, marks=False)
     # The headline workload's h2 = 0 share (about half of the synthetic traits end at the boundary and take the cheaper
     # shared-weights class) is a property of the DATA: one more timed loop with the class switched off (every trait through the
     # rank-R form: tuning key lr_shared = 0) says what the step costs without it.
@@ -593,6 +599,7 @@ def main():
         out = {
             "metric": "trait x marker LOD tests/sec", "value": tests / (dt / a.steps), "unit": "tests/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms_step, "higher_is_better": True,
+            "ms_per_step_no_phase_marks": (dt_nomarks / a.steps * 1e3) if dt_nomarks else None,
             "scaling": a.scaling, "vs_baseline": None, "dtype": "f32" if f32 else "f64", "data": "synthetic",
             "config": {"workload": workload_name(a, n, p, m_total, m_local, f32, world),
                        "n": n, "p": p, "m": m_total, "m_per_gpu": m_local, "method": a.method,
