@@ -2281,10 +2281,29 @@ __global__ void __launch_bounds__(256) k_isx(NullModel nm, const double* __restr
   for (int e = threadIdx.x; e < n; e += blockDim.x) sW[e] = fabs(1.0 / fma(delta, lam[e], 1.0));
   for (int e = threadIdx.x; e < n * C; e += blockDim.x) sZ[e] = Z0[e];
   __syncthreads();
+  constexpr int NA = C * (C + 1) / 2;
+  __shared__ double sA[CMAX * (CMAX + 1) / 2];
+  if constexpr (XF32) {
+    // (the n-long sums of Z'WZ by wave 0 -- lanes over k, one wave reduction per entry -- instead of by thread 0 alone: 7 us per
+    //  workgroup at n = 1000, in front of every workgroup's marker loop; the fp64 instantiations keep thread 0's summation order)
+    if (threadIdx.x < 64) {
+#pragma unroll
+      for (int q = 0; q < C; ++q)
+#pragma unroll
+        for (int r = 0; r <= q; ++r) {
+          double a = 0.0;
+          for (int k = threadIdx.x; k < n; k += 64) a = fma(sW[k] * sZ[q * n + k], sZ[r * n + k], a);
+          for (int off = 32; off > 0; off >>= 1) a += __shfl_xor(a, off);
+          if (threadIdx.x == 0) sA[q * (q + 1) / 2 + r] = a;
+        }
+    }
+    __syncthreads();
+  }
   if (threadIdx.x == 0) {
-    constexpr int NA = C * (C + 1) / 2;
     double A[NA], L[NA], Li[NA];
     for (int a = 0; a < NA; ++a) A[a] = 0.0;
+    if constexpr (XF32) { for (int a = 0; a < NA; ++a) A[a] = sA[a]; }
+    else
     for (int k = 0; k < n; ++k)
       for (int q = 0; q < C; ++q)
         for (int r = 0; r <= q; ++r) A[q * (q + 1) / 2 + r] = fma(sW[k] * sZ[q * n + k], sZ[r * n + k], A[q * (q + 1) / 2 + r]);
@@ -2320,12 +2339,39 @@ __global__ void __launch_bounds__(256) k_isx(NullModel nm, const double* __restr
     if constexpr (XF32) {
       typedef float f4x __attribute__((ext_vector_type(4)));
       const f4x* F = reinterpret_cast<const f4x*>(Xt);
-      for (int kh = 0; kh < 2 * ((n + 7) / 8); ++kh) {      // kh = kb * 2 + h holds k = 8 kb + 2 j + h, j = 0 .. 3
+      // two accumulator sets (h = 0 / 1 pieces), four pieces' loads per trip: the single fma chain of n terms behind one load per
+      // trip took 187 us at n = 1000, p = 1e5
+      double sxx1 = 0.0, sxz1[C];
+#pragma unroll
+      for (int q = 0; q < C; ++q) sxz1[q] = 0.0;
+      auto term1 = [&](int k, double x) {
+        const double wx = sW[k] * x;
+        sxx1 = fma(wx, x, sxx1);
+#pragma unroll
+        for (int q = 0; q < C; ++q) sxz1[q] = fma(wx, sZ[q * n + k], sxz1[q]);
+      };
+      const int KH = 2 * ((n + 7) / 8);                     // kh = kb * 2 + h holds k = 8 kb + 2 j + h, j = 0 .. 3
+      int kh = 0;
+      for (; kh + 4 <= KH; kh += 4) {
+        f4x v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = F[(int64_t)(kh + u) * ldx + i];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int kb = (kh + u) >> 1, h = (kh + u) & 1;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) { const int k = 8 * kb + 2 * j + h; if (k < n) { if (u & 1) term1(k, (double)v[u][j]); else term(k, (double)v[u][j]); } }
+        }
+      }
+      for (; kh < KH; ++kh) {
         const f4x v = F[(int64_t)kh * ldx + i];
         const int kb = kh >> 1, h = kh & 1;
 #pragma unroll
         for (int j = 0; j < 4; ++j) { const int k = 8 * kb + 2 * j + h; if (k < n) term(k, (double)v[j]); }
       }
+      sxx += sxx1;
+#pragma unroll
+      for (int q = 0; q < C; ++q) sxz[q] += sxz1[q];
     } else {
       for (int k = 0; k < n; ++k) term(k, Xt[(int64_t)k * ldx + i]);
     }
