@@ -1581,23 +1581,35 @@ __global__ void __launch_bounds__(NT) k_eigf_pairs(int n, const double* __restri
   if (t == 0) s_r = (s_red[2] <= s_red[3]) ? s_cnt[0][0] : s_cnt[0][1];
   __syncthreads();
   const int r = s_r;
-  // z_r = 1, upwards through D+ (thread 0), downwards through D- (thread 64); the entries overwrite the factor they came from
-  if (t == 0) {
-    double z = 1.0, nrm = 1.0;
-    for (int i = r - 1; i >= 0; --i) { z = -quot_fast(se[i], sDp[i]) * z; sDp[i] = z; nrm = fma(z, z, nrm); }
-    sDp[r] = 1.0;
-    s_red[0] = nrm;
-  } else if (t == 64) {
-    double z = 1.0, nrm = 0.0;
-    for (int i = r; i < n - 1; ++i) { z = -quot_fast(se[i], sDm[i + 1]) * z; sDm[i + 1] = z; nrm = fma(z, z, nrm); }
-    s_red[1] = nrm;
+  // z_r = 1, z_i = -(e_i / D+_i) z_(i+1) upwards, z_(i+1) = -(e_i / D-_(i+1)) z_i downwards.  The quotients do not depend on z:
+  // every lane takes its own, and the two recurrences are a suffix / a prefix PRODUCT around r -- seven doubling steps over LDS
+  // instead of two chains of up to n dependent quotient-and-multiply steps on two threads (13 k of this kernel's 112 k cycles).
+  double fct = 1.0;
+  if (t < n) { if (t < r) fct = -quot_fast(se[t], sDp[t]); else if (t > r) fct = -quot_fast(se[t - 1], sDm[t]); }
+  __syncthreads();                                     // (every quotient is taken before the factors are overwritten)
+  double* za = sDp; double* zb = sDm;
+  if (t < 128) za[t] = fct;
+  __syncthreads();
+  for (int s_ = 1; s_ < n; s_ <<= 1) {
+    if (t < n) {
+      double v = za[t];
+      if (t > r && t - s_ > r) v *= za[t - s_]; else if (t < r && t + s_ < r) v *= za[t + s_];
+      zb[t] = v;
+    }
+    __syncthreads();
+    double* tmp = za; za = zb; zb = tmp;
+  }
+  if (wave < 2) {
+    const double zt = (t < n) ? za[t] : 0.0;
+    const double nr = wsum(zt * zt);
+    if (lane == 0) s_red[wave] = nr;
   }
   __syncthreads();
   EPSTAMP(2);
   const double inv = fast_rsqrt(s_red[0] + s_red[1]);
   double res = 0.0;
   if (t < n) {
-    auto zat = [&](int i) { return ((i <= r) ? sDp[i] : sDm[i]) * inv; };
+    auto zat = [&](int i) { return za[i] * inv; };
     const double zi = zat(t);
     g.Zc[(size_t)k * n + t] = zi;
     double rr = (sd[t] - l) * zi;
