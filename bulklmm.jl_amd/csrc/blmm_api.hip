@@ -284,6 +284,17 @@ int prepare_eigen(blmm_ctx* ctx, const blmm_opts* o, int64_t n, const double* dC
   return BLMM_OK;
 }
 
+// the host entry points' deferred uploads (blmm_ctx::up_pending): on the copy stream, behind nothing; ev_in says when they are there
+static int flush_upload(blmm_ctx* ctx) {
+  if (!ctx->up_pending) return BLMM_OK;
+  ctx->up_pending = false;
+  for (int i = 0; i < 2; ++i)
+    if (ctx->up_bytes[i]) BLMM_HIP(hipMemcpyAsync(ctx->up_dst[i], ctx->up_src[i], ctx->up_bytes[i], hipMemcpyHostToDevice, ctx->copy));
+  BLMM_HIP(hipEventRecord(ctx->ev_in, ctx->copy));
+  ctx->in_wait = true;
+  return BLMM_OK;
+}
+
 // null-exact, low-rank weights form: the basis of the weight family needs only the sorted eigenvalues, so it starts on the side
 // stream right behind the eigen-decomposition, beside the rotation and the Brent search (joined before k_lr_panels)
 int rotate_markers(blmm_ctx* ctx, Pipe& P, const double* dG, int64_t p);
@@ -313,6 +324,7 @@ int start_wbasis(blmm_ctx* ctx, Pipe& P, const double* dG = nullptr, int64_t p =
     ctx->stream = ctx->side2;
     rc = launch_wbasis(ctx, P.lam, (int)n, P.npad, seg, ptr<double>(ctx->wbW), ptr<double>(ctx->wbQ), ptr<int>(ctx->wbRk), P.stat);
     ctx->stream = ctx->side;                                         // the launchers enqueue on ctx->stream
+    if (!rc && ctx->in_wait && hipStreamWaitEvent(ctx->side, ctx->ev_in, 0) != hipSuccess) rc = fail(ctx, BLMM_ERR_HIP, "hipStreamWaitEvent failed");
     if (!rc) rc = rotate_markers(ctx, P, dG, p);
     if (!rc && hipEventRecord(ctx->ev_wb, ctx->side) != hipSuccess) rc = fail(ctx, BLMM_ERR_HIP, "hipEventRecord failed");   // ev_wb: the rotated markers
     ctx->wb_on_side2 = true;
@@ -356,7 +368,12 @@ int prepare(blmm_ctx* ctx, const blmm_opts* o, const double* dY, int64_t n, int6
   int rc = prepare_eigen(ctx, o, n, dCovar, ncov, dK, dweights, centered, P, tm);
   const bool xt_recorded = ctx->stop_event_used;
   ctx->stop_event_next = nullptr; ctx->stop_event_used = false;
-  if (rc) return rc;
+  if (rc) { ctx->up_pending = false; return rc; }
+  // (host entry points) the eigen phase is queued: now the traits and the markers go up, beside it; this stream reads them next
+  if (ctx->up_pending) {
+    if ((rc = flush_upload(ctx))) return rc;
+    BLMM_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_in, 0));
+  }
   // (BLMM_ROTATE_SIDE=0: the marker rotation stays on the main stream behind the traits' -- A/B testing)
   static const bool rot_side = !(dev_env("BLMM_ROTATE_SIDE") && dev_env("BLMM_ROTATE_SIDE")[0] == '0');
   // only where the rotation is the small latency-bound kernel (n <= 160): the GEMM of larger n fills the chip by itself, and behind it
@@ -370,6 +387,7 @@ int prepare(blmm_ctx* ctx, const blmm_opts* o, const double* dY, int64_t n, int6
     hipStream_t main_stream = ctx->stream;
     if (!xt_recorded) BLMM_HIP(hipEventRecord(ctx->ev_xt, main_stream));
     BLMM_HIP(hipStreamWaitEvent(ctx->side, ctx->ev_xt, 0));
+    if (ctx->in_wait) BLMM_HIP(hipStreamWaitEvent(ctx->side, ctx->ev_in, 0));
     ctx->stream = ctx->side;
     rc = rotate_markers(ctx, P, dG, p);
     ctx->stream = main_stream;
@@ -379,6 +397,7 @@ int prepare(blmm_ctx* ctx, const blmm_opts* o, const double* dY, int64_t n, int6
   if ((rc = rotate_traits(ctx, P, dY, m))) return rc;
   if (skip_markers) { P.p = p; P.ldx = round_up(p > 0 ? p : 1, 128); P.Xt = nullptr; }   // the caller rotates them itself (fp32 permutation path)
   else if (!P.xt_side && (rc = rotate_markers(ctx, P, dG, p))) return rc;
+  ctx->in_wait = false;                     // every reader of the uploaded inputs is queued behind ev_in
   tm.mark();
   return BLMM_OK;
 }
@@ -686,7 +705,9 @@ int blmm_create(int device_id, void* hip_stream, blmm_ctx** out) {
       hipEventCreateWithFlags(&ctx->ev_b2, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&ctx->ev_q, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&ctx->ev_m, hipEventDisableTiming) != hipSuccess ||
-      hipEventCreateWithFlags(&ctx->ev_wb, hipEventDisableTiming) != hipSuccess) {
+      hipEventCreateWithFlags(&ctx->ev_wb, hipEventDisableTiming) != hipSuccess ||
+      hipStreamCreateWithFlags(&ctx->copy, hipStreamNonBlocking) != hipSuccess ||
+      hipEventCreateWithFlags(&ctx->ev_in, hipEventDisableTiming) != hipSuccess) {
     blmm_destroy(ctx);
     return BLMM_ERR_HIP;
   }
@@ -731,6 +752,8 @@ void blmm_destroy(blmm_ctx* ctx) {
   if (ctx->ev_q) (void)hipEventDestroy(ctx->ev_q);
   if (ctx->ev_m) (void)hipEventDestroy(ctx->ev_m);
   if (ctx->ev_wb) (void)hipEventDestroy(ctx->ev_wb);
+  if (ctx->ev_in) (void)hipEventDestroy(ctx->ev_in);
+  if (ctx->copy) { (void)hipStreamSynchronize(ctx->copy); (void)hipStreamDestroy(ctx->copy); }
   if (ctx->side2) { (void)hipStreamSynchronize(ctx->side2); (void)hipStreamDestroy(ctx->side2); }
   if (ctx->own_stream) hipStreamDestroy(ctx->stream);
   if (ctx->hflag) (void)hipHostFree(const_cast<int64_t*>(ctx->hflag));
@@ -1388,9 +1411,11 @@ static int upload_bulk_inputs(blmm_ctx* ctx, const double* Y, int64_t n, int64_t
   if ((rc = ensure(ctx, ctx->inY, sizeof(double) * n * (m > 0 ? m : 1)))) return rc;
   if ((rc = ensure(ctx, ctx->inG, sizeof(double) * n * (p > 0 ? p : 1)))) return rc;
   if ((rc = ensure(ctx, ctx->inK, sizeof(double) * n * n))) return rc;
-  BLMM_HIP(hipMemcpyAsync(ctx->inY.p, Y, sizeof(double) * n * m, hipMemcpyHostToDevice, ctx->stream));
-  BLMM_HIP(hipMemcpyAsync(ctx->inG.p, G, sizeof(double) * n * p, hipMemcpyHostToDevice, ctx->stream));
   BLMM_HIP(hipMemcpyAsync(ctx->inK.p, K, sizeof(double) * n * n, hipMemcpyHostToDevice, ctx->stream));
+  // Y and G: left for prepare(), which copies them on ctx->copy once the eigen phase is queued (see blmm_ctx::up_pending)
+  ctx->up_src[0] = Y; ctx->up_dst[0] = ctx->inY.p; ctx->up_bytes[0] = sizeof(double) * (size_t)n * (size_t)m;
+  ctx->up_src[1] = G; ctx->up_dst[1] = ctx->inG.p; ctx->up_bytes[1] = sizeof(double) * (size_t)n * (size_t)p;
+  ctx->up_pending = true; ctx->in_wait = false;
   *dCov = nullptr; *dW = nullptr;
   if (Covar && ncov > 0) {
     if ((rc = ensure(ctx, ctx->inCov, sizeof(double) * n * ncov))) return rc;
@@ -1434,6 +1459,7 @@ int blmm_bulkscan(blmm_ctx* ctx, const blmm_opts* opts, const double* Y, int64_t
   pv_hand_over(ctx, pvreq);
   rc = blmm_bulkscan_dev(ctx, opts, ptr<double>(ctx->inY), n, m, ptr<double>(ctx->inG), p, dCov, dCov ? ncov : 0,
                          ptr<double>(ctx->inK), dW, h2_grid, ngrid, ptr<double>(ctx->outL), p, ptr<double>(ctx->outH2), status);
+  ctx->up_pending = false; ctx->in_wait = false;        // (a call refused before prepare() never uploaded them)
   if (rc) { hipStreamSynchronize(ctx->stream); return rc; }
   const double hp2 = hprof ? now() : 0.0;
   if (hprof) (void)hipStreamSynchronize(ctx->stream);
@@ -1478,8 +1504,10 @@ int blmm_bulkscan_reduced(blmm_ctx* ctx, const blmm_opts* opts, const double* Y,
   d.tj = d.ti + (cap > 0 ? cap : 1);
   const double* dCov = nullptr; const double* dW = nullptr;
   if ((rc = upload_bulk_inputs(ctx, Y, n, m, G, p, Covar, ncov, K, weights, &dCov, &dW))) return rc;
-  if ((rc = reduced_impl(ctx, opts, ptr<double>(ctx->inY), n, m, ptr<double>(ctx->inG), p, dCov, dCov ? ncov : 0, ptr<double>(ctx->inK), dW,
-                         h2_grid, ngrid, &d, ptr<double>(ctx->outH2), status, &ctx->last_reduced_route))) return rc;
+  rc = reduced_impl(ctx, opts, ptr<double>(ctx->inY), n, m, ptr<double>(ctx->inG), p, dCov, dCov ? ncov : 0, ptr<double>(ctx->inK), dW,
+                    h2_grid, ngrid, &d, ptr<double>(ctx->outH2), status, &ctx->last_reduced_route);
+  ctx->up_pending = false; ctx->in_wait = false;
+  if (rc) return rc;
   if (m > 0) {
     if (out->colmax) BLMM_HIP(hipMemcpyAsync(out->colmax, d.colmax, sizeof(double) * (size_t)m, hipMemcpyDeviceToHost, ctx->stream));
     if (out->argmax) BLMM_HIP(hipMemcpyAsync(out->argmax, d.argmax, sizeof(int64_t) * (size_t)m, hipMemcpyDeviceToHost, ctx->stream));

@@ -106,6 +106,13 @@ struct blmm_ctx {
   // stream cost 10-12 us of its critical path (profiles/r04_timeline_notiming_*.txt).  stop_event_used: the launch took it.
   hipEvent_t stop_event_next = nullptr; bool stop_event_used = false;
   bool wb_on_side2 = false;            // start_wbasis: the weight basis went to the second side stream (lr_begin follows it there)
+  // Host entry points (blmm_bulkscan, blmm_bulkscan_reduced): K, the covariates and the weights go up first, the eigen phase is
+  // queued, and only then Y and G are copied -- on their own stream, beside the eigen kernels (0.23 ms at n = 79 that the caller
+  // used to wait for behind 27 MB of uploads).  up_pending: upload_bulk_inputs left them for prepare(); in_wait: the copies are
+  // in flight, whoever reads inY / inG waits for ev_in first.
+  hipStream_t copy = nullptr; hipEvent_t ev_in = nullptr;
+  bool up_pending = false, in_wait = false;
+  const void* up_src[2] = {nullptr, nullptr}; void* up_dst[2] = {nullptr, nullptr}; size_t up_bytes[2] = {0, 0};
   int num_cus = 0;                 // multiProcessorCount of the device (bounds every co-resident grid)
   // sticky device-side abort word in pinned, device-mapped host memory: a kernel that gives up (bounded spin of the
   // multi-workgroup weight-basis kernel) is reported by the NEXT API call / blmm_synchronize even when the failing
