@@ -633,13 +633,15 @@ def bulkscan(Y, G, K, Covar=None, *, method: str = "null-grid", h2_grid=None, nb
 
 
 def bulkscan_reduced(Y, G, K, Covar=None, *, method: str = "null-grid", h2_grid=None, threshold: Optional[float] = None,
-                     cap: int = 1 << 16, addIntercept: bool = True, weights=None, prior_variance: float = 1.0,
+                     cap: int = 1 << 20, addIntercept: bool = True, weights=None, prior_variance: float = 1.0,
                      prior_sample_size: float = 0.0, reml: bool = False, optim_interval: int = 1, decomp_scheme: str = "eigen",
                      ctx: Optional[Context] = None, return_status: bool = False) -> dict:
     """bulkscan WITHOUT the LOD matrix (blmm_bulkscan_reduced; not in the reference, whose users reduce L on the CPU:
     README.md:246-255, 354-359): per trait the peak LOD and its marker, and -- `threshold` given -- every (marker, trait, LOD) with
     LOD > threshold, computed in the scan kernels' epilogues; L is never written.  Returns {"max_lod": m, "argmax": m (0-based),
-    "h2_null_list": m [, "triplets": (i, j, lod) sorted by (trait, marker)], "route": 1 fused | 2 through a resident matrix}."""
+    "h2_null_list": m [, "triplets": (i, j, lod) sorted by (trait, marker)], "route": 1 fused | 2 through a resident matrix}.
+    `cap`: room for the triplets (16 bytes each, untouched pages cost nothing); more hits than that and the WHOLE call runs again
+    with the count it reported -- at the BXD shape, LOD > 5 gives 1e5 triplets, hence the default of 2^20."""
     if h2_grid is None:
         h2_grid = [i / 10.0 for i in range(10)]
     if method not in _METHODS:

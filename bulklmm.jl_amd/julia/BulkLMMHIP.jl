@@ -164,7 +164,7 @@ struct BlmmReduced   # include/bulklmm_hip.h: blmm_reduced
 end
 function bulkscan_reduced(Y::Array{Float64, 2}, G::Array{Float64, 2}, Covar::Union{Nothing, Array{Float64, 2}}, K::Array{Float64, 2};
                           method::String = "null-grid", h2_grid::Array{Float64, 1} = collect(0.0:0.1:0.9),
-                          threshold::Union{Nothing, Float64} = nothing, cap::Int64 = 65536, addIntercept::Bool = true,
+                          threshold::Union{Nothing, Float64} = nothing, cap::Int64 = 1048576, addIntercept::Bool = true,
                           weights::Union{Missing, Array{Float64, 1}} = missing, prior_variance::Float64 = 1.0,
                           prior_sample_size::Float64 = 0.0, reml::Bool = false, optim_interval::Int64 = 1,
                           decomp_scheme::String = "eigen")
