@@ -288,8 +288,10 @@ int prepare_eigen(blmm_ctx* ctx, const blmm_opts* o, int64_t n, const double* dC
 static int flush_upload(blmm_ctx* ctx) {
   if (!ctx->up_pending) return BLMM_OK;
   ctx->up_pending = false;
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < 2; ++i) {
     if (ctx->up_bytes[i]) BLMM_HIP(hipMemcpyAsync(ctx->up_dst[i], ctx->up_src[i], ctx->up_bytes[i], hipMemcpyHostToDevice, ctx->copy));
+    if (i == 0) BLMM_HIP(hipEventRecord(ctx->ev_inY, ctx->copy));     // the traits first: the main stream's rotation is the critical one
+  }
   BLMM_HIP(hipEventRecord(ctx->ev_in, ctx->copy));
   ctx->in_wait = true;
   return BLMM_OK;
@@ -372,8 +374,9 @@ int prepare(blmm_ctx* ctx, const blmm_opts* o, const double* dY, int64_t n, int6
   // (host entry points) the eigen phase is queued: now the traits and the markers go up, beside it; this stream reads them next
   if (ctx->up_pending) {
     if ((rc = flush_upload(ctx))) return rc;
-    BLMM_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_in, 0));
+    BLMM_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_inY, 0));
   }
+  const bool up_flight = ctx->in_wait;
   // (BLMM_ROTATE_SIDE=0: the marker rotation stays on the main stream behind the traits' -- A/B testing)
   static const bool rot_side = !(dev_env("BLMM_ROTATE_SIDE") && dev_env("BLMM_ROTATE_SIDE")[0] == '0');
   // only where the rotation is the small latency-bound kernel (n <= 160): the GEMM of larger n fills the chip by itself, and behind it
@@ -396,7 +399,10 @@ int prepare(blmm_ctx* ctx, const blmm_opts* o, const double* dY, int64_t n, int6
   }
   if ((rc = rotate_traits(ctx, P, dY, m))) return rc;
   if (skip_markers) { P.p = p; P.ldx = round_up(p > 0 ? p : 1, 128); P.Xt = nullptr; }   // the caller rotates them itself (fp32 permutation path)
-  else if (!P.xt_side && (rc = rotate_markers(ctx, P, dG, p))) return rc;
+  else if (!P.xt_side) {
+    if (up_flight) BLMM_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_in, 0));     // (the markers on this stream: they went up second)
+    if ((rc = rotate_markers(ctx, P, dG, p))) return rc;
+  }
   ctx->in_wait = false;                     // every reader of the uploaded inputs is queued behind ev_in
   tm.mark();
   return BLMM_OK;
@@ -707,7 +713,8 @@ int blmm_create(int device_id, void* hip_stream, blmm_ctx** out) {
       hipEventCreateWithFlags(&ctx->ev_m, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&ctx->ev_wb, hipEventDisableTiming) != hipSuccess ||
       hipStreamCreateWithFlags(&ctx->copy, hipStreamNonBlocking) != hipSuccess ||
-      hipEventCreateWithFlags(&ctx->ev_in, hipEventDisableTiming) != hipSuccess) {
+      hipEventCreateWithFlags(&ctx->ev_in, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&ctx->ev_inY, hipEventDisableTiming) != hipSuccess) {
     blmm_destroy(ctx);
     return BLMM_ERR_HIP;
   }
@@ -753,6 +760,7 @@ void blmm_destroy(blmm_ctx* ctx) {
   if (ctx->ev_m) (void)hipEventDestroy(ctx->ev_m);
   if (ctx->ev_wb) (void)hipEventDestroy(ctx->ev_wb);
   if (ctx->ev_in) (void)hipEventDestroy(ctx->ev_in);
+  if (ctx->ev_inY) (void)hipEventDestroy(ctx->ev_inY);
   if (ctx->copy) { (void)hipStreamSynchronize(ctx->copy); (void)hipStreamDestroy(ctx->copy); }
   if (ctx->side2) { (void)hipStreamSynchronize(ctx->side2); (void)hipStreamDestroy(ctx->side2); }
   if (ctx->own_stream) hipStreamDestroy(ctx->stream);

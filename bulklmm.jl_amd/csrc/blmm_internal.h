@@ -110,7 +110,7 @@ struct blmm_ctx {
   // queued, and only then Y and G are copied -- on their own stream, beside the eigen kernels (0.23 ms at n = 79 that the caller
   // used to wait for behind 27 MB of uploads).  up_pending: upload_bulk_inputs left them for prepare(); in_wait: the copies are
   // in flight, whoever reads inY / inG waits for ev_in first.
-  hipStream_t copy = nullptr; hipEvent_t ev_in = nullptr;
+  hipStream_t copy = nullptr; hipEvent_t ev_in = nullptr, ev_inY = nullptr;   // ev_inY: the traits are there (the main stream's need), ev_in: the markers too
   bool up_pending = false, in_wait = false;
   const void* up_src[2] = {nullptr, nullptr}; void* up_dst[2] = {nullptr, nullptr}; size_t up_bytes[2] = {0, 0};
   int num_cus = 0;                 // multiProcessorCount of the device (bounds every co-resident grid)
