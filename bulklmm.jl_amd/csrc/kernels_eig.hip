@@ -221,10 +221,16 @@ __global__ void __launch_bounds__(512) k_sytrd(const double* __restrict__ A, int
   for (int k = 0; k + 2 < n; ++k) {
     const int par = k & 1;
     // (a) the step's scalars from the partial sums (every thread, redundantly: no barrier)
-    double s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    // (the 3 x 16 per-wave partials: ONE read per wave -- lane l takes slot l, the three groups are the three DPP rows of 16 -- and a
+    //  row reduction; the plain `for (q < nwave) s += rd[q]` compiled to read -> wait -> add chains, and as 48 reads per thread it
+    //  was LDS-issue bound: 512 threads x 48 broadcast reads)
+    double s1, s2, s3;
     {
       const double* rd = rdA + par * 48;
-      for (int q = 0; q < nwave; ++q) { s1 += rd[q]; s2 += rd[16 + q]; s3 += rd[32 + q]; }
+      double v = rd[(lane < 48) ? lane : 0];
+      v = (lane < 48 && (lane & 15) < nwave) ? v : 0.0;
+      v += dpp_mov<0xB1>(v); v += dpp_mov<0x4E>(v); v += dpp_mov<0x141>(v); v += dpp_mov<0x140>(v);     // every lane: its row's total
+      s1 = lane_bcast(v, 0); s2 = lane_bcast(v, 16); s3 = lane_bcast(v, 32);
     }
     const double alpha = sx[k + 1];
     double beta, tk, sc;
@@ -314,8 +320,12 @@ __global__ void __launch_bounds__(512) k_sytrd(const double* __restrict__ A, int
     if (__syncthreads_or(bad ? 1 : 0)) { aborted = true; break; }        // barrier X
     PSTAMP(3);
     // (e) p'v, w = p - (tau/2)(p'v) v; (f) this step's pair, the next column in place, and the next step's three sums
-    s4 = 0.0;
-    for (int q = 0; q < nwave; ++q) s4 += rdB[q];
+    {
+      double v = rdB[lane & 15];
+      v = ((lane & 15) < nwave) ? v : 0.0;
+      v += dpp_mov<0xB1>(v); v += dpp_mov<0x4E>(v); v += dpp_mov<0x141>(v); v += dpp_mov<0x140>(v);
+      s4 = lane_bcast(v, 0);
+    }
     const double pk1 = sp[k + 1];
     const double cw = 0.5 * tk * fma(sc, s4, pk1);
     const double wk1 = pk1 - cw;                                         // v[k+1] = 1
