@@ -342,7 +342,7 @@ __global__ void __launch_bounds__(512) k_sytrd(const double* __restrict__ A, int
         if (j > k + 2) { n1 = fma(xn, xn, n1); n2 = fma(v, xn, n2); n3 = fma(wj, xn, n3); }
       }
     }
-    n1 = wsum(n1); n2 = wsum(n2); n3 = wsum(n3);
+    { double n4 = 0.0; wsum4(n1, n2, n3, n4); }                          // (three wave sums in one pass)
     if (lane == 0) { double* rn = rdA + (par ^ 1) * 48; rn[wave] = n1; rn[16 + wave] = n2; rn[32 + wave] = n3; }
     if (vown && t == 0) { d[k] = akk; e[k] = beta; tau[k] = tk; }
     akk = sa[k + 1] - 2.0 * wk1;                                         // sa[k+1] is not written above
