@@ -251,25 +251,33 @@ __global__ void __launch_bounds__(512) k_sytrd(const double* __restrict__ A, int
     PSTAMP(0);
     // (b) owned rows i > k:  p_i = tau ((A v)_i - vp_i (wp'v) - wp_i (vp'v)),  a_i = A[i][k+1] with the pending update applied
     const int li0 = (k + 1 > g) ? (k + 1 - g + G - 1) / G : 0;    // first local row with global index > k
-    for (int li = li0 + wave; li < nloc; li += nwave) {
-      const int i = g + li * G;
-      const double* row = Al + (size_t)li * n;
-      double acc = 0.0;
-      for (int j = k + 2 + lane; j < n; j += 64) acc = fma(row[j], sx[j], acc);
-      acc = wsum(acc);
-      if (lane == 0) {
-        const double vpi = svp[i], wpi = swp[i], rk1 = row[k + 1];
-        const double pi = tk * (fma(sc, acc, rk1) - vpi * wpv - wpi * vpv);
-        const double ai = rk1 - vpi * wpk1 - wpi * vpk1;
-        if (G > 1) {
-          const unsigned long long tg = (unsigned long long)(unsigned int)(k + 1) << 32;
-          const unsigned long long pb = (unsigned long long)__double_as_longlong(pi), ab = (unsigned long long)__double_as_longlong(ai);
-          unsigned long long* gq = ex.gr + ((size_t)par * n + i) * 4;
-          __hip_atomic_store(gq + 0, tg | (pb & 0xffffffffull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          __hip_atomic_store(gq + 1, tg | (pb >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          __hip_atomic_store(gq + 2, tg | (ab & 0xffffffffull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          __hip_atomic_store(gq + 3, tg | (ab >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        } else { sp[i] = pi; sa[i] = ai; }
+    // Two rows per trip (with ~10 rows and 8 waves the first waves own two; they used to take them one after the other: product,
+    // wave sum, publish, twice): the products share the loads of x, both sums go through one wsum4, and lanes 0 .. 7 publish the
+    // eight granules of the two rows with one store each.
+    for (int li = li0 + wave; li < nloc; li += 2 * nwave) {
+      const int liB = li + nwave;
+      const bool hasB = liB < nloc;
+      const double* rowA = Al + (size_t)li * n;
+      const double* rowB = Al + (size_t)(hasB ? liB : li) * n;
+      double accA = 0.0, accB = 0.0;
+      for (int j = k + 2 + lane; j < n; j += 64) { const double x = sx[j]; accA = fma(rowA[j], x, accA); accB = fma(rowB[j], x, accB); }
+      { double z0 = 0.0, z1 = 0.0; wsum4(accA, accB, z0, z1); }
+      if (lane < 8) {
+        const int r = lane >> 2, q = lane & 3;
+        if (r == 0 || hasB) {
+          const int i = g + (r ? liB : li) * G;
+          const double* row = r ? rowB : rowA;
+          const double acc = r ? accB : accA;
+          const double vpi = svp[i], wpi = swp[i], rk1 = row[k + 1];
+          const double pi = tk * (fma(sc, acc, rk1) - vpi * wpv - wpi * vpv);
+          const double ai = rk1 - vpi * wpk1 - wpi * vpk1;
+          if (G > 1) {
+            const unsigned long long tg = (unsigned long long)(unsigned int)(k + 1) << 32;
+            const unsigned long long pay = (unsigned long long)__double_as_longlong((q < 2) ? pi : ai);
+            unsigned long long* gq = ex.gr + ((size_t)par * n + i) * 4;
+            __hip_atomic_store(gq + q, tg | ((q & 1) ? (pay >> 32) : (pay & 0xffffffffull)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          } else if (q == 0) { sp[i] = pi; sa[i] = ai; }
+        }
       }
     }
     PSTAMP(1);
