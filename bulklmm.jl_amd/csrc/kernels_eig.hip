@@ -301,10 +301,15 @@ __global__ void __launch_bounds__(512) k_sytrd(const double* __restrict__ A, int
         unsigned long long q0, q1, q2, q3;
         int spin = 0;
         for (;;) {
-          q0 = __hip_atomic_load(gq + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          q1 = __hip_atomic_load(gq + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          q2 = __hip_atomic_load(gq + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          q3 = __hip_atomic_load(gq + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          // the four granules of a row (32 aligned bytes) with two 16-byte sc1 loads: every 8-byte granule validates itself by
+          // its tag, so a set read half old, half new only sends the loop round again
+          {
+            typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
+            u64x2 lo2, hi2;
+            asm volatile("global_load_dwordx4 %0, %2, off sc1\n\tglobal_load_dwordx4 %1, %2, off offset:16 sc1\n\ts_waitcnt vmcnt(0)"
+                         : "=&v"(lo2), "=&v"(hi2) : "v"(gq) : "memory");
+            q0 = lo2.x; q1 = lo2.y; q2 = hi2.x; q3 = hi2.y;
+          }
           if ((unsigned int)(q0 >> 32) == want && (unsigned int)(q1 >> 32) == want && (unsigned int)(q2 >> 32) == want &&
               (unsigned int)(q3 >> 32) == want) break;
           __builtin_amdgcn_s_sleep(1);
