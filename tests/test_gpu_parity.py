@@ -719,6 +719,36 @@ def test_bench_starts_its_own_ranks_and_shards_ragged(tmp_path):
     assert j["value"] > 0 and j["ms_per_step"] > 0 and j["roofline"]["frac"] > 0
 
 
+def test_bench_line_contract_on_one_gpu():
+    """The ONE JSON line of `python bench.py` (N = 1) on a small workload: the driver's keys, `roofline` and `cpu_baseline`, the
+    end-to-end section with the reduced outputs, and the round-4 fields -- the loop without the library's phase timings and the
+    list of sections that ran before the contract's timed loop (the timed loop is the LAST GPU section)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "BLMM_BENCH_BACKEND")}
+    run = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--n", "79", "--p", "640", "--m", "1300", "--steps", "3", "--warmup", "1",
+                          "--cpu-budget", "0.5"], capture_output=True, text=True, timeout=900, env=env)
+    assert run.returncode == 0, run.stdout[-2000:] + run.stderr[-3000:]
+    lines = [l for l in run.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    j = json.loads(lines[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+                "data", "config", "roofline", "cpu_baseline", "host_api"):
+        assert key in j, key
+    assert j["n_gpus"] == 1 and j["steps"] == 3 and j["warmup"] == 1 and j["dtype"] == "f64" and j["higher_is_better"] is True
+    assert abs(j["value"] - 640 * 1300 / (j["ms_per_step"] * 1e-3)) <= 1e-6 * j["value"]
+    r = j["roofline"]
+    assert r["bound"] in ("hbm", "mfma") and r["peak"] > 0 and abs(r["frac"] - r["achieved"] / r["peak"]) <= 1e-9 and r["kernel_ms"] > 0
+    c = j["cpu_baseline"]
+    assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and "sample" in c
+    h = j["host_api"]
+    assert h["end_to_end_ms_reduced_out"] > 0 and h["end_to_end_ms_keep_on_device"] > 0 and h["reduced_equals_keep_on_device"] is True
+    assert j["ms_per_step_no_phase_marks"] > 0
+    assert j["sections_before_timed_loop"] == ["cpu_baseline (host only)", "host_api", "all_rank_form loop", "no_phase_marks loop"]
+
+
 @pytest.mark.parametrize("method", ["null-exact", "perms"])
 def test_bench_sharded_rotation_path_with_two_ranks(method):
     """bench.py --gpus 2 at n >= 256: the marker rotation sharded over the ranks (prepare / rotate block / gather / prerotated
